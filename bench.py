@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- pdfposteriors() frames/s on synthetic lattices (BASELINE.json metric).
+
+One "step" = one pdfposteriors() call of the HIP engine over one batch of
+utterances whose log-likelihoods are already resident in HBM.  Default workload
+= BASELINE.json configs[2]: the LF-MMI denominator FSM (S = 2000, ~34 k arcs,
+P = 84), T = 1500 frames, B = 256 utterances per GPU (weak scaling: configs[3]
+is B = 2048 over 8 GPUs = 256 per GPU).  At N > 1 GPUs the utterances are
+sharded (they are independent: block-diagonal batch) and each step ends with
+the one real exchange of the path, the total-log-likelihood all-reduce (RCCL).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see the task contract), including
+  "roofline":     algorithmic bytes per launch / measured kernel time vs 8 TB/s HBM
+  "cpu_baseline": the C oracle (a port of the reference's CPU operation order;
+                  the Julia reference cannot run here) timed on the host cores
+                  on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+
+
+def make_workload(wl, name):
+    if name == "lfmmi_den":
+        return wl.lfmmi_denominator(2000, 84, seed=0), 1500, 256
+    if name == "ergodic64":
+        return wl.dense_ergodic(64, seed=0), 500, 32
+    if name == "wsj_den":
+        return wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "den_fsm_wsj.npz")), 700, 128
+    raise SystemExit(f"unknown workload {name}")
+
+
+def algorithmic_bytes(g, B, N, lens_sum):
+    """alpha written once and read once, emissions read twice,
+    posteriors written once, graph read once per pass (shared)."""
+    S1, P1, A = g.S + 1, g.P + 1, g.n_arcs
+    per_frame = 8 * S1 + 8 * P1
+    return B * (N + 1) * per_frame + 4 * lens_sum * g.P + 4 * B + 2 * (8 * A + 4 * (g.S + 2))
+
+
+def cpu_baseline(g, N, threads, budget_utts):
+    """The oracle (kind "port"): C restatement of the reference's CPU path
+    (CSC scatter SpMV, one logaddexp per arc, alpha and beta materialised,
+    float32), OpenMP over utterances."""
+    o, oc = ge.load_oracle()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import graphs
+
+    of = graphs.to_oracle(o, g, "log", np.float32)
+    rng = np.random.default_rng(123)
+    V = rng.standard_normal((budget_utts, N, g.P)).astype(np.float32)
+    oc.batch_shared(of, g.state2pdf, g.P, V[:1, : min(N, 20)], None, dtype=np.float32, nthreads=1)  # warm
+    t0 = time.perf_counter()
+    oc.batch_shared(of, g.state2pdf, g.P, V, None, dtype=np.float32, nthreads=threads)
+    dt = time.perf_counter() - t0
+    return budget_utts * N / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="lfmmi_den")
+    ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default: the config's)")
+    ap.add_argument("--frames", type=int, default=0)
+    ap.add_argument("--varlen", action="store_true", help="lengths U[N/2, N] instead of all N")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    mm = ge.load_package()
+    wl = importlib.import_module(mm.__name__ + ".workloads")
+    g, N, B = make_workload(wl, args.workload)
+    N = args.frames or N
+    B = args.batch or B
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(*([cf] * B))
+    gen = torch.Generator(device="cuda").manual_seed(1000 + rank)
+    V = torch.randn(B, N, g.P, device="cuda", generator=gen)
+    if args.varlen:
+        lens = torch.randint(N // 2, N + 1, (B,), device="cuda", generator=gen, dtype=torch.int32)
+    else:
+        lens = torch.full((B,), N, device="cuda", dtype=torch.int32)
+    frames_local = int(lens.sum().item())
+    gamma = torch.empty(B, N, g.P, device="cuda")
+
+    def step():
+        _, ttl = bf.pdfposteriors(V, lens, out=gamma)
+        return mm.dist.allreduce_logz(ttl) if world > 1 else ttl
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        _, ttl = bf.pdfposteriors(V, lens, out=gamma)
+        ev[i][1].record()
+        if world > 1:
+            mm.dist.allreduce_logz(ttl)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    frames_total = frames_local
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        f = torch.tensor([frames_local], device="cuda", dtype=torch.float64)
+        dist.all_reduce(f, op=dist.ReduceOp.SUM)
+        frames_total = int(f.item())
+    assert torch.isfinite(ttl).all(), "non-finite log-likelihoods"
+
+    if rank == 0:
+        abytes = algorithmic_bytes(g, B, N, frames_local)
+        achieved = abytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "pdfposteriors_frames_per_sec",
+            "value": frames_total * args.steps / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{g.name}: S={g.S} states, {g.n_arcs} arcs, P={g.P} pdfs, T={N} frames, "
+                            f"B={B} utterances/GPU, log semiring, shared graph"
+                            + (", lengths U[T/2,T]" if args.varlen else ""),
+                "global_batch": B * world,
+                "seq_len": N,
+                "parallelism": f"utterance-sharded x{world}",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "mm_log_kernel<MODE_FB>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": abytes,
+                "kernel_ms": kernel_ms,
+            },
+        }
+        if not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            nb = max(cores, 8)
+            v, dt = cpu_baseline(g, N, cores, nb)
+            out["cpu_baseline"] = {
+                "value": v,
+                "unit": "frames/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": f"{nb} utterances x {N} frames of the same workload, float32, OpenMP over utterances, {dt:.1f} s",
+            }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

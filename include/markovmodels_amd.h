@@ -1,0 +1,149 @@
+/* markovmodels_amd.h -- C ABI of the MI355X-native forward-backward / Viterbi
+ * engine that sits behind MarkovModels.jl's inference API.
+ *
+ * Every entry point names the reference interface (file:line under the
+ * MarkovModels.jl tree) it replaces.  The reference seam is Julia multiple
+ * dispatch on CuArray storage (src/fsm.jl:42-48, src/inference.jl:14-26,
+ * src/linalg.jl:163,240,335); this library moves the seam one level up: one
+ * call per `pdfposteriors` / `alpha-recursion` / `beta-recursion` instead of
+ * four kernel launches per frame.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all functions return an int status
+ *     (MM_OK = 0, negative = error) and record a message for mm_last_error().
+ *   - "device pointer" = memory of the HIP device that was current when the
+ *     handle was created; "host pointer" = ordinary memory.  Run calls are
+ *     asynchronous on the given hipStream_t (passed as void*, NULL = default
+ *     stream) and never synchronise the device.
+ *   - the caller owns every in/out buffer; the library owns its handles and
+ *     an internal workspace (the alpha store) that grows lazily and is freed
+ *     with the batch.
+ *   - weights/likelihoods are natural-log values of the Log/Tropical
+ *     semirings (zero(K) = -inf, one(K) = 0), bit-compatible with the
+ *     reference's Array{K} storage.  The engine computes in float32.
+ *   - the FSM is the reference's *extended* system (src/fsm.jl:19-28): S1 =
+ *     S + 1 states, the last one being the phony final state (self loop of
+ *     weight one); P1 = P + 1 pdfs, the last one being the phony pdf that
+ *     only the final state emits (examples/prepare-lfmmi-graphs.jl:15-23).
+ *   - state / pdf indices RETURNED by the library are 0-based.
+ */
+#ifndef MARKOVMODELS_AMD_H
+#define MARKOVMODELS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_ABI_VERSION 1
+
+enum mm_status {
+    MM_OK = 0,
+    MM_ERR_INVALID = -1,     /* bad handle / argument */
+    MM_ERR_DIM = -2,         /* the reference's DimensionMismatch (src/linalg.jl:166-167,242-244) */
+    MM_ERR_HIP = -3,         /* a HIP runtime call failed */
+    MM_ERR_UNSUPPORTED = -4, /* valid input the engine cannot run (e.g. graph too large for LDS) */
+    MM_ERR_NOMEM = -5
+};
+
+enum mm_semiring { MM_LOG = 0, MM_TROPICAL = 1 }; /* Semirings.jl LogSemiring / TropicalSemiring */
+enum mm_layout { MM_CSC = 0, MM_CSR = 1 };        /* how T_hat is handed over */
+
+typedef struct mm_fsm_s *mm_fsm_t;     /* one compiled FSM   ~ CompiledFSM   (src/inference.jl:3-12)  */
+typedef struct mm_batch_s *mm_batch_t; /* a batch of them    ~ batch()/rawunion (src/inference.jl:28-36, src/fsmops.jl:28-36) */
+
+int mm_abi_version(void);
+/* Message of the last error on the calling thread ("" if none). */
+const char *mm_last_error(void);
+
+/* compile(fsm, C_hat) (src/inference.jl:11-12) + adapt to the device
+ * (src/inference.jl:14-26): takes the reference FSM fields as they are stored
+ * on the host and builds the device-resident packed forms of T_hat' (forward)
+ * and T_hat (backward).
+ *   S1, nnz      size of T_hat (S1 x S1) and its stored entries
+ *   layout       MM_CSC: ptr = colptr (S1+1), idx = rowval  -- SparseMatrixCSC as in src/fsm.jl:14
+ *                MM_CSR: ptr = rowptr (S1+1), idx = colval  -- CuSparseMatrixCSR as in src/fsm.jl:45
+ *   index_bytes  4 (Cint, src/linalg.jl:80) or 8 (Int64);  index_base 0 or 1 (Julia)
+ *   val_bytes    4 (float) or 8 (double) for val / init_val
+ *   init_idx/val the n_init stored entries of alpha_hat (src/fsm.jl:10)
+ *   state2pdf    S1 entries (index_base based), the column of the single
+ *                stored entry of each row of C_hat; the last must be P1-1
+ * All pointers are host pointers and are not retained. */
+int mm_fsm_create(int semiring, int64_t S1, int64_t nnz, int layout, int index_bytes, int index_base,
+                  int val_bytes, const void *ptr, const void *idx, const void *val, int64_t n_init,
+                  const void *init_idx, const void *init_val, const int32_t *state2pdf, int32_t P1,
+                  mm_fsm_t *out);
+int mm_fsm_destroy(mm_fsm_t fsm);
+/* nstates + sizes (src/fsm.jl:84); any out pointer may be NULL.
+ * packed_slots[d] = arc slots of the packed form, d = 0 forward, 1 backward. */
+int mm_fsm_info(mm_fsm_t fsm, int64_t *S1, int64_t *nnz, int32_t *P1, int64_t packed_slots[2],
+                int64_t packed_items[2]);
+
+/* batch(cfsm...) (src/inference.jl:28-36) / rawunion(fsms...) (src/fsmops.jl:28-36):
+ * B independent FSMs in one block-diagonal system.  Handles may repeat; when
+ * all B are the same handle the graph is stored once (denominator case,
+ * examples/test_cuda.jl:112).  The FSM handles must outlive the batch. */
+int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out);
+int mm_batch_destroy(mm_batch_t batch);
+/* Sum over the batch of S1 (rows of the block-diagonal system). */
+int64_t mm_batch_total_states(mm_batch_t batch);
+/* Bytes of internal workspace a run with N frames needs (informational). */
+size_t mm_batch_workspace_bytes(mm_batch_t batch, int64_t N);
+
+/* pdfposteriors(fsm, V_hats, C_hats) (src/inference.jl:145-161), with
+ * expand() (src/inference.jl:54-60) done inside:
+ *   V      device, log-likelihoods of the P = P1-1 real pdfs; element (b, n, p)
+ *          at V[b*v_stride_b + n*v_stride_n + p], n = 0..N-1
+ *   lens   device int32[B] sequence lengths (<= N), or NULL for all N
+ *   gamma  device, out: posterior PROBABILITIES exp(log gamma) like
+ *          src/inference.jl:160; element (b, n, p) at
+ *          gamma[b*g_stride_b + n*g_stride_n + p*g_stride_p]; frames n >= len_b
+ *          are written as exact zeros.  (The reference returns a B x P x N
+ *          column-major array: g_stride_b = 1, g_stride_p = B, g_stride_n = B*P.)
+ *   ttl    device float[B], out: min over frames of the per-frame log
+ *          normaliser (src/inference.jl:159) = log Z_b
+ * An utterance with no accepting path (Z = 0) yields gamma = 0, ttl = -inf
+ * (the reference yields NaN: src/inference.jl:158; guarded only in the dead
+ * code at :198-200). */
+int mm_pdfposteriors_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t v_stride_n,
+                         const int32_t *lens, int64_t N, float *gamma, int64_t g_stride_b, int64_t g_stride_n,
+                         int64_t g_stride_p, float *ttl, void *stream);
+
+/* alpha-recursion(alpha_hat, T_hat', C_hat*V_hat) (src/inference.jl:62-74) as
+ * called from pdfposteriors (:150-152): out is the reference's state_A, a
+ * (sum S1) x (N+1) column-major matrix: element (b, n, s) at
+ * out[n*out_stride_n + state_offset_b + s] with state_offset_b the running sum
+ * of S1 over the batch.  Values are natural-log (un-normalised). */
+int mm_alpharecursion_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t v_stride_n,
+                          const int32_t *lens, int64_t N, float *out, int64_t out_stride_n, void *stream);
+/* beta-recursion(T_hat, C_hat*V_hat) (src/inference.jl:99-110); same layout (state_B). */
+int mm_betarecursion_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t v_stride_n,
+                         const int32_t *lens, int64_t N, float *out, int64_t out_stride_n, void *stream);
+
+/* bestpath (documented docs/src/inference.md:5-6, absent from src/ at this
+ * commit: src/MarkovModels.jl:56-57; historical use examples/demo.ipynb cell 23).
+ * Tropical alpha-recursion (src/inference.jl:62-74 with K = TropicalSemiring)
+ * plus back-pointers and an on-device back-trace.  The batch must have been
+ * built from MM_TROPICAL FSMs.
+ *   path   device int32, element (b, n) at path[b*path_stride_b + n]: 0-based
+ *          state at frame n < len_b, -1 for n >= len_b or when no path exists
+ *   score  device float[B]: weight of the best path (-inf if none)
+ *   bp     optional device int32 (NULL to use internal storage): back-pointers,
+ *          element (b, n, s) at bp[n*bp_stride_n + state_offset_b + s], n = 0..N;
+ *          bp = lowest source state among the maximisers, -1 if none. */
+int mm_viterbi_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t v_stride_n, const int32_t *lens,
+                   int64_t N, int32_t *path, int64_t path_stride_b, float *score, int32_t *bp,
+                   int64_t bp_stride_n, void *stream);
+
+/* Test aid (host only, no GPU): evaluate one semiring product out = M (x) in
+ * THROUGH THE PACKED FORM the kernels consume, direction 0: M = T_hat'
+ * (forward), 1: M = T_hat (backward).  in/out: host float[S1], natural log.
+ * argmax (may be NULL): for MM_TROPICAL the back-pointer per row. */
+int mm_debug_packed_product(mm_fsm_t fsm, int direction, const float *in, float *out, int32_t *argmax);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARKOVMODELS_AMD_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of libmarkovmodels_amd.so (C ABI: include/markovmodels_amd.h).
+
+There is NO fallback: if the HIP library has not been built the import fails
+loudly (run ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C markovmodels.jl_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmarkovmodels_amd.so")
+
+MM_OK = 0
+MM_LOG, MM_TROPICAL = 0, 1
+MM_CSC, MM_CSR = 0, 1
+SEMIRING_ID = {"log": MM_LOG, "tropical": MM_TROPICAL}
+
+#: every symbol include/markovmodels_amd.h declares
+SYMBOLS = [
+    "mm_abi_version",
+    "mm_last_error",
+    "mm_fsm_create",
+    "mm_fsm_destroy",
+    "mm_fsm_info",
+    "mm_batch_create",
+    "mm_batch_destroy",
+    "mm_batch_total_states",
+    "mm_batch_workspace_bytes",
+    "mm_pdfposteriors_f32",
+    "mm_alpharecursion_f32",
+    "mm_betarecursion_f32",
+    "mm_viterbi_f32",
+    "mm_debug_packed_product",
+]
+
+
+class MarkovModelsAMDError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"markovmodels_amd error {code}: {msg}")
+        self.code = code
+
+
+class DimensionMismatch(MarkovModelsAMDError):
+    """The reference's DimensionMismatch (src/linalg.jl:166-167)."""
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP engine is not built and there is no CPU fallback. "
+            "Build it with `make -C markovmodels.jl_amd/csrc` (hipcc --offload-arch=gfx950)."
+        )
+    # One HIP runtime per process: when torch is present its bundled libamdhip64 must be
+    # the instance the engine binds to (torch tensors and streams are handed to the engine).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    i64, i32, vp, fp = C.c_int64, C.c_int32, C.c_void_p, C.c_void_p
+    lib.mm_abi_version.restype = C.c_int
+    lib.mm_last_error.restype = C.c_char_p
+    lib.mm_fsm_create.restype = C.c_int
+    lib.mm_fsm_create.argtypes = [C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, i64, vp, vp, vp,
+                                  i32, C.POINTER(vp)]
+    lib.mm_fsm_destroy.restype = C.c_int
+    lib.mm_fsm_destroy.argtypes = [vp]
+    lib.mm_fsm_info.restype = C.c_int
+    lib.mm_fsm_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.POINTER(i64), C.POINTER(i64)]
+    lib.mm_batch_create.restype = C.c_int
+    lib.mm_batch_create.argtypes = [C.POINTER(vp), i64, C.POINTER(vp)]
+    lib.mm_batch_destroy.restype = C.c_int
+    lib.mm_batch_destroy.argtypes = [vp]
+    lib.mm_batch_total_states.restype = i64
+    lib.mm_batch_total_states.argtypes = [vp]
+    lib.mm_batch_workspace_bytes.restype = C.c_size_t
+    lib.mm_batch_workspace_bytes.argtypes = [vp, i64]
+    lib.mm_pdfposteriors_f32.restype = C.c_int
+    lib.mm_pdfposteriors_f32.argtypes = [vp, fp, i64, i64, vp, i64, fp, i64, i64, i64, fp, vp]
+    for name in ("mm_alpharecursion_f32", "mm_betarecursion_f32"):
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [vp, fp, i64, i64, vp, i64, fp, i64, vp]
+    lib.mm_viterbi_f32.restype = C.c_int
+    lib.mm_viterbi_f32.argtypes = [vp, fp, i64, i64, vp, i64, vp, i64, fp, vp, i64, vp]
+    lib.mm_debug_packed_product.restype = C.c_int
+    lib.mm_debug_packed_product.argtypes = [vp, C.c_int, vp, vp, vp]
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int):
+    if rc != MM_OK:
+        msg = lib.mm_last_error().decode("utf-8", "replace")
+        if rc == -2:
+            raise DimensionMismatch(rc, msg)
+        raise MarkovModelsAMDError(rc, msg)

@@ -1,0 +1,535 @@
+// mm_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the forward-backward /
+// Viterbi engine.  Included by mm_engine.hip (single translation unit).
+//
+// What these kernels replace in the reference (paths under MarkovModels.jl):
+//   per frame and direction  _cukernel_mul_smdv!   src/linalg.jl:213-233  (warp-per-row SpMV)
+//                            elementwise (*)       src/inference.jl:71,106
+//   once per call            _cukernel_mul_smdm!   src/linalg.jl:268-280  (C*V gather, C'*AB reduce)
+//                            _cukernel_bc_svdv!    src/linalg.jl:320-328  (alpha_hat (*) lhs[:,1])
+//                            A .* B, permutedims, sum, ./, minimum, exp   src/inference.jl:154-160
+// i.e. 4 launches per frame + ~10 per call become ONE persistent launch: one
+// workgroup per utterance walks all frames of the alpha-recursion
+// (src/inference.jl:62-74) and then the beta-recursion (:99-110) fused with the
+// posterior combine (:154-160).  beta, alpha.*beta and the state-level
+// emissions C*V are never materialised in HBM; only the (normalised) alpha
+// store is written once and read once.
+//
+// Numerics (log semiring): values live in the log2 domain, normalised per
+// frame by a lagged maximum (alpha~_n = alpha_n - C_n, C_n kept in double), so
+// float32 magnitudes stay O(1) instead of growing to O(N) as in the reference.
+// (+) over a CSR row is a two-pass log-sum-exp: lane-local max -> lane-group
+// max (cross-lane) -> sum of exp2 -> lane-group sum -> log2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mm_pack.h"
+
+namespace mm {
+
+#define MM_NINF (-__builtin_inff())
+#define MM_LOG2E 1.4426950408889634f
+#define MM_LN2 0.6931471805599453f
+#define MM_MAX_WAVES 16
+
+enum { MODE_FB = 0, MODE_ALPHA = 1, MODE_BETA = 2 };
+
+struct GraphDev {
+    const ItemMeta *items;
+    const RowInfo *rowinfo;
+    const Slot *slots;
+    int n_items;
+    int pad;
+};
+
+struct UttDesc {
+    GraphDev g[2];  // 0: T_hat' packed (forward), 1: T_hat packed (backward)
+    const float *init;  // dense alpha_hat [S1] (log2 domain for MM_LOG, natural for MM_TROPICAL)
+    const int *s2p;     // state -> pdf [S1]
+    int S1, S1p, P1, pad;
+    long long state_off;   // offset of this FSM in the block-diagonal state space
+    long long s1p_prefix;  // sum of S1p of the utterances before this one
+};
+
+struct RunParams {
+    const UttDesc *utts;
+    const float *V;
+    long long vsb, vsn;
+    const int *lens;
+    int N, B;
+    float *ws_alpha;  // [sum_b S1p_b][N+1] normalised alpha store (per utterance: [N+1][S1p])
+    double *ws_c;     // [B][N+2] per-frame log2 offsets C_n
+    float *gamma;
+    long long gsb, gsn, gsp;
+    float *ttl;
+    float *out;  // alpha / beta export
+    long long out_stride_n;
+    int *bp;  // viterbi
+    long long bp_stride_n;
+    int *path;
+    long long path_stride_b;
+    float *score;
+};
+
+// LDS carve (in floats) shared by host (size) and device (offsets).
+struct LdsPlan {
+    int buf, stage, em, bins, part, total;
+};
+__host__ __device__ inline LdsPlan lds_plan(int S1p, int P1p, bool with_stage) {
+    LdsPlan l;
+    l.buf = 0;
+    l.stage = l.buf + 2 * S1p;
+    l.em = l.stage + (with_stage ? 2 * S1p : 0);
+    l.bins = l.em + 2 * P1p;
+    l.part = l.bins + 2 * P1p;
+    l.total = l.part + 2 * MM_MAX_WAVES;
+    return l;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+// cross-lane reductions inside aligned lane groups of 1 << log2g lanes
+__device__ __forceinline__ float grp_max(float v, int log2g) {
+    for (int i = 0; i < log2g; ++i) v = fmaxf(v, __shfl_xor(v, 1 << i));
+    return v;
+}
+__device__ __forceinline__ float grp_sum(float v, int log2g) {
+    for (int i = 0; i < log2g; ++i) v += __shfl_xor(v, 1 << i);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) { return grp_max(v, 6); }
+__device__ __forceinline__ float wave_sum(float v) { return grp_sum(v, 6); }
+
+__device__ __forceinline__ Slot load_slot(const Slot *p) {
+    uint2 r = *reinterpret_cast<const uint2 *>(p);
+    Slot s;
+    s.col = r.x;
+    s.w = __uint_as_float(r.y);
+    return s;
+}
+
+// (+)_k w_k (*) a[col_k] over one CSR row in the log semiring (log2 domain),
+// the row being spread over a lane group: the replacement of
+// _cukernel_mul_smdv! + warp_reduce (src/linalg.jl:204-233).
+template <int R>
+__device__ __forceinline__ float lse_small(const Slot *sp, int log2g, const float *a) {
+    float x[R];
+    Slot s[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) s[k] = load_slot(sp + k * 64);
+#pragma unroll
+    for (int k = 0; k < R; ++k) x[k] = s[k].w + a[s[k].col];
+    float m = x[0];
+#pragma unroll
+    for (int k = 1; k < R; ++k) m = fmaxf(m, x[k]);
+    m = grp_max(m, log2g);
+    float m0 = (m > MM_NINF) ? m : 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < R; ++k) sum += fast_exp2(x[k] - m0);
+    sum = grp_sum(sum, log2g);
+    return m0 + fast_log2(sum);
+}
+
+// rows longer than 4 arcs per lane: online (running max, rescaled sum), chunks of 4
+__device__ __forceinline__ float lse_long(const Slot *sp, int R, int log2g, const float *a) {
+    float m = MM_NINF, sum = 0.f;
+    for (int k0 = 0; k0 < R; k0 += 4) {
+        float x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            Slot s = load_slot(sp + (k0 + k) * 64);
+            x[k] = s.w + a[s.col];
+        }
+        float cm = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+        float mn = fmaxf(m, cm);
+        float mn0 = (mn > MM_NINF) ? mn : 0.f;
+        sum = sum * fast_exp2(m - mn0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sum += fast_exp2(x[k] - mn0);
+        m = mn;
+    }
+    float M = grp_max(m, log2g);
+    float M0 = (M > MM_NINF) ? M : 0.f;
+    sum = grp_sum(sum * fast_exp2(m - M0), log2g);
+    return M0 + fast_log2(sum);
+}
+
+__device__ __forceinline__ float lse_item(const Slot *slots, const ItemMeta &im, int lane, const float *a) {
+    const Slot *sp = slots + (size_t)im.slot_row * 64 + lane;
+    const int R = im.R, lg = im.log2g;
+    switch (R) {
+        case 1: return lse_small<1>(sp, lg, a);
+        case 2: return lse_small<2>(sp, lg, a);
+        case 3: return lse_small<3>(sp, lg, a);
+        case 4: return lse_small<4>(sp, lg, a);
+        default: return lse_long(sp, R, lg, a);
+    }
+}
+
+__device__ __forceinline__ ItemMeta load_item(const ItemMeta *items, int it) {
+    // `it` is wave-uniform: let the scalar unit fetch the 8-byte descriptor
+    uint2 r = *reinterpret_cast<const uint2 *>(items + it);
+    ItemMeta m;
+    m.slot_row = __builtin_amdgcn_readfirstlane(r.x);
+    unsigned q = __builtin_amdgcn_readfirstlane(r.y);
+    m.R = (uint16_t)(q & 0xffff);
+    m.log2g = (uint16_t)(q >> 16);
+    return m;
+}
+
+// expand() (src/inference.jl:54-60) + the log2 scaling, one frame (1-based n) into LDS
+__device__ __forceinline__ void stage_em(float *dst, const float *Vb, long long vsn, int n, int len, int P, int tid,
+                                         int NT, float scale) {
+    for (int q = tid; q <= P; q += NT) {
+        float v;
+        if (q < P)
+            v = (n <= len) ? Vb[(long long)(n - 1) * vsn + q] * scale : MM_NINF;
+        else
+            v = (n <= len) ? MM_NINF : 0.f;
+        dst[q] = v;
+    }
+}
+
+__device__ __forceinline__ float part_max(const float *part, int NW) {
+    float M = MM_NINF;
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, part[w]);
+    return (M > MM_NINF) ? M : 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// Log-semiring kernel.  MODE_FB: pdfposteriors (src/inference.jl:145-161).
+// MODE_ALPHA / MODE_BETA: alpha-recursion / beta-recursion export (:62-74 / :99-110).
+// grid = B workgroups (one utterance each), block = 64 * NW threads.
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(1024) mm_log_kernel(RunParams p) {
+    extern __shared__ float lds[];
+    const int b = blockIdx.x;
+    const UttDesc &u = p.utts[b];
+    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6;
+    const int S1 = u.S1, S1p = u.S1p, P1 = u.P1, P = P1 - 1, P1p = (P1 + 3) & ~3;
+    const int fstate = S1 - 1;
+    int len = p.lens ? p.lens[b] : p.N;
+    len = len < 0 ? 0 : (len > p.N ? p.N : len);
+    // frames are 1-based n = 1 .. N+1 as in the reference; FB stops at len+1,
+    // where only the phony final state is alive (everything after is constant)
+    const int NF = (MODE == MODE_FB) ? len + 1 : p.N + 1;
+    const LdsPlan L = lds_plan(S1p, P1p, MODE == MODE_FB);
+    float *buf = lds + L.buf, *stage = lds + L.stage, *em = lds + L.em, *bins = lds + L.bins, *part = lds + L.part;
+    const float *Vb = p.V + (long long)b * p.vsb;
+    float *wsA = p.ws_alpha ? p.ws_alpha + u.s1p_prefix * (long long)(p.N + 1) : nullptr;
+    double *wsC = p.ws_c ? p.ws_c + (long long)b * (p.N + 2) : nullptr;
+    const GraphDev gf = u.g[0], gb = u.g[1];
+    double logZ2 = 0.0;
+
+    if (MODE != MODE_BETA) {
+        // ---------------- forward: alpha-recursion ----------------
+        stage_em(em + 1 * P1p, Vb, p.vsn, 1, len, P, tid, NT, MM_LOG2E);
+        for (int q = tid; q < 2 * S1p; q += NT) buf[q] = MM_NINF;
+        __syncthreads();
+        {   // frame 1: alpha_hat (*) lhs[:,1]   (src/inference.jl:68)
+            float wm = MM_NINF;
+            float *a1 = buf + 1 * S1p;
+            const float *e1 = em + 1 * P1p;
+            for (int s = tid; s < S1; s += NT) {
+                float v = u.init[s] + e1[u.s2p[s]];
+                a1[s] = v;
+                wm = fmaxf(wm, v);
+            }
+            wm = wave_max(wm);
+            if (lane == 0) part[1 * MM_MAX_WAVES + wave] = wm;
+            if (NF >= 2) stage_em(em + 0 * P1p, Vb, p.vsn, 2, len, P, tid, NT, MM_LOG2E);
+            if (tid == 0 && wsC) wsC[1] = 0.0;
+        }
+        __syncthreads();
+        double C = 0.0, Cprev = 0.0;
+        for (int n = 2; n <= NF; ++n) {
+            const float *ap = buf + ((n - 1) & 1) * S1p;
+            float *an = buf + (n & 1) * S1p;
+            const float *emn = em + (n & 1) * P1p;
+            const float M = part_max(part + ((n - 1) & 1) * MM_MAX_WAVES, NW);
+            Cprev = C;
+            C += (double)M;
+            if (tid == 0 && wsC) wsC[n] = C;
+            if (n + 1 <= NF) stage_em(em + ((n + 1) & 1) * P1p, Vb, p.vsn, n + 1, len, P, tid, NT, MM_LOG2E);
+            // frame n-1 leaves the chip once (coalesced), while frame n is computed
+            if (MODE == MODE_FB) {
+                float4 *dst = reinterpret_cast<float4 *>(wsA + (long long)(n - 1) * S1p);
+                const float4 *src = reinterpret_cast<const float4 *>(ap);
+                for (int q = tid; q < (S1p >> 2); q += NT) dst[q] = src[q];
+            } else {
+                float *dst = p.out + (long long)(n - 2) * p.out_stride_n + u.state_off;
+                const float c = (float)Cprev;
+                for (int s = tid; s < S1; s += NT) dst[s] = (ap[s] + c) * MM_LN2;
+            }
+            float wm = MM_NINF;
+            for (int it = wave; it < gf.n_items; it += NW) {
+                const ItemMeta im = load_item(gf.items, it);
+                const RowInfo ri = gf.rowinfo[(size_t)it * 64 + lane];
+                float v = lse_item(gf.slots, im, lane, ap);
+                if (ri.row >= 0 && (lane & ((1 << im.log2g) - 1)) == 0) {
+                    v = v + emn[ri.pdf] - M;   // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
+                    an[ri.row] = v;
+                    wm = fmaxf(wm, v);
+                }
+            }
+            wm = wave_max(wm);
+            if (lane == 0) part[(n & 1) * MM_MAX_WAVES + wave] = wm;
+            __syncthreads();
+        }
+        const float *alast = buf + (NF & 1) * S1p;
+        logZ2 = (double)alast[fstate] + C;
+        if (MODE == MODE_ALPHA) {
+            float *dst = p.out + (long long)(NF - 1) * p.out_stride_n + u.state_off;
+            const float c = (float)C;
+            for (int s = tid; s < S1; s += NT) dst[s] = (alast[s] + c) * MM_LN2;
+            return;
+        }
+        __syncthreads();
+    }
+
+    if (MODE == MODE_FB) {
+        // ---------------- backward: beta-recursion fused with the combine ----------------
+        const long long gbase = (long long)b * p.gsb;
+        if (!(logZ2 > -1e300)) {  // no accepting path: gamma = 0, ttl = -inf
+            for (long long q = tid; q < (long long)p.N * P; q += NT)
+                p.gamma[gbase + (q / P) * p.gsn + (q % P) * p.gsp] = 0.f;
+            if (tid == 0) p.ttl[b] = MM_NINF;
+            return;
+        }
+        // frame len+1: B (*) lhs = one for the final state only (src/inference.jl:104,106 + expand)
+        for (int q = tid; q < 2 * S1p; q += NT) buf[q] = MM_NINF;
+        for (int q = tid; q < 2 * P1p; q += NT) bins[q] = 0.f;
+        __syncthreads();
+        if (tid == 0) buf[(NF & 1) * S1p + fstate] = 0.f;
+        if (len >= 1) {
+            stage_em(em + (len & 1) * P1p, Vb, p.vsn, len, len, P, tid, NT, MM_LOG2E);
+            const float4 *src = reinterpret_cast<const float4 *>(wsA + (long long)len * S1p);
+            float4 *dst = reinterpret_cast<float4 *>(stage + (len & 1) * S1p);
+            for (int q = tid; q < (S1p >> 2); q += NT) dst[q] = src[q];
+        }
+        __syncthreads();
+        double D = 0.0;
+        float tmin = (float)logZ2;
+        for (int n = len; n >= 1; --n) {
+            const float *yp = buf + ((n + 1) & 1) * S1p;
+            float *yn = buf + (n & 1) * S1p;
+            const float *ast = stage + (n & 1) * S1p;
+            const float *emn = em + (n & 1) * P1p;
+            float *bn = bins + (n & 1) * P1p;
+            const float M = (n == len) ? 0.f : part_max(part + ((n + 1) & 1) * MM_MAX_WAVES, NW);
+            D += (double)M;
+            const double Cn = __hip_atomic_load(&wsC[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float kappa = (float)(logZ2 - Cn - D);
+            // finalise frame n+1 (one rotating wave): C' * AB, per-frame sum, divide, exp (src/inference.jl:155-160)
+            if (n < len && wave == ((n + 1) % NW)) {
+                float *bf = bins + ((n + 1) & 1) * P1p;
+                float s = 0.f;
+                for (int q = lane; q < P1; q += 64) s += bf[q];
+                s = wave_sum(s);
+                const float inv = 1.f / s;
+                float *gp = p.gamma + gbase + (long long)n * p.gsn;  // frame n+1 -> 0-based index n
+                for (int q = lane; q < P1; q += 64) {
+                    if (q < P) gp[q * p.gsp] = bf[q] * inv;
+                    bf[q] = 0.f;
+                }
+                tmin = fminf(tmin, (float)(logZ2 + (double)fast_log2(s)));
+            }
+            if (n - 1 >= 1) {
+                stage_em(em + ((n - 1) & 1) * P1p, Vb, p.vsn, n - 1, len, P, tid, NT, MM_LOG2E);
+                const float4 *src = reinterpret_cast<const float4 *>(wsA + (long long)(n - 1) * S1p);
+                float4 *dst = reinterpret_cast<float4 *>(stage + ((n - 1) & 1) * S1p);
+                for (int q = tid; q < (S1p >> 2); q += NT) dst[q] = src[q];
+            }
+            float wm = MM_NINF;
+            for (int it = wave; it < gb.n_items; it += NW) {
+                const ItemMeta im = load_item(gb.items, it);
+                const RowInfo ri = gb.rowinfo[(size_t)it * 64 + lane];
+                float v = lse_item(gb.slots, im, lane, yp);
+                if (ri.row >= 0 && (lane & ((1 << im.log2g) - 1)) == 0) {
+                    const float beta = v - M;  // T (B[:,n+1] (*) lhs[:,n+1])   (src/inference.jl:106-107)
+                    const float q = fast_exp2(ast[ri.row] + beta - kappa);  // state_A .* state_B / Z
+                    if (q > 0.f) atomicAdd(&bn[ri.pdf], q);
+                    const float y = beta + emn[ri.pdf];
+                    yn[ri.row] = y;
+                    wm = fmaxf(wm, y);
+                }
+            }
+            wm = wave_max(wm);
+            if (lane == 0) part[(n & 1) * MM_MAX_WAVES + wave] = wm;
+            __syncthreads();
+        }
+        // finalise frame 1, zero the frames beyond len, reduce ttl
+        if (len >= 1 && wave == 0) {
+            float *bf = bins + (1 & 1) * P1p;
+            float s = 0.f;
+            for (int q = lane; q < P1; q += 64) s += bf[q];
+            s = wave_sum(s);
+            const float inv = 1.f / s;
+            float *gp = p.gamma + gbase;
+            for (int q = lane; q < P; q += 64) gp[q * p.gsp] = bf[q] * inv;
+            tmin = fminf(tmin, (float)(logZ2 + (double)fast_log2(s)));
+        }
+        for (long long q = tid; q < (long long)(p.N - len) * P; q += NT)
+            p.gamma[gbase + (len + q / P) * p.gsn + (q % P) * p.gsp] = 0.f;
+        __syncthreads();  // part[] is free again
+        if (lane == 0) part[wave] = tmin;
+        __syncthreads();
+        if (tid == 0) {
+            float t = part[0];
+            for (int w = 1; w < NW; ++w) t = fminf(t, part[w]);
+            p.ttl[b] = t * MM_LN2;
+        }
+    }
+
+    if (MODE == MODE_BETA) {
+        // beta-recursion export (src/inference.jl:99-110): all N+1 frames, B[:,N+1] = one
+        for (int q = tid; q < 2 * S1p; q += NT) buf[q] = MM_NINF;
+        stage_em(em + (NF & 1) * P1p, Vb, p.vsn, NF, len, P, tid, NT, MM_LOG2E);
+        __syncthreads();
+        {
+            float *yl = buf + (NF & 1) * S1p;
+            const float *el = em + (NF & 1) * P1p;
+            float *dst = p.out + (long long)(NF - 1) * p.out_stride_n + u.state_off;
+            float wm = MM_NINF;
+            for (int s = tid; s < S1; s += NT) {
+                float y = el[u.s2p[s]];
+                yl[s] = y;
+                wm = fmaxf(wm, y);
+                dst[s] = 0.f;
+            }
+            wm = wave_max(wm);
+            if (lane == 0) part[(NF & 1) * MM_MAX_WAVES + wave] = wm;
+            if (NF - 1 >= 1) stage_em(em + ((NF - 1) & 1) * P1p, Vb, p.vsn, NF - 1, len, P, tid, NT, MM_LOG2E);
+        }
+        __syncthreads();
+        double D = 0.0;
+        for (int n = NF - 1; n >= 1; --n) {
+            const float *yp = buf + ((n + 1) & 1) * S1p;
+            float *yn = buf + (n & 1) * S1p;
+            const float *emn = em + (n & 1) * P1p;
+            const float M = part_max(part + ((n + 1) & 1) * MM_MAX_WAVES, NW);
+            D += (double)M;
+            const float d = (float)D;
+            if (n - 1 >= 1) stage_em(em + ((n - 1) & 1) * P1p, Vb, p.vsn, n - 1, len, P, tid, NT, MM_LOG2E);
+            float *dst = p.out + (long long)(n - 1) * p.out_stride_n + u.state_off;
+            float wm = MM_NINF;
+            for (int it = wave; it < gb.n_items; it += NW) {
+                const ItemMeta im = load_item(gb.items, it);
+                const RowInfo ri = gb.rowinfo[(size_t)it * 64 + lane];
+                float v = lse_item(gb.slots, im, lane, yp);
+                if (ri.row >= 0 && (lane & ((1 << im.log2g) - 1)) == 0) {
+                    const float beta = v - M;
+                    dst[ri.row] = (beta + d) * MM_LN2;
+                    const float y = beta + emn[ri.pdf];
+                    yn[ri.row] = y;
+                    wm = fmaxf(wm, y);
+                }
+            }
+            wm = wave_max(wm);
+            if (lane == 0) part[(n & 1) * MM_MAX_WAVES + wave] = wm;
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Tropical-semiring forward recursion with back-pointers (Viterbi).
+// Forward = alpha-recursion (src/inference.jl:62-74) with K = TropicalSemiring;
+// the arithmetic is the reference's float32 adds un-normalised, so values and
+// arg-max decisions are bit-identical to the CPU restatement.
+// Optional alpha export through p.out (natural log).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void trop_better(float &best, int &arg, float v, int c) {
+    if (v > best || (v == best && v > MM_NINF && c < arg)) {
+        best = v;
+        arg = c;
+    }
+}
+
+__global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
+    extern __shared__ float lds[];
+    const int b = blockIdx.x;
+    const UttDesc &u = p.utts[b];
+    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6;
+    const int S1 = u.S1, S1p = u.S1p, P1 = u.P1, P = P1 - 1, P1p = (P1 + 3) & ~3;
+    int len = p.lens ? p.lens[b] : p.N;
+    len = len < 0 ? 0 : (len > p.N ? p.N : len);
+    const int NF = p.N + 1;
+    const LdsPlan L = lds_plan(S1p, P1p, false);
+    float *buf = lds + L.buf, *em = lds + L.em;
+    const float *Vb = p.V + (long long)b * p.vsb;
+    const GraphDev gf = u.g[0];
+    int *bpb = p.bp ? p.bp + u.state_off : nullptr;
+
+    stage_em(em + 1 * P1p, Vb, p.vsn, 1, len, P, tid, NT, 1.0f);
+    for (int q = tid; q < 2 * S1p; q += NT) buf[q] = MM_NINF;
+    __syncthreads();
+    {
+        float *a1 = buf + 1 * S1p;
+        const float *e1 = em + 1 * P1p;
+        for (int s = tid; s < S1; s += NT) {
+            a1[s] = u.init[s] + e1[u.s2p[s]];
+            if (bpb) bpb[s] = -1;
+            if (p.out) p.out[u.state_off + s] = a1[s];
+        }
+        if (NF >= 2) stage_em(em + 0 * P1p, Vb, p.vsn, 2, len, P, tid, NT, 1.0f);
+    }
+    __syncthreads();
+    if (len == 0 && tid == 0 && p.score) p.score[b] = buf[1 * S1p + S1 - 1];
+    for (int n = 2; n <= NF; ++n) {
+        const float *ap = buf + ((n - 1) & 1) * S1p;
+        float *an = buf + (n & 1) * S1p;
+        const float *emn = em + (n & 1) * P1p;
+        if (n + 1 <= NF) stage_em(em + ((n + 1) & 1) * P1p, Vb, p.vsn, n + 1, len, P, tid, NT, 1.0f);
+        for (int it = wave; it < gf.n_items; it += NW) {
+            const ItemMeta im = load_item(gf.items, it);
+            const RowInfo ri = gf.rowinfo[(size_t)it * 64 + lane];
+            const Slot *sp = gf.slots + (size_t)im.slot_row * 64 + lane;
+            float best = MM_NINF;
+            int arg = -1;
+            for (int k = 0; k < im.R; ++k) {
+                Slot s = load_slot(sp + k * 64);
+                trop_better(best, arg, s.w + ap[s.col], (int)s.col);
+            }
+            for (int i = 0; i < im.log2g; ++i) {
+                float ov = __shfl_xor(best, 1 << i);
+                int oa = __shfl_xor(arg, 1 << i);
+                trop_better(best, arg, ov, oa);
+            }
+            if (ri.row >= 0 && (lane & ((1 << im.log2g) - 1)) == 0) {
+                const float v = best + emn[ri.pdf];
+                an[ri.row] = v;
+                if (bpb) bpb[(long long)(n - 1) * p.bp_stride_n + ri.row] = arg;
+                if (p.out) p.out[(long long)(n - 1) * p.out_stride_n + u.state_off + ri.row] = v;
+            }
+        }
+        __syncthreads();
+        if (n == len + 1 && tid == 0 && p.score) p.score[b] = an[S1 - 1];
+    }
+}
+
+// back-trace: one lane per utterance follows the back-pointers from the phony
+// final state at frame len+1 (historical bestpath, examples/demo.ipynb cell 23)
+__global__ void mm_backtrace_kernel(RunParams p) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= p.B) return;
+    const UttDesc &u = p.utts[b];
+    int len = p.lens ? p.lens[b] : p.N;
+    len = len < 0 ? 0 : (len > p.N ? p.N : len);
+    int *path = p.path + (long long)b * p.path_stride_b;
+    for (int n = len; n < p.N; ++n) path[n] = -1;
+    const bool ok = p.score[b] > MM_NINF;
+    int s = u.S1 - 1;
+    const int *bpb = p.bp + u.state_off;
+    for (int n = len; n >= 1; --n) {
+        if (ok) s = bpb[(long long)n * p.bp_stride_n + s];
+        path[n - 1] = ok ? s : -1;
+    }
+}
+
+}  // namespace mm

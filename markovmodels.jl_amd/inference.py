@@ -1,0 +1,279 @@
+"""Host-side mirror of src/inference.jl: CompiledFSM / compile / batch / expand /
+alpha-recursion / beta-recursion / pdfposteriors, plus bestpath
+(docs/src/inference.md:4-6).  Every compute entry point is ONE call into the
+HIP engine through the C ABI (include/markovmodels_amd.h); there is no CPU
+path here.
+
+Two ways in:
+  * the reference call shapes -- ``pdfposteriors(fsm, Vhats, Chats)`` with
+    ``Vhats`` made by ``expand`` (src/inference.jl:145-161), or the
+    prepare-once variant ``pdfposteriors(batch(cfsm...), Vhats)``
+    (``pdfposteriors2``, :164-180);
+  * the native one the bench uses -- ``BatchedFSM.pdfposteriors(V, lens)`` on
+    device-resident ``V[B, N, P]`` log-likelihoods and lengths, no host round
+    trips.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib
+from ._lib import SEMIRING_ID, check, lib
+from .fsm import FSM, StateMap, split_blocks, statemap
+
+_ZERO = -np.inf
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("markovmodels_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+    return torch
+
+
+class CompiledFSM:
+    """CompiledFSM{K} (src/inference.jl:3-12): alpha_hat, T_hat, T_hat', C_hat, C_hat'
+    prepared once -- here as the packed device forms the kernels stream."""
+
+    def __init__(self, fsm: FSM, C_hat: Union[StateMap, np.ndarray]):
+        if not isinstance(C_hat, StateMap):
+            C_hat = StateMap.from_matrix(C_hat)
+        if C_hat.shape[0] != fsm.S1:
+            raise _lib.DimensionMismatch(-2, f"C_hat has {C_hat.shape[0]} rows, the FSM {fsm.S1} states")
+        self.fsm = fsm
+        self.C_hat = C_hat
+        self.semiring = fsm.semiring
+        self.S1 = fsm.S1
+        self.P1 = C_hat.numpdf + 1
+        colptr = np.ascontiguousarray(fsm.colptr, dtype=np.int64)
+        rowval = np.ascontiguousarray(fsm.rowval, dtype=np.int64)
+        nzval = np.ascontiguousarray(fsm.nzval, dtype=np.float32 if fsm.nzval.dtype != np.float64 else np.float64)
+        aidx = np.ascontiguousarray(fsm.alpha_idx, dtype=np.int64)
+        aval = np.ascontiguousarray(fsm.alpha_val, dtype=nzval.dtype)
+        s2p = np.ascontiguousarray(C_hat.state2pdf, dtype=np.int32)
+        h = C.c_void_p()
+        check(lib.mm_fsm_create(SEMIRING_ID[self.semiring], self.S1, fsm.nnz, _lib.MM_CSC, 8, 0, nzval.dtype.itemsize,
+                                colptr.ctypes.data, rowval.ctypes.data, nzval.ctypes.data, aidx.shape[0],
+                                aidx.ctypes.data, aval.ctypes.data, s2p.ctypes.data, self.P1, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.mm_fsm_destroy(h)
+            self._h = None
+
+    def info(self) -> dict:
+        S1, nnz, P1 = C.c_int64(), C.c_int64(), C.c_int32()
+        slots, items = (C.c_int64 * 2)(), (C.c_int64 * 2)()
+        check(lib.mm_fsm_info(self._h, C.byref(S1), C.byref(nnz), C.byref(P1), slots, items))
+        return dict(S1=S1.value, nnz=nnz.value, P1=P1.value, packed_slots=list(slots), packed_items=list(items))
+
+    def packed_product(self, x: np.ndarray, direction: int = 0):
+        """Host evaluation of one semiring product through the packed form (test aid)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty(self.S1, dtype=np.float32)
+        arg = np.empty(self.S1, dtype=np.int32)
+        check(lib.mm_debug_packed_product(self._h, direction, x.ctypes.data, out.ctypes.data, arg.ctypes.data))
+        return out, arg
+
+
+def compile(fsm: FSM, C_hat) -> CompiledFSM:  # noqa: A001 - the reference's name
+    """compile(fsm, C_hat) (src/inference.jl:11-12)."""
+    return CompiledFSM(fsm, C_hat)
+
+
+class BatchedFSM:
+    """batch(cfsm...) (src/inference.jl:28-36): B independent compiled FSMs as
+    one block-diagonal system.  Repeating one CompiledFSM B times shares its
+    device storage (the denominator case)."""
+
+    def __init__(self, cfsms: Sequence[CompiledFSM]):
+        self.cfsms = list(cfsms)
+        self.B = len(self.cfsms)
+        arr = (C.c_void_p * self.B)(*[c._h for c in self.cfsms])
+        h = C.c_void_p()
+        check(lib.mm_batch_create(arr, self.B, C.byref(h)))
+        self._h = h
+        self.semiring = self.cfsms[0].semiring
+        self.P = self.cfsms[0].P1 - 1
+        if any(c.P1 != self.P + 1 for c in self.cfsms):
+            raise _lib.DimensionMismatch(-2, "all FSMs of a batch must share the number of pdfs")
+        self.total_states = int(lib.mm_batch_total_states(h))
+        self.state_offsets = np.cumsum([0] + [c.S1 for c in self.cfsms])
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.mm_batch_destroy(h)
+            self._h = None
+
+    # -- helpers -----------------------------------------------------------------
+    def _prep(self, V, lens):
+        torch = _torch()
+        as_numpy = not isinstance(V, torch.Tensor)
+        Vt = torch.as_tensor(np.ascontiguousarray(V, dtype=np.float32)).cuda() if as_numpy else V
+        if Vt.dtype != torch.float32 or not Vt.is_cuda:
+            raise TypeError("V must be a float32 tensor on the HIP device")
+        if Vt.dim() != 3 or Vt.shape[0] != self.B or Vt.shape[2] != self.P:
+            raise _lib.DimensionMismatch(-2, f"V must be [B={self.B}, N, P={self.P}], got {tuple(Vt.shape)}")
+        if Vt.stride(2) != 1:
+            Vt = Vt.contiguous()
+        lt = None
+        if lens is not None:
+            lt = torch.as_tensor(np.asarray(lens, dtype=np.int32)).cuda() if not isinstance(lens, torch.Tensor) else lens
+            lt = lt.to(device=Vt.device, dtype=torch.int32).contiguous()
+            if lt.numel() != self.B:
+                raise _lib.DimensionMismatch(-2, "lens must have B entries")
+        return torch, Vt, lt, as_numpy
+
+    @staticmethod
+    def _stream(torch):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # -- compute -------------------------------------------------------------------
+    def pdfposteriors(self, V, lens=None, out=None):
+        """One call of the engine: gamma[B, N, P] (probabilities), ttl[B]."""
+        torch, Vt, lt, as_numpy = self._prep(V, lens)
+        B, N, P = Vt.shape
+        gamma = out if out is not None else torch.empty((B, N, P), dtype=torch.float32, device=Vt.device)
+        ttl = torch.empty(B, dtype=torch.float32, device=Vt.device)
+        check(lib.mm_pdfposteriors_f32(self._h, Vt.data_ptr(), Vt.stride(0), Vt.stride(1),
+                                       lt.data_ptr() if lt is not None else None, N, gamma.data_ptr(), gamma.stride(0),
+                                       gamma.stride(1), gamma.stride(2), ttl.data_ptr(), self._stream(torch)))
+        if as_numpy:
+            return gamma.cpu().numpy(), ttl.cpu().numpy()
+        return gamma, ttl
+
+    def _export(self, fn, V, lens):
+        torch, Vt, lt, as_numpy = self._prep(V, lens)
+        B, N, P = Vt.shape
+        out = torch.empty((N + 1, self.total_states), dtype=torch.float32, device=Vt.device)
+        check(fn(self._h, Vt.data_ptr(), Vt.stride(0), Vt.stride(1), lt.data_ptr() if lt is not None else None, N,
+                 out.data_ptr(), out.stride(0), self._stream(torch)))
+        out = out.t()  # (sum S1) x (N+1) like the reference's state_A / state_B
+        return out.cpu().numpy() if as_numpy else out
+
+    def alpharecursion(self, V, lens=None):
+        return self._export(lib.mm_alpharecursion_f32, V, lens)
+
+    def betarecursion(self, V, lens=None):
+        return self._export(lib.mm_betarecursion_f32, V, lens)
+
+    def viterbi(self, V, lens=None, return_backpointers=False):
+        """Best paths: (path[B, N] 0-based states, -1 beyond len; score[B][, bp[N+1, sum S1]])."""
+        torch, Vt, lt, as_numpy = self._prep(V, lens)
+        B, N, P = Vt.shape
+        path = torch.empty((B, N), dtype=torch.int32, device=Vt.device)
+        score = torch.empty(B, dtype=torch.float32, device=Vt.device)
+        bp = torch.empty((N + 1, self.total_states), dtype=torch.int32, device=Vt.device) if return_backpointers else None
+        check(lib.mm_viterbi_f32(self._h, Vt.data_ptr(), Vt.stride(0), Vt.stride(1),
+                                 lt.data_ptr() if lt is not None else None, N, path.data_ptr(), path.stride(0),
+                                 score.data_ptr(), bp.data_ptr() if bp is not None else None,
+                                 bp.stride(0) if bp is not None else 0, self._stream(torch)))
+        res = (path, score) + ((bp,) if bp is not None else ())
+        if as_numpy:
+            res = tuple(r.cpu().numpy() for r in res)
+        return res
+
+
+def batch(*cfsms: CompiledFSM) -> BatchedFSM:
+    """batch(fsm1, fsms...) (src/inference.jl:28-36)."""
+    return BatchedFSM(cfsms)
+
+
+def expand(lhs, seqlength: Optional[int] = None):
+    """expand(V, seqlength) (src/inference.jl:54-60): the P x N log-likelihoods
+    become (P+1) x (N+1): a phony pdf row (zero up to seqlength, one after) and
+    an extra frame; real pdfs are zero beyond seqlength.  zero = -inf, one = 0
+    (Log/Tropical semirings)."""
+    a = np.asarray(lhs)
+    P, N = a.shape
+    L = N if seqlength is None else int(seqlength)
+    out = np.full((P + 1, N + 1), _ZERO, dtype=a.dtype if a.dtype.kind == "f" else np.float32)
+    out[:P, :L] = a[:, :L]
+    out[P, L:] = 0.0
+    return out
+
+
+def _unexpand(Vhats: Sequence[np.ndarray]):
+    """Recover (V[B, N, P], lens) from matrices made by ``expand``; anything that
+    is not of that form is rejected (the engine implements expand's semantics)."""
+    Vh = [np.asarray(v.cpu() if hasattr(v, "cpu") else v) for v in Vhats]
+    shp = Vh[0].shape
+    if any(v.shape != shp for v in Vh):
+        raise _lib.DimensionMismatch(-2, "all V_hat must share one (P+1) x (N+1) shape")
+    P1, N1 = shp
+    lens = []
+    for v in Vh:
+        ph = v[P1 - 1]
+        L = int(np.argmax(ph == 0)) if (ph == 0).any() else N1
+        ok = np.all(np.isneginf(ph[:L])) and np.all(ph[L:] == 0) and np.all(np.isneginf(v[: P1 - 1, L:])) and L <= N1 - 1
+        if not ok:
+            raise ValueError("V_hat is not of the form expand(V, seqlength) produces")
+        lens.append(L)
+    V = np.stack([v[: P1 - 1, : N1 - 1].T for v in Vh]).astype(np.float32)
+    V[~np.isfinite(V) & (V < 0)] = -np.inf
+    return np.ascontiguousarray(V), np.asarray(lens, dtype=np.int32)
+
+
+def _as_batch(fsm, Chats) -> BatchedFSM:
+    if isinstance(fsm, BatchedFSM):
+        return fsm
+    if isinstance(fsm, CompiledFSM):
+        return BatchedFSM([fsm])
+    if Chats is None:
+        raise TypeError("pdfposteriors(fsm::FSM, V_hats, C_hats) needs the state maps")
+    Cs = [c if isinstance(c, StateMap) else StateMap.from_matrix(c) for c in Chats]
+    parts = split_blocks(fsm, [c.shape[0] for c in Cs])
+    cache, cf = {}, []
+    for part, c in zip(parts, Cs):
+        key = (id(part), id(c))
+        if key not in cache:
+            cache[key] = CompiledFSM(part, c)
+        cf.append(cache[key])
+    return BatchedFSM(cf)
+
+
+def pdfposteriors(fsm, Vhats, Chats=None):
+    """pdfposteriors(fsm, V_hats, C_hats) (src/inference.jl:145-161) -- ``fsm`` the
+    rawunion of the batch -- or pdfposteriors2(cfsm, V_hats) (:164-180) when
+    given a BatchedFSM/CompiledFSM.  Returns (gamma[B, P, N] probabilities,
+    ttl[B]) as NumPy arrays, like the reference returns fresh arrays."""
+    bf = _as_batch(fsm, Chats)
+    V, lens = _unexpand(Vhats)
+    g, ttl = bf.pdfposteriors(V, lens)
+    return np.ascontiguousarray(g.transpose(0, 2, 1)), ttl
+
+
+def alpharecursion(fsm, Vhats, Chats=None):
+    """alpha-recursion (src/inference.jl:62-74) on C_hat * V_hat as pdfposteriors calls
+    it (:150-152): the (sum S1) x (N+1) matrix state_A."""
+    bf = _as_batch(fsm, Chats)
+    V, lens = _unexpand(Vhats)
+    return bf.alpharecursion(V, lens)
+
+
+def betarecursion(fsm, Vhats, Chats=None):
+    """beta-recursion (src/inference.jl:99-110): state_B."""
+    bf = _as_batch(fsm, Chats)
+    V, lens = _unexpand(Vhats)
+    return bf.betarecursion(V, lens)
+
+
+def bestpath(fsm, Vhats, Chats=None):
+    """bestpath (docs/src/inference.md:6; historical examples/demo.ipynb cell 23):
+    per utterance the 0-based state sequence of the best path and its weight."""
+    bf = _as_batch(fsm, Chats)
+    V, lens = _unexpand(Vhats)
+    path, score = bf.viterbi(V, lens)
+    return [path[b, : lens[b]].copy() for b in range(bf.B)], score
+
+
+# the reference's own (unicode) export names, src/MarkovModels.jl:40-45
+αrecursion = alpharecursion
+βrecursion = betarecursion

@@ -1,0 +1,216 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle
+on the same seeded inputs.  Tolerances follow BASELINE.json's north_star:
+log-posteriors within 1e-4 relative, Viterbi back-pointers bit exact."""
+import numpy as np
+import pytest
+
+import graphs
+
+pytestmark = pytest.mark.gpu
+
+RTOL_LOGPOST = 1e-4  # |d log gamma| <= 1e-4 * max(|log gamma|, 1)
+GAMMA_FLOOR = 1e-30
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    assert torch.cuda.is_available()
+    return torch
+
+
+def check_gamma(g, g_ref, lens):
+    g = np.asarray(g, dtype=np.float64)
+    assert np.isfinite(g).all()
+    for b, L in enumerate(lens):
+        assert (g[b, L:] == 0).all(), "frames beyond the sequence length must be exact zeros"
+    assert np.abs(g - g_ref).max() <= 2e-5
+    m = g_ref > GAMMA_FLOOR
+    assert (g[m] > 0).all()
+    lg, lr = np.log(g[m]), np.log(g_ref[m])
+    assert (np.abs(lg - lr) <= RTOL_LOGPOST * np.maximum(np.abs(lr), 1.0)).all(), np.abs(lg - lr).max()
+    for b, L in enumerate(lens):
+        assert np.allclose(g[b, :L].sum(-1), 1.0, atol=1e-5)
+
+
+def run_shared(mm, wl, oracle, torch, g, B, N, lens, seed=0, scale=1.0):
+    o, oc = oracle
+    rng = np.random.default_rng(seed)
+    V = (scale * rng.standard_normal((B, N, g.P))).astype(np.float32)
+    lens = np.asarray(lens, dtype=np.int32)
+    g_ref, t_ref = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V, lens, dtype=np.float64)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(*([cf] * B))
+    gam, ttl = bf.pdfposteriors(torch.from_numpy(V).cuda(), torch.from_numpy(lens).cuda())
+    torch.cuda.synchronize()
+    return gam.cpu().numpy(), ttl.cpu().numpy(), g_ref, t_ref, lens
+
+
+def test_known_answer_demo_notebook(mm, wl, torch):
+    """examples/demo.ipynb cell 13: 3-state left-to-right HMM, lhs = zeros(3, 5)."""
+    g = wl.l2r_hmm(3)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    gam, ttl = mm.pdfposteriors(cf, [mm.expand(np.zeros((3, 5), dtype=np.float32))])
+    ref = np.array([[1, .5, 1 / 6, 0, 0], [0, .5, 2 / 3, .5, 0], [0, 0, 1 / 6, .5, 1]])
+    assert np.allclose(gam[0], ref, atol=1e-6)
+    assert np.isclose(ttl[0], np.log(6 / 32), atol=1e-6)
+
+
+def test_known_answer_batch_varlen(mm, wl, torch):
+    """test/test_algorithms.jl:218-248: the same FSM twice, lhs = ones(3, 7), lengths [5, 7]."""
+    g = wl.l2r_hmm(3)
+    f = wl.to_fsm(mm, g)
+    C = mm.statemap(g.state2pdf, g.P)
+    lhs = np.ones((3, 7), dtype=np.float32)
+    gam, ttl = mm.pdfposteriors(mm.rawunion(f, f), [mm.expand(lhs, 5), mm.expand(lhs, 7)], [C, C])
+    r1 = np.array([[1, .5, 1 / 6, 0, 0], [0, .5, 2 / 3, .5, 0], [0, 0, 1 / 6, .5, 1]])
+    r2 = np.array([[1, 2 / 3, .4, .2, 1 / 15, 0, 0], [0, 1 / 3, 8 / 15, .6, 8 / 15, 1 / 3, 0],
+                   [0, 0, 1 / 15, .2, .4, 2 / 3, 1]])
+    assert np.allclose(gam[0][:, :5], r1, atol=1e-6) and (gam[0][:, 5:] == 0).all()
+    assert np.allclose(gam[1], r2, atol=1e-6)
+    assert np.allclose(ttl, [3.3260236, 4.8560199], atol=1e-5)
+
+
+@pytest.mark.parametrize("name,B,N", [("rand40", 5, 33), ("ergodic64", 4, 50), ("wide", 2, 9), ("lexicon", 2, 40),
+                                      ("lfmmi", 3, 40)])
+def test_pdfposteriors_vs_oracle(mm, wl, oracle, torch, name, B, N):
+    g = {"rand40": lambda: wl.random_fsm(40, 6, 3.0, seed=1), "ergodic64": lambda: wl.dense_ergodic(64),
+         "wide": lambda: wl.wide_row_fsm(), "lexicon": lambda: wl.lexicon_fsm(1200, 20),
+         "lfmmi": lambda: wl.lfmmi_denominator(2000, 84)}[name]()
+    lens = [N] + [max(1, N - 7 * (b + 1)) for b in range(B - 1)]
+    gam, ttl, g_ref, t_ref, lens = run_shared(mm, wl, oracle, torch, g, B, N, lens)
+    check_gamma(gam, g_ref, lens)
+    assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)
+
+
+def test_long_sequence_drift(mm, wl, oracle, torch):
+    """N = 1500 frames: the float32 engine must not drift (normalised recursion)."""
+    g = wl.random_fsm(60, 8, 3.0, seed=3)
+    gam, ttl, g_ref, t_ref, lens = run_shared(mm, wl, oracle, torch, g, 2, 1500, [1500, 1111], scale=2.0)
+    check_gamma(gam, g_ref, lens)
+    assert np.allclose(ttl, t_ref, rtol=1e-5)
+
+
+def test_edge_cases(mm, wl, oracle, torch):
+    o, oc = oracle
+    g = wl.random_fsm(12, 4, 2.0, seed=5)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    rng = np.random.default_rng(1)
+    # length-1 and length-0 utterances next to a full one
+    V = rng.standard_normal((3, 6, g.P)).astype(np.float32)
+    lens = np.array([6, 1, 0], dtype=np.int32)
+    gam, ttl = mm.batch(cf, cf, cf).pdfposteriors(V, lens)
+    g_ref, t_ref = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V[:2], lens[:2], dtype=np.float64)
+    check_gamma(gam[:2], g_ref, lens[:2])
+    assert np.allclose(ttl[:2], t_ref, rtol=1e-5, atol=1e-5)
+    assert (gam[2] == 0).all() and ttl[2] == -np.inf  # no path of length 0: defined as gamma = 0, ttl = -inf
+    # an utterance whose only paths are impossible (all emissions -inf on one frame)
+    V2 = V[:1].copy()
+    V2[0, 3, :] = -np.inf
+    gam2, ttl2 = mm.batch(cf).pdfposteriors(V2, np.array([6], dtype=np.int32))
+    assert (gam2 == 0).all() and ttl2[0] == -np.inf
+    # emission spike: one pdf wins a frame by 60 nats
+    V3 = V[:1].copy()
+    V3[0, 2, 1] += 60.0
+    g3, t3 = mm.batch(cf).pdfposteriors(V3, None)
+    r3, rt3 = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V3, None, dtype=np.float64)
+    check_gamma(g3, r3, [6])
+    assert np.allclose(t3, rt3, rtol=1e-5)
+
+
+def test_distinct_graphs_block_diagonal(mm, wl, oracle, torch):
+    """Numerator-style batch: a different FSM per utterance (rawunion, src/fsmops.jl:28-36)."""
+    o, oc = oracle
+    P = 7
+    gs = [wl.random_fsm(S, P, 2.5, seed=10 + S) for S in (9, 31, 70)]
+    fs = [wl.to_fsm(mm, g) for g in gs]
+    Cs = [mm.statemap(g.state2pdf, P) for g in gs]
+    rng = np.random.default_rng(2)
+    N = 21
+    lens = [21, 13, 17]
+    Vs = [rng.standard_normal((P, N)).astype(np.float32) for _ in gs]
+    gam, ttl = mm.pdfposteriors(mm.rawunion(*fs), [mm.expand(v, L) for v, L in zip(Vs, lens)], Cs)
+    for b, g in enumerate(gs):
+        gr, tr = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, P, Vs[b].T[None], [lens[b]], dtype=np.float64)
+        check_gamma(gam[b].T[None], gr, [lens[b]])
+        assert np.isclose(ttl[b], tr[0], rtol=1e-5)
+
+
+def test_alpha_beta_export(mm, wl, oracle, torch):
+    """alpha-recursion / beta-recursion (src/inference.jl:62-74, 99-110) = state_A / state_B of pdfposteriors."""
+    o, oc = oracle
+    g = wl.random_fsm(25, 5, 3.0, seed=7)
+    of = graphs.to_oracle(o, g)
+    C = mm.statemap(g.state2pdf, g.P)
+    f = wl.to_fsm(mm, g)
+    rng = np.random.default_rng(3)
+    N, lens = 14, [14, 9]
+    Vs = [rng.standard_normal((g.P, N)).astype(np.float32) for _ in lens]
+    Vh = [mm.expand(v, L) for v, L in zip(Vs, lens)]
+    A = mm.αrecursion(mm.rawunion(f, f), Vh, [C, C])
+    Bm = mm.βrecursion(mm.rawunion(f, f), Vh, [C, C])
+    S1 = g.S + 1
+    assert A.shape == (2 * S1, N + 1) and Bm.shape == (2 * S1, N + 1)
+    for b in range(2):
+        _, _, Ar, Br = oc.single(of, g.state2pdf, g.P, o.expand(Vs[b].astype(np.float64), lens[b], o.LOG), want_ab=True)
+        for got, ref in ((A[b * S1:(b + 1) * S1], Ar), (Bm[b * S1:(b + 1) * S1], Br)):
+            assert np.array_equal(np.isneginf(got), np.isneginf(ref))
+            m = np.isfinite(ref)
+            assert np.allclose(got[m], ref[m], rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["chain", "rand", "lexicon", "wide"])
+def test_viterbi_bit_exact(mm, wl, oracle, torch, name):
+    """Tropical recursion + back-pointers: bit exact against the C oracle (float32, same adds)."""
+    o, oc = oracle
+    if name == "chain":  # test/test_algorithms.jl:262-284: a -> b -> c -> d, lhs = ones(4, 4) => path 1 2 3 4
+        g = wl.GraphSpec("chain4", 4, np.array([0]), np.array([0.0]), np.arange(3), np.arange(1, 4), np.zeros(3),
+                         np.array([3]), np.array([0.0]), np.arange(4, dtype=np.int32), 4)
+        Vs, lens = np.ones((1, 4, 4), dtype=np.float32), [4]
+    else:
+        g = {"rand": lambda: wl.random_fsm(50, 6, 3.0, seed=4), "lexicon": lambda: wl.lexicon_fsm(900, 20),
+             "wide": lambda: wl.wide_row_fsm()}[name]()
+        rng = np.random.default_rng(5)
+        N = 37
+        lens = [37, 20, 1]
+        # quantised scores make exact ties frequent, so the lowest-index rule is exercised
+        Vs = (np.round(rng.standard_normal((3, N, g.P)) * 2) / 2).astype(np.float32)
+    f = wl.to_fsm(mm, g, semiring="tropical")
+    of = graphs.to_oracle(o, g, "tropical", np.float32)
+    cf = mm.compile(f, mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(*([cf] * len(lens)))
+    path, score, bp = bf.viterbi(Vs, np.asarray(lens, dtype=np.int32), return_backpointers=True)
+    S1 = g.S + 1
+    for b, L in enumerate(lens):
+        pr, sr, bpr = oc.viterbi(of, g.state2pdf, g.P, Vs[b], L, dtype=np.float32)
+        assert np.array_equal(path[b], pr), (b, path[b], pr)
+        assert score[b] == sr
+        assert np.array_equal(bp[:, b * S1:(b + 1) * S1], bpr)
+    if name == "chain":
+        assert path[0].tolist() == [0, 1, 2, 3]
+
+
+def test_reference_output_layout(mm, wl, oracle, torch):
+    """gamma written straight into the reference's B x P x N column-major layout (strides)."""
+    g = wl.random_fsm(20, 5, 3.0, seed=8)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    B, N = 3, 11
+    bf = mm.batch(*([cf] * B))
+    V = torch.randn(B, N, g.P, device="cuda")
+    g1, t1 = bf.pdfposteriors(V)
+    out = torch.empty(N, g.P, B, device="cuda").permute(2, 0, 1)  # element (b, n, p): b fastest
+    g2, t2 = bf.pdfposteriors(V, out=out)
+    assert torch.allclose(g1, g2, atol=1e-6) and torch.allclose(t1, t2)
+
+
+def test_errors(mm, wl, torch):
+    g = wl.random_fsm(10, 4, 2.0, seed=9)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(cf, cf)
+    with pytest.raises(mm.DimensionMismatch):
+        bf.pdfposteriors(np.zeros((3, 5, g.P), dtype=np.float32))
+    with pytest.raises(mm.DimensionMismatch):
+        bf.pdfposteriors(np.zeros((2, 5, g.P + 1), dtype=np.float32))
+    with pytest.raises(mm.MarkovModelsAMDError):
+        bf.viterbi(np.zeros((2, 5, g.P), dtype=np.float32))  # log-semiring batch

@@ -114,21 +114,37 @@ struct mm_batch_s {
     size_t ws_bytes = 0;
 };
 
-static int pick_waves(mm_batch_t h) {
+// Launch geometry.  NW waves per workgroup, NI register-resident items per wave
+// (mm_kernels.hip, "Register-resident graph"): NI <= 8 keeps 16 waves per CU inside the
+// 128-VGPR budget, NI = 24 uses 8 waves with up to 256 VGPRs.
+struct Geometry {
+    int NW, NI;
+};
+
+static Geometry pick_geometry(mm_batch_t h) {
+    Geometry g{16, 8};
+    const int it = h->max_items;
+    if (it <= 8 * MM_MAX_WAVES) {
+        g.NI = 8;
+        g.NW = std::max(1, (it + 7) / 8);
+    } else {
+        g.NI = 24;
+        g.NW = 8;
+    }
     if (const char *e = getenv("MM_NWAVES")) {
         int v = atoi(e);
-        if (v >= 1 && v <= MM_MAX_WAVES) return v;
+        if (v >= 1 && v <= MM_MAX_WAVES) g.NW = v;
     }
-    int it = h->max_items;
-    if (it <= 2) return 1;
-    if (it <= 6) return 2;
-    if (it <= 16) return 4;
-    if (it <= 48) return 8;
-    return 16;
+    if (const char *e = getenv("MM_NITEMS")) {
+        int v = atoi(e);
+        if (v == 0 || v == 8 || v == 24) g.NI = v;
+    }
+    if (g.NI == 24 && g.NW > 8) g.NW = 8;
+    return g;
 }
 
 template <typename K>
-static int launch(K kernel, mm_batch_t h, const RunParams &p, bool with_stage, void *stream) {
+static int launch(K kernel, mm_batch_t h, const RunParams &p, bool with_stage, int NW, void *stream) {
     const int P1p = (h->max_P1 + 3) & ~3;
     const LdsPlan L = lds_plan(h->max_S1p, P1p, with_stage);
     const size_t lds = size_t(L.total) * 4;
@@ -136,10 +152,25 @@ static int launch(K kernel, mm_batch_t h, const RunParams &p, bool with_stage, v
         return fail(MM_ERR_UNSUPPORTED, "FSM too large: " + std::to_string(lds) + " B of LDS needed, 163840 available");
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 int(lds)));
-    const int NW = pick_waves(h);
     hipLaunchKernelGGL(kernel, dim3(unsigned(h->B)), dim3(64 * NW), lds, static_cast<hipStream_t>(stream), p);
     HIP_TRY(hipGetLastError());
     return MM_OK;
+}
+
+template <int MODE>
+static int launch_log(mm_batch_t h, const RunParams &p, void *stream) {
+    const Geometry g = pick_geometry(h);
+    const bool st = MODE == MODE_FB;
+    switch (g.NI) {
+        case 0: return launch(mm_log_kernel<MODE, 0>, h, p, st, g.NW, stream);
+        case 8: return launch(mm_log_kernel<MODE, 8>, h, p, st, g.NW, stream);
+        default: return launch(mm_log_kernel<MODE, 24>, h, p, st, g.NW, stream);
+    }
+}
+
+static int tropical_waves(mm_batch_t h) {
+    Geometry g = pick_geometry(h);
+    return g.NI == 24 ? 16 : g.NW;
 }
 
 extern "C" {
@@ -411,7 +442,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     p.gsn = gsn;
     p.gsp = gsp;
     p.ttl = ttl;
-    return launch(mm_log_kernel<MODE_FB>, h, p, true, stream);
+    return launch_log<MODE_FB>(h, p, stream);
 }
 
 static int run_export(mm_batch_t h, int mode, const float *V, int64_t vsb, int64_t vsn, const int32_t *lens, int64_t N,
@@ -433,10 +464,10 @@ static int run_export(mm_batch_t h, int mode, const float *V, int64_t vsb, int64
     p.out_stride_n = out_stride_n;
     if (h->semiring == MM_TROPICAL) {
         if (mode != MODE_ALPHA) return fail(MM_ERR_UNSUPPORTED, "tropical beta-recursion export is not implemented");
-        return launch(mm_tropical_kernel, h, p, false, stream);
+        return launch(mm_tropical_kernel, h, p, false, tropical_waves(h), stream);
     }
-    if (mode == MODE_ALPHA) return launch(mm_log_kernel<MODE_ALPHA>, h, p, false, stream);
-    return launch(mm_log_kernel<MODE_BETA>, h, p, false, stream);
+    if (mode == MODE_ALPHA) return launch_log<MODE_ALPHA>(h, p, stream);
+    return launch_log<MODE_BETA>(h, p, stream);
 }
 
 int mm_alpharecursion_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const int32_t *lens, int64_t N,
@@ -477,7 +508,7 @@ int mm_viterbi_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const
     p.path = path;
     p.path_stride_b = path_stride_b;
     p.score = score;
-    rc = launch(mm_tropical_kernel, h, p, false, stream);
+    rc = launch(mm_tropical_kernel, h, p, false, tropical_waves(h), stream);
     if (rc) return rc;
     const int bt = 64;
     hipLaunchKernelGGL(mm_backtrace_kernel, dim3(unsigned((h->B + bt - 1) / bt)), dim3(bt), 0,

@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "mm_pack.h"
 
 namespace mm {
@@ -89,13 +91,35 @@ __host__ __device__ inline LdsPlan lds_plan(int S1p, int P1p, bool with_stage) {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 
-// cross-lane reductions inside aligned lane groups of 1 << log2g lanes
+// Cross-lane reductions inside aligned lane groups of 1 << log2g lanes (log2g is
+// wave-uniform).  Butterfly steps 1, 2 are DPP quad permutes, 4 and 8 the DPP
+// row_half_mirror / row_mirror (valid because the lower levels are already
+// uniform inside their quads / octets); only groups wider than a 16-lane DPP row
+// (rows with > 64 arcs) go through the LDS crossbar (ds_bpermute).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+#define MM_DPP_XOR1 0xB1   // quad_perm [1,0,3,2]
+#define MM_DPP_XOR2 0x4E   // quad_perm [2,3,0,1]
+#define MM_DPP_HALF_MIRROR 0x141
+#define MM_DPP_MIRROR 0x140
 __device__ __forceinline__ float grp_max(float v, int log2g) {
-    for (int i = 0; i < log2g; ++i) v = fmaxf(v, __shfl_xor(v, 1 << i));
+    if (log2g >= 1) v = fmaxf(v, dpp_mov<MM_DPP_XOR1>(v));
+    if (log2g >= 2) v = fmaxf(v, dpp_mov<MM_DPP_XOR2>(v));
+    if (log2g >= 3) v = fmaxf(v, dpp_mov<MM_DPP_HALF_MIRROR>(v));
+    if (log2g >= 4) v = fmaxf(v, dpp_mov<MM_DPP_MIRROR>(v));
+    if (log2g >= 5) v = fmaxf(v, __shfl_xor(v, 16));
+    if (log2g >= 6) v = fmaxf(v, __shfl_xor(v, 32));
     return v;
 }
 __device__ __forceinline__ float grp_sum(float v, int log2g) {
-    for (int i = 0; i < log2g; ++i) v += __shfl_xor(v, 1 << i);
+    if (log2g >= 1) v += dpp_mov<MM_DPP_XOR1>(v);
+    if (log2g >= 2) v += dpp_mov<MM_DPP_XOR2>(v);
+    if (log2g >= 3) v += dpp_mov<MM_DPP_HALF_MIRROR>(v);
+    if (log2g >= 4) v += dpp_mov<MM_DPP_MIRROR>(v);
+    if (log2g >= 5) v += __shfl_xor(v, 16);
+    if (log2g >= 6) v += __shfl_xor(v, 32);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) { return grp_max(v, 6); }
@@ -199,12 +223,126 @@ __device__ __forceinline__ float part_max(const float *part, int NW) {
 }
 
 // ---------------------------------------------------------------------------
+// Register-resident graph.  The packed graph is the same for every frame, so a
+// wave keeps its first NI items (those with R <= 4) in VGPRs for the whole
+// time loop: 4 weights, 4 column indices packed as u16 pairs and the packed
+// {row, pdf} per lane = 7 VGPRs per item.  With the whole graph on chip the
+// per-frame work touches HBM/L2 only for emissions and the alpha store.
+// Items beyond NI * NW (and all long rows) are streamed from L2 as before.
+// ---------------------------------------------------------------------------
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int NI>
+struct ItemRegs {
+    float w[NI > 0 ? NI : 1][4];
+    unsigned c[NI > 0 ? NI : 1][2];  // col0 | col1 << 16, col2 | col3 << 16
+    unsigned ri[NI > 0 ? NI : 1];    // row | pdf << 16 ; row 0xffff = padding
+    int meta[NI > 0 ? NI : 1];       // wave-uniform: R | log2g << 8 ; 0 = no item
+};
+
+template <int NI>
+__device__ __forceinline__ void load_item_regs(ItemRegs<NI> &rg, const GraphDev &g, int wave, int NW, int lane) {
+    static_for<0, NI>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int it = wave + i * NW;
+        int meta = 0;
+        unsigned ri = 0xffffu, c01 = 0u, c23 = 0u;
+        float w0 = MM_NINF, w1 = MM_NINF, w2 = MM_NINF, w3 = MM_NINF;
+        if (it < g.n_items) {
+            const ItemMeta im = load_item(g.items, it);
+            if (im.R <= 4) {
+                meta = (int)im.R | ((int)im.log2g << 8);
+                const RowInfo r = g.rowinfo[(size_t)it * 64 + lane];
+                ri = (r.row < 0 ? 0xffffu : (unsigned)r.row) | ((unsigned)r.pdf << 16);
+                const Slot *sp = g.slots + (size_t)im.slot_row * 64 + lane;
+                const Slot s0 = load_slot(sp);
+                w0 = s0.w;
+                c01 = s0.col;
+                if (im.R > 1) {
+                    const Slot s1 = load_slot(sp + 64);
+                    w1 = s1.w;
+                    c01 |= s1.col << 16;
+                }
+                if (im.R > 2) {
+                    const Slot s2 = load_slot(sp + 128);
+                    w2 = s2.w;
+                    c23 = s2.col;
+                }
+                if (im.R > 3) {
+                    const Slot s3 = load_slot(sp + 192);
+                    w3 = s3.w;
+                    c23 |= s3.col << 16;
+                }
+            }
+        }
+        rg.meta[i] = meta;
+        rg.ri[i] = ri;
+        rg.c[i][0] = c01;
+        rg.c[i][1] = c23;
+        rg.w[i][0] = w0;
+        rg.w[i][1] = w1;
+        rg.w[i][2] = w2;
+        rg.w[i][3] = w3;
+    });
+}
+
+// one register-resident item: two-pass log-sum-exp of <= 4 arcs per lane
+__device__ __forceinline__ float lse_regs(float w0, float w1, float w2, float w3, unsigned c01, unsigned c23, int R,
+                                          int lg, const float *a) {
+    float x0 = w0 + a[c01 & 0xffffu];
+    float x1 = w1 + a[c01 >> 16];
+    float x2 = MM_NINF, x3 = MM_NINF;
+    if (R > 2) {
+        x2 = w2 + a[c23 & 0xffffu];
+        x3 = w3 + a[c23 >> 16];
+    }
+    float m = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
+    m = grp_max(m, lg);
+    const float m0 = (m > MM_NINF) ? m : 0.f;
+    float sum = fast_exp2(x0 - m0) + fast_exp2(x1 - m0);
+    if (R > 2) sum += fast_exp2(x2 - m0) + fast_exp2(x3 - m0);
+    sum = grp_sum(sum, lg);
+    return m0 + fast_log2(sum);
+}
+
+// Visit every item of this wave: epi(value, row, pdf) runs on the leader lane of
+// each row group.  `a` = the LDS vector the arcs gather from.
+template <int NI, class Epi>
+__device__ __forceinline__ void for_items(const ItemRegs<NI> &rg, const GraphDev &g, int wave, int NW, int lane,
+                                          const float *a, Epi &&epi) {
+    static_for<0, NI>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int meta = rg.meta[i];
+        if (meta != 0) {
+            const int R = meta & 0xff, lg = meta >> 8;
+            const float v = lse_regs(rg.w[i][0], rg.w[i][1], rg.w[i][2], rg.w[i][3], rg.c[i][0], rg.c[i][1], R, lg, a);
+            const unsigned row = rg.ri[i] & 0xffffu;
+            if (row != 0xffffu && (lane & ((1 << lg) - 1)) == 0) epi(v, (int)row, (int)(rg.ri[i] >> 16));
+        }
+    });
+    // items beyond the register window, and long rows inside it (meta = 0 there): streamed from L2
+    for (int it = wave; it < g.n_items; it += NW) {
+        const ItemMeta im = load_item(g.items, it);
+        if (it < NI * NW && im.R <= 4) continue;
+        const RowInfo r = g.rowinfo[(size_t)it * 64 + lane];
+        const float v = lse_item(g.slots, im, lane, a);
+        if (r.row >= 0 && (lane & ((1 << im.log2g) - 1)) == 0) epi(v, r.row, r.pdf);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Log-semiring kernel.  MODE_FB: pdfposteriors (src/inference.jl:145-161).
 // MODE_ALPHA / MODE_BETA: alpha-recursion / beta-recursion export (:62-74 / :99-110).
 // grid = B workgroups (one utterance each), block = 64 * NW threads.
 // ---------------------------------------------------------------------------
-template <int MODE>
-__global__ void __launch_bounds__(1024) mm_log_kernel(RunParams p) {
+template <int MODE, int NI>
+__global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p) {
     extern __shared__ float lds[];
     const int b = blockIdx.x;
     const UttDesc &u = p.utts[b];
@@ -224,6 +362,7 @@ __global__ void __launch_bounds__(1024) mm_log_kernel(RunParams p) {
     double *wsC = p.ws_c ? p.ws_c + (long long)b * (p.N + 2) : nullptr;
     const GraphDev gf = u.g[0], gb = u.g[1];
     double logZ2 = 0.0;
+    ItemRegs<NI> rg;
 
     if (MODE != MODE_BETA) {
         // ---------------- forward: alpha-recursion ----------------
@@ -245,6 +384,7 @@ __global__ void __launch_bounds__(1024) mm_log_kernel(RunParams p) {
             if (tid == 0 && wsC) wsC[1] = 0.0;
         }
         __syncthreads();
+        load_item_regs<NI>(rg, gf, wave, NW, lane);
         double C = 0.0, Cprev = 0.0;
         for (int n = 2; n <= NF; ++n) {
             const float *ap = buf + ((n - 1) & 1) * S1p;
@@ -266,16 +406,11 @@ __global__ void __launch_bounds__(1024) mm_log_kernel(RunParams p) {
                 for (int s = tid; s < S1; s += NT) dst[s] = (ap[s] + c) * MM_LN2;
             }
             float wm = MM_NINF;
-            for (int it = wave; it < gf.n_items; it += NW) {
-                const ItemMeta im = load_item(gf.items, it);
-                const RowInfo ri = gf.rowinfo[(size_t)it * 64 + lane];
-                float v = lse_item(gf.slots, im, lane, ap);
-                if (ri.row >= 0 && (lane & ((1 << im.log2g) - 1)) == 0) {
-                    v = v + emn[ri.pdf] - M;   // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
-                    an[ri.row] = v;
-                    wm = fmaxf(wm, v);
-                }
-            }
+            for_items<NI>(rg, gf, wave, NW, lane, ap, [&](float v, int row, int pdf) {
+                v = v + emn[pdf] - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
+                an[row] = v;
+                wm = fmaxf(wm, v);
+            });
             wm = wave_max(wm);
             if (lane == 0) part[(n & 1) * MM_MAX_WAVES + wave] = wm;
             __syncthreads();
@@ -312,6 +447,7 @@ __global__ void __launch_bounds__(1024) mm_log_kernel(RunParams p) {
             for (int q = tid; q < (S1p >> 2); q += NT) dst[q] = src[q];
         }
         __syncthreads();
+        load_item_regs<NI>(rg, gb, wave, NW, lane);
         double D = 0.0;
         float tmin = (float)logZ2;
         for (int n = len; n >= 1; --n) {
@@ -345,19 +481,14 @@ __global__ void __launch_bounds__(1024) mm_log_kernel(RunParams p) {
                 for (int q = tid; q < (S1p >> 2); q += NT) dst[q] = src[q];
             }
             float wm = MM_NINF;
-            for (int it = wave; it < gb.n_items; it += NW) {
-                const ItemMeta im = load_item(gb.items, it);
-                const RowInfo ri = gb.rowinfo[(size_t)it * 64 + lane];
-                float v = lse_item(gb.slots, im, lane, yp);
-                if (ri.row >= 0 && (lane & ((1 << im.log2g) - 1)) == 0) {
-                    const float beta = v - M;  // T (B[:,n+1] (*) lhs[:,n+1])   (src/inference.jl:106-107)
-                    const float q = fast_exp2(ast[ri.row] + beta - kappa);  // state_A .* state_B / Z
-                    if (q > 0.f) atomicAdd(&bn[ri.pdf], q);
-                    const float y = beta + emn[ri.pdf];
-                    yn[ri.row] = y;
-                    wm = fmaxf(wm, y);
-                }
-            }
+            for_items<NI>(rg, gb, wave, NW, lane, yp, [&](float v, int row, int pdf) {
+                const float beta = v - M;  // T (B[:,n+1] (*) lhs[:,n+1])   (src/inference.jl:106-107)
+                const float q = fast_exp2(ast[row] + beta - kappa);  // state_A .* state_B / Z
+                if (q > 0.f) atomicAdd(&bn[pdf], q);
+                const float y = beta + emn[pdf];
+                yn[row] = y;
+                wm = fmaxf(wm, y);
+            });
             wm = wave_max(wm);
             if (lane == 0) part[(n & 1) * MM_MAX_WAVES + wave] = wm;
             __syncthreads();
@@ -406,6 +537,7 @@ __global__ void __launch_bounds__(1024) mm_log_kernel(RunParams p) {
             if (NF - 1 >= 1) stage_em(em + ((NF - 1) & 1) * P1p, Vb, p.vsn, NF - 1, len, P, tid, NT, MM_LOG2E);
         }
         __syncthreads();
+        load_item_regs<NI>(rg, gb, wave, NW, lane);
         double D = 0.0;
         for (int n = NF - 1; n >= 1; --n) {
             const float *yp = buf + ((n + 1) & 1) * S1p;
@@ -417,18 +549,13 @@ __global__ void __launch_bounds__(1024) mm_log_kernel(RunParams p) {
             if (n - 1 >= 1) stage_em(em + ((n - 1) & 1) * P1p, Vb, p.vsn, n - 1, len, P, tid, NT, MM_LOG2E);
             float *dst = p.out + (long long)(n - 1) * p.out_stride_n + u.state_off;
             float wm = MM_NINF;
-            for (int it = wave; it < gb.n_items; it += NW) {
-                const ItemMeta im = load_item(gb.items, it);
-                const RowInfo ri = gb.rowinfo[(size_t)it * 64 + lane];
-                float v = lse_item(gb.slots, im, lane, yp);
-                if (ri.row >= 0 && (lane & ((1 << im.log2g) - 1)) == 0) {
-                    const float beta = v - M;
-                    dst[ri.row] = (beta + d) * MM_LN2;
-                    const float y = beta + emn[ri.pdf];
-                    yn[ri.row] = y;
-                    wm = fmaxf(wm, y);
-                }
-            }
+            for_items<NI>(rg, gb, wave, NW, lane, yp, [&](float v, int row, int pdf) {
+                const float beta = v - M;
+                dst[row] = (beta + d) * MM_LN2;
+                const float y = beta + emn[pdf];
+                yn[row] = y;
+                wm = fmaxf(wm, y);
+            });
             wm = wave_max(wm);
             if (lane == 0) part[(n & 1) * MM_MAX_WAVES + wave] = wm;
             __syncthreads();

@@ -57,8 +57,12 @@ Packed pack_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::v
             tmp.push_back(std::move(t));
         }
     }
-    std::stable_sort(tmp.begin(), tmp.end(),
-                     [](const Tmp &a, const Tmp &b) { return item_cost(a.log2g, a.R) > item_cost(b.log2g, b.R); });
+    // register-eligible items (R <= 4) first, by decreasing cost; long rows last
+    std::stable_sort(tmp.begin(), tmp.end(), [](const Tmp &a, const Tmp &b) {
+        const bool la = a.R > 4, lb = b.R > 4;
+        if (la != lb) return lb;
+        return item_cost(a.log2g, a.R) > item_cost(b.log2g, b.R);
+    });
     int64_t slot_row = 0;
     for (auto &t : tmp) {
         ItemMeta m;

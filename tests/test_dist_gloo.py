@@ -1,0 +1,95 @@
+"""The N > 1 path on CPU: world_size 2 over gloo.  Utterances shard across ranks
+with no data-path collective; the one exchange is the total log-likelihood
+all-reduce / ttl all-gather (markovmodels.jl_amd/dist.py).  The per-rank
+"engine" here is the oracle (this is a test of the sharding + collectives, not
+of the kernels)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    import __graft_entry__ as ge
+    import graphs
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mm = ge.load_package()
+    wl = importlib.import_module(mm.__name__ + ".workloads")
+    o, oc = ge.load_oracle()
+    g = wl.random_fsm(15, 4, 2.5, seed=3)
+    B, N = 7, 12
+    rng = np.random.default_rng(0)
+    V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+    lens = rng.integers(3, N + 1, B).astype(np.int32)
+    lo, hi = mm.dist.shard_range(B, rank, world)
+    _, ttl = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V[lo:hi], lens[lo:hi], dtype=np.float64)
+    ttl_local = torch.from_numpy(ttl).float()
+    total = mm.dist.allreduce_logz(ttl_local)
+    sizes = [mm.dist.shard_range(B, r, world)[1] - mm.dist.shard_range(B, r, world)[0] for r in range(world)]
+    allttl = mm.dist.allgather_ttl(ttl_local, sizes)
+    q.put((rank, float(total), allttl.numpy().tolist()))
+    dist.destroy_process_group()
+
+
+def test_shard_helpers():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+
+    mm = ge.load_package()
+    for B, W in ((7, 2), (256, 8), (5, 8), (2048, 8)):
+        rs = [mm.dist.shard_range(B, r, W) for r in range(W)]
+        assert rs[0][0] == 0 and rs[-1][1] == B
+        assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+        assert max(h - l for l, h in rs) - min(h - l for l, h in rs) <= 1
+    parts = mm.dist.shard_by_length([10, 1, 9, 2, 8, 3], 2)
+    assert sorted(sum(parts, [])) == list(range(6))
+    loads = [sum([10, 1, 9, 2, 8, 3][i] for i in p) for p in parts]
+    assert abs(loads[0] - loads[1]) <= 1
+
+
+def test_two_rank_logz_allreduce():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    import __graft_entry__ as ge
+    import graphs
+
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    # single-process reference
+    mm = ge.load_package()
+    wl = importlib.import_module(mm.__name__ + ".workloads")
+    o, oc = ge.load_oracle()
+    g = wl.random_fsm(15, 4, 2.5, seed=3)
+    rng = np.random.default_rng(0)
+    V = rng.standard_normal((7, 12, g.P)).astype(np.float32)
+    lens = rng.integers(3, 13, 7).astype(np.int32)
+    _, ttl = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V, lens, dtype=np.float64)
+    for rank, total, allttl in res:
+        assert np.isclose(total, ttl.sum(), rtol=1e-6)
+        assert np.allclose(allttl, ttl, rtol=1e-6)

@@ -214,3 +214,25 @@ def test_errors(mm, wl, torch):
         bf.pdfposteriors(np.zeros((2, 5, g.P + 1), dtype=np.float32))
     with pytest.raises(mm.MarkovModelsAMDError):
         bf.viterbi(np.zeros((2, 5, g.P), dtype=np.float32))  # log-semiring batch
+
+
+@pytest.mark.parametrize("name", ["den_fsm_wsj", "num_fsm_wsj"])
+def test_wsj_graphs_against_committed_golden(mm, wl, torch, name):
+    """The reference's own benchmark graphs (misc/benchmark/*_fsm_wsj.txt, converted by
+    tests/golden/make_wsj_graphs.py) against the committed float64 oracle outputs."""
+    import os
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = wl.load_npz_graph(os.path.join(here, "golden", name + ".npz"))
+    z = np.load(os.path.join(here, "golden", name + "_oracle.npz"))
+    V, lens = z["V"], z["lens"]
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    gam, ttl = mm.batch(*([cf] * V.shape[0])).pdfposteriors(V, lens)
+    ok = np.isfinite(z["ttl"])
+    check_gamma(gam[ok], z["gamma"][ok].astype(np.float64), lens[ok])
+    assert np.allclose(ttl[ok], z["ttl"][ok], rtol=1e-5, atol=2e-4)  # log Z is a sum over ~N frames of O(1..10) terms
+    # utterances without an accepting path: the reference gives NaN (0/0), the engine gamma = 0, ttl = -inf
+    assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()
+    ct = mm.compile(wl.to_fsm(mm, g, semiring="tropical"), mm.statemap(g.state2pdf, g.P))
+    path, score = mm.batch(ct).viterbi(V[:1], lens[:1])
+    assert np.array_equal(path[0], z["path"]) and score[0] == z["score"]

@@ -1,0 +1,166 @@
+"""Host-side logic of the product that needs no GPU: FSM construction, rawunion,
+expand, state maps, the CSR -> packed-item compile step (checked through the
+host evaluator mm_debug_packed_product), the C ABI's argument validation."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import graphs
+
+
+def test_fsm_constructor_matches_oracle(mm, wl, oracle):
+    o, _ = oracle
+    g = wl.random_fsm(23, 5, 3.0, seed=11)
+    f = wl.to_fsm(mm, g)
+    of = graphs.to_oracle(o, g, dtype=np.float32)
+    assert np.array_equal(f.colptr, of.T_hat.colptr) and np.array_equal(f.rowval, of.T_hat.rowval)
+    assert np.allclose(f.nzval, of.T_hat.nzval)
+    assert np.array_equal(f.alpha_hat_dense(), of.alpha_hat)
+    assert mm.nstates(f) == g.S
+    # the arc-list constructor gives the same FSM, duplicates combined with (+)
+    f2 = mm.FSM(list(zip(g.init_idx.tolist(), g.init_w.tolist())),
+                [((int(i), int(j)), float(w)) for i, j, w in zip(g.src, g.dst, g.w)],
+                list(zip(g.final_idx.tolist(), g.final_w.tolist())), list(range(g.S)))
+    assert np.array_equal(f2.colptr, f.colptr) and np.allclose(f2.nzval, f.nzval)
+    dup = mm.FSM([(0, 0.0)], [((0, 1), np.log(0.25)), ((0, 1), np.log(0.25))], [(1, 0.0)], ["a", "b"])
+    assert np.isclose(dup.T_hat_dense()[0, 1], np.log(0.5))
+    # extended system: last row = [zero ... zero one]
+    Td = f.T_hat_dense()
+    assert Td[-1, -1] == 0 and np.isneginf(Td[-1, :-1]).all()
+
+
+def test_json_and_openfst_readers(mm):
+    s = json.dumps({"semiring": "LogSemiring{Float32}", "initstates": [[1, 0.0]],
+                    "arcs": [[1, 1, -0.5], [1, 2, -1.0], [2, 2, -0.25]], "finalstates": [[2, -0.125]],
+                    "labels": ["a", "b"]})
+    f = mm.FSM.from_json(s)
+    Td = f.T_hat_dense()
+    assert f.semiring == "log" and f.S1 == 3
+    assert np.isclose(Td[0, 1], -1.0) and np.isclose(Td[1, 2], -0.125) and Td[2, 2] == 0
+    txt = "0 1 3 3 0.5\n1 1 3 3 0.25\n1 2 7 7 1.5\n2 2 7 7 0.1\n2 0.75\n"
+    f, s2p, P = mm.FSM.from_openfst_text(txt)
+    assert f.S1 == 3 and P == 7 and s2p.tolist() == [2, 6]
+    assert np.isclose(f.T_hat_dense()[0, 1], -1.5) and np.isclose(f.alpha_hat_dense()[0], -0.5)
+
+
+def test_rawunion_and_split(mm, wl):
+    gs = [wl.random_fsm(S, 4, 2.0, seed=S) for S in (5, 9, 3)]
+    fs = [wl.to_fsm(mm, g) for g in gs]
+    u = mm.rawunion(*fs)
+    assert u.S1 == sum(f.S1 for f in fs)
+    D = u.T_hat_dense()
+    o = 0
+    for f in fs:
+        assert np.array_equal(D[o:o + f.S1, o:o + f.S1], f.T_hat_dense())
+        o += f.S1
+    assert np.isneginf(D[: fs[0].S1, fs[0].S1:]).all()
+    # split a union that carries no provenance
+    u._parts = None
+    from importlib import import_module
+    fsm_mod = import_module(mm.__name__ + ".fsm")
+    parts = fsm_mod.split_blocks(u, [f.S1 for f in fs])
+    for p, f in zip(parts, fs):
+        assert np.array_equal(p.T_hat_dense(), f.T_hat_dense())
+        assert np.array_equal(p.alpha_hat_dense(), f.alpha_hat_dense())
+    with pytest.raises(mm.DimensionMismatch):
+        fsm_mod.split_blocks(u, [3, 4])
+
+
+def test_expand_semantics(mm, oracle):
+    """expand (src/inference.jl:54-60) against the oracle restatement."""
+    o, _ = oracle
+    lhs = np.arange(12, dtype=np.float32).reshape(3, 4)
+    for L in (None, 4, 2, 0):
+        assert np.array_equal(mm.expand(lhs, L), o.expand(lhs, L, o.LOG))
+    e = mm.expand(lhs, 2)
+    assert e.shape == (4, 5) and np.isneginf(e[:3, 2:]).all() and (e[3, 2:] == 0).all() and np.isneginf(e[3, :2]).all()
+
+
+def test_statemap(mm):
+    C1 = mm.statemap([2, 0, 1], 3)
+    assert C1.shape == (4, 4) and C1.state2pdf.tolist() == [2, 0, 1, 3]
+    M = np.full((4, 4), -np.inf)
+    M[[0, 1, 2, 3], [2, 0, 1, 3]] = 0
+    assert mm.StateMap.from_matrix(M).state2pdf.tolist() == [2, 0, 1, 3]
+    with pytest.raises(ValueError):
+        M[0, 0] = 0
+        mm.StateMap.from_matrix(M)
+
+
+@pytest.mark.parametrize("gname", ["l2r", "rand", "ergodic", "lfmmi", "lexicon", "wide", "wsj_num"])
+def test_packed_form_products(mm, wl, gname):
+    """The compile step (CSR -> wave items) preserves both semiring products:
+    host evaluation THROUGH the packed form == dense reference, log and tropical."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = {"l2r": lambda: wl.l2r_hmm(3), "rand": lambda: wl.random_fsm(40, 6, 3.0, seed=1),
+         "ergodic": lambda: wl.dense_ergodic(64), "lfmmi": lambda: wl.lfmmi_denominator(2000, 84),
+         "lexicon": lambda: wl.lexicon_fsm(1500, 30), "wide": lambda: wl.wide_row_fsm(),
+         "wsj_num": lambda: wl.load_npz_graph(os.path.join(here, "golden", "num_fsm_wsj.npz"))}[gname]()
+    rng = np.random.default_rng(0)
+    for semiring in ("log", "tropical"):
+        f = wl.to_fsm(mm, g, semiring=semiring)
+        cf = mm.compile(f, mm.statemap(g.state2pdf, g.P))
+        info = cf.info()
+        assert info["S1"] == g.S + 1 and info["nnz"] == g.n_arcs
+        assert min(info["packed_slots"]) >= g.n_arcs
+        x = rng.standard_normal(f.S1).astype(np.float32)
+        x[rng.random(f.S1) < 0.2] = -np.inf
+        Td = f.T_hat_dense().astype(np.float64)
+        for d in (0, 1):
+            out, arg = cf.packed_product(x, d)
+            M = Td.T if d == 0 else Td
+            Z = M + x[None, :].astype(np.float64)
+            if semiring == "log":
+                mx = Z.max(1)
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    ref = np.where(np.isfinite(mx), mx + np.log(np.exp(Z - np.where(np.isfinite(mx), mx, 0)[:, None]).sum(1)), -np.inf)
+                assert np.array_equal(np.isfinite(out), np.isfinite(ref))
+                m = np.isfinite(ref)
+                assert np.allclose(out[m], ref[m], rtol=1e-5, atol=1e-5)
+            else:
+                Zf = (M.astype(np.float32) + x[None, :])
+                ref = Zf.max(1)
+                assert np.array_equal(out, ref)
+                ra = np.where(np.isfinite(ref), Zf.argmax(1), -1)  # argmax = first (lowest) index among maxima
+                assert np.array_equal(arg, ra)
+
+
+def test_create_validation(mm):
+    lib = mm._lib.lib if hasattr(mm, "_lib") else None
+    from importlib import import_module
+    L = import_module(mm.__name__ + "._lib")
+    lib = L.lib
+    h = C.c_void_p()
+    colptr = np.array([0, 1, 2], dtype=np.int64)
+    rowval = np.array([0, 1], dtype=np.int64)
+    nz = np.zeros(2, dtype=np.float32)
+    s2p = np.array([0, 1], dtype=np.int32)
+    ai = np.array([0], dtype=np.int64)
+    av = np.zeros(1, dtype=np.float32)
+
+    def create(**kw):
+        a = dict(semiring=0, S1=2, nnz=2, layout=0, ib=8, base=0, vb=4, colptr=colptr, rowval=rowval, s2p=s2p, P1=2)
+        a.update(kw)
+        return lib.mm_fsm_create(a["semiring"], a["S1"], a["nnz"], a["layout"], a["ib"], a["base"], a["vb"],
+                                 a["colptr"].ctypes.data, a["rowval"].ctypes.data, nz.ctypes.data, 1, ai.ctypes.data,
+                                 av.ctypes.data, a["s2p"].ctypes.data, a["P1"], C.byref(h))
+
+    assert create() == 0
+    assert lib.mm_fsm_destroy(h) == 0
+    assert create(semiring=7) == -1 and b"semiring" in lib.mm_last_error()
+    assert create(rowval=np.array([0, 5], dtype=np.int64)) == -2  # DimensionMismatch-class error
+    assert create(s2p=np.array([1, 0], dtype=np.int32)) == -2  # final state must map to the phony pdf
+    assert create(ib=2) == -1
+    assert create(colptr=np.array([0, 2, 1], dtype=np.int64)) == -2
+    # 1-based Int32 CSR input (the reference's GPU containers) gives the same packed sizes as 0-based Int64 CSC
+    g_rowptr = np.array([1, 2, 3], dtype=np.int32)
+    g_col = np.array([1, 2], dtype=np.int32)
+    ai32 = np.array([1], dtype=np.int32)
+    s2p1 = np.array([1, 2], dtype=np.int32)
+    rc = lib.mm_fsm_create(0, 2, 2, 1, 4, 1, 4, g_rowptr.ctypes.data, g_col.ctypes.data, nz.ctypes.data, 1,
+                           ai32.ctypes.data, av.ctypes.data, s2p1.ctypes.data, 2, C.byref(h))
+    assert rc == 0, lib.mm_last_error()
+    lib.mm_fsm_destroy(h)

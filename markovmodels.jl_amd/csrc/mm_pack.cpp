@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <map>
 #include <utility>
@@ -97,6 +98,35 @@ Packed pack_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::v
     }
     out.n_slot_rows = slot_row;
     return out;
+}
+
+QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &col,
+                     const std::vector<float> &val) {
+    QuadGraph g;
+    g.rowptr.resize(nrows + 1);
+    g.col.assign(col.begin(), col.end());
+    g.w.assign(val.begin(), val.end());
+    bool ok = nrows * 4 <= 65535;
+    for (int64_t r = 0; r <= nrows; ++r) g.rowptr[r] = int32_t(rowptr[r]);
+    for (int64_t r = 0; r < nrows; ++r) {
+        for (int64_t b = rowptr[r]; b < rowptr[r + 1]; b += 4) {
+            Quad q;
+            std::memset(&q, 0, sizeof(q));
+            q.rowoff = uint16_t(4 * r);
+            for (int k = 0; k < 4; ++k) {
+                int64_t a = b + k;
+                if (a < rowptr[r + 1]) {
+                    // the linear path needs 2^w and its products with values in [2^-126, 2^127] to stay normal
+                    if (!(val[a] > -100.f && val[a] < 20.f)) ok = false;
+                    q.wl[k] = std::exp2(val[a]);
+                    q.off[k] = uint16_t(4 * col[a]);
+                }
+            }
+            g.quads.push_back(q);
+        }
+    }
+    g.fast_ok = ok;
+    return g;
 }
 
 void eval_packed(const Packed &p, int semiring, const float *in, float *out, int32_t *argmax, int64_t nrows) {

@@ -51,6 +51,34 @@ struct Packed {
 Packed pack_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &col,
                  const std::vector<float> &val, const std::vector<int32_t> &row2pdf, float zero_w);
 
+// ---------------------------------------------------------------------------
+// "Quad" form for the fast forward-backward kernel (mm_kernel_quad.hip): every
+// row is cut into quads of 4 arcs (the last one padded with weight 0); quad q
+// belongs to lane q / KQ of the workgroup, which keeps its KQ quads in registers
+// for the whole time loop.  Weights are LINEAR (2^w), columns are LDS byte
+// offsets (4 * col).  Quads are stored in row order.
+// ---------------------------------------------------------------------------
+struct Quad {
+    float wl[4];       // 2^(log2 weight); 0 = padding
+    uint16_t off[4];   // 4 * source column (byte offset into the LDS vector)
+    uint16_t rowoff;   // 4 * row
+    uint16_t pad;
+    uint32_t pad2;
+};
+static_assert(sizeof(Quad) == 32, "Quad must be 32 bytes");
+
+struct QuadGraph {
+    std::vector<Quad> quads;
+    // row-ordered CSR with log2-domain weights: the exact fallback walks these
+    std::vector<int32_t> rowptr;
+    std::vector<int32_t> col;
+    std::vector<float> w;
+    bool fast_ok = false;  // all weights inside the range the linear path is valid for
+};
+
+QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &col,
+                     const std::vector<float> &val_log2);
+
 // Host evaluation of one product through the packed form, lane by lane, with the
 // same group structure as the kernels (test aid).  semiring 0 = log, 1 = tropical.
 void eval_packed(const Packed &p, int semiring, const float *in, float *out, int32_t *argmax, int64_t nrows);

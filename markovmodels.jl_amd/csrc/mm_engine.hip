@@ -13,6 +13,7 @@
 
 #include "../../include/markovmodels_amd.h"
 #include "mm_kernels.hip"
+#include "mm_kernel_quad.hip"
 #include "mm_pack.h"
 
 using namespace mm;
@@ -91,6 +92,9 @@ struct mm_fsm_s {
     int32_t P1;
     int S1p;
     Packed packed[2];
+    QuadGraph quad[2];
+    bool fast_ok = false;
+    QuadDev qdev[2];
     std::vector<float> init;  // dense alpha_hat, engine domain
     std::vector<int32_t> s2p;
     int device = -1;
@@ -107,7 +111,8 @@ struct mm_batch_s {
     int64_t B;
     int64_t total_states = 0;
     int64_t total_s1p = 0;
-    int max_S1p = 0, max_P1 = 0, max_items = 0;
+    int max_S1p = 0, max_P1 = 0, max_items = 0, max_quads = 0;
+    bool fast_ok = true;
     int device = -1;
     UttDesc *d_utts = nullptr;
     void *ws = nullptr;
@@ -165,6 +170,58 @@ static int launch_log(mm_batch_t h, const RunParams &p, void *stream) {
         case 0: return launch(mm_log_kernel<MODE, 0>, h, p, st, g.NW, stream);
         case 8: return launch(mm_log_kernel<MODE, 8>, h, p, st, g.NW, stream);
         default: return launch(mm_log_kernel<MODE, 24>, h, p, st, g.NW, stream);
+    }
+}
+
+// The quad kernel (mm_kernel_quad.hip): KQ register-resident quads per lane, NW waves.
+template <int KQ>
+static int launch_quad_kq(mm_batch_t h, const RunParams &p, int NW, void *stream) {
+    const int P1p = (h->max_P1 + 3) & ~3;
+    const size_t lds = size_t(lds_plan_q(h->max_S1p, P1p, std::max(h->max_quads, 64 * NW * KQ)).total) * 4;
+    if (lds > 160 * 1024) return fail(MM_ERR_UNSUPPORTED, "quad kernel: LDS plan does not fit");
+    auto kernel = mm_fbq_kernel<KQ>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                int(lds)));
+    hipLaunchKernelGGL(kernel, dim3(unsigned(h->B)), dim3(64 * NW), lds, static_cast<hipStream_t>(stream), p);
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+}
+
+static bool quad_kernel_usable(mm_batch_t h) {
+    if (const char *e = getenv("MM_KERNEL"))
+        if (!strcmp(e, "item")) return false;
+    if (!h->fast_ok || h->semiring != MM_LOG) return false;
+    const int P1p = (h->max_P1 + 3) & ~3;
+    return size_t(lds_plan_q(h->max_S1p, P1p, std::max(h->max_quads, 64 * MM_MAX_WAVES)).total) * 4 <= 150 * 1024;
+}
+
+static int launch_quad(mm_batch_t h, const RunParams &p, void *stream) {
+    static const int kqs[] = {1, 2, 3, 5, 7, 9, 11, 13};
+    int KQ = 13;
+    for (int k : kqs)
+        if (64 * MM_MAX_WAVES * k >= h->max_quads) {
+            KQ = k;
+            break;
+        }
+    if (const char *e = getenv("MM_KQ")) {
+        int v = atoi(e);
+        for (int k : kqs)
+            if (k == v) KQ = v;
+    }
+    int NW = std::min(MM_MAX_WAVES, std::max(1, (h->max_quads + 64 * KQ - 1) / (64 * KQ)));
+    if (const char *e = getenv("MM_NWAVES")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= MM_MAX_WAVES) NW = v;
+    }
+    switch (KQ) {
+        case 1: return launch_quad_kq<1>(h, p, NW, stream);
+        case 2: return launch_quad_kq<2>(h, p, NW, stream);
+        case 3: return launch_quad_kq<3>(h, p, NW, stream);
+        case 5: return launch_quad_kq<5>(h, p, NW, stream);
+        case 7: return launch_quad_kq<7>(h, p, NW, stream);
+        case 9: return launch_quad_kq<9>(h, p, NW, stream);
+        case 11: return launch_quad_kq<11>(h, p, NW, stream);
+        default: return launch_quad_kq<13>(h, p, NW, stream);
     }
 }
 
@@ -247,6 +304,11 @@ int mm_fsm_create(int semiring, int64_t S1, int64_t nnz, int layout, int index_b
     }
     f->packed[0] = pack_rows(S1, fwd.rowptr, fwd.col, fwd.val, f->s2p, NINF);
     f->packed[1] = pack_rows(S1, bwd.rowptr, bwd.col, bwd.val, f->s2p, NINF);
+    if (semiring == MM_LOG) {
+        f->quad[0] = make_quads(S1, fwd.rowptr, fwd.col, fwd.val);
+        f->quad[1] = make_quads(S1, bwd.rowptr, bwd.col, bwd.val);
+        f->fast_ok = f->quad[0].fast_ok && f->quad[1].fast_ok && P1 <= 65535;
+    }
     *out = f;
     return MM_OK;
 }
@@ -256,7 +318,21 @@ static int fsm_to_device(mm_fsm_t f) {
     HIP_TRY(hipGetDevice(&dev));
     if (f->dev_blob && f->device == dev) return MM_OK;
     if (f->dev_blob) return fail(MM_ERR_INVALID, "FSM already resident on another device");
-    size_t off = 0, o_items[2], o_rows[2], o_slots[2], o_init, o_s2p;
+    size_t off = 0, o_items[2], o_rows[2], o_slots[2], o_init, o_s2p, o_quads[2], o_qptr[2], o_qcol[2], o_qw[2], o_qst[2], o_qord[2];
+    for (int d = 0; d < 2; ++d) {
+        o_quads[d] = off;
+        off = align_up(off + f->quad[d].quads.size() * sizeof(Quad), 256);
+        o_qptr[d] = off;
+        off = align_up(off + f->quad[d].rowptr.size() * sizeof(int32_t), 256);
+        o_qcol[d] = off;
+        off = align_up(off + f->quad[d].col.size() * sizeof(int32_t), 256);
+        o_qw[d] = off;
+        off = align_up(off + f->quad[d].w.size() * sizeof(float), 256);
+        o_qst[d] = off;
+        off = align_up(off + f->quad[d].qstart.size() * sizeof(uint16_t), 256);
+        o_qord[d] = off;
+        off = align_up(off + f->quad[d].rord.size() * sizeof(uint16_t), 256);
+    }
     for (int d = 0; d < 2; ++d) {
         o_items[d] = off;
         off = align_up(off + f->packed[d].items.size() * sizeof(ItemMeta), 256);
@@ -275,6 +351,14 @@ static int fsm_to_device(mm_fsm_t f) {
         memcpy(host.data() + o_rows[d], f->packed[d].rowinfo.data(), f->packed[d].rowinfo.size() * sizeof(RowInfo));
         memcpy(host.data() + o_slots[d], f->packed[d].slots.data(), f->packed[d].slots.size() * sizeof(Slot));
     }
+    for (int d = 0; d < 2; ++d) {
+        memcpy(host.data() + o_quads[d], f->quad[d].quads.data(), f->quad[d].quads.size() * sizeof(Quad));
+        memcpy(host.data() + o_qptr[d], f->quad[d].rowptr.data(), f->quad[d].rowptr.size() * sizeof(int32_t));
+        memcpy(host.data() + o_qcol[d], f->quad[d].col.data(), f->quad[d].col.size() * sizeof(int32_t));
+        memcpy(host.data() + o_qw[d], f->quad[d].w.data(), f->quad[d].w.size() * sizeof(float));
+        memcpy(host.data() + o_qst[d], f->quad[d].qstart.data(), f->quad[d].qstart.size() * sizeof(uint16_t));
+        memcpy(host.data() + o_qord[d], f->quad[d].rord.data(), f->quad[d].rord.size() * sizeof(uint16_t));
+    }
     memcpy(host.data() + o_init, f->init.data(), f->init.size() * sizeof(float));
     memcpy(host.data() + o_s2p, f->s2p.data(), f->s2p.size() * sizeof(int32_t));
     void *blob = nullptr;
@@ -291,6 +375,14 @@ static int fsm_to_device(mm_fsm_t f) {
         f->gdev[d].slots = reinterpret_cast<const Slot *>(base + o_slots[d]);
         f->gdev[d].n_items = int(f->packed[d].items.size());
         f->gdev[d].pad = 0;
+        f->qdev[d].quads = reinterpret_cast<const Quad *>(base + o_quads[d]);
+        f->qdev[d].rowptr = reinterpret_cast<const int *>(base + o_qptr[d]);
+        f->qdev[d].col = reinterpret_cast<const int *>(base + o_qcol[d]);
+        f->qdev[d].w = reinterpret_cast<const float *>(base + o_qw[d]);
+        f->qdev[d].qstart = reinterpret_cast<const unsigned short *>(base + o_qst[d]);
+        f->qdev[d].rord = reinterpret_cast<const unsigned short *>(base + o_qord[d]);
+        f->qdev[d].nq = int(f->quad[d].quads.size());
+        f->qdev[d].pad = 0;
     }
     f->d_init = reinterpret_cast<const float *>(base + o_init);
     f->d_s2p = reinterpret_cast<const int *>(base + o_s2p);
@@ -354,6 +446,10 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         UttDesc &u = utts[b];
         u.g[0] = f->gdev[0];
         u.g[1] = f->gdev[1];
+        u.q[0] = f->qdev[0];
+        u.q[1] = f->qdev[1];
+        h->fast_ok = h->fast_ok && f->fast_ok;
+        h->max_quads = std::max(h->max_quads, std::max(f->qdev[0].nq, f->qdev[1].nq));
         u.init = f->d_init;
         u.s2p = f->d_s2p;
         u.S1 = int(f->S1);
@@ -442,6 +538,10 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     p.gsn = gsn;
     p.gsp = gsp;
     p.ttl = ttl;
+    if (quad_kernel_usable(h)) {
+        rc = launch_quad(h, p, stream);
+        if (rc != MM_ERR_UNSUPPORTED) return rc;
+    }
     return launch_log<MODE_FB>(h, p, stream);
 }
 

@@ -44,8 +44,20 @@ struct GraphDev {
     int pad;
 };
 
+struct QuadDev {  // quad form + row-ordered CSR (mm_pack.h QuadGraph), one direction
+    const Quad *quads;
+    const int *rowptr;
+    const int *col;
+    const float *w;
+    const unsigned short *qstart;
+    const unsigned short *rord;
+    int nq;
+    int pad;
+};
+
 struct UttDesc {
     GraphDev g[2];  // 0: T_hat' packed (forward), 1: T_hat packed (backward)
+    QuadDev q[2];   // same two matrices in quad form (log semiring only)
     const float *init;  // dense alpha_hat [S1] (log2 domain for MM_LOG, natural for MM_TROPICAL)
     const int *s2p;     // state -> pdf [S1]
     int S1, S1p, P1, pad;

@@ -125,6 +125,21 @@ QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const st
             g.quads.push_back(q);
         }
     }
+    if (g.quads.size() > 65535) ok = false;
+    g.qstart.assign(nrows + 1, 0);
+    std::vector<int32_t> order(nrows);
+    int64_t acc = 0;
+    for (int64_t r = 0; r < nrows; ++r) {
+        g.qstart[r] = uint16_t(acc);
+        acc += (rowptr[r + 1] - rowptr[r] + 3) / 4;
+        order[r] = int32_t(r);
+    }
+    g.qstart[nrows] = uint16_t(acc);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        return (rowptr[a + 1] - rowptr[a] + 3) / 4 > (rowptr[b + 1] - rowptr[b] + 3) / 4;
+    });
+    g.rord.resize(nrows);
+    for (int64_t r = 0; r < nrows; ++r) g.rord[r] = uint16_t(order[r]);
     g.fast_ok = ok;
     return g;
 }

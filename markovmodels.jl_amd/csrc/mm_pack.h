@@ -73,6 +73,8 @@ struct QuadGraph {
     std::vector<int32_t> rowptr;
     std::vector<int32_t> col;
     std::vector<float> w;
+    std::vector<uint16_t> qstart;  // [nrows + 1] first quad of every row
+    std::vector<uint16_t> rord;    // [nrows] rows by decreasing number of quads (balanced row-finishing loops)
     bool fast_ok = false;  // all weights inside the range the linear path is valid for
 };
 

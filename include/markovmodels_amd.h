@@ -143,6 +143,13 @@ int mm_viterbi_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t
  * argmax (may be NULL): for MM_TROPICAL the back-pointer per row. */
 int mm_debug_packed_product(mm_fsm_t fsm, int direction, const float *in, float *out, int32_t *argmax);
 
+/* Test aid (host only, no GPU): the same product evaluated THROUGH THE QUAD FORM of the fast
+ * pdfposteriors kernel (internal renumbering, quads of 4 arcs laid out for KQ quads per lane, per-lane
+ * running sums, row totals from the lane partials), in the linear domain relative to max(in) like the
+ * kernel does.  MM_LOG FSMs only.  stats (may be NULL) receives {quads, lanes, modelled LDS cycles per
+ * gather instruction with arcs in CSR order, the same after the bank-aware placement}. */
+int mm_debug_quad_product(mm_fsm_t fsm, int direction, int KQ, const float *in, float *out, double stats[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmarkovmodels_amd.so")
+LIB_PATH = os.environ.get("MM_AMD_LIB", os.path.join(_HERE, "libmarkovmodels_amd.so"))  # override: diagnostic builds
 
 MM_OK = 0
 MM_LOG, MM_TROPICAL = 0, 1
@@ -33,6 +33,7 @@ SYMBOLS = [
     "mm_betarecursion_f32",
     "mm_viterbi_f32",
     "mm_debug_packed_product",
+    "mm_debug_quad_product",
 ]
 
 
@@ -87,6 +88,8 @@ def _load():
     lib.mm_viterbi_f32.argtypes = [vp, fp, i64, i64, vp, i64, vp, i64, fp, vp, i64, vp]
     lib.mm_debug_packed_product.restype = C.c_int
     lib.mm_debug_packed_product.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.mm_debug_quad_product.restype = C.c_int
+    lib.mm_debug_quad_product.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     return lib
 
 

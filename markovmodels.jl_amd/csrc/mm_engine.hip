@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -86,15 +87,33 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace
 
+#ifdef MM_STAMPS
+static unsigned long long *g_dbg = nullptr;
+static size_t g_dbg_n = 0;
+#endif
+
+// The quad form of one FSM laid out for KQ quads per lane (mm_pack.h), resident on the device.
+struct QuadVariant {
+    int KQ = 0;
+    QuadGraph g[2];
+    std::vector<float> init_f;
+    std::vector<uint16_t> map_bf;
+    void *blob = nullptr;
+    QuadDev qdev[2];
+    const float *d_init_f = nullptr;
+    const unsigned short *d_map_bf = nullptr;
+};
+
 struct mm_fsm_s {
     int semiring;
     int64_t S1, nnz;
     int32_t P1;
     int S1p;
+    Csr mat[2];  // 0: T_hat' (forward), 1: T_hat (backward); engine-domain weights
     Packed packed[2];
-    QuadGraph quad[2];
-    bool fast_ok = false;
-    QuadDev qdev[2];
+    bool fast_ok = false;  // the quad kernel's linear path is valid for this FSM
+    int64_t nquads[2] = {0, 0};
+    std::map<int, QuadVariant *> variants;  // by KQ
     std::vector<float> init;  // dense alpha_hat, engine domain
     std::vector<int32_t> s2p;
     int device = -1;
@@ -113,6 +132,7 @@ struct mm_batch_s {
     int64_t total_s1p = 0;
     int max_S1p = 0, max_P1 = 0, max_items = 0, max_quads = 0;
     bool fast_ok = true;
+    int geo_kq = 0, geo_nw = 1;
     int device = -1;
     UttDesc *d_utts = nullptr;
     void *ws = nullptr;
@@ -174,11 +194,15 @@ static int launch_log(mm_batch_t h, const RunParams &p, void *stream) {
 }
 
 // The quad kernel (mm_kernel_quad.hip): KQ register-resident quads per lane, NW waves.
+static size_t quad_lds_bytes(mm_batch_t h, int KQ, int NW) {
+    const int P1p = (h->max_P1 + 3) & ~3;
+    const int vl = (h->max_quads + KQ - 1) / KQ;
+    return size_t(lds_plan_q(h->max_S1p, P1p, std::max(vl, 64 * NW) * KQ).total) * 4;
+}
+
 template <int KQ>
 static int launch_quad_kq(mm_batch_t h, const RunParams &p, int NW, void *stream) {
-    const int P1p = (h->max_P1 + 3) & ~3;
-    const size_t lds = size_t(lds_plan_q(h->max_S1p, P1p, std::max(h->max_quads, 64 * NW * KQ)).total) * 4;
-    if (lds > 160 * 1024) return fail(MM_ERR_UNSUPPORTED, "quad kernel: LDS plan does not fit");
+    const size_t lds = quad_lds_bytes(h, KQ, NW);
     auto kernel = mm_fbq_kernel<KQ>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 int(lds)));
@@ -190,38 +214,24 @@ static int launch_quad_kq(mm_batch_t h, const RunParams &p, int NW, void *stream
 static bool quad_kernel_usable(mm_batch_t h) {
     if (const char *e = getenv("MM_KERNEL"))
         if (!strcmp(e, "item")) return false;
-    if (!h->fast_ok || h->semiring != MM_LOG) return false;
-    const int P1p = (h->max_P1 + 3) & ~3;
-    return size_t(lds_plan_q(h->max_S1p, P1p, std::max(h->max_quads, 64 * MM_MAX_WAVES)).total) * 4 <= 150 * 1024;
+    if (!h->fast_ok || h->geo_kq < 1) return false;
+    return quad_lds_bytes(h, h->geo_kq, h->geo_nw) <= 160 * 1024;
 }
 
 static int launch_quad(mm_batch_t h, const RunParams &p, void *stream) {
-    static const int kqs[] = {1, 2, 3, 5, 7, 9, 11, 13};
-    int KQ = 13;
-    for (int k : kqs)
-        if (64 * MM_MAX_WAVES * k >= h->max_quads) {
-            KQ = k;
-            break;
-        }
-    if (const char *e = getenv("MM_KQ")) {
-        int v = atoi(e);
-        for (int k : kqs)
-            if (k == v) KQ = v;
-    }
-    int NW = std::min(MM_MAX_WAVES, std::max(1, (h->max_quads + 64 * KQ - 1) / (64 * KQ)));
-    if (const char *e = getenv("MM_NWAVES")) {
-        int v = atoi(e);
-        if (v >= 1 && v <= MM_MAX_WAVES) NW = v;
-    }
-    switch (KQ) {
+    const int NW = h->geo_nw;
+    switch (h->geo_kq) {
         case 1: return launch_quad_kq<1>(h, p, NW, stream);
         case 2: return launch_quad_kq<2>(h, p, NW, stream);
         case 3: return launch_quad_kq<3>(h, p, NW, stream);
         case 5: return launch_quad_kq<5>(h, p, NW, stream);
+        case 6: return launch_quad_kq<6>(h, p, NW, stream);
         case 7: return launch_quad_kq<7>(h, p, NW, stream);
         case 9: return launch_quad_kq<9>(h, p, NW, stream);
+        case 10: return launch_quad_kq<10>(h, p, NW, stream);
         case 11: return launch_quad_kq<11>(h, p, NW, stream);
-        default: return launch_quad_kq<13>(h, p, NW, stream);
+        case 13: return launch_quad_kq<13>(h, p, NW, stream);
+        default: return MM_ERR_UNSUPPORTED;
     }
 }
 
@@ -229,6 +239,20 @@ static int tropical_waves(mm_batch_t h) {
     Geometry g = pick_geometry(h);
     return g.NI == 24 ? 16 : g.NW;
 }
+
+namespace {
+// one device allocation per FSM: sections appended with 256-byte alignment
+struct Blob {
+    std::vector<char> host;
+    template <class T>
+    size_t add(const std::vector<T> &v) {
+        const size_t off = align_up(host.size(), 256);
+        host.resize(off + v.size() * sizeof(T));
+        if (!v.empty()) memcpy(host.data() + off, v.data(), v.size() * sizeof(T));
+        return off;
+    }
+};
+}  // namespace
 
 extern "C" {
 
@@ -304,12 +328,26 @@ int mm_fsm_create(int semiring, int64_t S1, int64_t nnz, int layout, int index_b
     }
     f->packed[0] = pack_rows(S1, fwd.rowptr, fwd.col, fwd.val, f->s2p, NINF);
     f->packed[1] = pack_rows(S1, bwd.rowptr, bwd.col, bwd.val, f->s2p, NINF);
+    f->mat[0] = fwd;
+    f->mat[1] = bwd;
     if (semiring == MM_LOG) {
-        f->quad[0] = make_quads(S1, fwd.rowptr, fwd.col, fwd.val);
-        f->quad[1] = make_quads(S1, bwd.rowptr, bwd.col, bwd.val);
-        f->fast_ok = f->quad[0].fast_ok && f->quad[1].fast_ok && P1 <= 65535;
+        f->nquads[0] = count_quads(S1, fwd.rowptr);
+        f->nquads[1] = count_quads(S1, bwd.rowptr);
+        f->fast_ok = quad_range_ok(S1, fwd.rowptr, fwd.val, P1) && quad_range_ok(S1, bwd.rowptr, bwd.val, P1);
     }
     *out = f;
+    return MM_OK;
+}
+
+static int upload(const Blob &bl, void **out) {
+    void *blob = nullptr;
+    HIP_TRY(hipMalloc(&blob, bl.host.size() ? bl.host.size() : 256));
+    hipError_t e = hipMemcpy(blob, bl.host.data(), bl.host.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(blob);
+        return fail(MM_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+    }
+    *out = blob;
     return MM_OK;
 }
 
@@ -318,56 +356,17 @@ static int fsm_to_device(mm_fsm_t f) {
     HIP_TRY(hipGetDevice(&dev));
     if (f->dev_blob && f->device == dev) return MM_OK;
     if (f->dev_blob) return fail(MM_ERR_INVALID, "FSM already resident on another device");
-    size_t off = 0, o_items[2], o_rows[2], o_slots[2], o_init, o_s2p, o_quads[2], o_qptr[2], o_qcol[2], o_qw[2], o_qst[2], o_qord[2];
+    Blob bl;
+    size_t o_items[2], o_rows[2], o_slots[2];
     for (int d = 0; d < 2; ++d) {
-        o_quads[d] = off;
-        off = align_up(off + f->quad[d].quads.size() * sizeof(Quad), 256);
-        o_qptr[d] = off;
-        off = align_up(off + f->quad[d].rowptr.size() * sizeof(int32_t), 256);
-        o_qcol[d] = off;
-        off = align_up(off + f->quad[d].col.size() * sizeof(int32_t), 256);
-        o_qw[d] = off;
-        off = align_up(off + f->quad[d].w.size() * sizeof(float), 256);
-        o_qst[d] = off;
-        off = align_up(off + f->quad[d].qstart.size() * sizeof(uint16_t), 256);
-        o_qord[d] = off;
-        off = align_up(off + f->quad[d].rord.size() * sizeof(uint16_t), 256);
+        o_items[d] = bl.add(f->packed[d].items);
+        o_rows[d] = bl.add(f->packed[d].rowinfo);
+        o_slots[d] = bl.add(f->packed[d].slots);
     }
-    for (int d = 0; d < 2; ++d) {
-        o_items[d] = off;
-        off = align_up(off + f->packed[d].items.size() * sizeof(ItemMeta), 256);
-        o_rows[d] = off;
-        off = align_up(off + f->packed[d].rowinfo.size() * sizeof(RowInfo), 256);
-        o_slots[d] = off;
-        off = align_up(off + f->packed[d].slots.size() * sizeof(Slot), 256);
-    }
-    o_init = off;
-    off = align_up(off + f->init.size() * sizeof(float), 256);
-    o_s2p = off;
-    off = align_up(off + f->s2p.size() * sizeof(int32_t), 256);
-    std::vector<char> host(off, 0);
-    for (int d = 0; d < 2; ++d) {
-        memcpy(host.data() + o_items[d], f->packed[d].items.data(), f->packed[d].items.size() * sizeof(ItemMeta));
-        memcpy(host.data() + o_rows[d], f->packed[d].rowinfo.data(), f->packed[d].rowinfo.size() * sizeof(RowInfo));
-        memcpy(host.data() + o_slots[d], f->packed[d].slots.data(), f->packed[d].slots.size() * sizeof(Slot));
-    }
-    for (int d = 0; d < 2; ++d) {
-        memcpy(host.data() + o_quads[d], f->quad[d].quads.data(), f->quad[d].quads.size() * sizeof(Quad));
-        memcpy(host.data() + o_qptr[d], f->quad[d].rowptr.data(), f->quad[d].rowptr.size() * sizeof(int32_t));
-        memcpy(host.data() + o_qcol[d], f->quad[d].col.data(), f->quad[d].col.size() * sizeof(int32_t));
-        memcpy(host.data() + o_qw[d], f->quad[d].w.data(), f->quad[d].w.size() * sizeof(float));
-        memcpy(host.data() + o_qst[d], f->quad[d].qstart.data(), f->quad[d].qstart.size() * sizeof(uint16_t));
-        memcpy(host.data() + o_qord[d], f->quad[d].rord.data(), f->quad[d].rord.size() * sizeof(uint16_t));
-    }
-    memcpy(host.data() + o_init, f->init.data(), f->init.size() * sizeof(float));
-    memcpy(host.data() + o_s2p, f->s2p.data(), f->s2p.size() * sizeof(int32_t));
+    const size_t o_init = bl.add(f->init), o_s2p = bl.add(f->s2p);
     void *blob = nullptr;
-    HIP_TRY(hipMalloc(&blob, off));
-    hipError_t e = hipMemcpy(blob, host.data(), off, hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        (void)hipFree(blob);
-        return fail(MM_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
-    }
+    int rc = upload(bl, &blob);
+    if (rc) return rc;
     char *base = static_cast<char *>(blob);
     for (int d = 0; d < 2; ++d) {
         f->gdev[d].items = reinterpret_cast<const ItemMeta *>(base + o_items[d]);
@@ -375,26 +374,78 @@ static int fsm_to_device(mm_fsm_t f) {
         f->gdev[d].slots = reinterpret_cast<const Slot *>(base + o_slots[d]);
         f->gdev[d].n_items = int(f->packed[d].items.size());
         f->gdev[d].pad = 0;
-        f->qdev[d].quads = reinterpret_cast<const Quad *>(base + o_quads[d]);
-        f->qdev[d].rowptr = reinterpret_cast<const int *>(base + o_qptr[d]);
-        f->qdev[d].col = reinterpret_cast<const int *>(base + o_qcol[d]);
-        f->qdev[d].w = reinterpret_cast<const float *>(base + o_qw[d]);
-        f->qdev[d].qstart = reinterpret_cast<const unsigned short *>(base + o_qst[d]);
-        f->qdev[d].rord = reinterpret_cast<const unsigned short *>(base + o_qord[d]);
-        f->qdev[d].nq = int(f->quad[d].quads.size());
-        f->qdev[d].pad = 0;
     }
     f->d_init = reinterpret_cast<const float *>(base + o_init);
     f->d_s2p = reinterpret_cast<const int *>(base + o_s2p);
     f->dev_blob = blob;
-    f->dev_bytes = off;
+    f->dev_bytes = bl.host.size();
     f->device = dev;
+    return MM_OK;
+}
+
+// build (once per KQ) and upload the quad form of an FSM
+static int quad_variant(mm_fsm_t f, int KQ, QuadVariant **out) {
+    auto it = f->variants.find(KQ);
+    if (it != f->variants.end()) {
+        *out = it->second;
+        return MM_OK;
+    }
+    QuadVariant *v = new QuadVariant();
+    v->KQ = KQ;
+    v->g[0] = make_quads(f->S1, f->mat[0].rowptr, f->mat[0].col, f->mat[0].val, f->s2p, f->P1, false, KQ);
+    v->g[1] = make_quads(f->S1, f->mat[1].rowptr, f->mat[1].col, f->mat[1].val, f->s2p, f->P1, true, KQ);
+    if (getenv("MM_VERBOSE"))
+        for (int d = 0; d < 2; ++d)
+            fprintf(stderr, "[mm] quad form dir %d: KQ %d, %zu quads, %lld arcs, LDS cycles/gather (bank model) %.2f -> %.2f\n",
+                    d, KQ, v->g[d].quads.size(), (long long)f->mat[d].rowptr[f->S1], v->g[d].conflict_before,
+                    v->g[d].conflict_after);
+    v->init_f.resize(f->S1);
+    v->map_bf.resize(f->S1);
+    for (int64_t i = 0; i < f->S1; ++i) {
+        v->init_f[i] = f->init[v->g[0].order[i]];
+        v->map_bf[i] = uint16_t(v->g[0].pos[v->g[1].order[i]]);
+    }
+    Blob bl;
+    size_t o_q[2], o_rec[2], o_ptr[2], o_col[2], o_w[2], o_pse[2];
+    for (int d = 0; d < 2; ++d) {
+        o_q[d] = bl.add(v->g[d].quads);
+        o_rec[d] = bl.add(v->g[d].recs);
+        o_ptr[d] = bl.add(v->g[d].rowptr);
+        o_col[d] = bl.add(v->g[d].col);
+        o_w[d] = bl.add(v->g[d].w);
+        o_pse[d] = bl.add(v->g[d].pdfstart);
+    }
+    const size_t o_initf = bl.add(v->init_f), o_map = bl.add(v->map_bf);
+    int rc = upload(bl, &v->blob);
+    if (rc) {
+        delete v;
+        return rc;
+    }
+    char *base = static_cast<char *>(v->blob);
+    for (int d = 0; d < 2; ++d) {
+        v->qdev[d].quads = reinterpret_cast<const Quad *>(base + o_q[d]);
+        v->qdev[d].recs = reinterpret_cast<const RowRec *>(base + o_rec[d]);
+        v->qdev[d].rowptr = reinterpret_cast<const int *>(base + o_ptr[d]);
+        v->qdev[d].col = reinterpret_cast<const int *>(base + o_col[d]);
+        v->qdev[d].w = reinterpret_cast<const float *>(base + o_w[d]);
+        v->qdev[d].pdfse = reinterpret_cast<const unsigned short *>(base + o_pse[d]);
+        v->qdev[d].nq = int(v->g[d].quads.size());
+        v->qdev[d].fpos = v->g[d].pos[f->S1 - 1];
+    }
+    v->d_init_f = reinterpret_cast<const float *>(base + o_initf);
+    v->d_map_bf = reinterpret_cast<const unsigned short *>(base + o_map);
+    f->variants[KQ] = v;
+    *out = v;
     return MM_OK;
 }
 
 int mm_fsm_destroy(mm_fsm_t f) {
     if (!f) return MM_OK;
     if (f->dev_blob) (void)hipFree(f->dev_blob);
+    for (auto &kv : f->variants) {
+        if (kv.second->blob) (void)hipFree(kv.second->blob);
+        delete kv.second;
+    }
     delete f;
     return MM_OK;
 }
@@ -422,6 +473,50 @@ int mm_debug_packed_product(mm_fsm_t f, int direction, const float *in, float *o
     return MM_OK;
 }
 
+int mm_debug_quad_product(mm_fsm_t f, int direction, int KQ, const float *in, float *out, double stats[4]) {
+    if (!f || !in || !out || direction < 0 || direction > 1 || KQ < 1 || KQ > 16)
+        return fail(MM_ERR_INVALID, "mm_debug_quad_product: bad argument");
+    if (f->semiring != MM_LOG) return fail(MM_ERR_INVALID, "mm_debug_quad_product: log-semiring FSMs only");
+    const Csr &m = f->mat[direction];
+    QuadGraph g = make_quads(f->S1, m.rowptr, m.col, m.val, f->s2p, f->P1, direction == 1, KQ);
+    const int64_t S1 = f->S1, nq = int64_t(g.quads.size());
+    // p = 2^(in * log2e - max) in the internal numbering
+    float mx = -std::numeric_limits<float>::infinity();
+    for (int64_t s = 0; s < S1; ++s) mx = std::max(mx, in[s] * MM_LOG2E);
+    if (!(mx > -std::numeric_limits<float>::infinity())) mx = 0.f;
+    std::vector<float> p(S1), qs(nq, 0.f);
+    for (int64_t i = 0; i < S1; ++i) p[i] = std::exp2(in[g.order[i]] * MM_LOG2E - mx);
+    const int64_t lanes = (nq + KQ - 1) / KQ;
+    for (int64_t l = 0; l < lanes; ++l) {
+        const uint32_t mask = g.quads[size_t(l * KQ)].mask;
+        float run = 0.f;
+        for (int j = 0; j < KQ && l * KQ + j < nq; ++j) {
+            const Quad &q = g.quads[size_t(l * KQ + j)];
+            float s = 0.f;
+            for (int k = 0; k < 4; ++k) s = std::fmaf(q.wl[k], p[q.off[k] / 4], s);
+            run = ((mask >> j) & 1u) ? run + s : s;
+            qs[size_t(l * KQ + j)] = run;
+        }
+    }
+    for (int64_t i = 0; i < S1; ++i) {
+        const RowRec &r = g.recs[i];
+        float acc = 0.f;
+        if (r.nq) {
+            const int qe = r.q0 + r.nq - 1;
+            acc = qs[qe];
+            for (int q = r.q0 + (KQ - 1 - r.q0 % KQ); q < qe; q += KQ) acc += qs[q];
+        }
+        out[g.order[i]] = (std::log2(acc) + mx) * MM_LN2;
+    }
+    if (stats) {
+        stats[0] = double(nq);
+        stats[1] = double(lanes);
+        stats[2] = g.conflict_before;
+        stats[3] = g.conflict_after;
+    }
+    return MM_OK;
+}
+
 int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     if (!out) return fail(MM_ERR_INVALID, "mm_batch_create: out is NULL");
     *out = nullptr;
@@ -436,20 +531,47 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     h->semiring = fsms[0]->semiring;
     h->fsms.assign(fsms, fsms + B);
     std::vector<UttDesc> utts(B);
+    // quad kernel: one geometry (quads per lane, waves) for the whole batch
+    int64_t nq_max = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        h->fast_ok = h->fast_ok && fsms[b]->fast_ok;
+        nq_max = std::max(nq_max, std::max(fsms[b]->nquads[0], fsms[b]->nquads[1]));
+    }
+    h->fast_ok = h->fast_ok && h->semiring == MM_LOG;
+    if (h->fast_ok) {
+        QuadGeometry geo = pick_quad_geometry(nq_max);
+        if (const char *e = getenv("MM_KQ")) {
+            int v = atoi(e);
+            if (v >= 1 && v <= 13) geo.KQ = v;
+        }
+        geo.NW = int(std::min<int64_t>(MM_MAX_WAVES, std::max<int64_t>(1, (nq_max + 64 * geo.KQ - 1) / (64 * geo.KQ))));
+        if (const char *e = getenv("MM_NWAVES")) {
+            int v = atoi(e);
+            if (v >= 1 && v <= MM_MAX_WAVES) geo.NW = v;
+        }
+        h->geo_kq = geo.KQ;
+        h->geo_nw = geo.NW;
+        h->max_quads = int(nq_max);
+    }
     for (int64_t b = 0; b < B; ++b) {
         mm_fsm_t f = fsms[b];
         int rc = fsm_to_device(f);
+        QuadVariant *qv = nullptr;
+        if (!rc && h->fast_ok) rc = quad_variant(f, h->geo_kq, &qv);
         if (rc) {
             delete h;
             return rc;
         }
         UttDesc &u = utts[b];
+        memset(&u, 0, sizeof(u));
         u.g[0] = f->gdev[0];
         u.g[1] = f->gdev[1];
-        u.q[0] = f->qdev[0];
-        u.q[1] = f->qdev[1];
-        h->fast_ok = h->fast_ok && f->fast_ok;
-        h->max_quads = std::max(h->max_quads, std::max(f->qdev[0].nq, f->qdev[1].nq));
+        if (qv) {
+            u.q[0] = qv->qdev[0];
+            u.q[1] = qv->qdev[1];
+            u.init_f = qv->d_init_f;
+            u.map_bf = qv->d_map_bf;
+        }
         u.init = f->d_init;
         u.s2p = f->d_s2p;
         u.S1 = int(f->S1);
@@ -473,6 +595,17 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     *out = h;
     return MM_OK;
 }
+
+#ifdef MM_STAMPS
+// diagnostic build: copy the per-wave phase cycle sums of the last pdfposteriors call to the host
+int mm_debug_read_stamps(unsigned long long *out, int64_t n) {
+    if (!g_dbg) return fail(MM_ERR_INVALID, "no stamps recorded");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, g_dbg, sizeof(unsigned long long) * size_t(std::min<int64_t>(n, int64_t(g_dbg_n))),
+                      hipMemcpyDeviceToHost));
+    return MM_OK;
+}
+#endif
 
 int mm_batch_destroy(mm_batch_t h) {
     if (!h) return MM_OK;
@@ -538,6 +671,13 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     p.gsn = gsn;
     p.gsp = gsp;
     p.ttl = ttl;
+#ifdef MM_STAMPS
+    if (!g_dbg) {
+        g_dbg_n = size_t(16) * MM_MAX_WAVES * size_t(h->B);
+        (void)hipMalloc(&g_dbg, sizeof(unsigned long long) * g_dbg_n);
+    }
+    p.dbg = g_dbg;
+#endif
     if (quad_kernel_usable(h)) {
         rc = launch_quad(h, p, stream);
         if (rc != MM_ERR_UNSUPPORTED) return rc;

@@ -16,13 +16,21 @@
 //     owns KQ quads for the whole time loop (linear weights + LDS byte offsets:
 //     6.5 VGPRs per quad).  The per-frame code is branch-free and statically
 //     unrolled, so all of a lane's gathers are in flight together.
-//   * every quad sum is stored to LDS (plain, conflict-free ds_write); after the
-//     barrier one thread per row adds up the row's quads in a fixed order
-//     (deterministic; LDS float atomics measured ~80 cycles per wave instruction
-//     and made the kernel LDS-bound) and finishes the row: log2, emission,
-//     normaliser, 2^x for the next frame, and in the backward pass the posterior
-//     accumulation.  Rows are visited in decreasing-size order so the lanes of a
-//     wave run loops of similar length.
+//   * a lane adds the quads of one row that sit next to each other in its
+//     registers (static per-lane bit mask), stores the running sums to LDS (plain
+//     ds_write; LDS float atomics measured ~80 cycles per wave instruction), and
+//     after the barrier one thread per row adds the few lane-partials of its row
+//     in a fixed order (deterministic) and finishes the row: log2, emission,
+//     normaliser, 2^x for the next frame.
+//   * states are renumbered per direction (mm_pack.h): rows by decreasing size,
+//     so the lanes of a wave run loops of similar length and every per-row LDS
+//     access is contiguous; in the backward direction grouped by pdf, so the
+//     reference's C' * (A .* B) (src/inference.jl:154-155) is a sum over
+//     contiguous positions done by one rotating wave -- no atomics anywhere.
+//     The alpha store in HBM is written coalesced in the forward numbering; the
+//     backward pass prefetches each thread's own rows through a register-held map.
+//   * inside a row the host places the arcs on the (quad, slot) grid so that the
+//     gathers of a half-wave hit distinct LDS banks where possible.
 //   * EXACT fallback per row: when the linear sum leaves the range where it is
 //     trustworthy (sum < 2^-90: the row lies > 62 nats below the frame maximum or
 //     is unreachable; or overflow) the row is recomputed as a two-pass
@@ -37,25 +45,24 @@ namespace mm {
 
 #define MM_Q_THR 8.0779357e-28f  // 2^-90
 #define MM_Q_BIG 1.2676506e30f   // 2^100
-#define MM_Q_SINK 64             // dummy accumulator slots for padding quads (one per lane: no conflicts)
+#define MM_Q_RPT 3               // rows per thread whose alpha prefetch is carried in registers
 
 struct LdsPlanQ {
-    int abuf, pbuf, qs, stage, em, bins, part, s2p, qstart, rord, total;
+    int abuf, pbuf, qs, qrow, em, part, recs, pdfse, psum, total;
 };
-// nqcap = max(number of quads, threads * KQ): one float per quad sum
+// nqcap = quad slots: threads * KQ, or more when the graph overflows the register window
 __host__ __device__ inline LdsPlanQ lds_plan_q(int S1p, int P1p, int nqcap) {
     LdsPlanQ l;
     l.abuf = 0;
     l.pbuf = l.abuf + 2 * S1p;
     l.qs = l.pbuf + S1p;
-    l.stage = l.qs + ((nqcap + 3) & ~3);
-    l.em = l.stage + 2 * S1p;
-    l.bins = l.em + 2 * P1p;
-    l.part = l.bins + 2 * P1p;
-    l.s2p = l.part + 2 * MM_MAX_WAVES;
-    l.qstart = l.s2p + (S1p + 1) / 2;
-    l.rord = l.qstart + (S1p + 4) / 2;
-    l.total = l.rord + (S1p + 1) / 2;
+    l.qrow = l.qs + ((nqcap + 3) & ~3);
+    l.em = l.qrow + S1p;
+    l.part = l.em + 2 * P1p;
+    l.recs = l.part + 2 * MM_MAX_WAVES;
+    l.pdfse = l.recs + 2 * S1p;
+    l.psum = l.pdfse + P1p;
+    l.total = l.psum + P1p;
     return l;
 }
 
@@ -63,11 +70,12 @@ template <int KQ>
 struct QuadRegs {
     float wl[KQ][4];
     unsigned off[KQ][2];  // off0 | off1 << 16, off2 | off3 << 16  (LDS byte offsets)
+    unsigned mask;        // bit j: quad j continues the row of quad j-1
 };
 
 __device__ __forceinline__ void load_quad(const Quad *q, float (&wl)[4], unsigned (&off)[2]) {
     const uint4 a = *reinterpret_cast<const uint4 *>(q);
-    const uint4 b = *(reinterpret_cast<const uint4 *>(q) + 1);
+    const uint2 b = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(q) + 16);
     wl[0] = __uint_as_float(a.x);
     wl[1] = __uint_as_float(a.y);
     wl[2] = __uint_as_float(a.z);
@@ -78,6 +86,7 @@ __device__ __forceinline__ void load_quad(const Quad *q, float (&wl)[4], unsigne
 
 template <int KQ>
 __device__ __forceinline__ void load_quad_regs(QuadRegs<KQ> &rg, const QuadDev &g, int tid) {
+    rg.mask = (tid * KQ < g.nq) ? g.quads[tid * KQ].mask : 0u;
     static_for<0, KQ>([&](auto J) {
         constexpr int j = decltype(J)::value;
         const int q = tid * KQ + j;
@@ -93,7 +102,8 @@ __device__ __forceinline__ float lds_f32(const float *base, unsigned byte_off) {
 
 __device__ __forceinline__ float quad_sum(const float (&wl)[4], unsigned off01, unsigned off23, const float *pbuf) {
     // keep the offsets packed: unpacking is loop invariant and hoisting it would cost 2 VGPRs per quad
-    asm volatile("" : "+v"(off01), "+v"(off23));
+    // (plain asm, not volatile: it must not order the LDS traffic around it)
+    asm("" : "+v"(off01), "+v"(off23));
     const float x0 = lds_f32(pbuf, off01 & 0xffffu), x1 = lds_f32(pbuf, off01 >> 16);
     const float x2 = lds_f32(pbuf, off23 & 0xffffu), x3 = lds_f32(pbuf, off23 >> 16);
     float acc = wl[0] * x0;
@@ -103,27 +113,62 @@ __device__ __forceinline__ float quad_sum(const float (&wl)[4], unsigned off01, 
     return acc;
 }
 
-// phase A: qs[q] = sum_k 2^w_k * p[col_k] over the 4 arcs of quad q.  Lane tid owns the
-// quads tid * KQ .. tid * KQ + KQ - 1 (KQ odd: the stores of a wave hit distinct banks);
-// a row's quads are contiguous in qs.
+// phase A.  qs[q] = running sum, inside lane q / KQ, of the quads of q's row up to q
+// (quad sum = sum_k 2^w_k * p[col_k] over its 4 arcs).  So the partial sums of a row are
+// found at the last quad of the row and at every lane end (q % KQ == KQ - 1) before it.
 template <int KQ>
-__device__ __forceinline__ void quad_phase(const QuadRegs<KQ> &rg, const QuadDev &g, int tid, int NT, const float *pbuf,
-                                           float *qs) {
+__device__ __forceinline__ void quad_phase(const QuadRegs<KQ> &rg, const QuadDev &g, int tid, int NT,
+                                           const float *__restrict__ pbuf, float *__restrict__ qs) {
+    // all gathers first (no LDS store in between, so they can all be in flight), then the stores
+    float s[KQ];
     static_for<0, KQ>([&](auto J) {
         constexpr int j = decltype(J)::value;
-        qs[tid * KQ + j] = quad_sum(rg.wl[j], rg.off[j][0], rg.off[j][1], pbuf);
+        s[j] = quad_sum(rg.wl[j], rg.off[j][0], rg.off[j][1], pbuf);
     });
-    for (int q = NT * KQ + tid; q < g.nq; q += NT) {  // quads beyond the register window: streamed from L2
-        float wl[4];
-        unsigned off[2];
-        load_quad(g.quads + q, wl, off);
-        qs[q] = quad_sum(wl, off[0], off[1], pbuf);
+    float run = 0.f;
+    unsigned mask = rg.mask;
+    asm("" : "+v"(mask));
+    static_for<0, KQ>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        // keep the running sum only if quad j continues the previous quad's row
+        const int keep = __builtin_amdgcn_sbfe(mask, j, 1);  // 0 or -1
+        run = s[j] + __int_as_float(__float_as_int(run) & keep);
+        qs[tid * KQ + j] = run;
+    });
+    // lanes beyond the register window ("virtual lanes"): the same, streamed from L2
+    for (int v = NT + tid; v * KQ < g.nq; v += NT) {
+        const unsigned m = g.quads[v * KQ].mask;
+        float r = 0.f;
+        for (int j = 0; j < KQ && v * KQ + j < g.nq; ++j) {
+            float wl[4];
+            unsigned off[2];
+            load_quad(g.quads + v * KQ + j, wl, off);
+            const float sj = quad_sum(wl, off[0], off[1], pbuf);
+            r = ((m >> j) & 1u) ? r + sj : sj;
+            qs[v * KQ + j] = r;
+        }
     }
 }
 
-// phase B helper: add up the quads [q0, q1) of one row in a fixed order; the loads of
-// a group of 8 are independent, so a long row costs few LDS round trips
-__device__ __forceinline__ float row_sum(const float *qs, int q0, int q1) {
+// phase B: the sum of row [q0, q0 + nq): its last quad plus the lane ends before it
+// (up to 4 independent loads per round trip)
+template <int KQ>
+__device__ __forceinline__ float row_total(const float *__restrict__ qs, int q0, int nq) {
+    if (nq == 0) return 0.f;
+    const int qe = q0 + nq - 1;
+    float acc = qs[qe];
+    for (int q = q0 + (KQ - 1 - q0 % KQ); q < qe; q += 4 * KQ) {
+        const float a = qs[q];
+        const float b = (q + KQ < qe) ? qs[q + KQ] : 0.f;
+        const float c = (q + 2 * KQ < qe) ? qs[q + 2 * KQ] : 0.f;
+        const float d = (q + 3 * KQ < qe) ? qs[q + 3 * KQ] : 0.f;
+        acc += (a + b) + (c + d);
+    }
+    return acc;
+}
+
+// add up the contiguous floats [q0, q1) in a fixed order (independent loads in groups of 8)
+__device__ __forceinline__ float seg_sum(const float *qs, int q0, int q1) {
     float acc = 0.f;
     int q = q0;
     for (; q + 8 <= q1; q += 8) {
@@ -131,16 +176,7 @@ __device__ __forceinline__ float row_sum(const float *qs, int q0, int q1) {
         const float a4 = qs[q + 4], a5 = qs[q + 5], a6 = qs[q + 6], a7 = qs[q + 7];
         acc += ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
     }
-    if (q + 4 <= q1) {
-        const float a0 = qs[q], a1 = qs[q + 1], a2 = qs[q + 2], a3 = qs[q + 3];
-        acc += (a0 + a1) + (a2 + a3);
-        q += 4;
-    }
-    if (q + 2 <= q1) {
-        acc += qs[q] + qs[q + 1];
-        q += 2;
-    }
-    if (q < q1) acc += qs[q];
+    for (; q < q1; ++q) acc += qs[q];
     return acc;
 }
 
@@ -156,6 +192,64 @@ __device__ __forceinline__ float exact_row(const QuadDev &g, int r, const float 
     return m + fast_log2(s);
 }
 
+struct RowRecU {
+    unsigned q0nq;  // q0 | nq << 16
+    unsigned pdf;
+};
+__device__ __forceinline__ RowRecU load_rec(const float *recs, int i) {
+    const uint2 r = reinterpret_cast<const uint2 *>(recs)[i];
+    return RowRecU{r.x, r.y & 0xffffu};
+}
+
+// emission of frame n (1-based) for pdf slot q: expand() (src/inference.jl:54-60) + log2 scaling.
+// The load is issued here and the LDS store happens later, off the critical path.
+// Returns the RAW value: the scaling happens at the store (em_scale), so that nothing waits for the load here.
+// Branch-free (every thread loads a valid, clamped address) so that the compiler has no reason to wait.
+__device__ __forceinline__ float em_load(const float *Vb, long long vsn, int n, int len, int P, int q) {
+    const int nn = n < 1 ? 1 : n, qq = q < P ? q : P - 1;
+    const float raw = Vb[(long long)(nn - 1) * vsn + qq];
+    const bool real = q < P;
+    return (n <= len) ? (real ? raw : MM_NINF) : (real ? MM_NINF : 0.f);
+}
+__device__ __forceinline__ float em_scale(float raw) { return raw * MM_LOG2E; }
+
+// max over the per-wave maxima of the previous frame: one LDS read + a DPP row reduction
+__device__ __forceinline__ float part_max_dpp(const float *part, int NW, int lane) {
+    float v = (lane < NW) ? part[lane] : MM_NINF;
+    v = grp_max(v, 4);
+    v = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+    return (v > MM_NINF) ? v : 0.f;
+}
+
+// C' * (A .* B) (src/inference.jl:154-155) without atomics: states of one pdf are contiguous in the
+// backward numbering.  Every wave sums 8 pdfs per pass, 8 lanes per pdf (+ a 3-step DPP reduction).
+__device__ __forceinline__ void pdf_sums(const float *qrow, const unsigned short *pdfse, float *psum, int P1, int wave,
+                                         int NW, int lane) {
+    for (int p0 = wave * 8; p0 < P1; p0 += NW * 8) {
+        const int pdf = p0 + (lane >> 3);
+        float s = 0.f;
+        if (pdf < P1) {
+            const unsigned se = reinterpret_cast<const unsigned *>(pdfse)[pdf];  // first | end << 16
+            for (int t = (int)(se & 0xffffu) + (lane & 7); t < (int)(se >> 16); t += 8) s += qrow[t];
+        }
+        s = grp_sum(s, 3);
+        if (pdf < P1 && (lane & 7) == 0) psum[pdf] = s;
+    }
+}
+
+// one wave: per-frame sum over the pdfs, divide, store gamma (src/inference.jl:156-160); returns the sum
+__device__ __forceinline__ float finish_frame(const float *psum, int P1, int P, int lane, float *gp, long long gsp) {
+    const float s0 = lane < P1 ? psum[lane] : 0.f, s1 = lane + 64 < P1 ? psum[lane + 64] : 0.f;
+    float tot = s0 + s1;
+    for (int q = lane + 128; q < P1; q += 64) tot += psum[q];
+    tot = wave_sum(tot);
+    const float inv = 1.f / tot;
+    if (lane < P) gp[lane * gsp] = s0 * inv;
+    if (lane + 64 < P) gp[(lane + 64) * gsp] = s1 * inv;
+    for (int q = lane + 128; q < P; q += 64) gp[q * gsp] = psum[q] * inv;
+    return tot;
+}
+
 template <int KQ>
 __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
     extern __shared__ float lds[];
@@ -164,41 +258,37 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6;
     const int S1 = u.S1, S1p = u.S1p, P1 = u.P1, P = P1 - 1, P1p = (P1 + 3) & ~3;
-    const int fstate = S1 - 1;
     int len = p.lens ? p.lens[b] : p.N;
     len = len < 0 ? 0 : (len > p.N ? p.N : len);
     const int NF = len + 1;
     const QuadDev qf = u.q[0], qb = u.q[1];
     const int nqmax = qf.nq > qb.nq ? qf.nq : qb.nq;
-    const LdsPlanQ L = lds_plan_q(S1p, P1p, nqmax > NT * KQ ? nqmax : NT * KQ);
-    float *abuf = lds + L.abuf, *pbuf = lds + L.pbuf, *qs = lds + L.qs, *stage = lds + L.stage;
-    float *em = lds + L.em, *bins = lds + L.bins, *part = lds + L.part;
-    unsigned short *s2p = reinterpret_cast<unsigned short *>(lds + L.s2p);
-    unsigned short *qstart = reinterpret_cast<unsigned short *>(lds + L.qstart);
-    unsigned short *rord = reinterpret_cast<unsigned short *>(lds + L.rord);
+    const int vl = (nqmax + KQ - 1) / KQ;  // lanes (real + virtual) that hold quads
+    const LdsPlanQ L = lds_plan_q(S1p, P1p, (vl > NT ? vl : NT) * KQ);
+    float *abuf = lds + L.abuf, *pbuf = lds + L.pbuf, *qs = lds + L.qs, *qrow = lds + L.qrow;
+    float *em = lds + L.em, *part = lds + L.part, *recs = lds + L.recs;
+    unsigned short *pdfse = reinterpret_cast<unsigned short *>(lds + L.pdfse);
+    float *psum = lds + L.psum;
     const float *Vb = p.V + (long long)b * p.vsb;
     float *wsA = p.ws_alpha + u.s1p_prefix * (long long)(p.N + 1);
     double *wsC = p.ws_c + (long long)b * (p.N + 2);
     QuadRegs<KQ> rg;
 
-    // ---------------- forward: alpha-recursion (src/inference.jl:62-74) ----------------
+    // ---------------- forward: alpha-recursion (src/inference.jl:62-74), forward numbering ----------------
     stage_em(em + 1 * P1p, Vb, p.vsn, 1, len, P, tid, NT, MM_LOG2E);
     for (int q = tid; q < 2 * S1p; q += NT) abuf[q] = MM_NINF;
     for (int q = tid; q < S1p; q += NT) pbuf[q] = 0.f;
-    for (int s = tid; s < S1; s += NT) {
-        s2p[s] = (unsigned short)u.s2p[s];
-        rord[s] = qf.rord[s];
-    }
-    for (int s = tid; s <= S1; s += NT) qstart[s] = qf.qstart[s];
+    for (int s = tid; s < S1; s += NT)
+        reinterpret_cast<uint2 *>(recs)[s] = reinterpret_cast<const uint2 *>(qf.recs)[s];
     __syncthreads();
     {   // frame 1: alpha_hat (*) lhs[:,1]   (src/inference.jl:68)
         float wm = MM_NINF;
         float *a1 = abuf + 1 * S1p;
         const float *e1 = em + 1 * P1p;
-        for (int s = tid; s < S1; s += NT) {
-            const float v = u.init[s] + e1[s2p[s]];
-            a1[s] = v;
-            pbuf[s] = fast_exp2(v);
+        for (int i = tid; i < S1; i += NT) {
+            const float v = u.init_f[i] + e1[load_rec(recs, i).pdf];
+            a1[i] = v;
+            pbuf[i] = fast_exp2(v);
             wm = fmaxf(wm, v);
         }
         wm = wave_max(wm);
@@ -209,42 +299,86 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
     load_quad_regs<KQ>(rg, qf, tid);
     __syncthreads();
     double C = 0.0;
+    MM_STAMP_DECL;
+    MM_STAMP_RESET;
     for (int n = 2; n <= NF; ++n) {
         const float *ap = abuf + ((n - 1) & 1) * S1p;
         float *an = abuf + (n & 1) * S1p;
         const float *emn = em + (n & 1) * P1p;
-        // frame 1's p = 2^a is un-normalised (C_1 = 0): the lagged normaliser enters from frame 2 on
-        const float M = part_max(part + ((n - 1) & 1) * MM_MAX_WAVES, NW);
+        const float M = part_max_dpp(part + ((n - 1) & 1) * MM_MAX_WAVES, NW, lane);
         C += (double)M;
         if (tid == 0) wsC[n] = C;
-        if (n + 1 <= NF) stage_em(em + ((n + 1) & 1) * P1p, Vb, p.vsn, n + 1, len, P, tid, NT, MM_LOG2E);
-        {   // frame n-1 leaves the chip once (coalesced), while frame n is computed
+        // emissions of frame n+1: loaded now, stored to LDS at the end of the step (waves 0..P/64 only)
+        const bool em_wave = wave * 64 <= P;
+        float ev = 0.f;
+        if (em_wave) ev = em_load(Vb, p.vsn, n + 1 <= p.N ? n + 1 : p.N, n + 1 <= len ? len : -1, P, tid);
+        MM_STAMP(0);
+        quad_phase<KQ>(rg, qf, tid, NT, pbuf, qs);
+        {   // frame n-1 leaves the chip once (coalesced, forward numbering) while frame n is computed
             float4 *dst = reinterpret_cast<float4 *>(wsA + (long long)(n - 1) * S1p);
             const float4 *src = reinterpret_cast<const float4 *>(ap);
             for (int q = tid; q < (S1p >> 2); q += NT) dst[q] = src[q];
         }
-        quad_phase<KQ>(rg, qf, tid, NT, pbuf, qs);
+        MM_STAMP(1);
         __syncthreads();
+        MM_STAMP(2);
         float wm = MM_NINF;
-        for (int i = tid; i < S1; i += NT) {
-            const int r = rord[i];
-            const float acc = row_sum(qs, qstart[r], qstart[r + 1]);
+        {   // this thread's rows tid, tid + NT, ...: the loads of the first MM_Q_RPT rows are issued together
+            RowRecU rec[MM_Q_RPT];
+            float acc[MM_Q_RPT];
+#pragma unroll
+            for (int k = 0; k < MM_Q_RPT; ++k) {
+                const int i = tid + k * NT;
+                rec[k] = load_rec(recs, i < S1 ? i : 0);
+                if (i >= S1) rec[k].q0nq = 0u;  // no quads: nothing to read
+            }
+#pragma unroll
+            for (int k = 0; k < MM_Q_RPT; ++k)
+                acc[k] = row_total<KQ>(qs, rec[k].q0nq & 0xffffu, rec[k].q0nq >> 16);
+#pragma unroll
+            for (int k = 0; k < MM_Q_RPT; ++k) {
+                const int i = tid + k * NT;
+                if (i < S1) {
+                    const bool ok = acc[k] >= MM_Q_THR && acc[k] <= MM_Q_BIG;
+                    float v = fast_log2(acc[k]);
+                    if (__builtin_expect(!ok, 0)) v = (rec[k].q0nq >> 16) ? exact_row(qf, i, ap) : MM_NINF;
+                    v = v + emn[rec[k].pdf] - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
+                    an[i] = v;
+                    pbuf[i] = fast_exp2(v);
+                    wm = fmaxf(wm, v);
+                }
+            }
+        }
+        for (int i = tid + MM_Q_RPT * NT; i < S1; i += NT) {
+            const RowRecU rec = load_rec(recs, i);
+            const float acc = row_total<KQ>(qs, rec.q0nq & 0xffffu, rec.q0nq >> 16);
             const bool ok = acc >= MM_Q_THR && acc <= MM_Q_BIG;
             float v = fast_log2(acc);
-            if (__builtin_expect(!ok, 0)) v = exact_row(qf, r, ap);
-            v = v + emn[s2p[r]] - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
-            an[r] = v;
-            pbuf[r] = fast_exp2(v);
+            if (__builtin_expect(!ok, 0)) v = (rec.q0nq >> 16) ? exact_row(qf, i, ap) : MM_NINF;
+            v = v + emn[rec.pdf] - M;
+            an[i] = v;
+            pbuf[i] = fast_exp2(v);
             wm = fmaxf(wm, v);
         }
         wm = wave_max(wm);
         if (lane == 0) part[(n & 1) * MM_MAX_WAVES + wave] = wm;
+        if (n + 1 <= NF) {
+            if (tid <= P) em[((n + 1) & 1) * P1p + tid] = em_scale(ev);
+            if (P >= NT) stage_em(em + ((n + 1) & 1) * P1p + NT, Vb + NT, p.vsn, n + 1, len, P - NT, tid, NT, MM_LOG2E);
+        }
+        MM_STAMP(3);
         __syncthreads();
+        MM_STAMP(4);
     }
-    const double logZ2 = (double)abuf[(NF & 1) * S1p + fstate] + C;
+#ifdef MM_STAMPS
+    if (p.dbg && lane == 0)
+        for (int k = 0; k < 8; ++k) p.dbg[((long long)b * MM_MAX_WAVES + wave) * 16 + k] = stamp_acc[k];
+    for (int k = 0; k < 8; ++k) stamp_acc[k] = 0;
+#endif
+    const double logZ2 = (double)abuf[(NF & 1) * S1p + qf.fpos] + C;
     __syncthreads();
 
-    // ---------------- backward: beta-recursion fused with the combine ----------------
+    // ---------------- backward: beta-recursion fused with the combine, backward numbering ----------------
     const long long gbase = (long long)b * p.gsb;
     if (!(logZ2 > -1e300)) {  // no accepting path: gamma = 0, ttl = -inf
         for (long long q = tid; q < (long long)p.N * P; q += NT)
@@ -253,86 +387,116 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
         return;
     }
     for (int q = tid; q < 2 * S1p; q += NT) abuf[q] = MM_NINF;
-    for (int q = tid; q < S1p; q += NT) pbuf[q] = 0.f;
-    for (int q = tid; q < 2 * P1p; q += NT) bins[q] = 0.f;
+    for (int q = tid; q < S1p; q += NT) {
+        pbuf[q] = 0.f;
+        qrow[q] = 0.f;
+    }
+    for (int s = tid; s < S1; s += NT) reinterpret_cast<uint2 *>(recs)[s] = reinterpret_cast<const uint2 *>(qb.recs)[s];
+    for (int s = tid; s < 2 * P1; s += NT) pdfse[s] = qb.pdfse[s];
+    // this thread's rows tid, tid + NT, ...: where their alpha sits in the (forward-numbered) store
+    int amap[MM_Q_RPT];
+    float acur[MM_Q_RPT], anxt[MM_Q_RPT];
+#pragma unroll
+    for (int k = 0; k < MM_Q_RPT; ++k) {
+        const int i = tid + k * NT;
+        amap[k] = (i < S1) ? (int)u.map_bf[i] : 0;
+        acur[k] = anxt[k] = 0.f;
+        if (len >= 1 && i < S1) acur[k] = wsA[(long long)len * S1p + amap[k]];
+    }
     __syncthreads();
     if (tid == 0) {  // frame len+1: B (*) lhs = one for the final state only
-        abuf[(NF & 1) * S1p + fstate] = 0.f;
-        pbuf[fstate] = 1.f;
+        abuf[(NF & 1) * S1p + qb.fpos] = 0.f;
+        pbuf[qb.fpos] = 1.f;
     }
-    if (len >= 1) {
-        stage_em(em + (len & 1) * P1p, Vb, p.vsn, len, len, P, tid, NT, MM_LOG2E);
-        const float4 *src = reinterpret_cast<const float4 *>(wsA + (long long)len * S1p);
-        float4 *dst = reinterpret_cast<float4 *>(stage + (len & 1) * S1p);
-        for (int q = tid; q < (S1p >> 2); q += NT) dst[q] = src[q];
-    }
+    if (len >= 1) stage_em(em + (len & 1) * P1p, Vb, p.vsn, len, len, P, tid, NT, MM_LOG2E);
     load_quad_regs<KQ>(rg, qb, tid);
-    for (int s = tid; s < S1; s += NT) rord[s] = qb.rord[s];
-    for (int s = tid; s <= S1; s += NT) qstart[s] = qb.qstart[s];
     __syncthreads();
     double D = 0.0;
     float tmin = (float)logZ2;
+    MM_STAMP_RESET;
     for (int n = len; n >= 1; --n) {
         const float *yp = abuf + ((n + 1) & 1) * S1p;
         float *yn = abuf + (n & 1) * S1p;
-        const float *ast = stage + (n & 1) * S1p;
         const float *emn = em + (n & 1) * P1p;
-        float *bn = bins + (n & 1) * P1p;
-        const float M = (n == len) ? 0.f : part_max(part + ((n + 1) & 1) * MM_MAX_WAVES, NW);
+        const float M = (n == len) ? 0.f : part_max_dpp(part + ((n + 1) & 1) * MM_MAX_WAVES, NW, lane);
         D += (double)M;
         const double Cn = __hip_atomic_load(&wsC[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float kappa = (float)(logZ2 - Cn - D);
-        // finalise frame n+1 (one rotating wave): C' * AB, per-frame sum, divide (src/inference.jl:155-160)
-        if (n < len && wave == ((n + 1) % NW)) {
-            float *bf = bins + ((n + 1) & 1) * P1p;
-            float s = 0.f;
-            for (int q = lane; q < P1; q += 64) s += bf[q];
-            s = wave_sum(s);
-            const float inv = 1.f / s;
-            float *gp = p.gamma + gbase + (long long)n * p.gsn;
-            for (int q = lane; q < P1; q += 64) {
-                if (q < P) gp[q * p.gsp] = bf[q] * inv;
-                bf[q] = 0.f;
-            }
+        // prefetch of frame n-1 (alpha of this thread's rows, emissions): consumed one step later
+        const bool em_wave = wave * 64 <= P;
+        float ev = 0.f;
+        if (em_wave) ev = em_load(Vb, p.vsn, n - 1, len, P, tid);
+        if (n - 1 >= 1) {
+            const float *src = wsA + (long long)(n - 1) * S1p;
+#pragma unroll
+            for (int k = 0; k < MM_Q_RPT; ++k)
+                if (tid + k * NT < S1) anxt[k] = src[amap[k]];
+        }
+        MM_STAMP(0);
+        if (n < len) pdf_sums(qrow, pdfse, psum, P1, wave, NW, lane);  // posteriors of frame n+1, per pdf
+        quad_phase<KQ>(rg, qb, tid, NT, pbuf, qs);
+        MM_STAMP(1);
+        __syncthreads();
+        MM_STAMP(2);
+        if (n < len && wave == ((n + 1) % NW)) {  // gamma of frame n+1
+            const float s = finish_frame(psum, P1, P, lane, p.gamma + gbase + (long long)n * p.gsn, p.gsp);
             tmin = fminf(tmin, (float)(logZ2 + (double)fast_log2(s)));
         }
-        if (n - 1 >= 1) {
-            stage_em(em + ((n - 1) & 1) * P1p, Vb, p.vsn, n - 1, len, P, tid, NT, MM_LOG2E);
-            const float4 *src = reinterpret_cast<const float4 *>(wsA + (long long)(n - 1) * S1p);
-            float4 *dst = reinterpret_cast<float4 *>(stage + ((n - 1) & 1) * S1p);
-            for (int q = tid; q < (S1p >> 2); q += NT) dst[q] = src[q];
-        }
-        quad_phase<KQ>(rg, qb, tid, NT, pbuf, qs);
-        __syncthreads();
+        const float kappa = (float)(logZ2 - Cn - D);
         float wm = MM_NINF;
-        for (int i = tid; i < S1; i += NT) {
-            const int r = rord[i];
-            const float acc = row_sum(qs, qstart[r], qstart[r + 1]);
-            const int pdf = s2p[r];
+#pragma unroll
+        for (int k = 0; k < MM_Q_RPT; ++k) {
+            const int i = tid + k * NT;
+            if (i < S1) {
+                const RowRecU rec = load_rec(recs, i);
+                const float acc = row_total<KQ>(qs, rec.q0nq & 0xffffu, rec.q0nq >> 16);
+                const bool ok = acc >= MM_Q_THR && acc <= MM_Q_BIG;
+                float v = fast_log2(acc);
+                if (__builtin_expect(!ok, 0)) v = (rec.q0nq >> 16) ? exact_row(qb, i, yp) : MM_NINF;
+                const float beta = v - M;  // T (B[:,n+1] (*) lhs[:,n+1])  (src/inference.jl:106-107)
+                qrow[i] = fast_exp2(acur[k] + beta - kappa);  // state_A .* state_B / Z
+                const float y = beta + emn[rec.pdf];
+                yn[i] = y;
+                pbuf[i] = fast_exp2(y);
+                wm = fmaxf(wm, y);
+            }
+        }
+        for (int i = tid + MM_Q_RPT * NT; i < S1; i += NT) {  // more rows per thread than register slots
+            const RowRecU rec = load_rec(recs, i);
+            const float acc = row_total<KQ>(qs, rec.q0nq & 0xffffu, rec.q0nq >> 16);
             const bool ok = acc >= MM_Q_THR && acc <= MM_Q_BIG;
             float v = fast_log2(acc);
-            if (__builtin_expect(!ok, 0)) v = exact_row(qb, r, yp);
-            const float beta = v - M;  // T (B[:,n+1] (*) lhs[:,n+1])  (src/inference.jl:106-107)
-            const float q = fast_exp2(ast[r] + beta - kappa);   // state_A .* state_B / Z
-            if (q > 0.f) atomicAdd(&bn[pdf], q);
-            const float y = beta + emn[pdf];
-            yn[r] = y;
-            pbuf[r] = fast_exp2(y);
+            if (__builtin_expect(!ok, 0)) v = (rec.q0nq >> 16) ? exact_row(qb, i, yp) : MM_NINF;
+            const float beta = v - M;
+            qrow[i] = fast_exp2(wsA[(long long)n * S1p + u.map_bf[i]] + beta - kappa);
+            const float y = beta + emn[rec.pdf];
+            yn[i] = y;
+            pbuf[i] = fast_exp2(y);
             wm = fmaxf(wm, y);
         }
         wm = wave_max(wm);
         if (lane == 0) part[(n & 1) * MM_MAX_WAVES + wave] = wm;
+        if (n - 1 >= 1) {
+            if (tid <= P) em[((n - 1) & 1) * P1p + tid] = em_scale(ev);
+            if (P >= NT) stage_em(em + ((n - 1) & 1) * P1p + NT, Vb + NT, p.vsn, n - 1, len, P - NT, tid, NT, MM_LOG2E);
+        }
+#pragma unroll
+        for (int k = 0; k < MM_Q_RPT; ++k) acur[k] = anxt[k];
+        MM_STAMP(3);
         __syncthreads();
+        MM_STAMP(4);
     }
-    if (len >= 1 && wave == 0) {
-        float *bf = bins + (1 & 1) * P1p;
-        float s = 0.f;
-        for (int q = lane; q < P1; q += 64) s += bf[q];
-        s = wave_sum(s);
-        const float inv = 1.f / s;
-        float *gp = p.gamma + gbase;
-        for (int q = lane; q < P; q += 64) gp[q * p.gsp] = bf[q] * inv;
-        tmin = fminf(tmin, (float)(logZ2 + (double)fast_log2(s)));
+#ifdef MM_STAMPS
+    if (p.dbg && lane == 0)
+        for (int k = 0; k < 8; ++k) p.dbg[((long long)b * MM_MAX_WAVES + wave) * 16 + 8 + k] = stamp_acc[k];
+#endif
+    // gamma of frame 1, zeros beyond len, ttl
+    if (len >= 1) {
+        pdf_sums(qrow, pdfse, psum, P1, wave, NW, lane);
+        __syncthreads();
+        if (wave == 0) {
+            const float s = finish_frame(psum, P1, P, lane, p.gamma + gbase, p.gsp);
+            tmin = fminf(tmin, (float)(logZ2 + (double)fast_log2(s)));
+        }
     }
     for (long long q = tid; q < (long long)(p.N - len) * P; q += NT)
         p.gamma[gbase + (len + q / P) * p.gsn + (q % P) * p.gsp] = 0.f;

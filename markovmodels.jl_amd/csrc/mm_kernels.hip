@@ -44,20 +44,22 @@ struct GraphDev {
     int pad;
 };
 
-struct QuadDev {  // quad form + row-ordered CSR (mm_pack.h QuadGraph), one direction
+struct QuadDev {  // one direction in quad form, internal numbering (mm_pack.h QuadGraph)
     const Quad *quads;
-    const int *rowptr;
+    const RowRec *recs;
+    const int *rowptr;  // CSR with log2 weights for the exact fallback
     const int *col;
     const float *w;
-    const unsigned short *qstart;
-    const unsigned short *rord;
+    const unsigned short *pdfse;  // [2 * P1] (first, end) internal positions of each pdf (backward only)
     int nq;
-    int pad;
+    int fpos;  // internal position of the phony final state
 };
 
 struct UttDesc {
     GraphDev g[2];  // 0: T_hat' packed (forward), 1: T_hat packed (backward)
     QuadDev q[2];   // same two matrices in quad form (log semiring only)
+    const float *init_f;            // alpha_hat in forward numbering
+    const unsigned short *map_bf;   // backward position -> forward position
     const float *init;  // dense alpha_hat [S1] (log2 domain for MM_LOG, natural for MM_TROPICAL)
     const int *s2p;     // state -> pdf [S1]
     int S1, S1p, P1, pad;
@@ -83,7 +85,30 @@ struct RunParams {
     int *path;
     long long path_stride_b;
     float *score;
+    unsigned long long *dbg;  // diagnostic builds only (-DMM_STAMPS): per-wave cycle sums per phase
 };
+
+// In-kernel cycle stamps (diagnostic build only; the shipped library executes none).
+#ifdef MM_STAMPS
+#define MM_STAMP(slot)                                                                     \
+    do {                                                                                   \
+        unsigned long long t_;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        stamp_acc[slot] += t_ - stamp_last;                                                \
+        stamp_last = t_;                                                                   \
+    } while (0)
+#define MM_STAMP_DECL unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = 0
+#define MM_STAMP_RESET                                                                     \
+    do {                                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory"); \
+    } while (0)
+#else
+#define MM_STAMP(slot) do { } while (0)
+#define MM_STAMP_DECL
+#define MM_STAMP_RESET do { } while (0)
+#endif
 
 // LDS carve (in floats) shared by host (size) and device (offsets).
 struct LdsPlan {

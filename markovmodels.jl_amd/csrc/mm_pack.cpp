@@ -100,47 +100,214 @@ Packed pack_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::v
     return out;
 }
 
+QuadGeometry pick_quad_geometry(int64_t nquads) {
+    // KQ multiples of 4 are avoided: lane tid stores its quad sums at tid * KQ + j, and
+    // a stride that is a multiple of 4 dwords makes those stores 4-way bank conflicted
+    static const int kqs[] = {1, 2, 3, 5, 6, 7, 9, 10, 11, 13};
+    QuadGeometry g{13, 16};
+    for (int k : kqs)
+        if (int64_t(64) * 16 * k >= nquads) {
+            g.KQ = k;
+            break;
+        }
+    g.NW = int(std::min<int64_t>(16, std::max<int64_t>(1, (nquads + 64 * g.KQ - 1) / (64 * g.KQ))));
+    return g;
+}
+
+namespace {
+
+// LDS cycles of one ds_read_b32 wave instruction under the bank model of the CDNA4 LDS
+// (two groups of 32 lanes, 32 banks of 4 bytes, identical addresses broadcast)
+struct BankTable {
+    // per bank: the distinct addresses present (small)
+    std::vector<uint16_t> addr[32];
+    int cost_of(uint16_t a) const {  // extra cycles this address would add
+        const auto &v = addr[(a >> 2) & 31];
+        for (uint16_t x : v)
+            if (x == a) return 0;
+        return int(v.size());
+    }
+    void add(uint16_t a) {
+        auto &v = addr[(a >> 2) & 31];
+        for (uint16_t x : v)
+            if (x == a) return;
+        v.push_back(a);
+    }
+    int cycles() const {
+        size_t m = 1;
+        for (auto &v : addr) m = std::max(m, v.size());
+        return int(m);
+    }
+    int least_loaded_bank() const {
+        int b = 0;
+        for (int i = 1; i < 32; ++i)
+            if (addr[i].size() < addr[b].size()) b = i;
+        return b;
+    }
+};
+
+}  // namespace
+
+int64_t count_quads(int64_t nrows, const std::vector<int64_t> &rowptr) {
+    int64_t n = 0;
+    for (int64_t r = 0; r < nrows; ++r) n += (rowptr[r + 1] - rowptr[r] + 3) / 4;
+    return n;
+}
+
+bool quad_range_ok(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<float> &val, int32_t P1) {
+    if (nrows * 4 > 65535 || P1 > 65535 || count_quads(nrows, rowptr) > 65535) return false;
+    // the linear path needs 2^w and its products with values in [2^-126, 2^127] to stay normal
+    for (float v : val)
+        if (!(v > -100.f && v < 20.f)) return false;
+    return true;
+}
+
 QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &col,
-                     const std::vector<float> &val) {
+                     const std::vector<float> &val, const std::vector<int32_t> &row2pdf, int32_t P1, bool pdf_major,
+                     int KQ) {
     QuadGraph g;
-    g.rowptr.resize(nrows + 1);
-    g.col.assign(col.begin(), col.end());
-    g.w.assign(val.begin(), val.end());
-    bool ok = nrows * 4 <= 65535;
-    for (int64_t r = 0; r <= nrows; ++r) g.rowptr[r] = int32_t(rowptr[r]);
-    for (int64_t r = 0; r < nrows; ++r) {
-        for (int64_t b = rowptr[r]; b < rowptr[r + 1]; b += 4) {
-            Quad q;
-            std::memset(&q, 0, sizeof(q));
-            q.rowoff = uint16_t(4 * r);
-            for (int k = 0; k < 4; ++k) {
-                int64_t a = b + k;
-                if (a < rowptr[r + 1]) {
-                    // the linear path needs 2^w and its products with values in [2^-126, 2^127] to stay normal
-                    if (!(val[a] > -100.f && val[a] < 20.f)) ok = false;
-                    q.wl[k] = std::exp2(val[a]);
-                    q.off[k] = uint16_t(4 * col[a]);
-                }
-            }
-            g.quads.push_back(q);
+    g.KQ = KQ;
+    auto nq_of = [&](int64_t r) { return (rowptr[r + 1] - rowptr[r] + 3) / 4; };
+    // ---- internal numbering
+    g.order.resize(nrows);
+    for (int64_t r = 0; r < nrows; ++r) g.order[r] = int32_t(r);
+    if (pdf_major) {
+        std::vector<double> sum(P1, 0.0), cnt(P1, 0.0);
+        for (int64_t r = 0; r < nrows; ++r) {
+            sum[row2pdf[r]] += double(nq_of(r));
+            cnt[row2pdf[r]] += 1.0;
+        }
+        std::vector<int32_t> pdf_order(P1), pdf_rank(P1);
+        for (int32_t p = 0; p < P1; ++p) pdf_order[p] = p;
+        std::stable_sort(pdf_order.begin(), pdf_order.end(), [&](int32_t a, int32_t b) {
+            return sum[a] / std::max(cnt[a], 1.0) > sum[b] / std::max(cnt[b], 1.0);
+        });
+        for (int32_t k = 0; k < P1; ++k) pdf_rank[pdf_order[k]] = k;
+        std::stable_sort(g.order.begin(), g.order.end(), [&](int32_t a, int32_t b) {
+            if (row2pdf[a] != row2pdf[b]) return pdf_rank[row2pdf[a]] < pdf_rank[row2pdf[b]];
+            return nq_of(a) > nq_of(b);
+        });
+    } else {
+        std::stable_sort(g.order.begin(), g.order.end(), [&](int32_t a, int32_t b) { return nq_of(a) > nq_of(b); });
+    }
+    g.pos.resize(nrows);
+    for (int64_t i = 0; i < nrows; ++i) g.pos[g.order[i]] = int32_t(i);
+    if (pdf_major) {
+        g.pdfstart.assign(P1 + 1, 0);
+        std::vector<int64_t> count(P1 + 1, 0);
+        // pdfstart is indexed by pdf id; positions of one pdf are contiguous
+        std::vector<int64_t> first(P1, -1), last(P1, -1);
+        for (int64_t i = 0; i < nrows; ++i) {
+            int32_t p = row2pdf[g.order[i]];
+            if (first[p] < 0) first[p] = i;
+            last[p] = i;
+        }
+        // store (start, end) pairs compactly: start[p], and end = start + count; keep two arrays in one:
+        // pdfstart[p] = first position, and the count is recovered from pdfcount below
+        g.pdfstart.assign(2 * size_t(P1), 0);
+        for (int32_t p = 0; p < P1; ++p) {
+            g.pdfstart[2 * p] = uint16_t(first[p] < 0 ? 0 : first[p]);
+            g.pdfstart[2 * p + 1] = uint16_t(first[p] < 0 ? 0 : last[p] + 1);
         }
     }
-    if (g.quads.size() > 65535) ok = false;
-    g.qstart.assign(nrows + 1, 0);
-    std::vector<int32_t> order(nrows);
-    int64_t acc = 0;
-    for (int64_t r = 0; r < nrows; ++r) {
-        g.qstart[r] = uint16_t(acc);
-        acc += (rowptr[r + 1] - rowptr[r] + 3) / 4;
-        order[r] = int32_t(r);
+    // ---- CSR in internal numbering
+    g.rowptr.assign(nrows + 1, 0);
+    g.col.resize(col.size());
+    g.w.resize(val.size());
+    g.recs.resize(nrows);
+    int64_t nq_total = 0, a_out = 0;
+    for (int64_t i = 0; i < nrows; ++i) {
+        const int64_t r = g.order[i];
+        g.rowptr[i] = int32_t(a_out);
+        for (int64_t a = rowptr[r]; a < rowptr[r + 1]; ++a, ++a_out) {
+            g.col[a_out] = g.pos[col[a]];
+            g.w[a_out] = val[a];
+        }
+        RowRec rec;
+        rec.q0 = uint16_t(nq_total);
+        rec.nq = uint16_t(nq_of(r));
+        rec.pdf = uint16_t(row2pdf[r]);
+        rec.pad = 0;
+        g.recs[i] = rec;
+        nq_total += nq_of(r);
     }
-    g.qstart[nrows] = uint16_t(acc);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-        return (rowptr[a + 1] - rowptr[a] + 3) / 4 > (rowptr[b + 1] - rowptr[b] + 3) / 4;
-    });
-    g.rord.resize(nrows);
-    for (int64_t r = 0; r < nrows; ++r) g.rord[r] = uint16_t(order[r]);
-    g.fast_ok = ok;
+    g.rowptr[nrows] = int32_t(a_out);
+    g.quads.assign(size_t(nq_total), Quad{});
+
+    // ---- arc placement.  Lane t of the workgroup owns quads [t*KQ, (t+1)*KQ); the gather
+    // instruction (j, k) of a half-wave reads slot k of quad j of its 32 lanes.
+    const int64_t lanes = (nq_total + KQ - 1) / KQ;
+    // row of every quad
+    std::vector<int32_t> qrow(static_cast<size_t>(nq_total), 0);
+    for (int64_t i = 0; i < nrows; ++i)
+        for (int q = 0; q < g.recs[i].nq; ++q) qrow[g.recs[i].q0 + q] = int32_t(i);
+    // naive placement first (arcs in CSR order), to report the model cost before/after
+    std::vector<char> used(g.col.size(), 0);
+    double cyc_naive = 0, cyc_sched = 0;
+    int64_t n_instr = 0;
+    for (int64_t l0 = 0; l0 < lanes; l0 += 32) {  // one half-wave
+        std::vector<BankTable> tab(size_t(KQ) * 4), tab0(size_t(KQ) * 4);
+        for (int64_t l = l0; l < std::min(lanes, l0 + 32); ++l) {
+            int j = 0;
+            while (j < KQ && l * KQ + j < nq_total) {
+                // segment of consecutive quads of this lane that belong to one row
+                const int32_t row = qrow[l * KQ + j];
+                int j1 = j;
+                while (j1 < KQ && l * KQ + j1 < nq_total && qrow[l * KQ + j1] == row) ++j1;
+                const int64_t qfirst = l * KQ + j, qrel = qfirst - g.recs[row].q0;
+                const int64_t a0 = g.rowptr[row] + 4 * qrel;
+                const int64_t a1 = std::min<int64_t>(g.rowptr[row + 1], a0 + 4 * int64_t(j1 - j));
+                // naive cost model
+                for (int64_t a = a0; a < a1; ++a) {
+                    const int jj = j + int((a - a0) / 4), kk = int((a - a0) % 4);
+                    tab0[size_t(jj) * 4 + kk].add(uint16_t(4 * g.col[a]));
+                }
+                // greedy: slot by slot, take the remaining arc of the pool that is cheapest there
+                for (int jj = j; jj < j1; ++jj)
+                    for (int kk = 0; kk < 4; ++kk) {
+                        BankTable &bt = tab[size_t(jj) * 4 + kk];
+                        int64_t best = -1;
+                        int best_cost = 1 << 30;
+                        for (int64_t a = a0; a < a1; ++a) {
+                            if (used[a]) continue;
+                            const int c = bt.cost_of(uint16_t(4 * g.col[a]));
+                            if (c < best_cost) {
+                                best_cost = c;
+                                best = a;
+                                if (c == 0) break;
+                            }
+                        }
+                        Quad &Q = g.quads[size_t(l * KQ + jj)];
+                        if (best >= 0) {
+                            used[best] = 1;
+                            Q.wl[kk] = std::exp2(g.w[best]);
+                            Q.off[kk] = uint16_t(4 * g.col[best]);
+                            bt.add(Q.off[kk]);
+                        } else {  // padding: weight 0, an address that costs nothing
+                            Q.wl[kk] = 0.f;
+                            Q.off[kk] = uint16_t(4 * bt.least_loaded_bank());
+                            if (Q.off[kk] >= 4 * nrows) Q.off[kk] = 0;
+                            bt.add(Q.off[kk]);
+                        }
+                    }
+                j = j1;
+            }
+        }
+        for (size_t i = 0; i < tab.size(); ++i) {
+            cyc_naive += tab0[i].cycles();
+            cyc_sched += tab[i].cycles();
+            ++n_instr;
+        }
+    }
+    // lane masks: which quads continue the row of their predecessor inside the lane
+    for (int64_t l = 0; l < lanes; ++l) {
+        uint32_t mask = 0;
+        for (int j = 1; j < KQ && l * KQ + j < nq_total; ++j)
+            if (qrow[l * KQ + j] == qrow[l * KQ + j - 1]) mask |= 1u << j;
+        g.quads[size_t(l * KQ)].mask = mask;
+    }
+    g.conflict_before = n_instr ? cyc_naive / double(n_instr) : 0;
+    g.conflict_after = n_instr ? cyc_sched / double(n_instr) : 0;
     return g;
 }
 

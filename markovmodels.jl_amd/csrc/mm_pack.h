@@ -52,34 +52,67 @@ Packed pack_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::v
                  const std::vector<float> &val, const std::vector<int32_t> &row2pdf, float zero_w);
 
 // ---------------------------------------------------------------------------
-// "Quad" form for the fast forward-backward kernel (mm_kernel_quad.hip): every
-// row is cut into quads of 4 arcs (the last one padded with weight 0); quad q
-// belongs to lane q / KQ of the workgroup, which keeps its KQ quads in registers
-// for the whole time loop.  Weights are LINEAR (2^w), columns are LDS byte
-// offsets (4 * col).  Quads are stored in row order.
+// "Quad" form for the fast forward-backward kernel (mm_kernel_quad.hip).
+//
+// Internal numbering: the rows (states) of one direction are renumbered by
+// decreasing number of quads (forward), or grouped by pdf and then by decreasing
+// size (backward, so that the posterior of a pdf is a sum over CONTIGUOUS
+// positions), so that the per-row loops of a wavefront have similar lengths and
+// every per-row LDS access of the finishing phase is contiguous across lanes.
+// Every row is cut into quads of 4 arcs (the last one padded with weight 0); quad
+// q belongs to lane q / KQ of the workgroup, which keeps its KQ quads in
+// registers for the whole time loop.  Weights are LINEAR (2^w), columns are LDS
+// byte offsets (4 * internal position of the source).  Inside a row the arcs are
+// placed on the (quad, slot) grid so that the 32 lanes of a half-wave that
+// execute the same gather instruction hit distinct LDS banks where possible
+// (identical addresses broadcast for free).
 // ---------------------------------------------------------------------------
 struct Quad {
-    float wl[4];       // 2^(log2 weight); 0 = padding
-    uint16_t off[4];   // 4 * source column (byte offset into the LDS vector)
-    uint16_t rowoff;   // 4 * row
-    uint16_t pad;
-    uint32_t pad2;
+    float wl[4];      // 2^(log2 weight); 0 = padding
+    uint16_t off[4];  // 4 * internal position of the source state
+    uint32_t mask;    // in the FIRST quad of a lane (q % KQ == 0): bit j set <=> quad q + j continues the
+                      // row of quad q + j - 1, i.e. its sum is added to the running sum of the lane
+    uint32_t pad;
 };
 static_assert(sizeof(Quad) == 32, "Quad must be 32 bytes");
 
+struct RowRec {  // one per internal position: what the row-finishing thread needs, one 8-byte LDS read
+    uint16_t q0;   // first quad of the row
+    uint16_t nq;   // number of quads
+    uint16_t pdf;
+    uint16_t pad;
+};
+
+struct QuadGeometry {
+    int KQ;  // quads per lane held in registers
+    int NW;  // wavefronts per workgroup
+};
+QuadGeometry pick_quad_geometry(int64_t nquads);
+
 struct QuadGraph {
-    std::vector<Quad> quads;
-    // row-ordered CSR with log2-domain weights: the exact fallback walks these
+    std::vector<int32_t> order;  // internal position -> original row
+    std::vector<int32_t> pos;    // original row -> internal position
+    std::vector<Quad> quads;     // in internal row order
+    std::vector<RowRec> recs;    // [nrows]
+    // CSR in internal numbering with log2-domain weights: the exact fallback walks these
     std::vector<int32_t> rowptr;
     std::vector<int32_t> col;
     std::vector<float> w;
-    std::vector<uint16_t> qstart;  // [nrows + 1] first quad of every row
-    std::vector<uint16_t> rord;    // [nrows] rows by decreasing number of quads (balanced row-finishing loops)
-    bool fast_ok = false;  // all weights inside the range the linear path is valid for
+    std::vector<uint16_t> pdfstart;  // [P1 + 1] first internal position of each pdf (pdf-major order only)
+    int KQ = 1;                      // quads per lane this form was laid out for
+    double conflict_before = 0, conflict_after = 0;  // mean LDS cycles per gather instruction (model)
 };
 
+// rowptr/col/val_log2: 0-based CSR (out[r] = (+)_k val[k] (*) in[col[k]]); col_pos: the internal
+// position of every column state in the vector the arcs gather from (= the numbering of the
+// SAME direction: forward gathers alpha_{n-1}, stored in forward numbering).
 QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &col,
-                     const std::vector<float> &val_log2);
+                     const std::vector<float> &val_log2, const std::vector<int32_t> &row2pdf, int32_t P1,
+                     bool pdf_major, int KQ);
+
+// Number of quads of a CSR matrix, and whether its weights fit the linear path of the quad kernel.
+int64_t count_quads(int64_t nrows, const std::vector<int64_t> &rowptr);
+bool quad_range_ok(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<float> &val_log2, int32_t P1);
 
 // Host evaluation of one product through the packed form, lane by lane, with the
 // same group structure as the kernels (test aid).  semiring 0 = log, 1 = tropical.

@@ -63,7 +63,7 @@ class CompiledFSM:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:  # lib is None while the interpreter shuts down
             lib.mm_fsm_destroy(h)
             self._h = None
 
@@ -80,6 +80,16 @@ class CompiledFSM:
         arg = np.empty(self.S1, dtype=np.int32)
         check(lib.mm_debug_packed_product(self._h, direction, x.ctypes.data, out.ctypes.data, arg.ctypes.data))
         return out, arg
+
+
+    def quad_product(self, x: np.ndarray, direction: int = 0, KQ: int = 5):
+        """Host evaluation of the same product through the quad form of the fast kernel (test aid).
+        Returns (out, stats = [quads, lanes, LDS cycles/gather naive, after placement])."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty(self.S1, dtype=np.float32)
+        stats = np.zeros(4, dtype=np.float64)
+        check(lib.mm_debug_quad_product(self._h, direction, KQ, x.ctypes.data, out.ctypes.data, stats.ctypes.data))
+        return out, stats
 
 
 def compile(fsm: FSM, C_hat) -> CompiledFSM:  # noqa: A001 - the reference's name
@@ -108,7 +118,7 @@ class BatchedFSM:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:
             lib.mm_batch_destroy(h)
             self._h = None
 

@@ -1,0 +1,156 @@
+# SPDX-License-Identifier: MIT
+#
+# MarkovModelsAMD.jl -- the binding a MarkovModels.jl maintainer would add so that
+# `pdfposteriors`, `αrecursion` and `βrecursion` run on an AMD MI355X through
+# libmarkovmodels_amd.so (C ABI: include/markovmodels_amd.h).
+#
+# NOT TESTED IN THIS REPOSITORY: the build image has no Julia.  The tested binding
+# of the same ABI is the Python/ctypes one in markovmodels.jl_amd/_lib.py; this file
+# mirrors it call for call.  Device memory comes from AMDGPU.jl (ROCArray).
+#
+# Seam (see INTEGRATION.md): the reference dispatches on CuArray storage
+# (src/fsm.jl:42-48, src/inference.jl:14-26, src/linalg.jl:163,240,335).  Here the
+# dispatch is on a device handle type, one level up: one ccall per inference call.
+
+module MarkovModelsAMD
+
+using MarkovModels
+using SparseArrays
+using Semirings
+using AMDGPU
+
+const LIB = get(ENV, "MARKOVMODELS_AMD_LIB", "libmarkovmodels_amd.so")
+
+const MM_LOG, MM_TROPICAL = Cint(0), Cint(1)
+const MM_CSC = Cint(0)
+
+struct MMError <: Exception
+    code::Cint
+    msg::String
+end
+
+function check(rc::Cint)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:mm_last_error, LIB), Cstring, ()))
+    rc == -2 && throw(DimensionMismatch(msg))      # src/linalg.jl:166-167
+    throw(MMError(rc, msg))
+end
+
+semiring_id(::Type{<:LogSemiring}) = MM_LOG
+semiring_id(::Type{<:TropicalSemiring}) = MM_TROPICAL
+
+"Device-resident compiled FSM: replaces adapt(CuArray, ::CompiledFSM) (src/inference.jl:14-26)."
+mutable struct ROCCompiledFSM{K}
+    handle::Ptr{Cvoid}
+    S1::Int
+    P1::Int
+end
+
+"""
+    compile(ROCCompiledFSM, fsm, Ĉ)
+
+`compile(fsm, Ĉ)` (src/inference.jl:11-12) + device adapt.  `Ĉ` is the state map
+of examples/prepare-lfmmi-graphs.jl:15-23 (exactly one stored entry per row).
+"""
+function compile(::Type{ROCCompiledFSM}, fsm::FSM{K}, Ĉ::AbstractSparseMatrix) where K
+    T̂ = SparseMatrixCSC(fsm.T̂)                       # colptr / rowval / nzval, Int64, 1-based
+    α̂ = SparseVector(fsm.α̂)
+    Ct = SparseMatrixCSC(copy(Ĉ'))                      # column s of Ĉ' = row s of Ĉ
+    all(diff(Ct.colptr) .== 1) || throw(ArgumentError("Ĉ must have exactly one entry per row"))
+    state2pdf = Vector{Int32}(Ct.rowval)                # 1-based pdf of every state
+    vals = val.(nonzeros(T̂))
+    avals = val.(nonzeros(α̂))
+    T = eltype(vals)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve T̂ α̂ state2pdf vals avals begin
+        check(ccall((:mm_fsm_create, LIB), Cint,
+            (Cint, Int64, Int64, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64,
+             Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int32}, Int32, Ref{Ptr{Cvoid}}),
+            semiring_id(K), size(T̂, 1), nnz(T̂), MM_CSC, 8, 1, sizeof(T),
+            pointer(T̂.colptr), pointer(T̂.rowval), pointer(vals), nnz(α̂),
+            pointer(SparseArrays.nonzeroinds(α̂)), pointer(avals), pointer(state2pdf),
+            Int32(size(Ĉ, 2)), h))
+    end
+    obj = ROCCompiledFSM{K}(h[], size(T̂, 1), size(Ĉ, 2))
+    finalizer(o -> ccall((:mm_fsm_destroy, LIB), Cint, (Ptr{Cvoid},), o.handle), obj)
+    obj
+end
+
+"batch(cfsm...) (src/inference.jl:28-36); repeating one handle shares its storage."
+mutable struct ROCBatch{K}
+    handle::Ptr{Cvoid}
+    fsms::Vector{ROCCompiledFSM{K}}      # keeps the FSM handles alive
+    P::Int
+end
+
+function MarkovModels.batch(f1::ROCCompiledFSM{K}, fs::ROCCompiledFSM{K}...) where K
+    all_ = ROCCompiledFSM{K}[f1, fs...]
+    hs = Ptr{Cvoid}[f.handle for f in all_]
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:mm_batch_create, LIB), Cint, (Ptr{Ptr{Cvoid}}, Int64, Ref{Ptr{Cvoid}}), hs, length(hs), h))
+    obj = ROCBatch{K}(h[], all_, f1.P1 - 1)
+    finalizer(o -> ccall((:mm_batch_destroy, LIB), Cint, (Ptr{Cvoid},), o.handle), obj)
+    obj
+end
+
+"""
+    pdfposteriors(b::ROCBatch, V::ROCArray{Float32,3}, lens)
+
+Drop-in for pdfposteriors(fsm, V̂s, Ĉs) (src/inference.jl:145-161) /
+pdfposteriors2 (:164-180).  `V` is P × N × B (Julia column-major: pdf fastest, the
+layout of `vcat(V̂s...)` without the phony row/frame: expand() happens inside);
+`lens` a ROCVector{Int32} or nothing.  Returns (γ::ROCArray{Float32,3} of size
+B × P × N like the reference, ttl::ROCVector{Float32}).
+"""
+function MarkovModels.pdfposteriors(b::ROCBatch, V::ROCArray{Float32,3}, lens = nothing)
+    P, N, B = size(V)
+    P == b.P || throw(DimensionMismatch("V has $P pdfs, the FSMs $(b.P)"))
+    γ = ROCArray{Float32}(undef, B, P, N)
+    ttl = ROCArray{Float32}(undef, B)
+    lp = lens === nothing ? Ptr{Int32}(C_NULL) : Ptr{Int32}(pointer(lens))
+    # strides in elements: V (b, n, p) -> p + P*n + P*N*b ; γ (b, n, p) -> b + B*p + B*P*n
+    check(ccall((:mm_pdfposteriors_f32, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Ptr{Int32}, Int64, Ptr{Float32}, Int64, Int64, Int64,
+         Ptr{Float32}, Ptr{Cvoid}),
+        b.handle, pointer(V), P * N, P, lp, N, pointer(γ), 1, B * P, B, pointer(ttl),
+        AMDGPU.stream().stream))
+    γ, ttl
+end
+
+function _recursion(sym::Symbol, b::ROCBatch, V::ROCArray{Float32,3}, lens)
+    P, N, B = size(V)
+    total = ccall((:mm_batch_total_states, LIB), Int64, (Ptr{Cvoid},), b.handle)
+    out = ROCArray{Float32}(undef, total, N + 1)          # (ΣS1) × (N+1) like state_A / state_B
+    lp = lens === nothing ? Ptr{Int32}(C_NULL) : Ptr{Int32}(pointer(lens))
+    check(ccall((sym, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Ptr{Int32}, Int64, Ptr{Float32}, Int64, Ptr{Cvoid}),
+        b.handle, pointer(V), P * N, P, lp, N, pointer(out), total, AMDGPU.stream().stream))
+    out
+end
+
+"αrecursion(α̂, T̂ᵀ, ĈV̂) (src/inference.jl:62-74) as pdfposteriors calls it (:150-152)."
+MarkovModels.αrecursion(b::ROCBatch, V::ROCArray{Float32,3}, lens = nothing) =
+    _recursion(:mm_alpharecursion_f32, b, V, lens)
+"βrecursion(T̂, ĈV̂) (src/inference.jl:99-110)."
+MarkovModels.βrecursion(b::ROCBatch, V::ROCArray{Float32,3}, lens = nothing) =
+    _recursion(:mm_betarecursion_f32, b, V, lens)
+
+"""
+    bestpath(b::ROCBatch{<:TropicalSemiring}, V, lens) -> (paths, scores)
+
+docs/src/inference.md:6 (absent from src/ at v0.10.0).  States are returned 1-based.
+"""
+function bestpath(b::ROCBatch{K}, V::ROCArray{Float32,3}, lens = nothing) where K <: TropicalSemiring
+    P, N, B = size(V)
+    path = ROCArray{Int32}(undef, N, B)
+    score = ROCArray{Float32}(undef, B)
+    lp = lens === nothing ? Ptr{Int32}(C_NULL) : Ptr{Int32}(pointer(lens))
+    check(ccall((:mm_viterbi_f32, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Ptr{Int32}, Int64, Ptr{Int32}, Int64, Ptr{Float32},
+         Ptr{Int32}, Int64, Ptr{Cvoid}),
+        b.handle, pointer(V), P * N, P, lp, N, pointer(path), N, pointer(score), C_NULL, 0,
+        AMDGPU.stream().stream))
+    Array(path) .+ Int32(1), Array(score)
+end
+
+end # module

@@ -241,63 +241,74 @@ QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const st
     std::vector<int32_t> qrow(static_cast<size_t>(nq_total), 0);
     for (int64_t i = 0; i < nrows; ++i)
         for (int q = 0; q < g.recs[i].nq; ++q) qrow[g.recs[i].q0 + q] = int32_t(i);
-    // naive placement first (arcs in CSR order), to report the model cost before/after
+    // Two candidate placements per half-wave: arcs in CSR order, and a greedy bank-aware one
+    // (slot by slot, the remaining arc of the row segment that is cheapest there); the cheaper
+    // one under the bank model is kept.
     std::vector<char> used(g.col.size(), 0);
     double cyc_naive = 0, cyc_sched = 0;
     int64_t n_instr = 0;
-    for (int64_t l0 = 0; l0 < lanes; l0 += 32) {  // one half-wave
-        std::vector<BankTable> tab(size_t(KQ) * 4), tab0(size_t(KQ) * 4);
-        for (int64_t l = l0; l < std::min(lanes, l0 + 32); ++l) {
+    auto place = [&](int64_t l0, int64_t l1, bool greedy, std::vector<Quad> &out) -> int64_t {
+        std::vector<BankTable> tab(size_t(KQ) * 4);
+        out.assign(size_t((l1 - l0) * KQ), Quad{});
+        for (int64_t l = l0; l < l1; ++l) {
             int j = 0;
             while (j < KQ && l * KQ + j < nq_total) {
                 // segment of consecutive quads of this lane that belong to one row
                 const int32_t row = qrow[l * KQ + j];
                 int j1 = j;
                 while (j1 < KQ && l * KQ + j1 < nq_total && qrow[l * KQ + j1] == row) ++j1;
-                const int64_t qfirst = l * KQ + j, qrel = qfirst - g.recs[row].q0;
+                const int64_t qrel = l * KQ + j - g.recs[row].q0;
                 const int64_t a0 = g.rowptr[row] + 4 * qrel;
                 const int64_t a1 = std::min<int64_t>(g.rowptr[row + 1], a0 + 4 * int64_t(j1 - j));
-                // naive cost model
-                for (int64_t a = a0; a < a1; ++a) {
-                    const int jj = j + int((a - a0) / 4), kk = int((a - a0) % 4);
-                    tab0[size_t(jj) * 4 + kk].add(uint16_t(4 * g.col[a]));
-                }
-                // greedy: slot by slot, take the remaining arc of the pool that is cheapest there
+                for (int64_t a = a0; a < a1; ++a) used[a] = 0;
+                int64_t next = a0;
                 for (int jj = j; jj < j1; ++jj)
                     for (int kk = 0; kk < 4; ++kk) {
                         BankTable &bt = tab[size_t(jj) * 4 + kk];
                         int64_t best = -1;
-                        int best_cost = 1 << 30;
-                        for (int64_t a = a0; a < a1; ++a) {
-                            if (used[a]) continue;
-                            const int c = bt.cost_of(uint16_t(4 * g.col[a]));
-                            if (c < best_cost) {
-                                best_cost = c;
-                                best = a;
-                                if (c == 0) break;
+                        if (!greedy) {
+                            if (next < a1) best = next++;
+                        } else {
+                            int best_cost = 1 << 30;
+                            for (int64_t a = a0; a < a1; ++a) {
+                                if (used[a]) continue;
+                                const int c = bt.cost_of(uint16_t(4 * g.col[a]));
+                                if (c < best_cost) {
+                                    best_cost = c;
+                                    best = a;
+                                    if (c == 0) break;
+                                }
                             }
                         }
-                        Quad &Q = g.quads[size_t(l * KQ + jj)];
+                        Quad &Q = out[size_t((l - l0) * KQ + jj)];
                         if (best >= 0) {
                             used[best] = 1;
                             Q.wl[kk] = std::exp2(g.w[best]);
                             Q.off[kk] = uint16_t(4 * g.col[best]);
-                            bt.add(Q.off[kk]);
                         } else {  // padding: weight 0, an address that costs nothing
                             Q.wl[kk] = 0.f;
-                            Q.off[kk] = uint16_t(4 * bt.least_loaded_bank());
-                            if (Q.off[kk] >= 4 * nrows) Q.off[kk] = 0;
-                            bt.add(Q.off[kk]);
+                            const int bnk = bt.least_loaded_bank();
+                            Q.off[kk] = uint16_t(4 * (bnk < nrows ? bnk : 0));
                         }
+                        bt.add(Q.off[kk]);
                     }
                 j = j1;
             }
         }
-        for (size_t i = 0; i < tab.size(); ++i) {
-            cyc_naive += tab0[i].cycles();
-            cyc_sched += tab[i].cycles();
-            ++n_instr;
-        }
+        int64_t cyc = 0;
+        for (auto &t : tab) cyc += t.cycles();
+        return cyc;
+    };
+    std::vector<Quad> qa, qb;
+    for (int64_t l0 = 0; l0 < lanes; l0 += 32) {  // one half-wave
+        const int64_t l1 = std::min(lanes, l0 + 32);
+        const int64_t ca = place(l0, l1, false, qa), cb = place(l0, l1, true, qb);
+        const std::vector<Quad> &best = cb < ca ? qb : qa;
+        for (int64_t l = l0; l < l1; ++l)
+            for (int j = 0; j < KQ && l * KQ + j < nq_total; ++j) g.quads[size_t(l * KQ + j)] = best[size_t((l - l0) * KQ + j)];
+        cyc_naive += double(ca);
+        cyc_sched += double(std::min(ca, cb));
+        n_instr += int64_t(KQ) * 4;
     }
     // lane masks: which quads continue the row of their predecessor inside the lane
     for (int64_t l = 0; l < lanes; ++l) {

@@ -164,3 +164,31 @@ def test_create_validation(mm):
                            ai32.ctypes.data, av.ctypes.data, s2p1.ctypes.data, 2, C.byref(h))
     assert rc == 0, lib.mm_last_error()
     lib.mm_fsm_destroy(h)
+
+
+@pytest.mark.parametrize("gname,kqs", [("l2r", (1, 2)), ("rand", (1, 3, 5)), ("ergodic", (1, 2, 7)), ("lfmmi", (9, 10, 13)),
+                                       ("lexicon", (5, 6)), ("wide", (1, 2, 11)), ("wsj_den", (13,))])
+def test_quad_form_products(mm, wl, gname, kqs):
+    """The quad form of the fast kernel (internal renumbering, quads of 4 arcs, bank-aware arc
+    placement, per-lane running sums, row totals from lane partials) preserves both products for
+    every lane geometry KQ: host evaluation through it == evaluation through the item form."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = {"l2r": lambda: wl.l2r_hmm(3), "rand": lambda: wl.random_fsm(40, 6, 3.0, seed=1),
+         "ergodic": lambda: wl.dense_ergodic(64), "lfmmi": lambda: wl.lfmmi_denominator(2000, 84),
+         "lexicon": lambda: wl.lexicon_fsm(1500, 30), "wide": lambda: wl.wide_row_fsm(),
+         "wsj_den": lambda: wl.load_npz_graph(os.path.join(here, "golden", "den_fsm_wsj.npz"))}[gname]()
+    f = wl.to_fsm(mm, g)
+    cf = mm.compile(f, mm.statemap(g.state2pdf, g.P))
+    rng = np.random.default_rng(3)
+    x = (3 * rng.standard_normal(f.S1)).astype(np.float32)
+    x[rng.random(f.S1) < 0.1] = -np.inf
+    for d in (0, 1):
+        ref, _ = cf.packed_product(x, d)
+        for KQ in kqs:
+            out, stats = cf.quad_product(x, d, KQ)
+            assert np.array_equal(np.isfinite(out), np.isfinite(ref))
+            m = np.isfinite(ref)
+            assert np.allclose(out[m], ref[m], rtol=1e-5, atol=2e-5), (gname, d, KQ)
+            assert stats[0] >= g.n_arcs / 4 and stats[1] == np.ceil(stats[0] / KQ)
+            # the bank-aware placement must not be worse than CSR order by more than noise
+            assert stats[3] <= stats[2] * 1.15 + 0.05

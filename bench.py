@@ -46,6 +46,22 @@ def make_workload(wl, name):
     raise SystemExit(f"unknown workload {name}")
 
 
+def measured_traffic(workload, B, N):
+    """HBM bytes per launch from the TCC PMC counters (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction of
+    MI355X_MICROARCH.md), collected with tools/traffic.sh in separate --pmc passes and committed under
+    profiles/ (rocprofv3 cannot wrap a bench run from inside).  Only quoted for the configuration it was
+    measured on; otherwise null."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{workload}.json"))):
+        best = json.load(open(f))
+        best["file"] = os.path.relpath(f, ROOT)
+    if best is None or (B, N) != (best.get("B", 256), best.get("N", 1500)):
+        return None, None
+    return best["hbm_bytes_per_launch"], best["file"]
+
+
 def algorithmic_bytes(g, B, N, lens_sum):
     """alpha written once and read once, emissions read twice,
     posteriors written once, graph read once per pass (shared)."""
@@ -147,6 +163,7 @@ def main():
     if rank == 0:
         abytes = algorithmic_bytes(g, B, N, frames_local)
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = (None, None) if args.varlen else measured_traffic(args.workload, B, N)
         out = {
             "metric": "pdfposteriors_frames_per_sec",
             "value": frames_total * args.steps / elapsed,
@@ -170,12 +187,13 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "mm_log_kernel<MODE_FB>",
+                "kernel": "mm_fbq_kernel<KQ> (quad kernel)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": abytes,
                 "kernel_ms": kernel_ms,
             },

@@ -109,7 +109,10 @@ struct mm_fsm_s {
     int64_t S1, nnz;
     int32_t P1;
     int S1p;
-    Csr mat[2];  // 0: T_hat' (forward), 1: T_hat (backward); engine-domain weights
+    Csr mat[2];   // 0: T_hat' (forward), 1: T_hat (backward); engine-domain weights
+    Csr qmat[2];  // the same restricted to the useful states (reachable from an initial state AND
+                  // able to reach the final state): the quad kernel computes posteriors, to which
+                  // the other states contribute exactly nothing
     Packed packed[2];
     bool fast_ok = false;  // the quad kernel's linear path is valid for this FSM
     int64_t nquads[2] = {0, 0};
@@ -331,9 +334,51 @@ int mm_fsm_create(int semiring, int64_t S1, int64_t nnz, int layout, int index_b
     f->mat[0] = fwd;
     f->mat[1] = bwd;
     if (semiring == MM_LOG) {
-        f->nquads[0] = count_quads(S1, fwd.rowptr);
-        f->nquads[1] = count_quads(S1, bwd.rowptr);
-        f->fast_ok = quad_range_ok(S1, fwd.rowptr, fwd.val, P1) && quad_range_ok(S1, bwd.rowptr, bwd.val, P1);
+        // useful states: forward reachable (over out-arcs = rows of T_hat) and co-reachable (over in-arcs)
+        std::vector<char> reach(S1, 0), coreach(S1, 0);
+        std::vector<int32_t> stack;
+        for (int64_t s = 0; s < S1; ++s)
+            if (f->init[s] > NINF) {
+                reach[s] = 1;
+                stack.push_back(int32_t(s));
+            }
+        while (!stack.empty()) {
+            const int32_t i = stack.back();
+            stack.pop_back();
+            for (int64_t k = bwd.rowptr[i]; k < bwd.rowptr[i + 1]; ++k)
+                if (bwd.val[k] > NINF && !reach[bwd.col[k]]) {
+                    reach[bwd.col[k]] = 1;
+                    stack.push_back(bwd.col[k]);
+                }
+        }
+        coreach[S1 - 1] = 1;
+        stack.push_back(int32_t(S1 - 1));
+        while (!stack.empty()) {
+            const int32_t j = stack.back();
+            stack.pop_back();
+            for (int64_t k = fwd.rowptr[j]; k < fwd.rowptr[j + 1]; ++k)
+                if (fwd.val[k] > NINF && !coreach[fwd.col[k]]) {
+                    coreach[fwd.col[k]] = 1;
+                    stack.push_back(fwd.col[k]);
+                }
+        }
+        for (int d = 0; d < 2; ++d) {
+            const Csr &m = d == 0 ? fwd : bwd;
+            Csr &q = f->qmat[d];
+            q.rowptr.assign(S1 + 1, 0);
+            for (int64_t r = 0; r < S1; ++r) {
+                if (reach[r] && coreach[r])
+                    for (int64_t k = m.rowptr[r]; k < m.rowptr[r + 1]; ++k)
+                        if (m.val[k] > NINF && reach[m.col[k]] && coreach[m.col[k]]) {
+                            q.col.push_back(m.col[k]);
+                            q.val.push_back(m.val[k]);
+                        }
+                q.rowptr[r + 1] = int64_t(q.col.size());
+            }
+            f->nquads[d] = count_quads(S1, q.rowptr);
+        }
+        f->fast_ok = quad_range_ok(S1, f->qmat[0].rowptr, f->qmat[0].val, P1) &&
+                     quad_range_ok(S1, f->qmat[1].rowptr, f->qmat[1].val, P1);
     }
     *out = f;
     return MM_OK;
@@ -392,12 +437,12 @@ static int quad_variant(mm_fsm_t f, int KQ, QuadVariant **out) {
     }
     QuadVariant *v = new QuadVariant();
     v->KQ = KQ;
-    v->g[0] = make_quads(f->S1, f->mat[0].rowptr, f->mat[0].col, f->mat[0].val, f->s2p, f->P1, false, KQ);
-    v->g[1] = make_quads(f->S1, f->mat[1].rowptr, f->mat[1].col, f->mat[1].val, f->s2p, f->P1, true, KQ);
+    v->g[0] = make_quads(f->S1, f->qmat[0].rowptr, f->qmat[0].col, f->qmat[0].val, f->s2p, f->P1, false, KQ);
+    v->g[1] = make_quads(f->S1, f->qmat[1].rowptr, f->qmat[1].col, f->qmat[1].val, f->s2p, f->P1, true, KQ);
     if (getenv("MM_VERBOSE"))
         for (int d = 0; d < 2; ++d)
             fprintf(stderr, "[mm] quad form dir %d: KQ %d, %zu quads, %lld arcs, LDS cycles/gather (bank model) %.2f -> %.2f\n",
-                    d, KQ, v->g[d].quads.size(), (long long)f->mat[d].rowptr[f->S1], v->g[d].conflict_before,
+                    d, KQ, v->g[d].quads.size(), (long long)f->qmat[d].rowptr[f->S1], v->g[d].conflict_before,
                     v->g[d].conflict_after);
     v->init_f.resize(f->S1);
     v->map_bf.resize(f->S1);

@@ -43,6 +43,17 @@
 
 namespace mm {
 
+// Pointers read out of the utterance descriptor are generic to the compiler; dereferencing them
+// as FLAT loads makes it wait vmcnt(0)/lgkmcnt(0) conservatively all over the frame loop.  They
+// always point to device global memory: say so.
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T *as_global(const T *p) {
+    return (const __attribute__((address_space(1))) T *)p;
+}
+
+typedef unsigned mm_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned mm_u32x2 __attribute__((ext_vector_type(2)));
+
 #define MM_Q_THR 8.0779357e-28f  // 2^-90
 #define MM_Q_BIG 1.2676506e30f   // 2^100
 #define MM_Q_RPT 3               // rows per thread whose alpha prefetch is carried in registers
@@ -74,8 +85,8 @@ struct QuadRegs {
 };
 
 __device__ __forceinline__ void load_quad(const Quad *q, float (&wl)[4], unsigned (&off)[2]) {
-    const uint4 a = *reinterpret_cast<const uint4 *>(q);
-    const uint2 b = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(q) + 16);
+    const mm_u32x4 a = *as_global(reinterpret_cast<const mm_u32x4 *>(q));
+    const mm_u32x2 b = *as_global(reinterpret_cast<const mm_u32x2 *>(reinterpret_cast<const char *>(q) + 16));
     wl[0] = __uint_as_float(a.x);
     wl[1] = __uint_as_float(a.y);
     wl[2] = __uint_as_float(a.z);
@@ -86,7 +97,7 @@ __device__ __forceinline__ void load_quad(const Quad *q, float (&wl)[4], unsigne
 
 template <int KQ>
 __device__ __forceinline__ void load_quad_regs(QuadRegs<KQ> &rg, const QuadDev &g, int tid) {
-    rg.mask = (tid * KQ < g.nq) ? g.quads[tid * KQ].mask : 0u;
+    rg.mask = (tid * KQ < g.nq) ? as_global(g.quads)[tid * KQ].mask : 0u;
     static_for<0, KQ>([&](auto J) {
         constexpr int j = decltype(J)::value;
         const int q = tid * KQ + j;
@@ -137,7 +148,7 @@ __device__ __forceinline__ void quad_phase(const QuadRegs<KQ> &rg, const QuadDev
     });
     // lanes beyond the register window ("virtual lanes"): the same, streamed from L2
     for (int v = NT + tid; v * KQ < g.nq; v += NT) {
-        const unsigned m = g.quads[v * KQ].mask;
+        const unsigned m = as_global(g.quads)[v * KQ].mask;
         float r = 0.f;
         for (int j = 0; j < KQ && v * KQ + j < g.nq; ++j) {
             float wl[4];
@@ -182,13 +193,16 @@ __device__ __forceinline__ float seg_sum(const float *qs, int q0, int q1) {
 
 // exact log-semiring row product from the log2 vector (two-pass log-sum-exp over the CSR row)
 __device__ __forceinline__ float exact_row(const QuadDev &g, int r, const float *a) {
-    const int b = g.rowptr[r], e = g.rowptr[r + 1];
+    const auto rowptr = as_global(g.rowptr);
+    const auto col = as_global(g.col);
+    const auto w = as_global(g.w);
+    const int b = rowptr[r], e = rowptr[r + 1];
     float m = MM_NINF;
-    for (int k = b; k < e; ++k) m = fmaxf(m, g.w[k] + a[g.col[k]]);
+    for (int k = b; k < e; ++k) m = fmaxf(m, w[k] + a[col[k]]);
     if (!(m > MM_NINF)) return MM_NINF;
     if (!(m < __builtin_inff())) return m;
     float s = 0.f;
-    for (int k = b; k < e; ++k) s += fast_exp2(g.w[k] + a[g.col[k]] - m);
+    for (int k = b; k < e; ++k) s += fast_exp2(w[k] + a[col[k]] - m);
     return m + fast_log2(s);
 }
 
@@ -201,17 +215,17 @@ __device__ __forceinline__ RowRecU load_rec(const float *recs, int i) {
     return RowRecU{r.x, r.y & 0xffffu};
 }
 
-// emission of frame n (1-based) for pdf slot q: expand() (src/inference.jl:54-60) + log2 scaling.
-// The load is issued here and the LDS store happens later, off the critical path.
-// Returns the RAW value: the scaling happens at the store (em_scale), so that nothing waits for the load here.
-// Branch-free (every thread loads a valid, clamped address) so that the compiler has no reason to wait.
-__device__ __forceinline__ float em_load(const float *Vb, long long vsn, int n, int len, int P, int q) {
-    const int nn = n < 1 ? 1 : n, qq = q < P ? q : P - 1;
-    const float raw = Vb[(long long)(nn - 1) * vsn + qq];
-    const bool real = q < P;
-    return (n <= len) ? (real ? raw : MM_NINF) : (real ? MM_NINF : 0.f);
+// Emissions of one frame (expand(), src/inference.jl:54-60): EVERY thread loads a raw value
+// from a clamped, always valid address -- no branch and no arithmetic at the load, so nothing
+// waits for it; em_value() turns it into the log2 emission when it is stored to LDS a phase later.
+__device__ __forceinline__ float em_load_raw(const float *Vb, long long vsn, int n, int N, int P, int q) {
+    const int nn = n < 1 ? 1 : (n > N ? N : n), qq = q < P ? q : P - 1;
+    return Vb[(long long)(nn - 1) * vsn + qq];
 }
-__device__ __forceinline__ float em_scale(float raw) { return raw * MM_LOG2E; }
+__device__ __forceinline__ float em_value(float raw, int n, int len, int P, int q) {
+    if (q < P) return (n <= len) ? raw * MM_LOG2E : MM_NINF;
+    return (n <= len) ? MM_NINF : 0.f;
+}
 
 // max over the per-wave maxima of the previous frame: one LDS read + a DPP row reduction
 __device__ __forceinline__ float part_max_dpp(const float *part, int NW, int lane) {
@@ -279,14 +293,14 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
     for (int q = tid; q < 2 * S1p; q += NT) abuf[q] = MM_NINF;
     for (int q = tid; q < S1p; q += NT) pbuf[q] = 0.f;
     for (int s = tid; s < S1; s += NT)
-        reinterpret_cast<uint2 *>(recs)[s] = reinterpret_cast<const uint2 *>(qf.recs)[s];
+        reinterpret_cast<mm_u32x2 *>(recs)[s] = as_global(reinterpret_cast<const mm_u32x2 *>(qf.recs))[s];
     __syncthreads();
     {   // frame 1: alpha_hat (*) lhs[:,1]   (src/inference.jl:68)
         float wm = MM_NINF;
         float *a1 = abuf + 1 * S1p;
         const float *e1 = em + 1 * P1p;
         for (int i = tid; i < S1; i += NT) {
-            const float v = u.init_f[i] + e1[load_rec(recs, i).pdf];
+            const float v = as_global(u.init_f)[i] + e1[load_rec(recs, i).pdf];
             a1[i] = v;
             pbuf[i] = fast_exp2(v);
             wm = fmaxf(wm, v);
@@ -299,6 +313,7 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
     load_quad_regs<KQ>(rg, qf, tid);
     __syncthreads();
     double C = 0.0;
+    float ev = 0.f;
     MM_STAMP_DECL;
     MM_STAMP_RESET;
     for (int n = 2; n <= NF; ++n) {
@@ -308,16 +323,23 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
         const float M = part_max_dpp(part + ((n - 1) & 1) * MM_MAX_WAVES, NW, lane);
         C += (double)M;
         if (tid == 0) wsC[n] = C;
-        // emissions of frame n+1: loaded now, stored to LDS at the end of the step (waves 0..P/64 only)
-        const bool em_wave = wave * 64 <= P;
-        float ev = 0.f;
-        if (em_wave) ev = em_load(Vb, p.vsn, n + 1 <= p.N ? n + 1 : p.N, n + 1 <= len ? len : -1, P, tid);
+        // emissions: frame n's raw values were loaded during step n-1 and are stored to LDS now (read
+        // after the next barrier); storing them here rather than at the end of the previous step keeps
+        // that step from waiting on its own alpha-store writes (vmcnt counts loads and stores in order)
+        if (n > 2) {
+            if (tid <= P) em[(n & 1) * P1p + tid] = em_value(ev, n, len, P, tid);
+            if (P >= NT) stage_em(em + (n & 1) * P1p + NT, Vb + NT, p.vsn, n, len, P - NT, tid, NT, MM_LOG2E);
+        }
+        ev = em_load_raw(Vb, p.vsn, n + 1, p.N, P, tid);
         MM_STAMP(0);
         quad_phase<KQ>(rg, qf, tid, NT, pbuf, qs);
         {   // frame n-1 leaves the chip once (coalesced, forward numbering) while frame n is computed
             float4 *dst = reinterpret_cast<float4 *>(wsA + (long long)(n - 1) * S1p);
             const float4 *src = reinterpret_cast<const float4 *>(ap);
-            for (int q = tid; q < (S1p >> 2); q += NT) dst[q] = src[q];
+            const int n4 = S1p >> 2;
+            if (tid < n4) dst[tid] = src[tid];
+            if (n4 > NT)
+                for (int q = tid + NT; q < n4; q += NT) dst[q] = src[q];
         }
         MM_STAMP(1);
         __syncthreads();
@@ -335,11 +357,15 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
 #pragma unroll
             for (int k = 0; k < MM_Q_RPT; ++k)
                 acc[k] = row_total<KQ>(qs, rec[k].q0nq & 0xffffu, rec[k].q0nq >> 16);
+            MM_STAMP(5);
 #pragma unroll
             for (int k = 0; k < MM_Q_RPT; ++k) {
                 const int i = tid + k * NT;
                 if (i < S1) {
                     const bool ok = acc[k] >= MM_Q_THR && acc[k] <= MM_Q_BIG;
+#ifdef MM_STAMPS
+                    stamp_acc[7] += __popcll(__ballot(!ok && (rec[k].q0nq >> 16)));
+#endif
                     float v = fast_log2(acc[k]);
                     if (__builtin_expect(!ok, 0)) v = (rec[k].q0nq >> 16) ? exact_row(qf, i, ap) : MM_NINF;
                     v = v + emn[rec[k].pdf] - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
@@ -349,6 +375,7 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
                 }
             }
         }
+        MM_STAMP(6);
         for (int i = tid + MM_Q_RPT * NT; i < S1; i += NT) {
             const RowRecU rec = load_rec(recs, i);
             const float acc = row_total<KQ>(qs, rec.q0nq & 0xffffu, rec.q0nq >> 16);
@@ -362,10 +389,6 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
         }
         wm = wave_max(wm);
         if (lane == 0) part[(n & 1) * MM_MAX_WAVES + wave] = wm;
-        if (n + 1 <= NF) {
-            if (tid <= P) em[((n + 1) & 1) * P1p + tid] = em_scale(ev);
-            if (P >= NT) stage_em(em + ((n + 1) & 1) * P1p + NT, Vb + NT, p.vsn, n + 1, len, P - NT, tid, NT, MM_LOG2E);
-        }
         MM_STAMP(3);
         __syncthreads();
         MM_STAMP(4);
@@ -391,15 +414,15 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
         pbuf[q] = 0.f;
         qrow[q] = 0.f;
     }
-    for (int s = tid; s < S1; s += NT) reinterpret_cast<uint2 *>(recs)[s] = reinterpret_cast<const uint2 *>(qb.recs)[s];
-    for (int s = tid; s < 2 * P1; s += NT) pdfse[s] = qb.pdfse[s];
+    for (int s = tid; s < S1; s += NT) reinterpret_cast<mm_u32x2 *>(recs)[s] = as_global(reinterpret_cast<const mm_u32x2 *>(qb.recs))[s];
+    for (int s = tid; s < 2 * P1; s += NT) pdfse[s] = as_global(qb.pdfse)[s];
     // this thread's rows tid, tid + NT, ...: where their alpha sits in the (forward-numbered) store
     int amap[MM_Q_RPT];
     float acur[MM_Q_RPT], anxt[MM_Q_RPT];
 #pragma unroll
     for (int k = 0; k < MM_Q_RPT; ++k) {
         const int i = tid + k * NT;
-        amap[k] = (i < S1) ? (int)u.map_bf[i] : 0;
+        amap[k] = (i < S1) ? (int)as_global(u.map_bf)[i] : 0;
         acur[k] = anxt[k] = 0.f;
         if (len >= 1 && i < S1) acur[k] = wsA[(long long)len * S1p + amap[k]];
     }
@@ -412,7 +435,7 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
     load_quad_regs<KQ>(rg, qb, tid);
     __syncthreads();
     double D = 0.0;
-    float tmin = (float)logZ2;
+    float tmin = (float)logZ2, evb = 0.f;
     MM_STAMP_RESET;
     for (int n = len; n >= 1; --n) {
         const float *yp = abuf + ((n + 1) & 1) * S1p;
@@ -422,9 +445,11 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
         D += (double)M;
         const double Cn = __hip_atomic_load(&wsC[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // prefetch of frame n-1 (alpha of this thread's rows, emissions): consumed one step later
-        const bool em_wave = wave * 64 <= P;
-        float ev = 0.f;
-        if (em_wave) ev = em_load(Vb, p.vsn, n - 1, len, P, tid);
+        if (n < len) {  // emissions of frame n, loaded during the previous step
+            if (tid <= P) em[(n & 1) * P1p + tid] = em_value(evb, n, len, P, tid);
+            if (P >= NT) stage_em(em + (n & 1) * P1p + NT, Vb + NT, p.vsn, n, len, P - NT, tid, NT, MM_LOG2E);
+        }
+        evb = em_load_raw(Vb, p.vsn, n - 1, p.N, P, tid);
         if (n - 1 >= 1) {
             const float *src = wsA + (long long)(n - 1) * S1p;
 #pragma unroll
@@ -467,7 +492,7 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
             float v = fast_log2(acc);
             if (__builtin_expect(!ok, 0)) v = (rec.q0nq >> 16) ? exact_row(qb, i, yp) : MM_NINF;
             const float beta = v - M;
-            qrow[i] = fast_exp2(wsA[(long long)n * S1p + u.map_bf[i]] + beta - kappa);
+            qrow[i] = fast_exp2(wsA[(long long)n * S1p + as_global(u.map_bf)[i]] + beta - kappa);
             const float y = beta + emn[rec.pdf];
             yn[i] = y;
             pbuf[i] = fast_exp2(y);
@@ -475,10 +500,6 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
         }
         wm = wave_max(wm);
         if (lane == 0) part[(n & 1) * MM_MAX_WAVES + wave] = wm;
-        if (n - 1 >= 1) {
-            if (tid <= P) em[((n - 1) & 1) * P1p + tid] = em_scale(ev);
-            if (P >= NT) stage_em(em + ((n - 1) & 1) * P1p + NT, Vb + NT, p.vsn, n - 1, len, P - NT, tid, NT, MM_LOG2E);
-        }
 #pragma unroll
         for (int k = 0; k < MM_Q_RPT; ++k) acur[k] = anxt[k];
         MM_STAMP(3);

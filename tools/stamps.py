@@ -38,6 +38,9 @@ for d, dn in enumerate(("forward", "backward")):
         x = s[:, :, d, k]
         print(f"  {nm:24s} {x.mean():8.0f} | {x[:, 0].mean():8.0f} | {x.mean(0).max():8.0f}   ({100 * x.mean() / tot:4.1f} %)")
     print(f"  total {tot:8.0f}")
+    print("  per-wave exact rows/step:", " ".join(f"{v:.2f}" for v in s[:, :, d, 7].mean(0)))
+    print("  per-wave B:totals     :", " ".join(f"{v:.0f}" for v in s[:, :, d, 5].mean(0)))
+    print("  per-wave B:finish     :", " ".join(f"{v:.0f}" for v in s[:, :, d, 6].mean(0)))
     print("  per-wave rows(phaseB):", " ".join(f"{v:.0f}" for v in s[:, :, d, 3].mean(0)))
     print("  per-wave quad_phase  :", " ".join(f"{v:.0f}" for v in s[:, :, d, 1].mean(0)))
     print("  per-wave top         :", " ".join(f"{v:.0f}" for v in s[:, :, d, 0].mean(0)))

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/traffic/{fetch,write,trace} into profiles/<tag>_traffic.json + a trimmed kernel-stats csv.
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports exactly half of the bytes of a wide
+coalesced streaming read (MI355X_MICROARCH.md, HBM): the read side is doubled, WRITE_SIZE is taken as is.
+usage: traffic_summary.py <tag> <workload>"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, workload = sys.argv[1], sys.argv[2]
+
+
+def counter(sub, name):
+    tot, n = 0.0, 0
+    for f in glob.glob(os.path.join(ROOT, "gpurun_out", "traffic", sub, "*", "*counter_collection.csv")):
+        per_dispatch = {}
+        for r in csv.DictReader(open(f)):
+            if "mm_" in r["Kernel_Name"] and r["Counter_Name"] == name:
+                per_dispatch[r["Dispatch_Id"]] = per_dispatch.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+        tot += sum(per_dispatch.values())
+        n += len(per_dispatch)
+    return tot / max(n, 1), n
+
+
+fetch_kib, nf = counter("fetch", "FETCH_SIZE")
+write_kib, nw = counter("write", "WRITE_SIZE")
+out = {
+    "workload": workload,
+    "kernel_launches_measured": [nf, nw],
+    "FETCH_SIZE_KiB_per_launch": fetch_kib,
+    "WRITE_SIZE_KiB_per_launch": write_kib,
+    "read_bytes_per_launch_corrected": 2.0 * fetch_kib * 1024,
+    "write_bytes_per_launch": write_kib * 1024,
+    "hbm_bytes_per_launch": 2.0 * fetch_kib * 1024 + write_kib * 1024,
+    "correction": "gfx950: FETCH_SIZE x2 for wide coalesced reads (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is",
+}
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_traffic_{workload}.json"), "w"), indent=1)
+print(json.dumps(out))
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", "traffic", "trace", "*", "*kernel_stats.csv")):
+    rows = list(csv.reader(open(f)))
+    with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats_{workload}.csv"), "w", newline="") as g:
+        w = csv.writer(g)
+        for r in rows:
+            r[0] = r[0][:100]
+            w.writerow(r)
+    print("\n".join(",".join(r[:4]) for r in rows[:3]))

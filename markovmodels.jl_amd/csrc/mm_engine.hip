@@ -476,6 +476,8 @@ static int quad_variant(mm_fsm_t f, int KQ, QuadVariant **out) {
         v->qdev[d].pdfse = reinterpret_cast<const unsigned short *>(base + o_pse[d]);
         v->qdev[d].nq = int(v->g[d].quads.size());
         v->qdev[d].fpos = v->g[d].pos[f->S1 - 1];
+        v->qdev[d].ncopy = v->g[d].ncopy;
+        v->qdev[d].pad = 0;
     }
     v->d_init_f = reinterpret_cast<const float *>(base + o_initf);
     v->d_map_bf = reinterpret_cast<const unsigned short *>(base + o_map);
@@ -538,7 +540,7 @@ int mm_debug_quad_product(mm_fsm_t f, int direction, int KQ, const float *in, fl
         for (int j = 0; j < KQ && l * KQ + j < nq; ++j) {
             const Quad &q = g.quads[size_t(l * KQ + j)];
             float s = 0.f;
-            for (int k = 0; k < 4; ++k) s = std::fmaf(q.wl[k], p[q.off[k] / 4], s);
+            for (int k = 0; k < 4; ++k) s = std::fmaf(q.wl[k], p[(q.off[k] / 4) % quad_pstride(f->S1p, g.ncopy)], s);
             run = ((mask >> j) & 1u) ? run + s : s;
             qs[size_t(l * KQ + j)] = run;
         }

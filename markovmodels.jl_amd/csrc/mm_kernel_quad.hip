@@ -66,7 +66,7 @@ __host__ __device__ inline LdsPlanQ lds_plan_q(int S1p, int P1p, int nqcap) {
     LdsPlanQ l;
     l.abuf = 0;
     l.pbuf = l.abuf + 2 * S1p;
-    l.qs = l.pbuf + S1p;
+    l.qs = l.pbuf + 2 * (((S1p + 31) & ~31) + 16);  // up to two bank-rotated copies of p (mm_pack.h quad_pstride)
     l.qrow = l.qs + ((nqcap + 3) & ~3);
     l.em = l.qrow + S1p;
     l.part = l.em + 2 * P1p;
@@ -287,11 +287,16 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
     float *wsA = p.ws_alpha + u.s1p_prefix * (long long)(p.N + 1);
     double *wsC = p.ws_c + (long long)b * (p.N + 2);
     QuadRegs<KQ> rg;
+    const int ncopy = qf.ncopy, pstride = quad_pstride(S1p, ncopy);
+    auto put_p = [&](int i, float v) {  // every copy of the linear vector
+        pbuf[i] = v;
+        if (ncopy > 1) pbuf[pstride + i] = v;
+    };
 
     // ---------------- forward: alpha-recursion (src/inference.jl:62-74), forward numbering ----------------
     stage_em(em + 1 * P1p, Vb, p.vsn, 1, len, P, tid, NT, MM_LOG2E);
     for (int q = tid; q < 2 * S1p; q += NT) abuf[q] = MM_NINF;
-    for (int q = tid; q < S1p; q += NT) pbuf[q] = 0.f;
+    for (int q = tid; q < 2 * (((S1p + 31) & ~31) + 16); q += NT) pbuf[q] = 0.f;
     for (int s = tid; s < S1; s += NT)
         reinterpret_cast<mm_u32x2 *>(recs)[s] = as_global(reinterpret_cast<const mm_u32x2 *>(qf.recs))[s];
     __syncthreads();
@@ -302,7 +307,7 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
         for (int i = tid; i < S1; i += NT) {
             const float v = as_global(u.init_f)[i] + e1[load_rec(recs, i).pdf];
             a1[i] = v;
-            pbuf[i] = fast_exp2(v);
+            put_p(i, fast_exp2(v));
             wm = fmaxf(wm, v);
         }
         wm = wave_max(wm);
@@ -354,23 +359,28 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
                 rec[k] = load_rec(recs, i < S1 ? i : 0);
                 if (i >= S1) rec[k].q0nq = 0u;  // no quads: nothing to read
             }
+            float e[MM_Q_RPT];
+#pragma unroll
+            for (int k = 0; k < MM_Q_RPT; ++k) e[k] = emn[rec[k].pdf];
+            // a row whose emission is zero(K) this frame is zero whatever its sum is (the phony final
+            // state, whose row is by far the longest, for every frame but the last): do not read it
 #pragma unroll
             for (int k = 0; k < MM_Q_RPT; ++k)
-                acc[k] = row_total<KQ>(qs, rec[k].q0nq & 0xffffu, rec[k].q0nq >> 16);
+                acc[k] = e[k] > MM_NINF ? row_total<KQ>(qs, rec[k].q0nq & 0xffffu, rec[k].q0nq >> 16) : 0.f;
             MM_STAMP(5);
 #pragma unroll
             for (int k = 0; k < MM_Q_RPT; ++k) {
                 const int i = tid + k * NT;
                 if (i < S1) {
-                    const bool ok = acc[k] >= MM_Q_THR && acc[k] <= MM_Q_BIG;
+                    const bool ok = (acc[k] >= MM_Q_THR && acc[k] <= MM_Q_BIG) || !(e[k] > MM_NINF);
 #ifdef MM_STAMPS
                     stamp_acc[7] += __popcll(__ballot(!ok && (rec[k].q0nq >> 16)));
 #endif
                     float v = fast_log2(acc[k]);
                     if (__builtin_expect(!ok, 0)) v = (rec[k].q0nq >> 16) ? exact_row(qf, i, ap) : MM_NINF;
-                    v = v + emn[rec[k].pdf] - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
+                    v = v + e[k] - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
                     an[i] = v;
-                    pbuf[i] = fast_exp2(v);
+                    put_p(i, fast_exp2(v));
                     wm = fmaxf(wm, v);
                 }
             }
@@ -384,7 +394,7 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
             if (__builtin_expect(!ok, 0)) v = (rec.q0nq >> 16) ? exact_row(qf, i, ap) : MM_NINF;
             v = v + emn[rec.pdf] - M;
             an[i] = v;
-            pbuf[i] = fast_exp2(v);
+            put_p(i, fast_exp2(v));
             wm = fmaxf(wm, v);
         }
         wm = wave_max(wm);
@@ -410,10 +420,8 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
         return;
     }
     for (int q = tid; q < 2 * S1p; q += NT) abuf[q] = MM_NINF;
-    for (int q = tid; q < S1p; q += NT) {
-        pbuf[q] = 0.f;
-        qrow[q] = 0.f;
-    }
+    for (int q = tid; q < 2 * (((S1p + 31) & ~31) + 16); q += NT) pbuf[q] = 0.f;
+    for (int q = tid; q < S1p; q += NT) qrow[q] = 0.f;
     for (int s = tid; s < S1; s += NT) reinterpret_cast<mm_u32x2 *>(recs)[s] = as_global(reinterpret_cast<const mm_u32x2 *>(qb.recs))[s];
     for (int s = tid; s < 2 * P1; s += NT) pdfse[s] = as_global(qb.pdfse)[s];
     // this thread's rows tid, tid + NT, ...: where their alpha sits in the (forward-numbered) store
@@ -429,7 +437,7 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
     __syncthreads();
     if (tid == 0) {  // frame len+1: B (*) lhs = one for the final state only
         abuf[(NF & 1) * S1p + qb.fpos] = 0.f;
-        pbuf[qb.fpos] = 1.f;
+        put_p(qb.fpos, 1.f);
     }
     if (len >= 1) stage_em(em + (len & 1) * P1p, Vb, p.vsn, len, len, P, tid, NT, MM_LOG2E);
     load_quad_regs<KQ>(rg, qb, tid);
@@ -481,7 +489,7 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
                 qrow[i] = fast_exp2(acur[k] + beta - kappa);  // state_A .* state_B / Z
                 const float y = beta + emn[rec.pdf];
                 yn[i] = y;
-                pbuf[i] = fast_exp2(y);
+                put_p(i, fast_exp2(y));
                 wm = fmaxf(wm, y);
             }
         }
@@ -495,7 +503,7 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
             qrow[i] = fast_exp2(wsA[(long long)n * S1p + as_global(u.map_bf)[i]] + beta - kappa);
             const float y = beta + emn[rec.pdf];
             yn[i] = y;
-            pbuf[i] = fast_exp2(y);
+            put_p(i, fast_exp2(y));
             wm = fmaxf(wm, y);
         }
         wm = wave_max(wm);

@@ -52,7 +52,9 @@ struct QuadDev {  // one direction in quad form, internal numbering (mm_pack.h Q
     const float *w;
     const unsigned short *pdfse;  // [2 * P1] (first, end) internal positions of each pdf (backward only)
     int nq;
-    int fpos;  // internal position of the phony final state
+    int fpos;   // internal position of the phony final state
+    int ncopy;  // LDS copies of the linear vector the quad offsets refer to (mm_pack.h quad_pstride)
+    int pad;
 };
 
 struct UttDesc {

@@ -146,6 +146,41 @@ struct BankTable {
     }
 };
 
+// the same with multiplicities, so that addresses can be removed again (local search)
+struct CountedBanks {
+    struct E {
+        uint16_t addr;
+        uint16_t n;
+    };
+    std::vector<E> bank[32];
+    void add(uint16_t a) {
+        auto &v = bank[(a >> 2) & 31];
+        for (auto &e : v)
+            if (e.addr == a) {
+                ++e.n;
+                return;
+            }
+        v.push_back(E{a, 1});
+    }
+    void remove(uint16_t a) {
+        auto &v = bank[(a >> 2) & 31];
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].addr == a) {
+                if (--v[i].n == 0) {
+                    v[i] = v.back();
+                    v.pop_back();
+                }
+                return;
+            }
+    }
+    int cycles() const {
+        size_t m = 1;
+        for (auto &v : bank) m = std::max(m, v.size());
+        return int(m);
+    }
+    bool conflicted(uint16_t a) const { return bank[(a >> 2) & 31].size() > 1; }
+};
+
 }  // namespace
 
 int64_t count_quads(int64_t nrows, const std::vector<int64_t> &rowptr) {
@@ -167,6 +202,9 @@ QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const st
                      int KQ) {
     QuadGraph g;
     g.KQ = KQ;
+    const int S1p = int((nrows + 3) / 4 * 4);
+    g.ncopy = quad_ncopy(S1p);
+    const int pstride = quad_pstride(S1p, g.ncopy);
     auto nq_of = [&](int64_t r) { return (rowptr[r + 1] - rowptr[r] + 3) / 4; };
     // ---- internal numbering
     g.order.resize(nrows);
@@ -266,17 +304,21 @@ QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const st
                     for (int kk = 0; kk < 4; ++kk) {
                         BankTable &bt = tab[size_t(jj) * 4 + kk];
                         int64_t best = -1;
+                        int best_copy = 0;
                         if (!greedy) {
                             if (next < a1) best = next++;
                         } else {
                             int best_cost = 1 << 30;
-                            for (int64_t a = a0; a < a1; ++a) {
+                            for (int64_t a = a0; a < a1 && best_cost > 0; ++a) {
                                 if (used[a]) continue;
-                                const int c = bt.cost_of(uint16_t(4 * g.col[a]));
-                                if (c < best_cost) {
-                                    best_cost = c;
-                                    best = a;
-                                    if (c == 0) break;
+                                for (int cp = 0; cp < g.ncopy; ++cp) {
+                                    const int c = bt.cost_of(uint16_t(4 * (g.col[a] + cp * pstride)));
+                                    if (c < best_cost) {
+                                        best_cost = c;
+                                        best = a;
+                                        best_copy = cp;
+                                        if (c == 0) break;
+                                    }
                                 }
                             }
                         }
@@ -284,7 +326,7 @@ QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const st
                         if (best >= 0) {
                             used[best] = 1;
                             Q.wl[kk] = std::exp2(g.w[best]);
-                            Q.off[kk] = uint16_t(4 * g.col[best]);
+                            Q.off[kk] = uint16_t(4 * (g.col[best] + best_copy * pstride));
                         } else {  // padding: weight 0, an address that costs nothing
                             Q.wl[kk] = 0.f;
                             const int bnk = bt.least_loaded_bank();
@@ -306,8 +348,73 @@ QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const st
         const std::vector<Quad> &best = cb < ca ? qb : qa;
         for (int64_t l = l0; l < l1; ++l)
             for (int j = 0; j < KQ && l * KQ + j < nq_total; ++j) g.quads[size_t(l * KQ + j)] = best[size_t((l - l0) * KQ + j)];
+        // local search on the kept placement: flip the copy of a conflicting slot, or swap it with
+        // another slot of the same row segment of its lane, whenever that lowers the modelled cycles
+        std::vector<CountedBanks> cb2(size_t(KQ) * 4);
+        auto Qat = [&](int64_t l, int j) -> Quad & { return g.quads[size_t(l * KQ + j)]; };
+        for (int64_t l = l0; l < l1; ++l)
+            for (int j = 0; j < KQ && l * KQ + j < nq_total; ++j)
+                for (int k = 0; k < 4; ++k) cb2[size_t(j) * 4 + k].add(Qat(l, j).off[k]);
+        for (int pass = 0; pass < 4; ++pass) {
+            bool improved = false;
+            for (int64_t l = l0; l < l1; ++l)
+                for (int j = 0; j < KQ && l * KQ + j < nq_total; ++j) {
+                    const int32_t row = qrow[l * KQ + j];
+                    for (int k = 0; k < 4; ++k) {
+                        CountedBanks &A = cb2[size_t(j) * 4 + k];
+                        uint16_t a = Qat(l, j).off[k];
+                        if (!A.conflicted(a)) continue;
+                        // (1) the other copy of the same source
+                        if (g.ncopy > 1 && Qat(l, j).wl[k] != 0.f) {
+                            const int cpy = int(a / 4) / pstride;
+                            const uint16_t alt = uint16_t(a + (cpy ? -4 * pstride : 4 * pstride));
+                            const int before = A.cycles();
+                            A.remove(a);
+                            A.add(alt);
+                            if (A.cycles() < before || (A.cycles() == before && !A.conflicted(alt))) {
+                                Qat(l, j).off[k] = alt;
+                                improved = true;
+                                a = alt;
+                                if (!A.conflicted(a)) continue;
+                            } else {
+                                A.remove(alt);
+                                A.add(a);
+                            }
+                        }
+                        // (2) swap with another slot of the same row segment in this lane
+                        bool done = false;
+                        for (int j2 = 0; j2 < KQ && l * KQ + j2 < nq_total && !done; ++j2) {
+                            if (qrow[l * KQ + j2] != row) continue;
+                            for (int k2 = 0; k2 < 4 && !done; ++k2) {
+                                if (j2 == j && k2 == k) continue;
+                                CountedBanks &B = cb2[size_t(j2) * 4 + k2];
+                                const uint16_t b = Qat(l, j2).off[k2];
+                                const int before = A.cycles() + (&A == &B ? 0 : B.cycles());
+                                A.remove(a);
+                                B.remove(b);
+                                A.add(b);
+                                B.add(a);
+                                const int after = A.cycles() + (&A == &B ? 0 : B.cycles());
+                                if (after < before) {
+                                    std::swap(Qat(l, j).off[k], Qat(l, j2).off[k2]);
+                                    std::swap(Qat(l, j).wl[k], Qat(l, j2).wl[k2]);
+                                    improved = done = true;
+                                } else {
+                                    A.remove(b);
+                                    B.remove(a);
+                                    A.add(a);
+                                    B.add(b);
+                                }
+                            }
+                        }
+                    }
+                }
+            if (!improved) break;
+        }
+        int64_t cfinal = 0;
+        for (auto &t : cb2) cfinal += t.cycles();
         cyc_naive += double(ca);
-        cyc_sched += double(std::min(ca, cb));
+        cyc_sched += double(cfinal);
         n_instr += int64_t(KQ) * 4;
     }
     // lane masks: which quads continue the row of their predecessor inside the lane

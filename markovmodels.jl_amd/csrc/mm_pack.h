@@ -83,6 +83,17 @@ struct RowRec {  // one per internal position: what the row-finishing thread nee
     uint16_t pad;
 };
 
+// The linear vector p is kept in `ncopy` LDS copies, copy c at float offset c * quad_pstride(): the
+// copies are rotated against each other by 32 / ncopy banks, so every arc can be read from ncopy
+// different banks and the placement picks the one that is free in its gather instruction.
+#ifdef __HIPCC__
+#define MM_HD __host__ __device__
+#else
+#define MM_HD
+#endif
+MM_HD inline int quad_pstride(int S1p, int ncopy) { return (S1p + 31) / 32 * 32 + 32 / ncopy; }
+inline int quad_ncopy(int64_t S1p) { return 4 * (int64_t(quad_pstride(int(S1p), 2)) + S1p) <= 65535 ? 2 : 1; }
+
 struct QuadGeometry {
     int KQ;  // quads per lane held in registers
     int NW;  // wavefronts per workgroup
@@ -100,6 +111,7 @@ struct QuadGraph {
     std::vector<float> w;
     std::vector<uint16_t> pdfstart;  // [P1 + 1] first internal position of each pdf (pdf-major order only)
     int KQ = 1;                      // quads per lane this form was laid out for
+    int ncopy = 1;                   // LDS copies of p the offsets refer to
     double conflict_before = 0, conflict_after = 0;  // mean LDS cycles per gather instruction (model)
 };
 

@@ -203,15 +203,23 @@ static size_t quad_lds_bytes(mm_batch_t h, int KQ, int NW) {
     return size_t(lds_plan_q(h->max_S1p, P1p, std::max(vl, 64 * NW) * KQ).total) * 4;
 }
 
-template <int KQ>
-static int launch_quad_kq(mm_batch_t h, const RunParams &p, int NW, void *stream) {
+template <int KQ, int RPT>
+static int launch_quad_kq_rpt(mm_batch_t h, const RunParams &p, int NW, void *stream) {
     const size_t lds = quad_lds_bytes(h, KQ, NW);
-    auto kernel = mm_fbq_kernel<KQ>;
+    auto kernel = mm_fbq_kernel<KQ, RPT>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 int(lds)));
     hipLaunchKernelGGL(kernel, dim3(unsigned(h->B)), dim3(64 * NW), lds, static_cast<hipStream_t>(stream), p);
     HIP_TRY(hipGetLastError());
     return MM_OK;
+}
+
+template <int KQ>
+static int launch_quad_kq(mm_batch_t h, const RunParams &p, int NW, void *stream) {
+    // rows per thread = ceil(max S1 / threads): 2 register-carried rows when that is enough
+    const int rows = (h->max_S1p + 64 * NW - 1) / (64 * NW);
+    if (rows <= 2) return launch_quad_kq_rpt<KQ, 2>(h, p, NW, stream);
+    return launch_quad_kq_rpt<KQ, 3>(h, p, NW, stream);
 }
 
 static bool quad_kernel_usable(mm_batch_t h) {
@@ -234,6 +242,13 @@ static int launch_quad(mm_batch_t h, const RunParams &p, void *stream) {
         case 10: return launch_quad_kq<10>(h, p, NW, stream);
         case 11: return launch_quad_kq<11>(h, p, NW, stream);
         case 13: return launch_quad_kq<13>(h, p, NW, stream);
+        // 8-wave geometries: twice the quads per lane in twice the registers (more gathers in flight)
+        case 15: return launch_quad_kq<15>(h, p, std::min(NW, 8), stream);
+        case 17: return launch_quad_kq<17>(h, p, std::min(NW, 8), stream);
+        case 19: return launch_quad_kq<19>(h, p, std::min(NW, 8), stream);
+        case 21: return launch_quad_kq<21>(h, p, std::min(NW, 8), stream);
+        case 23: return launch_quad_kq<23>(h, p, std::min(NW, 8), stream);
+        case 25: return launch_quad_kq<25>(h, p, std::min(NW, 8), stream);
         default: return MM_ERR_UNSUPPORTED;
     }
 }
@@ -521,7 +536,7 @@ int mm_debug_packed_product(mm_fsm_t f, int direction, const float *in, float *o
 }
 
 int mm_debug_quad_product(mm_fsm_t f, int direction, int KQ, const float *in, float *out, double stats[4]) {
-    if (!f || !in || !out || direction < 0 || direction > 1 || KQ < 1 || KQ > 16)
+    if (!f || !in || !out || direction < 0 || direction > 1 || KQ < 1 || KQ > 32)
         return fail(MM_ERR_INVALID, "mm_debug_quad_product: bad argument");
     if (f->semiring != MM_LOG) return fail(MM_ERR_INVALID, "mm_debug_quad_product: log-semiring FSMs only");
     const Csr &m = f->mat[direction];
@@ -589,9 +604,10 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         QuadGeometry geo = pick_quad_geometry(nq_max);
         if (const char *e = getenv("MM_KQ")) {
             int v = atoi(e);
-            if (v >= 1 && v <= 13) geo.KQ = v;
+            if (v >= 1 && v <= 25) geo.KQ = v;
         }
-        geo.NW = int(std::min<int64_t>(MM_MAX_WAVES, std::max<int64_t>(1, (nq_max + 64 * geo.KQ - 1) / (64 * geo.KQ))));
+        geo.NW = int(std::min<int64_t>(geo.KQ > 13 ? 8 : MM_MAX_WAVES,
+                                       std::max<int64_t>(1, (nq_max + 64 * geo.KQ - 1) / (64 * geo.KQ))));
         if (const char *e = getenv("MM_NWAVES")) {
             int v = atoi(e);
             if (v >= 1 && v <= MM_MAX_WAVES) geo.NW = v;

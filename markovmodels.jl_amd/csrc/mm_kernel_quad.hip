@@ -56,7 +56,6 @@ typedef unsigned mm_u32x2 __attribute__((ext_vector_type(2)));
 
 #define MM_Q_THR 8.0779357e-28f  // 2^-90
 #define MM_Q_BIG 1.2676506e30f   // 2^100
-#define MM_Q_RPT 3               // rows per thread whose alpha prefetch is carried in registers
 
 struct LdsPlanQ {
     int abuf, pbuf, qs, qrow, em, part, recs, pdfse, psum, total;
@@ -64,9 +63,10 @@ struct LdsPlanQ {
 // nqcap = quad slots: threads * KQ, or more when the graph overflows the register window
 __host__ __device__ inline LdsPlanQ lds_plan_q(int S1p, int P1p, int nqcap) {
     LdsPlanQ l;
-    l.abuf = 0;
-    l.pbuf = l.abuf + 2 * S1p;
-    l.qs = l.pbuf + 2 * (((S1p + 31) & ~31) + 16);  // up to two bank-rotated copies of p (mm_pack.h quad_pstride)
+    // p first: the gather offsets held in registers are then absolute LDS addresses (no base add)
+    l.pbuf = 0;
+    l.abuf = l.pbuf + 2 * (((S1p + 31) & ~31) + 16);  // up to two bank-rotated copies of p (mm_pack.h quad_pstride)
+    l.qs = l.abuf + 2 * S1p;
     l.qrow = l.qs + ((nqcap + 3) & ~3);
     l.em = l.qrow + S1p;
     l.part = l.em + 2 * P1p;
@@ -227,12 +227,29 @@ __device__ __forceinline__ float em_value(float raw, int n, int len, int P, int 
     return (n <= len) ? MM_NINF : 0.f;
 }
 
-// max over the per-wave maxima of the previous frame: one LDS read + a DPP row reduction
+// wave-wide max: 4 DPP steps inside the 16-lane rows, then the 4 row results through readlane
+// (no LDS crossbar round trips)
+__device__ __forceinline__ float wave_max_rl(float v) {
+    v = grp_max(v, 4);
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// max over the per-wave maxima of the previous frame (the lagged normaliser): one LDS read + a
+// DPP row reduction
 __device__ __forceinline__ float part_max_dpp(const float *part, int NW, int lane) {
     float v = (lane < NW) ? part[lane] : MM_NINF;
     v = grp_max(v, 4);
     v = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
     return (v > MM_NINF) ? v : 0.f;
+}
+__device__ __forceinline__ void part_put(float *part, int wave, int lane, float wmax) {
+    wmax = wave_max_rl(wmax);
+    if (lane == 0) part[wave] = wmax;
 }
 
 // C' * (A .* B) (src/inference.jl:154-155) without atomics: states of one pdf are contiguous in the
@@ -264,8 +281,10 @@ __device__ __forceinline__ float finish_frame(const float *psum, int P1, int P, 
     return tot;
 }
 
-template <int KQ>
-__global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
+// KQ: quads per lane held in registers.  RPT: rows per thread handled by the unrolled row-finishing code
+// (and whose alpha prefetch is carried in registers); more rows per thread go through a generic loop.
+template <int KQ, int RPT>
+__global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams p) {
     extern __shared__ float lds[];
     const int b = blockIdx.x;
     const UttDesc &u = p.utts[b];
@@ -285,7 +304,8 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
     float *psum = lds + L.psum;
     const float *Vb = p.V + (long long)b * p.vsb;
     float *wsA = p.ws_alpha + u.s1p_prefix * (long long)(p.N + 1);
-    double *wsC = p.ws_c + (long long)b * (p.N + 2);
+    // per-frame forward normalisers M_k (floats; the double workspace row of this utterance is reused)
+    float *wsM = reinterpret_cast<float *>(p.ws_c + (long long)b * (p.N + 2));
     QuadRegs<KQ> rg;
     const int ncopy = qf.ncopy, pstride = quad_pstride(S1p, ncopy);
     auto put_p = [&](int i, float v) {  // every copy of the linear vector
@@ -310,10 +330,8 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
             put_p(i, fast_exp2(v));
             wm = fmaxf(wm, v);
         }
-        wm = wave_max(wm);
-        if (lane == 0) part[1 * MM_MAX_WAVES + wave] = wm;
+        part_put(part + 1 * MM_MAX_WAVES, wave, lane, wm);
         if (NF >= 2) stage_em(em + 0 * P1p, Vb, p.vsn, 2, len, P, tid, NT, MM_LOG2E);
-        if (tid == 0) wsC[1] = 0.0;
     }
     load_quad_regs<KQ>(rg, qf, tid);
     __syncthreads();
@@ -325,9 +343,6 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
         const float *ap = abuf + ((n - 1) & 1) * S1p;
         float *an = abuf + (n & 1) * S1p;
         const float *emn = em + (n & 1) * P1p;
-        const float M = part_max_dpp(part + ((n - 1) & 1) * MM_MAX_WAVES, NW, lane);
-        C += (double)M;
-        if (tid == 0) wsC[n] = C;
         // emissions: frame n's raw values were loaded during step n-1 and are stored to LDS now (read
         // after the next barrier); storing them here rather than at the end of the previous step keeps
         // that step from waiting on its own alpha-store writes (vmcnt counts loads and stores in order)
@@ -346,30 +361,35 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
             if (n4 > NT)
                 for (int q = tid + NT; q < n4; q += NT) dst[q] = src[q];
         }
+        // everything phase B needs that does not depend on this frame's sums is read BEFORE the
+        // barrier: the normaliser, the row records and the emissions of this thread's rows
+        const float M = part_max_dpp(part + ((n - 1) & 1) * MM_MAX_WAVES, NW, lane);
+        C += (double)M;
+        if (tid == 0) wsM[n - 1] = M;  // M_{n-1}: C_n = sum_{k<n} M_k
         MM_STAMP(1);
         __syncthreads();
         MM_STAMP(2);
         float wm = MM_NINF;
-        {   // this thread's rows tid, tid + NT, ...: the loads of the first MM_Q_RPT rows are issued together
-            RowRecU rec[MM_Q_RPT];
-            float acc[MM_Q_RPT];
+        {   // this thread's rows tid, tid + NT, ...
+            RowRecU rec[RPT];
+            float e[RPT];
 #pragma unroll
-            for (int k = 0; k < MM_Q_RPT; ++k) {
+            for (int k = 0; k < RPT; ++k) {
                 const int i = tid + k * NT;
                 rec[k] = load_rec(recs, i < S1 ? i : 0);
                 if (i >= S1) rec[k].q0nq = 0u;  // no quads: nothing to read
             }
-            float e[MM_Q_RPT];
 #pragma unroll
-            for (int k = 0; k < MM_Q_RPT; ++k) e[k] = emn[rec[k].pdf];
+            for (int k = 0; k < RPT; ++k) e[k] = emn[rec[k].pdf];
+            float acc[RPT];
             // a row whose emission is zero(K) this frame is zero whatever its sum is (the phony final
             // state, whose row is by far the longest, for every frame but the last): do not read it
 #pragma unroll
-            for (int k = 0; k < MM_Q_RPT; ++k)
+            for (int k = 0; k < RPT; ++k)
                 acc[k] = e[k] > MM_NINF ? row_total<KQ>(qs, rec[k].q0nq & 0xffffu, rec[k].q0nq >> 16) : 0.f;
             MM_STAMP(5);
 #pragma unroll
-            for (int k = 0; k < MM_Q_RPT; ++k) {
+            for (int k = 0; k < RPT; ++k) {
                 const int i = tid + k * NT;
                 if (i < S1) {
                     const bool ok = (acc[k] >= MM_Q_THR && acc[k] <= MM_Q_BIG) || !(e[k] > MM_NINF);
@@ -377,28 +397,31 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
                     stamp_acc[7] += __popcll(__ballot(!ok && (rec[k].q0nq >> 16)));
 #endif
                     float v = fast_log2(acc[k]);
-                    if (__builtin_expect(!ok, 0)) v = (rec[k].q0nq >> 16) ? exact_row(qf, i, ap) : MM_NINF;
+                    // exact fallback, unless the sum is exactly 0 and no source can be alive-but-underflowed
+                    if (__builtin_expect(!ok, 0))
+                        v = (rec[k].q0nq >> 16) ? exact_row(qf, i, ap) : MM_NINF;
                     v = v + e[k] - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
+                    const float pv = fast_exp2(v);
                     an[i] = v;
-                    put_p(i, fast_exp2(v));
+                    put_p(i, pv);
                     wm = fmaxf(wm, v);
                 }
             }
         }
         MM_STAMP(6);
-        for (int i = tid + MM_Q_RPT * NT; i < S1; i += NT) {
+        for (int i = tid + RPT * NT; i < S1; i += NT) {
             const RowRecU rec = load_rec(recs, i);
             const float acc = row_total<KQ>(qs, rec.q0nq & 0xffffu, rec.q0nq >> 16);
             const bool ok = acc >= MM_Q_THR && acc <= MM_Q_BIG;
             float v = fast_log2(acc);
             if (__builtin_expect(!ok, 0)) v = (rec.q0nq >> 16) ? exact_row(qf, i, ap) : MM_NINF;
             v = v + emn[rec.pdf] - M;
+            const float pv = fast_exp2(v);
             an[i] = v;
-            put_p(i, fast_exp2(v));
+            put_p(i, pv);
             wm = fmaxf(wm, v);
         }
-        wm = wave_max(wm);
-        if (lane == 0) part[(n & 1) * MM_MAX_WAVES + wave] = wm;
+        part_put(part + (n & 1) * MM_MAX_WAVES, wave, lane, wm);
         MM_STAMP(3);
         __syncthreads();
         MM_STAMP(4);
@@ -408,7 +431,8 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
         for (int k = 0; k < 8; ++k) p.dbg[((long long)b * MM_MAX_WAVES + wave) * 16 + k] = stamp_acc[k];
     for (int k = 0; k < 8; ++k) stamp_acc[k] = 0;
 #endif
-    const double logZ2 = (double)abuf[(NF & 1) * S1p + qf.fpos] + C;
+    const float afin = abuf[(NF & 1) * S1p + qf.fpos];  // normalised log2 value of the final state, last frame
+    const double logZ2 = (double)afin + C;
     __syncthreads();
 
     // ---------------- backward: beta-recursion fused with the combine, backward numbering ----------------
@@ -425,10 +449,10 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
     for (int s = tid; s < S1; s += NT) reinterpret_cast<mm_u32x2 *>(recs)[s] = as_global(reinterpret_cast<const mm_u32x2 *>(qb.recs))[s];
     for (int s = tid; s < 2 * P1; s += NT) pdfse[s] = as_global(qb.pdfse)[s];
     // this thread's rows tid, tid + NT, ...: where their alpha sits in the (forward-numbered) store
-    int amap[MM_Q_RPT];
-    float acur[MM_Q_RPT], anxt[MM_Q_RPT];
+    int amap[RPT];
+    float acur[RPT], anxt[RPT];
 #pragma unroll
-    for (int k = 0; k < MM_Q_RPT; ++k) {
+    for (int k = 0; k < RPT; ++k) {
         const int i = tid + k * NT;
         amap[k] = (i < S1) ? (int)as_global(u.map_bf)[i] : 0;
         acur[k] = anxt[k] = 0.f;
@@ -442,16 +466,23 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
     if (len >= 1) stage_em(em + (len & 1) * P1p, Vb, p.vsn, len, len, P, tid, NT, MM_LOG2E);
     load_quad_regs<KQ>(rg, qb, tid);
     __syncthreads();
-    double D = 0.0;
-    float tmin = (float)logZ2, evb = 0.f;
+    // kappa_n = log2 Z - C_n - D_n = afin + G_n with G_n = sum_{k>=n} M_k(forward) - sum M(backward):
+    // accumulated incrementally (double; its magnitude stays small), no per-frame double loads
+    double G = 0.0;
+    float tmin = 0.f, evb = 0.f;  // min over frames of log2 of the per-frame sum (relative to log2 Z)
+    float mfn = len >= 1 ? wsM[len] : 0.f;  // forward normaliser M_len, then prefetched one step ahead
+    double *zslot = p.ws_c + (long long)b * (p.N + 2) + (p.N + 1);  // log2 Z parked in the row's last slot
+    if (tid == 0) {
+        wsM[0] = 0.f;
+        *zslot = logZ2;
+    }
     MM_STAMP_RESET;
     for (int n = len; n >= 1; --n) {
         const float *yp = abuf + ((n + 1) & 1) * S1p;
         float *yn = abuf + (n & 1) * S1p;
         const float *emn = em + (n & 1) * P1p;
-        const float M = (n == len) ? 0.f : part_max_dpp(part + ((n + 1) & 1) * MM_MAX_WAVES, NW, lane);
-        D += (double)M;
-        const double Cn = __hip_atomic_load(&wsC[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float mf = mfn;                 // M_n (forward)
+        mfn = wsM[n - 1];                     // M_{n-1} for the next step (wsM[0] = 0)
         // prefetch of frame n-1 (alpha of this thread's rows, emissions): consumed one step later
         if (n < len) {  // emissions of frame n, loaded during the previous step
             if (tid <= P) em[(n & 1) * P1p + tid] = em_value(evb, n, len, P, tid);
@@ -461,55 +492,63 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
         if (n - 1 >= 1) {
             const float *src = wsA + (long long)(n - 1) * S1p;
 #pragma unroll
-            for (int k = 0; k < MM_Q_RPT; ++k)
+            for (int k = 0; k < RPT; ++k)
                 if (tid + k * NT < S1) anxt[k] = src[amap[k]];
         }
         MM_STAMP(0);
         if (n < len) pdf_sums(qrow, pdfse, psum, P1, wave, NW, lane);  // posteriors of frame n+1, per pdf
         quad_phase<KQ>(rg, qb, tid, NT, pbuf, qs);
+        // read before the barrier what phase B needs and does not depend on this frame's sums
+        const float M = (n == len) ? 0.f : part_max_dpp(part + ((n + 1) & 1) * MM_MAX_WAVES, NW, lane);
+        G += (double)mf - (double)M;
         MM_STAMP(1);
         __syncthreads();
         MM_STAMP(2);
         if (n < len && wave == ((n + 1) % NW)) {  // gamma of frame n+1
             const float s = finish_frame(psum, P1, P, lane, p.gamma + gbase + (long long)n * p.gsn, p.gsp);
-            tmin = fminf(tmin, (float)(logZ2 + (double)fast_log2(s)));
+            tmin = fminf(tmin, fast_log2(s));
         }
-        const float kappa = (float)(logZ2 - Cn - D);
+        const float kappa = afin + (float)G;
         float wm = MM_NINF;
 #pragma unroll
-        for (int k = 0; k < MM_Q_RPT; ++k) {
+        for (int k = 0; k < RPT; ++k) {
             const int i = tid + k * NT;
             if (i < S1) {
                 const RowRecU rec = load_rec(recs, i);
                 const float acc = row_total<KQ>(qs, rec.q0nq & 0xffffu, rec.q0nq >> 16);
                 const bool ok = acc >= MM_Q_THR && acc <= MM_Q_BIG;
+#ifdef MM_STAMPS
+                stamp_acc[7] += __popcll(__ballot(!ok && (rec.q0nq >> 16)));
+#endif
                 float v = fast_log2(acc);
-                if (__builtin_expect(!ok, 0)) v = (rec.q0nq >> 16) ? exact_row(qb, i, yp) : MM_NINF;
+                // (the phony final state is exactly zero(K) or one(K) in the backward pass: no walk for it)
+                if (__builtin_expect(!ok, 0)) v = ((rec.q0nq >> 16) && i != qb.fpos) ? exact_row(qb, i, yp) : MM_NINF;
                 const float beta = v - M;  // T (B[:,n+1] (*) lhs[:,n+1])  (src/inference.jl:106-107)
                 qrow[i] = fast_exp2(acur[k] + beta - kappa);  // state_A .* state_B / Z
                 const float y = beta + emn[rec.pdf];
+                const float py = fast_exp2(y);
                 yn[i] = y;
-                put_p(i, fast_exp2(y));
+                put_p(i, py);
                 wm = fmaxf(wm, y);
             }
         }
-        for (int i = tid + MM_Q_RPT * NT; i < S1; i += NT) {  // more rows per thread than register slots
+        for (int i = tid + RPT * NT; i < S1; i += NT) {  // more rows per thread than register slots
             const RowRecU rec = load_rec(recs, i);
             const float acc = row_total<KQ>(qs, rec.q0nq & 0xffffu, rec.q0nq >> 16);
             const bool ok = acc >= MM_Q_THR && acc <= MM_Q_BIG;
             float v = fast_log2(acc);
-            if (__builtin_expect(!ok, 0)) v = (rec.q0nq >> 16) ? exact_row(qb, i, yp) : MM_NINF;
+            if (__builtin_expect(!ok, 0)) v = ((rec.q0nq >> 16) && i != qb.fpos) ? exact_row(qb, i, yp) : MM_NINF;
             const float beta = v - M;
             qrow[i] = fast_exp2(wsA[(long long)n * S1p + as_global(u.map_bf)[i]] + beta - kappa);
             const float y = beta + emn[rec.pdf];
+            const float py = fast_exp2(y);
             yn[i] = y;
-            put_p(i, fast_exp2(y));
+            put_p(i, py);
             wm = fmaxf(wm, y);
         }
-        wm = wave_max(wm);
-        if (lane == 0) part[(n & 1) * MM_MAX_WAVES + wave] = wm;
+        part_put(part + (n & 1) * MM_MAX_WAVES, wave, lane, wm);
 #pragma unroll
-        for (int k = 0; k < MM_Q_RPT; ++k) acur[k] = anxt[k];
+        for (int k = 0; k < RPT; ++k) acur[k] = anxt[k];
         MM_STAMP(3);
         __syncthreads();
         MM_STAMP(4);
@@ -524,18 +563,18 @@ __global__ void __launch_bounds__(1024) mm_fbq_kernel(RunParams p) {
         __syncthreads();
         if (wave == 0) {
             const float s = finish_frame(psum, P1, P, lane, p.gamma + gbase, p.gsp);
-            tmin = fminf(tmin, (float)(logZ2 + (double)fast_log2(s)));
+            tmin = fminf(tmin, fast_log2(s));
         }
     }
     for (long long q = tid; q < (long long)(p.N - len) * P; q += NT)
         p.gamma[gbase + (len + q / P) * p.gsn + (q % P) * p.gsp] = 0.f;
     __syncthreads();
-    if (lane == 0) part[wave] = tmin;
+    if (lane == 0) part[wave] = tmin;  // ttl = log Z + min over frames of log(per-frame sum)
     __syncthreads();
     if (tid == 0) {
         float t = part[0];
         for (int w = 1; w < NW; ++w) t = fminf(t, part[w]);
-        p.ttl[b] = t * MM_LN2;
+        p.ttl[b] = (float)((*zslot + (double)t) * (double)MM_LN2);
     }
 }
 

@@ -265,7 +265,9 @@ QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const st
         rec.q0 = uint16_t(nq_total);
         rec.nq = uint16_t(nq_of(r));
         rec.pdf = uint16_t(row2pdf[r]);
-        rec.pad = 0;
+        float wmin = 0.f;
+        for (int64_t a = rowptr[r]; a < rowptr[r + 1]; ++a) wmin = std::min(wmin, val[a]);
+        rec.wmin = int16_t(std::floor(std::max(wmin, -30000.f)));
         g.recs[i] = rec;
         nq_total += nq_of(r);
     }

@@ -80,7 +80,7 @@ struct RowRec {  // one per internal position: what the row-finishing thread nee
     uint16_t q0;   // first quad of the row
     uint16_t nq;   // number of quads
     uint16_t pdf;
-    uint16_t pad;
+    int16_t wmin;  // floor of the smallest log2 weight of the row (<= 0)
 };
 
 // The linear vector p is kept in `ncopy` LDS copies, copy c at float offset c * quad_pstride(): the

@@ -217,9 +217,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        # the JSON line must be the LAST line of stdout: RCCL writes a banner through C stdio, which is
+        # block-buffered on a pipe and would otherwise be flushed at exit, after our line
+        import ctypes
+
         sys.stdout.flush()
         sys.stderr.flush()
-        print(json.dumps(out), flush=True)  # the LAST line of output (RCCL prints its own banners)
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

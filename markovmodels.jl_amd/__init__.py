@@ -22,3 +22,4 @@ from .inference import (  # noqa: F401
     βrecursion,
 )
 from . import dist  # noqa: F401
+from .lfmmi import lfmmi_loss  # noqa: F401

@@ -236,3 +236,42 @@ def test_wsj_graphs_against_committed_golden(mm, wl, torch, name):
     ct = mm.compile(wl.to_fsm(mm, g, semiring="tropical"), mm.statemap(g.state2pdf, g.P))
     path, score = mm.batch(ct).viterbi(V[:1], lens[:1])
     assert np.array_equal(path[0], z["path"]) and score[0] == z["score"]
+
+
+def test_lfmmi_loss_and_gradient(mm, wl, oracle, torch):
+    """The caller's step (examples/test_cuda.jl:140-152): loss = -sum(ttl_num - ttl_den), gradient
+    = gamma_den - gamma_num, checked against the oracle and against finite differences of the oracle."""
+    o, oc = oracle
+    P, N = 6, 15
+    den = wl.random_fsm(30, P, 3.0, seed=21)
+    nums = [wl.random_fsm(S, P, 2.0, seed=30 + S) for S in (8, 11, 9)]
+    lens = np.array([15, 12, 9], dtype=np.int32)
+    rng = np.random.default_rng(7)
+    V = rng.standard_normal((3, N, P)).astype(np.float32)
+    cden = mm.compile(wl.to_fsm(mm, den), mm.statemap(den.state2pdf, P))
+    bden = mm.batch(cden, cden, cden)
+    bnum = mm.batch(*[mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, P)) for g in nums])
+    Vt = torch.from_numpy(V).cuda().requires_grad_(True)
+    loss, tn, td = mm.lfmmi_loss(Vt, bnum, bden, torch.from_numpy(lens).cuda())
+    loss.backward()
+
+    def ref_loss(Vx):
+        tot = 0.0
+        gd, tdn = oc.batch_shared(graphs.to_oracle(o, den), den.state2pdf, P, Vx, lens, dtype=np.float64)
+        gn = np.zeros_like(gd)
+        for b, g in enumerate(nums):
+            gb, tb = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, P, Vx[b:b + 1], lens[b:b + 1], dtype=np.float64)
+            gn[b] = gb[0]
+            tot -= tb[0] - tdn[b]
+        return tot, gd - gn
+
+    l_ref, g_ref = ref_loss(V.astype(np.float64))
+    assert np.isclose(float(loss.detach()), l_ref, rtol=1e-5, atol=1e-4)
+    assert np.allclose(Vt.grad.cpu().numpy(), g_ref, atol=2e-5)
+    # the analytic gradient is the derivative of the oracle's loss (central differences, a few entries)
+    for (b, n, p) in [(0, 3, 1), (1, 7, 4), (2, 0, 2)]:
+        Vp, Vm = V.astype(np.float64).copy(), V.astype(np.float64).copy()
+        Vp[b, n, p] += 1e-4
+        Vm[b, n, p] -= 1e-4
+        fd = (ref_loss(Vp)[0] - ref_loss(Vm)[0]) / 2e-4
+        assert np.isclose(fd, g_ref[b, n, p], atol=1e-5)

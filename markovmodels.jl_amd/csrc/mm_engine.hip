@@ -253,9 +253,18 @@ static int launch_quad(mm_batch_t h, const RunParams &p, void *stream) {
     }
 }
 
-static int tropical_waves(mm_batch_t h) {
-    Geometry g = pick_geometry(h);
-    return g.NI == 24 ? 16 : g.NW;
+static int launch_tropical(mm_batch_t h, const RunParams &p, void *stream) {
+    // register-resident items when the whole graph fits 8 items per wave, else streamed
+    const Geometry g = pick_geometry(h);
+    if (g.NI == 8) {  // as many waves as there is work for (latency), at most 8 items each
+        int NW = std::min(MM_MAX_WAVES, std::max(g.NW, (h->max_items + 3) / 4));
+        if (const char *e = getenv("MM_NWAVES")) {
+            int v = atoi(e);
+            if (v >= g.NW && v <= MM_MAX_WAVES) NW = v;
+        }
+        return launch(mm_tropical_kernel<8>, h, p, true, NW, stream);
+    }
+    return launch(mm_tropical_kernel<0>, h, p, true, 16, stream);
 }
 
 namespace {
@@ -767,7 +776,7 @@ static int run_export(mm_batch_t h, int mode, const float *V, int64_t vsb, int64
     p.out_stride_n = out_stride_n;
     if (h->semiring == MM_TROPICAL) {
         if (mode != MODE_ALPHA) return fail(MM_ERR_UNSUPPORTED, "tropical beta-recursion export is not implemented");
-        return launch(mm_tropical_kernel, h, p, false, tropical_waves(h), stream);
+        return launch_tropical(h, p, stream);
     }
     if (mode == MODE_ALPHA) return launch_log<MODE_ALPHA>(h, p, stream);
     return launch_log<MODE_BETA>(h, p, stream);
@@ -811,7 +820,7 @@ int mm_viterbi_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const
     p.path = path;
     p.path_stride_b = path_stride_b;
     p.score = score;
-    rc = launch(mm_tropical_kernel, h, p, false, tropical_waves(h), stream);
+    rc = launch_tropical(h, p, stream);
     if (rc) return rc;
     const int bt = 64;
     hipLaunchKernelGGL(mm_backtrace_kernel, dim3(unsigned((h->B + bt - 1) / bt)), dim3(bt), 0,

@@ -616,6 +616,24 @@ __device__ __forceinline__ void trop_better(float &best, int &arg, float v, int 
     }
 }
 
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+
+// (max, lowest arg-max) over an aligned lane group, same butterfly as grp_max
+__device__ __forceinline__ void trop_grp_reduce(float &best, int &arg, int log2g) {
+    if (log2g >= 1) trop_better(best, arg, dpp_mov<MM_DPP_XOR1>(best), dpp_mov_i<MM_DPP_XOR1>(arg));
+    if (log2g >= 2) trop_better(best, arg, dpp_mov<MM_DPP_XOR2>(best), dpp_mov_i<MM_DPP_XOR2>(arg));
+    if (log2g >= 3) trop_better(best, arg, dpp_mov<MM_DPP_HALF_MIRROR>(best), dpp_mov_i<MM_DPP_HALF_MIRROR>(arg));
+    if (log2g >= 4) trop_better(best, arg, dpp_mov<MM_DPP_MIRROR>(best), dpp_mov_i<MM_DPP_MIRROR>(arg));
+    if (log2g >= 5) trop_better(best, arg, __shfl_xor(best, 16), __shfl_xor(arg, 16));
+    if (log2g >= 6) trop_better(best, arg, __shfl_xor(best, 32), __shfl_xor(arg, 32));
+}
+
+// NI items per wave live in registers for the whole time loop (ItemRegs), the rest is streamed.
+// Back-pointers are collected in LDS and leave the chip as whole rows one frame later.
+template <int NI>
 __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
     extern __shared__ float lds[];
     const int b = blockIdx.x;
@@ -626,14 +644,19 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
     int len = p.lens ? p.lens[b] : p.N;
     len = len < 0 ? 0 : (len > p.N ? p.N : len);
     const int NF = p.N + 1;
-    const LdsPlan L = lds_plan(S1p, P1p, false);
+    const LdsPlan L = lds_plan(S1p, P1p, true);
     float *buf = lds + L.buf, *em = lds + L.em;
+    int *bpbuf = reinterpret_cast<int *>(lds + L.stage);  // [2][S1p]
     const float *Vb = p.V + (long long)b * p.vsb;
     const GraphDev gf = u.g[0];
     int *bpb = p.bp ? p.bp + u.state_off : nullptr;
+    ItemRegs<NI> rg;
 
     stage_em(em + 1 * P1p, Vb, p.vsn, 1, len, P, tid, NT, 1.0f);
-    for (int q = tid; q < 2 * S1p; q += NT) buf[q] = MM_NINF;
+    for (int q = tid; q < 2 * S1p; q += NT) {
+        buf[q] = MM_NINF;
+        bpbuf[q] = -1;
+    }
     __syncthreads();
     {
         float *a1 = buf + 1 * S1p;
@@ -645,15 +668,55 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
         }
         if (NF >= 2) stage_em(em + 0 * P1p, Vb, p.vsn, 2, len, P, tid, NT, 1.0f);
     }
+    load_item_regs<NI>(rg, gf, wave, NW, lane);
     __syncthreads();
     if (len == 0 && tid == 0 && p.score) p.score[b] = buf[1 * S1p + S1 - 1];
     for (int n = 2; n <= NF; ++n) {
         const float *ap = buf + ((n - 1) & 1) * S1p;
         float *an = buf + (n & 1) * S1p;
+        int *bpn = bpbuf + (n & 1) * S1p;
         const float *emn = em + (n & 1) * P1p;
-        if (n + 1 <= NF) stage_em(em + ((n + 1) & 1) * P1p, Vb, p.vsn, n + 1, len, P, tid, NT, 1.0f);
+        // emissions of frame n+1: raw load now (every thread, clamped address: nothing waits on it),
+        // stored to LDS at the end of the step
+        float evraw;
+        {
+            const int nn = n + 1 > p.N ? p.N : n + 1, qq = tid < P ? tid : P - 1;
+            evraw = Vb[(long long)(nn - 1) * p.vsn + qq];
+        }
+        if (bpb && n > 2) {  // back-pointers of frame n-1 (0-based row n-2): whole row, coalesced
+            const int *src = bpbuf + ((n - 1) & 1) * S1p;
+            int *dst = bpb + (long long)(n - 2) * p.bp_stride_n;
+            for (int s = tid; s < S1; s += NT) dst[s] = src[s];
+        }
+        auto finish = [&](float best, int arg, int row, int pdf) {
+            const float v = best + emn[pdf];
+            an[row] = v;
+            bpn[row] = arg;
+            if (p.out) p.out[(long long)(n - 1) * p.out_stride_n + u.state_off + row] = v;
+        };
+        static_for<0, NI>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const int meta = rg.meta[i];
+            if (meta != 0) {
+                const int R = meta & 0xff, lg = meta >> 8;
+                float best = MM_NINF;
+                int arg = -1;
+                const int c0 = rg.c[i][0] & 0xffffu, c1 = rg.c[i][0] >> 16;
+                trop_better(best, arg, rg.w[i][0] + ap[c0], c0);
+                trop_better(best, arg, rg.w[i][1] + ap[c1], c1);
+                if (R > 2) {
+                    const int c2 = rg.c[i][1] & 0xffffu, c3 = rg.c[i][1] >> 16;
+                    trop_better(best, arg, rg.w[i][2] + ap[c2], c2);
+                    trop_better(best, arg, rg.w[i][3] + ap[c3], c3);
+                }
+                trop_grp_reduce(best, arg, lg);
+                const unsigned row = rg.ri[i] & 0xffffu;
+                if (row != 0xffffu && (lane & ((1 << lg) - 1)) == 0) finish(best, arg, (int)row, (int)(rg.ri[i] >> 16));
+            }
+        });
         for (int it = wave; it < gf.n_items; it += NW) {
             const ItemMeta im = load_item(gf.items, it);
+            if (it < NI * NW && im.R <= 4) continue;  // register resident
             const RowInfo ri = gf.rowinfo[(size_t)it * 64 + lane];
             const Slot *sp = gf.slots + (size_t)im.slot_row * 64 + lane;
             float best = MM_NINF;
@@ -662,20 +725,24 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
                 Slot s = load_slot(sp + k * 64);
                 trop_better(best, arg, s.w + ap[s.col], (int)s.col);
             }
-            for (int i = 0; i < im.log2g; ++i) {
-                float ov = __shfl_xor(best, 1 << i);
-                int oa = __shfl_xor(arg, 1 << i);
-                trop_better(best, arg, ov, oa);
+            trop_grp_reduce(best, arg, im.log2g);
+            if (ri.row >= 0 && (lane & ((1 << im.log2g) - 1)) == 0) finish(best, arg, ri.row, ri.pdf);
+        }
+        if (n + 1 <= NF) {
+            if (tid <= P) {
+                float *dst = em + ((n + 1) & 1) * P1p;
+                if (tid < P) dst[tid] = (n + 1 <= len) ? evraw : MM_NINF;
+                else dst[tid] = (n + 1 <= len) ? MM_NINF : 0.f;
             }
-            if (ri.row >= 0 && (lane & ((1 << im.log2g) - 1)) == 0) {
-                const float v = best + emn[ri.pdf];
-                an[ri.row] = v;
-                if (bpb) bpb[(long long)(n - 1) * p.bp_stride_n + ri.row] = arg;
-                if (p.out) p.out[(long long)(n - 1) * p.out_stride_n + u.state_off + ri.row] = v;
-            }
+            if (P >= NT) stage_em(em + ((n + 1) & 1) * P1p + NT, Vb + NT, p.vsn, n + 1, len, P - NT, tid, NT, 1.0f);
         }
         __syncthreads();
         if (n == len + 1 && tid == 0 && p.score) p.score[b] = an[S1 - 1];
+    }
+    if (bpb && NF >= 2) {
+        const int *src = bpbuf + (NF & 1) * S1p;
+        int *dst = bpb + (long long)(NF - 1) * p.bp_stride_n;
+        for (int s = tid; s < S1; s += NT) dst[s] = src[s];
     }
 }
 

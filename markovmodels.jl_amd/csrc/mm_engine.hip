@@ -142,9 +142,9 @@ struct mm_batch_s {
     size_t ws_bytes = 0;
 };
 
-// Launch geometry.  NW waves per workgroup, NI register-resident items per wave
-// (mm_kernels.hip, "Register-resident graph"): NI <= 8 keeps 16 waves per CU inside the
-// 128-VGPR budget, NI = 24 uses 8 waves with up to 256 VGPRs.
+// Launch geometry of the item kernels: NW waves per workgroup, NI register-resident items per wave
+// (mm_kernels.hip, "Register-resident graph"; 8 items keep 16 waves per CU inside the 128-VGPR
+// budget), the remaining items are streamed from L2.
 struct Geometry {
     int NW, NI;
 };
@@ -152,22 +152,15 @@ struct Geometry {
 static Geometry pick_geometry(mm_batch_t h) {
     Geometry g{16, 8};
     const int it = h->max_items;
-    if (it <= 8 * MM_MAX_WAVES) {
-        g.NI = 8;
-        g.NW = std::max(1, (it + 7) / 8);
-    } else {
-        g.NI = 24;
-        g.NW = 8;
-    }
+    if (it <= 8 * MM_MAX_WAVES) g.NW = std::max(1, (it + 7) / 8);
     if (const char *e = getenv("MM_NWAVES")) {
         int v = atoi(e);
         if (v >= 1 && v <= MM_MAX_WAVES) g.NW = v;
     }
     if (const char *e = getenv("MM_NITEMS")) {
         int v = atoi(e);
-        if (v == 0 || v == 8 || v == 24) g.NI = v;
+        if (v == 0 || v == 8) g.NI = v;
     }
-    if (g.NI == 24 && g.NW > 8) g.NW = 8;
     return g;
 }
 
@@ -191,8 +184,7 @@ static int launch_log(mm_batch_t h, const RunParams &p, void *stream) {
     const bool st = MODE == MODE_FB;
     switch (g.NI) {
         case 0: return launch(mm_log_kernel<MODE, 0>, h, p, st, g.NW, stream);
-        case 8: return launch(mm_log_kernel<MODE, 8>, h, p, st, g.NW, stream);
-        default: return launch(mm_log_kernel<MODE, 24>, h, p, st, g.NW, stream);
+        default: return launch(mm_log_kernel<MODE, 8>, h, p, st, g.NW, stream);
     }
 }
 
@@ -249,6 +241,8 @@ static int launch_quad(mm_batch_t h, const RunParams &p, void *stream) {
         case 21: return launch_quad_kq<21>(h, p, std::min(NW, 8), stream);
         case 23: return launch_quad_kq<23>(h, p, std::min(NW, 8), stream);
         case 25: return launch_quad_kq<25>(h, p, std::min(NW, 8), stream);
+        case 27: return launch_quad_kq<27>(h, p, std::min(NW, 8), stream);
+        case 29: return launch_quad_kq<29>(h, p, std::min(NW, 8), stream);
         default: return MM_ERR_UNSUPPORTED;
     }
 }
@@ -256,7 +250,7 @@ static int launch_quad(mm_batch_t h, const RunParams &p, void *stream) {
 static int launch_tropical(mm_batch_t h, const RunParams &p, void *stream) {
     // register-resident items when the whole graph fits 8 items per wave, else streamed
     const Geometry g = pick_geometry(h);
-    if (g.NI == 8) {  // as many waves as there is work for (latency), at most 8 items each
+    if (g.NI == 8 && h->max_items <= 8 * MM_MAX_WAVES) {  // as many waves as there is work for (latency), at most 8 items each
         int NW = std::min(MM_MAX_WAVES, std::max(g.NW, (h->max_items + 3) / 4));
         if (const char *e = getenv("MM_NWAVES")) {
             int v = atoi(e);
@@ -613,7 +607,7 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         QuadGeometry geo = pick_quad_geometry(nq_max);
         if (const char *e = getenv("MM_KQ")) {
             int v = atoi(e);
-            if (v >= 1 && v <= 25) geo.KQ = v;
+            if (v >= 1 && v <= 29) geo.KQ = v;
         }
         geo.NW = int(std::min<int64_t>(geo.KQ > 13 ? 8 : MM_MAX_WAVES,
                                        std::max<int64_t>(1, (nq_max + 64 * geo.KQ - 1) / (64 * geo.KQ))));

@@ -275,3 +275,32 @@ def test_lfmmi_loss_and_gradient(mm, wl, oracle, torch):
         Vm[b, n, p] -= 1e-4
         fd = (ref_loss(Vp)[0] - ref_loss(Vm)[0]) / 2e-4
         assert np.isclose(fd, g_ref[b, n, p], atol=1e-5)
+
+
+@pytest.mark.parametrize("env", [{"MM_KERNEL": "item"}, {"MM_KQ": "1"}, {"MM_KQ": "2", "MM_NWAVES": "3"}, {"MM_KQ": "15"},
+                                 {"MM_KQ": "7"}])
+def test_kernel_variants_agree(mm, wl, oracle, torch, env):
+    """The general (item) kernel, the quad kernel with a streamed overflow (virtual lanes: KQ too small
+    for the graph), an 8-wave geometry and a 16-wave one all give the oracle's posteriors."""
+    import os
+
+    o, oc = oracle
+    g = wl.lfmmi_denominator(600, 40, seed=5)
+    rng = np.random.default_rng(11)
+    B, N = 3, 25
+    V = (1.5 * rng.standard_normal((B, N, g.P))).astype(np.float32)
+    lens = np.array([25, 18, 7], dtype=np.int32)
+    g_ref, t_ref = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V, lens, dtype=np.float64)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+        gam, ttl = mm.batch(cf, cf, cf).pdfposteriors(V, lens)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    check_gamma(gam, g_ref, lens)
+    assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)

@@ -1,0 +1,103 @@
+"""BASELINE.json's full-size configurations on the GPU, checked through size-independent
+properties (the oracle would need hours at these sizes): per-frame normalisation, exact zeros
+beyond the sequence length, invariance of the posteriors / shift of log Z under a per-frame
+emission offset, agreement of the two independent kernels, Viterbi path consistency."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    assert torch.cuda.is_available()
+    return torch
+
+
+def test_config3_lfmmi_denominator_full_size(mm, wl, torch):
+    """S = 2000, T = 1500, B = 256 (BASELINE configs[2])."""
+    g = wl.lfmmi_denominator(2000, 84, seed=0)
+    B, N = 256, 1500
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(*([cf] * B))
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    V = torch.randn(B, N, g.P, device="cuda", generator=gen)
+    lens = torch.randint(N // 2, N + 1, (B,), device="cuda", generator=gen, dtype=torch.int32)
+    lens[0] = N
+    gam, ttl = bf.pdfposteriors(V, lens)
+    assert torch.isfinite(gam).all() and torch.isfinite(ttl).all() and (gam >= 0).all()
+    frame = torch.arange(N, device="cuda")[None, :]
+    valid = frame < lens[:, None]
+    sums = gam.sum(-1)
+    assert torch.allclose(sums[valid], torch.ones_like(sums[valid]), atol=2e-5)
+    assert (gam[~valid] == 0).all()
+    # offset c_n added to every pdf of frame n: posteriors unchanged, log Z shifted by sum_n c_n
+    c = torch.randn(B, N, 1, device="cuda", generator=gen)
+    gam2, ttl2 = bf.pdfposteriors(V + c, lens)
+    shift = (c[:, :, 0] * valid).double().sum(1)
+    assert torch.allclose(gam2, gam, atol=2e-5)
+    assert torch.allclose(ttl2.double(), ttl.double() + shift, rtol=2e-6, atol=5e-3)
+    # the general (item) kernel is an independent implementation of the same path
+    os.environ["MM_KERNEL"] = "item"
+    try:
+        sub = slice(0, 32)
+        g_item, t_item = mm.batch(*([cf] * 32)).pdfposteriors(V[sub].contiguous(), lens[sub].contiguous())
+    finally:
+        os.environ.pop("MM_KERNEL", None)
+    assert torch.allclose(g_item, gam[sub], atol=2e-5)
+    assert torch.allclose(t_item, ttl[sub], rtol=1e-5, atol=5e-3)
+
+
+def test_config5_viterbi_full_size(mm, wl, torch):
+    """5000-state lexicon FSM, T = 1000, B = 128, tropical (BASELINE configs[4])."""
+    g = wl.lexicon_fsm(5000, 84, seed=0)
+    B, N = 128, 1000
+    ct = mm.compile(wl.to_fsm(mm, g, semiring="tropical"), mm.statemap(g.state2pdf, g.P))
+    bt = mm.batch(*([ct] * B))
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    V = torch.randn(B, N, g.P, device="cuda", generator=gen)
+    lens = torch.randint(N // 2, N + 1, (B,), device="cuda", generator=gen, dtype=torch.int32)
+    path, score = bt.viterbi(V, lens)
+    path, score, Vh, L = path.cpu().numpy(), score.cpu().numpy(), V.cpu().numpy(), lens.cpu().numpy()
+    assert np.isfinite(score).all()
+    # dense lookup of the arc weights (float32, like the engine)
+    W = np.full((g.S, g.S), -np.inf, dtype=np.float32)
+    W[g.src, g.dst] = g.w.astype(np.float32)
+    init = np.full(g.S, -np.inf, dtype=np.float32)
+    init[g.init_idx] = g.init_w.astype(np.float32)
+    fin = np.full(g.S, -np.inf, dtype=np.float32)
+    fin[g.final_idx] = g.final_w.astype(np.float32)
+    for b in range(0, B, 9):
+        p = path[b, : L[b]]
+        assert (p >= 0).all() and (p < g.S).all() and (path[b, L[b]:] == -1).all()
+        # the reported score is the weight of the reported path, accumulated in the engine's order
+        acc = np.float32(init[p[0]] + Vh[b, 0, g.state2pdf[p[0]]])
+        for n in range(1, L[b]):
+            acc = np.float32(np.float32(W[p[n - 1], p[n]] + acc) + Vh[b, n, g.state2pdf[p[n]]])
+        acc = np.float32(np.float32(fin[p[-1]] + acc) + np.float32(0))
+        assert np.isfinite(acc) and acc == score[b], (b, acc, score[b])
+    # max-plus <= log-sum-exp: the best path cannot beat the total
+    cl = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    _, ttl = mm.batch(*([cl] * B)).pdfposteriors(V, lens)
+    assert (score <= ttl.cpu().numpy() + 1e-3).all()
+
+
+def test_config2_dense_ergodic(mm, wl, oracle, torch):
+    """Dense 64-state ergodic HMM, T = 500, B = 32 (BASELINE configs[1]) against the oracle."""
+    import graphs
+
+    o, oc = oracle
+    g = wl.dense_ergodic(64, seed=0)
+    rng = np.random.default_rng(1)
+    V = rng.standard_normal((32, 500, g.P)).astype(np.float32)
+    g_ref, t_ref = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V, None, dtype=np.float64, nthreads=8)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    gam, ttl = mm.batch(*([cf] * 32)).pdfposteriors(V)
+    assert np.abs(gam - g_ref).max() <= 2e-5
+    m = g_ref > 1e-30
+    assert (np.abs(np.log(gam[m]) - np.log(g_ref[m])) <= 1e-4 * np.maximum(np.abs(np.log(g_ref[m])), 1)).all()
+    assert np.allclose(ttl, t_ref, rtol=1e-5)

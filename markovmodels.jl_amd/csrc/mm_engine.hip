@@ -566,10 +566,9 @@ int mm_debug_quad_product(mm_fsm_t f, int direction, int KQ, const float *in, fl
     for (int64_t i = 0; i < S1; ++i) {
         const RowRec &r = g.recs[i];
         float acc = 0.f;
-        if (r.nq) {
-            const int qe = r.q0 + r.nq - 1;
-            acc = qs[qe];
-            for (int q = r.q0 + (KQ - 1 - r.q0 % KQ); q < qe; q += KQ) acc += qs[q];
+        if (!r.empty) {
+            acc = qs[r.qe];
+            for (int k = 0; k < r.nextra; ++k) acc += qs[r.first + k * KQ];
         }
         out[g.order[i]] = (std::log2(acc) + mx) * MM_LN2;
     }

@@ -130,20 +130,17 @@ __device__ __forceinline__ float quad_sum(const float (&wl)[4], unsigned off01, 
 template <int KQ>
 __device__ __forceinline__ void quad_phase(const QuadRegs<KQ> &rg, const QuadDev &g, int tid, int NT,
                                            const float *__restrict__ pbuf, float *__restrict__ qs) {
-    // all gathers first (no LDS store in between, so they can all be in flight), then the stores
-    float s[KQ];
-    static_for<0, KQ>([&](auto J) {
-        constexpr int j = decltype(J)::value;
-        s[j] = quad_sum(rg.wl[j], rg.off[j][0], rg.off[j][1], pbuf);
-    });
+    // pbuf and qs never overlap (__restrict__): the stores of one quad do not hold back the gathers of
+    // the next, and no array of quad sums has to stay live
     float run = 0.f;
     unsigned mask = rg.mask;
     asm("" : "+v"(mask));
     static_for<0, KQ>([&](auto J) {
         constexpr int j = decltype(J)::value;
+        const float sj = quad_sum(rg.wl[j], rg.off[j][0], rg.off[j][1], pbuf);
         // keep the running sum only if quad j continues the previous quad's row
         const int keep = __builtin_amdgcn_sbfe(mask, j, 1);  // 0 or -1
-        run = s[j] + __int_as_float(__float_as_int(run) & keep);
+        run = sj + __int_as_float(__float_as_int(run) & keep);
         qs[tid * KQ + j] = run;
     });
     // lanes beyond the register window ("virtual lanes"): the same, streamed from L2
@@ -161,21 +158,34 @@ __device__ __forceinline__ void quad_phase(const QuadRegs<KQ> &rg, const QuadDev
     }
 }
 
-// phase B: the sum of row [q0, q0 + nq): its last quad plus the lane ends before it
-// (up to 4 independent loads per round trip)
+// phase B: the sum of a row from its record (mm_pack.h RowRec: x = qe | first << 16, y = pdf | nextra << 16
+// | empty << 24): the running sum in its last quad plus the ends of the lanes it started in.  Most rows
+// span at most three lanes: their loads are independent and branch-free.
 template <int KQ>
-__device__ __forceinline__ float row_total(const float *__restrict__ qs, int q0, int nq) {
-    if (nq == 0) return 0.f;
-    const int qe = q0 + nq - 1;
-    float acc = qs[qe];
-    for (int q = q0 + (KQ - 1 - q0 % KQ); q < qe; q += 4 * KQ) {
-        const float a = qs[q];
-        const float b = (q + KQ < qe) ? qs[q + KQ] : 0.f;
-        const float c = (q + 2 * KQ < qe) ? qs[q + 2 * KQ] : 0.f;
-        const float d = (q + 3 * KQ < qe) ? qs[q + 3 * KQ] : 0.f;
-        acc += (a + b) + (c + d);
+__device__ __forceinline__ float row_total(const float *__restrict__ qs, unsigned x, unsigned y) {
+    const unsigned ne = y >> 16;
+    const int first = x >> 16;
+    const float a = qs[x & 0xffffu];
+    const float b = ne > 0u ? qs[first] : 0.f;
+    const float c = ne > 1u ? qs[first + KQ] : 0.f;
+    float acc = a + (b + c);
+    if (__builtin_expect(ne > 2u, 0)) {
+        if (ne >> 8) return 0.f;  // no arcs
+        for (unsigned k = 2; k < ne; k += 4) {
+            const float *q = qs + first + k * KQ;
+            const float d0 = q[0];
+            const float d1 = (k + 1 < ne) ? q[KQ] : 0.f;
+            const float d2 = (k + 2 < ne) ? q[2 * KQ] : 0.f;
+            const float d3 = (k + 3 < ne) ? q[3 * KQ] : 0.f;
+            acc += (d0 + d1) + (d2 + d3);
+        }
     }
     return acc;
+}
+// is the linear-domain sum in the range where log2 of it is accurate?  (one subtract + one unsigned
+// compare; negative, NaN and zero fall outside)
+__device__ __forceinline__ bool sum_in_range(float acc) {
+    return (__float_as_uint(acc) - 0x12800000u) <= (0x71800000u - 0x12800000u);  // bits of 2^-90, 2^100
 }
 
 // add up the contiguous floats [q0, q1) in a fixed order (independent loads in groups of 8)
@@ -207,12 +217,13 @@ __device__ __forceinline__ float exact_row(const QuadDev &g, int r, const float 
 }
 
 struct RowRecU {
-    unsigned q0nq;  // q0 | nq << 16
-    unsigned pdf;
+    unsigned x, y;  // RowRec as two words: qe | first << 16,  pdf | nextra << 16 | empty << 24
+    __device__ __forceinline__ unsigned pdf() const { return y & 0xffffu; }
+    __device__ __forceinline__ bool has_arcs() const { return (y >> 24) == 0u; }
 };
 __device__ __forceinline__ RowRecU load_rec(const float *recs, int i) {
     const uint2 r = reinterpret_cast<const uint2 *>(recs)[i];
-    return RowRecU{r.x, r.y & 0xffffu};
+    return RowRecU{r.x, r.y};
 }
 
 // Emissions of one frame (expand(), src/inference.jl:54-60): EVERY thread loads a raw value
@@ -325,7 +336,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
         float *a1 = abuf + 1 * S1p;
         const float *e1 = em + 1 * P1p;
         for (int i = tid; i < S1; i += NT) {
-            const float v = as_global(u.init_f)[i] + e1[load_rec(recs, i).pdf];
+            const float v = as_global(u.init_f)[i] + e1[load_rec(recs, i).pdf()];
             a1[i] = v;
             put_p(i, fast_exp2(v));
             wm = fmaxf(wm, v);
@@ -376,30 +387,29 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
                 const int i = tid + k * NT;
-                rec[k] = load_rec(recs, i < S1 ? i : 0);
-                if (i >= S1) rec[k].q0nq = 0u;  // no quads: nothing to read
+                rec[k] = load_rec(recs, i < S1 ? i : S1 - 1);
             }
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) e[k] = emn[rec[k].pdf];
+            for (int k = 0; k < RPT; ++k) e[k] = emn[rec[k].pdf()];
             float acc[RPT];
             // a row whose emission is zero(K) this frame is zero whatever its sum is (the phony final
             // state, whose row is by far the longest, for every frame but the last): do not read it
 #pragma unroll
             for (int k = 0; k < RPT; ++k)
-                acc[k] = e[k] > MM_NINF ? row_total<KQ>(qs, rec[k].q0nq & 0xffffu, rec[k].q0nq >> 16) : 0.f;
+                acc[k] = e[k] > MM_NINF ? row_total<KQ>(qs, rec[k].x, rec[k].y) : 0.f;
             MM_STAMP(5);
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
                 const int i = tid + k * NT;
                 if (i < S1) {
-                    const bool ok = (acc[k] >= MM_Q_THR && acc[k] <= MM_Q_BIG) || !(e[k] > MM_NINF);
+                    const bool ok = sum_in_range(acc[k]) || !(e[k] > MM_NINF);
 #ifdef MM_STAMPS
-                    stamp_acc[7] += __popcll(__ballot(!ok && (rec[k].q0nq >> 16)));
+                    stamp_acc[7] += __popcll(__ballot(!ok && rec[k].has_arcs()));
 #endif
                     float v = fast_log2(acc[k]);
                     // exact fallback, unless the sum is exactly 0 and no source can be alive-but-underflowed
                     if (__builtin_expect(!ok, 0))
-                        v = (rec[k].q0nq >> 16) ? exact_row(qf, i, ap) : MM_NINF;
+                        v = rec[k].has_arcs() ? exact_row(qf, i, ap) : MM_NINF;
                     v = v + e[k] - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
                     const float pv = fast_exp2(v);
                     an[i] = v;
@@ -411,11 +421,11 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
         MM_STAMP(6);
         for (int i = tid + RPT * NT; i < S1; i += NT) {
             const RowRecU rec = load_rec(recs, i);
-            const float acc = row_total<KQ>(qs, rec.q0nq & 0xffffu, rec.q0nq >> 16);
-            const bool ok = acc >= MM_Q_THR && acc <= MM_Q_BIG;
+            const float acc = row_total<KQ>(qs, rec.x, rec.y);
+            const bool ok = sum_in_range(acc);
             float v = fast_log2(acc);
-            if (__builtin_expect(!ok, 0)) v = (rec.q0nq >> 16) ? exact_row(qf, i, ap) : MM_NINF;
-            v = v + emn[rec.pdf] - M;
+            if (__builtin_expect(!ok, 0)) v = rec.has_arcs() ? exact_row(qf, i, ap) : MM_NINF;
+            v = v + emn[rec.pdf()] - M;
             const float pv = fast_exp2(v);
             an[i] = v;
             put_p(i, pv);
@@ -515,17 +525,17 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
             const int i = tid + k * NT;
             if (i < S1) {
                 const RowRecU rec = load_rec(recs, i);
-                const float acc = row_total<KQ>(qs, rec.q0nq & 0xffffu, rec.q0nq >> 16);
-                const bool ok = acc >= MM_Q_THR && acc <= MM_Q_BIG;
+                const float acc = row_total<KQ>(qs, rec.x, rec.y);
+                const bool ok = sum_in_range(acc);
 #ifdef MM_STAMPS
-                stamp_acc[7] += __popcll(__ballot(!ok && (rec.q0nq >> 16)));
+                stamp_acc[7] += __popcll(__ballot(!ok && rec.has_arcs()));
 #endif
                 float v = fast_log2(acc);
                 // (the phony final state is exactly zero(K) or one(K) in the backward pass: no walk for it)
-                if (__builtin_expect(!ok, 0)) v = ((rec.q0nq >> 16) && i != qb.fpos) ? exact_row(qb, i, yp) : MM_NINF;
+                if (__builtin_expect(!ok, 0)) v = (rec.has_arcs() && i != qb.fpos) ? exact_row(qb, i, yp) : MM_NINF;
                 const float beta = v - M;  // T (B[:,n+1] (*) lhs[:,n+1])  (src/inference.jl:106-107)
                 qrow[i] = fast_exp2(acur[k] + beta - kappa);  // state_A .* state_B / Z
-                const float y = beta + emn[rec.pdf];
+                const float y = beta + emn[rec.pdf()];
                 const float py = fast_exp2(y);
                 yn[i] = y;
                 put_p(i, py);
@@ -534,13 +544,13 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
         }
         for (int i = tid + RPT * NT; i < S1; i += NT) {  // more rows per thread than register slots
             const RowRecU rec = load_rec(recs, i);
-            const float acc = row_total<KQ>(qs, rec.q0nq & 0xffffu, rec.q0nq >> 16);
-            const bool ok = acc >= MM_Q_THR && acc <= MM_Q_BIG;
+            const float acc = row_total<KQ>(qs, rec.x, rec.y);
+            const bool ok = sum_in_range(acc);
             float v = fast_log2(acc);
-            if (__builtin_expect(!ok, 0)) v = ((rec.q0nq >> 16) && i != qb.fpos) ? exact_row(qb, i, yp) : MM_NINF;
+            if (__builtin_expect(!ok, 0)) v = (rec.has_arcs() && i != qb.fpos) ? exact_row(qb, i, yp) : MM_NINF;
             const float beta = v - M;
             qrow[i] = fast_exp2(wsA[(long long)n * S1p + as_global(u.map_bf)[i]] + beta - kappa);
-            const float y = beta + emn[rec.pdf];
+            const float y = beta + emn[rec.pdf()];
             const float py = fast_exp2(y);
             yn[i] = y;
             put_p(i, py);

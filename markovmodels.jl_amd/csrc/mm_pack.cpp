@@ -265,6 +265,8 @@ QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const st
     g.col.resize(col.size());
     g.w.resize(val.size());
     g.recs.resize(nrows);
+    g.q0.resize(nrows);
+    g.nq.resize(nrows);
     int64_t nq_total = 0, a_out = 0;
     for (int64_t i = 0; i < nrows; ++i) {
         const int64_t r = g.order[i];
@@ -274,14 +276,17 @@ QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const st
             g.w[a_out] = val[a];
         }
         RowRec rec;
-        rec.q0 = uint16_t(nq_total);
-        rec.nq = uint16_t(nq_of(r));
+        const int64_t nqr = nq_of(r), q0 = nq_total, qe = q0 + nqr - 1;
+        const int64_t first = q0 + (KQ - 1 - q0 % KQ);
+        rec.qe = uint16_t(nqr ? qe : 0);
+        rec.first = uint16_t(nqr ? first : 0);
         rec.pdf = uint16_t(row2pdf[r]);
-        float wmin = 0.f;
-        for (int64_t a = rowptr[r]; a < rowptr[r + 1]; ++a) wmin = std::min(wmin, val[a]);
-        rec.wmin = int16_t(std::floor(std::max(wmin, -30000.f)));
+        rec.nextra = uint8_t(nqr && first < qe ? (qe - first + KQ - 1) / KQ : 0);
+        rec.empty = nqr ? 0 : 1;
+        g.q0[i] = int32_t(q0);
+        g.nq[i] = int32_t(nqr);
         g.recs[i] = rec;
-        nq_total += nq_of(r);
+        nq_total += nqr;
     }
     g.rowptr[nrows] = int32_t(a_out);
     g.quads.assign(size_t(nq_total), Quad{});
@@ -292,7 +297,7 @@ QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const st
     // row of every quad
     std::vector<int32_t> qrow(static_cast<size_t>(nq_total), 0);
     for (int64_t i = 0; i < nrows; ++i)
-        for (int q = 0; q < g.recs[i].nq; ++q) qrow[g.recs[i].q0 + q] = int32_t(i);
+        for (int q = 0; q < g.nq[i]; ++q) qrow[g.q0[i] + q] = int32_t(i);
     // Two candidate placements per half-wave: arcs in CSR order, and a greedy bank-aware one
     // (slot by slot, the remaining arc of the row segment that is cheapest there); the cheaper
     // one under the bank model is kept.
@@ -309,7 +314,7 @@ QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const st
                 const int32_t row = qrow[l * KQ + j];
                 int j1 = j;
                 while (j1 < KQ && l * KQ + j1 < nq_total && qrow[l * KQ + j1] == row) ++j1;
-                const int64_t qrel = l * KQ + j - g.recs[row].q0;
+                const int64_t qrel = l * KQ + j - g.q0[row];
                 const int64_t a0 = g.rowptr[row] + 4 * qrel;
                 const int64_t a1 = std::min<int64_t>(g.rowptr[row + 1], a0 + 4 * int64_t(j1 - j));
                 for (int64_t a = a0; a < a1; ++a) used[a] = 0;

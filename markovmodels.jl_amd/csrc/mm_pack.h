@@ -77,11 +77,14 @@ struct Quad {
 static_assert(sizeof(Quad) == 32, "Quad must be 32 bytes");
 
 struct RowRec {  // one per internal position: what the row-finishing thread needs, one 8-byte LDS read
-    uint16_t q0;   // first quad of the row
-    uint16_t nq;   // number of quads
+    uint16_t qe;      // last quad of the row: holds the running sum of the row's quads in its lane
+    uint16_t first;   // first lane-end quad (q % KQ == KQ - 1) of the row before qe
     uint16_t pdf;
-    int16_t wmin;  // floor of the smallest log2 weight of the row (<= 0)
+    uint8_t nextra;   // number of lane ends in [first, qe), KQ apart: partial sums of the earlier lanes
+    uint8_t empty;    // 1: the row has no arcs (its value is zero(K))
+    // (the first quad is recs[i - 1].qe + 1; kept on the host in QuadGraph::q0)
 };
+static_assert(sizeof(RowRec) == 8, "RowRec must be 8 bytes");
 
 // The linear vector p is kept in `ncopy` LDS copies, copy c at float offset c * quad_pstride(): the
 // copies are rotated against each other by 32 / ncopy banks, so every arc can be read from ncopy
@@ -105,6 +108,7 @@ struct QuadGraph {
     std::vector<int32_t> pos;    // original row -> internal position
     std::vector<Quad> quads;     // in internal row order
     std::vector<RowRec> recs;    // [nrows]
+    std::vector<int32_t> q0, nq; // [nrows] first quad and number of quads of every row (host side)
     // CSR in internal numbering with log2-domain weights: the exact fallback walks these
     std::vector<int32_t> rowptr;
     std::vector<int32_t> col;

@@ -558,8 +558,11 @@ int mm_debug_quad_product(mm_fsm_t f, int direction, int KQ, const float *in, fl
         for (int j = 0; j < KQ && l * KQ + j < nq; ++j) {
             const Quad &q = g.quads[size_t(l * KQ + j)];
             float s = 0.f;
-            for (int k = 0; k < 4; ++k) s = std::fmaf(q.wl[k], p[(q.off[k] / 4) % quad_pstride(f->S1p, g.ncopy)], s);
-            run = ((mask >> j) & 1u) ? run + s : s;
+            const bool cont = std::signbit(q.wl[0]);
+            if (cont != bool((mask >> j) & 1u)) return fail(MM_ERR_INVALID, "mm_debug_quad_product: sign flags and lane mask disagree");
+            for (int k = 0; k < 4; ++k)
+                s = std::fmaf(std::fabs(q.wl[k]), p[(q.off[k] / 4) % quad_pstride(f->S1p, g.ncopy)], s);
+            run = cont ? run + s : s;
             qs[size_t(l * KQ + j)] = run;
         }
     }

@@ -81,7 +81,6 @@ template <int KQ>
 struct QuadRegs {
     float wl[KQ][4];
     unsigned off[KQ][2];  // off0 | off1 << 16, off2 | off3 << 16  (LDS byte offsets)
-    unsigned mask;        // bit j: quad j continues the row of quad j-1
 };
 
 __device__ __forceinline__ void load_quad(const Quad *q, float (&wl)[4], unsigned (&off)[2]) {
@@ -97,7 +96,6 @@ __device__ __forceinline__ void load_quad(const Quad *q, float (&wl)[4], unsigne
 
 template <int KQ>
 __device__ __forceinline__ void load_quad_regs(QuadRegs<KQ> &rg, const QuadDev &g, int tid) {
-    rg.mask = (tid * KQ < g.nq) ? as_global(g.quads)[tid * KQ].mask : 0u;
     static_for<0, KQ>([&](auto J) {
         constexpr int j = decltype(J)::value;
         const int q = tid * KQ + j;
@@ -111,13 +109,36 @@ __device__ __forceinline__ float lds_f32(const float *base, unsigned byte_off) {
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-__device__ __forceinline__ float quad_sum(const float (&wl)[4], unsigned off01, unsigned off23, const float *pbuf) {
-    // keep the offsets packed: unpacking is loop invariant and hoisting it would cost 2 VGPRs per quad
-    // (plain asm, not volatile: it must not order the LDS traffic around it)
-    asm("" : "+v"(off01), "+v"(off23));
-    const float x0 = lds_f32(pbuf, off01 & 0xffffu), x1 = lds_f32(pbuf, off01 >> 16);
-    const float x2 = lds_f32(pbuf, off23 & 0xffffu), x3 = lds_f32(pbuf, off23 >> 16);
-    float acc = wl[0] * x0;
+// sum of one quad on top of `run`, the running sum of the lane: kept if the quad continues its
+// predecessor's row (sign bit of the first weight, mm_pack.h Quad), dropped if it starts a row.
+// The unpacking of the 16-bit LDS offsets and the sign test are loop invariant; hoisted out of the time
+// loop they would cost 2 VGPRs + 2 SGPRs per quad, which do not exist.  They are therefore written as asm
+// that also reads `vz`, a zero the compiler cannot see through (one instruction per address, no copies).
+typedef __attribute__((address_space(3))) const float *lds_cfptr;
+__device__ __forceinline__ float lds_abs(unsigned addr) { return *(lds_cfptr)(__UINTPTR_TYPE__)addr; }
+__device__ __forceinline__ unsigned lds_addr_of(const float *p) {
+    return (unsigned)(__UINTPTR_TYPE__)(lds_cfptr)p;
+}
+__device__ __forceinline__ unsigned unpack_lo(unsigned packed, unsigned vz) {
+    unsigned r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+        : "=v"(r) : "v"(vz), "v"(packed));
+    return r;
+}
+__device__ __forceinline__ unsigned unpack_hi(unsigned packed, unsigned vz) {
+    unsigned r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+        : "=v"(r) : "v"(vz), "v"(packed));
+    return r;
+}
+__device__ __forceinline__ float quad_sum(const float (&wl)[4], unsigned off01, unsigned off23, const float *pbuf,
+                                          float run, unsigned vz) {
+    // vz = LDS address of pbuf (0 in practice): the sums are absolute LDS addresses
+    const float x0 = lds_abs(unpack_lo(off01, vz)), x1 = lds_abs(unpack_hi(off01, vz));
+    const float x2 = lds_abs(unpack_lo(off23, vz)), x3 = lds_abs(unpack_hi(off23, vz));
+    float acc;  // run, or 0 when the sign bit of wl[0] is clear
+    asm("v_ashrrev_i32 %0, 31, %1\n\tv_and_b32 %0, %0, %2" : "=&v"(acc) : "v"(wl[0]), "v"(run));
+    acc = fmaf(__builtin_fabsf(wl[0]), x0, acc);
     acc = fmaf(wl[1], x1, acc);
     acc = fmaf(wl[2], x2, acc);
     acc = fmaf(wl[3], x3, acc);
@@ -133,26 +154,21 @@ __device__ __forceinline__ void quad_phase(const QuadRegs<KQ> &rg, const QuadDev
     // pbuf and qs never overlap (__restrict__): the stores of one quad do not hold back the gathers of
     // the next, and no array of quad sums has to stay live
     float run = 0.f;
-    unsigned mask = rg.mask;
-    asm("" : "+v"(mask));
+    unsigned vz = lds_addr_of(pbuf);
+    asm volatile("" : "+v"(vz));
     static_for<0, KQ>([&](auto J) {
         constexpr int j = decltype(J)::value;
-        const float sj = quad_sum(rg.wl[j], rg.off[j][0], rg.off[j][1], pbuf);
-        // keep the running sum only if quad j continues the previous quad's row
-        const int keep = __builtin_amdgcn_sbfe(mask, j, 1);  // 0 or -1
-        run = sj + __int_as_float(__float_as_int(run) & keep);
+        run = quad_sum(rg.wl[j], rg.off[j][0], rg.off[j][1], pbuf, run, vz);
         qs[tid * KQ + j] = run;
     });
     // lanes beyond the register window ("virtual lanes"): the same, streamed from L2
     for (int v = NT + tid; v * KQ < g.nq; v += NT) {
-        const unsigned m = as_global(g.quads)[v * KQ].mask;
         float r = 0.f;
         for (int j = 0; j < KQ && v * KQ + j < g.nq; ++j) {
             float wl[4];
             unsigned off[2];
             load_quad(g.quads + v * KQ + j, wl, off);
-            const float sj = quad_sum(wl, off[0], off[1], pbuf);
-            r = ((m >> j) & 1u) ? r + sj : sj;
+            r = quad_sum(wl, off[0], off[1], pbuf, r, vz);
             qs[v * KQ + j] = r;
         }
     }

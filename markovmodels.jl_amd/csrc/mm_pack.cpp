@@ -442,6 +442,13 @@ QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const st
         for (int j = 1; j < KQ && l * KQ + j < nq_total; ++j)
             if (qrow[l * KQ + j] == qrow[l * KQ + j - 1]) mask |= 1u << j;
         g.quads[size_t(l * KQ)].mask = mask;
+        // the kernel reads the same flag from the sign bit of the quad's first weight (weights are
+        // linear, hence non-negative: the bit is free), which costs no register
+        for (int j = 1; j < KQ && l * KQ + j < nq_total; ++j)
+            if ((mask >> j) & 1u) {
+                float &w0 = g.quads[size_t(l * KQ + j)].wl[0];
+                w0 = std::copysign(w0, -1.0f);
+            }
     }
     g.conflict_before = n_instr ? cyc_naive / double(n_instr) : 0;
     g.conflict_after = n_instr ? cyc_sched / double(n_instr) : 0;

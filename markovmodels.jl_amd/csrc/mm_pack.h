@@ -68,10 +68,11 @@ Packed pack_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::v
 // (identical addresses broadcast for free).
 // ---------------------------------------------------------------------------
 struct Quad {
-    float wl[4];      // 2^(log2 weight); 0 = padding
+    float wl[4];      // 2^(log2 weight); 0 = padding.  Sign bit of wl[0] set <=> the quad continues the row of
+                      // its predecessor in the lane (its sum is added to the lane's running sum)
     uint16_t off[4];  // 4 * internal position of the source state
     uint32_t mask;    // in the FIRST quad of a lane (q % KQ == 0): bit j set <=> quad q + j continues the
-                      // row of quad q + j - 1, i.e. its sum is added to the running sum of the lane
+                      // row of quad q + j - 1 (the same flags as the sign bits, for host-side checks)
     uint32_t pad;
 };
 static_assert(sizeof(Quad) == 32, "Quad must be 32 bytes");

@@ -137,6 +137,14 @@ int mm_viterbi_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t
                    int64_t N, int32_t *path, int64_t path_stride_b, float *score, int32_t *bp,
                    int64_t bp_stride_n, void *stream);
 
+/* totalsum(alpha, T, omega, n) / totalcumsum(alpha, T, omega, n) (src/algorithms.jl:8-29;
+ * totalweightsum(fsm, n) = totalcumsum, :36), one value per FSM of the batch, in the batch's semiring
+ * (Log or Tropical):  v_1 = alpha, v_k = T' v_{k-1};
+ *   cumulative = 0:  out[b] = omega . v_n            cumulative != 0:  out[b] = (+)_{k=1..n} omega . v_k
+ * Runs the emission-free alpha-recursion on the extended system (the phony final state's self loop of
+ * weight one is the accumulator) for n + 1 frames.  n >= 1; out: device float[B], natural log. */
+int mm_totalsum_f32(mm_batch_t batch, int64_t n, int cumulative, float *out, void *stream);
+
 /* Test aid (host only, no GPU): evaluate one semiring product out = M (x) in
  * THROUGH THE PACKED FORM the kernels consume, direction 0: M = T_hat'
  * (forward), 1: M = T_hat (backward).  in/out: host float[S1], natural log.

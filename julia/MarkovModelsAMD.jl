@@ -153,4 +153,18 @@ function bestpath(b::ROCBatch{K}, V::ROCArray{Float32,3}, lens = nothing) where 
     Array(path) .+ Int32(1), Array(score)
 end
 
+"""
+    totalsum(b::ROCBatch, n) / totalcumsum(b::ROCBatch, n) -> Vector{Float32}
+
+src/algorithms.jl:8-29 for every FSM of the batch (natural-log values of the batch's semiring).
+"""
+function _totalsum(b::ROCBatch, n::Integer, cumulative::Bool)
+    out = ROCArray{Float32}(undef, length(b.fsms))
+    check(ccall((:mm_totalsum_f32, LIB), Cint, (Ptr{Cvoid}, Int64, Cint, Ptr{Float32}, Ptr{Cvoid}),
+        b.handle, n, cumulative, pointer(out), AMDGPU.stream().stream))
+    Array(out)
+end
+MarkovModels.totalsum(b::ROCBatch, n::Integer) = _totalsum(b, n, false)
+MarkovModels.totalcumsum(b::ROCBatch, n::Integer) = _totalsum(b, n, true)
+
 end # module

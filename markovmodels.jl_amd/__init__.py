@@ -2,7 +2,7 @@
 
 Host-side mirror of the reference's hot-path interface (src/MarkovModels.jl:14-45:
 FSM, nstates, rawunion, CompiledFSM, batch, compile, expand, alpha-recursion,
-beta-recursion, pdfposteriors) over the C ABI in include/markovmodels_amd.h.
+beta-recursion, pdfposteriors, totalsum, totalcumsum, totalweightsum) over the C ABI in include/markovmodels_amd.h.
 The directory name contains a dot, so load it with
 ``__graft_entry__.load_package()`` (importlib) rather than a plain import.
 """
@@ -18,6 +18,9 @@ from .inference import (  # noqa: F401
     compile,
     expand,
     pdfposteriors,
+    totalcumsum,
+    totalsum,
+    totalweightsum,
     αrecursion,
     βrecursion,
 )

@@ -32,6 +32,7 @@ SYMBOLS = [
     "mm_alpharecursion_f32",
     "mm_betarecursion_f32",
     "mm_viterbi_f32",
+    "mm_totalsum_f32",
     "mm_debug_packed_product",
     "mm_debug_quad_product",
 ]
@@ -86,6 +87,8 @@ def _load():
         fn.argtypes = [vp, fp, i64, i64, vp, i64, fp, i64, vp]
     lib.mm_viterbi_f32.restype = C.c_int
     lib.mm_viterbi_f32.argtypes = [vp, fp, i64, i64, vp, i64, vp, i64, fp, vp, i64, vp]
+    lib.mm_totalsum_f32.restype = C.c_int
+    lib.mm_totalsum_f32.argtypes = [vp, i64, C.c_int, fp, vp]
     lib.mm_debug_packed_product.restype = C.c_int
     lib.mm_debug_packed_product.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.mm_debug_quad_product.restype = C.c_int

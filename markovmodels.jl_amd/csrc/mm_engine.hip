@@ -788,6 +788,31 @@ int mm_betarecursion_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     return run_export(h, MODE_BETA, V, vsb, vsn, lens, N, out, out_stride_n, stream);
 }
 
+int mm_totalsum_f32(mm_batch_t h, int64_t n, int cumulative, float *out, void *stream) {
+    static const float dummy = 0.f;
+    int rc = check_run(h, "mm_totalsum_f32", &dummy, n, -1);
+    if (rc) return rc;
+    if (!out) return fail(MM_ERR_INVALID, "mm_totalsum_f32: out is NULL");
+    // v_k and the running total live in the extended system (src/fsm.jl:19-28): the final state's self
+    // loop of weight one makes it the accumulator of omega . v_k; n + 1 frames of the alpha recursion
+    rc = ensure_ws(h, align_up(size_t(h->total_states) * size_t(n + 1) * 4, 256));
+    if (rc) return rc;
+    RunParams p{};
+    p.utts = h->d_utts;
+    p.N = int(n);
+    p.B = int(h->B);
+    p.out = static_cast<float *>(h->ws);
+    p.out_stride_n = h->total_states;
+    p.free_run = cumulative ? 2 : 1;
+    rc = h->semiring == MM_TROPICAL ? launch_tropical(h, p, stream) : launch_log<MODE_ALPHA>(h, p, stream);
+    if (rc) return rc;
+    const int bt = 64;
+    hipLaunchKernelGGL(mm_pick_final_kernel, dim3(unsigned((h->B + bt - 1) / bt)), dim3(bt), 0,
+                       static_cast<hipStream_t>(stream), h->d_utts, int(h->B), p.out, p.out_stride_n, int(n), out);
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+}
+
 int mm_viterbi_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const int32_t *lens, int64_t N,
                    int32_t *path, int64_t path_stride_b, float *score, int32_t *bp, int64_t bp_stride_n,
                    void *stream) {

@@ -88,6 +88,10 @@ struct RunParams {
     long long path_stride_b;
     float *score;
     unsigned long long *dbg;  // diagnostic builds only (-DMM_STAMPS): per-wave cycle sums per phase
+    // emission-free recursion of the total-sum family (src/algorithms.jl:8-29): every real pdf emits one(K)
+    // in every frame; the phony pdf emits zero(K) up to frame N (1: totalsum -- the final state then holds
+    // omega . v_N at frame N+1) or never (2: totalcumsum -- the final state accumulates omega . v_k)
+    int free_run;
 };
 
 // In-kernel cycle stamps (diagnostic build only; the shipped library executes none).
@@ -248,7 +252,7 @@ __device__ __forceinline__ void stage_em(float *dst, const float *Vb, long long 
     for (int q = tid; q <= P; q += NT) {
         float v;
         if (q < P)
-            v = (n <= len) ? Vb[(long long)(n - 1) * vsn + q] * scale : MM_NINF;
+            v = !Vb ? 0.f : ((n <= len) ? Vb[(long long)(n - 1) * vsn + q] * scale : MM_NINF);  // NULL: free run
         else
             v = (n <= len) ? MM_NINF : 0.f;
         dst[q] = v;
@@ -391,12 +395,13 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
     const int fstate = S1 - 1;
     int len = p.lens ? p.lens[b] : p.N;
     len = len < 0 ? 0 : (len > p.N ? p.N : len);
+    if (p.free_run == 2) len = 0;
     // frames are 1-based n = 1 .. N+1 as in the reference; FB stops at len+1,
     // where only the phony final state is alive (everything after is constant)
     const int NF = (MODE == MODE_FB) ? len + 1 : p.N + 1;
     const LdsPlan L = lds_plan(S1p, P1p, MODE == MODE_FB);
     float *buf = lds + L.buf, *stage = lds + L.stage, *em = lds + L.em, *bins = lds + L.bins, *part = lds + L.part;
-    const float *Vb = p.V + (long long)b * p.vsb;
+    const float *Vb = p.free_run ? nullptr : p.V + (long long)b * p.vsb;
     float *wsA = p.ws_alpha ? p.ws_alpha + u.s1p_prefix * (long long)(p.N + 1) : nullptr;
     double *wsC = p.ws_c ? p.ws_c + (long long)b * (p.N + 2) : nullptr;
     const GraphDev gf = u.g[0], gb = u.g[1];
@@ -643,11 +648,12 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
     const int S1 = u.S1, S1p = u.S1p, P1 = u.P1, P = P1 - 1, P1p = (P1 + 3) & ~3;
     int len = p.lens ? p.lens[b] : p.N;
     len = len < 0 ? 0 : (len > p.N ? p.N : len);
+    if (p.free_run == 2) len = 0;
     const int NF = p.N + 1;
     const LdsPlan L = lds_plan(S1p, P1p, true);
     float *buf = lds + L.buf, *em = lds + L.em;
     int *bpbuf = reinterpret_cast<int *>(lds + L.stage);  // [2][S1p]
-    const float *Vb = p.V + (long long)b * p.vsb;
+    const float *Vb = p.free_run ? nullptr : p.V + (long long)b * p.vsb;
     const GraphDev gf = u.g[0];
     int *bpb = p.bp ? p.bp + u.state_off : nullptr;
     ItemRegs<NI> rg;
@@ -681,7 +687,7 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
         float evraw;
         {
             const int nn = n + 1 > p.N ? p.N : n + 1, qq = tid < P ? tid : P - 1;
-            evraw = Vb[(long long)(nn - 1) * p.vsn + qq];
+            evraw = Vb ? Vb[(long long)(nn - 1) * p.vsn + qq] : 0.f;
         }
         if (bpb && n > 2) {  // back-pointers of frame n-1 (0-based row n-2): whole row, coalesced
             const int *src = bpbuf + ((n - 1) & 1) * S1p;
@@ -731,10 +737,10 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
         if (n + 1 <= NF) {
             if (tid <= P) {
                 float *dst = em + ((n + 1) & 1) * P1p;
-                if (tid < P) dst[tid] = (n + 1 <= len) ? evraw : MM_NINF;
+                if (tid < P) dst[tid] = (!Vb || n + 1 <= len) ? evraw : MM_NINF;
                 else dst[tid] = (n + 1 <= len) ? MM_NINF : 0.f;
             }
-            if (P >= NT) stage_em(em + ((n + 1) & 1) * P1p + NT, Vb + NT, p.vsn, n + 1, len, P - NT, tid, NT, 1.0f);
+            if (P >= NT) stage_em(em + ((n + 1) & 1) * P1p + NT, Vb ? Vb + NT : nullptr, p.vsn, n + 1, len, P - NT, tid, NT, 1.0f);
         }
         __syncthreads();
         if (n == len + 1 && tid == 0 && p.score) p.score[b] = an[S1 - 1];
@@ -763,6 +769,12 @@ __global__ void mm_backtrace_kernel(RunParams p) {
         if (ok) s = bpb[(long long)n * p.bp_stride_n + s];
         path[n - 1] = ok ? s : -1;
     }
+}
+
+// total-sum family: the value of the phony final state in frame n+1 (0-based row n) of the exported recursion
+__global__ void mm_pick_final_kernel(const UttDesc *utts, int B, const float *A, long long stride_n, int n, float *out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) out[b] = A[(long long)n * stride_n + utts[b].state_off + utts[b].S1 - 1];
 }
 
 }  // namespace mm

@@ -191,6 +191,15 @@ class BatchedFSM:
         return res
 
 
+    def totalsum(self, n: int, cumulative: bool = False):
+        """Per FSM of the batch: omega . v_n (totalsum) or the semiring sum over k <= n of omega . v_k
+        (totalcumsum), v_1 = alpha, v_k = T' v_{k-1} (src/algorithms.jl:8-29).  float32 tensor [B]."""
+        torch = _torch()
+        out = torch.empty(self.B, dtype=torch.float32, device="cuda")
+        check(lib.mm_totalsum_f32(self._h, int(n), int(bool(cumulative)), out.data_ptr(), self._stream(torch)))
+        return out
+
+
 def batch(*cfsms: CompiledFSM) -> BatchedFSM:
     """batch(fsm1, fsms...) (src/inference.jl:28-36)."""
     return BatchedFSM(cfsms)
@@ -282,6 +291,35 @@ def bestpath(fsm, Vhats, Chats=None):
     V, lens = _unexpand(Vhats)
     path, score = bf.viterbi(V, lens)
     return [path[b, : lens[b]].copy() for b in range(bf.B)], score
+
+
+def _total(fsm, n, cumulative):
+    if isinstance(fsm, (BatchedFSM, CompiledFSM)):
+        bf = _as_batch(fsm, None)
+    else:  # no emissions are involved: any state map will do
+        bf = BatchedFSM([CompiledFSM(fsm, StateMap(np.zeros(fsm.S1 - 1, dtype=np.int64), 1))])
+    out = bf.totalsum(n, cumulative).cpu().numpy()
+    return out if isinstance(fsm, BatchedFSM) else float(out[0])
+
+
+def totalsum(fsm, n: int):
+    """totalsum(alpha, T, omega, n) (src/algorithms.jl:23-29) of an FSM: the weight of all paths of exactly n
+    states, in the FSM's semiring, as a natural-log float (an array for a BatchedFSM)."""
+    return _total(fsm, n, False)
+
+
+def totalcumsum(fsm, n: int):
+    """totalcumsum(alpha, T, omega, n) (src/algorithms.jl:8-16): paths of up to n states."""
+    return _total(fsm, n, True)
+
+
+def totalweightsum(fsm, n: Optional[int] = None):
+    """totalweightsum(fsm, n = nstates(fsm)) (src/algorithms.jl:36)."""
+    if n is None:
+        if isinstance(fsm, BatchedFSM):
+            raise TypeError("totalweightsum of a batch needs n")
+        n = fsm.S1 - 1
+    return _total(fsm, n, True)
 
 
 # the reference's own (unicode) export names, src/MarkovModels.jl:40-45

@@ -332,6 +332,44 @@ def betarecursion(T_hat: CSC, lhs: np.ndarray, K: Semiring) -> np.ndarray:
     return B
 
 
+# ----------------------------------------------------------------------------
+# total-sum family  (src/algorithms.jl)
+# ----------------------------------------------------------------------------
+
+
+def _dense_Tt_v(T: np.ndarray, v: np.ndarray, K: Semiring) -> np.ndarray:
+    """T' * v in the semiring K (dense; T[i, j] = weight of arc i -> j)."""
+    return K.reduce(K.mul(T, v[:, None]), axis=0)
+
+
+def _dot(v: np.ndarray, w: np.ndarray, K: Semiring):
+    return K.reduce(K.mul(v, w), axis=0)
+
+
+def totalcumsum(alpha: np.ndarray, T: np.ndarray, omega: np.ndarray, n: int, K: Semiring):
+    """totalcumsum(alpha, T, omega, n) (src/algorithms.jl:8-16)."""
+    v = alpha
+    total = _dot(v, omega, K)
+    for _ in range(2, n + 1):
+        v = _dense_Tt_v(T, v, K)
+        total = K.add(total, _dot(v, omega, K))
+    return total
+
+
+def totalsum(alpha: np.ndarray, T: np.ndarray, omega: np.ndarray, n: int, K: Semiring):
+    """totalsum(alpha, T, omega, n) (src/algorithms.jl:23-29)."""
+    v = alpha
+    for _ in range(2, n + 1):
+        v = _dense_Tt_v(T, v, K)
+    return _dot(v, omega, K)
+
+
+def totalweightsum(fsm: FSM, n: Optional[int] = None):
+    """totalweightsum(fsm, n = nstates(fsm)) (src/algorithms.jl:36)."""
+    a, T, w = fsm_parts(fsm)
+    return totalcumsum(a, T, w, fsm.nstates if n is None else n, fsm.K)
+
+
 def pdfposteriors(fsm: FSM, Vhats: Sequence[np.ndarray], Chats: Sequence[CSC]):
     """pdfposteriors(fsm, V_hats, C_hats) (src/inference.jl:145-161).
 

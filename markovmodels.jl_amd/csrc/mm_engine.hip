@@ -569,9 +569,14 @@ int mm_debug_quad_product(mm_fsm_t f, int direction, int KQ, const float *in, fl
     for (int64_t i = 0; i < S1; ++i) {
         const RowRec &r = g.recs[i];
         float acc = 0.f;
-        if (!r.empty) {
-            acc = qs[r.qe];
-            for (int k = 0; k < r.nextra; ++k) acc += qs[r.first + k * KQ];
+        if (r.qe) {  // the kernel's row_total(): qs2 = {0, 0, qs...}
+            auto at = [&](int idx) { return idx < MM_QS_PAD ? 0.f : qs[size_t(idx - MM_QS_PAD)]; };
+            if (r.i2 == MM_ROW_LONG) {
+                acc = at(r.qe);
+                for (int q = r.i1; q < r.qe; q += KQ) acc += at(q);
+            } else {
+                acc = at(r.qe) + (at(r.i1) + at(r.i2));
+            }
         }
         out[g.order[i]] = (std::log2(acc) + mx) * MM_LN2;
     }

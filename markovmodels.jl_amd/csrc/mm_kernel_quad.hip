@@ -67,7 +67,7 @@ __host__ __device__ inline LdsPlanQ lds_plan_q(int S1p, int P1p, int nqcap) {
     l.pbuf = 0;
     l.abuf = l.pbuf + 2 * (((S1p + 31) & ~31) + 16);  // up to two bank-rotated copies of p (mm_pack.h quad_pstride)
     l.qs = l.abuf + 2 * S1p;
-    l.qrow = l.qs + ((nqcap + 3) & ~3);
+    l.qrow = l.qs + ((nqcap + MM_QS_PAD + 3) & ~3);  // two always-zero slots, then the quad sums
     l.em = l.qrow + S1p;
     l.part = l.em + 2 * P1p;
     l.recs = l.part + 2 * MM_MAX_WAVES;
@@ -174,29 +174,31 @@ __device__ __forceinline__ void quad_phase(const QuadRegs<KQ> &rg, const QuadDev
     }
 }
 
-// phase B: the sum of a row from its record (mm_pack.h RowRec: x = qe | first << 16, y = pdf | nextra << 16
-// | empty << 24): the running sum in its last quad plus the ends of the lanes it started in.  Most rows
-// span at most three lanes: their loads are independent and branch-free.
+// phase B: the sum of a row from its record (mm_pack.h RowRec as two words: x = qe | i1 << 16, y = pdf |
+// i2 << 16; qs2 = the two zero slots followed by the quad sums): the running sum in its last quad plus the
+// ends of the lanes it started in.  Rows that span at most three lanes -- nearly all -- take three
+// unconditional, independent loads (absent terms read a zero slot).
+__device__ __forceinline__ float row_short(const float *__restrict__ qs2, unsigned x, unsigned y) {
+    const float a = qs2[x & 0xffffu], b = qs2[x >> 16], c = qs2[y >> 16];
+    return a + (b + c);
+}
+__device__ __forceinline__ bool row_is_long(unsigned y) { return (y >> 16) == (unsigned)MM_ROW_LONG; }
 template <int KQ>
-__device__ __forceinline__ float row_total(const float *__restrict__ qs, unsigned x, unsigned y) {
-    const unsigned ne = y >> 16;
-    const int first = x >> 16;
-    const float a = qs[x & 0xffffu];
-    const float b = ne > 0u ? qs[first] : 0.f;
-    const float c = ne > 1u ? qs[first + KQ] : 0.f;
-    float acc = a + (b + c);
-    if (__builtin_expect(ne > 2u, 0)) {
-        if (ne >> 8) return 0.f;  // no arcs
-        for (unsigned k = 2; k < ne; k += 4) {
-            const float *q = qs + first + k * KQ;
-            const float d0 = q[0];
-            const float d1 = (k + 1 < ne) ? q[KQ] : 0.f;
-            const float d2 = (k + 2 < ne) ? q[2 * KQ] : 0.f;
-            const float d3 = (k + 3 < ne) ? q[3 * KQ] : 0.f;
-            acc += (d0 + d1) + (d2 + d3);
-        }
+__device__ __forceinline__ float row_long(const float *__restrict__ qs2, unsigned x) {
+    const int qe = x & 0xffffu;
+    float acc = qs2[qe];
+    for (int q = x >> 16; q < qe; q += 4 * KQ) {
+        const float d0 = qs2[q];
+        const float d1 = (q + KQ < qe) ? qs2[q + KQ] : 0.f;
+        const float d2 = (q + 2 * KQ < qe) ? qs2[q + 2 * KQ] : 0.f;
+        const float d3 = (q + 3 * KQ < qe) ? qs2[q + 3 * KQ] : 0.f;
+        acc += (d0 + d1) + (d2 + d3);
     }
     return acc;
+}
+template <int KQ>
+__device__ __forceinline__ float row_total(const float *__restrict__ qs2, unsigned x, unsigned y) {
+    return row_is_long(y) ? row_long<KQ>(qs2, x) : row_short(qs2, x, y);
 }
 // is the linear-domain sum in the range where log2 of it is accurate?  (one subtract + one unsigned
 // compare; negative, NaN and zero fall outside)
@@ -233,13 +235,35 @@ __device__ __forceinline__ float exact_row(const QuadDev &g, int r, const float 
 }
 
 struct RowRecU {
-    unsigned x, y;  // RowRec as two words: qe | first << 16,  pdf | nextra << 16 | empty << 24
+    unsigned x, y;  // RowRec as two words: qe | i1 << 16,  pdf | i2 << 16
     __device__ __forceinline__ unsigned pdf() const { return y & 0xffffu; }
-    __device__ __forceinline__ bool has_arcs() const { return (y >> 24) == 0u; }
+    __device__ __forceinline__ bool has_arcs() const { return (x & 0xffffu) != 0u; }
 };
 __device__ __forceinline__ RowRecU load_rec(const float *recs, int i) {
     const uint2 r = reinterpret_cast<const uint2 *>(recs)[i];
     return RowRecU{r.x, r.y};
+}
+// The records of this thread's rows tid, tid + NT, ... are read from LDS BEFORE the barrier that ends the
+// quad phase (they do not depend on it; the registers of the gathers are free by then), so that after the
+// barrier the emissions and partial sums of all rows are fetched by independent loads at once.
+template <int RPT>
+__device__ __forceinline__ void load_row_recs(RowRecU (&rr)[RPT], const float *recs, int tid, int NT, int S1) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int i = tid + k * NT;
+        rr[k] = load_rec(recs, i < S1 ? i : S1 - 1);  // no row: a valid record, the result is not stored
+    }
+}
+// does this thread own a row that needs the long walk?  (decided once per direction)
+template <int RPT>
+__device__ __forceinline__ bool any_long_row(const QuadDev &g, int tid, int NT, int S1) {
+    bool anylong = false;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int i = tid + k * NT;
+        if (i < S1) anylong |= row_is_long(as_global(reinterpret_cast<const mm_u32x2 *>(g.recs))[i].y);
+    }
+    return anylong;
 }
 
 // Emissions of one frame (expand(), src/inference.jl:54-60): EVERY thread loads a raw value
@@ -254,23 +278,38 @@ __device__ __forceinline__ float em_value(float raw, int n, int len, int P, int 
     return (n <= len) ? MM_NINF : 0.f;
 }
 
-// wave-wide max: 4 DPP steps inside the 16-lane rows, then the 4 row results through readlane
-// (no LDS crossbar round trips)
+// max without the canonicalising v_max x, x the compiler puts in front of every fmaxf (the hardware
+// instruction already returns the other operand for a NaN), and the 16-lane row maximum as four one-
+// instruction DPP steps (s_nop: a DPP read needs two wait states after the VALU write of its source)
+__device__ __forceinline__ float max_nc(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+        : "+v"(v));
+    return v;
+}
+// wave-wide max: the 16-lane rows by DPP, then the 4 row results through readlane (no LDS crossbar trips)
 __device__ __forceinline__ float wave_max_rl(float v) {
-    v = grp_max(v, 4);
+    v = row16_max(v);
     const int iv = __builtin_bit_cast(int, v);
     const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
     const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
     const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
     const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
-    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));  // scalar operands: folded on the scalar unit where possible
 }
 
 // max over the per-wave maxima of the previous frame (the lagged normaliser): one LDS read + a
 // DPP row reduction
 __device__ __forceinline__ float part_max_dpp(const float *part, int NW, int lane) {
     float v = (lane < NW) ? part[lane] : MM_NINF;
-    v = grp_max(v, 4);
+    v = row16_max(v);
     v = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
     return (v > MM_NINF) ? v : 0.f;
 }
@@ -325,7 +364,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
     const int nqmax = qf.nq > qb.nq ? qf.nq : qb.nq;
     const int vl = (nqmax + KQ - 1) / KQ;  // lanes (real + virtual) that hold quads
     const LdsPlanQ L = lds_plan_q(S1p, P1p, (vl > NT ? vl : NT) * KQ);
-    float *abuf = lds + L.abuf, *pbuf = lds + L.pbuf, *qs = lds + L.qs, *qrow = lds + L.qrow;
+    float *abuf = lds + L.abuf, *pbuf = lds + L.pbuf, *qs2 = lds + L.qs, *qs = qs2 + MM_QS_PAD, *qrow = lds + L.qrow;
     float *em = lds + L.em, *part = lds + L.part, *recs = lds + L.recs;
     unsigned short *pdfse = reinterpret_cast<unsigned short *>(lds + L.pdfse);
     float *psum = lds + L.psum;
@@ -342,6 +381,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
 
     // ---------------- forward: alpha-recursion (src/inference.jl:62-74), forward numbering ----------------
     stage_em(em + 1 * P1p, Vb, p.vsn, 1, len, P, tid, NT, MM_LOG2E);
+    if (tid < MM_QS_PAD) qs2[tid] = 0.f;  // absent terms of the row sums read these
     for (int q = tid; q < 2 * S1p; q += NT) abuf[q] = MM_NINF;
     for (int q = tid; q < 2 * (((S1p + 31) & ~31) + 16); q += NT) pbuf[q] = 0.f;
     for (int s = tid; s < S1; s += NT)
@@ -355,12 +395,13 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
             const float v = as_global(u.init_f)[i] + e1[load_rec(recs, i).pdf()];
             a1[i] = v;
             put_p(i, fast_exp2(v));
-            wm = fmaxf(wm, v);
+            wm = max_nc(wm, v);
         }
         part_put(part + 1 * MM_MAX_WAVES, wave, lane, wm);
         if (NF >= 2) stage_em(em + 0 * P1p, Vb, p.vsn, 2, len, P, tid, NT, MM_LOG2E);
     }
     load_quad_regs<KQ>(rg, qf, tid);
+    bool anylong = any_long_row<RPT>(qf, tid, NT, S1);
     __syncthreads();
     double C = 0.0;
     float ev = 0.f;
@@ -393,26 +434,25 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
         const float M = part_max_dpp(part + ((n - 1) & 1) * MM_MAX_WAVES, NW, lane);
         C += (double)M;
         if (tid == 0) wsM[n - 1] = M;  // M_{n-1}: C_n = sum_{k<n} M_k
+        RowRecU rr[RPT];
+        load_row_recs<RPT>(rr, recs, tid, NT, S1);
         MM_STAMP(1);
         __syncthreads();
         MM_STAMP(2);
         float wm = MM_NINF;
-        {   // this thread's rows tid, tid + NT, ...
-            RowRecU rec[RPT];
-            float e[RPT];
+        {   // this thread's rows tid, tid + NT, ...: emissions and partial sums, all loads independent
+            float e[RPT], acc[RPT];
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int i = tid + k * NT;
-                rec[k] = load_rec(recs, i < S1 ? i : S1 - 1);
+            for (int k = 0; k < RPT; ++k) e[k] = emn[rr[k].pdf()];
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) acc[k] = row_short(qs2, rr[k].x, rr[k].y);
+            if (__builtin_expect(anylong, 0)) {
+                // a long row whose emission is zero(K) this frame is zero whatever its sum is (the phony
+                // final state, whose row is by far the longest, for every frame but the last): not read
+#pragma unroll
+                for (int k = 0; k < RPT; ++k)
+                    if (row_is_long(rr[k].y)) acc[k] = e[k] > MM_NINF ? row_long<KQ>(qs2, rr[k].x) : 0.f;
             }
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) e[k] = emn[rec[k].pdf()];
-            float acc[RPT];
-            // a row whose emission is zero(K) this frame is zero whatever its sum is (the phony final
-            // state, whose row is by far the longest, for every frame but the last): do not read it
-#pragma unroll
-            for (int k = 0; k < RPT; ++k)
-                acc[k] = e[k] > MM_NINF ? row_total<KQ>(qs, rec[k].x, rec[k].y) : 0.f;
             MM_STAMP(5);
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
@@ -420,24 +460,23 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
                 if (i < S1) {
                     const bool ok = sum_in_range(acc[k]) || !(e[k] > MM_NINF);
 #ifdef MM_STAMPS
-                    stamp_acc[7] += __popcll(__ballot(!ok && rec[k].has_arcs()));
+                    stamp_acc[7] += __popcll(__ballot(!ok && rr[k].has_arcs()));
 #endif
                     float v = fast_log2(acc[k]);
                     // exact fallback, unless the sum is exactly 0 and no source can be alive-but-underflowed
-                    if (__builtin_expect(!ok, 0))
-                        v = rec[k].has_arcs() ? exact_row(qf, i, ap) : MM_NINF;
+                    if (__builtin_expect(!ok, 0)) v = rr[k].has_arcs() ? exact_row(qf, i, ap) : MM_NINF;
                     v = v + e[k] - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
                     const float pv = fast_exp2(v);
                     an[i] = v;
                     put_p(i, pv);
-                    wm = fmaxf(wm, v);
+                    wm = max_nc(wm, v);
                 }
             }
         }
         MM_STAMP(6);
         for (int i = tid + RPT * NT; i < S1; i += NT) {
             const RowRecU rec = load_rec(recs, i);
-            const float acc = row_total<KQ>(qs, rec.x, rec.y);
+            const float acc = row_total<KQ>(qs2, rec.x, rec.y);
             const bool ok = sum_in_range(acc);
             float v = fast_log2(acc);
             if (__builtin_expect(!ok, 0)) v = rec.has_arcs() ? exact_row(qf, i, ap) : MM_NINF;
@@ -445,7 +484,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
             const float pv = fast_exp2(v);
             an[i] = v;
             put_p(i, pv);
-            wm = fmaxf(wm, v);
+            wm = max_nc(wm, v);
         }
         part_put(part + (n & 1) * MM_MAX_WAVES, wave, lane, wm);
         MM_STAMP(3);
@@ -491,6 +530,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
     }
     if (len >= 1) stage_em(em + (len & 1) * P1p, Vb, p.vsn, len, len, P, tid, NT, MM_LOG2E);
     load_quad_regs<KQ>(rg, qb, tid);
+    anylong = any_long_row<RPT>(qb, tid, NT, S1);
     __syncthreads();
     // kappa_n = log2 Z - C_n - D_n = afin + G_n with G_n = sum_{k>=n} M_k(forward) - sum M(backward):
     // accumulated incrementally (double; its magnitude stays small), no per-frame double loads
@@ -536,12 +576,14 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
         }
         const float kappa = afin + (float)G;
         float wm = MM_NINF;
+        // (one row after the other here: fetching all rows' terms at once, as the forward pass does, was
+        // measured 30 % slower for this pass)
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const int i = tid + k * NT;
             if (i < S1) {
                 const RowRecU rec = load_rec(recs, i);
-                const float acc = row_total<KQ>(qs, rec.x, rec.y);
+                const float acc = row_total<KQ>(qs2, rec.x, rec.y);
                 const bool ok = sum_in_range(acc);
 #ifdef MM_STAMPS
                 stamp_acc[7] += __popcll(__ballot(!ok && rec.has_arcs()));
@@ -550,17 +592,17 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
                 // (the phony final state is exactly zero(K) or one(K) in the backward pass: no walk for it)
                 if (__builtin_expect(!ok, 0)) v = (rec.has_arcs() && i != qb.fpos) ? exact_row(qb, i, yp) : MM_NINF;
                 const float beta = v - M;  // T (B[:,n+1] (*) lhs[:,n+1])  (src/inference.jl:106-107)
-                qrow[i] = fast_exp2(acur[k] + beta - kappa);  // state_A .* state_B / Z
+                qrow[i] = fast_exp2(acur[k] + beta - kappa);
                 const float y = beta + emn[rec.pdf()];
                 const float py = fast_exp2(y);
                 yn[i] = y;
                 put_p(i, py);
-                wm = fmaxf(wm, y);
+                wm = max_nc(wm, y);
             }
         }
         for (int i = tid + RPT * NT; i < S1; i += NT) {  // more rows per thread than register slots
             const RowRecU rec = load_rec(recs, i);
-            const float acc = row_total<KQ>(qs, rec.x, rec.y);
+            const float acc = row_total<KQ>(qs2, rec.x, rec.y);
             const bool ok = sum_in_range(acc);
             float v = fast_log2(acc);
             if (__builtin_expect(!ok, 0)) v = (rec.has_arcs() && i != qb.fpos) ? exact_row(qb, i, yp) : MM_NINF;
@@ -570,7 +612,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
             const float py = fast_exp2(y);
             yn[i] = y;
             put_p(i, py);
-            wm = fmaxf(wm, y);
+            wm = max_nc(wm, y);
         }
         part_put(part + (n & 1) * MM_MAX_WAVES, wave, lane, wm);
 #pragma unroll

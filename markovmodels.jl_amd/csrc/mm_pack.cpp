@@ -202,7 +202,7 @@ int64_t count_quads(int64_t nrows, const std::vector<int64_t> &rowptr) {
 }
 
 bool quad_range_ok(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<float> &val, int32_t P1) {
-    if (nrows * 4 > 65535 || P1 > 65535 || count_quads(nrows, rowptr) > 65535) return false;
+    if (nrows * 4 > 65535 || P1 > 65535 || count_quads(nrows, rowptr) + MM_QS_PAD > 65535) return false;
     // the linear path needs 2^w and its products with values in [2^-126, 2^127] to stay normal
     for (float v : val)
         if (!(v > -100.f && v < 20.f)) return false;
@@ -278,11 +278,11 @@ QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const st
         RowRec rec;
         const int64_t nqr = nq_of(r), q0 = nq_total, qe = q0 + nqr - 1;
         const int64_t first = q0 + (KQ - 1 - q0 % KQ);
-        rec.qe = uint16_t(nqr ? qe : 0);
-        rec.first = uint16_t(nqr ? first : 0);
+        const int64_t nextra = nqr && first < qe ? (qe - first + KQ - 1) / KQ : 0;
+        rec.qe = uint16_t(nqr ? qe + MM_QS_PAD : 0);
+        rec.i1 = uint16_t(nextra >= 1 ? first + MM_QS_PAD : 0);
         rec.pdf = uint16_t(row2pdf[r]);
-        rec.nextra = uint8_t(nqr && first < qe ? (qe - first + KQ - 1) / KQ : 0);
-        rec.empty = nqr ? 0 : 1;
+        rec.i2 = uint16_t(nextra >= 3 ? MM_ROW_LONG : nextra == 2 ? first + KQ + MM_QS_PAD : 0);
         g.q0[i] = int32_t(q0);
         g.nq[i] = int32_t(nqr);
         g.recs[i] = rec;

@@ -77,14 +77,17 @@ struct Quad {
 };
 static_assert(sizeof(Quad) == 32, "Quad must be 32 bytes");
 
-struct RowRec {  // one per internal position: what the row-finishing thread needs, one 8-byte LDS read
-    uint16_t qe;      // last quad of the row: holds the running sum of the row's quads in its lane
-    uint16_t first;   // first lane-end quad (q % KQ == KQ - 1) of the row before qe
+// RowRec: one per internal position: what the thread that finishes the row needs, as indices into the array of
+// per-lane running quad sums.  That array starts with two slots that always hold 0 (index = quad + 2):
+// absent terms point at slot 0, so the common case is three unconditional loads and two adds.
+struct RowRec {
+    uint16_t qe;   // 2 + last quad of the row (it holds the running sum of the row's quads in its lane);
+                   // 0: the row has no arcs (its value is zero(K))
+    uint16_t i1;   // 2 + first lane-end quad (q % KQ == KQ - 1) of the row before its last quad, or 0
     uint16_t pdf;
-    uint8_t nextra;   // number of lane ends in [first, qe), KQ apart: partial sums of the earlier lanes
-    uint8_t empty;    // 1: the row has no arcs (its value is zero(K))
-    // (the first quad is recs[i - 1].qe + 1; kept on the host in QuadGraph::q0)
+    uint16_t i2;   // 2 + second lane end, or 0; 1 (MM_ROW_LONG): more than two -- walk i1, i1 + KQ, ... < qe
 };
+enum { MM_ROW_LONG = 1, MM_QS_PAD = 2 };
 static_assert(sizeof(RowRec) == 8, "RowRec must be 8 bytes");
 
 // The linear vector p is kept in `ncopy` LDS copies, copy c at float offset c * quad_pstride(): the

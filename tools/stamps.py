@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["MM_AMD_LIB"] = os.path.join(ROOT, "markovmodels.jl_amd", "libmarkovmodels_amd_stamps.so")
+os.environ.setdefault("MM_AMD_LIB", os.path.join(ROOT, "markovmodels.jl_amd", "libmarkovmodels_amd_stamps.so"))
 import __graft_entry__ as ge  # noqa: E402
 import torch  # noqa: E402
 

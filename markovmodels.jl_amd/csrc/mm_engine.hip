@@ -93,13 +93,14 @@ static size_t g_dbg_n = 0;
 #endif
 
 // The quad form of one FSM laid out for KQ quads per lane (mm_pack.h), resident on the device.
-struct QuadVariant {
-    int KQ = 0;
-    QuadGraph g[2];
-    std::vector<float> init_f;
-    std::vector<uint16_t> map_bf;
+struct QuadVariant {  // the quad form of ONE direction of an FSM for one KQ (quads per lane)
+    int KQ = 0, dir = 0;
+    QuadGraph g;
+    std::vector<float> init_f;      // dir 0: alpha_hat in forward numbering
+    std::vector<uint16_t> map_bf;   // dir 1: backward position -> forward position (the alpha store's order)
+    std::vector<uint16_t> dist;     // internal numbering
     void *blob = nullptr;
-    QuadDev qdev[2];
+    QuadDev qdev;
     const float *d_init_f = nullptr;
     const unsigned short *d_map_bf = nullptr;
 };
@@ -116,7 +117,7 @@ struct mm_fsm_s {
     Packed packed[2];
     bool fast_ok = false;  // the quad kernel's linear path is valid for this FSM
     int64_t nquads[2] = {0, 0};
-    std::map<int, QuadVariant *> variants;  // by KQ
+    std::map<int, QuadVariant *> variants;  // by 2 * KQ + direction
     std::vector<float> init;  // dense alpha_hat, engine domain
     std::vector<int32_t> s2p;
     int device = -1;
@@ -133,9 +134,12 @@ struct mm_batch_s {
     int64_t B;
     int64_t total_states = 0;
     int64_t total_s1p = 0;
-    int max_S1p = 0, max_P1 = 0, max_items = 0, max_quads = 0;
+    int max_S1p = 0, max_P1 = 0, max_items = 0;
+    int max_quads[2] = {0, 0};  // per direction (0 forward, 1 backward)
+    int64_t max_xcsr = 0;  // floats of the largest exact-fallback CSR (rowptr + col + w) of the batch
+    int xcsr = 0;          // floats of LDS reserved for it (0: it stays in global memory)
     bool fast_ok = true;
-    int geo_kq = 0, geo_nw = 1;
+    int geo_kq[2] = {0, 0}, geo_nw[2] = {1, 1};  // quad kernel geometry of the forward and the backward kernel
     int device = -1;
     UttDesc *d_utts = nullptr;
     void *ws = nullptr;
@@ -188,63 +192,72 @@ static int launch_log(mm_batch_t h, const RunParams &p, void *stream) {
     }
 }
 
-// The quad kernel (mm_kernel_quad.hip): KQ register-resident quads per lane, NW waves.
-static size_t quad_lds_bytes(mm_batch_t h, int KQ, int NW) {
-    const int P1p = (h->max_P1 + 3) & ~3;
-    const int vl = (h->max_quads + KQ - 1) / KQ;
-    return size_t(lds_plan_q(h->max_S1p, P1p, std::max(vl, 64 * NW) * KQ).total) * 4;
+// The quad kernels (mm_kernel_quad.hip): KQ register-resident quads per lane, NW waves; one kernel per
+// direction (PASS 0: forward, 1: backward), each with the geometry its own matrix needs.
+static size_t quad_lds_bytes(mm_batch_t h, int dir) {
+    const int P1p = (h->max_P1 + 3) & ~3, KQ = h->geo_kq[dir], NW = h->geo_nw[dir];
+    const int vl = (h->max_quads[dir] + KQ - 1) / KQ;
+    return (size_t(lds_plan_q(h->max_S1p, P1p, std::max(vl, 64 * NW) * KQ).total) + size_t(h->xcsr)) * 4;
 }
 
-template <int KQ, int RPT>
-static int launch_quad_kq_rpt(mm_batch_t h, const RunParams &p, int NW, void *stream) {
-    const size_t lds = quad_lds_bytes(h, KQ, NW);
-    auto kernel = mm_fbq_kernel<KQ, RPT>;
+template <int KQ, int RPT, int PASS>
+static int launch_quad_kq_rpt(mm_batch_t h, const RunParams &p, void *stream) {
+    const size_t lds = quad_lds_bytes(h, PASS);
+    auto kernel = mm_fbq_kernel<KQ, RPT, PASS>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 int(lds)));
-    hipLaunchKernelGGL(kernel, dim3(unsigned(h->B)), dim3(64 * NW), lds, static_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(kernel, dim3(unsigned(h->B)), dim3(64 * h->geo_nw[PASS]), lds, static_cast<hipStream_t>(stream), p);
     HIP_TRY(hipGetLastError());
     return MM_OK;
 }
 
-template <int KQ>
-static int launch_quad_kq(mm_batch_t h, const RunParams &p, int NW, void *stream) {
+template <int KQ, int PASS>
+static int launch_quad_kq(mm_batch_t h, const RunParams &p, void *stream) {
     // rows per thread = ceil(max S1 / threads): 2 register-carried rows when that is enough
-    const int rows = (h->max_S1p + 64 * NW - 1) / (64 * NW);
-    if (rows <= 2) return launch_quad_kq_rpt<KQ, 2>(h, p, NW, stream);
-    return launch_quad_kq_rpt<KQ, 3>(h, p, NW, stream);
+    const int NT = 64 * h->geo_nw[PASS], rows = (h->max_S1p + NT - 1) / NT;
+    if (rows <= 2) return launch_quad_kq_rpt<KQ, 2, PASS>(h, p, stream);
+    return launch_quad_kq_rpt<KQ, 3, PASS>(h, p, stream);
 }
 
 static bool quad_kernel_usable(mm_batch_t h) {
     if (const char *e = getenv("MM_KERNEL"))
         if (!strcmp(e, "item")) return false;
-    if (!h->fast_ok || h->geo_kq < 1) return false;
-    return quad_lds_bytes(h, h->geo_kq, h->geo_nw) <= 160 * 1024;
+    if (!h->fast_ok || h->geo_kq[0] < 1 || h->geo_kq[1] < 1) return false;
+    return quad_lds_bytes(h, 0) <= 160 * 1024 && quad_lds_bytes(h, 1) <= 160 * 1024;
 }
 
-static int launch_quad(mm_batch_t h, const RunParams &p, void *stream) {
-    const int NW = h->geo_nw;
-    switch (h->geo_kq) {
-        case 1: return launch_quad_kq<1>(h, p, NW, stream);
-        case 2: return launch_quad_kq<2>(h, p, NW, stream);
-        case 3: return launch_quad_kq<3>(h, p, NW, stream);
-        case 5: return launch_quad_kq<5>(h, p, NW, stream);
-        case 6: return launch_quad_kq<6>(h, p, NW, stream);
-        case 7: return launch_quad_kq<7>(h, p, NW, stream);
-        case 9: return launch_quad_kq<9>(h, p, NW, stream);
-        case 10: return launch_quad_kq<10>(h, p, NW, stream);
-        case 11: return launch_quad_kq<11>(h, p, NW, stream);
-        case 13: return launch_quad_kq<13>(h, p, NW, stream);
+template <int PASS>
+static int launch_quad_pass(mm_batch_t h, const RunParams &p, void *stream) {
+    switch (h->geo_kq[PASS]) {
+        case 1: return launch_quad_kq<1, PASS>(h, p, stream);
+        case 2: return launch_quad_kq<2, PASS>(h, p, stream);
+        case 3: return launch_quad_kq<3, PASS>(h, p, stream);
+        case 5: return launch_quad_kq<5, PASS>(h, p, stream);
+        case 6: return launch_quad_kq<6, PASS>(h, p, stream);
+        case 7: return launch_quad_kq<7, PASS>(h, p, stream);
+        case 9: return launch_quad_kq<9, PASS>(h, p, stream);
+        case 10: return launch_quad_kq<10, PASS>(h, p, stream);
+        case 11: return launch_quad_kq<11, PASS>(h, p, stream);
+        case 13: return launch_quad_kq<13, PASS>(h, p, stream);
         // 8-wave geometries: twice the quads per lane in twice the registers (more gathers in flight)
-        case 15: return launch_quad_kq<15>(h, p, std::min(NW, 8), stream);
-        case 17: return launch_quad_kq<17>(h, p, std::min(NW, 8), stream);
-        case 19: return launch_quad_kq<19>(h, p, std::min(NW, 8), stream);
-        case 21: return launch_quad_kq<21>(h, p, std::min(NW, 8), stream);
-        case 23: return launch_quad_kq<23>(h, p, std::min(NW, 8), stream);
-        case 25: return launch_quad_kq<25>(h, p, std::min(NW, 8), stream);
-        case 27: return launch_quad_kq<27>(h, p, std::min(NW, 8), stream);
-        case 29: return launch_quad_kq<29>(h, p, std::min(NW, 8), stream);
+        case 15: return launch_quad_kq<15, PASS>(h, p, stream);
+        case 17: return launch_quad_kq<17, PASS>(h, p, stream);
+        case 19: return launch_quad_kq<19, PASS>(h, p, stream);
+        case 21: return launch_quad_kq<21, PASS>(h, p, stream);
+        case 23: return launch_quad_kq<23, PASS>(h, p, stream);
+        case 25: return launch_quad_kq<25, PASS>(h, p, stream);
+        case 27: return launch_quad_kq<27, PASS>(h, p, stream);
+        case 29: return launch_quad_kq<29, PASS>(h, p, stream);
         default: return MM_ERR_UNSUPPORTED;
     }
+}
+
+// forward kernel, then backward kernel on the same stream: alpha, the per-frame normalisers and log Z travel
+// through the workspace
+static int launch_quad(mm_batch_t h, const RunParams &p, void *stream) {
+    int rc = launch_quad_pass<0>(h, p, stream);
+    if (rc) return rc;
+    return launch_quad_pass<1>(h, p, stream);
 }
 
 static int launch_tropical(mm_batch_t h, const RunParams &p, void *stream) {
@@ -446,60 +459,68 @@ static int fsm_to_device(mm_fsm_t f) {
     return MM_OK;
 }
 
-// build (once per KQ) and upload the quad form of an FSM
-static int quad_variant(mm_fsm_t f, int KQ, QuadVariant **out) {
-    auto it = f->variants.find(KQ);
+// build (once per direction and KQ) and upload the quad form of an FSM
+static int quad_variant(mm_fsm_t f, int dir, int KQ, QuadVariant **out) {
+    auto it = f->variants.find(2 * KQ + dir);
     if (it != f->variants.end()) {
         *out = it->second;
         return MM_OK;
     }
     QuadVariant *v = new QuadVariant();
     v->KQ = KQ;
-    v->g[0] = make_quads(f->S1, f->qmat[0].rowptr, f->qmat[0].col, f->qmat[0].val, f->s2p, f->P1, false, KQ);
-    v->g[1] = make_quads(f->S1, f->qmat[1].rowptr, f->qmat[1].col, f->qmat[1].val, f->s2p, f->P1, true, KQ);
+    v->dir = dir;
+    v->g = make_quads(f->S1, f->qmat[dir].rowptr, f->qmat[dir].col, f->qmat[dir].val, f->s2p, f->P1, dir == 1, KQ);
     if (getenv("MM_VERBOSE"))
-        for (int d = 0; d < 2; ++d)
-            fprintf(stderr, "[mm] quad form dir %d: KQ %d, %zu quads, %lld arcs, LDS cycles/gather (bank model) %.2f -> %.2f\n",
-                    d, KQ, v->g[d].quads.size(), (long long)f->qmat[d].rowptr[f->S1], v->g[d].conflict_before,
-                    v->g[d].conflict_after);
-    v->init_f.resize(f->S1);
-    v->map_bf.resize(f->S1);
-    for (int64_t i = 0; i < f->S1; ++i) {
-        v->init_f[i] = f->init[v->g[0].order[i]];
-        v->map_bf[i] = uint16_t(v->g[0].pos[v->g[1].order[i]]);
+        fprintf(stderr, "[mm] quad form dir %d: KQ %d, %zu quads, %lld arcs, LDS cycles/gather (bank model) %.2f -> %.2f\n",
+                dir, KQ, v->g.quads.size(), (long long)f->qmat[dir].rowptr[f->S1], v->g.conflict_before,
+                v->g.conflict_after);
+    if (dir == 0) {
+        v->init_f.resize(f->S1);
+        for (int64_t i = 0; i < f->S1; ++i) v->init_f[i] = f->init[v->g.order[i]];
+    } else {
+        // the forward numbering does not depend on KQ (rows by decreasing quads): take it from any forward form
+        std::vector<int32_t> order_f, pos_f;
+        quad_order(f->S1, f->qmat[0].rowptr, f->s2p, f->P1, false, order_f, pos_f);
+        v->map_bf.resize(f->S1);
+        for (int64_t i = 0; i < f->S1; ++i) v->map_bf[i] = uint16_t(pos_f[v->g.order[i]]);
+    }
+    {   // distances in original numbering: forward = arcs from an initial state (successor lists = rows of
+        // T_hat, qmat[1]); backward = arcs to the phony final state (predecessor lists = rows of T_hat', qmat[0])
+        std::vector<int32_t> seeds;
+        if (dir == 0) {
+            for (int64_t s = 0; s < f->S1; ++s)
+                if (f->init[s] > -std::numeric_limits<float>::infinity()) seeds.push_back(int32_t(s));
+        } else {
+            seeds.push_back(int32_t(f->S1 - 1));
+        }
+        const std::vector<uint16_t> d0 = reach_distance(f->S1, f->qmat[1 - dir].rowptr, f->qmat[1 - dir].col, seeds);
+        v->dist.resize(f->S1);
+        for (int64_t i = 0; i < f->S1; ++i) v->dist[i] = d0[v->g.order[i]];
     }
     Blob bl;
-    size_t o_q[2], o_rec[2], o_ptr[2], o_col[2], o_w[2], o_pse[2];
-    for (int d = 0; d < 2; ++d) {
-        o_q[d] = bl.add(v->g[d].quads);
-        o_rec[d] = bl.add(v->g[d].recs);
-        o_ptr[d] = bl.add(v->g[d].rowptr);
-        o_col[d] = bl.add(v->g[d].col);
-        o_w[d] = bl.add(v->g[d].w);
-        o_pse[d] = bl.add(v->g[d].pdfstart);
-    }
-    const size_t o_initf = bl.add(v->init_f), o_map = bl.add(v->map_bf);
+    const size_t o_q = bl.add(v->g.quads), o_rec = bl.add(v->g.recs), o_ptr = bl.add(v->g.rowptr);
+    const size_t o_col = bl.add(v->g.col), o_w = bl.add(v->g.w), o_pse = bl.add(v->g.pdfstart);
+    const size_t o_dist = bl.add(v->dist), o_initf = bl.add(v->init_f), o_map = bl.add(v->map_bf);
     int rc = upload(bl, &v->blob);
     if (rc) {
         delete v;
         return rc;
     }
     char *base = static_cast<char *>(v->blob);
-    for (int d = 0; d < 2; ++d) {
-        v->qdev[d].quads = reinterpret_cast<const Quad *>(base + o_q[d]);
-        v->qdev[d].recs = reinterpret_cast<const RowRec *>(base + o_rec[d]);
-        v->qdev[d].rowptr = reinterpret_cast<const int *>(base + o_ptr[d]);
-        v->qdev[d].col = reinterpret_cast<const int *>(base + o_col[d]);
-        v->qdev[d].w = reinterpret_cast<const float *>(base + o_w[d]);
-        v->qdev[d].pdfse = reinterpret_cast<const unsigned short *>(base + o_pse[d]);
-        v->qdev[d].nq = int(v->g[d].quads.size());
-        v->qdev[d].fpos = v->g[d].pos[f->S1 - 1];
-        v->qdev[d].ncopy = v->g[d].ncopy;
-        v->qdev[d].pad = 0;
-    }
+    v->qdev.quads = reinterpret_cast<const Quad *>(base + o_q);
+    v->qdev.recs = reinterpret_cast<const RowRec *>(base + o_rec);
+    v->qdev.rowptr = reinterpret_cast<const int *>(base + o_ptr);
+    v->qdev.col = reinterpret_cast<const int *>(base + o_col);
+    v->qdev.w = reinterpret_cast<const float *>(base + o_w);
+    v->qdev.pdfse = reinterpret_cast<const unsigned short *>(base + o_pse);
+    v->qdev.dist = reinterpret_cast<const unsigned short *>(base + o_dist);
+    v->qdev.nq = int(v->g.quads.size());
+    v->qdev.fpos = v->g.pos[f->S1 - 1];
+    v->qdev.ncopy = v->g.ncopy;
+    v->qdev.pad = 0;
     v->d_init_f = reinterpret_cast<const float *>(base + o_initf);
     v->d_map_bf = reinterpret_cast<const unsigned short *>(base + o_map);
-    f->variants[KQ] = v;
+    f->variants[2 * KQ + dir] = v;
     *out = v;
     return MM_OK;
 }
@@ -603,34 +624,41 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     h->semiring = fsms[0]->semiring;
     h->fsms.assign(fsms, fsms + B);
     std::vector<UttDesc> utts(B);
-    // quad kernel: one geometry (quads per lane, waves) for the whole batch
-    int64_t nq_max = 0;
+    // quad kernels: one geometry (quads per lane, waves) per direction for the whole batch
+    int64_t nq_max[2] = {0, 0};
     for (int64_t b = 0; b < B; ++b) {
         h->fast_ok = h->fast_ok && fsms[b]->fast_ok;
-        nq_max = std::max(nq_max, std::max(fsms[b]->nquads[0], fsms[b]->nquads[1]));
+        for (int d = 0; d < 2; ++d) nq_max[d] = std::max(nq_max[d], fsms[b]->nquads[d]);
     }
     h->fast_ok = h->fast_ok && h->semiring == MM_LOG;
     if (h->fast_ok) {
-        QuadGeometry geo = pick_quad_geometry(nq_max);
-        if (const char *e = getenv("MM_KQ")) {
-            int v = atoi(e);
-            if (v >= 1 && v <= 29) geo.KQ = v;
+        for (int d = 0; d < 2; ++d) {
+            QuadGeometry geo = pick_quad_geometry(nq_max[d]);
+            if (const char *e = getenv("MM_KQ")) {
+                int v = atoi(e);
+                if (v >= 1 && v <= 29) geo.KQ = v;
+            }
+            geo.NW = int(std::min<int64_t>(geo.KQ > 13 ? 8 : MM_MAX_WAVES,
+                                           std::max<int64_t>(1, (nq_max[d] + 64 * geo.KQ - 1) / (64 * geo.KQ))));
+            if (const char *e = getenv("MM_NWAVES")) {
+                int v = atoi(e);
+                if (v >= 1 && v <= (geo.KQ > 13 ? 8 : MM_MAX_WAVES)) geo.NW = v;
+            }
+            h->geo_kq[d] = geo.KQ;
+            h->geo_nw[d] = geo.NW;
+            h->max_quads[d] = int(nq_max[d]);
         }
-        geo.NW = int(std::min<int64_t>(geo.KQ > 13 ? 8 : MM_MAX_WAVES,
-                                       std::max<int64_t>(1, (nq_max + 64 * geo.KQ - 1) / (64 * geo.KQ))));
-        if (const char *e = getenv("MM_NWAVES")) {
-            int v = atoi(e);
-            if (v >= 1 && v <= MM_MAX_WAVES) geo.NW = v;
-        }
-        h->geo_kq = geo.KQ;
-        h->geo_nw = geo.NW;
-        h->max_quads = int(nq_max);
+        // small graphs keep the CSR the exact fallback walks in LDS (left-to-right graphs spread the
+        // values of one frame over far more than the float range: most of their rows take that path)
+        for (int64_t b = 0; b < B; ++b)
+            h->max_xcsr = std::max<int64_t>(h->max_xcsr, fsms[b]->S1 + 1 + 2 * std::max(fsms[b]->qmat[0].rowptr[fsms[b]->S1],
+                                                                                  fsms[b]->qmat[1].rowptr[fsms[b]->S1]));
     }
     for (int64_t b = 0; b < B; ++b) {
         mm_fsm_t f = fsms[b];
         int rc = fsm_to_device(f);
-        QuadVariant *qv = nullptr;
-        if (!rc && h->fast_ok) rc = quad_variant(f, h->geo_kq, &qv);
+        QuadVariant *qv[2] = {nullptr, nullptr};
+        for (int d = 0; d < 2 && !rc && h->fast_ok; ++d) rc = quad_variant(f, d, h->geo_kq[d], &qv[d]);
         if (rc) {
             delete h;
             return rc;
@@ -639,11 +667,11 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         memset(&u, 0, sizeof(u));
         u.g[0] = f->gdev[0];
         u.g[1] = f->gdev[1];
-        if (qv) {
-            u.q[0] = qv->qdev[0];
-            u.q[1] = qv->qdev[1];
-            u.init_f = qv->d_init_f;
-            u.map_bf = qv->d_map_bf;
+        if (qv[0] && qv[1]) {
+            u.q[0] = qv[0]->qdev;
+            u.q[1] = qv[1]->qdev;
+            u.init_f = qv[0]->d_init_f;
+            u.map_bf = qv[1]->d_map_bf;
         }
         u.init = f->d_init;
         u.s2p = f->d_s2p;
@@ -664,6 +692,10 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         if (h->d_utts) (void)hipFree(h->d_utts);
         delete h;
         return fail(MM_ERR_HIP, "mm_batch_create: device allocation failed");
+    }
+    if (h->fast_ok && !getenv("MM_NO_XCSR")) {
+        h->xcsr = int((h->max_xcsr + 3) & ~int64_t(3));
+        if (h->max_xcsr > 16 * 1024 || quad_lds_bytes(h, 0) > 128 * 1024 || quad_lds_bytes(h, 1) > 128 * 1024) h->xcsr = 0;
     }
     *out = h;
     return MM_OK;
@@ -744,6 +776,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     p.gsn = gsn;
     p.gsp = gsp;
     p.ttl = ttl;
+    p.xcsr = h->xcsr;
 #ifdef MM_STAMPS
     if (!g_dbg) {
         g_dbg_n = size_t(16) * MM_MAX_WAVES * size_t(h->B);

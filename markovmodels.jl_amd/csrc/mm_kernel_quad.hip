@@ -58,7 +58,7 @@ typedef unsigned mm_u32x2 __attribute__((ext_vector_type(2)));
 #define MM_Q_BIG 1.2676506e30f   // 2^100
 
 struct LdsPlanQ {
-    int abuf, pbuf, qs, qrow, em, part, recs, pdfse, psum, total;
+    int abuf, pbuf, qs, qrow, em, part, recs, dist, pdfse, psum, total;
 };
 // nqcap = quad slots: threads * KQ, or more when the graph overflows the register window
 __host__ __device__ inline LdsPlanQ lds_plan_q(int S1p, int P1p, int nqcap) {
@@ -71,7 +71,8 @@ __host__ __device__ inline LdsPlanQ lds_plan_q(int S1p, int P1p, int nqcap) {
     l.em = l.qrow + S1p;
     l.part = l.em + 2 * P1p;
     l.recs = l.part + 2 * MM_MAX_WAVES;
-    l.pdfse = l.recs + 2 * S1p;
+    l.dist = l.recs + 2 * S1p;  // u16 per row
+    l.pdfse = l.dist + ((S1p + 7) & ~7) / 2;
     l.psum = l.pdfse + P1p;
     l.total = l.psum + P1p;
     return l;
@@ -234,6 +235,29 @@ __device__ __forceinline__ float exact_row(const QuadDev &g, int r, const float 
     return m + fast_log2(s);
 }
 
+// the same walk over a copy of the CSR in LDS (small graphs, RunParams::xcsr)
+__device__ __forceinline__ float exact_row_lds(const int *rowptr, const int *col, const float *w, int r, const float *a) {
+    const int b = rowptr[r], e = rowptr[r + 1];
+    float m = MM_NINF;
+    for (int k = b; k < e; ++k) m = fmaxf(m, w[k] + a[col[k]]);
+    if (!(m > MM_NINF)) return MM_NINF;
+    if (!(m < __builtin_inff())) return m;
+    float s = 0.f;
+    for (int k = b; k < e; ++k) s += fast_exp2(w[k] + a[col[k]] - m);
+    return m + fast_log2(s);
+}
+// copy one direction's CSR into LDS: rowptr[S1 + 1], col[nnz], w[nnz]
+__device__ __forceinline__ void stage_xcsr(float *xc, const QuadDev &g, int S1, int tid, int NT) {
+    const int nnz = as_global(g.rowptr)[S1];
+    int *xr = reinterpret_cast<int *>(xc), *xcol = xr + S1 + 1;
+    float *xw = reinterpret_cast<float *>(xcol + nnz);
+    for (int s = tid; s <= S1; s += NT) xr[s] = as_global(g.rowptr)[s];
+    for (int k = tid; k < nnz; k += NT) {
+        xcol[k] = as_global(g.col)[k];
+        xw[k] = as_global(g.w)[k];
+    }
+}
+
 struct RowRecU {
     unsigned x, y;  // RowRec as two words: qe | i1 << 16,  pdf | i2 << 16
     __device__ __forceinline__ unsigned pdf() const { return y & 0xffffu; }
@@ -243,6 +267,14 @@ __device__ __forceinline__ RowRecU load_rec(const float *recs, int i) {
     const uint2 r = reinterpret_cast<const uint2 *>(recs)[i];
     return RowRecU{r.x, r.y};
 }
+// A row whose sum came out of range is usually simply dead: no path of this many arcs from an initial
+// state (forward) / to the final state (backward) exists (mm_pack.h reach_distance).  Those are zero(K)
+// without a walk; only the others go through exact_row().
+__device__ __forceinline__ bool row_is_dead(const unsigned short *distl, int i, int steps) {
+    const unsigned d = distl[i];
+    return d == 0xffffu || (unsigned)steps < d;
+}
+
 // The records of this thread's rows tid, tid + NT, ... are read from LDS BEFORE the barrier that ends the
 // quad phase (they do not depend on it; the registers of the gathers are free by then), so that after the
 // barrier the emissions and partial sums of all rows are fetched by independent loads at once.
@@ -349,7 +381,11 @@ __device__ __forceinline__ float finish_frame(const float *psum, int P1, int P, 
 
 // KQ: quads per lane held in registers.  RPT: rows per thread handled by the unrolled row-finishing code
 // (and whose alpha prefetch is carried in registers); more rows per thread go through a generic loop.
-template <int KQ, int RPT>
+// PASS 0: the forward kernel (alpha-recursion; leaves alpha, the per-frame normalisers and log Z in the
+// workspace).  PASS 1: the backward kernel (beta-recursion fused with the combine).  Two kernels rather than
+// one: each keeps only its own direction's pointers, masks and loop state in registers, and each direction
+// gets the number of quads per lane (KQ) its own matrix needs.
+template <int KQ, int RPT, int PASS>
 __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams p) {
     extern __shared__ float lds[];
     const int b = blockIdx.x;
@@ -361,24 +397,39 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
     len = len < 0 ? 0 : (len > p.N ? p.N : len);
     const int NF = len + 1;
     const QuadDev qf = u.q[0], qb = u.q[1];
-    const int nqmax = qf.nq > qb.nq ? qf.nq : qb.nq;
-    const int vl = (nqmax + KQ - 1) / KQ;  // lanes (real + virtual) that hold quads
+    const int nqd = PASS == 0 ? qf.nq : qb.nq;
+    const int vl = (nqd + KQ - 1) / KQ;  // lanes (real + virtual) that hold quads
     const LdsPlanQ L = lds_plan_q(S1p, P1p, (vl > NT ? vl : NT) * KQ);
     float *abuf = lds + L.abuf, *pbuf = lds + L.pbuf, *qs2 = lds + L.qs, *qs = qs2 + MM_QS_PAD, *qrow = lds + L.qrow;
     float *em = lds + L.em, *part = lds + L.part, *recs = lds + L.recs;
     unsigned short *pdfse = reinterpret_cast<unsigned short *>(lds + L.pdfse);
+    unsigned short *distl = reinterpret_cast<unsigned short *>(lds + L.dist);
     float *psum = lds + L.psum;
+    float *xc = lds + L.total;  // exact-fallback CSR, when the batch reserved LDS for it
+    const bool xres = p.xcsr > 0;
+    auto exact = [&](const QuadDev &g, int i, const float *a) -> float {
+        if (xres) {
+            const int *xr = reinterpret_cast<const int *>(xc), *xcol = xr + S1 + 1;
+            return exact_row_lds(xr, xcol, reinterpret_cast<const float *>(xcol + xr[S1]), i, a);
+        }
+        return exact_row(g, i, a);
+    };
     const float *Vb = p.V + (long long)b * p.vsb;
     float *wsA = p.ws_alpha + u.s1p_prefix * (long long)(p.N + 1);
     // per-frame forward normalisers M_k (floats; the double workspace row of this utterance is reused)
     float *wsM = reinterpret_cast<float *>(p.ws_c + (long long)b * (p.N + 2));
+    // hand-over between the two kernels, in the utterance's workspace row: [N] = normalised log2 value of the
+    // final state in the last frame, [N + 1] = log2 Z
+    double *hand = p.ws_c + (long long)b * (p.N + 2) + p.N;
     QuadRegs<KQ> rg;
-    const int ncopy = qf.ncopy, pstride = quad_pstride(S1p, ncopy);
+    const int ncopy = (PASS == 0 ? qf : qb).ncopy, pstride = quad_pstride(S1p, ncopy);
     auto put_p = [&](int i, float v) {  // every copy of the linear vector
         pbuf[i] = v;
         if (ncopy > 1) pbuf[pstride + i] = v;
     };
 
+    MM_STAMP_DECL;
+    if constexpr (PASS == 0) {
     // ---------------- forward: alpha-recursion (src/inference.jl:62-74), forward numbering ----------------
     stage_em(em + 1 * P1p, Vb, p.vsn, 1, len, P, tid, NT, MM_LOG2E);
     if (tid < MM_QS_PAD) qs2[tid] = 0.f;  // absent terms of the row sums read these
@@ -386,6 +437,8 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
     for (int q = tid; q < 2 * (((S1p + 31) & ~31) + 16); q += NT) pbuf[q] = 0.f;
     for (int s = tid; s < S1; s += NT)
         reinterpret_cast<mm_u32x2 *>(recs)[s] = as_global(reinterpret_cast<const mm_u32x2 *>(qf.recs))[s];
+    for (int s = tid; s < S1; s += NT) distl[s] = as_global(qf.dist)[s];
+    if (xres) stage_xcsr(xc, qf, S1, tid, NT);
     __syncthreads();
     {   // frame 1: alpha_hat (*) lhs[:,1]   (src/inference.jl:68)
         float wm = MM_NINF;
@@ -405,7 +458,6 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
     __syncthreads();
     double C = 0.0;
     float ev = 0.f;
-    MM_STAMP_DECL;
     MM_STAMP_RESET;
     for (int n = 2; n <= NF; ++n) {
         const float *ap = abuf + ((n - 1) & 1) * S1p;
@@ -464,7 +516,8 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
 #endif
                     float v = fast_log2(acc[k]);
                     // exact fallback, unless the sum is exactly 0 and no source can be alive-but-underflowed
-                    if (__builtin_expect(!ok, 0)) v = rr[k].has_arcs() ? exact_row(qf, i, ap) : MM_NINF;
+                    if (__builtin_expect(!ok, 0))
+                        v = (rr[k].has_arcs() && !row_is_dead(distl, i, n - 1)) ? exact(qf, i, ap) : MM_NINF;
                     v = v + e[k] - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
                     const float pv = fast_exp2(v);
                     an[i] = v;
@@ -479,7 +532,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
             const float acc = row_total<KQ>(qs2, rec.x, rec.y);
             const bool ok = sum_in_range(acc);
             float v = fast_log2(acc);
-            if (__builtin_expect(!ok, 0)) v = rec.has_arcs() ? exact_row(qf, i, ap) : MM_NINF;
+            if (__builtin_expect(!ok, 0)) v = (rec.has_arcs() && !row_is_dead(distl, i, n - 1)) ? exact(qf, i, ap) : MM_NINF;
             v = v + emn[rec.pdf()] - M;
             const float pv = fast_exp2(v);
             an[i] = v;
@@ -496,11 +549,15 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
         for (int k = 0; k < 8; ++k) p.dbg[((long long)b * MM_MAX_WAVES + wave) * 16 + k] = stamp_acc[k];
     for (int k = 0; k < 8; ++k) stamp_acc[k] = 0;
 #endif
-    const float afin = abuf[(NF & 1) * S1p + qf.fpos];  // normalised log2 value of the final state, last frame
-    const double logZ2 = (double)afin + C;
-    __syncthreads();
-
+    if (tid == 0) {
+        const float afin = abuf[(NF & 1) * S1p + qf.fpos];  // normalised log2 value of the final state, last frame
+        hand[0] = (double)afin;
+        hand[1] = (double)afin + C;
+    }
+    } else {
     // ---------------- backward: beta-recursion fused with the combine, backward numbering ----------------
+    const float afin = (float)hand[0];
+    const double logZ2 = hand[1];
     const long long gbase = (long long)b * p.gsb;
     if (!(logZ2 > -1e300)) {  // no accepting path: gamma = 0, ttl = -inf
         for (long long q = tid; q < (long long)p.N * P; q += NT)
@@ -510,8 +567,11 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
     }
     for (int q = tid; q < 2 * S1p; q += NT) abuf[q] = MM_NINF;
     for (int q = tid; q < 2 * (((S1p + 31) & ~31) + 16); q += NT) pbuf[q] = 0.f;
+    if (tid < MM_QS_PAD) qs2[tid] = 0.f;  // absent terms of the row sums read these
     for (int q = tid; q < S1p; q += NT) qrow[q] = 0.f;
     for (int s = tid; s < S1; s += NT) reinterpret_cast<mm_u32x2 *>(recs)[s] = as_global(reinterpret_cast<const mm_u32x2 *>(qb.recs))[s];
+    for (int s = tid; s < S1; s += NT) distl[s] = as_global(qb.dist)[s];
+    if (xres) stage_xcsr(xc, qb, S1, tid, NT);
     for (int s = tid; s < 2 * P1; s += NT) pdfse[s] = as_global(qb.pdfse)[s];
     // this thread's rows tid, tid + NT, ...: where their alpha sits in the (forward-numbered) store
     int amap[RPT];
@@ -530,18 +590,14 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
     }
     if (len >= 1) stage_em(em + (len & 1) * P1p, Vb, p.vsn, len, len, P, tid, NT, MM_LOG2E);
     load_quad_regs<KQ>(rg, qb, tid);
-    anylong = any_long_row<RPT>(qb, tid, NT, S1);
     __syncthreads();
     // kappa_n = log2 Z - C_n - D_n = afin + G_n with G_n = sum_{k>=n} M_k(forward) - sum M(backward):
     // accumulated incrementally (double; its magnitude stays small), no per-frame double loads
     double G = 0.0;
     float tmin = 0.f, evb = 0.f;  // min over frames of log2 of the per-frame sum (relative to log2 Z)
     float mfn = len >= 1 ? wsM[len] : 0.f;  // forward normaliser M_len, then prefetched one step ahead
-    double *zslot = p.ws_c + (long long)b * (p.N + 2) + (p.N + 1);  // log2 Z parked in the row's last slot
-    if (tid == 0) {
-        wsM[0] = 0.f;
-        *zslot = logZ2;
-    }
+    double *zslot = hand + 1;  // log2 Z
+    if (tid == 0) wsM[0] = 0.f;
     MM_STAMP_RESET;
     for (int n = len; n >= 1; --n) {
         const float *yp = abuf + ((n + 1) & 1) * S1p;
@@ -590,7 +646,8 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
 #endif
                 float v = fast_log2(acc);
                 // (the phony final state is exactly zero(K) or one(K) in the backward pass: no walk for it)
-                if (__builtin_expect(!ok, 0)) v = (rec.has_arcs() && i != qb.fpos) ? exact_row(qb, i, yp) : MM_NINF;
+                if (__builtin_expect(!ok, 0))
+                    v = (rec.has_arcs() && i != qb.fpos && !row_is_dead(distl, i, NF - n)) ? exact(qb, i, yp) : MM_NINF;
                 const float beta = v - M;  // T (B[:,n+1] (*) lhs[:,n+1])  (src/inference.jl:106-107)
                 qrow[i] = fast_exp2(acur[k] + beta - kappa);
                 const float y = beta + emn[rec.pdf()];
@@ -605,7 +662,8 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
             const float acc = row_total<KQ>(qs2, rec.x, rec.y);
             const bool ok = sum_in_range(acc);
             float v = fast_log2(acc);
-            if (__builtin_expect(!ok, 0)) v = (rec.has_arcs() && i != qb.fpos) ? exact_row(qb, i, yp) : MM_NINF;
+            if (__builtin_expect(!ok, 0))
+                    v = (rec.has_arcs() && i != qb.fpos && !row_is_dead(distl, i, NF - n)) ? exact(qb, i, yp) : MM_NINF;
             const float beta = v - M;
             qrow[i] = fast_exp2(wsA[(long long)n * S1p + as_global(u.map_bf)[i]] + beta - kappa);
             const float y = beta + emn[rec.pdf()];
@@ -644,6 +702,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
         for (int w = 1; w < NW; ++w) t = fminf(t, part[w]);
         p.ttl[b] = (float)((*zslot + (double)t) * (double)MM_LN2);
     }
+    }  // PASS
 }
 
 }  // namespace mm

@@ -51,6 +51,7 @@ struct QuadDev {  // one direction in quad form, internal numbering (mm_pack.h Q
     const int *col;
     const float *w;
     const unsigned short *pdfse;  // [2 * P1] (first, end) internal positions of each pdf (backward only)
+    const unsigned short *dist;   // [S1] fewest arcs from an initial state (forward) / to the final state (backward)
     int nq;
     int fpos;   // internal position of the phony final state
     int ncopy;  // LDS copies of the linear vector the quad offsets refer to (mm_pack.h quad_pstride)
@@ -92,6 +93,7 @@ struct RunParams {
     // in every frame; the phony pdf emits zero(K) up to frame N (1: totalsum -- the final state then holds
     // omega . v_N at frame N+1) or never (2: totalcumsum -- the final state accumulates omega . v_k)
     int free_run;
+    int xcsr;  // quad kernel: floats of LDS holding the exact-fallback CSR (0: walk it in global memory)
 };
 
 // In-kernel cycle stamps (diagnostic build only; the shipped library executes none).

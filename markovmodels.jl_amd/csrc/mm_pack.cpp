@@ -201,6 +201,32 @@ int64_t count_quads(int64_t nrows, const std::vector<int64_t> &rowptr) {
     return n;
 }
 
+std::vector<uint16_t> reach_distance(int64_t n, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &col,
+                                     const std::vector<int32_t> &seeds) {
+    std::vector<int64_t> d;
+    d.assign(size_t(n), -1);
+    std::vector<int32_t> frontier;
+    for (int32_t s : seeds)
+        if (s >= 0 && s < n && d[s] < 0) {
+            d[s] = 0;
+            frontier.push_back(s);
+        }
+    for (int64_t level = 1; !frontier.empty(); ++level) {
+        std::vector<int32_t> next;
+        for (int32_t s : frontier)
+            for (int64_t a = rowptr[s]; a < rowptr[s + 1]; ++a)
+                if (d[col[a]] < 0) {
+                    d[col[a]] = level;
+                    next.push_back(col[a]);
+                }
+        frontier.swap(next);
+    }
+    std::vector<uint16_t> out;
+    out.resize(size_t(n));
+    for (int64_t s = 0; s < n; ++s) out[s] = d[s] < 0 ? uint16_t(0xffff) : d[s] >= 0xffff ? uint16_t(0) : uint16_t(d[s]);
+    return out;
+}
+
 bool quad_range_ok(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<float> &val, int32_t P1) {
     if (nrows * 4 > 65535 || P1 > 65535 || count_quads(nrows, rowptr) + MM_QS_PAD > 65535) return false;
     // the linear path needs 2^w and its products with values in [2^-126, 2^127] to stay normal
@@ -209,18 +235,11 @@ bool quad_range_ok(int64_t nrows, const std::vector<int64_t> &rowptr, const std:
     return true;
 }
 
-QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &col,
-                     const std::vector<float> &val, const std::vector<int32_t> &row2pdf, int32_t P1, bool pdf_major,
-                     int KQ) {
-    QuadGraph g;
-    g.KQ = KQ;
-    const int S1p = int((nrows + 3) / 4 * 4);
-    g.ncopy = quad_ncopy(S1p);
-    const int pstride = quad_pstride(S1p, g.ncopy);
+void quad_order(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &row2pdf, int32_t P1,
+                bool pdf_major, std::vector<int32_t> &order, std::vector<int32_t> &pos) {
     auto nq_of = [&](int64_t r) { return (rowptr[r + 1] - rowptr[r] + 3) / 4; };
-    // ---- internal numbering
-    g.order.resize(nrows);
-    for (int64_t r = 0; r < nrows; ++r) g.order[r] = int32_t(r);
+    order.resize(nrows);
+    for (int64_t r = 0; r < nrows; ++r) order[r] = int32_t(r);
     if (pdf_major) {
         std::vector<double> sum(P1, 0.0), cnt(P1, 0.0);
         for (int64_t r = 0; r < nrows; ++r) {
@@ -233,15 +252,28 @@ QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const st
             return sum[a] / std::max(cnt[a], 1.0) > sum[b] / std::max(cnt[b], 1.0);
         });
         for (int32_t k = 0; k < P1; ++k) pdf_rank[pdf_order[k]] = k;
-        std::stable_sort(g.order.begin(), g.order.end(), [&](int32_t a, int32_t b) {
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
             if (row2pdf[a] != row2pdf[b]) return pdf_rank[row2pdf[a]] < pdf_rank[row2pdf[b]];
             return nq_of(a) > nq_of(b);
         });
     } else {
-        std::stable_sort(g.order.begin(), g.order.end(), [&](int32_t a, int32_t b) { return nq_of(a) > nq_of(b); });
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return nq_of(a) > nq_of(b); });
     }
-    g.pos.resize(nrows);
-    for (int64_t i = 0; i < nrows; ++i) g.pos[g.order[i]] = int32_t(i);
+    pos.resize(nrows);
+    for (int64_t i = 0; i < nrows; ++i) pos[order[i]] = int32_t(i);
+}
+
+QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &col,
+                     const std::vector<float> &val, const std::vector<int32_t> &row2pdf, int32_t P1, bool pdf_major,
+                     int KQ) {
+    QuadGraph g;
+    g.KQ = KQ;
+    const int S1p = int((nrows + 3) / 4 * 4);
+    g.ncopy = quad_ncopy(S1p);
+    const int pstride = quad_pstride(S1p, g.ncopy);
+    auto nq_of = [&](int64_t r) { return (rowptr[r + 1] - rowptr[r] + 3) / 4; };
+    // ---- internal numbering
+    quad_order(nrows, rowptr, row2pdf, P1, pdf_major, g.order, g.pos);
     if (pdf_major) {
         g.pdfstart.assign(P1 + 1, 0);
         std::vector<int64_t> count(P1 + 1, 0);

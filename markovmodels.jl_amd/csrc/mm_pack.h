@@ -132,6 +132,19 @@ QuadGraph make_quads(int64_t nrows, const std::vector<int64_t> &rowptr, const st
 
 // Number of quads of a CSR matrix, and whether its weights fit the linear path of the quad kernel.
 int64_t count_quads(int64_t nrows, const std::vector<int64_t> &rowptr);
+// The internal numbering make_quads() gives the rows of one direction (it does not depend on KQ): forward =
+// by decreasing number of quads, backward (pdf_major) = states of one pdf adjacent.  order: position -> row,
+// pos: row -> position.
+void quad_order(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &row2pdf, int32_t P1,
+                bool pdf_major, std::vector<int32_t> &order, std::vector<int32_t> &pos);
+
+// Fewest arcs from a seed state to every state, following adjacency rowptr/col (row -> its successors):
+// 0xffff = unreachable, 0 = seed or unknown (too far to store).  A state can carry weight at a recursion
+// step only if that step is at least its distance, so a row whose quad sum is exactly 0 before that is
+// known to be zero(K) without walking its arcs (mm_kernel_quad.hip).
+std::vector<uint16_t> reach_distance(int64_t n, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &col,
+                                     const std::vector<int32_t> &seeds);
+
 bool quad_range_ok(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<float> &val_log2, int32_t P1);
 
 // Host evaluation of one product through the packed form, lane by lane, with the

@@ -14,8 +14,13 @@ import torch  # noqa: E402
 
 mm = ge.load_package()
 wl = importlib.import_module(mm.__name__ + ".workloads")
-g = wl.lfmmi_denominator(2000, 84, seed=0)
-B, N = 256, 1500
+which = sys.argv[1] if len(sys.argv) > 1 else "lfmmi_den"
+if which == "wsj_num":
+    g, B, N = wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "num_fsm_wsj.npz")), 128, 700
+elif which == "wsj_den":
+    g, B, N = wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "den_fsm_wsj.npz")), 128, 700
+else:
+    g, B, N = wl.lfmmi_denominator(2000, 84, seed=0), 256, 1500
 cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
 bf = mm.batch(*([cf] * B))
 V = torch.randn(B, N, g.P, device="cuda")
@@ -31,4 +36,4 @@ for name, Vx in (("full", V), ("forward only", V.clone())):
         _, ttl = bf.pdfposteriors(Vx, out=gamma)
     ev[1].record()
     torch.cuda.synchronize()
-    print(f"{name:14s} {ev[0].elapsed_time(ev[1]) / 5:.3f} ms   ttl[0] = {float(ttl[0]):.3f}")
+    print(f"{which} {name:14s} {ev[0].elapsed_time(ev[1]) / 5:.3f} ms   ttl[0] = {float(ttl[0]):.3f}")

@@ -17,8 +17,14 @@ import torch  # noqa: E402
 mm = ge.load_package()
 wl = importlib.import_module(mm.__name__ + ".workloads")
 L = importlib.import_module(mm.__name__ + "._lib")
-g = wl.lfmmi_denominator(2000, 84, seed=0)
-B, N = 256, int(os.environ.get("N", 300))
+which = sys.argv[1] if len(sys.argv) > 1 else "lfmmi_den"
+if which == "wsj_num":
+    g, B = wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "num_fsm_wsj.npz")), 128
+elif which == "wsj_den":
+    g, B = wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "den_fsm_wsj.npz")), 128
+else:
+    g, B = wl.lfmmi_denominator(2000, 84, seed=0), 256
+N = int(os.environ.get("N", 300))
 cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
 bf = mm.batch(*([cf] * B))
 V = torch.randn(B, N, g.P, device="cuda")

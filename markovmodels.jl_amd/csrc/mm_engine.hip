@@ -693,7 +693,7 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         delete h;
         return fail(MM_ERR_HIP, "mm_batch_create: device allocation failed");
     }
-    if (h->fast_ok && !getenv("MM_NO_XCSR")) {
+    if (h->fast_ok && h->geo_kq[0] <= 3 && h->geo_kq[1] <= 3 && !getenv("MM_NO_XCSR")) {
         h->xcsr = int((h->max_xcsr + 3) & ~int64_t(3));
         if (h->max_xcsr > 16 * 1024 || quad_lds_bytes(h, 0) > 128 * 1024 || quad_lds_bytes(h, 1) > 128 * 1024) h->xcsr = 0;
     }

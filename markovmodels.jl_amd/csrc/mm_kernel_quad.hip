@@ -150,7 +150,7 @@ __device__ __forceinline__ float quad_sum(const float (&wl)[4], unsigned off01, 
 // (quad sum = sum_k 2^w_k * p[col_k] over its 4 arcs).  So the partial sums of a row are
 // found at the last quad of the row and at every lane end (q % KQ == KQ - 1) before it.
 template <int KQ>
-__device__ __forceinline__ void quad_phase(const QuadRegs<KQ> &rg, const QuadDev &g, int tid, int NT,
+__device__ __forceinline__ void quad_phase(const QuadRegs<KQ> &rg, const QuadDev &g, int nq, int tid, int NT,
                                            const float *__restrict__ pbuf, float *__restrict__ qs) {
     // pbuf and qs never overlap (__restrict__): the stores of one quad do not hold back the gathers of
     // the next, and no array of quad sums has to stay live
@@ -163,9 +163,9 @@ __device__ __forceinline__ void quad_phase(const QuadRegs<KQ> &rg, const QuadDev
         qs[tid * KQ + j] = run;
     });
     // lanes beyond the register window ("virtual lanes"): the same, streamed from L2
-    for (int v = NT + tid; v * KQ < g.nq; v += NT) {
+    for (int v = NT + tid; v * KQ < nq; v += NT) {
         float r = 0.f;
-        for (int j = 0; j < KQ && v * KQ + j < g.nq; ++j) {
+        for (int j = 0; j < KQ && v * KQ + j < nq; ++j) {
             float wl[4];
             unsigned off[2];
             load_quad(g.quads + v * KQ + j, wl, off);
@@ -396,8 +396,10 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
     int len = p.lens ? p.lens[b] : p.N;
     len = len < 0 ? 0 : (len > p.N ? p.N : len);
     const int NF = len + 1;
-    const QuadDev qf = u.q[0], qb = u.q[1];
-    const int nqd = PASS == 0 ? qf.nq : qb.nq;
+    // this kernel's direction.  A reference on purpose: the pointers only the set-up and the cold exact path
+    // need are re-read from memory there instead of occupying scalar registers through the time loop
+    const QuadDev &qf = u.q[0], &qb = u.q[1];
+    const int nqd = u.q[PASS].nq, fpos = u.q[PASS].fpos;
     const int vl = (nqd + KQ - 1) / KQ;  // lanes (real + virtual) that hold quads
     const LdsPlanQ L = lds_plan_q(S1p, P1p, (vl > NT ? vl : NT) * KQ);
     float *abuf = lds + L.abuf, *pbuf = lds + L.pbuf, *qs2 = lds + L.qs, *qs = qs2 + MM_QS_PAD, *qrow = lds + L.qrow;
@@ -406,7 +408,8 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
     unsigned short *distl = reinterpret_cast<unsigned short *>(lds + L.dist);
     float *psum = lds + L.psum;
     float *xc = lds + L.total;  // exact-fallback CSR, when the batch reserved LDS for it
-    const bool xres = p.xcsr > 0;
+    // (only the geometries of small graphs carry this code: it must not cost the large ones registers)
+    const bool xres = KQ <= 3 && p.xcsr > 0;
     auto exact = [&](const QuadDev &g, int i, const float *a) -> float {
         if (xres) {
             const int *xr = reinterpret_cast<const int *>(xc), *xcol = xr + S1 + 1;
@@ -422,7 +425,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
     // final state in the last frame, [N + 1] = log2 Z
     double *hand = p.ws_c + (long long)b * (p.N + 2) + p.N;
     QuadRegs<KQ> rg;
-    const int ncopy = (PASS == 0 ? qf : qb).ncopy, pstride = quad_pstride(S1p, ncopy);
+    const int ncopy = u.q[PASS].ncopy, pstride = quad_pstride(S1p, ncopy);
     auto put_p = [&](int i, float v) {  // every copy of the linear vector
         pbuf[i] = v;
         if (ncopy > 1) pbuf[pstride + i] = v;
@@ -472,7 +475,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
         }
         ev = em_load_raw(Vb, p.vsn, n + 1, p.N, P, tid);
         MM_STAMP(0);
-        quad_phase<KQ>(rg, qf, tid, NT, pbuf, qs);
+        quad_phase<KQ>(rg, qf, nqd, tid, NT, pbuf, qs);
         {   // frame n-1 leaves the chip once (coalesced, forward numbering) while frame n is computed
             float4 *dst = reinterpret_cast<float4 *>(wsA + (long long)(n - 1) * S1p);
             const float4 *src = reinterpret_cast<const float4 *>(ap);
@@ -550,7 +553,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
     for (int k = 0; k < 8; ++k) stamp_acc[k] = 0;
 #endif
     if (tid == 0) {
-        const float afin = abuf[(NF & 1) * S1p + qf.fpos];  // normalised log2 value of the final state, last frame
+        const float afin = abuf[(NF & 1) * S1p + fpos];  // normalised log2 value of the final state, last frame
         hand[0] = (double)afin;
         hand[1] = (double)afin + C;
     }
@@ -585,8 +588,8 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
     }
     __syncthreads();
     if (tid == 0) {  // frame len+1: B (*) lhs = one for the final state only
-        abuf[(NF & 1) * S1p + qb.fpos] = 0.f;
-        put_p(qb.fpos, 1.f);
+        abuf[(NF & 1) * S1p + fpos] = 0.f;
+        put_p(fpos, 1.f);
     }
     if (len >= 1) stage_em(em + (len & 1) * P1p, Vb, p.vsn, len, len, P, tid, NT, MM_LOG2E);
     load_quad_regs<KQ>(rg, qb, tid);
@@ -619,7 +622,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
         }
         MM_STAMP(0);
         if (n < len) pdf_sums(qrow, pdfse, psum, P1, wave, NW, lane);  // posteriors of frame n+1, per pdf
-        quad_phase<KQ>(rg, qb, tid, NT, pbuf, qs);
+        quad_phase<KQ>(rg, qb, nqd, tid, NT, pbuf, qs);
         // read before the barrier what phase B needs and does not depend on this frame's sums
         const float M = (n == len) ? 0.f : part_max_dpp(part + ((n + 1) & 1) * MM_MAX_WAVES, NW, lane);
         G += (double)mf - (double)M;
@@ -647,7 +650,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
                 float v = fast_log2(acc);
                 // (the phony final state is exactly zero(K) or one(K) in the backward pass: no walk for it)
                 if (__builtin_expect(!ok, 0))
-                    v = (rec.has_arcs() && i != qb.fpos && !row_is_dead(distl, i, NF - n)) ? exact(qb, i, yp) : MM_NINF;
+                    v = (rec.has_arcs() && i != fpos && !row_is_dead(distl, i, NF - n)) ? exact(qb, i, yp) : MM_NINF;
                 const float beta = v - M;  // T (B[:,n+1] (*) lhs[:,n+1])  (src/inference.jl:106-107)
                 qrow[i] = fast_exp2(acur[k] + beta - kappa);
                 const float y = beta + emn[rec.pdf()];
@@ -663,7 +666,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
             const bool ok = sum_in_range(acc);
             float v = fast_log2(acc);
             if (__builtin_expect(!ok, 0))
-                    v = (rec.has_arcs() && i != qb.fpos && !row_is_dead(distl, i, NF - n)) ? exact(qb, i, yp) : MM_NINF;
+                    v = (rec.has_arcs() && i != fpos && !row_is_dead(distl, i, NF - n)) ? exact(qb, i, yp) : MM_NINF;
             const float beta = v - M;
             qrow[i] = fast_exp2(wsA[(long long)n * S1p + as_global(u.map_bf)[i]] + beta - kappa);
             const float y = beta + emn[rec.pdf()];

@@ -156,7 +156,8 @@ struct Geometry {
 static Geometry pick_geometry(mm_batch_t h) {
     Geometry g{16, 8};
     const int it = h->max_items;
-    if (it <= 8 * MM_MAX_WAVES) g.NW = std::max(1, (it + 7) / 8);
+    // one workgroup per CU whatever its size: spread the items over as many waves as there are items
+    g.NW = std::max(1, std::min(MM_MAX_WAVES, it));
     if (const char *e = getenv("MM_NWAVES")) {
         int v = atoi(e);
         if (v >= 1 && v <= MM_MAX_WAVES) g.NW = v;

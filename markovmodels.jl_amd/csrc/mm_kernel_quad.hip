@@ -298,58 +298,6 @@ __device__ __forceinline__ bool any_long_row(const QuadDev &g, int tid, int NT, 
     return anylong;
 }
 
-// Emissions of one frame (expand(), src/inference.jl:54-60): EVERY thread loads a raw value
-// from a clamped, always valid address -- no branch and no arithmetic at the load, so nothing
-// waits for it; em_value() turns it into the log2 emission when it is stored to LDS a phase later.
-__device__ __forceinline__ float em_load_raw(const float *Vb, long long vsn, int n, int N, int P, int q) {
-    const int nn = n < 1 ? 1 : (n > N ? N : n), qq = q < P ? q : P - 1;
-    return Vb[(long long)(nn - 1) * vsn + qq];
-}
-__device__ __forceinline__ float em_value(float raw, int n, int len, int P, int q) {
-    if (q < P) return (n <= len) ? raw * MM_LOG2E : MM_NINF;
-    return (n <= len) ? MM_NINF : 0.f;
-}
-
-// max without the canonicalising v_max x, x the compiler puts in front of every fmaxf (the hardware
-// instruction already returns the other operand for a NaN), and the 16-lane row maximum as four one-
-// instruction DPP steps (s_nop: a DPP read needs two wait states after the VALU write of its source)
-__device__ __forceinline__ float max_nc(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float row16_max(float v) {
-    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
-        : "+v"(v));
-    return v;
-}
-// wave-wide max: the 16-lane rows by DPP, then the 4 row results through readlane (no LDS crossbar trips)
-__device__ __forceinline__ float wave_max_rl(float v) {
-    v = row16_max(v);
-    const int iv = __builtin_bit_cast(int, v);
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
-    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
-    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));  // scalar operands: folded on the scalar unit where possible
-}
-
-// max over the per-wave maxima of the previous frame (the lagged normaliser): one LDS read + a
-// DPP row reduction
-__device__ __forceinline__ float part_max_dpp(const float *part, int NW, int lane) {
-    float v = (lane < NW) ? part[lane] : MM_NINF;
-    v = row16_max(v);
-    v = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
-    return (v > MM_NINF) ? v : 0.f;
-}
-__device__ __forceinline__ void part_put(float *part, int wave, int lane, float wmax) {
-    wmax = wave_max_rl(wmax);
-    if (lane == 0) part[wave] = wmax;
-}
-
 // C' * (A .* B) (src/inference.jl:154-155) without atomics: states of one pdf are contiguous in the
 // backward numbering.  Every wave sums 8 pdfs per pass, 8 lanes per pdf (+ a 3-step DPP reduction).
 __device__ __forceinline__ void pdf_sums(const float *qrow, const unsigned short *pdfse, float *psum, int P1, int wave,

@@ -267,6 +267,59 @@ __device__ __forceinline__ float part_max(const float *part, int NW) {
     return (M > MM_NINF) ? M : 0.f;
 }
 
+// Emissions of one frame (expand(), src/inference.jl:54-60): EVERY thread loads a raw value
+// from a clamped, always valid address -- no branch and no arithmetic at the load, so nothing
+// waits for it; em_value() turns it into the log2 emission when it is stored to LDS a phase later.
+__device__ __forceinline__ float em_load_raw(const float *Vb, long long vsn, int n, int N, int P, int q) {
+    const int nn = n < 1 ? 1 : (n > N ? N : n), qq = q < P ? q : P - 1;
+    return Vb[(long long)(nn - 1) * vsn + qq];
+}
+__device__ __forceinline__ float em_value(float raw, int n, int len, int P, int q) {
+    if (q < P) return (n <= len) ? raw * MM_LOG2E : MM_NINF;
+    return (n <= len) ? MM_NINF : 0.f;
+}
+
+// max without the canonicalising v_max x, x the compiler puts in front of every fmaxf (the hardware
+// instruction already returns the other operand for a NaN), and the 16-lane row maximum as four one-
+// instruction DPP steps (s_nop: a DPP read needs two wait states after the VALU write of its source)
+__device__ __forceinline__ float max_nc(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+        : "+v"(v));
+    return v;
+}
+// wave-wide max: the 16-lane rows by DPP, then the 4 row results through readlane (no LDS crossbar trips)
+__device__ __forceinline__ float wave_max_rl(float v) {
+    v = row16_max(v);
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));  // scalar operands: folded on the scalar unit where possible
+}
+
+// max over the per-wave maxima of the previous frame (the lagged normaliser): one LDS read + a
+// DPP row reduction
+__device__ __forceinline__ float part_max_dpp(const float *part, int NW, int lane) {
+    float v = (lane < NW) ? part[lane] : MM_NINF;
+    v = row16_max(v);
+    v = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+    return (v > MM_NINF) ? v : 0.f;
+}
+__device__ __forceinline__ void part_put(float *part, int wave, int lane, float wmax) {
+    wmax = wave_max_rl(wmax);
+    if (lane == 0) part[wave] = wmax;
+}
+
+
 // ---------------------------------------------------------------------------
 // Register-resident graph.  The packed graph is the same for every frame, so a
 // wave keeps its first NI items (those with R <= 4) in VGPRs for the whole
@@ -432,15 +485,22 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
         __syncthreads();
         load_item_regs<NI>(rg, gf, wave, NW, lane);
         double C = 0.0, Cprev = 0.0;
+        // the emissions travel one frame ahead in a register: loaded during step n-1, stored to LDS at the top
+        // of step n, read after the barrier that ends it -- no step waits for its own global load
+        float evp = Vb ? em_load_raw(Vb, p.vsn, 3, p.N, P, tid) : 0.f;
         for (int n = 2; n <= NF; ++n) {
             const float *ap = buf + ((n - 1) & 1) * S1p;
             float *an = buf + (n & 1) * S1p;
             const float *emn = em + (n & 1) * P1p;
-            const float M = part_max(part + ((n - 1) & 1) * MM_MAX_WAVES, NW);
+            const float M = part_max_dpp(part + ((n - 1) & 1) * MM_MAX_WAVES, NW, lane);
             Cprev = C;
             C += (double)M;
             if (tid == 0 && wsC) wsC[n] = C;
-            if (n + 1 <= NF) stage_em(em + ((n + 1) & 1) * P1p, Vb, p.vsn, n + 1, len, P, tid, NT, MM_LOG2E);
+            if (n + 1 <= NF) {
+                if (tid <= P) em[((n + 1) & 1) * P1p + tid] = Vb ? em_value(evp, n + 1, len, P, tid) : ((tid < P || n + 1 > len) ? 0.f : MM_NINF);
+                if (P >= NT) stage_em(em + ((n + 1) & 1) * P1p + NT, Vb ? Vb + NT : nullptr, p.vsn, n + 1, len, P - NT, tid, NT, MM_LOG2E);
+            }
+            if (Vb) evp = em_load_raw(Vb, p.vsn, n + 2, p.N, P, tid);
             // frame n-1 leaves the chip once (coalesced), while frame n is computed
             if (MODE == MODE_FB) {
                 float4 *dst = reinterpret_cast<float4 *>(wsA + (long long)(n - 1) * S1p);
@@ -455,10 +515,9 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
             for_items<NI>(rg, gf, wave, NW, lane, ap, [&](float v, int row, int pdf) {
                 v = v + emn[pdf] - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
                 an[row] = v;
-                wm = fmaxf(wm, v);
+                wm = max_nc(wm, v);
             });
-            wm = wave_max(wm);
-            if (lane == 0) part[(n & 1) * MM_MAX_WAVES + wave] = wm;
+            part_put(part + (n & 1) * MM_MAX_WAVES, wave, lane, wm);
             __syncthreads();
         }
         const float *alast = buf + (NF & 1) * S1p;
@@ -496,15 +555,30 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
         load_item_regs<NI>(rg, gb, wave, NW, lane);
         double D = 0.0;
         float tmin = (float)logZ2;
+        // frame n-1 (emissions, alpha, C) travels in registers: loaded during step n+1, stored to LDS at the
+        // top of step n, read in step n-1 -- no step waits for its own global loads
+        constexpr int AK = 2;  // float4 of alpha per thread carried in registers; more rows are staged in place
+        const int n4 = S1p >> 2;
+        float evp = 0.f;
+        float4 apre[AK];
+        double Cn = len >= 1 ? __hip_atomic_load(&wsC[len], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0, Cpre = 0.0;
+        auto prefetch = [&](int f) {  // frame f >= 1
+            evp = em_load_raw(Vb, p.vsn, f, p.N, P, tid);
+            const float4 *src = reinterpret_cast<const float4 *>(wsA + (long long)f * S1p);
+#pragma unroll
+            for (int k = 0; k < AK; ++k)
+                if (tid + k * NT < n4) apre[k] = src[tid + k * NT];
+            Cpre = __hip_atomic_load(&wsC[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        if (len >= 2) prefetch(len - 1);
         for (int n = len; n >= 1; --n) {
             const float *yp = buf + ((n + 1) & 1) * S1p;
             float *yn = buf + (n & 1) * S1p;
             const float *ast = stage + (n & 1) * S1p;
             const float *emn = em + (n & 1) * P1p;
             float *bn = bins + (n & 1) * P1p;
-            const float M = (n == len) ? 0.f : part_max(part + ((n + 1) & 1) * MM_MAX_WAVES, NW);
+            const float M = (n == len) ? 0.f : part_max_dpp(part + ((n + 1) & 1) * MM_MAX_WAVES, NW, lane);
             D += (double)M;
-            const double Cn = __hip_atomic_load(&wsC[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float kappa = (float)(logZ2 - Cn - D);
             // finalise frame n+1 (one rotating wave): C' * AB, per-frame sum, divide, exp (src/inference.jl:155-160)
             if (n < len && wave == ((n + 1) % NW)) {
@@ -520,11 +594,19 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
                 }
                 tmin = fminf(tmin, (float)(logZ2 + (double)fast_log2(s)));
             }
-            if (n - 1 >= 1) {
-                stage_em(em + ((n - 1) & 1) * P1p, Vb, p.vsn, n - 1, len, P, tid, NT, MM_LOG2E);
-                const float4 *src = reinterpret_cast<const float4 *>(wsA + (long long)(n - 1) * S1p);
+            if (n - 1 >= 1) {  // frame n-1 from the registers into the buffers frame n+1 has left
+                if (tid <= P) em[((n - 1) & 1) * P1p + tid] = em_value(evp, n - 1, len, P, tid);
+                if (P >= NT) stage_em(em + ((n - 1) & 1) * P1p + NT, Vb + NT, p.vsn, n - 1, len, P - NT, tid, NT, MM_LOG2E);
                 float4 *dst = reinterpret_cast<float4 *>(stage + ((n - 1) & 1) * S1p);
-                for (int q = tid; q < (S1p >> 2); q += NT) dst[q] = src[q];
+#pragma unroll
+                for (int k = 0; k < AK; ++k)
+                    if (tid + k * NT < n4) dst[tid + k * NT] = apre[k];
+                if (n4 > AK * NT) {
+                    const float4 *src = reinterpret_cast<const float4 *>(wsA + (long long)(n - 1) * S1p);
+                    for (int q = tid + AK * NT; q < n4; q += NT) dst[q] = src[q];
+                }
+                Cn = Cpre;
+                if (n - 2 >= 1) prefetch(n - 2);
             }
             float wm = MM_NINF;
             for_items<NI>(rg, gb, wave, NW, lane, yp, [&](float v, int row, int pdf) {
@@ -533,10 +615,9 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
                 if (q > 0.f) atomicAdd(&bn[pdf], q);
                 const float y = beta + emn[pdf];
                 yn[row] = y;
-                wm = fmaxf(wm, y);
+                wm = max_nc(wm, y);
             });
-            wm = wave_max(wm);
-            if (lane == 0) part[(n & 1) * MM_MAX_WAVES + wave] = wm;
+            part_put(part + (n & 1) * MM_MAX_WAVES, wave, lane, wm);
             __syncthreads();
         }
         // finalise frame 1, zero the frames beyond len, reduce ttl

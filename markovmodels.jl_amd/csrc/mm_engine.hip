@@ -639,8 +639,12 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
                 int v = atoi(e);
                 if (v >= 1 && v <= 29) geo.KQ = v;
             }
+            // enough waves for the quads, and for at most two rows per thread where the workgroup can be that large
+            int64_t s1_max = 0;
+            for (int64_t b = 0; b < B; ++b) s1_max = std::max(s1_max, fsms[b]->S1);
             geo.NW = int(std::min<int64_t>(geo.KQ > 13 ? 8 : MM_MAX_WAVES,
-                                           std::max<int64_t>(1, (nq_max[d] + 64 * geo.KQ - 1) / (64 * geo.KQ))));
+                                           std::max<int64_t>({1, (nq_max[d] + 64 * geo.KQ - 1) / (64 * geo.KQ),
+                                                              (s1_max + 127) / 128})));
             if (const char *e = getenv("MM_NWAVES")) {
                 int v = atoi(e);
                 if (v >= 1 && v <= (geo.KQ > 13 ? 8 : MM_MAX_WAVES)) geo.NW = v;

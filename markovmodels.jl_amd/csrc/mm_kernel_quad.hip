@@ -74,7 +74,7 @@ __host__ __device__ inline LdsPlanQ lds_plan_q(int S1p, int P1p, int nqcap) {
     l.dist = l.recs + 2 * S1p;  // u16 per row
     l.pdfse = l.dist + ((S1p + 7) & ~7) / 2;
     l.psum = l.pdfse + P1p;
-    l.total = l.psum + P1p;
+    l.total = l.psum + 2 * P1p;  // two frames: one being summed, one being normalised and written out
     return l;
 }
 
@@ -545,6 +545,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
     // kappa_n = log2 Z - C_n - D_n = afin + G_n with G_n = sum_{k>=n} M_k(forward) - sum M(backward):
     // accumulated incrementally (double; its magnitude stays small), no per-frame double loads
     double G = 0.0;
+    const int fin_wave = NW > 2 ? 2 : 0;
     float tmin = 0.f, evb = 0.f;  // min over frames of log2 of the per-frame sum (relative to log2 Z)
     float mfn = len >= 1 ? wsM[len] : 0.f;  // forward normaliser M_len, then prefetched one step ahead
     double *zslot = hand + 1;  // log2 Z
@@ -569,7 +570,14 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
                 if (tid + k * NT < S1) anxt[k] = src[amap[k]];
         }
         MM_STAMP(0);
-        if (n < len) pdf_sums(qrow, pdfse, psum, P1, wave, NW, lane);  // posteriors of frame n+1, per pdf
+        // gamma of frame n+2: its per-pdf sums were completed in the previous step.  One wave normalises
+        // and writes them now, ahead of its quad phase -- a wave of the first quarter, whose rows (sorted
+        // by length within the pdf groups) leave it waiting at the next barrier anyway
+        if (n + 2 <= len && wave == fin_wave) {
+            const float s = finish_frame(psum + ((n + 2) & 1) * P1p, P1, P, lane, p.gamma + gbase + (long long)(n + 1) * p.gsn, p.gsp);
+            tmin = fminf(tmin, fast_log2(s));
+        }
+        if (n < len) pdf_sums(qrow, pdfse, psum + ((n + 1) & 1) * P1p, P1, wave, NW, lane);  // frame n+1, per pdf
         quad_phase<KQ>(rg, qb, nqd, tid, NT, pbuf, qs);
         // read before the barrier what phase B needs and does not depend on this frame's sums
         const float M = (n == len) ? 0.f : part_max_dpp(part + ((n + 1) & 1) * MM_MAX_WAVES, NW, lane);
@@ -577,10 +585,6 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
         MM_STAMP(1);
         __syncthreads();
         MM_STAMP(2);
-        if (n < len && wave == ((n + 1) % NW)) {  // gamma of frame n+1
-            const float s = finish_frame(psum, P1, P, lane, p.gamma + gbase + (long long)n * p.gsn, p.gsp);
-            tmin = fminf(tmin, fast_log2(s));
-        }
         const float kappa = afin + (float)G;
         float wm = MM_NINF;
         // (one row after the other here: fetching all rows' terms at once, as the forward pass does, was
@@ -635,11 +639,15 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
         for (int k = 0; k < 8; ++k) p.dbg[((long long)b * MM_MAX_WAVES + wave) * 16 + 8 + k] = stamp_acc[k];
 #endif
     // gamma of frame 1, zeros beyond len, ttl
+    if (len >= 2 && wave == fin_wave) {  // frame 2: summed in the last step
+        const float s = finish_frame(psum + 0 * P1p, P1, P, lane, p.gamma + gbase + p.gsn, p.gsp);
+        tmin = fminf(tmin, fast_log2(s));
+    }
     if (len >= 1) {
-        pdf_sums(qrow, pdfse, psum, P1, wave, NW, lane);
+        pdf_sums(qrow, pdfse, psum + 1 * P1p, P1, wave, NW, lane);
         __syncthreads();
         if (wave == 0) {
-            const float s = finish_frame(psum, P1, P, lane, p.gamma + gbase, p.gsp);
+            const float s = finish_frame(psum + 1 * P1p, P1, P, lane, p.gamma + gbase, p.gsp);
             tmin = fminf(tmin, fast_log2(s));
         }
     }

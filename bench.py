@@ -191,7 +191,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "mm_fbq_kernel<KQ> (quad kernel)",
+                "kernel": "mm_fbq_kernel<KQ,RPT,0> + mm_fbq_kernel<KQ,RPT,1> (forward + backward quad kernels of one call)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -220,11 +220,56 @@ __device__ __forceinline__ float seg_sum(const float *qs, int q0, int q1) {
     return acc;
 }
 
-// exact log-semiring row product from the log2 vector (two-pass log-sum-exp over the CSR row)
+// exact log-semiring row product from the log2 vector: two-pass log-sum-exp over the CSR row.  The arcs
+// are fetched four at a time with independent loads (index and weight, then the gathered values), and the
+// first four stay in registers for the second pass -- rows of left-to-right graphs rarely have more.
+template <class IP, class FP>
+__device__ __forceinline__ float exact_row_walk(IP rowptr, IP col, FP w, int r, const float *a) {
+    const int b = rowptr[r], e = rowptr[r + 1];
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = b + i < e ? b + i : b;  // clamped: a valid arc, masked below
+        const int c = col[k];
+        const float wk = w[k];
+        t[i] = (b + i < e) ? wk + a[c] : MM_NINF;
+    }
+    float m = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
+    for (int k0 = b + 4; k0 < e; k0 += 4) {
+        float u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + i < e ? k0 + i : k0;
+            const int c = col[k];
+            const float wk = w[k];
+            u[i] = (k0 + i < e) ? wk + a[c] : MM_NINF;
+        }
+        m = fmaxf(m, fmaxf(fmaxf(u[0], u[1]), fmaxf(u[2], u[3])));
+    }
+    if (!(m > MM_NINF) || b >= e) return MM_NINF;
+    if (!(m < __builtin_inff())) return m;
+    float s = (fast_exp2(t[0] - m) + fast_exp2(t[1] - m)) + (fast_exp2(t[2] - m) + fast_exp2(t[3] - m));
+    for (int k0 = b + 4; k0 < e; k0 += 4) {
+        float u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + i < e ? k0 + i : k0;
+            const int c = col[k];
+            const float wk = w[k];
+            u[i] = (k0 + i < e) ? wk + a[c] : MM_NINF;
+        }
+        s += (fast_exp2(u[0] - m) + fast_exp2(u[1] - m)) + (fast_exp2(u[2] - m) + fast_exp2(u[3] - m));
+    }
+    return m + fast_log2(s);
+}
+// FAST: the pipelined walk (small-graph geometries, where most rows come here and registers are plentiful);
+// otherwise the plain loop, whose few registers do not disturb the allocation of the large geometries
+template <bool FAST>
 __device__ __forceinline__ float exact_row(const QuadDev &g, int r, const float *a) {
     const auto rowptr = as_global(g.rowptr);
     const auto col = as_global(g.col);
     const auto w = as_global(g.w);
+    if constexpr (FAST) return exact_row_walk(rowptr, col, w, r, a);
     const int b = rowptr[r], e = rowptr[r + 1];
     float m = MM_NINF;
     for (int k = b; k < e; ++k) m = fmaxf(m, w[k] + a[col[k]]);
@@ -234,17 +279,9 @@ __device__ __forceinline__ float exact_row(const QuadDev &g, int r, const float 
     for (int k = b; k < e; ++k) s += fast_exp2(w[k] + a[col[k]] - m);
     return m + fast_log2(s);
 }
-
 // the same walk over a copy of the CSR in LDS (small graphs, RunParams::xcsr)
 __device__ __forceinline__ float exact_row_lds(const int *rowptr, const int *col, const float *w, int r, const float *a) {
-    const int b = rowptr[r], e = rowptr[r + 1];
-    float m = MM_NINF;
-    for (int k = b; k < e; ++k) m = fmaxf(m, w[k] + a[col[k]]);
-    if (!(m > MM_NINF)) return MM_NINF;
-    if (!(m < __builtin_inff())) return m;
-    float s = 0.f;
-    for (int k = b; k < e; ++k) s += fast_exp2(w[k] + a[col[k]] - m);
-    return m + fast_log2(s);
+    return exact_row_walk(rowptr, col, w, r, a);
 }
 // copy one direction's CSR into LDS: rowptr[S1 + 1], col[nnz], w[nnz]
 __device__ __forceinline__ void stage_xcsr(float *xc, const QuadDev &g, int S1, int tid, int NT) {
@@ -363,7 +400,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
             const int *xr = reinterpret_cast<const int *>(xc), *xcol = xr + S1 + 1;
             return exact_row_lds(xr, xcol, reinterpret_cast<const float *>(xcol + xr[S1]), i, a);
         }
-        return exact_row(g, i, a);
+        return exact_row<(KQ <= 3)>(g, i, a);
     };
     const float *Vb = p.V + (long long)b * p.vsb;
     float *wsA = p.ws_alpha + u.s1p_prefix * (long long)(p.N + 1);

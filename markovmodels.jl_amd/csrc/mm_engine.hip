@@ -141,6 +141,7 @@ struct mm_batch_s {
     bool fast_ok = true;
     int geo_kq[2] = {0, 0}, geo_nw[2] = {1, 1};  // quad kernel geometry of the forward and the backward kernel
     int device = -1;
+    int n_cus = 256;  // compute units of the device
     UttDesc *d_utts = nullptr;
     void *ws = nullptr;
     size_t ws_bytes = 0;
@@ -692,6 +693,12 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         h->max_P1 = std::max(h->max_P1, int(f->P1));
         h->max_items = std::max(h->max_items, std::max(f->gdev[0].n_items, f->gdev[1].n_items));
     }
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            h->n_cus = cus;
+    }
     if (hipGetDevice(&h->device) != hipSuccess || hipMalloc(&h->d_utts, sizeof(UttDesc) * B) != hipSuccess ||
         hipMemcpy(h->d_utts, utts.data(), sizeof(UttDesc) * B, hipMemcpyHostToDevice) != hipSuccess) {
         if (h->d_utts) (void)hipFree(h->d_utts);
@@ -732,7 +739,7 @@ static size_t ws_c_bytes(mm_batch_t h, int64_t N) { return align_up(size_t(h->B)
 
 size_t mm_batch_workspace_bytes(mm_batch_t h, int64_t N) {
     if (!h || N < 0) return 0;
-    return ws_alpha_bytes(h, N) + ws_c_bytes(h, N);
+    return ws_alpha_bytes(h, N) + ws_c_bytes(h, N) + align_up(size_t(h->B) * 4, 256);  // + the longest-first order
 }
 
 static int ensure_ws(mm_batch_t h, size_t bytes) {
@@ -764,7 +771,9 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     int rc = check_run(h, "mm_pdfposteriors_f32", V, N, MM_LOG);
     if (rc) return rc;
     if (!gamma || !ttl) return fail(MM_ERR_INVALID, "mm_pdfposteriors_f32: gamma/ttl is NULL");
-    rc = ensure_ws(h, ws_alpha_bytes(h, N) + ws_c_bytes(h, N));
+    // more utterances than CUs and different lengths: hand the workgroups out longest first
+    const bool ordered = lens && h->B > h->n_cus && h->B <= 8192;
+    rc = ensure_ws(h, ws_alpha_bytes(h, N) + ws_c_bytes(h, N) + (ordered ? align_up(size_t(h->B) * 4, 256) : 0));
     if (rc) return rc;
     RunParams p{};
     p.utts = h->d_utts;
@@ -782,6 +791,13 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     p.gsp = gsp;
     p.ttl = ttl;
     p.xcsr = h->xcsr;
+    if (ordered) {
+        int *order = reinterpret_cast<int *>(static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N));
+        hipLaunchKernelGGL(mm_length_order_kernel, dim3(unsigned((h->B + 255) / 256)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), lens, int(h->B), int(N), order);
+        HIP_TRY(hipGetLastError());
+        p.order = order;
+    }
 #ifdef MM_STAMPS
     if (!g_dbg) {
         g_dbg_n = size_t(16) * MM_MAX_WAVES * size_t(h->B);

@@ -373,7 +373,7 @@ __device__ __forceinline__ float finish_frame(const float *psum, int P1, int P, 
 template <int KQ, int RPT, int PASS>
 __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams p) {
     extern __shared__ float lds[];
-    const int b = blockIdx.x;
+    const int b = p.order ? p.order[blockIdx.x] : blockIdx.x;
     const UttDesc &u = p.utts[b];
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6;

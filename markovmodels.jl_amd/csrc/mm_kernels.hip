@@ -94,6 +94,9 @@ struct RunParams {
     // omega . v_N at frame N+1) or never (2: totalcumsum -- the final state accumulates omega . v_k)
     int free_run;
     int xcsr;  // quad kernel: floats of LDS holding the exact-fallback CSR (0: walk it in global memory)
+    // workgroup -> utterance, longest first (NULL: identity).  With more utterances than CUs the workgroups
+    // are handed out in this order, so the long utterances start first and the short ones fill the tail.
+    const int *order;
 };
 
 // In-kernel cycle stamps (diagnostic build only; the shipped library executes none).
@@ -442,7 +445,7 @@ __device__ __forceinline__ void for_items(const ItemRegs<NI> &rg, const GraphDev
 template <int MODE, int NI>
 __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p) {
     extern __shared__ float lds[];
-    const int b = blockIdx.x;
+    const int b = p.order ? p.order[blockIdx.x] : blockIdx.x;
     const UttDesc &u = p.utts[b];
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6;
@@ -858,6 +861,20 @@ __global__ void mm_backtrace_kernel(RunParams p) {
 __global__ void mm_pick_final_kernel(const UttDesc *utts, int B, const float *A, long long stride_n, int n, float *out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) out[b] = A[(long long)n * stride_n + utts[b].state_off + utts[b].S1 - 1];
+}
+
+// order[rank] = utterance, by decreasing length (ties by index): O(B) work per thread, B <= a few thousand
+__global__ void mm_length_order_kernel(const int *lens, int B, int N, int *order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    auto clamp = [&](int l) { return l < 0 ? 0 : (l > N ? N : l); };
+    const int li = clamp(lens[i]);
+    int rank = 0;
+    for (int j = 0; j < B; ++j) {
+        const int lj = clamp(lens[j]);
+        rank += (lj > li) || (lj == li && j < i);
+    }
+    order[rank] = i;
 }
 
 }  // namespace mm

@@ -304,3 +304,17 @@ def test_kernel_variants_agree(mm, wl, oracle, torch, env):
                 os.environ[k] = v
     check_gamma(gam, g_ref, lens)
     assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)
+
+
+def test_more_utterances_than_cus_longest_first(mm, wl, oracle, torch):
+    """More utterances than compute units with different lengths: the workgroups are handed out longest
+    first (mm_length_order_kernel); every utterance must still land in its own output rows."""
+    g = wl.random_fsm(30, 5, 3.0, seed=11)
+    B, N = 333, 12
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, N + 1, size=B).astype(np.int32)
+    gam, ttl, g_ref, t_ref, lens = run_shared(mm, wl, oracle, torch, g, B, N, lens, seed=6)
+    ok = np.isfinite(t_ref)
+    check_gamma(gam[ok], g_ref[ok], lens[ok])
+    assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-5)
+    assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()

@@ -451,7 +451,8 @@ static int fsm_to_device(mm_fsm_t f) {
         f->gdev[d].rowinfo = reinterpret_cast<const RowInfo *>(base + o_rows[d]);
         f->gdev[d].slots = reinterpret_cast<const Slot *>(base + o_slots[d]);
         f->gdev[d].n_items = int(f->packed[d].items.size());
-        f->gdev[d].pad = 0;
+        f->gdev[d].n_short = 0;
+        for (const auto &im : f->packed[d].items) f->gdev[d].n_short += im.R <= 4 ? 1 : 0;
     }
     f->d_init = reinterpret_cast<const float *>(base + o_init);
     f->d_s2p = reinterpret_cast<const int *>(base + o_s2p);

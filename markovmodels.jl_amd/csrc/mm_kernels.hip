@@ -41,7 +41,7 @@ struct GraphDev {
     const RowInfo *rowinfo;
     const Slot *slots;
     int n_items;
-    int pad;
+    int n_short;  // items with <= 4 arcs per lane; they come first and can be register resident
 };
 
 struct QuadDev {  // one direction in quad form, internal numbering (mm_pack.h QuadGraph)
@@ -428,9 +428,10 @@ __device__ __forceinline__ void for_items(const ItemRegs<NI> &rg, const GraphDev
         }
     });
     // items beyond the register window, and long rows inside it (meta = 0 there): streamed from L2
+    const int resident = NI * NW < g.n_short ? NI * NW : g.n_short;  // (known without touching memory)
     for (int it = wave; it < g.n_items; it += NW) {
+        if (it < resident) continue;
         const ItemMeta im = load_item(g.items, it);
-        if (it < NI * NW && im.R <= 4) continue;
         const RowInfo r = g.rowinfo[(size_t)it * 64 + lane];
         const float v = lse_item(g.slots, im, lane, a);
         if (r.row >= 0 && (lane & ((1 << im.log2g) - 1)) == 0) epi(v, r.row, r.pdf);
@@ -806,9 +807,10 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
                 if (row != 0xffffu && (lane & ((1 << lg) - 1)) == 0) finish(best, arg, (int)row, (int)(rg.ri[i] >> 16));
             }
         });
+        const int resident = NI * NW < gf.n_short ? NI * NW : gf.n_short;  // (known without touching memory)
         for (int it = wave; it < gf.n_items; it += NW) {
+            if (it < resident) continue;
             const ItemMeta im = load_item(gf.items, it);
-            if (it < NI * NW && im.R <= 4) continue;  // register resident
             const RowInfo ri = gf.rowinfo[(size_t)it * 64 + lane];
             const Slot *sp = gf.slots + (size_t)im.slot_row * 64 + lane;
             float best = MM_NINF;

@@ -153,6 +153,7 @@ __device__ __forceinline__ float dpp_mov(float v) {
 #define MM_DPP_HALF_MIRROR 0x141
 #define MM_DPP_MIRROR 0x140
 __device__ __forceinline__ float grp_max(float v, int log2g) {
+    if (log2g == 0) return v;  // one lane per row (the common case): one branch instead of six
     if (log2g >= 1) v = fmaxf(v, dpp_mov<MM_DPP_XOR1>(v));
     if (log2g >= 2) v = fmaxf(v, dpp_mov<MM_DPP_XOR2>(v));
     if (log2g >= 3) v = fmaxf(v, dpp_mov<MM_DPP_HALF_MIRROR>(v));
@@ -162,6 +163,7 @@ __device__ __forceinline__ float grp_max(float v, int log2g) {
     return v;
 }
 __device__ __forceinline__ float grp_sum(float v, int log2g) {
+    if (log2g == 0) return v;
     if (log2g >= 1) v += dpp_mov<MM_DPP_XOR1>(v);
     if (log2g >= 2) v += dpp_mov<MM_DPP_XOR2>(v);
     if (log2g >= 3) v += dpp_mov<MM_DPP_HALF_MIRROR>(v);
@@ -715,6 +717,7 @@ __device__ __forceinline__ int dpp_mov_i(int v) {
 
 // (max, lowest arg-max) over an aligned lane group, same butterfly as grp_max
 __device__ __forceinline__ void trop_grp_reduce(float &best, int &arg, int log2g) {
+    if (log2g == 0) return;
     if (log2g >= 1) trop_better(best, arg, dpp_mov<MM_DPP_XOR1>(best), dpp_mov_i<MM_DPP_XOR1>(arg));
     if (log2g >= 2) trop_better(best, arg, dpp_mov<MM_DPP_XOR2>(best), dpp_mov_i<MM_DPP_XOR2>(arg));
     if (log2g >= 3) trop_better(best, arg, dpp_mov<MM_DPP_HALF_MIRROR>(best), dpp_mov_i<MM_DPP_HALF_MIRROR>(arg));

@@ -116,6 +116,7 @@ struct mm_fsm_s {
                   // the other states contribute exactly nothing
     Packed packed[2];
     bool fast_ok = false;  // the quad kernel's linear path is valid for this FSM
+    int depth = 0;         // most arcs from an initial state to any (useful) state
     int64_t nquads[2] = {0, 0};
     std::map<int, QuadVariant *> variants;  // by 2 * KQ + direction
     std::vector<float> init;  // dense alpha_hat, engine domain
@@ -136,6 +137,7 @@ struct mm_batch_s {
     int64_t total_s1p = 0;
     int max_S1p = 0, max_P1 = 0, max_items = 0;
     int max_quads[2] = {0, 0};  // per direction (0 forward, 1 backward)
+    int max_depth = 0;     // deepest FSM of the batch (mm_fsm_s::depth)
     int64_t max_xcsr = 0;  // floats of the largest exact-fallback CSR (rowptr + col + w) of the batch
     int xcsr = 0;          // floats of LDS reserved for it (0: it stays in global memory)
     bool fast_ok = true;
@@ -225,6 +227,9 @@ static bool quad_kernel_usable(mm_batch_t h) {
     if (const char *e = getenv("MM_KERNEL"))
         if (!strcmp(e, "item")) return false;
     if (!h->fast_ok || h->geo_kq[0] < 1 || h->geo_kq[1] < 1) return false;
+    // small deep graphs (numerators): measured on the reference's WSJ numerator graph (depth 165),
+    // item kernel 2.3 ms against 2.7 ms; shallow graphs of the same size are 1.6x faster on the quad kernels
+    if (h->max_depth >= 64 && h->geo_kq[0] <= 3 && h->geo_kq[1] <= 3 && !getenv("MM_KERNEL")) return false;
     return quad_lds_bytes(h, 0) <= 160 * 1024 && quad_lds_bytes(h, 1) <= 160 * 1024;
 }
 
@@ -412,6 +417,14 @@ int mm_fsm_create(int semiring, int64_t S1, int64_t nnz, int layout, int index_b
         }
         f->fast_ok = quad_range_ok(S1, f->qmat[0].rowptr, f->qmat[0].val, P1) &&
                      quad_range_ok(S1, f->qmat[1].rowptr, f->qmat[1].val, P1);
+        // depth = the most arcs any state is away from the initial states.  A deep (left-to-right) graph keeps
+        // states alive whose values differ by more than the float range within one frame, so most rows of the
+        // quad kernels' linear-domain sums would take the exact fallback: such graphs run on the item kernel.
+        std::vector<int32_t> seeds;
+        for (int64_t s = 0; s < S1; ++s)
+            if (f->init[s] > NINF) seeds.push_back(int32_t(s));
+        for (uint16_t d : reach_distance(S1, f->qmat[1].rowptr, f->qmat[1].col, seeds))
+            if (d != 0xffff) f->depth = std::max(f->depth, int(d));
     }
     *out = f;
     return MM_OK;
@@ -632,6 +645,7 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     for (int64_t b = 0; b < B; ++b) {
         h->fast_ok = h->fast_ok && fsms[b]->fast_ok;
         for (int d = 0; d < 2; ++d) nq_max[d] = std::max(nq_max[d], fsms[b]->nquads[d]);
+        h->max_depth = std::max(h->max_depth, fsms[b]->depth);
     }
     h->fast_ok = h->fast_ok && h->semiring == MM_LOG;
     if (h->fast_ok) {

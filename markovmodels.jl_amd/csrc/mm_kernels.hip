@@ -494,11 +494,14 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
         // the emissions travel one frame ahead in a register: loaded during step n-1, stored to LDS at the top
         // of step n, read after the barrier that ends it -- no step waits for its own global load
         float evp = Vb ? em_load_raw(Vb, p.vsn, 3, p.N, P, tid) : 0.f;
+        MM_STAMP_DECL;
+        MM_STAMP_RESET;
         for (int n = 2; n <= NF; ++n) {
             const float *ap = buf + ((n - 1) & 1) * S1p;
             float *an = buf + (n & 1) * S1p;
             const float *emn = em + (n & 1) * P1p;
             const float M = part_max_dpp(part + ((n - 1) & 1) * MM_MAX_WAVES, NW, lane);
+            MM_STAMP(0);
             Cprev = C;
             C += (double)M;
             if (tid == 0 && wsC) wsC[n] = C;
@@ -517,15 +520,23 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
                 const float c = (float)Cprev;
                 for (int s = tid; s < S1; s += NT) dst[s] = (ap[s] + c) * MM_LN2;
             }
+            MM_STAMP(1);
             float wm = MM_NINF;
             for_items<NI>(rg, gf, wave, NW, lane, ap, [&](float v, int row, int pdf) {
                 v = v + emn[pdf] - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
                 an[row] = v;
                 wm = max_nc(wm, v);
             });
+            MM_STAMP(2);
             part_put(part + (n & 1) * MM_MAX_WAVES, wave, lane, wm);
+            MM_STAMP(3);
             __syncthreads();
+            MM_STAMP(4);
         }
+#ifdef MM_STAMPS
+        if (p.dbg && lane == 0)
+            for (int k = 0; k < 8; ++k) p.dbg[((long long)b * MM_MAX_WAVES + wave) * 16 + k] = stamp_acc[k];
+#endif
         const float *alast = buf + (NF & 1) * S1p;
         logZ2 = (double)alast[fstate] + C;
         if (MODE == MODE_ALPHA) {

@@ -158,6 +158,12 @@ int mm_debug_packed_product(mm_fsm_t fsm, int direction, const float *in, float 
  * gather instruction with arcs in CSR order, the same after the bank-aware placement}. */
 int mm_debug_quad_product(mm_fsm_t fsm, int direction, int KQ, const float *in, float *out, double stats[4]);
 
+/* Test aid (host only, no GPU): the static bound the fast kernels use to recognise dead rows without a walk --
+ * the fewest arcs from an initial state to every state (direction 0) or from every state to the phony final
+ * state (direction 1), on the pruned graph; -1 = unreachable (such states are dropped).  out: host int32[S1].
+ * alpha_n[s] (resp. beta_n[s]) is zero(K) whenever n - 1 (resp. len + 1 - n) is smaller.  MM_LOG FSMs only. */
+int mm_debug_reach_distance(mm_fsm_t fsm, int direction, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

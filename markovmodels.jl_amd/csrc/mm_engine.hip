@@ -575,6 +575,21 @@ int mm_debug_packed_product(mm_fsm_t f, int direction, const float *in, float *o
     return MM_OK;
 }
 
+int mm_debug_reach_distance(mm_fsm_t f, int direction, int32_t *out) {
+    if (!f || !out || direction < 0 || direction > 1) return fail(MM_ERR_INVALID, "mm_debug_reach_distance: bad argument");
+    if (f->qmat[0].rowptr.empty()) return fail(MM_ERR_INVALID, "mm_debug_reach_distance: log-semiring FSMs only");
+    std::vector<int32_t> seeds;
+    if (direction == 0) {
+        for (int64_t s = 0; s < f->S1; ++s)
+            if (f->init[s] > -std::numeric_limits<float>::infinity()) seeds.push_back(int32_t(s));
+    } else {
+        seeds.push_back(int32_t(f->S1 - 1));
+    }
+    const std::vector<uint16_t> d = reach_distance(f->S1, f->qmat[1 - direction].rowptr, f->qmat[1 - direction].col, seeds);
+    for (int64_t s = 0; s < f->S1; ++s) out[s] = d[s] == 0xffff ? -1 : int32_t(d[s]);
+    return MM_OK;
+}
+
 int mm_debug_quad_product(mm_fsm_t f, int direction, int KQ, const float *in, float *out, double stats[4]) {
     if (!f || !in || !out || direction < 0 || direction > 1 || KQ < 1 || KQ > 32)
         return fail(MM_ERR_INVALID, "mm_debug_quad_product: bad argument");

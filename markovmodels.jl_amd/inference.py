@@ -82,6 +82,13 @@ class CompiledFSM:
         return out, arg
 
 
+    def reach_distance(self, direction: int = 0) -> np.ndarray:
+        """Fewest arcs from an initial state (direction 0) / to the phony final state (direction 1) for every
+        state of the extended FSM, -1 = unreachable: the static dead-row bound of the fast kernels (host only)."""
+        out = np.empty(self.S1, dtype=np.int32)
+        check(lib.mm_debug_reach_distance(self._h, direction, out.ctypes.data))
+        return out
+
     def quad_product(self, x: np.ndarray, direction: int = 0, KQ: int = 5):
         """Host evaluation of the same product through the quad form of the fast kernel (test aid).
         Returns (out, stats = [quads, lanes, LDS cycles/gather naive, after placement])."""

@@ -192,3 +192,33 @@ def test_quad_form_products(mm, wl, gname, kqs):
             assert stats[0] >= g.n_arcs / 4 and stats[1] == np.ceil(stats[0] / KQ)
             # the bank-aware placement must not be worse than CSR order by more than noise
             assert stats[3] <= stats[2] * 1.15 + 0.05
+
+
+def test_reach_distance_bounds_the_support_of_alpha_and_beta(mm, wl, oracle):
+    """mm_debug_reach_distance: BFS distances on the pruned graph, checked against the oracle's recursions:
+    alpha_n[s] is zero(K) for n - 1 < d_f[s], beta_n[s] for (N + 1) - n < d_b[s], and both bounds are tight
+    (some frame reaches every useful state exactly at its distance when all emissions are finite)."""
+    o, _ = oracle
+    for g in (wl.l2r_hmm(5), wl.random_fsm(40, 4, 2.0, seed=3), wl.lexicon_fsm(60, seed=1)):
+        cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+        df, db = cf.reach_distance(0), cf.reach_distance(1)
+        S1, N = g.S + 1, 2 * (g.S + 1)
+        fsm = graphs.to_oracle(o, g)
+        lhs = o.expand(np.zeros((g.P, N)), N, fsm.K)
+        C = o.statemap(g.state2pdf, g.P, fsm.K)
+        state_lhs = o.spmm_csc(C, lhs, fsm.K)
+        A = o.alpharecursion(fsm.alpha_hat, fsm.T_hat.transpose(), state_lhs, fsm.K)
+        Bm = o.betarecursion(fsm.T_hat, state_lhs, fsm.K)
+        useful = (df >= 0) & (db >= 0)
+        assert useful[S1 - 1] and df[S1 - 1] > 0 and db[S1 - 1] == 0
+        for s in np.nonzero(useful)[0]:
+            # frames are 1-based n = 1 .. N+1 in the reference; column n-1 here
+            alive_f = np.nonzero(np.isfinite(A[s]))[0]
+            if s != S1 - 1:  # (the final state only lives in the last frame: its emission is zero(K) before)
+                assert alive_f.size and alive_f[0] >= df[s], (g.name, s)
+            if s == S1 - 1:
+                continue
+            # (the reference initialises beta's last column to one(K) for every state: src/inference.jl:104)
+            alive_b = np.nonzero(np.isfinite(Bm[s, :N]))[0]
+            assert alive_b.size and (N - alive_b[-1]) >= db[s], (g.name, s)
+            assert (N - alive_b[-1]) == db[s], (g.name, s)  # tight: beta reaches s exactly db arcs before the end

@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
             if (tid <= P) em[(n & 1) * P1p + tid] = em_value(ev, n, len, P, tid);
             if (P >= NT) stage_em(em + (n & 1) * P1p + NT, Vb + NT, p.vsn, n, len, P - NT, tid, NT, MM_LOG2E);
         }
-        if (wave * 64 <= P) ev = em_load_raw(Vb, p.vsn, n + 1, p.N, P, tid);  // (waves that hold a pdf)
+        if (KQ > 13 || wave * 64 <= P) ev = em_load_raw(Vb, p.vsn, n + 1, p.N, P, tid);  // (16-wave geometries: only the waves that hold a pdf; measured)
         MM_STAMP(0);
         quad_phase<KQ>(rg, qf, nqd, tid, NT, pbuf, qs);
         {   // frame n-1 leaves the chip once (coalesced, forward numbering) while frame n is computed

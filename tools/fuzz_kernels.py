@@ -36,8 +36,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 res = {}
 for kern in ("quad", "item"):
     env = dict(os.environ)
-    if kern == "item":
-        env["MM_KERNEL"] = "item"
+    env["MM_KERNEL"] = kern  # ("quad" switches the depth heuristic off)
     f = f"/tmp/fuzz_{kern}.npz"
     subprocess.check_call([sys.executable, __file__, "child", f], env=env)
     res[kern] = np.load(f)

@@ -450,6 +450,18 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
     }
     load_quad_regs<KQ>(rg, qf, tid);
     bool anylong = any_long_row<RPT>(qf, tid, NT, S1);
+    // where the geometry leaves registers, the forward kernel keeps its rows' records (and their unpacked
+    // addresses) for good; otherwise they are re-read from LDS every step, before the barrier
+    constexpr bool RR = KQ <= 10 || (KQ > 13 && KQ <= 25);
+    RowRecU rr[RPT];
+    if constexpr (RR) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int i = tid + k * NT;
+            const mm_u32x2 r = as_global(reinterpret_cast<const mm_u32x2 *>(qf.recs))[i < S1 ? i : S1 - 1];
+            rr[k] = RowRecU{r.x, r.y};
+        }
+    }
     __syncthreads();
     double C = 0.0;
     float ev = 0.f;
@@ -481,8 +493,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
         const float M = part_max_dpp(part + ((n - 1) & 1) * MM_MAX_WAVES, NW, lane);
         C += (double)M;
         if (tid == 0) wsM[n - 1] = M;  // M_{n-1}: C_n = sum_{k<n} M_k
-        RowRecU rr[RPT];
-        load_row_recs<RPT>(rr, recs, tid, NT, S1);
+        if constexpr (!RR) load_row_recs<RPT>(rr, recs, tid, NT, S1);
         MM_STAMP(1);
         __syncthreads();
         MM_STAMP(2);

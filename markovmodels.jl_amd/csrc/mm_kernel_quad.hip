@@ -637,6 +637,8 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
         // read before the barrier what phase B needs and does not depend on this frame's sums
         const float M = (n == len) ? 0.f : part_max_dpp(part + ((n + 1) & 1) * MM_MAX_WAVES, NW, lane);
         G += (double)mf - (double)M;
+        RowRecU rrb[RPT];
+        load_row_recs<RPT>(rrb, recs, tid, NT, S1);
         MM_STAMP(1);
         __syncthreads();
         MM_STAMP(2);
@@ -648,7 +650,7 @@ __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams 
         for (int k = 0; k < RPT; ++k) {
             const int i = tid + k * NT;
             if (i < S1) {
-                const RowRecU rec = load_rec(recs, i);
+                const RowRecU rec = rrb[k];
                 const float acc = row_total<KQ>(qs2, rec.x, rec.y);
                 const bool ok = sum_in_range(acc);
 #ifdef MM_STAMPS

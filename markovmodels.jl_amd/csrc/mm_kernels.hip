@@ -416,17 +416,19 @@ __device__ __forceinline__ float lse_regs(float w0, float w1, float w2, float w3
 
 // Visit every item of this wave: epi(value, row, pdf) runs on the leader lane of
 // each row group.  `a` = the LDS vector the arcs gather from.
+// (epi also receives emn[pdf], fetched before the log-sum-exp so that its LDS round trip is not appended to it)
 template <int NI, class Epi>
 __device__ __forceinline__ void for_items(const ItemRegs<NI> &rg, const GraphDev &g, int wave, int NW, int lane,
-                                          const float *a, Epi &&epi) {
+                                          const float *a, const float *emn, Epi &&epi) {
     static_for<0, NI>([&](auto I) {
         constexpr int i = decltype(I)::value;
         const int meta = rg.meta[i];
         if (meta != 0) {
             const int R = meta & 0xff, lg = meta >> 8;
-            const float v = lse_regs(rg.w[i][0], rg.w[i][1], rg.w[i][2], rg.w[i][3], rg.c[i][0], rg.c[i][1], R, lg, a);
             const unsigned row = rg.ri[i] & 0xffffu;
-            if (row != 0xffffu && (lane & ((1 << lg) - 1)) == 0) epi(v, (int)row, (int)(rg.ri[i] >> 16));
+            const float e = emn[row != 0xffffu ? (rg.ri[i] >> 16) : 0u];
+            const float v = lse_regs(rg.w[i][0], rg.w[i][1], rg.w[i][2], rg.w[i][3], rg.c[i][0], rg.c[i][1], R, lg, a);
+            if (row != 0xffffu && (lane & ((1 << lg) - 1)) == 0) epi(v, (int)row, (int)(rg.ri[i] >> 16), e);
         }
     });
     // items beyond the register window, and long rows inside it (meta = 0 there): streamed from L2
@@ -435,8 +437,9 @@ __device__ __forceinline__ void for_items(const ItemRegs<NI> &rg, const GraphDev
         if (it < resident) continue;
         const ItemMeta im = load_item(g.items, it);
         const RowInfo r = g.rowinfo[(size_t)it * 64 + lane];
+        const float e = emn[r.row >= 0 ? r.pdf : 0];
         const float v = lse_item(g.slots, im, lane, a);
-        if (r.row >= 0 && (lane & ((1 << im.log2g) - 1)) == 0) epi(v, r.row, r.pdf);
+        if (r.row >= 0 && (lane & ((1 << im.log2g) - 1)) == 0) epi(v, r.row, r.pdf, e);
     }
 }
 
@@ -522,8 +525,8 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
             }
             MM_STAMP(1);
             float wm = MM_NINF;
-            for_items<NI>(rg, gf, wave, NW, lane, ap, [&](float v, int row, int pdf) {
-                v = v + emn[pdf] - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
+            for_items<NI>(rg, gf, wave, NW, lane, ap, emn, [&](float v, int row, int pdf, float e) {
+                v = v + e - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
                 an[row] = v;
                 wm = max_nc(wm, v);
             });
@@ -626,11 +629,11 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
                 if (n - 2 >= 1) prefetch(n - 2);
             }
             float wm = MM_NINF;
-            for_items<NI>(rg, gb, wave, NW, lane, yp, [&](float v, int row, int pdf) {
+            for_items<NI>(rg, gb, wave, NW, lane, yp, emn, [&](float v, int row, int pdf, float e) {
                 const float beta = v - M;  // T (B[:,n+1] (*) lhs[:,n+1])   (src/inference.jl:106-107)
                 const float q = fast_exp2(ast[row] + beta - kappa);  // state_A .* state_B / Z
                 if (q > 0.f) atomicAdd(&bn[pdf], q);
-                const float y = beta + emn[pdf];
+                const float y = beta + e;
                 yn[row] = y;
                 wm = max_nc(wm, y);
             });
@@ -693,10 +696,10 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
             if (n - 1 >= 1) stage_em(em + ((n - 1) & 1) * P1p, Vb, p.vsn, n - 1, len, P, tid, NT, MM_LOG2E);
             float *dst = p.out + (long long)(n - 1) * p.out_stride_n + u.state_off;
             float wm = MM_NINF;
-            for_items<NI>(rg, gb, wave, NW, lane, yp, [&](float v, int row, int pdf) {
+            for_items<NI>(rg, gb, wave, NW, lane, yp, emn, [&](float v, int row, int pdf, float e) {
                 const float beta = v - M;
                 dst[row] = (beta + d) * MM_LN2;
-                const float y = beta + emn[pdf];
+                const float y = beta + e;
                 yn[row] = y;
                 wm = fmaxf(wm, y);
             });

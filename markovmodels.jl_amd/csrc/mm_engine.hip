@@ -190,6 +190,11 @@ template <int MODE>
 static int launch_log(mm_batch_t h, const RunParams &p, void *stream) {
     const Geometry g = pick_geometry(h);
     const bool st = MODE == MODE_FB;
+    if (MODE == MODE_FB && g.NI != 0) {  // forward kernel, then backward kernel on the same stream
+        int rc = launch(mm_log_kernel<MODE, 8, 1>, h, p, st, g.NW, stream);
+        if (rc) return rc;
+        return launch(mm_log_kernel<MODE, 8, 2>, h, p, st, g.NW, stream);
+    }
     switch (g.NI) {
         case 0: return launch(mm_log_kernel<MODE, 0>, h, p, st, g.NW, stream);
         default: return launch(mm_log_kernel<MODE, 8>, h, p, st, g.NW, stream);

@@ -448,7 +448,10 @@ __device__ __forceinline__ void for_items(const ItemRegs<NI> &rg, const GraphDev
 // MODE_ALPHA / MODE_BETA: alpha-recursion / beta-recursion export (:62-74 / :99-110).
 // grid = B workgroups (one utterance each), block = 64 * NW threads.
 // ---------------------------------------------------------------------------
-template <int MODE, int NI>
+// PASS (MODE_FB only): 0 = the whole call in one kernel, 1 = forward half (leaves alpha, C_n and log2 Z -- in
+// wsC[0] -- in the workspace), 2 = backward half.  Two kernels for the same reason as the quad path: each half
+// gets its own register allocation and schedule.
+template <int MODE, int NI, int PASS = 0>
 __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p) {
     extern __shared__ float lds[];
     const int b = p.order ? p.order[blockIdx.x] : blockIdx.x;
@@ -472,7 +475,7 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
     double logZ2 = 0.0;
     ItemRegs<NI> rg;
 
-    if (MODE != MODE_BETA) {
+    if (MODE != MODE_BETA && PASS != 2) {
         // ---------------- forward: alpha-recursion ----------------
         stage_em(em + 1 * P1p, Vb, p.vsn, 1, len, P, tid, NT, MM_LOG2E);
         for (int q = tid; q < 2 * S1p; q += NT) buf[q] = MM_NINF;
@@ -542,6 +545,10 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
 #endif
         const float *alast = buf + (NF & 1) * S1p;
         logZ2 = (double)alast[fstate] + C;
+        if (PASS == 1) {
+            if (tid == 0) wsC[0] = logZ2;
+            return;
+        }
         if (MODE == MODE_ALPHA) {
             float *dst = p.out + (long long)(NF - 1) * p.out_stride_n + u.state_off;
             const float c = (float)C;
@@ -551,8 +558,9 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
         __syncthreads();
     }
 
-    if (MODE == MODE_FB) {
+    if (MODE == MODE_FB && PASS != 1) {
         // ---------------- backward: beta-recursion fused with the combine ----------------
+        if (PASS == 2) logZ2 = wsC[0];
         const long long gbase = (long long)b * p.gsb;
         if (!(logZ2 > -1e300)) {  // no accepting path: gamma = 0, ttl = -inf
             for (long long q = tid; q < (long long)p.N * P; q += NT)

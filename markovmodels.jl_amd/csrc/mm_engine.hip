@@ -160,7 +160,7 @@ static Geometry pick_geometry(mm_batch_t h) {
     Geometry g{16, 8};
     const int it = h->max_items;
     // one workgroup per CU whatever its size: spread the items over as many waves as there are items
-    g.NW = std::max(1, std::min(MM_MAX_WAVES, it));
+    g.NW = std::max(1, std::min(MM_MAX_WAVES, it + 1));  // + one wave without items: it normalises the frames (FB)
     if (const char *e = getenv("MM_NWAVES")) {
         int v = atoi(e);
         if (v >= 1 && v <= MM_MAX_WAVES) g.NW = v;

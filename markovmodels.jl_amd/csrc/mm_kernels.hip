@@ -609,7 +609,9 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
             D += (double)M;
             const float kappa = (float)(logZ2 - Cn - D);
             // finalise frame n+1 (one rotating wave): C' * AB, per-frame sum, divide, exp (src/inference.jl:155-160)
-            if (n < len && wave == ((n + 1) % NW)) {
+            // (the last wave: the host gives the workgroup one wave more than it has items when it can, so that
+            // this work runs beside the items instead of in front of one)
+            if (n < len && wave == NW - 1) {
                 float *bf = bins + ((n + 1) & 1) * P1p;
                 float s = 0.f;
                 for (int q = lane; q < P1; q += 64) s += bf[q];

@@ -318,3 +318,28 @@ def test_more_utterances_than_cus_longest_first(mm, wl, oracle, torch):
     check_gamma(gam[ok], g_ref[ok], lens[ok])
     assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-5)
     assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()
+
+
+def test_call_is_capturable_in_a_hip_graph(mm, wl, torch):
+    """Once the workspace has its size a pdfposteriors call only launches kernels on the caller's stream:
+    it can be captured in a hipGraph and replayed."""
+    g = wl.random_fsm(200, 10, 4.0, seed=4)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    B, N = 8, 30
+    bf = mm.batch(*([cf] * B))
+    V = torch.randn(B, N, g.P, device="cuda")
+    lens = torch.tensor([N, N - 3, 5, 1, N, 0, 17, N], dtype=torch.int32, device="cuda")
+    gamma = torch.empty(B, N, g.P, device="cuda")
+    _, t0 = bf.pdfposteriors(V, lens, out=gamma)
+    g0 = gamma.clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):  # (torch wants the warm-up on a side stream)
+        bf.pdfposteriors(V, lens, out=gamma)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        _, t1 = bf.pdfposteriors(V, lens, out=gamma)
+    gamma.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gamma, g0) and torch.equal(t0, t1)

@@ -106,10 +106,6 @@ __device__ __forceinline__ void load_quad_regs(QuadRegs<KQ> &rg, const QuadDev &
     });
 }
 
-__device__ __forceinline__ float lds_f32(const float *base, unsigned byte_off) {
-    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
-}
-
 // sum of one quad on top of `run`, the running sum of the lane: kept if the quad continues its
 // predecessor's row (sign bit of the first weight, mm_pack.h Quad), dropped if it starts a row.
 // The unpacking of the 16-bit LDS offsets and the sign test are loop invariant; hoisted out of the time
@@ -205,19 +201,6 @@ __device__ __forceinline__ float row_total(const float *__restrict__ qs2, unsign
 // compare; negative, NaN and zero fall outside)
 __device__ __forceinline__ bool sum_in_range(float acc) {
     return (__float_as_uint(acc) - 0x12800000u) <= (0x71800000u - 0x12800000u);  // bits of 2^-90, 2^100
-}
-
-// add up the contiguous floats [q0, q1) in a fixed order (independent loads in groups of 8)
-__device__ __forceinline__ float seg_sum(const float *qs, int q0, int q1) {
-    float acc = 0.f;
-    int q = q0;
-    for (; q + 8 <= q1; q += 8) {
-        const float a0 = qs[q], a1 = qs[q + 1], a2 = qs[q + 2], a3 = qs[q + 3];
-        const float a4 = qs[q + 4], a5 = qs[q + 5], a6 = qs[q + 6], a7 = qs[q + 7];
-        acc += ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
-    }
-    for (; q < q1; ++q) acc += qs[q];
-    return acc;
 }
 
 // exact log-semiring row product from the log2 vector: two-pass log-sum-exp over the CSR row.  The arcs

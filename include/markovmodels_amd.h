@@ -118,7 +118,8 @@ int mm_pdfposteriors_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, i
  * of S1 over the batch.  Values are natural-log (un-normalised). */
 int mm_alpharecursion_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t v_stride_n,
                           const int32_t *lens, int64_t N, float *out, int64_t out_stride_n, void *stream);
-/* beta-recursion(T_hat, C_hat*V_hat) (src/inference.jl:99-110); same layout (state_B). */
+/* beta-recursion(T_hat, C_hat*V_hat) (src/inference.jl:99-110); same layout (state_B).  Log and Tropical
+ * batches (the latter is what maxstateposteriors -- docs/src/inference.md:5 -- combines with the tropical alpha). */
 int mm_betarecursion_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t v_stride_n,
                          const int32_t *lens, int64_t N, float *out, int64_t out_stride_n, void *stream);
 

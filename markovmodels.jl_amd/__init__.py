@@ -17,6 +17,7 @@ from .inference import (  # noqa: F401
     betarecursion,
     compile,
     expand,
+    maxstateposteriors,
     pdfposteriors,
     totalcumsum,
     totalsum,

@@ -865,8 +865,10 @@ static int run_export(mm_batch_t h, int mode, const float *V, int64_t vsb, int64
     p.out = out;
     p.out_stride_n = out_stride_n;
     if (h->semiring == MM_TROPICAL) {
-        if (mode != MODE_ALPHA) return fail(MM_ERR_UNSUPPORTED, "tropical beta-recursion export is not implemented");
-        return launch_tropical(h, p, stream);
+        if (mode == MODE_ALPHA) return launch_tropical(h, p, stream);
+        const Geometry g = pick_geometry(h);
+        if (g.NI == 0) return launch(mm_log_kernel<MODE_BETA, 0, 0, true>, h, p, false, g.NW, stream);
+        return launch(mm_log_kernel<MODE_BETA, 8, 0, true>, h, p, false, g.NW, stream);
     }
     if (mode == MODE_ALPHA) return launch_log<MODE_ALPHA>(h, p, stream);
     return launch_log<MODE_BETA>(h, p, stream);

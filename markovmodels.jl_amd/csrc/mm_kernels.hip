@@ -242,6 +242,17 @@ __device__ __forceinline__ float lse_item(const Slot *slots, const ItemMeta &im,
     }
 }
 
+// tropical semiring: (+) = max -- the same item walk without the exponentials
+__device__ __forceinline__ float max_item(const Slot *slots, const ItemMeta &im, int lane, const float *a) {
+    const Slot *sp = slots + (size_t)im.slot_row * 64 + lane;
+    float m = MM_NINF;
+    for (int k = 0; k < im.R; ++k) {
+        const Slot s = load_slot(sp + k * 64);
+        m = fmaxf(m, s.w + a[s.col]);
+    }
+    return grp_max(m, im.log2g);
+}
+
 __device__ __forceinline__ ItemMeta load_item(const ItemMeta *items, int it) {
     // `it` is wave-uniform: let the scalar unit fetch the 8-byte descriptor
     uint2 r = *reinterpret_cast<const uint2 *>(items + it);
@@ -414,10 +425,17 @@ __device__ __forceinline__ float lse_regs(float w0, float w1, float w2, float w3
     return m0 + fast_log2(sum);
 }
 
+__device__ __forceinline__ float max_regs(float w0, float w1, float w2, float w3, unsigned c01, unsigned c23, int R,
+                                          int lg, const float *a) {
+    float m = fmaxf(w0 + a[c01 & 0xffffu], w1 + a[c01 >> 16]);
+    if (R > 2) m = fmaxf(m, fmaxf(w2 + a[c23 & 0xffffu], w3 + a[c23 >> 16]));
+    return grp_max(m, lg);
+}
+
 // Visit every item of this wave: epi(value, row, pdf) runs on the leader lane of
 // each row group.  `a` = the LDS vector the arcs gather from.
 // (epi also receives emn[pdf], fetched before the log-sum-exp so that its LDS round trip is not appended to it)
-template <int NI, class Epi>
+template <int NI, bool TROP = false, class Epi>
 __device__ __forceinline__ void for_items(const ItemRegs<NI> &rg, const GraphDev &g, int wave, int NW, int lane,
                                           const float *a, const float *emn, Epi &&epi) {
     static_for<0, NI>([&](auto I) {
@@ -427,7 +445,8 @@ __device__ __forceinline__ void for_items(const ItemRegs<NI> &rg, const GraphDev
             const int R = meta & 0xff, lg = meta >> 8;
             const unsigned row = rg.ri[i] & 0xffffu;
             const float e = emn[row != 0xffffu ? (rg.ri[i] >> 16) : 0u];
-            const float v = lse_regs(rg.w[i][0], rg.w[i][1], rg.w[i][2], rg.w[i][3], rg.c[i][0], rg.c[i][1], R, lg, a);
+            const float v = TROP ? max_regs(rg.w[i][0], rg.w[i][1], rg.w[i][2], rg.w[i][3], rg.c[i][0], rg.c[i][1], R, lg, a)
+                                 : lse_regs(rg.w[i][0], rg.w[i][1], rg.w[i][2], rg.w[i][3], rg.c[i][0], rg.c[i][1], R, lg, a);
             if (row != 0xffffu && (lane & ((1 << lg) - 1)) == 0) epi(v, (int)row, (int)(rg.ri[i] >> 16), e);
         }
     });
@@ -438,7 +457,7 @@ __device__ __forceinline__ void for_items(const ItemRegs<NI> &rg, const GraphDev
         const ItemMeta im = load_item(g.items, it);
         const RowInfo r = g.rowinfo[(size_t)it * 64 + lane];
         const float e = emn[r.row >= 0 ? r.pdf : 0];
-        const float v = lse_item(g.slots, im, lane, a);
+        const float v = TROP ? max_item(g.slots, im, lane, a) : lse_item(g.slots, im, lane, a);
         if (r.row >= 0 && (lane & ((1 << im.log2g) - 1)) == 0) epi(v, r.row, r.pdf, e);
     }
 }
@@ -451,7 +470,9 @@ __device__ __forceinline__ void for_items(const ItemRegs<NI> &rg, const GraphDev
 // PASS (MODE_FB only): 0 = the whole call in one kernel, 1 = forward half (leaves alpha, C_n and log2 Z -- in
 // wsC[0] -- in the workspace), 2 = backward half.  Two kernels for the same reason as the quad path: each half
 // gets its own register allocation and schedule.
-template <int MODE, int NI, int PASS = 0>
+// TROP (MODE_BETA only): the tropical semiring's beta-recursion -- max instead of log-sum-exp, natural-log
+// values, no normalisation (float adds only, like the Viterbi kernel).
+template <int MODE, int NI, int PASS = 0, bool TROP = false>
 __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p) {
     extern __shared__ float lds[];
     const int b = p.order ? p.order[blockIdx.x] : blockIdx.x;
@@ -676,7 +697,7 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
     if (MODE == MODE_BETA) {
         // beta-recursion export (src/inference.jl:99-110): all N+1 frames, B[:,N+1] = one
         for (int q = tid; q < 2 * S1p; q += NT) buf[q] = MM_NINF;
-        stage_em(em + (NF & 1) * P1p, Vb, p.vsn, NF, len, P, tid, NT, MM_LOG2E);
+        stage_em(em + (NF & 1) * P1p, Vb, p.vsn, NF, len, P, tid, NT, (TROP ? 1.0f : MM_LOG2E));
         __syncthreads();
         {
             float *yl = buf + (NF & 1) * S1p;
@@ -691,7 +712,7 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
             }
             wm = wave_max(wm);
             if (lane == 0) part[(NF & 1) * MM_MAX_WAVES + wave] = wm;
-            if (NF - 1 >= 1) stage_em(em + ((NF - 1) & 1) * P1p, Vb, p.vsn, NF - 1, len, P, tid, NT, MM_LOG2E);
+            if (NF - 1 >= 1) stage_em(em + ((NF - 1) & 1) * P1p, Vb, p.vsn, NF - 1, len, P, tid, NT, (TROP ? 1.0f : MM_LOG2E));
         }
         __syncthreads();
         load_item_regs<NI>(rg, gb, wave, NW, lane);
@@ -700,15 +721,15 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
             const float *yp = buf + ((n + 1) & 1) * S1p;
             float *yn = buf + (n & 1) * S1p;
             const float *emn = em + (n & 1) * P1p;
-            const float M = part_max(part + ((n + 1) & 1) * MM_MAX_WAVES, NW);
+            const float M = TROP ? 0.f : part_max(part + ((n + 1) & 1) * MM_MAX_WAVES, NW);
             D += (double)M;
             const float d = (float)D;
-            if (n - 1 >= 1) stage_em(em + ((n - 1) & 1) * P1p, Vb, p.vsn, n - 1, len, P, tid, NT, MM_LOG2E);
+            if (n - 1 >= 1) stage_em(em + ((n - 1) & 1) * P1p, Vb, p.vsn, n - 1, len, P, tid, NT, (TROP ? 1.0f : MM_LOG2E));
             float *dst = p.out + (long long)(n - 1) * p.out_stride_n + u.state_off;
             float wm = MM_NINF;
-            for_items<NI>(rg, gb, wave, NW, lane, yp, emn, [&](float v, int row, int pdf, float e) {
+            for_items<NI, TROP>(rg, gb, wave, NW, lane, yp, emn, [&](float v, int row, int pdf, float e) {
                 const float beta = v - M;
-                dst[row] = (beta + d) * MM_LN2;
+                dst[row] = TROP ? beta : (beta + d) * MM_LN2;
                 const float y = beta + e;
                 yn[row] = y;
                 wm = fmaxf(wm, y);

@@ -300,6 +300,27 @@ def bestpath(fsm, Vhats, Chats=None):
     return [path[b, : lens[b]].copy() for b in range(bf.B)], score
 
 
+def maxstateposteriors(fsm, Vhats, Chats=None):
+    """maxstateposteriors (docs/src/inference.md:5; absent from src/ at this commit, historical use
+    test/test_algorithms.jl:280): the max-marginals of the tropical semiring, mu = alpha (*) beta (/) best --
+    for every state and frame the weight of the best complete path through it, relative to the best path
+    overall (0 on a best path, -inf where no complete path passes).  Tropical FSMs; returns the
+    (sum S1) x (N+1) matrix in the layout of alpha-recursion / beta-recursion."""
+    bf = _as_batch(fsm, Chats)
+    if bf.semiring != "tropical":
+        raise TypeError("maxstateposteriors needs TropicalSemiring FSMs")
+    V, lens = _unexpand(Vhats)
+    A = bf.alpharecursion(V, lens)
+    Bm = bf.betarecursion(V, lens)
+    mu = A + Bm
+    N1 = mu.shape[1]
+    for b in range(bf.B):
+        lo, hi = int(bf.state_offsets[b]), int(bf.state_offsets[b + 1])
+        best = A[hi - 1, N1 - 1]  # alpha of the phony final state in the last frame = weight of the best path
+        mu[lo:hi] = mu[lo:hi] - best if np.isfinite(best) else -np.inf
+    return mu
+
+
 def _total(fsm, n, cumulative):
     if isinstance(fsm, (BatchedFSM, CompiledFSM)):
         bf = _as_batch(fsm, None)

@@ -343,3 +343,42 @@ def test_call_is_capturable_in_a_hip_graph(mm, wl, torch):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(gamma, g0) and torch.equal(t0, t1)
+
+
+def test_tropical_beta_and_maxstateposteriors(mm, wl, oracle, torch):
+    """beta-recursion with K = TropicalSemiring (src/inference.jl:99-110) and the max-marginals mu = alpha (*) beta
+    (/) best (maxstateposteriors, docs/src/inference.md:5): against the NumPy oracle's generic recursions, and
+    the defining properties -- mu <= 0, mu = 0 exactly along the Viterbi path, every frame's maximum is 0."""
+    o, _ = oracle
+    for g, N, lens in ((wl.random_fsm(30, 5, 3.0, seed=9), 12, [12, 7]), (wl.lexicon_fsm(80, seed=2), 25, [25, 25]),
+                       (wl.wide_row_fsm(seed=1), 9, [9, 4])):
+        K = o.TROPICAL
+        of = graphs.to_oracle(o, g, "tropical")
+        C = mm.statemap(g.state2pdf, g.P)
+        f = wl.to_fsm(mm, g, "tropical")
+        rng = np.random.default_rng(3)
+        Vs = [rng.standard_normal((g.P, N)).astype(np.float32) for _ in lens]
+        Vh = [mm.expand(v, L) for v, L in zip(Vs, lens)]
+        fu = mm.rawunion(f, f)
+        Bm = mm.βrecursion(fu, Vh, [C, C])
+        A = mm.αrecursion(fu, Vh, [C, C])
+        mu = mm.maxstateposteriors(fu, Vh, [C, C])
+        paths, scores = mm.bestpath(fu, Vh, [C, C])
+        S1 = g.S + 1
+        Co = o.statemap(g.state2pdf, g.P, K)
+        for b, L in enumerate(lens):
+            lhs = o.spmm_csc(Co, o.expand(Vs[b].astype(np.float64), L, K), K)
+            Ar = o.alpharecursion(of.alpha_hat, of.T_hat.transpose(), lhs, K)
+            Br = o.betarecursion(of.T_hat, lhs, K)
+            for got, ref in ((A[b * S1:(b + 1) * S1], Ar), (Bm[b * S1:(b + 1) * S1], Br)):
+                assert np.array_equal(np.isneginf(got), np.isneginf(ref))
+                m = np.isfinite(ref)
+                assert np.allclose(got[m], ref[m], rtol=1e-5, atol=1e-4)
+            m_b = mu[b * S1:(b + 1) * S1]
+            if not np.isfinite(scores[b]):
+                assert np.isneginf(m_b).all()
+                continue
+            assert (m_b <= 1e-4).all()
+            assert np.allclose(m_b.max(axis=0), 0.0, atol=1e-4)  # some best path passes every frame
+            for n, s in enumerate(paths[b]):  # ... and the Viterbi path is one of them
+                assert abs(m_b[s, n]) <= 1e-4, (g.name, b, n, s, m_b[s, n])

@@ -159,6 +159,14 @@ int mm_debug_packed_product(mm_fsm_t fsm, int direction, const float *in, float 
  * gather instruction with arcs in CSR order, the same after the bank-aware placement}. */
 int mm_debug_quad_product(mm_fsm_t fsm, int direction, int KQ, const float *in, float *out, double stats[4]);
 
+/* Test aid (host only, no GPU): the same product evaluated THROUGH THE ROW-LANE FORM of the row kernels (mm_rows.h:
+ * rows sorted by size and dealt to the compute waves as segments, arcs in per-lane register slots, group sums,
+ * internal numbering = finishing order), in the linear domain relative to max(in) like the kernels do.  MM_LOG FSMs
+ * only.  stats (may be NULL) receives {arc slots per lane (KA), compute waves, segments, real arcs / arc slots,
+ * cost of the most loaded wave, of the least loaded one, modelled LDS cycles per gather instruction with arcs in
+ * CSR order, the same after the bank-aware placement}.  Returns MM_ERR_UNSUPPORTED if the FSM does not fit the form. */
+int mm_debug_row_product(mm_fsm_t fsm, int direction, const float *in, float *out, double stats[8]);
+
 /* Test aid (host only, no GPU): the static bound the fast kernels use to recognise dead rows without a walk --
  * the fewest arcs from an initial state to every state (direction 0) or from every state to the phony final
  * state (direction 1), on the pruned graph; -1 = unreachable (such states are dropped).  out: host int32[S1].

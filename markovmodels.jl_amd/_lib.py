@@ -35,6 +35,7 @@ SYMBOLS = [
     "mm_totalsum_f32",
     "mm_debug_packed_product",
     "mm_debug_quad_product",
+    "mm_debug_row_product",
     "mm_debug_reach_distance",
 ]
 
@@ -96,6 +97,8 @@ def _load():
     lib.mm_debug_reach_distance.argtypes = [vp, C.c_int, vp]
     lib.mm_debug_quad_product.restype = C.c_int
     lib.mm_debug_quad_product.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+    lib.mm_debug_row_product.restype = C.c_int
+    lib.mm_debug_row_product.argtypes = [vp, C.c_int, vp, vp, vp]
     return lib
 
 

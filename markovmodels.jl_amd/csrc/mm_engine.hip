@@ -15,7 +15,9 @@
 #include "../../include/markovmodels_amd.h"
 #include "mm_kernels.hip"
 #include "mm_kernel_quad.hip"
+#include "mm_kernel_rows.hip"
 #include "mm_pack.h"
+#include "mm_rows.h"
 
 using namespace mm;
 
@@ -105,6 +107,14 @@ struct QuadVariant {  // the quad form of ONE direction of an FSM for one KQ (qu
     const unsigned short *d_map_bf = nullptr;
 };
 
+// The row-lane form of ONE direction of an FSM (mm_rows.h), resident on the device.
+struct RowVariant {
+    RowGraph g;
+    std::vector<float> init;     // forward: alpha_hat by position
+    void *blob = nullptr;
+    RowDev rdev;
+};
+
 struct mm_fsm_s {
     int semiring;
     int64_t S1, nnz;
@@ -119,6 +129,8 @@ struct mm_fsm_s {
     int depth = 0;         // most arcs from an initial state to any (useful) state
     int64_t nquads[2] = {0, 0};
     std::map<int, QuadVariant *> variants;  // by 2 * KQ + direction
+    RowVariant *rows[2] = {nullptr, nullptr};  // row-lane forms (built on first use; rows_tried: do not retry)
+    bool rows_tried = false;
     std::vector<float> init;  // dense alpha_hat, engine domain
     std::vector<int32_t> s2p;
     int device = -1;
@@ -129,7 +141,33 @@ struct mm_fsm_s {
     const int *d_s2p = nullptr;
 };
 
+// Test/diagnostic switches.  Read from the environment ONCE, at mm_batch_create, and only when MM_DEBUG is
+// set: the run entry points never call getenv.  MM_KERNEL = item | quad | row forces a pdfposteriors kernel,
+// MM_KQ / MM_NWAVES / MM_NITEMS force a geometry, MM_NO_XCSR keeps the exact-fallback CSR out of LDS,
+// MM_VERBOSE prints the packing statistics.
+struct DebugOpts {
+    enum { K_AUTO = 0, K_ITEM, K_QUAD, K_ROW };
+    int kernel = K_AUTO;
+    int kq = 0, nwaves = 0, nitems = -1;
+    bool no_xcsr = false, verbose = false;
+};
+static DebugOpts read_debug_opts() {
+    DebugOpts d;
+    const char *on = getenv("MM_DEBUG");
+    if (!on || !*on || !strcmp(on, "0")) return d;
+    if (const char *e = getenv("MM_KERNEL"))
+        d.kernel = !strcmp(e, "item") ? DebugOpts::K_ITEM : !strcmp(e, "quad") ? DebugOpts::K_QUAD
+                 : !strcmp(e, "row") ? DebugOpts::K_ROW : DebugOpts::K_AUTO;
+    if (const char *e = getenv("MM_KQ")) d.kq = atoi(e);
+    if (const char *e = getenv("MM_NWAVES")) d.nwaves = atoi(e);
+    if (const char *e = getenv("MM_NITEMS")) d.nitems = atoi(e);
+    d.no_xcsr = getenv("MM_NO_XCSR") != nullptr;
+    d.verbose = getenv("MM_VERBOSE") != nullptr;
+    return d;
+}
+
 struct mm_batch_s {
+    DebugOpts dbg;
     std::vector<mm_fsm_t> fsms;
     int semiring;
     int64_t B;
@@ -142,6 +180,8 @@ struct mm_batch_s {
     int xcsr = 0;          // floats of LDS reserved for it (0: it stays in global memory)
     bool fast_ok = true;
     int geo_kq[2] = {0, 0}, geo_nw[2] = {1, 1};  // quad kernel geometry of the forward and the backward kernel
+    bool rows_ok = false;                        // every FSM has its row-lane forms: the row kernels can run
+    int row_ka[2] = {0, 0}, row_nwc[2] = {1, 1}, row_slotrows[2] = {0, 0};
     int device = -1;
     int n_cus = 256;  // compute units of the device
     UttDesc *d_utts = nullptr;
@@ -161,14 +201,8 @@ static Geometry pick_geometry(mm_batch_t h) {
     const int it = h->max_items;
     // one workgroup per CU whatever its size: spread the items over as many waves as there are items
     g.NW = std::max(1, std::min(MM_MAX_WAVES, it + 1));  // + one wave without items: it normalises the frames (FB)
-    if (const char *e = getenv("MM_NWAVES")) {
-        int v = atoi(e);
-        if (v >= 1 && v <= MM_MAX_WAVES) g.NW = v;
-    }
-    if (const char *e = getenv("MM_NITEMS")) {
-        int v = atoi(e);
-        if (v == 0 || v == 8) g.NI = v;
-    }
+    if (h->dbg.nwaves >= 1 && h->dbg.nwaves <= MM_MAX_WAVES) g.NW = h->dbg.nwaves;
+    if (h->dbg.nitems == 0 || h->dbg.nitems == 8) g.NI = h->dbg.nitems;
     return g;
 }
 
@@ -229,12 +263,11 @@ static int launch_quad_kq(mm_batch_t h, const RunParams &p, void *stream) {
 }
 
 static bool quad_kernel_usable(mm_batch_t h) {
-    if (const char *e = getenv("MM_KERNEL"))
-        if (!strcmp(e, "item")) return false;
+    if (h->dbg.kernel == DebugOpts::K_ITEM) return false;
     if (!h->fast_ok || h->geo_kq[0] < 1 || h->geo_kq[1] < 1) return false;
     // small deep graphs (numerators): measured on the reference's WSJ numerator graph (depth 165),
     // item kernel 2.3 ms against 2.7 ms; shallow graphs of the same size are 1.6x faster on the quad kernels
-    if (h->max_depth >= 64 && h->geo_kq[0] <= 3 && h->geo_kq[1] <= 3 && !getenv("MM_KERNEL")) return false;
+    if (h->max_depth >= 64 && h->geo_kq[0] <= 3 && h->geo_kq[1] <= 3 && h->dbg.kernel == DebugOpts::K_AUTO) return false;
     return quad_lds_bytes(h, 0) <= 160 * 1024 && quad_lds_bytes(h, 1) <= 160 * 1024;
 }
 
@@ -277,13 +310,39 @@ static int launch_tropical(mm_batch_t h, const RunParams &p, void *stream) {
     const Geometry g = pick_geometry(h);
     if (g.NI == 8 && h->max_items <= 8 * MM_MAX_WAVES) {  // as many waves as there is work for (latency), at most 8 items each
         int NW = std::min(MM_MAX_WAVES, std::max(g.NW, (h->max_items + 3) / 4));
-        if (const char *e = getenv("MM_NWAVES")) {
-            int v = atoi(e);
-            if (v >= g.NW && v <= MM_MAX_WAVES) NW = v;
-        }
+        if (h->dbg.nwaves >= g.NW && h->dbg.nwaves <= MM_MAX_WAVES) NW = h->dbg.nwaves;
         return launch(mm_tropical_kernel<8>, h, p, true, NW, stream);
     }
     return launch(mm_tropical_kernel<0>, h, p, true, 16, stream);
+}
+
+// The row kernels (mm_kernel_rows.hip): KA register-resident arcs per lane, NWC compute waves + 1 service wave.
+#define MM_ROW_RS 8192
+static const int kRowKA[] = {16, 32, 40, 44};  // instantiated register windows (48 arcs per lane spill)
+
+template <int KA, int PASS>
+static int launch_row_ka(mm_batch_t h, const RunParams &p, void *stream) {
+    const size_t lds = row_lds_bytes(MM_ROW_RS, PASS, h->row_slotrows[PASS]);
+    if (lds > 160 * 1024) return fail(MM_ERR_UNSUPPORTED, "row kernel: LDS");
+    auto kernel = mm_fbr_kernel<KA, MM_ROW_RS, PASS>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    hipLaunchKernelGGL(kernel, dim3(unsigned(h->B)), dim3(64 * (h->row_nwc[PASS] + 1)), lds, static_cast<hipStream_t>(stream), p);
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+}
+template <int PASS>
+static int launch_row_pass(mm_batch_t h, const RunParams &p, void *stream) {
+    const int ka = h->row_ka[PASS];
+    if (ka <= 16) return launch_row_ka<16, PASS>(h, p, stream);
+    if (ka <= 32) return launch_row_ka<32, PASS>(h, p, stream);
+    if (ka <= 40) return launch_row_ka<40, PASS>(h, p, stream);
+    if (ka <= 44) return launch_row_ka<44, PASS>(h, p, stream);
+    return MM_ERR_UNSUPPORTED;
+}
+static int launch_rows(mm_batch_t h, const RunParams &p, void *stream) {
+    int rc = launch_row_pass<0>(h, p, stream);
+    if (rc) return rc;
+    return launch_row_pass<1>(h, p, stream);
 }
 
 namespace {
@@ -348,7 +407,7 @@ int mm_fsm_create(int semiring, int64_t S1, int64_t nnz, int layout, int index_b
     f->S1 = S1;
     f->nnz = nnz;
     f->P1 = P1;
-    f->S1p = int((S1 + 3) / 4 * 4);
+    f->S1p = int((S1 + 1 + 3) / 4 * 4);  // at least one slot beyond the last state (the row kernels' "no row" position)
     f->s2p.resize(S1);
     for (int64_t s = 0; s < S1; ++s) {
         int32_t pdf = state2pdf[s] - index_base;
@@ -481,7 +540,7 @@ static int fsm_to_device(mm_fsm_t f) {
 }
 
 // build (once per direction and KQ) and upload the quad form of an FSM
-static int quad_variant(mm_fsm_t f, int dir, int KQ, QuadVariant **out) {
+static int quad_variant(mm_fsm_t f, int dir, int KQ, bool verbose, QuadVariant **out) {
     auto it = f->variants.find(2 * KQ + dir);
     if (it != f->variants.end()) {
         *out = it->second;
@@ -491,7 +550,7 @@ static int quad_variant(mm_fsm_t f, int dir, int KQ, QuadVariant **out) {
     v->KQ = KQ;
     v->dir = dir;
     v->g = make_quads(f->S1, f->qmat[dir].rowptr, f->qmat[dir].col, f->qmat[dir].val, f->s2p, f->P1, dir == 1, KQ);
-    if (getenv("MM_VERBOSE"))
+    if (verbose)
         fprintf(stderr, "[mm] quad form dir %d: KQ %d, %zu quads, %lld arcs, LDS cycles/gather (bank model) %.2f -> %.2f\n",
                 dir, KQ, v->g.quads.size(), (long long)f->qmat[dir].rowptr[f->S1], v->g.conflict_before,
                 v->g.conflict_after);
@@ -546,6 +605,75 @@ static int quad_variant(mm_fsm_t f, int dir, int KQ, QuadVariant **out) {
     return MM_OK;
 }
 
+// build (once) and upload the row-lane forms of both directions of an FSM; *ok = false if it does not fit them
+static int row_variants(mm_fsm_t f, bool verbose, bool *ok) {
+    *ok = f->rows[0] && f->rows[1];
+    if (f->rows_tried) return MM_OK;
+    f->rows_tried = true;
+    if (f->semiring != MM_LOG || !f->fast_ok || f->P1 > 250 || (f->S1 + 1) * 4 > MM_ROW_RS) return MM_OK;
+    RowPackOpts opt;
+    opt.rs = MM_ROW_RS;
+    opt.ka_max = kRowKA[sizeof(kRowKA) / sizeof(kRowKA[0]) - 1];
+    RowVariant *rv[2] = {new RowVariant(), new RowVariant()};
+    const std::vector<int32_t> none;
+    // (arc weights below 2^-60 leave too little of the float range to the values: such graphs run on the other kernels)
+    bool fits = make_rows(f->S1, f->qmat[0].rowptr, f->qmat[0].col, f->qmat[0].val, f->s2p, f->P1, false, none, opt, rv[0]->g) &&
+                make_rows(f->S1, f->qmat[1].rowptr, f->qmat[1].col, f->qmat[1].val, f->s2p, f->P1, true, rv[0]->g.pos, opt, rv[1]->g);
+    fits = fits && std::min(rv[0]->g.wmin_log2, rv[1]->g.wmin_log2) >= -60.f;
+    if (!fits) {
+        delete rv[0];
+        delete rv[1];
+        return MM_OK;
+    }
+    const float NINF = -std::numeric_limits<float>::infinity();
+    for (int dir = 0; dir < 2; ++dir) {
+        RowVariant *v = rv[dir];
+        if (verbose)
+            fprintf(stderr, "[mm] row form dir %d: KA %d, %d compute waves, %d segments, arcs/slots %.3f, cost %d..%d, "
+                            "LDS cycles/gather (bank model) %.2f -> %.2f\n",
+                    dir, v->g.KA, v->g.NWC, v->g.nslotrows - 1, v->g.pad_eff, v->g.mincost, v->g.maxcost, v->g.conflict_before,
+                    v->g.conflict_after);
+        if (dir == 0) {
+            v->init.resize(f->S1);
+            for (int64_t i = 0; i < f->S1; ++i) v->init[i] = f->init[v->g.order[i]];
+        }
+        Blob bl;
+        const size_t o_w = bl.add(v->g.w), o_a = bl.add(v->g.addr), o_s = bl.add(v->g.slots), o_sc = bl.add(v->g.sched);
+        const size_t o_ptr = bl.add(v->g.rowptr), o_col = bl.add(v->g.col), o_cw = bl.add(v->g.cw);
+        const size_t o_pdf = bl.add(v->g.rowpdf), o_pse = bl.add(v->g.pdfse), o_init = bl.add(v->init);
+        int rc = upload(bl, &v->blob);
+        if (rc) {
+            for (RowVariant *x : rv) {
+                if (x->blob) (void)hipFree(x->blob);
+                delete x;
+            }
+            return rc;
+        }
+        char *base = static_cast<char *>(v->blob);
+        RowDev &d = v->rdev;
+        d.w = reinterpret_cast<const float *>(base + o_w);
+        d.addr = reinterpret_cast<const unsigned *>(base + o_a);
+        d.slots = reinterpret_cast<const unsigned *>(base + o_s);
+        d.sched = reinterpret_cast<const RowSched *>(base + o_sc);
+        d.rowptr = reinterpret_cast<const int *>(base + o_ptr);
+        d.col = reinterpret_cast<const int *>(base + o_col);
+        d.cw = reinterpret_cast<const float *>(base + o_cw);
+        d.rowpdf = reinterpret_cast<const unsigned short *>(base + o_pdf);
+        d.pdfse = reinterpret_cast<const unsigned short *>(base + o_pse);
+        d.init = reinterpret_cast<const float *>(base + o_init);
+        d.KA = v->g.KA;
+        d.NWC = v->g.NWC;
+        d.nslotrows = v->g.nslotrows;
+        d.fpos = v->g.pos[f->S1 - 1];
+        d.rows = int(f->S1);
+        d.thr = 125.f + std::min(rv[0]->g.wmin_log2, rv[1]->g.wmin_log2);
+    }
+    f->rows[0] = rv[0];
+    f->rows[1] = rv[1];
+    *ok = true;
+    return MM_OK;
+}
+
 int mm_fsm_destroy(mm_fsm_t f) {
     if (!f) return MM_OK;
     if (f->dev_blob) (void)hipFree(f->dev_blob);
@@ -553,6 +681,11 @@ int mm_fsm_destroy(mm_fsm_t f) {
         if (kv.second->blob) (void)hipFree(kv.second->blob);
         delete kv.second;
     }
+    for (RowVariant *rv : f->rows)
+        if (rv) {
+            if (rv->blob) (void)hipFree(rv->blob);
+            delete rv;
+        }
     delete f;
     return MM_OK;
 }
@@ -646,6 +779,44 @@ int mm_debug_quad_product(mm_fsm_t f, int direction, int KQ, const float *in, fl
     return MM_OK;
 }
 
+int mm_debug_row_product(mm_fsm_t f, int direction, const float *in, float *out, double stats[8]) {
+    if (!f || !in || !out || direction < 0 || direction > 1) return fail(MM_ERR_INVALID, "mm_debug_row_product: bad argument");
+    if (f->semiring != MM_LOG) return fail(MM_ERR_INVALID, "mm_debug_row_product: log-semiring FSMs only");
+    RowPackOpts opt;
+    opt.rs = MM_ROW_RS;
+    opt.ka_max = kRowKA[sizeof(kRowKA) / sizeof(kRowKA[0]) - 1];
+    RowGraph gf, g;
+    const std::vector<int32_t> none;
+    const Csr &mf = f->mat[0], &m = f->mat[direction];
+    if ((f->S1 + 1) * 4 > MM_ROW_RS || !make_rows(f->S1, mf.rowptr, mf.col, mf.val, f->s2p, f->P1, false, none, opt, gf))
+        return fail(MM_ERR_UNSUPPORTED, "mm_debug_row_product: the FSM does not fit the row-lane form");
+    if (direction == 1) {
+        if (!make_rows(f->S1, m.rowptr, m.col, m.val, f->s2p, f->P1, true, gf.pos, opt, g))
+            return fail(MM_ERR_UNSUPPORTED, "mm_debug_row_product: the FSM does not fit the row-lane form");
+    } else {
+        g = gf;
+    }
+    const int64_t S1 = f->S1;
+    float mx = -std::numeric_limits<float>::infinity();
+    for (int64_t s = 0; s < S1; ++s) mx = std::max(mx, in[s] * MM_LOG2E);
+    if (!(mx > -std::numeric_limits<float>::infinity())) mx = 0.f;
+    std::vector<float> pl(S1 + 1, 0.f), ol(S1 + 1, 0.f);
+    for (int64_t i = 0; i < S1; ++i) pl[i] = std::exp2(in[g.order[i]] * MM_LOG2E - mx);
+    eval_rows(g, pl.data(), ol.data());
+    for (int64_t i = 0; i < S1; ++i) out[g.order[i]] = (std::log2(ol[i]) + mx) * MM_LN2;
+    if (stats) {
+        stats[0] = g.KA;
+        stats[1] = g.NWC;
+        stats[2] = g.nslotrows - 1;
+        stats[3] = g.pad_eff;
+        stats[4] = g.maxcost;
+        stats[5] = g.mincost;
+        stats[6] = g.conflict_before;
+        stats[7] = g.conflict_after;
+    }
+    return MM_OK;
+}
+
 int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     if (!out) return fail(MM_ERR_INVALID, "mm_batch_create: out is NULL");
     *out = nullptr;
@@ -656,6 +827,7 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             return fail(MM_ERR_INVALID, "mm_batch_create: FSMs of one batch must share the semiring (FSM{K})");
     }
     mm_batch_s *h = new mm_batch_s();
+    h->dbg = read_debug_opts();
     h->B = B;
     h->semiring = fsms[0]->semiring;
     h->fsms.assign(fsms, fsms + B);
@@ -671,20 +843,14 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     if (h->fast_ok) {
         for (int d = 0; d < 2; ++d) {
             QuadGeometry geo = pick_quad_geometry(nq_max[d]);
-            if (const char *e = getenv("MM_KQ")) {
-                int v = atoi(e);
-                if (v >= 1 && v <= 29) geo.KQ = v;
-            }
+            if (h->dbg.kq >= 1 && h->dbg.kq <= 29) geo.KQ = h->dbg.kq;
             // enough waves for the quads, and for at most two rows per thread where the workgroup can be that large
             int64_t s1_max = 0;
             for (int64_t b = 0; b < B; ++b) s1_max = std::max(s1_max, fsms[b]->S1);
             geo.NW = int(std::min<int64_t>(geo.KQ > 13 ? 8 : MM_MAX_WAVES,
                                            std::max<int64_t>({1, (nq_max[d] + 64 * geo.KQ - 1) / (64 * geo.KQ),
                                                               (s1_max + 127) / 128})));
-            if (const char *e = getenv("MM_NWAVES")) {
-                int v = atoi(e);
-                if (v >= 1 && v <= (geo.KQ > 13 ? 8 : MM_MAX_WAVES)) geo.NW = v;
-            }
+            if (h->dbg.nwaves >= 1 && h->dbg.nwaves <= (geo.KQ > 13 ? 8 : MM_MAX_WAVES)) geo.NW = h->dbg.nwaves;
             h->geo_kq[d] = geo.KQ;
             h->geo_nw[d] = geo.NW;
             h->max_quads[d] = int(nq_max[d]);
@@ -695,11 +861,25 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             h->max_xcsr = std::max<int64_t>(h->max_xcsr, fsms[b]->S1 + 1 + 2 * std::max(fsms[b]->qmat[0].rowptr[fsms[b]->S1],
                                                                                   fsms[b]->qmat[1].rowptr[fsms[b]->S1]));
     }
+    // row kernels: every FSM of the batch needs its row-lane forms.  Small deep (left-to-right) graphs keep states
+    // alive whose values differ by more than the float range within one frame, so most of their rows would take the
+    // exact fallback of the linear-domain kernels: they run on the item kernel (unless a kernel is forced).
+    h->rows_ok = h->fast_ok && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD &&
+                 !(h->max_depth >= 64 && nq_max[0] <= 3 * 1024 && nq_max[1] <= 3 * 1024 && h->dbg.kernel == DebugOpts::K_AUTO);
+    for (int64_t b = 0; b < B && h->rows_ok; ++b) {
+        bool ok = false;
+        int rc = row_variants(fsms[b], h->dbg.verbose, &ok);
+        if (rc) {
+            delete h;
+            return rc;
+        }
+        h->rows_ok = ok;
+    }
     for (int64_t b = 0; b < B; ++b) {
         mm_fsm_t f = fsms[b];
         int rc = fsm_to_device(f);
         QuadVariant *qv[2] = {nullptr, nullptr};
-        for (int d = 0; d < 2 && !rc && h->fast_ok; ++d) rc = quad_variant(f, d, h->geo_kq[d], &qv[d]);
+        for (int d = 0; d < 2 && !rc && h->fast_ok; ++d) rc = quad_variant(f, d, h->geo_kq[d], h->dbg.verbose, &qv[d]);
         if (rc) {
             delete h;
             return rc;
@@ -714,6 +894,13 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             u.init_f = qv[0]->d_init_f;
             u.map_bf = qv[1]->d_map_bf;
         }
+        if (h->rows_ok)
+            for (int d = 0; d < 2; ++d) {
+                u.r[d] = f->rows[d]->rdev;
+                h->row_ka[d] = std::max(h->row_ka[d], f->rows[d]->g.KA);
+                h->row_nwc[d] = std::max(h->row_nwc[d], f->rows[d]->g.NWC);
+                h->row_slotrows[d] = std::max(h->row_slotrows[d], f->rows[d]->g.nslotrows);
+            }
         u.init = f->d_init;
         u.s2p = f->d_s2p;
         u.S1 = int(f->S1);
@@ -740,7 +927,7 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         delete h;
         return fail(MM_ERR_HIP, "mm_batch_create: device allocation failed");
     }
-    if (h->fast_ok && h->geo_kq[0] <= 3 && h->geo_kq[1] <= 3 && !getenv("MM_NO_XCSR")) {
+    if (h->fast_ok && h->geo_kq[0] <= 3 && h->geo_kq[1] <= 3 && !h->dbg.no_xcsr) {
         h->xcsr = int((h->max_xcsr + 3) & ~int64_t(3));
         if (h->max_xcsr > 16 * 1024 || quad_lds_bytes(h, 0) > 128 * 1024 || quad_lds_bytes(h, 1) > 128 * 1024) h->xcsr = 0;
     }
@@ -774,7 +961,7 @@ static size_t ws_c_bytes(mm_batch_t h, int64_t N) { return align_up(size_t(h->B)
 
 size_t mm_batch_workspace_bytes(mm_batch_t h, int64_t N) {
     if (!h || N < 0) return 0;
-    return ws_alpha_bytes(h, N) + ws_c_bytes(h, N) + align_up(size_t(h->B) * 4, 256);  // + the longest-first order
+    return ws_alpha_bytes(h, N) + ws_c_bytes(h, N) + 2 * align_up(size_t(h->B) * 4, 256);  // + longest-first order, redo marks
 }
 
 static int ensure_ws(mm_batch_t h, size_t bytes) {
@@ -808,7 +995,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     if (!gamma || !ttl) return fail(MM_ERR_INVALID, "mm_pdfposteriors_f32: gamma/ttl is NULL");
     // more utterances than CUs and different lengths: hand the workgroups out longest first
     const bool ordered = lens && h->B > h->n_cus && h->B <= 8192;
-    rc = ensure_ws(h, ws_alpha_bytes(h, N) + ws_c_bytes(h, N) + (ordered ? align_up(size_t(h->B) * 4, 256) : 0));
+    rc = ensure_ws(h, ws_alpha_bytes(h, N) + ws_c_bytes(h, N) + 2 * align_up(size_t(h->B) * 4, 256));  // + order, redo
     if (rc) return rc;
     RunParams p{};
     p.utts = h->d_utts;
@@ -840,6 +1027,14 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     }
     p.dbg = g_dbg;
 #endif
+    if (h->rows_ok) {
+        // the row kernels, then -- for the utterances they marked (linear sums outside the trusted range), normally
+        // none: every workgroup then leaves at once -- the exact kernels
+        p.redo = reinterpret_cast<int *>(static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N) +
+                                         align_up(size_t(h->B) * 4, 256));
+        rc = launch_rows(h, p, stream);
+        if (rc) return rc;
+    }
     if (quad_kernel_usable(h)) {
         rc = launch_quad(h, p, stream);
         if (rc != MM_ERR_UNSUPPORTED) return rc;

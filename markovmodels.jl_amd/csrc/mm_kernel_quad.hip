@@ -357,6 +357,7 @@ template <int KQ, int RPT, int PASS>
 __global__ void __launch_bounds__(KQ > 13 ? 512 : 1024) mm_fbq_kernel(RunParams p) {
     extern __shared__ float lds[];
     const int b = p.order ? p.order[blockIdx.x] : blockIdx.x;
+    if (p.redo && !p.redo[b]) return;  // launched behind the row kernels: only the utterances they marked
     const UttDesc &u = p.utts[b];
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6;

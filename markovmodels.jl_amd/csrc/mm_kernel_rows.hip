@@ -1,0 +1,522 @@
+// mm_kernel_rows.hip -- the "row" pdfposteriors kernels for gfx950: forward (alpha-recursion,
+// src/inference.jl:62-74) and backward (beta-recursion :99-110 fused with the combine :154-160).
+// Included by mm_engine.hip after mm_kernel_quad.hip.
+//
+// Same contract and numerics as the quad kernels (linear-domain row products with a frame-level shift,
+// exact log-sum-exp fallback per row), different organisation of a frame (mm_rows.h):
+//
+//   * a row of the semiring product belongs to ONE lane (an aligned group of 2..64 lanes when it is long),
+//     which holds the row's arcs in registers (linear weight + absolute LDS byte address: two VGPRs per
+//     arc, no unpacking) and finishes the row itself -- (group sum by DPP,) log2, emission, normaliser, 2^x,
+//     stores.  The quad kernels write per-lane partial sums to LDS, cross a barrier and read them back in a
+//     second phase; here a frame has ONE barrier, no partial sums in LDS, and the LDS-bound gathers of one
+//     wave overlap the issue-bound finishing code of another instead of all waves being in the same phase.
+//   * the linear vector p = 2^a~ is double buffered by frame parity (the buffer being read / written is a
+//     compile-time immediate offset of the ds instructions: the frame loop is unrolled by two);
+//   * one SERVICE wave per workgroup (the last) owns all traffic that would otherwise make the compute waves
+//     wait on vmcnt: it stages the emissions (one frame ahead) and, backward, the alpha rows (two frames
+//     ahead) from HBM into LDS, normalises and stores the posteriors, and keeps the normaliser sums.  The
+//     compute waves issue only fire-and-forget stores (forward: the alpha store, straight from registers,
+//     coalesced in the forward numbering) and no global loads at all in steady state;
+//   * the per-frame emission maximum E_n is part of the frame normaliser (a~_n = a_n - C_n with
+//     C_n = sum_{k<=n} E_k + sum_{k<n} M_k), so log-likelihoods far from 0 (GMM scores around -300 nats) stay
+//     on the linear path.
+#pragma once
+#include "mm_kernel_quad.hip"
+#include "mm_rows.h"
+
+namespace mm {
+
+typedef float mm_f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float *lds_fptr;
+typedef __attribute__((address_space(3))) unsigned *lds_uptr;
+__device__ __forceinline__ float ldsr(unsigned addr) { return *(lds_cfptr)(__UINTPTR_TYPE__)addr; }
+__device__ __forceinline__ unsigned ldsru(unsigned addr) { return *(lds_uptr)(__UINTPTR_TYPE__)addr; }
+__device__ __forceinline__ void ldsw(unsigned addr, float v) { *(lds_fptr)(__UINTPTR_TYPE__)addr = v; }
+__device__ __forceinline__ void ldswu(unsigned addr, unsigned v) { *(lds_uptr)(__UINTPTR_TYPE__)addr = v; }
+
+#define MM_ROW_EMS 1024  // bytes per emission buffer: P1p + 4 <= 256 floats
+
+// LDS byte layout (absolute addresses; the kernels have no static LDS, the dynamic segment starts at 0).
+// Everything a finish touches sits at a compile-time offset from the row's 4 * position.
+template <int RS, int PASS>
+struct RowLay {
+    static constexpr unsigned P(int par, int c) { return unsigned(par * (2 * RS + 128) + c * (RS + 64)); }
+    static constexpr unsigned A(int par) { return unsigned(4 * RS + 256 + par * RS); }
+    static constexpr unsigned Q(int par) { return unsigned(6 * RS + 256 + par * RS); }   // backward only
+    static constexpr unsigned AL(int par) { return unsigned(8 * RS + 256 + par * RS); }  // backward only
+    static constexpr unsigned EMB = unsigned((PASS ? 10 : 6) * RS + 256);
+    static constexpr unsigned EM(int par) { return EMB + unsigned(par * MM_ROW_EMS); }
+    static constexpr unsigned PART(int par) { return EMB + 2 * MM_ROW_EMS + unsigned(par * 64); }
+    static constexpr unsigned PSUM(int par) { return EMB + 2 * MM_ROW_EMS + 128 + unsigned(par * MM_ROW_EMS); }
+    static constexpr unsigned PDFSE = EMB + 4 * MM_ROW_EMS + 128;          // u16 [2 * P1] <= 1024 bytes
+    static constexpr unsigned SLOTS = PDFSE + (PASS ? 1024u : 0u);
+};
+inline size_t row_lds_bytes(int RS, int pass, int nslotrows) {
+    const size_t slots = size_t(nslotrows) * 64 * 4 * (pass ? 2 : 1);
+    const size_t emb = size_t(pass ? 10 : 6) * RS + 256;
+    return emb + 4 * MM_ROW_EMS + 128 + (pass ? 1024 : 0) + slots;
+}
+
+// emissions of one frame (expand(), src/inference.jl:54-60) in the log2 domain relative to the frame's
+// maximum E over the real pdfs: lane handles pdfs lane, lane + 64, ...  Returns E (0 when no real pdf emits).
+__device__ __forceinline__ float row_stage_em(unsigned dst, const float (&raw)[4], int n, int len, int P, int lane) {
+    float v[4], E = MM_NINF;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = lane + 64 * j;
+        v[j] = em_value(raw[j], n, len, P, q);
+        if (q < P) E = max_nc(E, v[j]);
+    }
+    E = wave_max_rl(E);
+    if (!(E > MM_NINF)) E = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = lane + 64 * j;
+        if (q <= P) ldsw(dst + 4u * q, v[j] - E);
+    }
+    return E;
+}
+__device__ __forceinline__ void row_load_em(float (&raw)[4], const float *Vb, long long vsn, int n, int N, int P, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) raw[j] = (lane + 64 * j <= P || j == 0) ? em_load_raw(Vb, vsn, n, N, P, lane + 64 * j) : 0.f;
+}
+
+// Range of the linear path.  A state whose normalised log2 value v is finite but below -thr is alive with a linear
+// image 2^v that products with the arc weights (>= 2^wmin) could no longer represent as normal floats: sums over it
+// would silently lose it.  The row kernels do not handle that case: they mark the UTTERANCE in `redo`, and the exact
+// kernels (quad / item: per-row log-sum-exp fallback) run it again after them (mm_engine.hip) -- results are the log
+// semiring's for every input, only speed depends on the data.  thr = 125 + wmin (RowDev::thr), so every product of
+// an unmarked utterance is >= 2^-125; a row sum that is exactly 0 then means that every source is exactly zero(K),
+// and log2 of it (-inf) is the semiring's answer.  (An exact row walk inlined in every finish -- what the quad
+// kernels do -- costs the compute waves ~40 VGPRs, which the register-resident graph needs.)
+__device__ __forceinline__ bool row_out_of_range(float v, float thr) { return __builtin_fabsf(v) > thr && v != MM_NINF; }
+
+// Sum over aligned groups of 1 << lg lanes, valid in the LAST lane of every group (the lane that finishes the row):
+// five one-instruction DPP steps at most, no LDS crossbar and no lane-index registers (the butterfly of the item
+// kernel needs ds_bpermute and three VGPRs of lane arithmetic for groups wider than a DPP row).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, true));
+}
+__device__ __forceinline__ float grp_sum_last(float v, int lg) {
+    v = dpp_add<0x111, 0xF>(v);                // row_shr:1
+    if (lg >= 2) v = dpp_add<0x112, 0xF>(v);   // row_shr:2
+    if (lg >= 3) v = dpp_add<0x114, 0xF>(v);   // row_shr:4
+    if (lg >= 4) v = dpp_add<0x118, 0xF>(v);   // row_shr:8
+    if (lg >= 5) v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+    if (lg >= 6) v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// The arcs of a compute wave, two at a time, statically unrolled (the graph registers need static indices);
+// a segment may end after any pair (wave-uniform bit test).  The gathers run D pairs ahead of the FMAs.
+template <int K2, int KA, int D, unsigned RDOFF, class F>
+__device__ __forceinline__ void row_pairs(const float (&wr)[KA], const unsigned (&ar)[KA], float (&x)[2 * D], float &acc,
+                                          unsigned em_lo, unsigned em_hi, int &slots_left, F &&finish) {
+    constexpr int s0 = (2 * K2) % (2 * D);
+    acc = fmaf(wr[2 * K2], x[s0], acc);
+    acc = fmaf(wr[2 * K2 + 1], x[s0 + 1], acc);
+    if constexpr (2 * (K2 + D) < KA) {
+        x[s0] = ldsr(ar[2 * (K2 + D)] + RDOFF);
+        x[s0 + 1] = ldsr(ar[2 * (K2 + D) + 1] + RDOFF);
+    }
+    if (((K2 < 32 ? em_lo : em_hi) >> (K2 & 31)) & 1u) {
+        finish();
+        if (--slots_left == 0) return;
+    }
+    if constexpr (K2 + 1 < KA / 2) row_pairs<K2 + 1, KA, D, RDOFF>(wr, ar, x, acc, em_lo, em_hi, slots_left, finish);
+}
+
+// A value that is the same in every lane, moved to scalar registers.  (The utterance descriptor is read through an
+// index that may come from memory -- the longest-first order -- so the compiler keeps everything derived from it
+// in vector registers otherwise: ~30 VGPRs that the graph needs.)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T>
+__device__ __forceinline__ T *uni(T *ptr) {
+    const unsigned long long v = (unsigned long long)ptr;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+struct RowU {  // RowDev in scalar registers
+    const float *w;
+    const unsigned *addr;
+    const unsigned *slots;
+    const RowSched *sched;
+    const unsigned short *rowpdf, *pdfse;
+    const float *init;
+    int KA, NWC, nslotrows, fpos, rows;
+    float thr;
+};
+__device__ __forceinline__ RowU uni(const RowDev &d) {
+    RowU r;
+    r.w = uni(d.w);
+    r.addr = uni(d.addr);
+    r.slots = uni(d.slots);
+    r.sched = uni(d.sched);
+    r.rowpdf = uni(d.rowpdf);
+    r.pdfse = uni(d.pdfse);
+    r.init = uni(d.init);
+    r.KA = uni(d.KA);
+    r.NWC = uni(d.NWC);
+    r.nslotrows = uni(d.nslotrows);
+    r.fpos = uni(d.fpos);
+    r.rows = uni(d.rows);
+    r.thr = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, d.thr)));
+    return r;
+}
+
+// what a compute wave keeps across the frames
+template <int KA>
+struct RowRegs {
+    float w[KA];
+    unsigned a[KA];
+};
+
+template <int KA, int RS, int PASS>
+__global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
+    extern __shared__ float lds[];
+    using L = RowLay<RS, PASS>;
+    constexpr int D = 3;  // gather pairs in flight ahead of the FMAs
+    const int b = uni(p.order ? p.order[blockIdx.x] : (int)blockIdx.x);
+    const UttDesc &u = p.utts[b];
+    const RowU r = uni(u.r[PASS]);
+    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, NWC = NW - 1;
+    const bool service = wave == NWC;
+    const int S1 = r.rows, S1p = uni(u.S1p), P1 = uni(u.P1), P = P1 - 1, P1p = (P1 + 3) & ~3;
+    int len = uni(p.lens ? p.lens[b] : p.N);
+    len = len < 0 ? 0 : (len > p.N ? p.N : len);
+    const int NF = len + 1;
+    const float *Vb = p.V + (long long)b * p.vsb;
+    const long long s1p_prefix = ((long long)uni((int)(u.s1p_prefix >> 32)) << 32) | (unsigned)uni((int)u.s1p_prefix);
+    float *wsA = p.ws_alpha + s1p_prefix * (long long)(p.N + 1);
+    float *wsM = reinterpret_cast<float *>(p.ws_c + (long long)b * (p.N + 2));
+    double *hand = p.ws_c + (long long)b * (p.N + 2) + p.N;
+    if (lds_addr_of(lds) != 0u) __builtin_trap();  // the layout uses absolute LDS addresses
+
+    // ---- set-up common to both directions
+    const int fpos = r.fpos;
+    if constexpr (PASS == 0) {
+        if (tid == 0) p.redo[b] = 0;
+    } else {
+        if (uni(p.redo[b])) return;  // marked by the forward kernel: the exact kernels compute this utterance
+        const double logZ2 = hand[1];
+        if (!(logZ2 > -1e300)) {  // no accepting path: gamma = 0, ttl = -inf
+            const long long gbase = (long long)b * p.gsb;
+            for (long long q = tid; q < (long long)p.N * P; q += NT) p.gamma[gbase + (q / P) * p.gsn + (q % P) * p.gsp] = 0.f;
+            if (tid == 0) p.ttl[b] = MM_NINF;
+            return;
+        }
+    }
+    for (unsigned q = tid * 4u; q < 4u * RS + 256u; q += NT * 4u) ldsw(q, 0.f);                  // p, both parities
+    for (unsigned q = tid * 4u; q < 2u * RS; q += NT * 4u) ldsw(L::A(0) + q, MM_NINF);
+    if constexpr (PASS == 1)
+        for (unsigned q = tid * 4u; q < 2u * RS; q += NT * 4u) ldsw(L::Q(0) + q, 0.f);
+    if (tid < 32) ldsw(L::PART(0) + 4u * tid, MM_NINF);
+    if (tid < 2) ldsw(L::EM(tid) + 4u * P1p, MM_NINF);  // the emission slot of lanes without a row
+    const int nslotwords = r.nslotrows * 64 * (PASS ? 2 : 1);
+    for (int q = tid; q < nslotwords; q += NT) ldswu(L::SLOTS + 4u * q, as_global(r.slots)[q]);
+    int *redo = p.redo + b;
+    const float thr = r.thr;
+    if constexpr (PASS == 1)
+        for (int q = tid; q < P1; q += NT) ldswu(L::PDFSE + 4u * q, as_global(reinterpret_cast<const unsigned *>(r.pdfse))[q]);
+    // schedule of a compute wave
+    unsigned long long endmask = 0, lgw0 = 0;
+    int nslots = 0;
+    unsigned slot_base = 0;
+    if (!service && wave < r.NWC) {
+        const RowSched &sc = r.sched[wave];
+        endmask = sc.endmask;
+        lgw0 = sc.lg;
+        nslots = (int)sc.nslots;
+        slot_base = L::SLOTS + (sc.slot0 * 64u + lane) * (PASS ? 8u : 4u);
+    }
+    // graph registers of a compute wave: loaded at the top of the compute branch of each direction, so that they are
+    // never live together with the staging registers of the service wave
+    RowRegs<KA> rg;
+    auto load_graph = [&]() {
+        // straight-line: every load from a clamped, always valid index (no branches, all loads in flight together)
+        const int ka = r.KA, nt = 64 * r.NWC;
+        const bool mine = wave < r.NWC;
+        const auto wp = as_global(r.w);
+        const auto ap = as_global(r.addr);
+        const int t0 = mine ? tid : 0;
+#pragma unroll
+        for (int k = 0; k < KA; ++k) {
+            const int idx = (k < ka ? k * nt : 0) + t0;
+            rg.w[k] = wp[idx];
+            rg.a[k] = ap[idx];
+        }
+#pragma unroll
+        for (int k = 0; k < KA; ++k)
+            if (!mine || k >= ka) {
+                rg.w[k] = 0.f;
+                rg.a[k] = 0u;
+            }
+    };
+    unsigned em_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)endmask);
+    unsigned em_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(endmask >> 32));
+    lgw0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(lgw0 >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((unsigned)lgw0);
+    nslots = __builtin_amdgcn_readfirstlane(nslots);
+    __syncthreads();
+
+    // The two roles run separate code from here on, each with the same sequence of barriers (two in the prologue, one
+    // per frame): their register-resident state -- the graph of a compute wave, the staging registers of the service
+    // wave -- is then never live together.
+    if constexpr (PASS == 0) {
+        // =================== forward: alpha-recursion (src/inference.jl:62-74) ===================
+        // frame 1: alpha_hat (*) lhs[:,1]   (src/inference.jl:68), by all threads once its emissions are staged
+        auto frame1 = [&]() {
+            float wm = MM_NINF;
+            for (int i = tid; i < S1; i += NT) {
+                const float v = as_global(r.init)[i] + ldsr(L::EM(1) + 4u * as_global(r.rowpdf)[i]);
+                if (row_out_of_range(v, thr)) *redo = 1;
+                ldsw(L::A(1) + 4u * i, v);
+                const float pv = fast_exp2(v);
+                ldsw(L::P(1, 0) + 4u * i, pv);
+                ldsw(L::P(1, 1) + 4u * i, pv);
+                wsA[(long long)1 * S1p + i] = v;
+                wm = max_nc(wm, v);
+            }
+            part_put(reinterpret_cast<float *>(lds) + L::PART(1) / 4, wave, lane, wm);
+        };
+        if (service) {
+            float raw[4];
+            double C = 0.0;
+            row_load_em(raw, Vb, p.vsn, 1, p.N, P, lane);
+            C += (double)row_stage_em(L::EM(1), raw, 1, len, P, lane);
+            row_load_em(raw, Vb, p.vsn, 2, p.N, P, lane);
+            __syncthreads();
+            frame1();
+            if (NF >= 2) {
+                C += (double)row_stage_em(L::EM(0), raw, 2, len, P, lane);
+                row_load_em(raw, Vb, p.vsn, 3, p.N, P, lane);
+            }
+            __syncthreads();
+            auto step = [&](auto RDc, int n) {
+                constexpr int RD = decltype(RDc)::value;
+                const float M = part_max_dpp(reinterpret_cast<float *>(lds) + L::PART(RD) / 4, NW, lane);
+                C += (double)M;
+                if (lane == 0) wsM[n - 1] = M;  // M_{n-1}
+                if (n + 1 <= NF) C += (double)row_stage_em(L::EM(RD), raw, n + 1, len, P, lane);
+                row_load_em(raw, Vb, p.vsn, n + 2, p.N, P, lane);
+                __syncthreads();
+            };
+            for (int n = 2; n <= NF; n += 2) {
+                step(std::integral_constant<int, 1>{}, n);
+                if (n + 1 <= NF) step(std::integral_constant<int, 0>{}, n + 1);
+            }
+            if (lane == 0) {
+                const float afin = ldsr(L::A(NF & 1) + 4u * fpos);  // normalised log2 value of the final state, last frame
+                hand[0] = (double)afin;
+                hand[1] = (double)afin + C;
+            }
+        } else {
+            __syncthreads();
+            frame1();
+            __syncthreads();
+            load_graph();
+            auto step = [&](auto RDc, int n) {
+                constexpr int RD = decltype(RDc)::value, WR = 1 - RD;
+                if (nslots > 0) {
+                    const float M = part_max_dpp(reinterpret_cast<float *>(lds) + L::PART(RD) / 4, NW, lane);
+                    // (the alpha store has rows 0..N; frame len+1 is not needed by the backward pass: it goes to the unused row 0)
+                    float *wsAn = wsA + (long long)(n <= len ? n : 0) * S1p;
+                    float acc = 0.f, wm = MM_NINF;
+                    unsigned long long lgw = lgw0;
+                    unsigned sa = slot_base;
+                    unsigned info = ldsru(sa);
+                    float e = ldsr((info >> 16) + L::EM(WR));
+                    float x[2 * D];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        x[2 * j] = (2 * j < KA) ? ldsr(rg.a[(2 * j < KA) ? 2 * j : 0] + L::P(RD, 0)) : 0.f;
+                        x[2 * j + 1] = (2 * j + 1 < KA) ? ldsr(rg.a[(2 * j + 1 < KA) ? 2 * j + 1 : 0] + L::P(RD, 0)) : 0.f;
+                    }
+                    int left = nslots;
+                    auto finish = [&]() {
+                        const int lg = (int)(lgw & 15ull);
+                        lgw >>= 4;
+                        float s = acc;
+                        if (lg) s = grp_sum_last(s, lg);
+                        const unsigned pos4 = info & 0xffffu;
+                        const float v = fast_log2(s) + e - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
+                        if (__builtin_expect(row_out_of_range(v, thr), 0)) *redo = 1;
+                        const float pv = fast_exp2(v);
+                        ldsw(pos4 + L::A(WR), v);
+                        ldsw(pos4 + L::P(WR, 0), pv);
+                        ldsw(pos4 + L::P(WR, 1), pv);
+                        *reinterpret_cast<float *>(reinterpret_cast<char *>(wsAn) + pos4) = v;
+                        wm = max_nc(wm, v);
+                        acc = 0.f;
+                        sa += 256u;
+                        info = ldsru(sa);
+                        e = ldsr((info >> 16) + L::EM(WR));
+                    };
+                    // (opaque per step: hoisted out of the frame loop, the bit tests of all pairs would each occupy a scalar
+                    // register pair for the whole loop)
+                    asm volatile("" : "+s"(em_lo), "+s"(em_hi));
+                    row_pairs<0, KA, D, L::P(RD, 0)>(rg.w, rg.a, x, acc, em_lo, em_hi, left, finish);
+                    part_put(reinterpret_cast<float *>(lds) + L::PART(WR) / 4, wave, lane, wm);
+                }
+                __syncthreads();
+            };
+            for (int n = 2; n <= NF; n += 2) {
+                step(std::integral_constant<int, 1>{}, n);
+                if (n + 1 <= NF) step(std::integral_constant<int, 0>{}, n + 1);
+            }
+        }
+    } else {
+        // ============ backward: beta-recursion (src/inference.jl:99-110) fused with the combine (:154-160) ============
+        const float afin = (float)hand[0];
+        const long long gbase = (long long)b * p.gsb;
+        float tmin = 0.f;
+        if (tid == 0) {  // frame len+1: B (*) lhs = one for the final state only
+            ldsw(L::A(NF & 1) + 4u * fpos, 0.f);
+            ldsw(L::P(NF & 1, 0) + 4u * fpos, 1.f);
+            ldsw(L::P(NF & 1, 1) + 4u * fpos, 1.f);
+        }
+        // run steps n = len .. 1; step n reads y_{n+1} from parity (n + 1) & 1
+        auto run = [&](auto &&step) {
+            int n = len;
+            if (n >= 1 && ((n + 1) & 1) == 0) {
+                step(std::integral_constant<int, 0>{}, n);
+                --n;
+            }
+            for (; n >= 1; n -= 2) {
+                step(std::integral_constant<int, 1>{}, n);
+                if (n - 1 >= 1) step(std::integral_constant<int, 0>{}, n - 1);
+            }
+        };
+        if (service) {
+            float raw[4];
+            constexpr int NA = (RS / 4 + 255) / 256;
+            mm_f32x4 arow[NA];  // one alpha row in flight (RS / 4 floats at most)
+            const int n4 = S1p >> 2;
+            auto load_arow = [&](int n) {
+                const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(wsA + (long long)(n < 1 ? 1 : n) * S1p);
+#pragma unroll
+                for (int j = 0; j < NA; ++j) {
+                    const int q = lane + 64 * j;
+                    arow[j] = as_global(src)[q < n4 ? q : 0];
+                }
+            };
+            auto store_arow = [&](unsigned dst) {
+#pragma unroll
+                for (int j = 0; j < NA; ++j) {
+                    const int q = lane + 64 * j;
+                    if (q < n4) *(__attribute__((address_space(3))) mm_f32x4 *)(__UINTPTR_TYPE__)(dst + 16u * q) = arow[j];
+                }
+            };
+            if (len >= 1) {
+                row_load_em(raw, Vb, p.vsn, len, p.N, P, lane);
+                (void)row_stage_em(L::EM(len & 1), raw, len, len, P, lane);
+                row_load_em(raw, Vb, p.vsn, len - 1, p.N, P, lane);
+                load_arow(len);
+                store_arow(L::AL(len & 1));
+                load_arow(len - 1);
+            }
+            __syncthreads();
+            run([&](auto RDc, int n) {
+                constexpr int RD = decltype(RDc)::value, WR = 1 - RD;
+                // emissions and alpha row of frame n-1 (loaded during the previous step) go to LDS; frame n-2's are requested
+                if (n - 1 >= 1) {
+                    (void)row_stage_em(L::EM(RD), raw, n - 1, len, P, lane);
+                    store_arow(L::AL(RD));
+                }
+                row_load_em(raw, Vb, p.vsn, n - 2, p.N, P, lane);
+                load_arow(n - 2);
+                // gamma of frame n+2: its per-pdf sums were completed in the previous step
+                if (n + 2 <= len) {
+                    const float s = finish_frame(reinterpret_cast<float *>(lds) + L::PSUM(WR) / 4, P1, P, lane,
+                                                 p.gamma + gbase + (long long)(n + 1) * p.gsn, p.gsp);
+                    tmin = fminf(tmin, fast_log2(s));
+                }
+                __syncthreads();
+            });
+        } else {
+            __syncthreads();
+            // kappa_n = log2 Z - C_n - D_n = afin + G_n with G_n = sum_{k>=n} M_k(forward) - sum M(backward):
+            // accumulated incrementally (double; its magnitude stays small)
+            double G = 0.0;
+            float mfn = len >= 1 ? wsM[len] : 0.f;
+            load_graph();
+            run([&](auto RDc, int n) {
+                constexpr int RD = decltype(RDc)::value, WR = 1 - RD;
+                const float mf = mfn;  // M_n (forward)
+                mfn = n - 1 >= 1 ? wsM[n - 1] : 0.f;  // M_{n-1} for the next step
+                const float M = (n == len) ? 0.f : part_max_dpp(reinterpret_cast<float *>(lds) + L::PART(RD) / 4, NW, lane);
+                G += (double)mf - (double)M;
+                const float kappa = afin + (float)G;
+                if (n < len)  // frame n+1, per pdf
+                    pdf_sums(reinterpret_cast<float *>(lds) + L::Q(RD) / 4, reinterpret_cast<unsigned short *>(lds) + L::PDFSE / 2,
+                             reinterpret_cast<float *>(lds) + L::PSUM(RD) / 4, P1, wave, NWC, lane);
+                if (nslots > 0) {
+                    float acc = 0.f, wm = MM_NINF;
+                    unsigned long long lgw = lgw0;
+                    unsigned sa = slot_base;
+                    unsigned info = ldsru(sa), info2 = ldsru(sa + 4u);
+                    float e = ldsr((info >> 16) + L::EM(WR));
+                    float al = ldsr((info2 & 0xffffu) + L::AL(WR));
+                    float x[2 * D];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        x[2 * j] = (2 * j < KA) ? ldsr(rg.a[(2 * j < KA) ? 2 * j : 0] + L::P(RD, 0)) : 0.f;
+                        x[2 * j + 1] = (2 * j + 1 < KA) ? ldsr(rg.a[(2 * j + 1 < KA) ? 2 * j + 1 : 0] + L::P(RD, 0)) : 0.f;
+                    }
+                    int left = nslots;
+                    auto finish = [&]() {
+                        const int lg = (int)(lgw & 15ull);
+                        lgw >>= 4;
+                        float s = acc;
+                        if (lg) s = grp_sum_last(s, lg);
+                        const unsigned pos4 = info & 0xffffu;
+                        const float beta = fast_log2(s) - M;  // T (B[:,n+1] (*) lhs[:,n+1])  (src/inference.jl:106-107)
+                        ldsw((info2 >> 16) + L::Q(WR), fast_exp2(al + beta - kappa));
+                        const float y = beta + e;
+                        if (__builtin_expect(row_out_of_range(y, thr), 0)) *redo = 1;
+                        const float py = fast_exp2(y);
+                        ldsw(pos4 + L::A(WR), y);
+                        ldsw(pos4 + L::P(WR, 0), py);
+                        ldsw(pos4 + L::P(WR, 1), py);
+                        wm = max_nc(wm, y);
+                        acc = 0.f;
+                        sa += 512u;
+                        info = ldsru(sa);
+                        info2 = ldsru(sa + 4u);
+                        e = ldsr((info >> 16) + L::EM(WR));
+                        al = ldsr((info2 & 0xffffu) + L::AL(WR));
+                    };
+                    asm volatile("" : "+s"(em_lo), "+s"(em_hi));
+                    row_pairs<0, KA, D, L::P(RD, 0)>(rg.w, rg.a, x, acc, em_lo, em_hi, left, finish);
+                    part_put(reinterpret_cast<float *>(lds) + L::PART(WR) / 4, wave, lane, wm);
+                }
+                __syncthreads();
+            });
+        }
+        // gamma of frames 2 and 1, zeros beyond len, ttl
+        if (service && len >= 2) {  // frame 2: summed in the last step
+            const float s = finish_frame(reinterpret_cast<float *>(lds) + L::PSUM(0) / 4, P1, P, lane, p.gamma + gbase + p.gsn, p.gsp);
+            tmin = fminf(tmin, fast_log2(s));
+        }
+        if (len >= 1) {
+            if (!service)
+                pdf_sums(reinterpret_cast<float *>(lds) + L::Q(1) / 4, reinterpret_cast<unsigned short *>(lds) + L::PDFSE / 2,
+                         reinterpret_cast<float *>(lds) + L::PSUM(1) / 4, P1, wave, NWC, lane);
+            __syncthreads();
+            if (service) {
+                const float s = finish_frame(reinterpret_cast<float *>(lds) + L::PSUM(1) / 4, P1, P, lane, p.gamma + gbase, p.gsp);
+                tmin = fminf(tmin, fast_log2(s));
+            }
+        }
+        for (long long q = tid; q < (long long)(p.N - len) * P; q += NT)
+            p.gamma[gbase + (len + q / P) * p.gsn + (q % P) * p.gsp] = 0.f;
+        if (service && lane == 0)  // ttl = log Z + min over frames of log(per-frame sum)   (src/inference.jl:159)
+            p.ttl[b] = (float)((hand[1] + (double)tmin) * (double)MM_LN2);
+    }
+}
+
+}  // namespace mm

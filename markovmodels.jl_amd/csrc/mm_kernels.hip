@@ -58,9 +58,26 @@ struct QuadDev {  // one direction in quad form, internal numbering (mm_pack.h Q
     int pad;
 };
 
+struct RowSched;
+struct RowDev {  // one direction in row-lane form, internal numbering (mm_rows.h RowGraph)
+    const float *w;               // [KA][64 * NWC] linear weights
+    const unsigned *addr;         // [KA][64 * NWC] LDS byte addresses of the sources
+    const unsigned *slots;        // [nslotrows][64] x 1 (forward) / 2 (backward) words
+    const RowSched *sched;        // [NWC]
+    const int *rowptr;            // CSR with log2 weights for the exact fallback
+    const int *col;
+    const float *cw;
+    const unsigned short *rowpdf; // [rows] pdf of the row at each position
+    const unsigned short *pdfse;  // [2 * P1] (first, end) of each pdf in pdf-major order (backward only)
+    const float *init;            // [rows] alpha_hat by position, log2 domain (forward only)
+    int KA, NWC, nslotrows, fpos, rows;
+    float thr;  // |normalised log2 value| beyond which the linear path is not trusted (mm_kernel_rows.hip)
+};
+
 struct UttDesc {
     GraphDev g[2];  // 0: T_hat' packed (forward), 1: T_hat packed (backward)
     QuadDev q[2];   // same two matrices in quad form (log semiring only)
+    RowDev r[2];    // ... and in row-lane form (log semiring only; KA == 0: not available)
     const float *init_f;            // alpha_hat in forward numbering
     const unsigned short *map_bf;   // backward position -> forward position
     const float *init;  // dense alpha_hat [S1] (log2 domain for MM_LOG, natural for MM_TROPICAL)
@@ -97,6 +114,9 @@ struct RunParams {
     // workgroup -> utterance, longest first (NULL: identity).  With more utterances than CUs the workgroups
     // are handed out in this order, so the long utterances start first and the short ones fill the tail.
     const int *order;
+    // Row kernels: redo[b] != 0 marks an utterance whose linear-domain sums left the trusted range; the exact kernels
+    // launched after them skip every utterance that is not marked (NULL: run all).
+    int *redo;
 };
 
 // In-kernel cycle stamps (diagnostic build only; the shipped library executes none).
@@ -476,6 +496,7 @@ template <int MODE, int NI, int PASS = 0, bool TROP = false>
 __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p) {
     extern __shared__ float lds[];
     const int b = p.order ? p.order[blockIdx.x] : blockIdx.x;
+    if (p.redo && !p.redo[b]) return;  // launched behind the row kernels: only the utterances they marked
     const UttDesc &u = p.utts[b];
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6;

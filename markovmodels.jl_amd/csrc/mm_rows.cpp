@@ -1,0 +1,412 @@
+// mm_rows.cpp -- see mm_rows.h
+#include "mm_rows.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+namespace mm {
+namespace {
+
+struct Unit {   // one row as the kernel sees it
+    int32_t row;
+    int g;      // lanes per row (power of two)
+    int A;      // arc slots per lane (even, >= 2)
+    int deg;
+};
+struct Segment {  // 64 / g units of one g class
+    int g, A;
+    std::vector<int32_t> rows;  // <= 64 / g
+    int wave = -1;
+};
+
+int log2i(int g) {
+    int l = 0;
+    while ((1 << l) < g) ++l;
+    return l;
+}
+
+// distinct addresses per bank of one gather instruction of a half-wave, with multiplicities
+struct Banks {
+    struct E {
+        uint32_t addr;
+        uint16_t n;
+    };
+    std::vector<E> bank[32];
+    static int of(uint32_t a) { return int(a >> 2) & 31; }
+    void add(uint32_t a) {
+        auto &v = bank[of(a)];
+        for (auto &e : v)
+            if (e.addr == a) {
+                ++e.n;
+                return;
+            }
+        v.push_back(E{a, 1});
+    }
+    void remove(uint32_t a) {
+        auto &v = bank[of(a)];
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].addr == a) {
+                if (--v[i].n == 0) {
+                    v[i] = v.back();
+                    v.pop_back();
+                }
+                return;
+            }
+    }
+    int cost_of(uint32_t a) const {  // extra cycles this address would add (0: free bank or a broadcast)
+        const auto &v = bank[of(a)];
+        for (auto &e : v)
+            if (e.addr == a) return 0;
+        return int(v.size());
+    }
+    int cycles() const {
+        size_t m = 1;
+        for (auto &v : bank) m = std::max(m, v.size());
+        return int(m);
+    }
+    bool conflicted(uint32_t a) const { return bank[of(a)].size() > 1; }
+    int least_loaded() const {
+        int b = 0;
+        for (int i = 1; i < 32; ++i)
+            if (bank[i].size() < bank[b].size()) b = i;
+        return b;
+    }
+};
+
+struct Plan {
+    std::vector<Segment> segs;
+    std::vector<std::vector<int>> wave_segs;  // per wave: indices into segs, in execution order
+    int KA = 0, maxcost = 0, mincost = 0;
+    bool ok = false;
+};
+
+Plan plan_for(int64_t nrows, const std::vector<int64_t> &rowptr, int acap, const RowPackOpts &opt) {
+    Plan p;
+    std::vector<Unit> units;
+    units.reserve(size_t(nrows));
+    for (int64_t r = 0; r < nrows; ++r) {
+        const int d = int(rowptr[r + 1] - rowptr[r]);
+        int g = 1;
+        while ((std::max(d, 1) + g - 1) / g > acap && g < 64) g *= 2;
+        int A = (std::max(d, 1) + g - 1) / g;
+        A = (A + 1) & ~1;
+        units.push_back(Unit{int32_t(r), g, A, d});
+    }
+    for (int g = 1; g <= 64; g *= 2) {
+        std::vector<Unit> us;
+        for (auto &u : units)
+            if (u.g == g) us.push_back(u);
+        if (us.empty()) continue;
+        std::stable_sort(us.begin(), us.end(), [](const Unit &a, const Unit &b) { return a.A > b.A; });
+        const size_t per = size_t(64 / g);
+        for (size_t i = 0; i < us.size(); i += per) {
+            Segment s;
+            s.g = g;
+            s.A = us[i].A;
+            for (size_t j = i; j < std::min(us.size(), i + per); ++j) s.rows.push_back(us[j].row);
+            p.segs.push_back(std::move(s));
+        }
+    }
+    const int nwc = std::max(1, std::min<int>(opt.nwc_max, int(p.segs.size())));
+    auto cost = [&](const Segment &s) { return s.A + opt.finish_cost + opt.group_cost * log2i(s.g); };
+    std::vector<int> idx(p.segs.size());
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost(p.segs[a]) > cost(p.segs[b]); });
+    std::vector<int> load(nwc, 0), arcs(nwc, 0);
+    p.wave_segs.assign(nwc, {});
+    for (int i : idx) {
+        int best = -1;
+        for (int w = 0; w < nwc; ++w) {
+            if (int(p.wave_segs[w].size()) >= MM_ROW_MAX_SLOTS) continue;
+            if (best < 0 || load[w] < load[best] || (load[w] == load[best] && arcs[w] < arcs[best])) best = w;
+        }
+        if (best < 0) return p;  // more than MM_ROW_MAX_SLOTS segments per wave
+        p.segs[i].wave = best;
+        p.wave_segs[best].push_back(i);
+        load[best] += cost(p.segs[i]);
+        arcs[best] += p.segs[i].A;
+    }
+    for (auto &ws : p.wave_segs)
+        std::stable_sort(ws.begin(), ws.end(), [&](int a, int b) { return p.segs[a].A > p.segs[b].A; });
+    p.KA = *std::max_element(arcs.begin(), arcs.end());
+    p.maxcost = *std::max_element(load.begin(), load.end());
+    p.mincost = *std::min_element(load.begin(), load.end());
+    p.ok = p.KA <= opt.ka_max && p.KA <= 128;
+    return p;
+}
+
+}  // namespace
+
+bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &col,
+               const std::vector<float> &val, const std::vector<int32_t> &row2pdf, int32_t P1, bool backward,
+               const std::vector<int32_t> &fwd_pos, const RowPackOpts &opt, RowGraph &g) {
+    g = RowGraph();
+    if (nrows < 1 || (nrows + 1) * 4 > opt.rs || (nrows + 1) * 4 > 65532 || P1 > 8000) return false;
+    // ---- schedule: the cap on arcs per lane of one row decides how many rows are split over lane groups; take
+    // the cap whose most loaded wave is cheapest
+    Plan best;
+    for (int acap : {12, 16, 24, 32, 48, 64}) {
+        if (acap > opt.ka_max) continue;
+        Plan p = plan_for(nrows, rowptr, acap, opt);
+        if (!p.ok) continue;
+        if (!best.ok || p.maxcost < best.maxcost || (p.maxcost == best.maxcost && p.KA < best.KA)) best = std::move(p);
+    }
+    if (!best.ok) return false;
+    const int NWC = int(best.wave_segs.size());
+    const int KA = std::max(2, (best.KA + 1) & ~1), NT = 64 * NWC;
+    g.KA = KA;
+    g.NWC = NWC;
+    g.rs = opt.rs;
+    g.trash = int(nrows);
+    g.slot_words = backward ? 2 : 1;
+    g.maxcost = best.maxcost;
+    g.mincost = best.mincost;
+    // ---- numbering: the order in which the rows are finished
+    g.order.assign(size_t(nrows), -1);
+    g.pos.assign(size_t(nrows), -1);
+    {
+        int32_t next = 0;
+        for (int w = 0; w < NWC; ++w)
+            for (int si : best.wave_segs[w])
+                for (int32_t r : best.segs[si].rows) {
+                    g.pos[r] = next;
+                    g.order[next] = r;
+                    ++next;
+                }
+        if (next != nrows) return false;
+    }
+    g.rowpdf.resize(size_t(nrows));
+    for (int64_t i = 0; i < nrows; ++i) g.rowpdf[i] = uint16_t(row2pdf[g.order[i]]);
+    // pdf-major order of the rows (backward: the posterior of a pdf is a sum over contiguous entries)
+    std::vector<int32_t> qpos(size_t(nrows), 0);
+    if (backward) {
+        std::vector<int32_t> byp(static_cast<size_t>(nrows));
+        std::iota(byp.begin(), byp.end(), 0);
+        std::stable_sort(byp.begin(), byp.end(), [&](int32_t a, int32_t b) { return row2pdf[a] < row2pdf[b]; });
+        g.pdfse.assign(2 * size_t(P1), 0);
+        std::vector<int64_t> first(P1, -1), last(P1, -1);
+        for (int64_t i = 0; i < nrows; ++i) {
+            qpos[byp[i]] = int32_t(i);
+            const int32_t p = row2pdf[byp[i]];
+            if (first[p] < 0) first[p] = i;
+            last[p] = i;
+        }
+        for (int32_t p = 0; p < P1; ++p) {
+            g.pdfse[2 * p] = uint16_t(first[p] < 0 ? 0 : first[p]);
+            g.pdfse[2 * p + 1] = uint16_t(first[p] < 0 ? 0 : last[p] + 1);
+        }
+    }
+    // ---- CSR in internal numbering (exact fallback)
+    g.rowptr.assign(size_t(nrows) + 1, 0);
+    g.col.resize(col.size());
+    g.cw.resize(val.size());
+    {
+        int64_t a_out = 0;
+        for (int64_t i = 0; i < nrows; ++i) {
+            const int64_t r = g.order[i];
+            g.rowptr[i] = int32_t(a_out);
+            for (int64_t a = rowptr[r]; a < rowptr[r + 1]; ++a, ++a_out) {
+                g.col[a_out] = g.pos[col[a]];
+                g.cw[a_out] = val[a];
+            }
+        }
+        g.rowptr[nrows] = int32_t(a_out);
+    }
+    // ---- schedules, slot table
+    const int zero_pdf = (P1 + 3) & ~3;  // emission slot that always holds zero(K)
+    g.sched.assign(NWC, RowSched{0, 0, 0, 0});
+    int nslots = 0;
+    for (int w = 0; w < NWC; ++w) nslots += int(best.wave_segs[w].size());
+    g.nslotrows = nslots + 1;  // + one padding row: the prefetch after a wave's last finish reads one row ahead
+    g.slots.assign(size_t(g.nslotrows) * 64 * g.slot_words, 0);
+    g.w.assign(size_t(KA) * NT, 0.f);
+    g.addr.assign(size_t(KA) * NT, 0u);
+    const uint32_t copy1 = uint32_t(opt.rs + 64);
+    double cyc_naive = 0, cyc_sched = 0;
+    int64_t n_instr = 0, real_arcs = 0;
+    int slotrow = 0;
+    for (int w = 0; w < NWC; ++w) {
+        RowSched &sc = g.sched[w];
+        sc.slot0 = uint32_t(slotrow);
+        sc.nslots = uint32_t(best.wave_segs[w].size());
+        int k0 = 0, sidx = 0;
+        for (int si : best.wave_segs[w]) {
+            const Segment &s = best.segs[si];
+            const int lg = log2i(s.g);
+            sc.lg |= uint64_t(lg) << (4 * sidx);
+            sc.endmask |= uint64_t(1) << ((k0 + s.A) / 2 - 1);
+            // slot table row
+            for (int l = 0; l < 64; ++l) {
+                const size_t e = (size_t(slotrow) * 64 + l) * g.slot_words;
+                const int grp = l / s.g;
+                // the LAST lane of a row's group holds the group sum and finishes the row; the others finish nothing
+                if (grp < int(s.rows.size()) && l % s.g == s.g - 1) {
+                    const int32_t r = s.rows[grp];
+                    g.slots[e] = uint32_t(4 * g.pos[r]) | (uint32_t(4 * row2pdf[r]) << 16);
+                    if (backward) g.slots[e + 1] = uint32_t(4 * fwd_pos[r]) | (uint32_t(4 * qpos[r]) << 16);
+                } else {
+                    g.slots[e] = uint32_t(4 * g.trash) | (uint32_t(4 * zero_pdf) << 16);
+                    if (backward) g.slots[e + 1] = 0u | (uint32_t(4 * g.trash) << 16);
+                }
+            }
+            // arcs of the segment: every lane of a row's group takes every g-th arc; inside its A slots the
+            // lane's arcs are ordered (and their copy chosen) by the bank model, one half-wave at a time
+            for (int half = 0; half < 2; ++half) {
+                std::vector<Banks> tabn(s.A), tab(s.A);
+                struct LaneArcs {
+                    std::vector<int64_t> arcs;  // indices into the internal CSR
+                };
+                LaneArcs la[32];
+                for (int l = 0; l < 32; ++l) {
+                    const int lane = half * 32 + l, grp = lane / s.g, sub = lane % s.g;
+                    if (grp >= int(s.rows.size())) continue;
+                    const int64_t i = g.pos[s.rows[grp]];
+                    for (int64_t a = g.rowptr[i] + sub; a < g.rowptr[i + 1]; a += s.g) la[l].arcs.push_back(a);
+                }
+                // naive placement (CSR order, copy 0) for the statistics
+                for (int l = 0; l < 32; ++l)
+                    for (int k = 0; k < s.A; ++k)
+                        tabn[k].add(k < int(la[l].arcs.size()) ? uint32_t(4 * g.col[la[l].arcs[k]]) : uint32_t(4 * (l % int(nrows))));
+                // greedy: lane after lane, slot after slot, the remaining arc / copy that is cheapest there
+                std::vector<std::vector<uint32_t>> ad(32, std::vector<uint32_t>(s.A, 0u));
+                std::vector<std::vector<float>> wt(32, std::vector<float>(s.A, 0.f));
+                for (int l = 0; l < 32; ++l) {
+                    std::vector<char> used(la[l].arcs.size(), 0);
+                    for (int k = 0; k < s.A; ++k) {
+                        int bi = -1, bcost = 1 << 30;
+                        uint32_t baddr = 0;
+                        for (size_t i = 0; i < la[l].arcs.size() && bcost > 0; ++i) {
+                            if (used[i]) continue;
+                            for (uint32_t cp = 0; cp < 2; ++cp) {
+                                const uint32_t a = uint32_t(4 * g.col[la[l].arcs[i]]) + cp * copy1;
+                                const int c = tab[k].cost_of(a);
+                                if (c < bcost) {
+                                    bcost = c;
+                                    bi = int(i);
+                                    baddr = a;
+                                    if (c == 0) break;
+                                }
+                            }
+                        }
+                        if (bi >= 0) {
+                            used[bi] = 1;
+                            ad[l][k] = baddr;
+                            wt[l][k] = std::exp2(g.cw[la[l].arcs[bi]]);
+                            ++real_arcs;
+                        } else {  // padding: weight 0, an address that costs nothing
+                            const int bnk = tab[k].least_loaded();
+                            ad[l][k] = uint32_t(4 * (bnk < nrows ? bnk : 0));
+                            wt[l][k] = 0.f;
+                        }
+                        tab[k].add(ad[l][k]);
+                    }
+                }
+                // local search: flip the copy of a conflicting slot, or swap it with another slot of the lane
+                for (int pass = 0; pass < 4; ++pass) {
+                    bool improved = false;
+                    for (int l = 0; l < 32; ++l)
+                        for (int k = 0; k < s.A; ++k) {
+                            uint32_t a = ad[l][k];
+                            if (!tab[k].conflicted(a)) continue;
+                            if (wt[l][k] != 0.f) {
+                                const uint32_t alt = a >= copy1 ? a - copy1 : a + copy1;
+                                const int before = tab[k].cycles();
+                                tab[k].remove(a);
+                                tab[k].add(alt);
+                                if (tab[k].cycles() < before || (tab[k].cycles() == before && !tab[k].conflicted(alt))) {
+                                    ad[l][k] = a = alt;
+                                    improved = true;
+                                    if (!tab[k].conflicted(a)) continue;
+                                } else {
+                                    tab[k].remove(alt);
+                                    tab[k].add(a);
+                                }
+                            }
+                            for (int k2 = 0; k2 < s.A; ++k2) {
+                                if (k2 == k) continue;
+                                const uint32_t b = ad[l][k2];
+                                const int before = tab[k].cycles() + tab[k2].cycles();
+                                tab[k].remove(a);
+                                tab[k2].remove(b);
+                                tab[k].add(b);
+                                tab[k2].add(a);
+                                if (tab[k].cycles() + tab[k2].cycles() < before) {
+                                    std::swap(ad[l][k], ad[l][k2]);
+                                    std::swap(wt[l][k], wt[l][k2]);
+                                    improved = true;
+                                    break;
+                                }
+                                tab[k].remove(b);
+                                tab[k2].remove(a);
+                                tab[k].add(a);
+                                tab[k2].add(b);
+                            }
+                        }
+                    if (!improved) break;
+                }
+                for (int k = 0; k < s.A; ++k) {
+                    cyc_naive += tabn[k].cycles();
+                    cyc_sched += tab[k].cycles();
+                    ++n_instr;
+                    for (int l = 0; l < 32; ++l) {
+                        const size_t e = size_t(k0 + k) * NT + size_t(w) * 64 + half * 32 + l;
+                        g.w[e] = wt[l][k];
+                        g.addr[e] = ad[l][k];
+                    }
+                }
+            }
+            k0 += s.A;
+            ++sidx;
+            ++slotrow;
+        }
+    }
+    // the padding row of the slot table
+    for (int l = 0; l < 64; ++l) {
+        const size_t e = (size_t(slotrow) * 64 + l) * g.slot_words;
+        g.slots[e] = uint32_t(4 * g.trash) | (uint32_t(4 * zero_pdf) << 16);
+        if (backward) g.slots[e + 1] = 0u | (uint32_t(4 * g.trash) << 16);
+    }
+    g.conflict_before = n_instr ? cyc_naive / double(n_instr) : 0;
+    g.conflict_after = n_instr ? cyc_sched / double(n_instr) : 0;
+    g.pad_eff = n_instr ? double(real_arcs) / (32.0 * double(n_instr)) : 0;
+    g.wmin_log2 = 0.f;
+    for (float v : val)
+        if (v > -std::numeric_limits<float>::infinity()) g.wmin_log2 = std::min(g.wmin_log2, v);
+    return true;
+}
+
+void eval_rows(const RowGraph &g, const float *in_lin, float *out_lin) {
+    const int NT = 64 * g.NWC;
+    const uint32_t copy1 = uint32_t(g.rs + 64);
+    for (int w = 0; w < g.NWC; ++w) {
+        const RowSched &sc = g.sched[w];
+        float acc[64];
+        for (int l = 0; l < 64; ++l) acc[l] = 0.f;
+        int slot = 0;
+        for (int k2 = 0; k2 < g.KA / 2 && slot < int(sc.nslots); ++k2) {
+            for (int k = 2 * k2; k < 2 * k2 + 2; ++k)
+                for (int l = 0; l < 64; ++l) {
+                    const size_t e = size_t(k) * NT + size_t(w) * 64 + l;
+                    uint32_t a = g.addr[e];
+                    if (a >= copy1) a -= copy1;
+                    acc[l] = std::fmaf(g.w[e], in_lin[a / 4], acc[l]);
+                }
+            if (!((sc.endmask >> k2) & 1)) continue;
+            const int lg = int((sc.lg >> (4 * slot)) & 15), gsz = 1 << lg;
+            for (int l0 = 0; l0 < 64; l0 += gsz) {
+                float s = 0.f;
+                for (int l = l0; l < l0 + gsz; ++l) s += acc[l];
+                const uint32_t info = g.slots[(size_t(sc.slot0 + slot) * 64 + l0 + gsz - 1) * g.slot_words];
+                const int p = int(info & 0xffffu) / 4;
+                if (p != g.trash) out_lin[p] = s;
+            }
+            for (int l = 0; l < 64; ++l) acc[l] = 0.f;
+            ++slot;
+        }
+    }
+}
+
+}  // namespace mm

@@ -1,0 +1,91 @@
+// mm_rows.h -- host-side "compile" step for the row kernels (mm_kernel_rows.hip): CSR rows -> the
+// register-resident "row-lane" form.
+//
+// Like mm_pack.h this replaces the reference's per-call container plumbing (CSC<->CSR conversion
+// src/linalg.jl:12-49, transpose materialisation :55-67) with a prepare-once layout in the spirit of
+// CompiledFSM (src/inference.jl:3-12).  Where the reference's SpMV gives every CSR row a 32-lane warp
+// (src/linalg.jl:213-233), here a row belongs to ONE lane (or to an aligned group of g = 2..64 lanes when it
+// is long), which keeps its arcs in registers for the whole time loop and owns the row's result:
+//
+//   * a workgroup has NWC compute waves (+ one service wave that moves emissions, alpha rows and posteriors
+//     between HBM and LDS); every lane of a compute wave holds KA arc slots (linear weight 2^w and the LDS
+//     byte address of the source state's value);
+//   * the KA slots of a wave are cut into SEGMENTS, the same cut for all 64 lanes of the wave: in segment s
+//     every lane group of g_s lanes sums the arcs of one row (A_s arcs per lane; rows are sorted by size so
+//     that the rows of one segment are about equally long; shorter ones are padded with weight 0).  At the
+//     end of a segment the wave "finishes" its 64 / g_s rows: (group sum,) log2, emission, normaliser, 2^x,
+//     stores -- one finish per row per frame, no partial sums through LDS and no barrier between the
+//     products and the finishing step (the quad kernels need both);
+//   * the segments are dealt to the waves longest-processing-time first under a cost model (arcs + a constant
+//     per finish), so that the waves reach the single barrier of a frame together;
+//   * internal numbering ("position") of the states of one direction = the order in which they are finished
+//     (wave, segment, lane group): the stores of a finish go to 64 / g consecutive positions (conflict free
+//     in LDS, coalesced in the alpha store);
+//   * inside a row the arcs are placed on the (slot, lane) grid so that the 32 lanes of a half-wave that
+//     execute the same gather hit distinct LDS banks where possible; the linear vector is kept in two copies
+//     rotated by 16 banks, and every arc reads the copy whose bank is free in its instruction.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace mm {
+
+enum { MM_ROW_MAX_SLOTS = 16 };  // segments per wave (4 bits of RowSched::lg each)
+
+struct RowSched {       // one compute wave
+    uint64_t endmask;   // bit k: a segment ends after arc pair k (arcs 2k, 2k+1)
+    uint64_t lg;        // log2(lanes per row) of the wave's i-th segment in bits [4i, 4i+4)
+    uint32_t slot0;     // first row of the wave in the slot table
+    uint32_t nslots;    // segments of the wave (>= 1)
+};
+static_assert(sizeof(RowSched) == 24, "RowSched must be 24 bytes");
+
+struct RowGraph {
+    int KA = 0;         // arc slots per lane (even)
+    int NWC = 0;        // compute waves
+    int rs = 0;         // byte stride between the LDS regions the addresses refer to (copy 1 of the linear vector
+                        // lives rs + 64 bytes above copy 0: rotated by 16 banks)
+    int nslotrows = 0;  // rows of the slot table (sum of the waves' segments) + 1 padding row
+    int trash = 0;      // position written by lanes that finish no row (= number of rows)
+    std::vector<int32_t> order;   // position -> original row
+    std::vector<int32_t> pos;     // original row -> position
+    std::vector<float> w;         // [KA][64 * NWC] linear weights (2^log2 weight; 0 = padding)
+    std::vector<uint32_t> addr;   // [KA][64 * NWC] LDS byte address of the source value, relative to copy 0 of the
+                                  // buffer being read
+    std::vector<uint32_t> slots;  // [nslotrows][64] x words: word 0 = 4 * position | (4 * pdf) << 16 of the row the
+                                  // lane finishes in that segment -- the LAST lane of a row's group; every other lane
+                                  // gets position `trash` and the pdf slot that always holds zero(K); backward only,
+                                  // word 1 = 4 * (position in the forward numbering) | (4 * position in pdf-major order) << 16
+    int slot_words = 1;
+    std::vector<RowSched> sched;  // [NWC]
+    std::vector<uint16_t> rowpdf; // [rows] pdf of the row at each position
+    // CSR in internal numbering with log2-domain weights: the exact fallback walks these
+    std::vector<int32_t> rowptr, col;
+    std::vector<float> cw;
+    std::vector<uint16_t> pdfse;  // backward: [2 * P1] (first, end) of each pdf in pdf-major order
+    double conflict_before = 0, conflict_after = 0;  // modelled LDS cycles per gather instruction
+    double pad_eff = 0;           // real arcs / arc slots
+    float wmin_log2 = 0;          // smallest log2 weight of an arc
+    int maxcost = 0, mincost = 0; // cost model: most / least loaded wave
+};
+
+struct RowPackOpts {
+    int nwc_max = 15;     // compute waves available
+    int ka_max = 48;      // register budget (arc slots per lane)
+    int rs = 8192;        // LDS region stride in bytes
+    int finish_cost = 8;  // cost of one finish in units of one arc (gather + FMA)
+    int group_cost = 2;   // extra cost per butterfly level of a grouped (g > 1) segment
+};
+
+// rowptr/col/val_log2: 0-based CSR of M (out[r] = (+)_k val[k] (*) in[col[k]]), square, nrows rows.
+// fwd_pos (backward form only, else empty): position of every original row in the forward numbering.
+// Returns false if the graph does not fit (KA > ka_max, too many segments per wave, positions beyond the region).
+bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &col,
+               const std::vector<float> &val_log2, const std::vector<int32_t> &row2pdf, int32_t P1, bool backward,
+               const std::vector<int32_t> &fwd_pos, const RowPackOpts &opt, RowGraph &out);
+
+// Host evaluation of one product through the row form exactly as a workgroup walks it (lane by lane, segment
+// by segment, group sums), in the linear domain: in_lin[position] -> out_lin[position].  Test aid.
+void eval_rows(const RowGraph &g, const float *in_lin, float *out_lin);
+
+}  // namespace mm

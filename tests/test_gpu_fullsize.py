@@ -1,11 +1,17 @@
-"""BASELINE.json's full-size configurations on the GPU, checked through size-independent
-properties (the oracle would need hours at these sizes): per-frame normalisation, exact zeros
-beyond the sequence length, invariance of the posteriors / shift of log Z under a per-frame
-emission offset, agreement of the two independent kernels, Viterbi path consistency."""
+"""BASELINE.json's full-size configurations on the GPU.  The whole batch is checked through
+size-independent properties (per-frame normalisation, exact zeros beyond the sequence length,
+invariance of the posteriors / shift of log Z under a per-frame emission offset, agreement of the
+independent kernels, Viterbi path consistency); a few utterances of every configuration -- the
+longest, the shortest and two others -- are compared with the CPU oracle at full size (one
+1500-frame utterance of the config-3 graph takes the C oracle ~3 s)."""
+import math
 import os
 
 import numpy as np
 import pytest
+
+import graphs
+from test_gpu_parity import check_gamma
 
 pytestmark = pytest.mark.gpu
 
@@ -18,7 +24,36 @@ def torch():
     return torch
 
 
-def test_config3_lfmmi_denominator_full_size(mm, wl, torch):
+def pick_utterances(lens):
+    """longest, shortest and two others"""
+    lens = np.asarray(lens)
+    return sorted({int(np.argmax(lens)), int(np.argmin(lens)), len(lens) // 3, (2 * len(lens)) // 3})
+
+
+def test_config1_l2r_hmm_T100(mm, wl, oracle, torch):
+    """3-state left-to-right HMM, T = 100, B = 1 (BASELINE configs[0]; the reference runs it on the Julia CPU
+    path, here it goes through the same HIP engine).  lhs = 0: every accepting path has weight 2^-100 and there
+    are C(99, 2) of them (test/test_algorithms.jl:13-26's FSM, examples/demo.ipynb cell 13 at N = 5)."""
+    o, oc = oracle
+    g = wl.l2r_hmm(3)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    N = 100
+    gam, ttl = mm.pdfposteriors(cf, [mm.expand(np.zeros((3, N), dtype=np.float32))])
+    assert np.isclose(ttl[0], math.log(math.comb(N - 1, 2)) - N * math.log(2.0), rtol=1e-6)
+    # closed form of the state posteriors: state 1 occupied at frame n (0-based) iff the first jump comes later
+    tot = math.comb(N - 1, 2)
+    p1 = np.array([math.comb(N - 1 - n, 2) / tot for n in range(N)])       # both jumps after frame n
+    p3 = np.array([math.comb(n, 2) / tot for n in range(N)])               # both jumps before or at frame n
+    assert np.allclose(gam[0][0], p1, atol=2e-6) and np.allclose(gam[0][2], p3, atol=2e-6)
+    rng = np.random.default_rng(100)
+    V = rng.standard_normal((1, N, g.P)).astype(np.float32)
+    g_ref, t_ref = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V, None, dtype=np.float64)
+    gam, ttl = mm.batch(cf).pdfposteriors(V)
+    check_gamma(gam, g_ref, [N])
+    assert np.allclose(ttl, t_ref, rtol=1e-6)
+
+
+def test_config3_lfmmi_denominator_full_size(mm, wl, oracle, torch):
     """S = 2000, T = 1500, B = 256 (BASELINE configs[2])."""
     g = wl.lfmmi_denominator(2000, 84, seed=0)
     B, N = 256, 1500
@@ -42,17 +77,25 @@ def test_config3_lfmmi_denominator_full_size(mm, wl, torch):
     assert torch.allclose(gam2, gam, atol=2e-5)
     assert torch.allclose(ttl2.double(), ttl.double() + shift, rtol=2e-6, atol=5e-3)
     # the general (item) kernel is an independent implementation of the same path
-    os.environ["MM_KERNEL"] = "item"
+    os.environ.update({"MM_DEBUG": "1", "MM_KERNEL": "item"})
     try:
         sub = slice(0, 32)
         g_item, t_item = mm.batch(*([cf] * 32)).pdfposteriors(V[sub].contiguous(), lens[sub].contiguous())
     finally:
         os.environ.pop("MM_KERNEL", None)
+        os.environ.pop("MM_DEBUG", None)
     assert torch.allclose(g_item, gam[sub], atol=2e-5)
     assert torch.allclose(t_item, ttl[sub], rtol=1e-5, atol=5e-3)
+    # the oracle at full size on four utterances (float64)
+    o, oc = oracle
+    sel = pick_utterances(lens.cpu().numpy())
+    Vs, Ls = V[sel].cpu().numpy(), lens[sel].cpu().numpy()
+    g_ref, t_ref = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, Vs, Ls, dtype=np.float64, nthreads=4)
+    check_gamma(gam[sel].cpu().numpy(), g_ref, Ls)
+    assert np.allclose(ttl[sel].cpu().numpy(), t_ref, rtol=1e-6)
 
 
-def test_config5_viterbi_full_size(mm, wl, torch):
+def test_config5_viterbi_full_size(mm, wl, oracle, torch):
     """5000-state lexicon FSM, T = 1000, B = 128, tropical (BASELINE configs[4])."""
     g = wl.lexicon_fsm(5000, 84, seed=0)
     B, N = 128, 1000
@@ -61,9 +104,18 @@ def test_config5_viterbi_full_size(mm, wl, torch):
     gen = torch.Generator(device="cuda").manual_seed(4)
     V = torch.randn(B, N, g.P, device="cuda", generator=gen)
     lens = torch.randint(N // 2, N + 1, (B,), device="cuda", generator=gen, dtype=torch.int32)
-    path, score = bt.viterbi(V, lens)
+    path, score, bp = bt.viterbi(V, lens, return_backpointers=True)
     path, score, Vh, L = path.cpu().numpy(), score.cpu().numpy(), V.cpu().numpy(), lens.cpu().numpy()
     assert np.isfinite(score).all()
+    # the oracle at full size on four utterances: paths, scores and back-pointers bit exact (float32, same adds)
+    o, oc = oracle
+    of = graphs.to_oracle(o, g, "tropical", np.float32)
+    S1 = g.S + 1
+    for b in pick_utterances(L):
+        pr, sr, bpr = oc.viterbi(of, g.state2pdf, g.P, Vh[b], int(L[b]), dtype=np.float32)
+        assert np.array_equal(path[b], pr) and score[b] == sr
+        assert np.array_equal(bp[: L[b] + 1, b * S1:(b + 1) * S1].cpu().numpy(), bpr[: L[b] + 1])
+    del bp
     # dense lookup of the arc weights (float32, like the engine)
     W = np.full((g.S, g.S), -np.inf, dtype=np.float32)
     W[g.src, g.dst] = g.w.astype(np.float32)

@@ -194,6 +194,37 @@ def test_quad_form_products(mm, wl, gname, kqs):
             assert stats[3] <= stats[2] * 1.15 + 0.05
 
 
+@pytest.mark.parametrize("gname", ["l2r", "rand", "ergodic", "lfmmi", "lfmmi600", "lexicon", "wide", "num_wsj"])
+def test_row_form_products(mm, wl, gname):
+    """The row-lane form of the row kernels (rows sorted by size and dealt to the compute waves as segments of
+    equally long rows, arcs in per-lane register slots with bank-aware placement, lane-group sums for long rows,
+    internal numbering = finishing order) preserves both products: host evaluation through it == evaluation
+    through the item form.  The schedule must be balanced and the placement no worse than CSR order."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = {"l2r": lambda: wl.l2r_hmm(3), "rand": lambda: wl.random_fsm(40, 6, 3.0, seed=1),
+         "ergodic": lambda: wl.dense_ergodic(64), "lfmmi": lambda: wl.lfmmi_denominator(2000, 84),
+         "lfmmi600": lambda: wl.lfmmi_denominator(600, 40, seed=5),
+         "lexicon": lambda: wl.lexicon_fsm(1500, 30), "wide": lambda: wl.wide_row_fsm(),
+         "num_wsj": lambda: wl.load_npz_graph(os.path.join(here, "golden", "num_fsm_wsj.npz"))}[gname]()
+    f = wl.to_fsm(mm, g)
+    cf = mm.compile(f, mm.statemap(g.state2pdf, g.P))
+    rng = np.random.default_rng(3)
+    x = (3 * rng.standard_normal(f.S1)).astype(np.float32)
+    x[rng.random(f.S1) < 0.1] = -np.inf
+    for d in (0, 1):
+        ref, _ = cf.packed_product(x, d)
+        out, stats = cf.row_product(x, d)
+        assert np.array_equal(np.isfinite(out), np.isfinite(ref)), (gname, d)
+        m = np.isfinite(ref)
+        assert np.allclose(out[m], ref[m], rtol=1e-5, atol=2e-5), (gname, d)
+        ka, nwc, nseg, eff, cmax, cmin = stats[:6]
+        assert ka % 2 == 0 and 2 <= ka <= 48 and 1 <= nwc <= 15 and nseg >= nwc
+        assert eff <= 1.0 and (g.n_arcs < 5000 or eff > 0.75), (gname, d, eff)   # padding of the equal-length segments
+        # the waves reach the barrier together (small graphs have fewer segments than waves: nothing to balance)
+        assert g.n_arcs < 20000 or cmax <= 1.25 * cmin + 4, (gname, d, cmax, cmin)
+        assert stats[7] <= stats[6] * 1.15 + 0.05                                 # bank-aware placement
+
+
 def test_reach_distance_bounds_the_support_of_alpha_and_beta(mm, wl, oracle):
     """mm_debug_reach_distance: BFS distances on the pruned graph, checked against the oracle's recursions:
     alpha_n[s] is zero(K) for n - 1 < d_f[s], beta_n[s] for (N + 1) - n < d_b[s], and both bounds are tight

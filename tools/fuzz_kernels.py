@@ -36,6 +36,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 res = {}
 for kern in ("quad", "item"):
     env = dict(os.environ)
+    env["MM_DEBUG"] = "1"
     env["MM_KERNEL"] = kern  # ("quad" switches the depth heuristic off)
     f = f"/tmp/fuzz_{kern}.npz"
     subprocess.check_call([sys.executable, __file__, "child", f], env=env)

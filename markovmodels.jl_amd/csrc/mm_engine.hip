@@ -638,6 +638,9 @@ static int row_variants(mm_fsm_t f, bool verbose, bool *ok) {
             for (int64_t i = 0; i < f->S1; ++i) v->init[i] = f->init[v->g.order[i]];
         }
         Blob bl;
+        // (zero rows up to MM_ROW_KA_PAD arc slots: the kernels load their whole register window unconditionally)
+        v->g.w.resize(size_t(MM_ROW_KA_PAD) * 64 * v->g.NWC, 0.f);
+        v->g.addr.resize(size_t(MM_ROW_KA_PAD) * 64 * v->g.NWC, 0u);
         const size_t o_w = bl.add(v->g.w), o_a = bl.add(v->g.addr), o_s = bl.add(v->g.slots), o_sc = bl.add(v->g.sched);
         const size_t o_ptr = bl.add(v->g.rowptr), o_col = bl.add(v->g.col), o_cw = bl.add(v->g.cw);
         const size_t o_pdf = bl.add(v->g.rowpdf), o_pse = bl.add(v->g.pdfse), o_init = bl.add(v->init);

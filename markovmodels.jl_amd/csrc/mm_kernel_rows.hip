@@ -18,9 +18,11 @@
 //     ahead) from HBM into LDS, normalises and stores the posteriors, and keeps the normaliser sums.  The
 //     compute waves issue only fire-and-forget stores (forward: the alpha store, straight from registers,
 //     coalesced in the forward numbering) and no global loads at all in steady state;
-//   * the per-frame emission maximum E_n is part of the frame normaliser (a~_n = a_n - C_n with
-//     C_n = sum_{k<=n} E_k + sum_{k<n} M_k), so log-likelihoods far from 0 (GMM scores around -300 nats) stay
-//     on the linear path.
+//   * the per-frame emission maximum E_n is part of the frame normaliser, so log-likelihoods far from 0 (GMM
+//     scores around -300 nats) stay on the linear path; the other part S_n is chosen by the service wave TWO steps
+//     ahead, from the maximum over the states of frame n-2, which it finds by scanning the log2 vector while the
+//     compute waves work on frame n-1 (struct RowNorm; a~_n = a_n - C_n, C_n = sum_{k<=n} (E_k + S_k)).  No wave
+//     reduction and no dependent LDS round trip sits between the barrier and the first gathers of a frame.
 #pragma once
 #include "mm_kernel_quad.hip"
 #include "mm_rows.h"
@@ -36,6 +38,7 @@ __device__ __forceinline__ void ldsw(unsigned addr, float v) { *(lds_fptr)(__UIN
 __device__ __forceinline__ void ldswu(unsigned addr, unsigned v) { *(lds_uptr)(__UINTPTR_TYPE__)addr = v; }
 
 #define MM_ROW_EMS 1024  // bytes per emission buffer: P1p + 4 <= 256 floats
+#define MM_ROW_KA_PAD 48 // arc-slot rows of the device arrays (>= every instantiated register window)
 
 // LDS byte layout (absolute addresses; the kernels have no static LDS, the dynamic segment starts at 0).
 // Everything a finish touches sits at a compile-time offset from the row's 4 * position.
@@ -47,7 +50,7 @@ struct RowLay {
     static constexpr unsigned AL(int par) { return unsigned(8 * RS + 256 + par * RS); }  // backward only
     static constexpr unsigned EMB = unsigned((PASS ? 10 : 6) * RS + 256);
     static constexpr unsigned EM(int par) { return EMB + unsigned(par * MM_ROW_EMS); }
-    static constexpr unsigned PART(int par) { return EMB + 2 * MM_ROW_EMS + unsigned(par * 64); }
+    static constexpr unsigned MS(int par) { return EMB + 2 * MM_ROW_EMS + unsigned(par * 64); }  // normaliser of a frame
     static constexpr unsigned PSUM(int par) { return EMB + 2 * MM_ROW_EMS + 128 + unsigned(par * MM_ROW_EMS); }
     static constexpr unsigned PDFSE = EMB + 4 * MM_ROW_EMS + 128;          // u16 [2 * P1] <= 1024 bytes
     static constexpr unsigned SLOTS = PDFSE + (PASS ? 1024u : 0u);
@@ -108,6 +111,46 @@ __device__ __forceinline__ float grp_sum_last(float v, int lg) {
     if (lg >= 6) v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3
     return v;
 }
+
+// Service wave: maximum of the log2 vector at LDS byte address abase (n4 float4s), 0 if nothing is alive
+__device__ __forceinline__ float row_scan_max(unsigned abase, int n4, int lane) {
+    float m = MM_NINF;
+    for (int q = lane; q < n4; q += 64) {
+        const mm_f32x4 v = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(abase + 16u * q);
+        m = max_nc(max_nc(m, max_nc(v.x, v.y)), max_nc(v.z, v.w));
+    }
+    return wave_max_rl(m);
+}
+
+// Service wave: the frame normaliser.  Frame k subtracts S_k, chosen two steps ahead (the maximum m_{k-2} of frame k-2
+// is the newest one known when S_k is posted).  With m_k = m_{k-1} + c_k - S_k (c_k: the frame's own growth),
+// subtracting the stale maximum itself (S_k = m_{k-2}) gives m_k = m_{k-1} - m_{k-2} + c_k: an undamped oscillator
+// driven by the noise of c, whose amplitude random-walks out of the float range over a long utterance.  Instead the
+// missing step is predicted with a running mean cbar of the observed growths:
+//     S_{k} = m_{k-2} - S_{k-1} + 2 cbar   =>   m_k = (c_{k-1} - cbar) + (c_k - cbar):  bounded, nothing accumulates.
+// Whatever float is posted is exactly what the compute waves subtract and what the bookkeeping adds up.
+struct RowNorm {
+    float m_prev = 0.f, s_cur = 0.f, s_prev = 0.f, cbar = 0.f;
+    int seen = 0;
+    // m: maximum of the newest complete frame; returns the normaliser of the frame after next
+    __device__ __forceinline__ float next(float m) {
+        if (!(m > MM_NINF)) {  // nothing alive: the utterance has no path; keep the state
+            s_prev = s_cur;
+            s_cur = 0.f;
+            return 0.f;
+        }
+        if (seen >= 1) {
+            const float c = m - m_prev + s_prev;
+            cbar = seen == 1 ? c : cbar + 0.25f * (c - cbar);
+        }
+        const float s_next = m - s_cur + 2.f * cbar;
+        m_prev = m;
+        s_prev = s_cur;
+        s_cur = s_next;
+        ++seen;
+        return s_next;
+    }
+};
 
 // The arcs of a compute wave, two at a time, statically unrolled (the graph registers need static indices);
 // a segment may end after any pair (wave-uniform bit test).  The gathers run D pairs ahead of the FMAs.
@@ -214,7 +257,7 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
     for (unsigned q = tid * 4u; q < 2u * RS; q += NT * 4u) ldsw(L::A(0) + q, MM_NINF);
     if constexpr (PASS == 1)
         for (unsigned q = tid * 4u; q < 2u * RS; q += NT * 4u) ldsw(L::Q(0) + q, 0.f);
-    if (tid < 32) ldsw(L::PART(0) + 4u * tid, MM_NINF);
+    if (tid < 32) ldsw(L::MS(0) + 4u * tid, 0.f);
     if (tid < 2) ldsw(L::EM(tid) + 4u * P1p, MM_NINF);  // the emission slot of lanes without a row
     const int nslotwords = r.nslotrows * 64 * (PASS ? 2 : 1);
     for (int q = tid; q < nslotwords; q += NT) ldswu(L::SLOTS + 4u * q, as_global(r.slots)[q]);
@@ -237,24 +280,26 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
     // never live together with the staging registers of the service wave
     RowRegs<KA> rg;
     auto load_graph = [&]() {
-        // straight-line: every load from a clamped, always valid index (no branches, all loads in flight together)
-        const int ka = r.KA, nt = 64 * r.NWC;
+        // straight-line, no per-slot conditions: the device arrays are padded with zero rows up to MM_ROW_KA_PAD arc
+        // slots (mm_engine.hip), so every wave loads KA rows whatever the graph's own KA is
+        static_assert(KA <= MM_ROW_KA_PAD, "register window larger than the padding of the device arrays");
+        const int nt = 64 * r.NWC;
         const bool mine = wave < r.NWC;
         const auto wp = as_global(r.w);
         const auto ap = as_global(r.addr);
         const int t0 = mine ? tid : 0;
 #pragma unroll
         for (int k = 0; k < KA; ++k) {
-            const int idx = (k < ka ? k * nt : 0) + t0;
-            rg.w[k] = wp[idx];
-            rg.a[k] = ap[idx];
+            rg.w[k] = wp[k * nt + t0];
+            rg.a[k] = ap[k * nt + t0];
         }
+        if (!mine) {
 #pragma unroll
-        for (int k = 0; k < KA; ++k)
-            if (!mine || k >= ka) {
+            for (int k = 0; k < KA; ++k) {
                 rg.w[k] = 0.f;
                 rg.a[k] = 0u;
             }
+        }
     };
     unsigned em_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)endmask);
     unsigned em_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(endmask >> 32));
@@ -270,7 +315,6 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
         // =================== forward: alpha-recursion (src/inference.jl:62-74) ===================
         // frame 1: alpha_hat (*) lhs[:,1]   (src/inference.jl:68), by all threads once its emissions are staged
         auto frame1 = [&]() {
-            float wm = MM_NINF;
             for (int i = tid; i < S1; i += NT) {
                 const float v = as_global(r.init)[i] + ldsr(L::EM(1) + 4u * as_global(r.rowpdf)[i]);
                 if (row_out_of_range(v, thr)) *redo = 1;
@@ -279,9 +323,7 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                 ldsw(L::P(1, 0) + 4u * i, pv);
                 ldsw(L::P(1, 1) + 4u * i, pv);
                 wsA[(long long)1 * S1p + i] = v;
-                wm = max_nc(wm, v);
             }
-            part_put(reinterpret_cast<float *>(lds) + L::PART(1) / 4, wave, lane, wm);
         };
         if (service) {
             float raw[4];
@@ -296,12 +338,19 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                 row_load_em(raw, Vb, p.vsn, 3, p.N, P, lane);
             }
             __syncthreads();
+            RowNorm norm;
             auto step = [&](auto RDc, int n) {
                 constexpr int RD = decltype(RDc)::value;
-                const float M = part_max_dpp(reinterpret_cast<float *>(lds) + L::PART(RD) / 4, NW, lane);
-                C += (double)M;
-                if (lane == 0) wsM[n - 1] = M;  // M_{n-1}
-                if (n + 1 <= NF) C += (double)row_stage_em(L::EM(RD), raw, n + 1, len, P, lane);
+                // frame n+1: its emissions, and its normaliser from the maximum of frame n-1 (complete since the last barrier)
+                if (n + 1 <= NF) {
+                    const float M = norm.next(row_scan_max(L::A(RD), (S1 + 3) >> 2, lane));
+                    C += (double)M;
+                    if (lane == 0) {
+                        ldsw(L::MS(RD), M);
+                        wsM[n + 1] = M;  // what frame n+1 subtracts (frames 1 and 2: nothing)
+                    }
+                    C += (double)row_stage_em(L::EM(RD), raw, n + 1, len, P, lane);
+                }
                 row_load_em(raw, Vb, p.vsn, n + 2, p.N, P, lane);
                 __syncthreads();
             };
@@ -322,20 +371,21 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
             auto step = [&](auto RDc, int n) {
                 constexpr int RD = decltype(RDc)::value, WR = 1 - RD;
                 if (nslots > 0) {
-                    const float M = part_max_dpp(reinterpret_cast<float *>(lds) + L::PART(RD) / 4, NW, lane);
-                    // (the alpha store has rows 0..N; frame len+1 is not needed by the backward pass: it goes to the unused row 0)
-                    float *wsAn = wsA + (long long)(n <= len ? n : 0) * S1p;
-                    float acc = 0.f, wm = MM_NINF;
-                    unsigned long long lgw = lgw0;
-                    unsigned sa = slot_base;
-                    unsigned info = ldsru(sa);
-                    float e = ldsr((info >> 16) + L::EM(WR));
+                    // the first gathers leave before anything else
                     float x[2 * D];
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
                         x[2 * j] = (2 * j < KA) ? ldsr(rg.a[(2 * j < KA) ? 2 * j : 0] + L::P(RD, 0)) : 0.f;
                         x[2 * j + 1] = (2 * j + 1 < KA) ? ldsr(rg.a[(2 * j + 1 < KA) ? 2 * j + 1 : 0] + L::P(RD, 0)) : 0.f;
                     }
+                    unsigned sa = slot_base;
+                    unsigned info = ldsru(sa);
+                    const float M = ldsr(L::MS(WR));  // M_{n-2}, posted by the service wave during the previous step
+                    float e = ldsr((info >> 16) + L::EM(WR));
+                    // (the alpha store has rows 0..N; frame len+1 is not needed by the backward pass: it goes to the unused row 0)
+                    float *wsAn = wsA + (long long)(n <= len ? n : 0) * S1p;
+                    float acc = 0.f;
+                    unsigned long long lgw = lgw0;
                     int left = nslots;
                     auto finish = [&]() {
                         const int lg = (int)(lgw & 15ull);
@@ -350,7 +400,6 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                         ldsw(pos4 + L::P(WR, 0), pv);
                         ldsw(pos4 + L::P(WR, 1), pv);
                         *reinterpret_cast<float *>(reinterpret_cast<char *>(wsAn) + pos4) = v;
-                        wm = max_nc(wm, v);
                         acc = 0.f;
                         sa += 256u;
                         info = ldsru(sa);
@@ -360,7 +409,6 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                     // register pair for the whole loop)
                     asm volatile("" : "+s"(em_lo), "+s"(em_hi));
                     row_pairs<0, KA, D, L::P(RD, 0)>(rg.w, rg.a, x, acc, em_lo, em_hi, left, finish);
-                    part_put(reinterpret_cast<float *>(lds) + L::PART(WR) / 4, wave, lane, wm);
                 }
                 __syncthreads();
             };
@@ -420,6 +468,7 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                 load_arow(len - 1);
             }
             __syncthreads();
+            RowNorm norm;
             run([&](auto RDc, int n) {
                 constexpr int RD = decltype(RDc)::value, WR = 1 - RD;
                 // emissions and alpha row of frame n-1 (loaded during the previous step) go to LDS; frame n-2's are requested
@@ -429,6 +478,11 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                 }
                 row_load_em(raw, Vb, p.vsn, n - 2, p.N, P, lane);
                 load_arow(n - 2);
+                // the normaliser of frame n-1, from the maximum of y_{n+1} (complete since the last barrier)
+                if (n - 1 >= 1) {
+                    const float M = norm.next(row_scan_max(L::A(RD), (S1 + 3) >> 2, lane));
+                    if (lane == 0) ldsw(L::MS(RD), M);
+                }
                 // gamma of frame n+2: its per-pdf sums were completed in the previous step
                 if (n + 2 <= len) {
                     const float s = finish_frame(reinterpret_cast<float *>(lds) + L::PSUM(WR) / 4, P1, P, lane,
@@ -441,32 +495,35 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
             __syncthreads();
             // kappa_n = log2 Z - C_n - D_n = afin + G_n with G_n = sum_{k>=n} M_k(forward) - sum M(backward):
             // accumulated incrementally (double; its magnitude stays small)
+            // (frame m of the forward pass subtracted wsM[m] = M_{m-2}; frames 1 and 2 nothing)
             double G = 0.0;
-            float mfn = len >= 1 ? wsM[len] : 0.f;
+            float mfn = len + 1 >= 3 ? wsM[len + 1] : 0.f;
             load_graph();
             run([&](auto RDc, int n) {
                 constexpr int RD = decltype(RDc)::value, WR = 1 - RD;
-                const float mf = mfn;  // M_n (forward)
-                mfn = n - 1 >= 1 ? wsM[n - 1] : 0.f;  // M_{n-1} for the next step
-                const float M = (n == len) ? 0.f : part_max_dpp(reinterpret_cast<float *>(lds) + L::PART(RD) / 4, NW, lane);
+                float x[2 * D];
+                if (nslots > 0) {  // the first gathers leave before anything else
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        x[2 * j] = (2 * j < KA) ? ldsr(rg.a[(2 * j < KA) ? 2 * j : 0] + L::P(RD, 0)) : 0.f;
+                        x[2 * j + 1] = (2 * j + 1 < KA) ? ldsr(rg.a[(2 * j + 1 < KA) ? 2 * j + 1 : 0] + L::P(RD, 0)) : 0.f;
+                    }
+                }
+                const float mf = mfn;                  // what frame n+1 of the forward pass subtracted
+                mfn = n >= 3 ? wsM[n] : 0.f;           // ... frame n, for the next step
+                const float M = ldsr(L::MS(WR));       // the normaliser of this step (max of y_{n+2}; 0 for the first two)
                 G += (double)mf - (double)M;
                 const float kappa = afin + (float)G;
                 if (n < len)  // frame n+1, per pdf
                     pdf_sums(reinterpret_cast<float *>(lds) + L::Q(RD) / 4, reinterpret_cast<unsigned short *>(lds) + L::PDFSE / 2,
                              reinterpret_cast<float *>(lds) + L::PSUM(RD) / 4, P1, wave, NWC, lane);
                 if (nslots > 0) {
-                    float acc = 0.f, wm = MM_NINF;
+                    float acc = 0.f;
                     unsigned long long lgw = lgw0;
                     unsigned sa = slot_base;
                     unsigned info = ldsru(sa), info2 = ldsru(sa + 4u);
                     float e = ldsr((info >> 16) + L::EM(WR));
                     float al = ldsr((info2 & 0xffffu) + L::AL(WR));
-                    float x[2 * D];
-#pragma unroll
-                    for (int j = 0; j < D; ++j) {
-                        x[2 * j] = (2 * j < KA) ? ldsr(rg.a[(2 * j < KA) ? 2 * j : 0] + L::P(RD, 0)) : 0.f;
-                        x[2 * j + 1] = (2 * j + 1 < KA) ? ldsr(rg.a[(2 * j + 1 < KA) ? 2 * j + 1 : 0] + L::P(RD, 0)) : 0.f;
-                    }
                     int left = nslots;
                     auto finish = [&]() {
                         const int lg = (int)(lgw & 15ull);
@@ -482,7 +539,6 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                         ldsw(pos4 + L::A(WR), y);
                         ldsw(pos4 + L::P(WR, 0), py);
                         ldsw(pos4 + L::P(WR, 1), py);
-                        wm = max_nc(wm, y);
                         acc = 0.f;
                         sa += 512u;
                         info = ldsru(sa);
@@ -492,7 +548,6 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                     };
                     asm volatile("" : "+s"(em_lo), "+s"(em_hi));
                     row_pairs<0, KA, D, L::P(RD, 0)>(rg.w, rg.a, x, acc, em_lo, em_hi, left, finish);
-                    part_put(reinterpret_cast<float *>(lds) + L::PART(WR) / 4, wave, lane, wm);
                 }
                 __syncthreads();
             });

@@ -318,7 +318,7 @@ static int launch_tropical(mm_batch_t h, const RunParams &p, void *stream) {
 
 // The row kernels (mm_kernel_rows.hip): KA register-resident arcs per lane, NWC compute waves + 1 service wave.
 #define MM_ROW_RS 8192
-static const int kRowKA[] = {16, 32, 40, 44};  // instantiated register windows (48 arcs per lane spill)
+static const int kRowKA[] = {24, 40, 42, 44};  // instantiated register windows (48 arcs per lane spill)
 
 template <int KA, int PASS>
 static int launch_row_ka(mm_batch_t h, const RunParams &p, void *stream) {
@@ -333,9 +333,9 @@ static int launch_row_ka(mm_batch_t h, const RunParams &p, void *stream) {
 template <int PASS>
 static int launch_row_pass(mm_batch_t h, const RunParams &p, void *stream) {
     const int ka = h->row_ka[PASS];
-    if (ka <= 16) return launch_row_ka<16, PASS>(h, p, stream);
-    if (ka <= 32) return launch_row_ka<32, PASS>(h, p, stream);
+    if (ka <= 24) return launch_row_ka<24, PASS>(h, p, stream);
     if (ka <= 40) return launch_row_ka<40, PASS>(h, p, stream);
+    if (ka <= 42) return launch_row_ka<42, PASS>(h, p, stream);
     if (ka <= 44) return launch_row_ka<44, PASS>(h, p, stream);
     return MM_ERR_UNSUPPORTED;
 }
@@ -633,6 +633,15 @@ static int row_variants(mm_fsm_t f, bool verbose, bool *ok) {
                             "LDS cycles/gather (bank model) %.2f -> %.2f\n",
                     dir, v->g.KA, v->g.NWC, v->g.nslotrows - 1, v->g.pad_eff, v->g.mincost, v->g.maxcost, v->g.conflict_before,
                     v->g.conflict_after);
+        if (verbose)
+            for (int w = 0; w < v->g.NWC; ++w) {
+                const RowSched &sc = v->g.sched[w];
+                int last = 0;
+                for (int k = 0; k < 64; ++k)
+                    if ((sc.endmask >> k) & 1) last = k;
+                fprintf(stderr, "[mm]   wave %2d: %u segments, %d arcs, lg %llx\n", w, sc.nslots, 2 * (last + 1),
+                        (unsigned long long)sc.lg);
+            }
         if (dir == 0) {
             v->init.resize(f->S1);
             for (int64_t i = 0; i < f->S1; ++i) v->init[i] = f->init[v->g.order[i]];

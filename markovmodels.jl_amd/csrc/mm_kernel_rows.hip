@@ -45,10 +45,12 @@ __device__ __forceinline__ void ldswu(unsigned addr, unsigned v) { *(lds_uptr)(_
 template <int RS, int PASS>
 struct RowLay {
     static constexpr unsigned P(int par, int c) { return unsigned(par * (2 * RS + 128) + c * (RS + 64)); }
-    static constexpr unsigned A(int par) { return unsigned(4 * RS + 256 + par * RS); }
-    static constexpr unsigned Q(int par) { return unsigned(6 * RS + 256 + par * RS); }   // backward only
-    static constexpr unsigned AL(int par) { return unsigned(8 * RS + 256 + par * RS); }  // backward only
-    static constexpr unsigned EMB = unsigned((PASS ? 10 : 6) * RS + 256);
+    // targets of the service wave's LDS-DMA (kept below 64 KiB): raw emissions of 4 frames in flight (frame & 3),
+    // backward also the alpha rows of 3 frames (frame % 3)
+    static constexpr unsigned AL(int k) { return unsigned(4 * RS + 256 + k * RS); }  // backward only
+    static constexpr unsigned RAW(int k) { return unsigned((PASS ? 7 : 4) * RS + 256 + k * 1024); }
+    static constexpr unsigned Q(int par) { return RAW(4) + unsigned(par * RS); }     // backward only
+    static constexpr unsigned EMB = PASS ? Q(2) : RAW(4);
     static constexpr unsigned EM(int par) { return EMB + unsigned(par * MM_ROW_EMS); }
     static constexpr unsigned MS(int par) { return EMB + 2 * MM_ROW_EMS + unsigned(par * 64); }  // normaliser of a frame
     static constexpr unsigned PSUM(int par) { return EMB + 2 * MM_ROW_EMS + 128 + unsigned(par * MM_ROW_EMS); }
@@ -57,7 +59,7 @@ struct RowLay {
 };
 inline size_t row_lds_bytes(int RS, int pass, int nslotrows) {
     const size_t slots = size_t(nslotrows) * 64 * 4 * (pass ? 2 : 1);
-    const size_t emb = size_t(pass ? 10 : 6) * RS + 256;
+    const size_t emb = size_t(pass ? 9 : 4) * RS + 256 + 4096;
     return emb + 4 * MM_ROW_EMS + 128 + (pass ? 1024 : 0) + slots;
 }
 
@@ -80,9 +82,34 @@ __device__ __forceinline__ float row_stage_em(unsigned dst, const float (&raw)[4
     }
     return E;
 }
-__device__ __forceinline__ void row_load_em(float (&raw)[4], const float *Vb, long long vsn, int n, int N, int P, int lane) {
+// LDS-DMA (cdna_hip_programming.md 5.7): one wave instruction moves 4 or 16 bytes per lane from per-lane global
+// addresses straight into the LDS block [dst + 64 * lane-size): no destination register, so nothing the compiler
+// would make the wave wait for; completion is counted by vmcnt, which the service wave waits on by hand.
+__device__ __forceinline__ void dma_b32(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma_b128(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+#define MM_ROW_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// raw emissions of frame n (clamped to a valid frame and pdf: expand() decides later what they mean): always 4 DMAs
+// of 256 bytes, so that the number of outstanding operations per step is a constant
+__device__ __forceinline__ void row_dma_em(unsigned dst, const float *Vb, long long vsn, int n, int N, int P, int lane) {
+    const int nn = n < 1 ? 1 : (n > N ? N : n);
+    const float *row = Vb + (long long)(nn - 1) * vsn;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) raw[j] = (lane + 64 * j <= P || j == 0) ? em_load_raw(Vb, vsn, n, N, P, lane + 64 * j) : 0.f;
+    for (int j = 0; j < 4; ++j) {
+        const int q = lane + 64 * j;
+        dma_b32(row + (q < P ? q : P - 1), dst + 256u * j);
+    }
+}
+__device__ __forceinline__ void row_read_em(float (&raw)[4], unsigned src, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) raw[j] = ldsr(src + 256u * j + 4u * lane);
 }
 
 // Range of the linear path.  A state whose normalised log2 value v is finite but below -thr is alive with a linear
@@ -112,14 +139,15 @@ __device__ __forceinline__ float grp_sum_last(float v, int lg) {
     return v;
 }
 
-// Service wave: maximum of the log2 vector at LDS byte address abase (n4 float4s), 0 if nothing is alive
-__device__ __forceinline__ float row_scan_max(unsigned abase, int n4, int lane) {
-    float m = MM_NINF;
+// Service wave: log2 of the maximum of the linear vector at LDS byte address pbase (n4 float4s); -inf if nothing is
+// alive.  (The log2 vector itself is not kept in LDS: one store per finish less.)
+__device__ __forceinline__ float row_scan_max(unsigned pbase, int n4, int lane) {
+    float m = 0.f;
     for (int q = lane; q < n4; q += 64) {
-        const mm_f32x4 v = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(abase + 16u * q);
+        const mm_f32x4 v = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(pbase + 16u * q);
         m = max_nc(max_nc(m, max_nc(v.x, v.y)), max_nc(v.z, v.w));
     }
-    return wave_max_rl(m);
+    return fast_log2(wave_max_rl(m));
 }
 
 // Service wave: the frame normaliser.  Frame k subtracts S_k, chosen two steps ahead (the maximum m_{k-2} of frame k-2
@@ -151,6 +179,59 @@ struct RowNorm {
         return s_next;
     }
 };
+
+// C' * (A .* B) (src/inference.jl:154-155) for the row kernels: states of one pdf are contiguous in the pdf-major
+// order of Q; a wave sums 8 pdfs with 8 lanes each.  Split in two so that no dependent LDS round trip sits at the
+// top of a step: the loads are issued right behind the first gathers of the frame (up to 4 per lane, independent;
+// the pdf's range is loop invariant), the additions and the 3-step DPP reduction follow the last segment.
+struct PdfLane {
+    unsigned first4, end4;  // byte offsets of this lane's pdf range in Q (first4 includes the lane's own start)
+    int pdf;                // -1: none
+    bool lead;              // the lane of its group of 8 that stores the sum
+};
+__device__ __forceinline__ PdfLane pdf_lane(unsigned pdfse_base, int P1, int wave, int lane) {
+    PdfLane pl;
+    pl.pdf = wave * 8 + (lane >> 3);
+    pl.lead = (lane & 7) == 0;
+    pl.first4 = pl.end4 = 0u;
+    if (pl.pdf < P1) {
+        const unsigned se = ldsru(pdfse_base + 4u * pl.pdf);  // first | end << 16
+        pl.first4 = 4u * ((se & 0xffffu) + (lane & 7));
+        pl.end4 = 4u * (se >> 16);
+    } else {
+        pl.pdf = -1;
+    }
+    return pl;
+}
+__device__ __forceinline__ void pdf_load(float (&pq)[4], const PdfLane &pl, unsigned qbase) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned a = pl.first4 + 32u * k;
+        pq[k] = ldsr(qbase + (a < pl.end4 ? a : 0u));  // (clamped: an always valid address, masked below)
+    }
+}
+__device__ __forceinline__ void pdf_finish(const float (&pq)[4], const PdfLane &pl, unsigned qbase, unsigned psum_base) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += (pl.first4 + 32u * k < pl.end4) ? pq[k] : 0.f;
+    for (unsigned a = pl.first4 + 128u; a < pl.end4; a += 32u) s += ldsr(qbase + a);  // pdfs with more than 32 states
+    s = grp_sum(s, 3);
+    if (pl.pdf >= 0 && pl.lead) ldsw(psum_base + 4u * pl.pdf, s);
+}
+// pdfs beyond the first pass (more than 8 per compute wave): the plain dependent walk
+__device__ __forceinline__ void pdf_sums_rest(unsigned qbase, unsigned pdfse_base, unsigned psum_base, int P1, int wave, int NWC,
+                                              int lane) {
+    for (int p0 = 8 * NWC + wave * 8; p0 < P1; p0 += NWC * 8) {
+        const int pdf = p0 + (lane >> 3);
+        float s = 0.f;
+        if (pdf < P1) {
+            const unsigned se = ldsru(pdfse_base + 4u * pdf);
+            for (unsigned a = 4u * ((se & 0xffffu) + (lane & 7)); a < 4u * (se >> 16); a += 32u) s += ldsr(qbase + a);
+        }
+        s = grp_sum(s, 3);
+        if (pdf < P1 && (lane & 7) == 0) ldsw(psum_base + 4u * pdf, s);
+    }
+}
 
 // The arcs of a compute wave, two at a time, statically unrolled (the graph registers need static indices);
 // a segment may end after any pair (wave-uniform bit test).  The gathers run D pairs ahead of the FMAs.
@@ -221,7 +302,10 @@ template <int KA, int RS, int PASS>
 __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
     extern __shared__ float lds[];
     using L = RowLay<RS, PASS>;
-    constexpr int D = 3;  // gather pairs in flight ahead of the FMAs
+#ifndef MM_ROW_D
+#define MM_ROW_D 3
+#endif
+    constexpr int D = MM_ROW_D;  // gather pairs in flight ahead of the FMAs
     const int b = uni(p.order ? p.order[blockIdx.x] : (int)blockIdx.x);
     const UttDesc &u = p.utts[b];
     const RowU r = uni(u.r[PASS]);
@@ -238,6 +322,12 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
     float *wsM = reinterpret_cast<float *>(p.ws_c + (long long)b * (p.N + 2));
     double *hand = p.ws_c + (long long)b * (p.N + 2) + p.N;
     if (lds_addr_of(lds) != 0u) __builtin_trap();  // the layout uses absolute LDS addresses
+    MM_STAMP_DECL;
+    // Issue arbitration between the four waves of a SIMD goes by priority, then age.  The service wave is the youngest
+    // of its SIMD and would get the leftover slots only (measured with cycle stamps: its ~300 instructions took a whole
+    // frame); its work is short, so it goes first.  (Among the compute waves age stays: the segments are dealt out so
+    // that the older waves get more, mm_rows.h RowPackOpts::group_speed.)
+    if (service) __builtin_amdgcn_s_setprio(3);
 
     // ---- set-up common to both directions
     const int fpos = r.fpos;
@@ -254,7 +344,6 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
         }
     }
     for (unsigned q = tid * 4u; q < 4u * RS + 256u; q += NT * 4u) ldsw(q, 0.f);                  // p, both parities
-    for (unsigned q = tid * 4u; q < 2u * RS; q += NT * 4u) ldsw(L::A(0) + q, MM_NINF);
     if constexpr (PASS == 1)
         for (unsigned q = tid * 4u; q < 2u * RS; q += NT * 4u) ldsw(L::Q(0) + q, 0.f);
     if (tid < 32) ldsw(L::MS(0) + 4u * tid, 0.f);
@@ -318,7 +407,6 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
             for (int i = tid; i < S1; i += NT) {
                 const float v = as_global(r.init)[i] + ldsr(L::EM(1) + 4u * as_global(r.rowpdf)[i]);
                 if (row_out_of_range(v, thr)) *redo = 1;
-                ldsw(L::A(1) + 4u * i, v);
                 const float pv = fast_exp2(v);
                 ldsw(L::P(1, 0) + 4u * i, pv);
                 ldsw(L::P(1, 1) + 4u * i, pv);
@@ -326,24 +414,30 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
             }
         };
         if (service) {
+            // raw emissions of frame f arrive by LDS-DMA in RAW(f & 3), requested three frames before they are staged
             float raw[4];
             double C = 0.0;
-            row_load_em(raw, Vb, p.vsn, 1, p.N, P, lane);
+            for (int f = 1; f <= 4; ++f) row_dma_em(L::RAW(0) + 1024u * (f & 3), Vb, p.vsn, f, p.N, P, lane);
+            MM_ROW_VMCNT(0);
+            row_read_em(raw, L::RAW(1), lane);
             C += (double)row_stage_em(L::EM(1), raw, 1, len, P, lane);
-            row_load_em(raw, Vb, p.vsn, 2, p.N, P, lane);
+            row_dma_em(L::RAW(1), Vb, p.vsn, 5, p.N, P, lane);  // (step n requests frame n + 4)
             __syncthreads();
             frame1();
             if (NF >= 2) {
+                row_read_em(raw, L::RAW(2), lane);
                 C += (double)row_stage_em(L::EM(0), raw, 2, len, P, lane);
-                row_load_em(raw, Vb, p.vsn, 3, p.N, P, lane);
             }
             __syncthreads();
             RowNorm norm;
             auto step = [&](auto RDc, int n) {
-                constexpr int RD = decltype(RDc)::value;
-                // frame n+1: its emissions, and its normaliser from the maximum of frame n-1 (complete since the last barrier)
+                constexpr int RD = decltype(RDc)::value;  // = parity of frame n+1
+                // frame n+1: its emissions (requested at step n-2; the 4 DMAs of step n-1 may still be in flight), and its
+                // normaliser from the maximum of frame n-1 (complete since the last barrier)
+                MM_ROW_VMCNT(4);
                 if (n + 1 <= NF) {
-                    const float M = norm.next(row_scan_max(L::A(RD), (S1 + 3) >> 2, lane));
+                    row_read_em(raw, L::RAW(0) + 1024u * ((n + 1) & 3), lane);
+                    const float M = norm.next(row_scan_max(L::P(RD, 0), (S1 + 3) >> 2, lane));
                     C += (double)M;
                     if (lane == 0) {
                         ldsw(L::MS(RD), M);
@@ -351,15 +445,18 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                     }
                     C += (double)row_stage_em(L::EM(RD), raw, n + 1, len, P, lane);
                 }
-                row_load_em(raw, Vb, p.vsn, n + 2, p.N, P, lane);
+                row_dma_em(L::RAW(0) + 1024u * ((n + 4) & 3), Vb, p.vsn, n + 4, p.N, P, lane);  // (its buffer was read at step n-1)
+                MM_STAMP(0);
                 __syncthreads();
+                MM_STAMP(1);
             };
+            MM_STAMP_RESET;
             for (int n = 2; n <= NF; n += 2) {
                 step(std::integral_constant<int, 1>{}, n);
                 if (n + 1 <= NF) step(std::integral_constant<int, 0>{}, n + 1);
             }
             if (lane == 0) {
-                const float afin = ldsr(L::A(NF & 1) + 4u * fpos);  // normalised log2 value of the final state, last frame
+                const float afin = fast_log2(ldsr(L::P(NF & 1, 0) + 4u * fpos));  // normalised log2 value of the final state, last frame
                 hand[0] = (double)afin;
                 hand[1] = (double)afin + C;
             }
@@ -396,7 +493,6 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                         const float v = fast_log2(s) + e - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
                         if (__builtin_expect(row_out_of_range(v, thr), 0)) *redo = 1;
                         const float pv = fast_exp2(v);
-                        ldsw(pos4 + L::A(WR), v);
                         ldsw(pos4 + L::P(WR, 0), pv);
                         ldsw(pos4 + L::P(WR, 1), pv);
                         *reinterpret_cast<float *>(reinterpret_cast<char *>(wsAn) + pos4) = v;
@@ -410,8 +506,11 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                     asm volatile("" : "+s"(em_lo), "+s"(em_hi));
                     row_pairs<0, KA, D, L::P(RD, 0)>(rg.w, rg.a, x, acc, em_lo, em_hi, left, finish);
                 }
+                MM_STAMP(0);
                 __syncthreads();
+                MM_STAMP(1);
             };
+            MM_STAMP_RESET;
             for (int n = 2; n <= NF; n += 2) {
                 step(std::integral_constant<int, 1>{}, n);
                 if (n + 1 <= NF) step(std::integral_constant<int, 0>{}, n + 1);
@@ -423,7 +522,6 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
         const long long gbase = (long long)b * p.gsb;
         float tmin = 0.f;
         if (tid == 0) {  // frame len+1: B (*) lhs = one for the final state only
-            ldsw(L::A(NF & 1) + 4u * fpos, 0.f);
             ldsw(L::P(NF & 1, 0) + 4u * fpos, 1.f);
             ldsw(L::P(NF & 1, 1) + 4u * fpos, 1.f);
         }
@@ -440,48 +538,56 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
             }
         };
         if (service) {
+            // raw emissions (RAW(f & 3)) and alpha rows (AL(f % 3)) arrive by LDS-DMA, requested three and two steps
+            // before the step that uses them
             float raw[4];
-            constexpr int NA = (RS / 4 + 255) / 256;
-            mm_f32x4 arow[NA];  // one alpha row in flight (RS / 4 floats at most)
             const int n4 = S1p >> 2;
-            auto load_arow = [&](int n) {
-                const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(wsA + (long long)(n < 1 ? 1 : n) * S1p);
+            constexpr int NA = (RS / 4 + 255) / 256;
+            auto dma_arow = [&](int f) {
+                const int ff = f < 1 ? 1 : f;
+                const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(wsA + (long long)ff * S1p);
+                const unsigned dst = L::AL(0) + (unsigned)(ff % 3) * RS;
 #pragma unroll
                 for (int j = 0; j < NA; ++j) {
                     const int q = lane + 64 * j;
-                    arow[j] = as_global(src)[q < n4 ? q : 0];
-                }
-            };
-            auto store_arow = [&](unsigned dst) {
-#pragma unroll
-                for (int j = 0; j < NA; ++j) {
-                    const int q = lane + 64 * j;
-                    if (q < n4) *(__attribute__((address_space(3))) mm_f32x4 *)(__UINTPTR_TYPE__)(dst + 16u * q) = arow[j];
+                    dma_b128(src + (q < n4 ? q : 0), dst + 1024u * j);  // (always NA DMAs: a constant number in flight)
                 }
             };
             if (len >= 1) {
-                row_load_em(raw, Vb, p.vsn, len, p.N, P, lane);
+                for (int f = len; f >= len - 2; --f) row_dma_em(L::RAW(0) + 1024u * (f & 3), Vb, p.vsn, f, p.N, P, lane);
+                dma_arow(len);
+                dma_arow(len - 1);
+                MM_ROW_VMCNT(0);
+                row_read_em(raw, L::RAW(0) + 1024u * (len & 3), lane);
                 (void)row_stage_em(L::EM(len & 1), raw, len, len, P, lane);
-                row_load_em(raw, Vb, p.vsn, len - 1, p.N, P, lane);
-                load_arow(len);
-                store_arow(L::AL(len & 1));
-                load_arow(len - 1);
             }
+            // kappa_n = log2 Z - C_n - D_n (what a~ + b~ of frame n still lacks to a log2 posterior) = afin + G_n with
+            // G_n = sum_{k>n} S_k(forward) - sum_{k>=n} S_k(backward): accumulated in double (its magnitude stays small),
+            // posted to the compute waves together with the frame's normaliser.  Frame m of the forward pass subtracted
+            // wsM[m] (frames 1 and 2 nothing); the first two backward frames subtract nothing.
+            double G = len + 1 >= 3 ? (double)wsM[len + 1] : 0.0;  // G_len
+            if (lane == 0) ldsw(L::MS(len & 1) + 4u, afin + (float)G);
             __syncthreads();
             RowNorm norm;
+            MM_STAMP_RESET;
             run([&](auto RDc, int n) {
-                constexpr int RD = decltype(RDc)::value, WR = 1 - RD;
-                // emissions and alpha row of frame n-1 (loaded during the previous step) go to LDS; frame n-2's are requested
+                constexpr int RD = decltype(RDc)::value, WR = 1 - RD;  // RD = parity of frames n+1 and n-1
+                // emissions of frame n-1 (requested at step n+2; the 4 + NA DMAs of step n+1 may still be in flight)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NA) : "memory");
                 if (n - 1 >= 1) {
+                    row_read_em(raw, L::RAW(0) + 1024u * ((n - 1) & 3), lane);
                     (void)row_stage_em(L::EM(RD), raw, n - 1, len, P, lane);
-                    store_arow(L::AL(RD));
                 }
-                row_load_em(raw, Vb, p.vsn, n - 2, p.N, P, lane);
-                load_arow(n - 2);
+                row_dma_em(L::RAW(0) + 1024u * ((n - 3) & 3), Vb, p.vsn, n - 3, p.N, P, lane);
+                dma_arow(n - 2);
                 // the normaliser of frame n-1, from the maximum of y_{n+1} (complete since the last barrier)
                 if (n - 1 >= 1) {
-                    const float M = norm.next(row_scan_max(L::A(RD), (S1 + 3) >> 2, lane));
-                    if (lane == 0) ldsw(L::MS(RD), M);
+                    const float M = norm.next(row_scan_max(L::P(RD, 0), (S1 + 3) >> 2, lane));
+                    G += (double)(n >= 3 ? wsM[n] : 0.f) - (double)M;  // G_{n-1} = G_n + S_n(forward) - S_{n-1}(backward)
+                    if (lane == 0) {
+                        ldsw(L::MS(RD), M);
+                        ldsw(L::MS(RD) + 4u, afin + (float)G);
+                    }
                 }
                 // gamma of frame n+2: its per-pdf sums were completed in the previous step
                 if (n + 2 <= len) {
@@ -489,19 +595,20 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                                                  p.gamma + gbase + (long long)(n + 1) * p.gsn, p.gsp);
                     tmin = fminf(tmin, fast_log2(s));
                 }
+                // the alpha row of frame n-1 (requested at step n+1) must be in LDS when the compute waves leave the barrier
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NA) : "memory");
+                MM_STAMP(0);
                 __syncthreads();
+                MM_STAMP(1);
             });
         } else {
             __syncthreads();
-            // kappa_n = log2 Z - C_n - D_n = afin + G_n with G_n = sum_{k>=n} M_k(forward) - sum M(backward):
-            // accumulated incrementally (double; its magnitude stays small)
-            // (frame m of the forward pass subtracted wsM[m] = M_{m-2}; frames 1 and 2 nothing)
-            double G = 0.0;
-            float mfn = len + 1 >= 3 ? wsM[len + 1] : 0.f;
             load_graph();
+            const PdfLane pl = pdf_lane(L::PDFSE, P1, wave, lane);  // the pdf this lane sums (first pass: 8 pdfs per wave)
+            MM_STAMP_RESET;
             run([&](auto RDc, int n) {
                 constexpr int RD = decltype(RDc)::value, WR = 1 - RD;
-                float x[2 * D];
+                float x[2 * D], pq[4];
                 if (nslots > 0) {  // the first gathers leave before anything else
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
@@ -509,21 +616,17 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                         x[2 * j + 1] = (2 * j + 1 < KA) ? ldsr(rg.a[(2 * j + 1 < KA) ? 2 * j + 1 : 0] + L::P(RD, 0)) : 0.f;
                     }
                 }
-                const float mf = mfn;                  // what frame n+1 of the forward pass subtracted
-                mfn = n >= 3 ? wsM[n] : 0.f;           // ... frame n, for the next step
-                const float M = ldsr(L::MS(WR));       // the normaliser of this step (max of y_{n+2}; 0 for the first two)
-                G += (double)mf - (double)M;
-                const float kappa = afin + (float)G;
-                if (n < len)  // frame n+1, per pdf
-                    pdf_sums(reinterpret_cast<float *>(lds) + L::Q(RD) / 4, reinterpret_cast<unsigned short *>(lds) + L::PDFSE / 2,
-                             reinterpret_cast<float *>(lds) + L::PSUM(RD) / 4, P1, wave, NWC, lane);
+                const float M = ldsr(L::MS(WR));           // the normaliser of this step (chosen two steps ago; 0 for the first two)
+                const float kappa = ldsr(L::MS(WR) + 4u);  // ... and what a~ + b~ lacks to a log2 posterior, both from the service wave
+                const unsigned alb = L::AL(0) + (unsigned)(n % 3) * RS;  // where the service wave put the alpha row of frame n
+                pdf_load(pq, pl, L::Q(RD));  // frame n+1, per pdf (finished after the segments)
                 if (nslots > 0) {
                     float acc = 0.f;
                     unsigned long long lgw = lgw0;
                     unsigned sa = slot_base;
                     unsigned info = ldsru(sa), info2 = ldsru(sa + 4u);
                     float e = ldsr((info >> 16) + L::EM(WR));
-                    float al = ldsr((info2 & 0xffffu) + L::AL(WR));
+                    float al = ldsr((info2 & 0xffffu) + alb);
                     int left = nslots;
                     auto finish = [&]() {
                         const int lg = (int)(lgw & 15ull);
@@ -536,7 +639,6 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                         const float y = beta + e;
                         if (__builtin_expect(row_out_of_range(y, thr), 0)) *redo = 1;
                         const float py = fast_exp2(y);
-                        ldsw(pos4 + L::A(WR), y);
                         ldsw(pos4 + L::P(WR, 0), py);
                         ldsw(pos4 + L::P(WR, 1), py);
                         acc = 0.f;
@@ -544,12 +646,18 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                         info = ldsru(sa);
                         info2 = ldsru(sa + 4u);
                         e = ldsr((info >> 16) + L::EM(WR));
-                        al = ldsr((info2 & 0xffffu) + L::AL(WR));
+                        al = ldsr((info2 & 0xffffu) + alb);
                     };
                     asm volatile("" : "+s"(em_lo), "+s"(em_hi));
                     row_pairs<0, KA, D, L::P(RD, 0)>(rg.w, rg.a, x, acc, em_lo, em_hi, left, finish);
                 }
+                if (n < len) {
+                    pdf_finish(pq, pl, L::Q(RD), L::PSUM(RD));
+                    if (P1 > 8 * NWC) pdf_sums_rest(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane);
+                }
+                MM_STAMP(0);
                 __syncthreads();
+                MM_STAMP(1);
             });
         }
         // gamma of frames 2 and 1, zeros beyond len, ttl
@@ -572,6 +680,10 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
         if (service && lane == 0)  // ttl = log Z + min over frames of log(per-frame sum)   (src/inference.jl:159)
             p.ttl[b] = (float)((hand[1] + (double)tmin) * (double)MM_LN2);
     }
+#ifdef MM_STAMPS
+    if (p.dbg && lane == 0)
+        for (int k = 0; k < 8; ++k) p.dbg[((long long)b * MM_MAX_WAVES + wave) * 16 + 8 * PASS + k] = stamp_acc[k];
+#endif
 }
 
 }  // namespace mm

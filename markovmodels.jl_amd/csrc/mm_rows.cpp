@@ -117,11 +117,14 @@ Plan plan_for(int64_t nrows, const std::vector<int64_t> &rowptr, int acap, const
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost(p.segs[a]) > cost(p.segs[b]); });
     std::vector<int> load(nwc, 0), arcs(nwc, 0);
     p.wave_segs.assign(nwc, {});
+    auto level = [&](int w, int extra) { return float(load[w] + extra) / opt.group_speed[std::min(w >> 2, 3)]; };
     for (int i : idx) {
         int best = -1;
+        const int c = cost(p.segs[i]);
         for (int w = 0; w < nwc; ++w) {
             if (int(p.wave_segs[w].size()) >= MM_ROW_MAX_SLOTS) continue;
-            if (best < 0 || load[w] < load[best] || (load[w] == load[best] && arcs[w] < arcs[best])) best = w;
+            if (arcs[w] + p.segs[i].A > opt.ka_max) continue;
+            if (best < 0 || level(w, c) < level(best, c) || (level(w, c) == level(best, c) && arcs[w] < arcs[best])) best = w;
         }
         if (best < 0) return p;  // more than MM_ROW_MAX_SLOTS segments per wave
         p.segs[i].wave = best;
@@ -132,8 +135,12 @@ Plan plan_for(int64_t nrows, const std::vector<int64_t> &rowptr, int acap, const
     for (auto &ws : p.wave_segs)
         std::stable_sort(ws.begin(), ws.end(), [&](int a, int b) { return p.segs[a].A > p.segs[b].A; });
     p.KA = *std::max_element(arcs.begin(), arcs.end());
-    p.maxcost = *std::max_element(load.begin(), load.end());
-    p.mincost = *std::min_element(load.begin(), load.end());
+    p.maxcost = 0;
+    p.mincost = 1 << 30;
+    for (int w = 0; w < nwc; ++w) {  // (levelled cost: what the frame time follows)
+        p.maxcost = std::max(p.maxcost, int(level(w, 0) + 0.5f));
+        p.mincost = std::min(p.mincost, int(level(w, 0) + 0.5f));
+    }
     p.ok = p.KA <= opt.ka_max && p.KA <= 128;
     return p;
 }

@@ -75,6 +75,11 @@ struct RowPackOpts {
     int rs = 8192;        // LDS region stride in bytes
     int finish_cost = 8;  // cost of one finish in units of one arc (gather + FMA)
     int group_cost = 2;   // extra cost per butterfly level of a grouped (g > 1) segment
+    // Relative speed of waves 4k..4k+3 of the workgroup.  The four waves of a SIMD (one of each such group) are
+    // arbitrated oldest first, so with equal work the later waves of a workgroup reach the frame's barrier last
+    // and spend the tail of the frame alone, latency bound (measured with cycle stamps: +30 % for the last group).
+    // The segments are dealt so that load / speed is level.
+    float group_speed[4] = {1.0f, 0.92f, 0.80f, 0.70f};
 };
 
 // rowptr/col/val_log2: 0-based CSR of M (out[r] = (+)_k val[k] (*) in[col[k]]), square, nrows rows.

@@ -37,35 +37,47 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 
 
 
 def make_workload(wl, name):
+    """(graph, frames, utterances per GPU, semiring).  lfmmi_den = BASELINE.json configs[2] (the metric's
+    configuration); lexicon5000 = configs[4] (Viterbi); ergodic64 = configs[1]; wsj_den / wsj_num = the reference's
+    own benchmark graphs (misc/benchmark/README.md: T = 700, B = 128)."""
     if name == "lfmmi_den":
-        return wl.lfmmi_denominator(2000, 84, seed=0), 1500, 256
+        return wl.lfmmi_denominator(2000, 84, seed=0), 1500, 256, "log"
     if name == "ergodic64":
-        return wl.dense_ergodic(64, seed=0), 500, 32
+        return wl.dense_ergodic(64, seed=0), 500, 32, "log"
     if name == "wsj_den":
-        return wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "den_fsm_wsj.npz")), 700, 128
+        return wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "den_fsm_wsj.npz")), 700, 128, "log"
+    if name == "wsj_num":
+        return wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "num_fsm_wsj.npz")), 700, 128, "log"
+    if name == "lexicon5000":
+        return wl.lexicon_fsm(5000, 84, seed=0), 1000, 128, "tropical"
     raise SystemExit(f"unknown workload {name}")
 
 
 def measured_traffic(workload, B, N):
     """HBM bytes per launch from the TCC PMC counters (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction of
-    MI355X_MICROARCH.md), collected with tools/traffic.sh in separate --pmc passes and committed under
-    profiles/ (rocprofv3 cannot wrap a bench run from inside).  Only quoted for the configuration it was
-    measured on; otherwise null."""
+    MI355X_MICROARCH.md), collected by tools/measure.sh in separate --pmc passes and committed under
+    profiles/ (rocprofv3 cannot wrap a bench run from inside).  Only quoted when the profile was taken on
+    exactly the kernel sources that run now (tools/srchash.py) and on this configuration; otherwise null."""
     import glob
 
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{workload}.json"))):
-        best = json.load(open(f))
-        best["file"] = os.path.relpath(f, ROOT)
-    if best is None or (B, N) != (best.get("B", 256), best.get("N", 1500)):
-        return None, None
-    return best["hbm_bytes_per_launch"], best["file"]
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from srchash import source_hash
+
+    sha = source_hash()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{workload}.json")), reverse=True):
+        t = json.load(open(f))
+        if t.get("source_hash") == sha and (B, N) == (t.get("B"), t.get("N")):
+            return t["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return None, None
 
 
-def algorithmic_bytes(g, B, N, lens_sum):
-    """alpha written once and read once, emissions read twice,
-    posteriors written once, graph read once per pass (shared)."""
+def algorithmic_bytes(g, B, N, lens_sum, semiring="log"):
+    """SURVEY.md 8(d).  Forward-backward: alpha written once and read once, emissions read twice, posteriors
+    written once, graph read once per pass (shared).  Viterbi: emissions read once, int32 back-pointers written
+    once ((N+1)(4(P+1) + 4(S+1)) per utterance), the path written once (4N)."""
     S1, P1, A = g.S + 1, g.P + 1, g.n_arcs
+    if semiring == "tropical":
+        return B * ((N + 1) * (4 * P1 + 4 * S1) + 4 * N) + 4 * B + (8 * A + 4 * (g.S + 2))
     per_frame = 8 * S1 + 8 * P1
     return B * (N + 1) * per_frame + 4 * lens_sum * g.P + 4 * B + 2 * (8 * A + 4 * (g.S + 2))
 
@@ -91,11 +103,25 @@ def cpu_baseline(g, N, threads, budget_utts):
 
 
 def host_cores():
-    """Hardware threads this process may run on (not os.cpu_count(): the box may be cgroup/affinity limited)."""
+    """CPU cores this process can actually use: the affinity mask, capped by the cgroup's CPU quota (a container
+    can see 256 hardware threads and be allowed the time of 8: more threads than that only take turns)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def main():
@@ -128,10 +154,10 @@ def main():
 
     mm = ge.load_package()
     wl = importlib.import_module(mm.__name__ + ".workloads")
-    g, N, B = make_workload(wl, args.workload)
+    g, N, B, semiring = make_workload(wl, args.workload)
     N = args.frames or N
     B = args.batch or B
-    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    cf = mm.compile(wl.to_fsm(mm, g, semiring), mm.statemap(g.state2pdf, g.P))
     bf = mm.batch(*([cf] * B))
     gen = torch.Generator(device="cuda").manual_seed(1000 + rank)
     V = torch.randn(B, N, g.P, device="cuda", generator=gen)
@@ -140,10 +166,16 @@ def main():
     else:
         lens = torch.full((B,), N, device="cuda", dtype=torch.int32)
     frames_local = int(lens.sum().item())
-    gamma = torch.empty(B, N, g.P, device="cuda")
+    gamma = torch.empty(B, N, g.P, device="cuda") if semiring == "log" else None
+
+    def call():
+        """one pass of the hot path over the batch: pdfposteriors (log semiring) or bestpath (tropical)"""
+        if semiring == "log":
+            return bf.pdfposteriors(V, lens, out=gamma)[1]
+        return bf.viterbi(V, lens)[1]
 
     def step():
-        _, ttl = bf.pdfposteriors(V, lens, out=gamma)
+        ttl = call()
         return mm.dist.allreduce_logz(ttl) if use_dist else ttl
 
     for _ in range(args.warmup):
@@ -155,7 +187,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()
-        _, ttl = bf.pdfposteriors(V, lens, out=gamma)
+        ttl = call()
         ev[i][1].record()
         if use_dist:
             mm.dist.allreduce_logz(ttl)
@@ -175,11 +207,11 @@ def main():
     assert os.environ.get("MM_BENCH_NOCHECK") or torch.isfinite(ttl).all(), "non-finite log-likelihoods"
 
     if rank == 0:
-        abytes = algorithmic_bytes(g, B, N, frames_local)
+        abytes = algorithmic_bytes(g, B, N, frames_local, semiring)
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = (None, None) if args.varlen else measured_traffic(args.workload, B, N)
         out = {
-            "metric": "pdfposteriors_frames_per_sec",
+            "metric": "pdfposteriors_frames_per_sec" if semiring == "log" else "bestpath_frames_per_sec",
             "value": frames_total * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
@@ -193,7 +225,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{g.name}: S={g.S} states, {g.n_arcs} arcs, P={g.P} pdfs, T={N} frames, "
-                            f"B={B} utterances/GPU, log semiring, shared graph"
+                            f"B={B} utterances/GPU, {semiring} semiring, shared graph"
                             + (", lengths U[T/2,T]" if args.varlen else ""),
                 "global_batch": B * world,
                 "seq_len": N,
@@ -201,7 +233,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "mm_fbq_kernel<KQ,RPT,0> + mm_fbq_kernel<KQ,RPT,1> (forward + backward quad kernels of one call)",
+                "kernel": bf.kernels(semiring) + " (all launches of one call; HIP events around the call)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -214,7 +246,7 @@ def main():
         }
         # what actually bounds the kernels: one random 4-byte LDS read per arc and pass (32 lanes per clock
         # and CU without bank conflicts; MI355X_MICROARCH.md: 256 CUs, 128 B/clk/CU LDS, 2.4 GHz)
-        lds_bytes = 2 * 4 * g.n_arcs * frames_local
+        lds_bytes = (2 if semiring == "log" else 1) * 4 * g.n_arcs * frames_local
         out["lds_gather_roofline"] = {
             "bound": "lds",
             "achieved": lds_bytes / (kernel_ms * 1e-3) / 1e9,

@@ -17,7 +17,13 @@
  *     stream) and never synchronise the device.
  *   - the caller owns every in/out buffer; the library owns its handles and
  *     an internal workspace (the alpha store) that grows lazily and is freed
- *     with the batch.
+ *     with the batch.  ONE workspace per batch: run calls on the same batch
+ *     must be issued on one stream (or otherwise ordered); calls on different
+ *     batches are independent.  Growing the workspace frees the old one
+ *     (hipFree synchronises): size it once with mm_batch_reserve() before
+ *     capturing run calls in a hipGraph -- a run call that would have to grow
+ *     the workspace while its stream is capturing fails with MM_ERR_INVALID
+ *     instead of invalidating the pointers earlier captures baked in.
  *   - weights/likelihoods are natural-log values of the Log/Tropical
  *     semirings (zero(K) = -inf, one(K) = 0), bit-compatible with the
  *     reference's Array{K} storage.  The engine computes in float32.
@@ -89,6 +95,11 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out);
 int mm_batch_destroy(mm_batch_t batch);
 /* Sum over the batch of S1 (rows of the block-diagonal system). */
 int64_t mm_batch_total_states(mm_batch_t batch);
+/* Names of the kernels a run entry launches for this batch (the engine picks them from the graphs' sizes and
+ * shapes): entry 0 = mm_pdfposteriors_f32, 1 = mm_viterbi_f32.  Informational (bench.py quotes it). */
+int mm_batch_kernels(mm_batch_t batch, int entry, char *buf, size_t n);
+/* Allocate the internal workspace for runs of up to N frames now (synchronises if it has to grow). */
+int mm_batch_reserve(mm_batch_t batch, int64_t N);
 /* Bytes of internal workspace a run with N frames needs (informational). */
 size_t mm_batch_workspace_bytes(mm_batch_t batch, int64_t N);
 
@@ -122,6 +133,16 @@ int mm_alpharecursion_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, 
  * batches (the latter is what maxstateposteriors -- docs/src/inference.md:5 -- combines with the tropical alpha). */
 int mm_betarecursion_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t v_stride_n,
                          const int32_t *lens, int64_t N, float *out, int64_t out_stride_n, void *stream);
+
+/* maxstateposteriors (documented docs/src/inference.md:5, absent from src/ at this commit: src/MarkovModels.jl:56-57;
+ * historical use test/test_algorithms.jl:279-281): the max-marginals of the tropical semiring,
+ * mu = alpha (*) beta (/) best -- for every state and frame the weight of the best complete path through it relative
+ * to the best path overall (0 on a best path, -inf where no complete path passes, -inf everywhere if the utterance
+ * has no path).  MM_TROPICAL batches.  out: device, the layout of mm_alpharecursion_f32 (element (b, n, s) at
+ * out[n*out_stride_n + state_offset_b + s], n = 0..N).  Computed on the device: tropical alpha and beta recursions
+ * and the combination. */
+int mm_maxstateposteriors_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t v_stride_n,
+                              const int32_t *lens, int64_t N, float *out, int64_t out_stride_n, void *stream);
 
 /* bestpath (documented docs/src/inference.md:5-6, absent from src/ at this
  * commit: src/MarkovModels.jl:56-57; historical use examples/demo.ipynb cell 23).

@@ -159,18 +159,8 @@ end
 docs/src/inference.md:5 (absent from src/ at v0.10.0): the max-marginals alpha (*) beta (/) best of the tropical
 semiring, (sum of S+1) x (N+1), 0 along a best path.
 """
-function maxstateposteriors(b::ROCBatch{K}, V::ROCArray{Float32,3}, lens = nothing) where K <: TropicalSemiring
-    A = Array(MarkovModels.αrecursion(b, V, lens)); B = Array(MarkovModels.βrecursion(b, V, lens))
-    μ = A .+ B
-    off = 0
-    for f in b.fsms
-        S1 = nstates(f) + 1
-        best = A[off + S1, end]
-        μ[off+1:off+S1, :] .= isfinite(best) ? μ[off+1:off+S1, :] .- best : -Inf32
-        off += S1
-    end
-    μ
-end
+maxstateposteriors(b::ROCBatch{K}, V::ROCArray{Float32,3}, lens = nothing) where K <: TropicalSemiring =
+    _recursion(:mm_maxstateposteriors_f32, b, V, lens)   # one device call: tropical alpha, beta and the combination
 
 """
     totalsum(b::ROCBatch, n) / totalcumsum(b::ROCBatch, n) -> Vector{Float32}

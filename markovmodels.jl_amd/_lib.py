@@ -28,9 +28,12 @@ SYMBOLS = [
     "mm_batch_destroy",
     "mm_batch_total_states",
     "mm_batch_workspace_bytes",
+    "mm_batch_kernels",
+    "mm_batch_reserve",
     "mm_pdfposteriors_f32",
     "mm_alpharecursion_f32",
     "mm_betarecursion_f32",
+    "mm_maxstateposteriors_f32",
     "mm_viterbi_f32",
     "mm_totalsum_f32",
     "mm_debug_packed_product",
@@ -81,9 +84,13 @@ def _load():
     lib.mm_batch_total_states.argtypes = [vp]
     lib.mm_batch_workspace_bytes.restype = C.c_size_t
     lib.mm_batch_workspace_bytes.argtypes = [vp, i64]
+    lib.mm_batch_reserve.restype = C.c_int
+    lib.mm_batch_reserve.argtypes = [vp, i64]
+    lib.mm_batch_kernels.restype = C.c_int
+    lib.mm_batch_kernels.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
     lib.mm_pdfposteriors_f32.restype = C.c_int
     lib.mm_pdfposteriors_f32.argtypes = [vp, fp, i64, i64, vp, i64, fp, i64, i64, i64, fp, vp]
-    for name in ("mm_alpharecursion_f32", "mm_betarecursion_f32"):
+    for name in ("mm_alpharecursion_f32", "mm_betarecursion_f32", "mm_maxstateposteriors_f32"):
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = [vp, fp, i64, i64, vp, i64, fp, i64, vp]

@@ -968,6 +968,34 @@ int mm_batch_destroy(mm_batch_t h) {
 
 int64_t mm_batch_total_states(mm_batch_t h) { return h ? h->total_states : -1; }
 
+int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
+    if (!h || !buf || n < 2) return fail(MM_ERR_INVALID, "mm_batch_kernels: bad argument");
+    std::string s;
+    if (entry == 0) {  // mm_pdfposteriors_f32
+        const bool quad = quad_kernel_usable(h);
+        const std::string exact = quad ? "mm_fbq_kernel<" + std::to_string(h->geo_kq[0]) + ",*,0> + mm_fbq_kernel<" +
+                                             std::to_string(h->geo_kq[1]) + ",*,1>"
+                                       : std::string("mm_log_kernel<MODE_FB> (forward, backward)");
+        if (h->rows_ok) {
+            auto ka = [&](int d) {
+                for (int k : kRowKA)
+                    if (h->row_ka[d] <= k) return k;
+                return 0;
+            };
+            s = "mm_fbr_kernel<" + std::to_string(ka(0)) + ",8192,0> + mm_fbr_kernel<" + std::to_string(ka(1)) +
+                ",8192,1>, then for marked utterances only " + exact;
+        } else {
+            s = exact;
+        }
+    } else if (entry == 1) {  // mm_viterbi_f32
+        s = "mm_tropical_kernel + mm_backtrace_kernel";
+    } else {
+        return fail(MM_ERR_INVALID, "mm_batch_kernels: unknown entry");
+    }
+    snprintf(buf, n, "%s", s.c_str());
+    return MM_OK;
+}
+
 static size_t ws_alpha_bytes(mm_batch_t h, int64_t N) { return align_up(size_t(h->total_s1p) * size_t(N + 1) * 4, 256); }
 static size_t ws_c_bytes(mm_batch_t h, int64_t N) { return align_up(size_t(h->B) * size_t(N + 2) * 8, 256); }
 
@@ -976,8 +1004,14 @@ size_t mm_batch_workspace_bytes(mm_batch_t h, int64_t N) {
     return ws_alpha_bytes(h, N) + ws_c_bytes(h, N) + 2 * align_up(size_t(h->B) * 4, 256);  // + longest-first order, redo marks
 }
 
-static int ensure_ws(mm_batch_t h, size_t bytes) {
+
+static int ensure_ws(mm_batch_t h, size_t bytes, void *stream = nullptr) {
     if (h->ws_bytes >= bytes) return MM_OK;
+    // growing frees the old workspace: never while the caller's stream is capturing (a graph captured earlier on this
+    // batch has the old pointers baked in; mm_batch_reserve is the way to size it up front)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return fail(MM_ERR_INVALID, "the workspace would have to grow during stream capture: call mm_batch_reserve first");
     if (h->ws) {
         HIP_TRY(hipFree(h->ws));  // synchronises: only on growth
         h->ws = nullptr;
@@ -986,6 +1020,15 @@ static int ensure_ws(mm_batch_t h, size_t bytes) {
     HIP_TRY(hipMalloc(&h->ws, bytes));
     h->ws_bytes = bytes;
     return MM_OK;
+}
+
+int mm_batch_reserve(mm_batch_t h, int64_t N) {
+    if (!h || N < 1) return fail(MM_ERR_INVALID, "mm_batch_reserve: bad argument");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != h->device) return fail(MM_ERR_INVALID, "mm_batch_reserve: batch lives on another device");
+    // (the Viterbi back-pointers and the total-sum rows share the workspace: [N + 1][total states] words)
+    return ensure_ws(h, std::max(mm_batch_workspace_bytes(h, N), align_up(size_t(h->total_states) * size_t(N + 1) * 4, 256)));
 }
 
 static int check_run(mm_batch_t h, const char *who, const float *V, int64_t N, int want_semiring) {
@@ -1007,7 +1050,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     if (!gamma || !ttl) return fail(MM_ERR_INVALID, "mm_pdfposteriors_f32: gamma/ttl is NULL");
     // more utterances than CUs and different lengths: hand the workgroups out longest first
     const bool ordered = lens && h->B > h->n_cus && h->B <= 8192;
-    rc = ensure_ws(h, ws_alpha_bytes(h, N) + ws_c_bytes(h, N) + 2 * align_up(size_t(h->B) * 4, 256));  // + order, redo
+    rc = ensure_ws(h, mm_batch_workspace_bytes(h, N), stream);
     if (rc) return rc;
     RunParams p{};
     p.utts = h->d_utts;
@@ -1091,6 +1134,32 @@ int mm_betarecursion_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     return run_export(h, MODE_BETA, V, vsb, vsn, lens, N, out, out_stride_n, stream);
 }
 
+int mm_maxstateposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const int32_t *lens, int64_t N,
+                              float *out, int64_t out_stride_n, void *stream) {
+    int rc = check_run(h, "mm_maxstateposteriors_f32", V, N, MM_TROPICAL);
+    if (rc) return rc;
+    if (!out) return fail(MM_ERR_INVALID, "mm_maxstateposteriors_f32: out is NULL");
+    if (out_stride_n < h->total_states) return fail(MM_ERR_DIM, "mm_maxstateposteriors_f32: out_stride_n < total states");
+    // tropical alpha into `out`, tropical beta into the workspace, then mu = alpha (*) beta (/) best in place
+    const size_t beta_bytes = align_up(size_t(h->total_states) * size_t(N + 1) * 4, 256);
+    rc = ensure_ws(h, beta_bytes + align_up(size_t(h->B) * 4, 256), stream);
+    if (rc) return rc;
+    float *beta = static_cast<float *>(h->ws);
+    float *best = reinterpret_cast<float *>(static_cast<char *>(h->ws) + beta_bytes);
+    rc = run_export(h, MODE_ALPHA, V, vsb, vsn, lens, N, out, out_stride_n, stream);
+    if (rc) return rc;
+    rc = run_export(h, MODE_BETA, V, vsb, vsn, lens, N, beta, h->total_states, stream);
+    if (rc) return rc;
+    const int bt = 64;
+    hipLaunchKernelGGL(mm_pick_final_kernel, dim3(unsigned((h->B + bt - 1) / bt)), dim3(bt), 0, static_cast<hipStream_t>(stream),
+                       h->d_utts, int(h->B), out, (long long)out_stride_n, int(N), best);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(mm_maxmarginal_kernel, dim3(unsigned(h->B), unsigned(N + 1)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       h->d_utts, out, (long long)out_stride_n, beta, (long long)h->total_states, best);
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+}
+
 int mm_totalsum_f32(mm_batch_t h, int64_t n, int cumulative, float *out, void *stream) {
     static const float dummy = 0.f;
     int rc = check_run(h, "mm_totalsum_f32", &dummy, n, -1);
@@ -1098,7 +1167,7 @@ int mm_totalsum_f32(mm_batch_t h, int64_t n, int cumulative, float *out, void *s
     if (!out) return fail(MM_ERR_INVALID, "mm_totalsum_f32: out is NULL");
     // v_k and the running total live in the extended system (src/fsm.jl:19-28): the final state's self
     // loop of weight one makes it the accumulator of omega . v_k; n + 1 frames of the alpha recursion
-    rc = ensure_ws(h, align_up(size_t(h->total_states) * size_t(n + 1) * 4, 256));
+    rc = ensure_ws(h, align_up(size_t(h->total_states) * size_t(n + 1) * 4, 256), stream);
     if (rc) return rc;
     RunParams p{};
     p.utts = h->d_utts;
@@ -1125,7 +1194,7 @@ int mm_viterbi_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const
     if (path_stride_b < N) return fail(MM_ERR_DIM, "mm_viterbi_f32: path_stride_b < N");
     RunParams p{};
     if (!bp) {
-        rc = ensure_ws(h, align_up(size_t(h->total_states) * size_t(N + 1) * 4, 256));
+        rc = ensure_ws(h, align_up(size_t(h->total_states) * size_t(N + 1) * 4, 256), stream);
         if (rc) return rc;
         bp = static_cast<int32_t *>(h->ws);
         bp_stride_n = h->total_states;

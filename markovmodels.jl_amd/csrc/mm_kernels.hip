@@ -934,6 +934,18 @@ __global__ void mm_pick_final_kernel(const UttDesc *utts, int B, const float *A,
     if (b < B) out[b] = A[(long long)n * stride_n + utts[b].state_off + utts[b].S1 - 1];
 }
 
+// maxstateposteriors (docs/src/inference.md:5): mu = alpha (*) beta (/) best in place of alpha, one workgroup per
+// (utterance, frame); best[b] = alpha of the phony final state in the last frame (mm_pick_final_kernel).
+__global__ void mm_maxmarginal_kernel(const UttDesc *utts, float *A, long long a_stride_n, const float *Bt, long long b_stride_n,
+                                      const float *best) {
+    const int b = blockIdx.x, n = blockIdx.y;
+    const UttDesc &u = utts[b];
+    const float bb = best[b];
+    float *a = A + (long long)n * a_stride_n + u.state_off;
+    const float *bt = Bt + (long long)n * b_stride_n + u.state_off;
+    for (int s = threadIdx.x; s < u.S1; s += blockDim.x) a[s] = (bb > MM_NINF) ? a[s] + bt[s] - bb : MM_NINF;
+}
+
 // order[rank] = utterance, by decreasing length (ties by index): O(B) work per thread, B <= a few thousand
 __global__ void mm_length_order_kernel(const int *lens, int B, int N, int *order) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

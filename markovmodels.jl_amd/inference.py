@@ -168,6 +168,12 @@ class BatchedFSM:
         """One call of the engine: gamma[B, N, P] (probabilities), ttl[B]."""
         torch, Vt, lt, as_numpy = self._prep(V, lens)
         B, N, P = Vt.shape
+        if out is not None:
+            # the kernels write through raw pointers and strides: a wrong buffer is memory corruption, not an exception
+            if not isinstance(out, torch.Tensor) or out.dtype != torch.float32 or out.device != Vt.device:
+                raise TypeError("out must be a float32 tensor on V's device")
+            if out.dim() != 3 or tuple(out.shape) != (B, N, P):
+                raise _lib.DimensionMismatch(-2, f"out must be [B={B}, N={N}, P={P}], got {tuple(out.shape)}")
         gamma = out if out is not None else torch.empty((B, N, P), dtype=torch.float32, device=Vt.device)
         ttl = torch.empty(B, dtype=torch.float32, device=Vt.device)
         check(lib.mm_pdfposteriors_f32(self._h, Vt.data_ptr(), Vt.stride(0), Vt.stride(1),
@@ -186,11 +192,28 @@ class BatchedFSM:
         out = out.t()  # (sum S1) x (N+1) like the reference's state_A / state_B
         return out.cpu().numpy() if as_numpy else out
 
+    def maxstateposteriors(self, V, lens=None):
+        """Max-marginals of the tropical semiring, (sum S1) x (N+1), computed on the device."""
+        return self._export(lib.mm_maxstateposteriors_f32, V, lens)
+
     def alpharecursion(self, V, lens=None):
         return self._export(lib.mm_alpharecursion_f32, V, lens)
 
     def betarecursion(self, V, lens=None):
         return self._export(lib.mm_betarecursion_f32, V, lens)
+
+    def reserve(self, N: int):
+        """Size the internal workspace for runs of up to N frames now (so that later calls -- e.g. ones captured in
+        a hipGraph -- never reallocate)."""
+        check(lib.mm_batch_reserve(self._h, int(N)))
+
+    def kernels(self, semiring: str = "log") -> str:
+        """The kernels the engine launches for this batch (informational)."""
+        import ctypes
+
+        buf = ctypes.create_string_buffer(512)
+        check(lib.mm_batch_kernels(self._h, 0 if semiring == "log" else 1, buf, 512))
+        return buf.value.decode()
 
     def viterbi(self, V, lens=None, return_backpointers=False):
         """Best paths: (path[B, N] 0-based states, -1 beyond len; score[B][, bp[N+1, sum S1]])."""
@@ -321,15 +344,7 @@ def maxstateposteriors(fsm, Vhats, Chats=None):
     if bf.semiring != "tropical":
         raise TypeError("maxstateposteriors needs TropicalSemiring FSMs")
     V, lens = _unexpand(Vhats)
-    A = bf.alpharecursion(V, lens)
-    Bm = bf.betarecursion(V, lens)
-    mu = A + Bm
-    N1 = mu.shape[1]
-    for b in range(bf.B):
-        lo, hi = int(bf.state_offsets[b]), int(bf.state_offsets[b + 1])
-        best = A[hi - 1, N1 - 1]  # alpha of the phony final state in the last frame = weight of the best path
-        mu[lo:hi] = mu[lo:hi] - best if np.isfinite(best) else -np.inf
-    return mu
+    return bf.maxstateposteriors(V, lens)
 
 
 def _total(fsm, n, cumulative):

@@ -16,6 +16,7 @@
 #include "mm_kernels.hip"
 #include "mm_kernel_quad.hip"
 #include "mm_kernel_rows.hip"
+#include "mm_kernel_pairs.hip"
 #include "mm_pack.h"
 #include "mm_rows.h"
 
@@ -131,6 +132,7 @@ struct mm_fsm_s {
     std::map<int, QuadVariant *> variants;  // by 2 * KQ + direction
     RowVariant *rows[2] = {nullptr, nullptr};  // row-lane forms (built on first use; rows_tried: do not retry)
     bool rows_tried = false;
+    RowVariant *prows[2] = {nullptr, nullptr};  // ... and their pair variants (mm_kernel_pairs.hip)
     std::vector<float> init;  // dense alpha_hat, engine domain
     std::vector<int32_t> s2p;
     int device = -1;
@@ -142,11 +144,11 @@ struct mm_fsm_s {
 };
 
 // Test/diagnostic switches.  Read from the environment ONCE, at mm_batch_create, and only when MM_DEBUG is
-// set: the run entry points never call getenv.  MM_KERNEL = item | quad | row forces a pdfposteriors kernel,
+// set: the run entry points never call getenv.  MM_KERNEL = item | quad | row | pair forces a pdfposteriors kernel,
 // MM_KQ / MM_NWAVES / MM_NITEMS force a geometry, MM_NO_XCSR keeps the exact-fallback CSR out of LDS,
 // MM_VERBOSE prints the packing statistics.
 struct DebugOpts {
-    enum { K_AUTO = 0, K_ITEM, K_QUAD, K_ROW };
+    enum { K_AUTO = 0, K_ITEM, K_QUAD, K_ROW, K_PAIR };
     int kernel = K_AUTO;
     int kq = 0, nwaves = 0, nitems = -1;
     bool no_xcsr = false, verbose = false;
@@ -157,7 +159,7 @@ static DebugOpts read_debug_opts() {
     if (!on || !*on || !strcmp(on, "0")) return d;
     if (const char *e = getenv("MM_KERNEL"))
         d.kernel = !strcmp(e, "item") ? DebugOpts::K_ITEM : !strcmp(e, "quad") ? DebugOpts::K_QUAD
-                 : !strcmp(e, "row") ? DebugOpts::K_ROW : DebugOpts::K_AUTO;
+                 : !strcmp(e, "row") ? DebugOpts::K_ROW : !strcmp(e, "pair") ? DebugOpts::K_PAIR : DebugOpts::K_AUTO;
     if (const char *e = getenv("MM_KQ")) d.kq = atoi(e);
     if (const char *e = getenv("MM_NWAVES")) d.nwaves = atoi(e);
     if (const char *e = getenv("MM_NITEMS")) d.nitems = atoi(e);
@@ -182,6 +184,10 @@ struct mm_batch_s {
     int geo_kq[2] = {0, 0}, geo_nw[2] = {1, 1};  // quad kernel geometry of the forward and the backward kernel
     bool rows_ok = false;                        // every FSM has its row-lane forms: the row kernels can run
     int row_ka[2] = {0, 0}, row_nwc[2] = {1, 1}, row_slotrows[2] = {0, 0};
+    bool pairs_ok = false;                       // one FSM shared by all utterances, in pair form: the pair kernels can run
+    int pair_ka = 0, pair_nwc = 1, pair_slotrows = 0;
+    hipStream_t side = nullptr;                  // the backward agents of the pair kernels run beside the forward ones
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int device = -1;
     int n_cus = 256;  // compute units of the device
     UttDesc *d_utts = nullptr;
@@ -343,6 +349,51 @@ static int launch_rows(mm_batch_t h, const RunParams &p, void *stream) {
     int rc = launch_row_pass<0>(h, p, stream);
     if (rc) return rc;
     return launch_row_pass<1>(h, p, stream);
+}
+
+// The pair kernels (mm_kernel_pairs.hip): phase A and phase B, each as a forward-agent and a backward-agent launch
+// that run concurrently (the caller's stream and the batch's side stream, joined by events).
+template <int KA, int PHASE, int DIR>
+__global__ void __launch_bounds__(1024) mm_fbp_kernel_dir(RunParams p) {
+    pair_agent<KA, MM_ROW_RS, PHASE, DIR>(p, blockIdx.x);
+}
+template <int KA, int PHASE, int DIR>
+static int launch_pair_one(mm_batch_t h, const RunParams &p, hipStream_t st) {
+    const size_t lds = pair_lds_bytes(MM_ROW_RS, PHASE, h->pair_slotrows);
+    if (lds > 160 * 1024) return fail(MM_ERR_UNSUPPORTED, "pair kernel: LDS");
+    auto kernel = mm_fbp_kernel_dir<KA, PHASE, DIR>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    const unsigned npairs = unsigned((h->B + 1) / 2);
+    hipLaunchKernelGGL(kernel, dim3(npairs), dim3(64 * (h->pair_nwc + 1)), lds, st, p);
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+}
+template <int KA>
+static int launch_pairs_ka(mm_batch_t h, const RunParams &p, hipStream_t s0) {
+    hipStream_t s1 = h->side;
+    HIP_TRY(hipEventRecord(h->ev[0], s0));  // fork
+    HIP_TRY(hipStreamWaitEvent(s1, h->ev[0], 0));
+    int rc = launch_pair_one<KA, 0, 0>(h, p, s0);
+    if (!rc) rc = launch_pair_one<KA, 0, 1>(h, p, s1);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev[1], s0));  // phase B of either direction needs phase A of both
+    HIP_TRY(hipEventRecord(h->ev[2], s1));
+    HIP_TRY(hipStreamWaitEvent(s0, h->ev[2], 0));
+    HIP_TRY(hipStreamWaitEvent(s1, h->ev[1], 0));
+    rc = launch_pair_one<KA, 1, 0>(h, p, s0);
+    if (!rc) rc = launch_pair_one<KA, 1, 1>(h, p, s1);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev[3], s1));  // join
+    HIP_TRY(hipStreamWaitEvent(s0, h->ev[3], 0));
+    hipLaunchKernelGGL(mm_pair_finish_kernel, dim3(unsigned(h->B)), dim3(256), 0, s0, p);
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+}
+static int launch_pairs(mm_batch_t h, const RunParams &p, void *stream) {
+    hipStream_t s0 = static_cast<hipStream_t>(stream);
+    if (h->pair_ka <= 40) return launch_pairs_ka<40>(h, p, s0);
+    if (h->pair_ka <= 44) return launch_pairs_ka<44>(h, p, s0);
+    return MM_ERR_UNSUPPORTED;
 }
 
 namespace {
@@ -605,6 +656,78 @@ static int quad_variant(mm_fsm_t f, int dir, int KQ, bool verbose, QuadVariant *
     return MM_OK;
 }
 
+static int upload_row_variant(mm_fsm_t f, RowVariant *v, int dir, float thr) {
+    Blob bl;
+    // (zero rows up to MM_ROW_KA_PAD arc slots: the kernels load their whole register window unconditionally)
+    v->g.w.resize(size_t(MM_ROW_KA_PAD) * 64 * v->g.NWC, 0.f);
+    v->g.addr.resize(size_t(MM_ROW_KA_PAD) * 64 * v->g.NWC, 0u);
+    const size_t o_w = bl.add(v->g.w), o_a = bl.add(v->g.addr), o_s = bl.add(v->g.slots), o_sc = bl.add(v->g.sched);
+    const size_t o_ptr = bl.add(v->g.rowptr), o_col = bl.add(v->g.col), o_cw = bl.add(v->g.cw);
+    const size_t o_pdf = bl.add(v->g.rowpdf), o_pse = bl.add(v->g.pdfse), o_init = bl.add(v->init);
+    int rc = upload(bl, &v->blob);
+    if (rc) return rc;
+    char *base = static_cast<char *>(v->blob);
+    RowDev &d = v->rdev;
+    d.w = reinterpret_cast<const float *>(base + o_w);
+    d.addr = reinterpret_cast<const unsigned *>(base + o_a);
+    d.slots = reinterpret_cast<const unsigned *>(base + o_s);
+    d.sched = reinterpret_cast<const RowSched *>(base + o_sc);
+    d.rowptr = reinterpret_cast<const int *>(base + o_ptr);
+    d.col = reinterpret_cast<const int *>(base + o_col);
+    d.cw = reinterpret_cast<const float *>(base + o_cw);
+    d.rowpdf = reinterpret_cast<const unsigned short *>(base + o_pdf);
+    d.pdfse = reinterpret_cast<const unsigned short *>(base + o_pse);
+    d.init = reinterpret_cast<const float *>(base + o_init);
+    d.KA = v->g.KA;
+    d.NWC = v->g.NWC;
+    d.nslotrows = v->g.nslotrows;
+    d.fpos = v->g.pos[f->S1 - 1];
+    d.rows = int(f->S1);
+    d.thr = thr;
+    (void)dir;
+    return MM_OK;
+}
+
+// the pair variants of the row-lane forms (same schedule rules; 8-byte positions, one copy of the vector, the other
+// direction's numbering in the slot table)
+static int pair_variants(mm_fsm_t f, bool verbose, bool *ok) {
+    *ok = f->prows[0] && f->prows[1];
+    if (*ok || !f->rows[0] || !f->rows[1]) return MM_OK;  // (only FSMs that fit the row forms are tried)
+    RowPackOpts opt;
+    opt.rs = MM_ROW_RS;
+    opt.ka_max = 44;
+    opt.pair = true;
+    RowVariant *rv[2] = {new RowVariant(), new RowVariant()};
+    const std::vector<int32_t> none;
+    bool fits = make_rows(f->S1, f->qmat[0].rowptr, f->qmat[0].col, f->qmat[0].val, f->s2p, f->P1, false, none, opt, rv[0]->g) &&
+                make_rows(f->S1, f->qmat[1].rowptr, f->qmat[1].col, f->qmat[1].val, f->s2p, f->P1, true, rv[0]->g.pos, opt, rv[1]->g);
+    if (fits) set_partner(rv[0]->g, rv[1]->g.pos);
+    int rc = MM_OK;
+    for (int dir = 0; dir < 2 && fits && !rc; ++dir) {
+        if (verbose)
+            fprintf(stderr, "[mm] pair form dir %d: KA %d, %d compute waves, %d segments, arcs/slots %.3f, cost %d..%d, "
+                            "LDS cycles/gather (bank model) %.2f -> %.2f\n",
+                    dir, rv[dir]->g.KA, rv[dir]->g.NWC, rv[dir]->g.nslotrows - 1, rv[dir]->g.pad_eff, rv[dir]->g.mincost,
+                    rv[dir]->g.maxcost, rv[dir]->g.conflict_before, rv[dir]->g.conflict_after);
+        if (dir == 0) {
+            rv[0]->init.resize(size_t(f->S1));
+            for (int64_t i = 0; i < f->S1; ++i) rv[0]->init[i] = f->init[rv[0]->g.order[i]];
+        }
+        rc = upload_row_variant(f, rv[dir], dir, f->rows[0]->rdev.thr);
+    }
+    if (!fits || rc) {
+        for (RowVariant *x : rv) {
+            if (x->blob) (void)hipFree(x->blob);
+            delete x;
+        }
+        return rc;
+    }
+    f->prows[0] = rv[0];
+    f->prows[1] = rv[1];
+    *ok = true;
+    return MM_OK;
+}
+
 // build (once) and upload the row-lane forms of both directions of an FSM; *ok = false if it does not fit them
 static int row_variants(mm_fsm_t f, bool verbose, bool *ok) {
     *ok = f->rows[0] && f->rows[1];
@@ -646,14 +769,7 @@ static int row_variants(mm_fsm_t f, bool verbose, bool *ok) {
             v->init.resize(f->S1);
             for (int64_t i = 0; i < f->S1; ++i) v->init[i] = f->init[v->g.order[i]];
         }
-        Blob bl;
-        // (zero rows up to MM_ROW_KA_PAD arc slots: the kernels load their whole register window unconditionally)
-        v->g.w.resize(size_t(MM_ROW_KA_PAD) * 64 * v->g.NWC, 0.f);
-        v->g.addr.resize(size_t(MM_ROW_KA_PAD) * 64 * v->g.NWC, 0u);
-        const size_t o_w = bl.add(v->g.w), o_a = bl.add(v->g.addr), o_s = bl.add(v->g.slots), o_sc = bl.add(v->g.sched);
-        const size_t o_ptr = bl.add(v->g.rowptr), o_col = bl.add(v->g.col), o_cw = bl.add(v->g.cw);
-        const size_t o_pdf = bl.add(v->g.rowpdf), o_pse = bl.add(v->g.pdfse), o_init = bl.add(v->init);
-        int rc = upload(bl, &v->blob);
+        int rc = upload_row_variant(f, v, dir, 125.f + std::min(rv[0]->g.wmin_log2, rv[1]->g.wmin_log2));
         if (rc) {
             for (RowVariant *x : rv) {
                 if (x->blob) (void)hipFree(x->blob);
@@ -661,24 +777,6 @@ static int row_variants(mm_fsm_t f, bool verbose, bool *ok) {
             }
             return rc;
         }
-        char *base = static_cast<char *>(v->blob);
-        RowDev &d = v->rdev;
-        d.w = reinterpret_cast<const float *>(base + o_w);
-        d.addr = reinterpret_cast<const unsigned *>(base + o_a);
-        d.slots = reinterpret_cast<const unsigned *>(base + o_s);
-        d.sched = reinterpret_cast<const RowSched *>(base + o_sc);
-        d.rowptr = reinterpret_cast<const int *>(base + o_ptr);
-        d.col = reinterpret_cast<const int *>(base + o_col);
-        d.cw = reinterpret_cast<const float *>(base + o_cw);
-        d.rowpdf = reinterpret_cast<const unsigned short *>(base + o_pdf);
-        d.pdfse = reinterpret_cast<const unsigned short *>(base + o_pse);
-        d.init = reinterpret_cast<const float *>(base + o_init);
-        d.KA = v->g.KA;
-        d.NWC = v->g.NWC;
-        d.nslotrows = v->g.nslotrows;
-        d.fpos = v->g.pos[f->S1 - 1];
-        d.rows = int(f->S1);
-        d.thr = 125.f + std::min(rv[0]->g.wmin_log2, rv[1]->g.wmin_log2);
     }
     f->rows[0] = rv[0];
     f->rows[1] = rv[1];
@@ -693,7 +791,7 @@ int mm_fsm_destroy(mm_fsm_t f) {
         if (kv.second->blob) (void)hipFree(kv.second->blob);
         delete kv.second;
     }
-    for (RowVariant *rv : f->rows)
+    for (RowVariant *rv : {f->rows[0], f->rows[1], f->prows[0], f->prows[1]})
         if (rv) {
             if (rv->blob) (void)hipFree(rv->blob);
             delete rv;
@@ -887,6 +985,24 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         }
         h->rows_ok = ok;
     }
+    // pair kernels: all utterances on ONE FSM (the graph registers are shared by the two utterances of a workgroup)
+    h->pairs_ok = h->rows_ok && B >= 2 && h->dbg.kernel != DebugOpts::K_ROW;
+    for (int64_t b = 1; b < B && h->pairs_ok; ++b) h->pairs_ok = fsms[b] == fsms[0];
+    if (h->pairs_ok) {
+        bool ok = false;
+        int rc = pair_variants(fsms[0], h->dbg.verbose, &ok);
+        if (rc) {
+            delete h;
+            return rc;
+        }
+        h->pairs_ok = ok;
+        if (ok) {
+            h->pair_ka = std::max(fsms[0]->prows[0]->g.KA, fsms[0]->prows[1]->g.KA);
+            h->pair_nwc = std::max(fsms[0]->prows[0]->g.NWC, fsms[0]->prows[1]->g.NWC);
+            h->pair_slotrows = std::max(fsms[0]->prows[0]->g.nslotrows, fsms[0]->prows[1]->g.nslotrows);
+            h->pairs_ok = h->pair_ka <= 44 && pair_lds_bytes(MM_ROW_RS, 1, h->pair_slotrows) <= 160 * 1024;
+        }
+    }
     for (int64_t b = 0; b < B; ++b) {
         mm_fsm_t f = fsms[b];
         int rc = fsm_to_device(f);
@@ -906,6 +1022,8 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             u.init_f = qv[0]->d_init_f;
             u.map_bf = qv[1]->d_map_bf;
         }
+        if (h->pairs_ok)
+            for (int d = 0; d < 2; ++d) u.rp[d] = f->prows[d]->rdev;
         if (h->rows_ok)
             for (int d = 0; d < 2; ++d) {
                 u.r[d] = f->rows[d]->rdev;
@@ -939,6 +1057,11 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         delete h;
         return fail(MM_ERR_HIP, "mm_batch_create: device allocation failed");
     }
+    if (h->pairs_ok) {
+        bool good = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < 4 && good; ++i) good = hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming) == hipSuccess;
+        if (!good) h->pairs_ok = false;
+    }
     if (h->fast_ok && h->geo_kq[0] <= 3 && h->geo_kq[1] <= 3 && !h->dbg.no_xcsr) {
         h->xcsr = int((h->max_xcsr + 3) & ~int64_t(3));
         if (h->max_xcsr > 16 * 1024 || quad_lds_bytes(h, 0) > 128 * 1024 || quad_lds_bytes(h, 1) > 128 * 1024) h->xcsr = 0;
@@ -960,6 +1083,9 @@ int mm_debug_read_stamps(unsigned long long *out, int64_t n) {
 
 int mm_batch_destroy(mm_batch_t h) {
     if (!h) return MM_OK;
+    if (h->side) (void)hipStreamDestroy(h->side);
+    for (hipEvent_t e : h->ev)
+        if (e) (void)hipEventDestroy(e);
     if (h->d_utts) (void)hipFree(h->d_utts);
     if (h->ws) (void)hipFree(h->ws);
     delete h;
@@ -976,7 +1102,11 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
         const std::string exact = quad ? "mm_fbq_kernel<" + std::to_string(h->geo_kq[0]) + ",*,0> + mm_fbq_kernel<" +
                                              std::to_string(h->geo_kq[1]) + ",*,1>"
                                        : std::string("mm_log_kernel<MODE_FB> (forward, backward)");
-        if (h->rows_ok) {
+        if (h->pairs_ok) {
+            const std::string k = std::to_string(h->pair_ka <= 40 ? 40 : 44);
+            s = "mm_fbp_kernel_dir<" + k + ",A,fwd> || <" + k + ",A,bwd>, then <" + k + ",B,fwd> || <" + k +
+                ",B,bwd>, mm_pair_finish_kernel, then for marked utterances only " + exact;
+        } else if (h->rows_ok) {
             auto ka = [&](int d) {
                 for (int k : kRowKA)
                     if (h->row_ka[d] <= k) return k;
@@ -996,12 +1126,20 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
     return MM_OK;
 }
 
-static size_t ws_alpha_bytes(mm_batch_t h, int64_t N) { return align_up(size_t(h->total_s1p) * size_t(N + 1) * 4, 256); }
-static size_t ws_c_bytes(mm_batch_t h, int64_t N) { return align_up(size_t(h->B) * size_t(N + 2) * 8, 256); }
+// (the pair kernels keep N + 2 vectors per utterance and one workspace slot more than utterances)
+static size_t ws_alpha_bytes(mm_batch_t h, int64_t N) {
+    if (h->pairs_ok) return align_up(size_t(h->B + 1) * size_t(h->max_S1p) * size_t(N + 2) * 4, 256);
+    return align_up(size_t(h->total_s1p) * size_t(N + 1) * 4, 256);
+}
+static size_t ws_c_bytes(mm_batch_t h, int64_t N) { return align_up(size_t(h->B + 1) * size_t(N + 2) * 8, 256); }
+static size_t ws_tail_bytes(mm_batch_t h) {  // longest-first order, redo marks, pair hand-over, per-direction log Z minima
+    return 2 * align_up(size_t(h->B + 1) * 4, 256) + align_up(size_t(h->B + 1) * 2 * sizeof(PairHand), 256) +
+           align_up(size_t(h->B) * 2 * 8, 256);
+}
 
 size_t mm_batch_workspace_bytes(mm_batch_t h, int64_t N) {
     if (!h || N < 0) return 0;
-    return ws_alpha_bytes(h, N) + ws_c_bytes(h, N) + 2 * align_up(size_t(h->B) * 4, 256);  // + longest-first order, redo marks
+    return ws_alpha_bytes(h, N) + ws_c_bytes(h, N) + ws_tail_bytes(h);
 }
 
 
@@ -1048,8 +1186,9 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     int rc = check_run(h, "mm_pdfposteriors_f32", V, N, MM_LOG);
     if (rc) return rc;
     if (!gamma || !ttl) return fail(MM_ERR_INVALID, "mm_pdfposteriors_f32: gamma/ttl is NULL");
-    // more utterances than CUs and different lengths: hand the workgroups out longest first
-    const bool ordered = lens && h->B > h->n_cus && h->B <= 8192;
+    // more utterances than CUs and different lengths: hand the workgroups out longest first; the pair kernels also
+    // pair the utterances in that order (the two of a pair run the same number of frames)
+    const bool ordered = lens && (h->B > h->n_cus || h->pairs_ok) && h->B <= 8192;
     rc = ensure_ws(h, mm_batch_workspace_bytes(h, N), stream);
     if (rc) return rc;
     RunParams p{};
@@ -1069,7 +1208,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     p.ttl = ttl;
     p.xcsr = h->xcsr;
     if (ordered) {
-        int *order = reinterpret_cast<int *>(static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N));
+        int *order = reinterpret_cast<int *>(static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N));  // (first of the tail)
         hipLaunchKernelGGL(mm_length_order_kernel, dim3(unsigned((h->B + 255) / 256)), dim3(256), 0,
                            static_cast<hipStream_t>(stream), lens, int(h->B), int(N), order);
         HIP_TRY(hipGetLastError());
@@ -1083,11 +1222,18 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     p.dbg = g_dbg;
 #endif
     if (h->rows_ok) {
-        // the row kernels, then -- for the utterances they marked (linear sums outside the trusted range), normally
-        // none: every workgroup then leaves at once -- the exact kernels
-        p.redo = reinterpret_cast<int *>(static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N) +
-                                         align_up(size_t(h->B) * 4, 256));
-        rc = launch_rows(h, p, stream);
+        // the pair or row kernels, then -- for the utterances they marked (linear sums outside the trusted range),
+        // normally none: every workgroup then leaves at once -- the exact kernels
+        char *tail = static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N);
+        p.redo = reinterpret_cast<int *>(tail + align_up(size_t(h->B + 1) * 4, 256));
+        if (h->pairs_ok) {
+            p.pair_s1p = h->max_S1p;
+            p.pair_hand = tail + 2 * align_up(size_t(h->B + 1) * 4, 256);
+            p.pair_zmin = reinterpret_cast<double *>(static_cast<char *>(p.pair_hand) + align_up(size_t(h->B + 1) * 2 * sizeof(PairHand), 256));
+            rc = launch_pairs(h, p, stream);
+        } else {
+            rc = launch_rows(h, p, stream);
+        }
         if (rc) return rc;
     }
     if (quad_kernel_usable(h)) {

@@ -1,0 +1,581 @@
+// mm_kernel_pairs.hip -- the "pair" pdfposteriors kernels for gfx950: the row kernels' organisation
+// (mm_kernel_rows.hip, mm_rows.h: one lane per row of the semiring product, register-resident graph, one barrier per
+// frame, a service wave for all HBM traffic) with two changes that take the LDS gathers off the critical path:
+//
+//   * TWO utterances per workgroup share the graph registers.  The linear vectors of the two utterances sit side by
+//     side in LDS (8 bytes per state), so ONE ds_read_b64 per arc fetches both values: per utterance and frame half
+//     the gather instructions, half the address registers and half the LDS cycles of the row kernels (whose frame was
+//     ~80 % LDS-array time).  Batches whose utterances share one FSM only (the denominator case,
+//     examples/test_cuda.jl:112); the utterances of a pair run the same number of frames, so they are paired by length.
+//   * BIDIRECTIONAL time split.  With two utterances per workgroup B utterances give B / 2 workgroups per direction --
+//     half the chip for B = #CUs.  So the alpha-recursion (src/inference.jl:62-74) of a pair and its beta-recursion
+//     (:99-110) run CONCURRENTLY, as two workgroups ("agents"): the forward agent walks frames 1, 2, ..., the backward
+//     agent N+1, N, ...; in phase A (first launch) each stores its normalised log2 vectors for its half of the frames,
+//     in phase B (second launch) each continues through the other half and combines its fresh vector with the vector
+//     the other agent stored for that frame (:154-160: A .* B, C' * AB, per-frame sum, divide).  Every frame's state
+//     vector is still written once and read once (the algorithmic bytes of SURVEY.md 8(d) are unchanged), the serial
+//     depth of a call is N+1 steps instead of 2(N+1), and the hand-over between the phases is a kernel boundary -- no
+//     in-kernel waiting of one workgroup on another.
+//
+// An agent's steps are numbered t = 1, 2, ...: step t handles frame t (forward) or NF + 1 - t (backward), NF = the
+// pair's frames = max(len) + 1.  Step 1 is the initial vector (alpha_hat (*) lhs[:,1], or one(K) at the final state);
+// all double buffers go by the parity of t, the DMA rings by t % 3 / t & 3, in both directions alike.
+// Numerics as in the row kernels (frame normaliser S_t chosen two steps ahead by the service wave, emission maximum
+// E_t, range check + redo marks); the posterior of frame f is normalised by the frame's own sum exactly like the
+// reference (:157-158), and log Z of a frame = log2(sum) + the two agents' cumulative offsets (double), ttl = the
+// minimum over the frames (:159).
+#pragma once
+#include "mm_kernel_rows.hip"
+
+namespace mm {
+
+typedef float mm_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ mm_f32x2 ldsr2(unsigned addr) { return *(__attribute__((address_space(3))) const mm_f32x2 *)(__UINTPTR_TYPE__)addr; }
+__device__ __forceinline__ void ldsw2(unsigned addr, float a, float b) {
+    mm_f32x2 v = {a, b};
+    *(__attribute__((address_space(3))) mm_f32x2 *)(__UINTPTR_TYPE__)addr = v;
+}
+
+// LDS byte layout of the pair kernels (absolute addresses).  RS2 = bytes of one pair vector.
+template <int RS, int PHASE>
+struct PairLay {
+    static constexpr unsigned RS2 = 2 * RS;
+    static constexpr unsigned PP(int par) { return unsigned(par) * RS2; }                          // p pairs [pos][2]
+    static constexpr unsigned RAW(int k, int u) { return 2 * RS2 + unsigned(2 * k + u) * 1024u; }  // raw emissions, k < 4
+    static constexpr unsigned EM(int par) { return 2 * RS2 + 8192u + unsigned(par) * 2048u; }      // [pdf][2] pairs
+    static constexpr unsigned MS(int par) { return 2 * RS2 + 12288u + unsigned(par) * 64u; }       // {S_0, S_1} of a step
+    static constexpr unsigned OWN(int k) { return 2 * RS2 + 12288u + 128u + unsigned(k) * 16u; }   // own offsets, k < 4: 2 doubles
+    static constexpr unsigned POFF(int k, int u) { return 2 * RS2 + 12288u + 256u + unsigned(2 * k + u) * 256u; }  // partner offsets, k < 8
+    static constexpr unsigned PSUM(int par) { return 2 * RS2 + 12288u + 256u + 4096u + unsigned(par) * 2048u; }   // [pdf][2]
+    static constexpr unsigned PDFSE = 2 * RS2 + 12288u + 256u + 4096u + 4096u;                     // u16 [2 * P1]
+    static constexpr unsigned FIX = PDFSE + 1024u;
+    static constexpr unsigned AL(int k, int u) { return FIX + unsigned(2 * k + u) * RS; }          // partner rows (phase B), k < 3
+    static constexpr unsigned Q(int par) { return FIX + 6u * RS + unsigned(par) * RS2; }           // q pairs [qpos][2] (phase B)
+    static constexpr unsigned SLOTS = PHASE ? FIX + 6u * RS + 2 * RS2 : FIX;
+};
+inline size_t pair_lds_bytes(int RS, int phase, int nslotrows) {
+    const size_t fix = size_t(4 * RS) + 12288 + 256 + 4096 + 4096 + 1024;
+    return fix + (phase ? size_t(6 * RS) + size_t(4 * RS) : 0) + size_t(nslotrows) * 64 * 8;
+}
+
+struct PairUtt {  // one utterance of the pair (scalar registers)
+    const float *Vb;
+    float *rows;      // [N + 2][S1p] state vectors of the frames (alpha~ up to the split, beta~ beyond)
+    double *offs;     // [N + 2] cumulative offset of the stored vector of every frame
+    int b, len, valid;
+};
+
+// emissions of one frame for utterance u of the pair: raw values from LDS (DMA), log2 domain relative to the frame's
+// maximum E (row_stage_em for interleaved pairs).  Returns E.
+__device__ __forceinline__ float pair_stage_em(unsigned dst, unsigned rawsrc, int u, int n, int len, int P, int lane) {
+    float v[4], E = MM_NINF;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = lane + 64 * j;
+        v[j] = em_value(ldsr(rawsrc + 256u * j + 4u * lane), n, len, P, q);
+        if (q < P) E = max_nc(E, v[j]);
+    }
+    E = wave_max_rl(E);
+    if (!(E > MM_NINF)) E = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = lane + 64 * j;
+        if (q <= P) ldsw(dst + 8u * q + 4u * u, v[j] - E);
+    }
+    return E;
+}
+
+// service wave: log2 of the maxima of both linear vectors (pairs [pos][2]; n2 float4s = 2 states each)
+__device__ __forceinline__ void pair_scan_max(unsigned pbase, int n2, int lane, float &m0, float &m1) {
+    float a = 0.f, b = 0.f;
+    for (int q = lane; q < n2; q += 64) {
+        const mm_f32x4 v = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(pbase + 16u * q);
+        a = max_nc(a, max_nc(v.x, v.z));
+        b = max_nc(b, max_nc(v.y, v.w));
+    }
+    m0 = fast_log2(wave_max_rl(a));
+    m1 = fast_log2(wave_max_rl(b));
+}
+
+// one wave: per-frame sum over the pdfs of utterance u (psum pairs [pdf][2]), divide, store gamma
+// (src/inference.jl:156-160); returns log2 of the sum (-inf, and gamma = 0, if nothing is alive)
+__device__ __forceinline__ float pair_finish_frame(unsigned psum, int u, int P1, int P, int lane, float *gp, long long gsp, bool store) {
+    float s[4], tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = lane + 64 * j;
+        s[j] = q < P1 ? ldsr(psum + 8u * q + 4u * u) : 0.f;
+        tot += s[j];
+    }
+    tot = wave_sum(tot);
+    const float inv = tot > 0.f ? 1.f / tot : 0.f;
+    if (store) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = lane + 64 * j;
+            if (q < P) gp[q * gsp] = s[j] * inv;
+        }
+    }
+    return fast_log2(tot);
+}
+
+// pdf sums of both utterances (q pairs in pdf-major order): 8 pdfs per wave and pass, 8 lanes per pdf
+__device__ __forceinline__ void pair_pdf_sums(unsigned qbase, unsigned pdfse_base, unsigned psum_base, int P1, int wave, int NWC, int lane) {
+    for (int p0 = wave * 8; p0 < P1; p0 += NWC * 8) {
+        const int pdf = p0 + (lane >> 3);
+        float s0 = 0.f, s1 = 0.f;
+        if (pdf < P1) {
+            const unsigned se = ldsru(pdfse_base + 4u * pdf);  // first | end << 16
+            const unsigned a0 = 8u * ((se & 0xffffu) + (lane & 7)), a1 = 8u * (se >> 16);
+            mm_f32x2 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = ldsr2(qbase + (a0 + 64u * k < a1 ? a0 + 64u * k : 0u));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (a0 + 64u * k < a1) {
+                    s0 += v[k].x;
+                    s1 += v[k].y;
+                }
+            for (unsigned a = a0 + 256u; a < a1; a += 64u) {
+                const mm_f32x2 w = ldsr2(qbase + a);
+                s0 += w.x;
+                s1 += w.y;
+            }
+        }
+        s0 = grp_sum(s0, 3);
+        s1 = grp_sum(s1, 3);
+        if (pdf < P1 && (lane & 7) == 0) ldsw2(psum_base + 8u * pdf, s0, s1);
+    }
+}
+
+// the arcs of a compute wave, two at a time, for two utterances (row_pairs with 8-byte gathers)
+template <int K2, int KA, int D, class F>
+__device__ __forceinline__ void pair_pairs(const float (&wr)[KA], const unsigned (&ar)[KA], mm_f32x2 (&x)[2 * D], float &acc0,
+                                           float &acc1, unsigned rdoff, unsigned em_lo, unsigned em_hi, int &slots_left, F &&finish) {
+    constexpr int s0 = (2 * K2) % (2 * D);
+    acc0 = fmaf(wr[2 * K2], x[s0].x, acc0);
+    acc1 = fmaf(wr[2 * K2], x[s0].y, acc1);
+    acc0 = fmaf(wr[2 * K2 + 1], x[s0 + 1].x, acc0);
+    acc1 = fmaf(wr[2 * K2 + 1], x[s0 + 1].y, acc1);
+    if constexpr (2 * (K2 + D) < KA) {
+        x[s0] = ldsr2(ar[2 * (K2 + D)] + rdoff);
+        x[s0 + 1] = ldsr2(ar[2 * (K2 + D) + 1] + rdoff);
+    }
+    if (((K2 < 32 ? em_lo : em_hi) >> (K2 & 31)) & 1u) {
+        finish();
+        if (--slots_left == 0) return;
+    }
+    if constexpr (K2 + 1 < KA / 2) pair_pairs<K2 + 1, KA, D>(wr, ar, x, acc0, acc1, rdoff, em_lo, em_hi, slots_left, finish);
+}
+
+struct PairHand {  // what an agent hands from phase A to phase B, per utterance
+    float m_prev, s_cur, s_prev, cbar;
+    int seen, pad;
+    double cum;
+};
+
+// One agent: direction DIR (0: forward / alpha, 1: backward / beta) of pair `pair`, phase PHASE (0: A, 1: B).
+template <int KA, int RS, int PHASE, int DIR>
+__device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
+    extern __shared__ float lds[];
+    using L = PairLay<RS, PHASE>;
+    constexpr int D = 3;
+    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, NWC = NW - 1;
+    const bool service = wave == NWC;
+    if (service) __builtin_amdgcn_s_setprio(3);
+    // ---- the two utterances
+    PairUtt U[2];
+    int NFp = 1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = 2 * pair + u;
+        const bool valid = i < p.B;
+        const int ii = valid ? i : p.B - 1;  // (odd batch: the last pair runs its first utterance twice, the copy writes nothing outside the workspace)
+        const int b = uni(p.order ? p.order[ii] : ii);
+        int len = uni(p.lens ? p.lens[b] : p.N);
+        len = len < 0 ? 0 : (len > p.N ? p.N : len);
+        const int slot = valid ? b : p.B;  // workspace slot
+        U[u].b = b;
+        U[u].len = len;
+        U[u].valid = valid;
+        U[u].Vb = p.V + (long long)b * p.vsb;
+        U[u].rows = p.ws_alpha + (long long)slot * (long long)(p.N + 2) * p.pair_s1p;
+        U[u].offs = p.ws_c + (long long)slot * (p.N + 2);
+        NFp = len + 1 > NFp ? len + 1 : NFp;
+    }
+    const UttDesc &ud = p.utts[U[0].b];
+    const RowU r = uni(ud.rp[DIR]);
+    const int S1 = r.rows, S1p = p.pair_s1p, P1 = uni(ud.P1), P = P1 - 1, P1p = (P1 + 3) & ~3;
+    const float thr = r.thr;
+    // split: forward steps 1..m are phase A, backward steps 1..NFp-m
+    int m = NFp / 2;
+    m = m < 1 ? 1 : m;
+    const int tA = DIR ? NFp - m : m, tEnd = NFp;
+    auto frame_of = [&](int t) { return DIR ? NFp + 1 - t : t; };
+    PairHand *hand = reinterpret_cast<PairHand *>(p.pair_hand) + ((long long)pair * 2 + DIR) * 2;
+    if (lds_addr_of(lds) != 0u) __builtin_trap();
+
+    // ---- LDS set-up
+    for (unsigned q = tid * 4u; q < 2u * L::RS2; q += NT * 4u) ldsw(L::PP(0) + q, 0.f);
+    if constexpr (PHASE == 1)
+        for (unsigned q = tid * 4u; q < 2u * L::RS2; q += NT * 4u) ldsw(L::Q(0) + q, 0.f);
+    if (tid < 32) ldsw(L::MS(0) + 4u * tid, 0.f);
+    if (tid < 4) ldsw(L::EM(tid >> 1) + 8u * P1p + 4u * (tid & 1), MM_NINF);  // the emission slot of lanes without a row
+    const int nslotwords = r.nslotrows * 128;
+    for (int q = tid; q < nslotwords; q += NT) ldswu(L::SLOTS + 4u * q, as_global(r.slots)[q]);
+    if constexpr (PHASE == 1)
+        for (int q = tid; q < P1; q += NT) ldswu(L::PDFSE + 4u * q, as_global(reinterpret_cast<const unsigned *>(r.pdfse))[q]);
+    int *redo0 = p.redo + U[0].b, *redo1 = p.redo + (U[1].valid ? U[1].b : p.B);
+    if (PHASE == 0 && DIR == 0 && tid == 0) {
+        *redo0 = 0;
+        *redo1 = 0;
+    }
+    unsigned long long endmask = 0, lgw0 = 0;
+    int nslots = 0;
+    unsigned slot_base = 0;
+    if (!service && wave < r.NWC) {
+        const RowSched &sc = r.sched[wave];
+        endmask = sc.endmask;
+        lgw0 = sc.lg;
+        nslots = (int)sc.nslots;
+        slot_base = L::SLOTS + (sc.slot0 * 64u + lane) * 8u;
+    }
+    unsigned em_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)endmask);
+    unsigned em_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(endmask >> 32));
+    lgw0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(lgw0 >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((unsigned)lgw0);
+    nslots = __builtin_amdgcn_readfirstlane(nslots);
+    RowRegs<KA> rg;
+    auto load_graph = [&]() {
+        static_assert(KA <= MM_ROW_KA_PAD, "register window larger than the padding of the device arrays");
+        const int nt = 64 * r.NWC;
+        const bool mine = wave < r.NWC;
+        const auto wp = as_global(r.w);
+        const auto ap = as_global(r.addr);
+        const int t0 = mine ? tid : 0;
+#pragma unroll
+        for (int k = 0; k < KA; ++k) {
+            rg.w[k] = wp[k * nt + t0];
+            rg.a[k] = ap[k * nt + t0];
+        }
+        if (!mine) {
+#pragma unroll
+            for (int k = 0; k < KA; ++k) {
+                rg.w[k] = 0.f;
+                rg.a[k] = 0u;
+            }
+        }
+    };
+    // steps of this launch: (t0, t1]; the vector of step t0 is the starting point
+    const int t0 = PHASE ? tA : 1, t1 = PHASE ? tEnd : tA;
+    __syncthreads();
+
+    if (service) {
+        // ================= service wave =================
+        RowNorm norm[2];
+        double cum[2] = {0.0, 0.0};
+        double zmin[2] = {__builtin_inf(), __builtin_inf()};
+        auto dma_raw = [&](int t) {  // raw emissions of step t (clamped) -> RAW(t & 3, u)
+            const int tt = t < 1 ? 1 : (t > tEnd ? tEnd : t);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) row_dma_em(L::RAW(0, u) + 2048u * (t & 3), U[u].Vb, p.vsn, frame_of(tt), p.N, P, lane);
+        };
+        auto dma_partner = [&](int t) {  // the other agent's vector + offset of step t's frame -> AL(t % 3, u), POFF(t & 3, u)
+            const int tt = t < 1 ? 1 : (t > tEnd ? tEnd : t);
+            int f = frame_of(tt);
+            f = f > p.N ? p.N : f;  // (frame N+1 is never combined)
+            const int n4 = S1p >> 2;
+            constexpr int NA = (RS / 4 + 255) / 256;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(U[u].rows + (long long)f * S1p);
+                const unsigned dst = L::AL(0, u) + (unsigned)(tt % 3) * 2u * RS;
+#pragma unroll
+                for (int j = 0; j < NA; ++j) {
+                    const int q = lane + 64 * j;
+                    dma_b128(src + (q < n4 ? q : 0), dst + 1024u * j);
+                }
+                dma_b32(reinterpret_cast<const unsigned *>(U[u].offs + f) + (lane & 1), L::POFF(0, u) + 512u * (t & 7));
+            }
+        };
+        constexpr int NDMA = 8 + (PHASE ? 2 * ((RS / 4 + 255) / 256) + 2 : 0);  // DMAs issued per step (a lower bound of the VMEM operations)
+        // stage the emissions of step t into EM(t & 1) and account its offsets; S = the normaliser the step subtracts
+        auto stage = [&](int t, const float (&S)[2]) {
+            float E[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                E[u] = pair_stage_em(L::EM(t & 1), L::RAW(0, u) + 2048u * (t & 3), u, frame_of(t), U[u].len, P, lane);
+                cum[u] += (double)S[u] + (double)E[u];
+            }
+            if (lane == 0) {
+                ldsw2(L::MS(t & 1), S[0], S[1]);
+                // the offset that turns the step's stored vector into log2 values: forward alpha~ includes the emission
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const double off = DIR ? cum[u] - (double)E[u] : cum[u];
+                    *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(L::OWN(t & 3) + 8u * u) = off;
+                    if (PHASE == 0) U[u].offs[frame_of(t)] = off;
+                }
+            }
+        };
+        // ---- prologue: everything step t0 + 1 needs
+        for (int t = t0; t <= t0 + 3; ++t) dma_raw(t);
+        if constexpr (PHASE == 1) {
+            dma_partner(t0 + 1);
+            dma_partner(t0 + 2);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const PairHand h = hand[u];
+                norm[u].m_prev = h.m_prev;
+                norm[u].s_cur = h.s_cur;
+                norm[u].s_prev = h.s_prev;
+                norm[u].cbar = h.cbar;
+                norm[u].seen = h.seen;
+                cum[u] = h.cum;
+            }
+        }
+        MM_ROW_VMCNT(0);
+        if (PHASE == 0 || DIR == 1) {  // emissions of the starting step: the initial alpha needs them, and so does
+            float E[2];                // rebuilding the backward agent's linear vector from its stored beta~
+#pragma unroll
+            for (int u = 0; u < 2; ++u) E[u] = pair_stage_em(L::EM(t0 & 1), L::RAW(0, u) + 2048u * (t0 & 3), u, frame_of(t0), U[u].len, P, lane);
+            if (PHASE == 0) {  // step 1 subtracts nothing but E
+#pragma unroll
+                for (int u = 0; u < 2; ++u) cum[u] = (double)E[u];
+                if (DIR == 0 && lane == 0) {
+                    U[0].offs[1] = cum[0];
+                    U[1].offs[1] = cum[1];
+                }
+            }
+        }
+        __syncthreads();  // (1) emissions of step t0 staged
+        if (t0 + 1 <= t1) {
+            const float S[2] = {norm[0].s_cur, norm[1].s_cur};  // (phase A: 0 -- step 2 subtracts nothing but E)
+            stage(t0 + 1, S);
+        }
+        dma_raw(t0 + 4);
+        __syncthreads();  // (2) starting vector in LDS, step t0 + 1 prepared
+        auto step = [&](auto RDc, int t) {
+            constexpr int RD = decltype(RDc)::value, WR = 1 - RD;  // RD = parity of steps t - 1 and t + 1
+            // emissions of step t + 1 (requested at step t - 2: the DMAs of step t - 1 may still be in flight)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            // the normaliser of step t + 1 from the maxima of step t - 1 (complete since the last barrier)
+            float mx[2];
+            pair_scan_max(L::PP(RD), (S1 + 2) >> 1, lane, mx[0], mx[1]);
+            if (t + 1 <= tEnd) {
+                const float S[2] = {norm[0].next(mx[0]), norm[1].next(mx[1])};
+                if (t + 1 <= t1) stage(t + 1, S);
+            }
+            dma_raw(t + 4);
+            if constexpr (PHASE == 1) {
+                dma_partner(t + 2);
+                // gamma of step t - 2: its per-pdf sums were completed in the previous step
+                if (t - 2 > t0) {
+                    const int f = frame_of(t - 2);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const bool live = f >= 1 && f <= U[u].len;
+                        const float lt = pair_finish_frame(L::PSUM(WR), u, P1, P, lane,
+                                                           p.gamma + (long long)U[u].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp,
+                                                           live && U[u].valid);
+                        if (live) {
+                            const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN((t - 2) & 3) + 8u * u);
+                            const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 512u * ((t - 2) & 7));
+                            const double z = (double)lt + own + oth;
+                            zmin[u] = z < zmin[u] ? z : zmin[u];
+                        }
+                    }
+                }
+                // the partner vector of step t + 1 (requested at step t - 1) must be in LDS when the compute waves leave the barrier
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            }
+            __syncthreads();
+        };
+        for (int t = t0 + 1; t <= t1; t += 2) {
+            if (t & 1) step(std::integral_constant<int, 0>{}, t);
+            else step(std::integral_constant<int, 1>{}, t);
+            if (t + 1 <= t1) {
+                if ((t + 1) & 1) step(std::integral_constant<int, 0>{}, t + 1);
+                else step(std::integral_constant<int, 1>{}, t + 1);
+            }
+        }
+        if constexpr (PHASE == 0) {
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    PairHand h;
+                    h.m_prev = norm[u].m_prev;
+                    h.s_cur = norm[u].s_cur;
+                    h.s_prev = norm[u].s_prev;
+                    h.cbar = norm[u].cbar;
+                    h.seen = norm[u].seen;
+                    h.pad = 0;
+                    h.cum = cum[u];
+                    hand[u] = h;
+                }
+            }
+        } else {
+            // the last two steps' posteriors: (a) sums of step t1 by the compute waves, gamma of step t1 - 1 here; (b) gamma of step t1
+            MM_ROW_VMCNT(0);
+            for (int k = 1; k >= 0; --k) {
+                const int t = t1 - k;
+                if (k == 0) __syncthreads();  // (a)
+                if (t > t0) {
+                    const int f = frame_of(t);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const bool live = f >= 1 && f <= U[u].len;
+                        const float lt = pair_finish_frame(L::PSUM(t & 1), u, P1, P, lane,
+                                                           p.gamma + (long long)U[u].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp,
+                                                           live && U[u].valid);
+                        if (live) {
+                            const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN(t & 3) + 8u * u);
+                            const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 512u * (t & 7));
+                            const double z = (double)lt + own + oth;
+                            zmin[u] = z < zmin[u] ? z : zmin[u];
+                        }
+                    }
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (U[u].valid) p.pair_zmin[(long long)U[u].b * 2 + DIR] = zmin[u];
+            }
+        }
+    } else {
+        // ================= compute waves =================
+        __syncthreads();  // (1)
+        // the starting vector (step t0)
+        if (PHASE == 0 && DIR == 0) {  // alpha_hat (*) lhs[:,1]   (src/inference.jl:68)
+            for (int i = tid; i < S1; i += 64 * NWC) {
+                const unsigned e8 = 8u * as_global(r.rowpdf)[i];
+                const mm_f32x2 e = ldsr2(L::EM(1) + e8);
+                const float a = as_global(r.init)[i];
+                const float v0 = a + e.x, v1 = a + e.y;
+                if (row_out_of_range(v0, thr)) *redo0 = 1;
+                if (row_out_of_range(v1, thr)) *redo1 = 1;
+                ldsw2(L::PP(1) + 8u * i, fast_exp2(v0), fast_exp2(v1));
+                U[0].rows[(long long)1 * S1p + i] = v0;
+                U[1].rows[(long long)1 * S1p + i] = v1;
+            }
+        } else if (DIR == 1 && t0 == 1) {  // B[:, N+1] = one at the final state   (src/inference.jl:104)
+            if (tid == 0) ldsw2(L::PP(1) + 8u * r.fpos, 1.f, 1.f);
+        } else {  // phase B: the vector this agent stored at the end of phase A
+            const int f = frame_of(t0);
+            for (int i = tid; i < S1; i += 64 * NWC) {
+                float v0 = U[0].rows[(long long)f * S1p + i], v1 = U[1].rows[(long long)f * S1p + i];
+                if (DIR == 1) {  // beta~ is stored without the frame's emission
+                    const mm_f32x2 e = ldsr2(L::EM(t0 & 1) + 8u * as_global(r.rowpdf)[i]);
+                    v0 += e.x;
+                    v1 += e.y;
+                }
+                ldsw2(L::PP(t0 & 1) + 8u * i, fast_exp2(v0), fast_exp2(v1));
+            }
+        }
+        load_graph();
+        __syncthreads();  // (2)
+        auto step = [&](auto RDc, int t) {
+            constexpr int RD = decltype(RDc)::value, WR = 1 - RD;
+            if (nslots > 0) {
+                mm_f32x2 x[2 * D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    x[2 * j] = ldsr2(rg.a[(2 * j < KA) ? 2 * j : 0] + L::PP(RD));
+                    x[2 * j + 1] = ldsr2(rg.a[(2 * j + 1 < KA) ? 2 * j + 1 : 0] + L::PP(RD));
+                }
+                unsigned sa = slot_base;
+                unsigned info = ldsru(sa), info2 = PHASE ? ldsru(sa + 4u) : 0u;
+                const mm_f32x2 S = ldsr2(L::MS(WR));  // the step's normalisers, posted by the service wave
+                mm_f32x2 e = ldsr2((info >> 16) + L::EM(WR));
+                const int f = frame_of(t);
+                const unsigned alb = L::AL(0, 0) + (unsigned)(t % 3) * 2u * RS;
+                float al0 = 0.f, al1 = 0.f;
+                if constexpr (PHASE == 1) {
+                    al0 = ldsr((info2 & 0xffffu) + alb);
+                    al1 = ldsr((info2 & 0xffffu) + alb + RS);
+                }
+                float *row0 = U[0].rows + (long long)(f <= p.N ? f : 0) * S1p, *row1 = U[1].rows + (long long)(f <= p.N ? f : 0) * S1p;
+                float acc0 = 0.f, acc1 = 0.f;
+                unsigned long long lgw = lgw0;
+                int left = nslots;
+                auto finish = [&]() {
+                    const int lg = (int)(lgw & 15ull);
+                    lgw >>= 4;
+                    float s0 = acc0, s1 = acc1;
+                    if (lg) {
+                        s0 = grp_sum_last(s0, lg);
+                        s1 = grp_sum_last(s1, lg);
+                    }
+                    const unsigned pos8 = info & 0xffffu;
+                    // forward: (T' alpha) (*) lhs (src/inference.jl:70-71); backward: T (B (*) lhs) (:106-107), the emission is
+                    // added for the next step's product only
+                    const float b0 = fast_log2(s0) - S.x, b1 = fast_log2(s1) - S.y;
+                    const float y0 = b0 + e.x, y1 = b1 + e.y;
+                    if (__builtin_expect(row_out_of_range(y0, thr), 0)) *redo0 = 1;
+                    if (__builtin_expect(row_out_of_range(y1, thr), 0)) *redo1 = 1;
+                    ldsw2(pos8 + L::PP(WR), fast_exp2(y0), fast_exp2(y1));
+                    const float st0 = DIR ? b0 : y0, st1 = DIR ? b1 : y1;  // the vector that is stored / combined
+                    if constexpr (PHASE == 0) {
+                        *reinterpret_cast<float *>(reinterpret_cast<char *>(row0) + (pos8 >> 1)) = st0;
+                        *reinterpret_cast<float *>(reinterpret_cast<char *>(row1) + (pos8 >> 1)) = st1;
+                    } else {
+                        ldsw2((info2 >> 16) + L::Q(WR), fast_exp2(st0 + al0), fast_exp2(st1 + al1));  // A .* B   (:154)
+                    }
+                    acc0 = acc1 = 0.f;
+                    sa += 512u;
+                    info = ldsru(sa);
+                    e = ldsr2((info >> 16) + L::EM(WR));
+                    if constexpr (PHASE == 1) {
+                        info2 = ldsru(sa + 4u);
+                        al0 = ldsr((info2 & 0xffffu) + alb);
+                        al1 = ldsr((info2 & 0xffffu) + alb + RS);
+                    }
+                };
+                asm volatile("" : "+s"(em_lo), "+s"(em_hi));
+                pair_pairs<0, KA, D>(rg.w, rg.a, x, acc0, acc1, L::PP(RD), em_lo, em_hi, left, finish);
+            }
+            if constexpr (PHASE == 1)  // C' * (A .* B) of the previous step (:155)
+                if (t - 1 > t0) pair_pdf_sums(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane);
+            __syncthreads();
+        };
+        for (int t = t0 + 1; t <= t1; t += 2) {
+            if (t & 1) step(std::integral_constant<int, 0>{}, t);
+            else step(std::integral_constant<int, 1>{}, t);
+            if (t + 1 <= t1) {
+                if ((t + 1) & 1) step(std::integral_constant<int, 0>{}, t + 1);
+                else step(std::integral_constant<int, 1>{}, t + 1);
+            }
+        }
+        if constexpr (PHASE == 1) {
+            if (t1 > t0) pair_pdf_sums(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane);
+            __syncthreads();  // (a)
+        }
+    }
+}
+
+template <int KA, int RS, int PHASE>
+__global__ void __launch_bounds__(1024) mm_fbp_kernel(RunParams p) {
+    const int pair = blockIdx.x >> 1;
+    if (blockIdx.x & 1) pair_agent<KA, RS, PHASE, 1>(p, pair);
+    else pair_agent<KA, RS, PHASE, 0>(p, pair);
+}
+
+// ttl = min over the frames of the per-frame log-normaliser (src/inference.jl:159); zeros beyond the sequence lengths
+__global__ void mm_pair_finish_kernel(RunParams p) {
+    const int b = blockIdx.x;
+    int len = p.lens ? p.lens[b] : p.N;
+    len = len < 0 ? 0 : (len > p.N ? p.N : len);
+    const int P = p.utts[b].P1 - 1;
+    if (threadIdx.x == 0) {
+        const double z0 = p.pair_zmin[2 * b], z1 = p.pair_zmin[2 * b + 1];
+        const double z = z0 < z1 ? z0 : z1;
+        p.ttl[b] = (z < __builtin_inf()) ? (float)(z * (double)MM_LN2) : MM_NINF;  // (no frame: no path of length 0)
+    }
+    const long long gbase = (long long)b * p.gsb;
+    for (long long q = threadIdx.x; q < (long long)(p.N - len) * P; q += blockDim.x)
+        p.gamma[gbase + (len + q / P) * p.gsn + (q % P) * p.gsp] = 0.f;
+}
+
+}  // namespace mm

@@ -78,6 +78,7 @@ struct UttDesc {
     GraphDev g[2];  // 0: T_hat' packed (forward), 1: T_hat packed (backward)
     QuadDev q[2];   // same two matrices in quad form (log semiring only)
     RowDev r[2];    // ... and in row-lane form (log semiring only; KA == 0: not available)
+    RowDev rp[2];   // ... and in the pair variant of the row-lane form (mm_rows.h RowPackOpts::pair)
     const float *init_f;            // alpha_hat in forward numbering
     const unsigned short *map_bf;   // backward position -> forward position
     const float *init;  // dense alpha_hat [S1] (log2 domain for MM_LOG, natural for MM_TROPICAL)
@@ -117,6 +118,12 @@ struct RunParams {
     // Row kernels: redo[b] != 0 marks an utterance whose linear-domain sums left the trusted range; the exact kernels
     // launched after them skip every utterance that is not marked (NULL: run all).
     int *redo;
+    // Pair kernels (mm_kernel_pairs.hip): ws_alpha holds [B + 1][N + 2][pair_s1p] state vectors, ws_c [B + 1][N + 2]
+    // cumulative offsets; pair_hand [pairs][2 directions][2 utterances] what phase A hands to phase B; pair_zmin
+    // [B][2 directions] the minimum over the frames of the per-frame log2 normaliser.
+    int pair_s1p;
+    void *pair_hand;
+    double *pair_zmin;
 };
 
 // In-kernel cycle stamps (diagnostic build only; the shipped library executes none).

@@ -151,7 +151,8 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                const std::vector<float> &val, const std::vector<int32_t> &row2pdf, int32_t P1, bool backward,
                const std::vector<int32_t> &fwd_pos, const RowPackOpts &opt, RowGraph &g) {
     g = RowGraph();
-    if (nrows < 1 || (nrows + 1) * 4 > opt.rs || (nrows + 1) * 4 > 65532 || P1 > 8000) return false;
+    if (nrows < 1 || (nrows + 1) * (opt.pair ? 8 : 4) > (opt.pair ? 2 : 1) * opt.rs || (nrows + 1) * 8 > 65528 || P1 > 8000)
+        return false;
     // ---- schedule: the cap on arcs per lane of one row decides how many rows are split over lane groups; take
     // the cap whose most loaded wave is cheapest
     Plan best;
@@ -168,7 +169,11 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     g.NWC = NWC;
     g.rs = opt.rs;
     g.trash = int(nrows);
-    g.slot_words = backward ? 2 : 1;
+    g.slot_words = (backward || opt.pair) ? 2 : 1;
+    g.scale = opt.pair ? 8 : 4;
+    g.ncopy = opt.pair ? 1 : 2;
+    const uint32_t SC = uint32_t(g.scale);
+    const bool want_q = backward || opt.pair;  // pdf-major positions
     g.maxcost = best.maxcost;
     g.mincost = best.mincost;
     // ---- numbering: the order in which the rows are finished
@@ -189,7 +194,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     for (int64_t i = 0; i < nrows; ++i) g.rowpdf[i] = uint16_t(row2pdf[g.order[i]]);
     // pdf-major order of the rows (backward: the posterior of a pdf is a sum over contiguous entries)
     std::vector<int32_t> qpos(size_t(nrows), 0);
-    if (backward) {
+    if (want_q) {
         std::vector<int32_t> byp(static_cast<size_t>(nrows));
         std::iota(byp.begin(), byp.end(), 0);
         std::stable_sort(byp.begin(), byp.end(), [&](int32_t a, int32_t b) { return row2pdf[a] < row2pdf[b]; });
@@ -232,6 +237,9 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     g.w.assign(size_t(KA) * NT, 0.f);
     g.addr.assign(size_t(KA) * NT, 0u);
     const uint32_t copy1 = uint32_t(opt.rs + 64);
+    const uint32_t ncopy = uint32_t(g.ncopy);
+    // (bank model: a 4-byte read occupies bank (a / 4) % 32; an 8-byte read of the pair form the bank pair
+    // (a / 8) % 32 -- the same structure, so the pair addresses are modelled as a / 2)
     double cyc_naive = 0, cyc_sched = 0;
     int64_t n_instr = 0, real_arcs = 0;
     int slotrow = 0;
@@ -252,11 +260,12 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                 // the LAST lane of a row's group holds the group sum and finishes the row; the others finish nothing
                 if (grp < int(s.rows.size()) && l % s.g == s.g - 1) {
                     const int32_t r = s.rows[grp];
-                    g.slots[e] = uint32_t(4 * g.pos[r]) | (uint32_t(4 * row2pdf[r]) << 16);
-                    if (backward) g.slots[e + 1] = uint32_t(4 * fwd_pos[r]) | (uint32_t(4 * qpos[r]) << 16);
+                    g.slots[e] = uint32_t(SC * g.pos[r]) | (uint32_t(SC * row2pdf[r]) << 16);
+                    if (g.slot_words == 2)
+                        g.slots[e + 1] = uint32_t(4 * (fwd_pos.empty() ? 0 : fwd_pos[r])) | (uint32_t(SC * qpos[r]) << 16);
                 } else {
-                    g.slots[e] = uint32_t(4 * g.trash) | (uint32_t(4 * zero_pdf) << 16);
-                    if (backward) g.slots[e + 1] = 0u | (uint32_t(4 * g.trash) << 16);
+                    g.slots[e] = uint32_t(SC * g.trash) | (uint32_t(SC * zero_pdf) << 16);
+                    if (g.slot_words == 2) g.slots[e + 1] = 0u | (uint32_t(SC * g.trash) << 16);
                 }
             }
             // arcs of the segment: every lane of a row's group takes every g-th arc; inside its A slots the
@@ -276,7 +285,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                 // naive placement (CSR order, copy 0) for the statistics
                 for (int l = 0; l < 32; ++l)
                     for (int k = 0; k < s.A; ++k)
-                        tabn[k].add(k < int(la[l].arcs.size()) ? uint32_t(4 * g.col[la[l].arcs[k]]) : uint32_t(4 * (l % int(nrows))));
+                        tabn[k].add(k < int(la[l].arcs.size()) ? uint32_t(4 * g.col[la[l].arcs[k]]) : uint32_t(4 * (l % int(nrows))));  // (model units)
                 // greedy: lane after lane, slot after slot, the remaining arc / copy that is cheapest there
                 std::vector<std::vector<uint32_t>> ad(32, std::vector<uint32_t>(s.A, 0u));
                 std::vector<std::vector<float>> wt(32, std::vector<float>(s.A, 0.f));
@@ -287,7 +296,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                         uint32_t baddr = 0;
                         for (size_t i = 0; i < la[l].arcs.size() && bcost > 0; ++i) {
                             if (used[i]) continue;
-                            for (uint32_t cp = 0; cp < 2; ++cp) {
+                            for (uint32_t cp = 0; cp < ncopy; ++cp) {
                                 const uint32_t a = uint32_t(4 * g.col[la[l].arcs[i]]) + cp * copy1;
                                 const int c = tab[k].cost_of(a);
                                 if (c < bcost) {
@@ -318,7 +327,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                         for (int k = 0; k < s.A; ++k) {
                             uint32_t a = ad[l][k];
                             if (!tab[k].conflicted(a)) continue;
-                            if (wt[l][k] != 0.f) {
+                            if (wt[l][k] != 0.f && ncopy > 1) {
                                 const uint32_t alt = a >= copy1 ? a - copy1 : a + copy1;
                                 const int before = tab[k].cycles();
                                 tab[k].remove(a);
@@ -361,7 +370,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                     for (int l = 0; l < 32; ++l) {
                         const size_t e = size_t(k0 + k) * NT + size_t(w) * 64 + half * 32 + l;
                         g.w[e] = wt[l][k];
-                        g.addr[e] = ad[l][k];
+                        g.addr[e] = opt.pair ? 2 * ad[l][k] : ad[l][k];  // (placement worked in 4-byte model units)
                     }
                 }
             }
@@ -373,8 +382,8 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     // the padding row of the slot table
     for (int l = 0; l < 64; ++l) {
         const size_t e = (size_t(slotrow) * 64 + l) * g.slot_words;
-        g.slots[e] = uint32_t(4 * g.trash) | (uint32_t(4 * zero_pdf) << 16);
-        if (backward) g.slots[e + 1] = 0u | (uint32_t(4 * g.trash) << 16);
+        g.slots[e] = uint32_t(SC * g.trash) | (uint32_t(SC * zero_pdf) << 16);
+        if (g.slot_words == 2) g.slots[e + 1] = 0u | (uint32_t(SC * g.trash) << 16);
     }
     g.conflict_before = n_instr ? cyc_naive / double(n_instr) : 0;
     g.conflict_after = n_instr ? cyc_sched / double(n_instr) : 0;
@@ -383,6 +392,16 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     for (float v : val)
         if (v > -std::numeric_limits<float>::infinity()) g.wmin_log2 = std::min(g.wmin_log2, v);
     return true;
+}
+
+void set_partner(RowGraph &g, const std::vector<int32_t> &partner_pos) {
+    if (g.slot_words != 2) return;
+    const uint32_t SC = uint32_t(g.scale);
+    for (size_t e = 0; e < g.slots.size(); e += 2) {
+        const uint32_t p = (g.slots[e] & 0xffffu) / SC;
+        if (int(p) == g.trash) continue;
+        g.slots[e + 1] = (g.slots[e + 1] & 0xffff0000u) | uint32_t(4 * partner_pos[g.order[p]]);
+    }
 }
 
 void eval_rows(const RowGraph &g, const float *in_lin, float *out_lin) {
@@ -398,8 +417,8 @@ void eval_rows(const RowGraph &g, const float *in_lin, float *out_lin) {
                 for (int l = 0; l < 64; ++l) {
                     const size_t e = size_t(k) * NT + size_t(w) * 64 + l;
                     uint32_t a = g.addr[e];
-                    if (a >= copy1) a -= copy1;
-                    acc[l] = std::fmaf(g.w[e], in_lin[a / 4], acc[l]);
+                    if (g.ncopy > 1 && a >= copy1) a -= copy1;
+                    acc[l] = std::fmaf(g.w[e], in_lin[a / uint32_t(g.scale)], acc[l]);
                 }
             if (!((sc.endmask >> k2) & 1)) continue;
             const int lg = int((sc.lg >> (4 * slot)) & 15), gsz = 1 << lg;
@@ -407,7 +426,7 @@ void eval_rows(const RowGraph &g, const float *in_lin, float *out_lin) {
                 float s = 0.f;
                 for (int l = l0; l < l0 + gsz; ++l) s += acc[l];
                 const uint32_t info = g.slots[(size_t(sc.slot0 + slot) * 64 + l0 + gsz - 1) * g.slot_words];
-                const int p = int(info & 0xffffu) / 4;
+                const int p = int(info & 0xffffu) / g.scale;
                 if (p != g.trash) out_lin[p] = s;
             }
             for (int l = 0; l < 64; ++l) acc[l] = 0.f;

@@ -57,6 +57,8 @@ struct RowGraph {
                                   // gets position `trash` and the pdf slot that always holds zero(K); backward only,
                                   // word 1 = 4 * (position in the forward numbering) | (4 * position in pdf-major order) << 16
     int slot_words = 1;
+    int scale = 4;      // bytes per position in the addresses and slot-table fields (8: pair form)
+    int ncopy = 2;      // copies of the linear vector the addresses refer to
     std::vector<RowSched> sched;  // [NWC]
     std::vector<uint16_t> rowpdf; // [rows] pdf of the row at each position
     // CSR in internal numbering with log2-domain weights: the exact fallback walks these
@@ -80,6 +82,12 @@ struct RowPackOpts {
     // and spend the tail of the frame alone, latency bound (measured with cycle stamps: +30 % for the last group).
     // The segments are dealt so that load / speed is level.
     float group_speed[4] = {1.0f, 0.92f, 0.80f, 0.70f};
+    // Pair form (mm_kernel_pairs.hip: two utterances per workgroup share the graph registers; the linear vector holds
+    // their values side by side, 8 bytes per state, fetched by one ds_read_b64): addresses and slot-table fields are
+    // 8 * position / 8 * pdf, ONE copy of the vector (the pair kernels are not bound by the LDS), and the slot table
+    // has two words in both directions: word 1 = 4 * (position in the OTHER direction's numbering) |
+    // (8 * position in pdf-major order) << 16 (set_partner() fills the forward form's once the backward form exists).
+    bool pair = false;
 };
 
 // rowptr/col/val_log2: 0-based CSR of M (out[r] = (+)_k val[k] (*) in[col[k]]), square, nrows rows.
@@ -88,6 +96,10 @@ struct RowPackOpts {
 bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &col,
                const std::vector<float> &val_log2, const std::vector<int32_t> &row2pdf, int32_t P1, bool backward,
                const std::vector<int32_t> &fwd_pos, const RowPackOpts &opt, RowGraph &out);
+
+// Pair forms: write the other direction's numbering into word 1 of the slot table (partner_pos: original row ->
+// position in the other direction).
+void set_partner(RowGraph &g, const std::vector<int32_t> &partner_pos);
 
 // Host evaluation of one product through the row form exactly as a workgroup walks it (lane by lane, segment
 // by segment, group sums), in the linear domain: in_lin[position] -> out_lin[position].  Test aid.

@@ -261,7 +261,8 @@ def main():
             cores = host_cores()
             n1 = max(1, min(4, int(round(6000 / max(N, 1)))))  # ~10 s at ~600 frames/s
             v1, dt1 = cpu_baseline(g, N, 1, n1)
-            nb = 2 * cores
+            per_thread = max(2, int(round(15.0 * v1 / max(N, 1))))  # ~15 s of work per thread at the one-thread rate
+            nb = per_thread * cores
             v, dt = cpu_baseline(g, N, cores, nb)
             out["cpu_baseline"] = {
                 "value": v,
@@ -269,7 +270,7 @@ def main():
                 "cores": cores,
                 "kind": "port",
                 "sample": f"{nb} utterances x {N} frames of the same workload, float32, OpenMP over utterances "
-                          f"(2 per thread), {dt:.1f} s",
+                          f"({per_thread} per thread), {dt:.1f} s",
                 "one_thread": {
                     "value": v1,
                     "unit": "frames/s",

@@ -697,6 +697,8 @@ static int pair_variants(mm_fsm_t f, bool verbose, bool *ok) {
     opt.rs = MM_ROW_RS;
     opt.ka_max = 44;
     opt.pair = true;
+    opt.ka_choices[0] = 40;
+    opt.ka_choices[1] = 44;
     RowVariant *rv[2] = {new RowVariant(), new RowVariant()};
     const std::vector<int32_t> none;
     bool fits = make_rows(f->S1, f->qmat[0].rowptr, f->qmat[0].col, f->qmat[0].val, f->s2p, f->P1, false, none, opt, rv[0]->g) &&
@@ -707,7 +709,7 @@ static int pair_variants(mm_fsm_t f, bool verbose, bool *ok) {
         if (verbose)
             fprintf(stderr, "[mm] pair form dir %d: KA %d, %d compute waves, %d segments, arcs/slots %.3f, cost %d..%d, "
                             "LDS cycles/gather (bank model) %.2f -> %.2f\n",
-                    dir, rv[dir]->g.KA, rv[dir]->g.NWC, rv[dir]->g.nslotrows - 1, rv[dir]->g.pad_eff, rv[dir]->g.mincost,
+                    dir, rv[dir]->g.KA, rv[dir]->g.NWC, rv[dir]->g.nslotrows - 2, rv[dir]->g.pad_eff, rv[dir]->g.mincost,
                     rv[dir]->g.maxcost, rv[dir]->g.conflict_before, rv[dir]->g.conflict_after);
         if (dir == 0) {
             rv[0]->init.resize(size_t(f->S1));
@@ -737,6 +739,7 @@ static int row_variants(mm_fsm_t f, bool verbose, bool *ok) {
     RowPackOpts opt;
     opt.rs = MM_ROW_RS;
     opt.ka_max = kRowKA[sizeof(kRowKA) / sizeof(kRowKA[0]) - 1];
+    for (size_t i = 0; i < sizeof(kRowKA) / sizeof(kRowKA[0]); ++i) opt.ka_choices[i] = kRowKA[i];
     RowVariant *rv[2] = {new RowVariant(), new RowVariant()};
     const std::vector<int32_t> none;
     // (arc weights below 2^-60 leave too little of the float range to the values: such graphs run on the other kernels)
@@ -754,7 +757,7 @@ static int row_variants(mm_fsm_t f, bool verbose, bool *ok) {
         if (verbose)
             fprintf(stderr, "[mm] row form dir %d: KA %d, %d compute waves, %d segments, arcs/slots %.3f, cost %d..%d, "
                             "LDS cycles/gather (bank model) %.2f -> %.2f\n",
-                    dir, v->g.KA, v->g.NWC, v->g.nslotrows - 1, v->g.pad_eff, v->g.mincost, v->g.maxcost, v->g.conflict_before,
+                    dir, v->g.KA, v->g.NWC, v->g.nslotrows - 2, v->g.pad_eff, v->g.mincost, v->g.maxcost, v->g.conflict_before,
                     v->g.conflict_after);
         if (verbose)
             for (int w = 0; w < v->g.NWC; ++w) {
@@ -762,8 +765,8 @@ static int row_variants(mm_fsm_t f, bool verbose, bool *ok) {
                 int last = 0;
                 for (int k = 0; k < 64; ++k)
                     if ((sc.endmask >> k) & 1) last = k;
-                fprintf(stderr, "[mm]   wave %2d: %u segments, %d arcs, lg %llx\n", w, sc.nslots, 2 * (last + 1),
-                        (unsigned long long)sc.lg);
+                fprintf(stderr, "[mm]   wave %2d: %u segments, %d arcs, lg %llx\n", w, sc.nslots & 0xffffu,
+                        2 * (last + 1 - int(sc.nslots >> 16)), (unsigned long long)sc.lg);
             }
         if (dir == 0) {
             v->init.resize(f->S1);
@@ -917,7 +920,7 @@ int mm_debug_row_product(mm_fsm_t f, int direction, const float *in, float *out,
     if (stats) {
         stats[0] = g.KA;
         stats[1] = g.NWC;
-        stats[2] = g.nslotrows - 1;
+        stats[2] = g.nslotrows - 2;
         stats[3] = g.pad_eff;
         stats[4] = g.maxcost;
         stats[5] = g.mincost;

@@ -85,38 +85,73 @@ __device__ __forceinline__ float pair_stage_em(unsigned dst, unsigned rawsrc, in
     return E;
 }
 
-// service wave: log2 of the maxima of both linear vectors (pairs [pos][2]; n2 float4s = 2 states each)
+// service wave: log2 of the maxima of both linear vectors (pairs [pos][2]; n2 float4s = 2 states each, n2 <= 64 * NB).
+// All loads are issued before the first maximum (clamped indices: a duplicate changes no maximum) -- a loop with one
+// load per trip costs the wave one LDS round trip per trip, and the service wave is the one wave whose own latency
+// chain every step waits for.
+template <int NB>
 __device__ __forceinline__ void pair_scan_max(unsigned pbase, int n2, int lane, float &m0, float &m1) {
     float a = 0.f, b = 0.f;
-    for (int q = lane; q < n2; q += 64) {
-        const mm_f32x4 v = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(pbase + 16u * q);
-        a = max_nc(a, max_nc(v.x, v.z));
-        b = max_nc(b, max_nc(v.y, v.w));
+#pragma unroll
+    for (int j0 = 0; j0 < NB; j0 += 4) {  // (batches of 4 loads: 16 registers; more spill in the phase B kernels)
+        mm_f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = lane + 64 * (j0 + j);
+            v[j] = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(pbase + 16u * (q < n2 ? q : n2 - 1));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a = max_nc(a, max_nc(v[j].x, v[j].z));
+            b = max_nc(b, max_nc(v[j].y, v[j].w));
+        }
     }
     m0 = fast_log2(wave_max_rl(a));
     m1 = fast_log2(wave_max_rl(b));
 }
 
-// one wave: per-frame sum over the pdfs of utterance u (psum pairs [pdf][2]), divide, store gamma
-// (src/inference.jl:156-160); returns log2 of the sum (-inf, and gamma = 0, if nothing is alive)
-__device__ __forceinline__ float pair_finish_frame(unsigned psum, int u, int P1, int P, int lane, float *gp, long long gsp, bool store) {
-    float s[4], tot = 0.f;
+// wave-wide sum without the LDS crossbar: 16-lane rows by DPP, then the 4 row results through readlane
+__device__ __forceinline__ float wave_sum_rl(float v) {
+    v += dpp_mov<MM_DPP_XOR1>(v);
+    v += dpp_mov<MM_DPP_XOR2>(v);
+    v += dpp_mov<MM_DPP_HALF_MIRROR>(v);
+    v += dpp_mov<MM_DPP_MIRROR>(v);
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// one wave, both utterances of the pair: per-frame sums over the pdfs (psum pairs [pdf][2]), divide, store gamma
+// (src/inference.jl:156-160); lt[u] = log2 of the sum (-inf, and gamma = 0, if nothing is alive)
+__device__ __forceinline__ void pair_finish_frames(unsigned psum, int P1, int P, int lane, float *gp0, float *gp1, long long gsp,
+                                                   bool store0, bool store1, float (&lt)[2]) {
+    mm_f32x2 s[4];
+    float t0 = 0.f, t1 = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int q = lane + 64 * j;
-        s[j] = q < P1 ? ldsr(psum + 8u * q + 4u * u) : 0.f;
-        tot += s[j];
-    }
-    tot = wave_sum(tot);
-    const float inv = tot > 0.f ? 1.f / tot : 0.f;
-    if (store) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = lane + 64 * j;
-            if (q < P) gp[q * gsp] = s[j] * inv;
+        s[j] = ldsr2(psum + 8u * (q < P1 ? q : 0));
+        if (q < P1) {
+            t0 += s[j].x;
+            t1 += s[j].y;
         }
     }
-    return fast_log2(tot);
+    t0 = wave_sum_rl(t0);
+    t1 = wave_sum_rl(t1);
+    const float i0 = t0 > 0.f ? 1.f / t0 : 0.f, i1 = t1 > 0.f ? 1.f / t1 : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = lane + 64 * j;
+        if (q < P) {
+            if (store0) gp0[q * gsp] = s[j].x * i0;
+            if (store1) gp1[q * gsp] = s[j].y * i1;
+        }
+    }
+    lt[0] = fast_log2(t0);
+    lt[1] = fast_log2(t1);
 }
 
 // pdf sums of both utterances (q pairs in pdf-major order): 8 pdfs per wave and pass, 8 lanes per pdf
@@ -148,10 +183,14 @@ __device__ __forceinline__ void pair_pdf_sums(unsigned qbase, unsigned pdfse_bas
     }
 }
 
-// the arcs of a compute wave, two at a time, for two utterances (row_pairs with 8-byte gathers)
-template <int K2, int KA, int D, class F>
-__device__ __forceinline__ void pair_pairs(const float (&wr)[KA], const unsigned (&ar)[KA], mm_f32x2 (&x)[2 * D], float &acc0,
-                                           float &acc1, unsigned rdoff, unsigned em_lo, unsigned em_hi, int &slots_left, F &&finish) {
+// The arcs of a compute wave, two at a time, for two utterances (8-byte gathers, D pairs ahead of the FMAs), statically
+// unrolled (the graph registers need static indices).  A segment may end after any pair (wave-uniform bit test).  Every
+// wave runs the whole window: the pairs behind its last segment have weight 0 (a few wasted gathers); leaving early
+// costs more -- however it is written, the compiler keeps a "done" flag that every pair re-tests (3 scalar
+// instructions per pair).
+template <int K2, int KA, int D>
+__device__ __forceinline__ void pair_one(const float (&wr)[KA], const unsigned (&ar)[KA], mm_f32x2 (&x)[2 * D], float &acc0,
+                                         float &acc1, unsigned rdoff) {
     constexpr int s0 = (2 * K2) % (2 * D);
     acc0 = fmaf(wr[2 * K2], x[s0].x, acc0);
     acc1 = fmaf(wr[2 * K2], x[s0].y, acc1);
@@ -161,12 +200,14 @@ __device__ __forceinline__ void pair_pairs(const float (&wr)[KA], const unsigned
         x[s0] = ldsr2(ar[2 * (K2 + D)] + rdoff);
         x[s0 + 1] = ldsr2(ar[2 * (K2 + D) + 1] + rdoff);
     }
-    if (((K2 < 32 ? em_lo : em_hi) >> (K2 & 31)) & 1u) {
-        finish();
-        if (--slots_left == 0) return;
-    }
-    if constexpr (K2 + 1 < KA / 2) pair_pairs<K2 + 1, KA, D>(wr, ar, x, acc0, acc1, rdoff, em_lo, em_hi, slots_left, finish);
 }
+#define MM_PAIR_ONE(k)                                                                       \
+    if constexpr (2 * (k) < KA) {                                                            \
+        pair_one<(2 * (k) < KA ? (k) : 0), KA, D>(rg.w, rg.a, x, acc0, acc1, rdoff);         \
+        if ((((k) < 32 ? em_lo : em_hi) >> ((k) & 31)) & 1u) finish();                       \
+    }
+#define MM_PAIR_CASES(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) \
+    M(20) M(21) M(22) M(23)
 
 struct PairHand {  // what an agent hands from phase A to phase B, per utterance
     float m_prev, s_cur, s_prev, cbar;
@@ -215,6 +256,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
     auto frame_of = [&](int t) { return DIR ? NFp + 1 - t : t; };
     PairHand *hand = reinterpret_cast<PairHand *>(p.pair_hand) + ((long long)pair * 2 + DIR) * 2;
     if (lds_addr_of(lds) != 0u) __builtin_trap();
+    MM_STAMP_DECL;
 
     // ---- LDS set-up
     for (unsigned q = tid * 4u; q < 2u * L::RS2; q += NT * 4u) ldsw(L::PP(0) + q, 0.f);
@@ -232,13 +274,14 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
         *redo1 = 0;
     }
     unsigned long long endmask = 0, lgw0 = 0;
-    int nslots = 0;
+    int nslots = 0, start2 = 0;
     unsigned slot_base = 0;
     if (!service && wave < r.NWC) {
         const RowSched &sc = r.sched[wave];
         endmask = sc.endmask;
         lgw0 = sc.lg;
-        nslots = (int)sc.nslots;
+        nslots = (int)(sc.nslots & 0xffffu);
+        start2 = (int)(sc.nslots >> 16);
         slot_base = L::SLOTS + (sc.slot0 * 64u + lane) * 8u;
     }
     unsigned em_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)endmask);
@@ -246,6 +289,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
     lgw0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(lgw0 >> 32)) << 32) |
            (unsigned)__builtin_amdgcn_readfirstlane((unsigned)lgw0);
     nslots = __builtin_amdgcn_readfirstlane(nslots);
+    start2 = __builtin_amdgcn_readfirstlane(start2);
     RowRegs<KA> rg;
     auto load_graph = [&]() {
         static_assert(KA <= MM_ROW_KA_PAD, "register window larger than the padding of the device arrays");
@@ -356,13 +400,30 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
         }
         dma_raw(t0 + 4);
         __syncthreads();  // (2) starting vector in LDS, step t0 + 1 prepared
+        // posteriors and per-frame log Z of step ts (its per-pdf sums are complete)
+        auto frames_of_step = [&](int ts, unsigned psum) {
+            const int f = frame_of(ts);
+            const bool live0 = f >= 1 && f <= U[0].len, live1 = f >= 1 && f <= U[1].len;
+            float lt[2];
+            pair_finish_frames(psum, P1, P, lane, p.gamma + (long long)U[0].b * p.gsb + (long long)(f - 1) * p.gsn,
+                               p.gamma + (long long)U[1].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp, live0 && U[0].valid,
+                               live1 && U[1].valid, lt);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (u ? live1 : live0) {
+                    const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN(ts & 3) + 8u * u);
+                    const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 512u * (ts & 7));
+                    const double z = (double)lt[u] + own + oth;
+                    zmin[u] = z < zmin[u] ? z : zmin[u];
+                }
+        };
         auto step = [&](auto RDc, int t) {
             constexpr int RD = decltype(RDc)::value, WR = 1 - RD;  // RD = parity of steps t - 1 and t + 1
             // emissions of step t + 1 (requested at step t - 2: the DMAs of step t - 1 may still be in flight)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
             // the normaliser of step t + 1 from the maxima of step t - 1 (complete since the last barrier)
             float mx[2];
-            pair_scan_max(L::PP(RD), (S1 + 2) >> 1, lane, mx[0], mx[1]);
+            pair_scan_max<(RS / 8 + 63) / 64>(L::PP(RD), (S1 + 2) >> 1, lane, mx[0], mx[1]);
             if (t + 1 <= tEnd) {
                 const float S[2] = {norm[0].next(mx[0]), norm[1].next(mx[1])};
                 if (t + 1 <= t1) stage(t + 1, S);
@@ -371,27 +432,15 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
             if constexpr (PHASE == 1) {
                 dma_partner(t + 2);
                 // gamma of step t - 2: its per-pdf sums were completed in the previous step
-                if (t - 2 > t0) {
-                    const int f = frame_of(t - 2);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const bool live = f >= 1 && f <= U[u].len;
-                        const float lt = pair_finish_frame(L::PSUM(WR), u, P1, P, lane,
-                                                           p.gamma + (long long)U[u].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp,
-                                                           live && U[u].valid);
-                        if (live) {
-                            const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN((t - 2) & 3) + 8u * u);
-                            const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 512u * ((t - 2) & 7));
-                            const double z = (double)lt + own + oth;
-                            zmin[u] = z < zmin[u] ? z : zmin[u];
-                        }
-                    }
-                }
+                if (t - 2 > t0) frames_of_step(t - 2, L::PSUM(WR));
                 // the partner vector of step t + 1 (requested at step t - 1) must be in LDS when the compute waves leave the barrier
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
             }
-            __syncthreads();
+            MM_STAMP(0);
+            MM_STEP_SYNC();
+            MM_STAMP(1);
         };
+        MM_STAMP_RESET;
         for (int t = t0 + 1; t <= t1; t += 2) {
             if (t & 1) step(std::integral_constant<int, 0>{}, t);
             else step(std::integral_constant<int, 1>{}, t);
@@ -421,22 +470,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
             for (int k = 1; k >= 0; --k) {
                 const int t = t1 - k;
                 if (k == 0) __syncthreads();  // (a)
-                if (t > t0) {
-                    const int f = frame_of(t);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const bool live = f >= 1 && f <= U[u].len;
-                        const float lt = pair_finish_frame(L::PSUM(t & 1), u, P1, P, lane,
-                                                           p.gamma + (long long)U[u].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp,
-                                                           live && U[u].valid);
-                        if (live) {
-                            const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN(t & 3) + 8u * u);
-                            const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 512u * (t & 7));
-                            const double z = (double)lt + own + oth;
-                            zmin[u] = z < zmin[u] ? z : zmin[u];
-                        }
-                    }
-                }
+                if (t > t0) frames_of_step(t, L::PSUM(t & 1));
             }
             if (lane == 0) {
 #pragma unroll
@@ -479,14 +513,18 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
         auto step = [&](auto RDc, int t) {
             constexpr int RD = decltype(RDc)::value, WR = 1 - RD;
             if (nslots > 0) {
+                constexpr unsigned rdoff = L::PP(RD);
                 mm_f32x2 x[2 * D];
 #pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    x[2 * j] = ldsr2(rg.a[(2 * j < KA) ? 2 * j : 0] + L::PP(RD));
-                    x[2 * j + 1] = ldsr2(rg.a[(2 * j + 1 < KA) ? 2 * j + 1 : 0] + L::PP(RD));
+                for (int j = 0; j < D; ++j) {  // the first gathers leave before anything else
+                    x[2 * j] = ldsr2(rg.a[(2 * j < KA) ? 2 * j : 0] + rdoff);
+                    x[2 * j + 1] = ldsr2(rg.a[(2 * j + 1 < KA) ? 2 * j + 1 : 0] + rdoff);
                 }
+                // the slot table runs one segment ahead (infoN / info2N), so that the emission and partner reads of a segment,
+                // which need its slot word as their address, never wait for a load issued just before them
                 unsigned sa = slot_base;
                 unsigned info = ldsru(sa), info2 = PHASE ? ldsru(sa + 4u) : 0u;
+                unsigned infoN = ldsru(sa + 512u), info2N = PHASE ? ldsru(sa + 516u) : 0u;
                 const mm_f32x2 S = ldsr2(L::MS(WR));  // the step's normalisers, posted by the service wave
                 mm_f32x2 e = ldsr2((info >> 16) + L::EM(WR));
                 const int f = frame_of(t);
@@ -499,7 +537,6 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                 float *row0 = U[0].rows + (long long)(f <= p.N ? f : 0) * S1p, *row1 = U[1].rows + (long long)(f <= p.N ? f : 0) * S1p;
                 float acc0 = 0.f, acc1 = 0.f;
                 unsigned long long lgw = lgw0;
-                int left = nslots;
                 auto finish = [&]() {
                     const int lg = (int)(lgw & 15ull);
                     lgw >>= 4;
@@ -513,8 +550,10 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                     // added for the next step's product only
                     const float b0 = fast_log2(s0) - S.x, b1 = fast_log2(s1) - S.y;
                     const float y0 = b0 + e.x, y1 = b1 + e.y;
-                    if (__builtin_expect(row_out_of_range(y0, thr), 0)) *redo0 = 1;
-                    if (__builtin_expect(row_out_of_range(y1, thr), 0)) *redo1 = 1;
+                    // (wave-uniform branches: a per-lane `if` here makes the compiler structurise the whole pair sequence --
+                    // a "done" flag re-tested before every pair)
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(row_out_of_range(y0, thr)) != 0ull, 0)) *redo0 = 1;
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(row_out_of_range(y1, thr)) != 0ull, 0)) *redo1 = 1;
                     ldsw2(pos8 + L::PP(WR), fast_exp2(y0), fast_exp2(y1));
                     const float st0 = DIR ? b0 : y0, st1 = DIR ? b1 : y1;  // the vector that is stored / combined
                     if constexpr (PHASE == 0) {
@@ -525,21 +564,26 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                     }
                     acc0 = acc1 = 0.f;
                     sa += 512u;
-                    info = ldsru(sa);
+                    info = infoN;
                     e = ldsr2((info >> 16) + L::EM(WR));
+                    infoN = ldsru(sa + 512u);
                     if constexpr (PHASE == 1) {
-                        info2 = ldsru(sa + 4u);
+                        info2 = info2N;
                         al0 = ldsr((info2 & 0xffffu) + alb);
                         al1 = ldsr((info2 & 0xffffu) + alb + RS);
+                        info2N = ldsru(sa + 516u);
                     }
                 };
                 asm volatile("" : "+s"(em_lo), "+s"(em_hi));
-                pair_pairs<0, KA, D>(rg.w, rg.a, x, acc0, acc1, L::PP(RD), em_lo, em_hi, left, finish);
+                MM_PAIR_CASES(MM_PAIR_ONE)
             }
             if constexpr (PHASE == 1)  // C' * (A .* B) of the previous step (:155)
                 if (t - 1 > t0) pair_pdf_sums(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane);
-            __syncthreads();
+            MM_STAMP(0);
+            MM_STEP_SYNC();
+            MM_STAMP(1);
         };
+        MM_STAMP_RESET;
         for (int t = t0 + 1; t <= t1; t += 2) {
             if (t & 1) step(std::integral_constant<int, 0>{}, t);
             else step(std::integral_constant<int, 1>{}, t);
@@ -553,10 +597,14 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
             __syncthreads();  // (a)
         }
     }
+#ifdef MM_STAMPS
+    if (p.dbg && lane == 0)  // [pair][wave][phase * 2 + dir][work, barrier]
+        for (int k = 0; k < 2; ++k) p.dbg[(((long long)pair * MM_MAX_WAVES + wave) * 4 + PHASE * 2 + DIR) * 2 + k] = stamp_acc[k];
+#endif
 }
 
 template <int KA, int RS, int PHASE>
-__global__ void __launch_bounds__(1024) mm_fbp_kernel(RunParams p) {
+__global__ void __launch_bounds__(1024) mm_fbp_kernel(RunParams p) {  // (both agents in one launch: spills; kept for reference)
     const int pair = blockIdx.x >> 1;
     if (blockIdx.x & 1) pair_agent<KA, RS, PHASE, 1>(p, pair);
     else pair_agent<KA, RS, PHASE, 0>(p, pair);

@@ -37,6 +37,17 @@ __device__ __forceinline__ unsigned ldsru(unsigned addr) { return *(lds_uptr)(__
 __device__ __forceinline__ void ldsw(unsigned addr, float v) { *(lds_fptr)(__UINTPTR_TYPE__)addr = v; }
 __device__ __forceinline__ void ldswu(unsigned addr, unsigned v) { *(lds_uptr)(__UINTPTR_TYPE__)addr = v; }
 
+// The barrier that ends a step.  The scheduling fences matter: with a bare __syncthreads() the compiler moves code of
+// the neighbouring steps across it in a way that cost the pair kernels 20 % (3.6 -> 4.4 ms per call, measured).
+#ifndef MM_STEP_SYNC
+#define MM_STEP_SYNC()                     \
+    do {                                   \
+        __builtin_amdgcn_sched_barrier(0); \
+        __syncthreads();                   \
+        __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+#endif
+
 #define MM_ROW_EMS 1024  // bytes per emission buffer: P1p + 4 <= 256 floats
 #define MM_ROW_KA_PAD 48 // arc-slot rows of the device arrays (>= every instantiated register window)
 
@@ -139,14 +150,21 @@ __device__ __forceinline__ float grp_sum_last(float v, int lg) {
     return v;
 }
 
-// Service wave: log2 of the maximum of the linear vector at LDS byte address pbase (n4 float4s); -inf if nothing is
-// alive.  (The log2 vector itself is not kept in LDS: one store per finish less.)
+// Service wave: log2 of the maximum of the linear vector at LDS byte address pbase (n4 float4s, n4 <= 64 * NB); -inf if
+// nothing is alive.  (The log2 vector itself is not kept in LDS: one store per finish less.)  All loads are issued
+// before the first maximum (clamped indices: a duplicate changes no maximum): a loop with one load per trip costs the
+// wave one LDS round trip per trip.
+template <int NB>
 __device__ __forceinline__ float row_scan_max(unsigned pbase, int n4, int lane) {
-    float m = 0.f;
-    for (int q = lane; q < n4; q += 64) {
-        const mm_f32x4 v = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(pbase + 16u * q);
-        m = max_nc(max_nc(m, max_nc(v.x, v.y)), max_nc(v.z, v.w));
+    mm_f32x4 v[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int q = lane + 64 * j;
+        v[j] = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(pbase + 16u * (q < n4 ? q : n4 - 1));
     }
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) m = max_nc(max_nc(m, max_nc(v[j].x, v[j].y)), max_nc(v[j].z, v[j].w));
     return fast_log2(wave_max_rl(m));
 }
 
@@ -362,7 +380,7 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
         const RowSched &sc = r.sched[wave];
         endmask = sc.endmask;
         lgw0 = sc.lg;
-        nslots = (int)sc.nslots;
+        nslots = (int)(sc.nslots & 0xffffu);  // (the wave's arcs are right-aligned in the window, mm_rows.h: the leading pairs are zero)
         slot_base = L::SLOTS + (sc.slot0 * 64u + lane) * (PASS ? 8u : 4u);
     }
     // graph registers of a compute wave: loaded at the top of the compute branch of each direction, so that they are
@@ -437,7 +455,7 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                 MM_ROW_VMCNT(4);
                 if (n + 1 <= NF) {
                     row_read_em(raw, L::RAW(0) + 1024u * ((n + 1) & 3), lane);
-                    const float M = norm.next(row_scan_max(L::P(RD, 0), (S1 + 3) >> 2, lane));
+                    const float M = norm.next(row_scan_max<(RS / 16 + 63) / 64>(L::P(RD, 0), (S1 + 3) >> 2, lane));
                     C += (double)M;
                     if (lane == 0) {
                         ldsw(L::MS(RD), M);
@@ -447,7 +465,7 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                 }
                 row_dma_em(L::RAW(0) + 1024u * ((n + 4) & 3), Vb, p.vsn, n + 4, p.N, P, lane);  // (its buffer was read at step n-1)
                 MM_STAMP(0);
-                __syncthreads();
+                MM_STEP_SYNC();
                 MM_STAMP(1);
             };
             MM_STAMP_RESET;
@@ -507,7 +525,7 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                     row_pairs<0, KA, D, L::P(RD, 0)>(rg.w, rg.a, x, acc, em_lo, em_hi, left, finish);
                 }
                 MM_STAMP(0);
-                __syncthreads();
+                MM_STEP_SYNC();
                 MM_STAMP(1);
             };
             MM_STAMP_RESET;
@@ -582,7 +600,7 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                 dma_arow(n - 2);
                 // the normaliser of frame n-1, from the maximum of y_{n+1} (complete since the last barrier)
                 if (n - 1 >= 1) {
-                    const float M = norm.next(row_scan_max(L::P(RD, 0), (S1 + 3) >> 2, lane));
+                    const float M = norm.next(row_scan_max<(RS / 16 + 63) / 64>(L::P(RD, 0), (S1 + 3) >> 2, lane));
                     G += (double)(n >= 3 ? wsM[n] : 0.f) - (double)M;  // G_{n-1} = G_n + S_n(forward) - S_{n-1}(backward)
                     if (lane == 0) {
                         ldsw(L::MS(RD), M);
@@ -598,7 +616,7 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                 // the alpha row of frame n-1 (requested at step n+1) must be in LDS when the compute waves leave the barrier
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NA) : "memory");
                 MM_STAMP(0);
-                __syncthreads();
+                MM_STEP_SYNC();
                 MM_STAMP(1);
             });
         } else {
@@ -656,7 +674,7 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                     if (P1 > 8 * NWC) pdf_sums_rest(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane);
                 }
                 MM_STAMP(0);
-                __syncthreads();
+                MM_STEP_SYNC();
                 MM_STAMP(1);
             });
         }

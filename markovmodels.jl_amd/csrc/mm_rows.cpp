@@ -164,7 +164,13 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     }
     if (!best.ok) return false;
     const int NWC = int(best.wave_segs.size());
-    const int KA = std::max(2, (best.KA + 1) & ~1), NT = 64 * NWC;
+    int KA = std::max(2, (best.KA + 1) & ~1);
+    for (int c : opt.ka_choices)
+        if (c >= KA) {
+            KA = c;
+            break;
+        }
+    const int NT = 64 * NWC;
     g.KA = KA;
     g.NWC = NWC;
     g.rs = opt.rs;
@@ -232,7 +238,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     g.sched.assign(NWC, RowSched{0, 0, 0, 0});
     int nslots = 0;
     for (int w = 0; w < NWC; ++w) nslots += int(best.wave_segs[w].size());
-    g.nslotrows = nslots + 1;  // + one padding row: the prefetch after a wave's last finish reads one row ahead
+    g.nslotrows = nslots + 2;  // + two padding rows: the prefetch after a wave's last finishes reads up to two rows ahead
     g.slots.assign(size_t(g.nslotrows) * 64 * g.slot_words, 0);
     g.w.assign(size_t(KA) * NT, 0.f);
     g.addr.assign(size_t(KA) * NT, 0u);
@@ -246,8 +252,11 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     for (int w = 0; w < NWC; ++w) {
         RowSched &sc = g.sched[w];
         sc.slot0 = uint32_t(slotrow);
-        sc.nslots = uint32_t(best.wave_segs[w].size());
-        int k0 = 0, sidx = 0;
+        int arcs_w = 0;
+        for (int si : best.wave_segs[w]) arcs_w += best.segs[si].A;
+        (void)arcs_w;
+        int k0 = 0, sidx = 0;  // left-aligned: the wave leaves the pair sequence after its last segment
+        sc.nslots = uint32_t(best.wave_segs[w].size()) | (uint32_t(k0 / 2) << 16);
         for (int si : best.wave_segs[w]) {
             const Segment &s = best.segs[si];
             const int lg = log2i(s.g);
@@ -379,12 +388,13 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
             ++slotrow;
         }
     }
-    // the padding row of the slot table
-    for (int l = 0; l < 64; ++l) {
-        const size_t e = (size_t(slotrow) * 64 + l) * g.slot_words;
-        g.slots[e] = uint32_t(SC * g.trash) | (uint32_t(SC * zero_pdf) << 16);
-        if (g.slot_words == 2) g.slots[e + 1] = 0u | (uint32_t(SC * g.trash) << 16);
-    }
+    // the padding rows of the slot table
+    for (int pr = 0; pr < 2; ++pr)
+        for (int l = 0; l < 64; ++l) {
+            const size_t e = (size_t(slotrow + pr) * 64 + l) * g.slot_words;
+            g.slots[e] = uint32_t(SC * g.trash) | (uint32_t(SC * zero_pdf) << 16);
+            if (g.slot_words == 2) g.slots[e + 1] = 0u | (uint32_t(SC * g.trash) << 16);
+        }
     g.conflict_before = n_instr ? cyc_naive / double(n_instr) : 0;
     g.conflict_after = n_instr ? cyc_sched / double(n_instr) : 0;
     g.pad_eff = n_instr ? double(real_arcs) / (32.0 * double(n_instr)) : 0;
@@ -412,7 +422,7 @@ void eval_rows(const RowGraph &g, const float *in_lin, float *out_lin) {
         float acc[64];
         for (int l = 0; l < 64; ++l) acc[l] = 0.f;
         int slot = 0;
-        for (int k2 = 0; k2 < g.KA / 2 && slot < int(sc.nslots); ++k2) {
+        for (int k2 = int(sc.nslots >> 16); k2 < g.KA / 2 && slot < int(sc.nslots & 0xffffu); ++k2) {
             for (int k = 2 * k2; k < 2 * k2 + 2; ++k)
                 for (int l = 0; l < 64; ++l) {
                     const size_t e = size_t(k) * NT + size_t(w) * 64 + l;

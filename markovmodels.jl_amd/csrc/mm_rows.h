@@ -36,7 +36,7 @@ struct RowSched {       // one compute wave
     uint64_t endmask;   // bit k: a segment ends after arc pair k (arcs 2k, 2k+1)
     uint64_t lg;        // log2(lanes per row) of the wave's i-th segment in bits [4i, 4i+4)
     uint32_t slot0;     // first row of the wave in the slot table
-    uint32_t nslots;    // segments of the wave (>= 1)
+    uint32_t nslots;    // segments of the wave (>= 1) | (first arc pair of the wave, currently always 0) << 16
 };
 static_assert(sizeof(RowSched) == 24, "RowSched must be 24 bytes");
 
@@ -88,6 +88,8 @@ struct RowPackOpts {
     // has two words in both directions: word 1 = 4 * (position in the OTHER direction's numbering) |
     // (8 * position in pdf-major order) << 16 (set_partner() fills the forward form's once the backward form exists).
     bool pair = false;
+    // register windows the kernels are instantiated for: KA is rounded up to one of them (0-terminated; empty: any even KA)
+    int ka_choices[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // rowptr/col/val_log2: 0-based CSR of M (out[r] = (+)_k val[k] (*) in[col[k]]), square, nrows rows.

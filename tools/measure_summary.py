@@ -25,7 +25,12 @@ sha = source_hash()
 
 
 def short(k):
-    return k.replace("void mm::", "").replace("(mm::RunParams)", "")
+    return k.replace("void mm::", "").replace("void ", "").replace("(mm::RunParams)", "")
+
+
+def ours(k):
+    """the engine's kernels (namespace mm, or the global-namespace launch wrappers mm_*)"""
+    return "mm::mm_" in k or k.startswith("void mm_") or k.startswith("mm_")
 
 
 def counters(sub):
@@ -33,7 +38,7 @@ def counters(sub):
     acc, disp = {}, {}
     for f in glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if "mm::mm_" not in r["Kernel_Name"]:
+            if not ours(r["Kernel_Name"]):
                 continue
             k = short(r["Kernel_Name"])
             acc.setdefault(k, {}).setdefault(r["Counter_Name"], 0.0)
@@ -53,7 +58,7 @@ for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
         w = csv.writer(g)
         w.writerow(rows[0] + [f"source_hash={sha}"])
         for r in rows[1:]:
-            if "mm::mm_" in r[0]:
+            if ours(r[0]):
                 w.writerow(r)
                 stats[short(r[0])] = {"calls": int(r[1]), "avg_ns": float(r[3])}
 

@@ -188,23 +188,44 @@ __device__ __forceinline__ void pair_pdf_sums(unsigned qbase, unsigned pdfse_bas
 // wave runs the whole window: the pairs behind its last segment have weight 0 (a few wasted gathers); leaving early
 // costs more -- however it is written, the compiler keeps a "done" flag that every pair re-tests (3 scalar
 // instructions per pair).
-template <int K2, int KA, int D>
-__device__ __forceinline__ void pair_one(const float (&wr)[KA], const unsigned (&ar)[KA], mm_f32x2 (&x)[2 * D], float &acc0,
-                                         float &acc1, unsigned rdoff) {
+// acc += w (broadcast) * x for the two utterances in ONE packed FMA (v_pk_fma_f32 issues at the rate of v_fma_f32 on
+// gfx950): the weights of an arc pair share an aligned register pair, op_sel picks the half that both lanes of the
+// packed operation use.
+__device__ __forceinline__ void pk_fma_wlo(mm_f32x2 &acc, const mm_f32x2 &w2, const mm_f32x2 &x) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w2), "v"(x));
+}
+__device__ __forceinline__ void pk_fma_whi(mm_f32x2 &acc, const mm_f32x2 &w2, const mm_f32x2 &x) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w2), "v"(x));
+}
+
+template <int KA>
+struct PairRegs {  // what a compute wave keeps across the steps
+    mm_f32x2 w2[KA / 2];
+    unsigned a[KA];
+};
+
+template <int K2, int KA, int D, bool PK>
+__device__ __forceinline__ void pair_one(const mm_f32x2 (&wr)[KA / 2], const unsigned (&ar)[KA], mm_f32x2 (&x)[2 * D], mm_f32x2 &accA,
+                                         mm_f32x2 &accB, unsigned rdoff) {
     constexpr int s0 = (2 * K2) % (2 * D);
-    acc0 = fmaf(wr[2 * K2], x[s0].x, acc0);
-    acc1 = fmaf(wr[2 * K2], x[s0].y, acc1);
-    acc0 = fmaf(wr[2 * K2 + 1], x[s0 + 1].x, acc0);
-    acc1 = fmaf(wr[2 * K2 + 1], x[s0 + 1].y, acc1);
+    if constexpr (PK) {
+        pk_fma_wlo(accA, wr[K2], x[s0]);
+        pk_fma_whi(accB, wr[K2], x[s0 + 1]);
+    } else {  // (phase B has no room for the aligned register pairs of the packed form)
+        accA.x = fmaf(wr[K2].x, x[s0].x, accA.x);
+        accA.y = fmaf(wr[K2].x, x[s0].y, accA.y);
+        accA.x = fmaf(wr[K2].y, x[s0 + 1].x, accA.x);
+        accA.y = fmaf(wr[K2].y, x[s0 + 1].y, accA.y);
+    }
     if constexpr (2 * (K2 + D) < KA) {
         x[s0] = ldsr2(ar[2 * (K2 + D)] + rdoff);
         x[s0 + 1] = ldsr2(ar[2 * (K2 + D) + 1] + rdoff);
     }
 }
-#define MM_PAIR_ONE(k)                                                                       \
-    if constexpr (2 * (k) < KA) {                                                            \
-        pair_one<(2 * (k) < KA ? (k) : 0), KA, D>(rg.w, rg.a, x, acc0, acc1, rdoff);         \
-        if ((((k) < 32 ? em_lo : em_hi) >> ((k) & 31)) & 1u) finish();                       \
+#define MM_PAIR_ONE(k)                                                                               \
+    if constexpr (2 * (k) < KA) {                                                                    \
+        pair_one<(2 * (k) < KA ? (k) : 0), KA, D, PHASE == 0>(rg.w2, rg.a, x, accA, accB, rdoff);    \
+        if ((((k) < 32 ? em_lo : em_hi) >> ((k) & 31)) & 1u) finish();                               \
     }
 #define MM_PAIR_CASES(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) \
     M(20) M(21) M(22) M(23)
@@ -220,7 +241,10 @@ template <int KA, int RS, int PHASE, int DIR>
 __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
     extern __shared__ float lds[];
     using L = PairLay<RS, PHASE>;
-    constexpr int D = 3;
+#ifndef MM_PAIR_DA
+#define MM_PAIR_DA 3
+#endif
+    constexpr int D = PHASE ? 3 : MM_PAIR_DA;  // gather pairs in flight ahead of the FMAs
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, NWC = NW - 1;
     const bool service = wave == NWC;
@@ -290,7 +314,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
            (unsigned)__builtin_amdgcn_readfirstlane((unsigned)lgw0);
     nslots = __builtin_amdgcn_readfirstlane(nslots);
     start2 = __builtin_amdgcn_readfirstlane(start2);
-    RowRegs<KA> rg;
+    PairRegs<KA> rg;
     auto load_graph = [&]() {
         static_assert(KA <= MM_ROW_KA_PAD, "register window larger than the padding of the device arrays");
         const int nt = 64 * r.NWC;
@@ -300,13 +324,15 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
         const int t0 = mine ? tid : 0;
 #pragma unroll
         for (int k = 0; k < KA; ++k) {
-            rg.w[k] = wp[k * nt + t0];
+            if (k & 1) rg.w2[k / 2].y = wp[k * nt + t0];
+            else rg.w2[k / 2].x = wp[k * nt + t0];
             rg.a[k] = ap[k * nt + t0];
         }
         if (!mine) {
 #pragma unroll
             for (int k = 0; k < KA; ++k) {
-                rg.w[k] = 0.f;
+                if (k & 1) rg.w2[k / 2].y = 0.f;
+                else rg.w2[k / 2].x = 0.f;
                 rg.a[k] = 0u;
             }
         }
@@ -535,25 +561,36 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                     al1 = ldsr((info2 & 0xffffu) + alb + RS);
                 }
                 float *row0 = U[0].rows + (long long)(f <= p.N ? f : 0) * S1p, *row1 = U[1].rows + (long long)(f <= p.N ? f : 0) * S1p;
-                float acc0 = 0.f, acc1 = 0.f;
+                // even / odd arcs (phase B has no registers to spare: one chain there)
+                float worst = 0.f;
+                mm_f32x2 accA = {0.f, 0.f}, accB_ = {0.f, 0.f};
+                mm_f32x2 &accB = PHASE ? accA : accB_;
                 unsigned long long lgw = lgw0;
                 auto finish = [&]() {
                     const int lg = (int)(lgw & 15ull);
                     lgw >>= 4;
-                    float s0 = acc0, s1 = acc1;
+                    float s0 = accA.x, s1 = accA.y;
+                    if constexpr (PHASE == 0) {
+                        s0 += accB.x;
+                        s1 += accB.y;
+                    }
                     if (lg) {
-                        s0 = grp_sum_last(s0, lg);
-                        s1 = grp_sum_last(s1, lg);
+                        if constexpr (PHASE == 0) {
+                            grp_sum_last2(s0, s1, lg);
+                        } else {
+                            s0 = grp_sum_last(s0, lg);
+                            s1 = grp_sum_last(s1, lg);
+                        }
                     }
                     const unsigned pos8 = info & 0xffffu;
                     // forward: (T' alpha) (*) lhs (src/inference.jl:70-71); backward: T (B (*) lhs) (:106-107), the emission is
                     // added for the next step's product only
                     const float b0 = fast_log2(s0) - S.x, b1 = fast_log2(s1) - S.y;
                     const float y0 = b0 + e.x, y1 = b1 + e.y;
-                    // (wave-uniform branches: a per-lane `if` here makes the compiler structurise the whole pair sequence --
-                    // a "done" flag re-tested before every pair)
-                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(row_out_of_range(y0, thr)) != 0ull, 0)) *redo0 = 1;
-                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(row_out_of_range(y1, thr)) != 0ull, 0)) *redo1 = 1;
+                    // range check, deferred to the end of the step: the largest finite |y| of the lane.  |y| * 0 + |y| is NaN
+                    // for -inf (the semiring's zero: in range) and v_max ignores NaN operands.
+                    worst = __builtin_fmaxf(worst, __builtin_fmaxf(__builtin_fmaf(__builtin_fabsf(y0), 0.f, __builtin_fabsf(y0)),
+                                                                   __builtin_fmaf(__builtin_fabsf(y1), 0.f, __builtin_fabsf(y1))));
                     ldsw2(pos8 + L::PP(WR), fast_exp2(y0), fast_exp2(y1));
                     const float st0 = DIR ? b0 : y0, st1 = DIR ? b1 : y1;  // the vector that is stored / combined
                     if constexpr (PHASE == 0) {
@@ -562,13 +599,14 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                     } else {
                         ldsw2((info2 >> 16) + L::Q(WR), fast_exp2(st0 + al0), fast_exp2(st1 + al1));  // A .* B   (:154)
                     }
-                    acc0 = acc1 = 0.f;
+                    accA = accB_ = mm_f32x2{0.f, 0.f};
                     sa += 512u;
-                    info = infoN;
+                    // (a plain copy is coalesced away and paid for with register moves on the no-finish path of EVERY pair)
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(info) : "v"(infoN));
                     e = ldsr2((info >> 16) + L::EM(WR));
                     infoN = ldsru(sa + 512u);
                     if constexpr (PHASE == 1) {
-                        info2 = info2N;
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(info2) : "v"(info2N));
                         al0 = ldsr((info2 & 0xffffu) + alb);
                         al1 = ldsr((info2 & 0xffffu) + alb + RS);
                         info2N = ldsru(sa + 516u);
@@ -576,6 +614,12 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                 };
                 asm volatile("" : "+s"(em_lo), "+s"(em_hi));
                 MM_PAIR_CASES(MM_PAIR_ONE)
+                // out of the linear range somewhere: both utterances go to the exact kernels (the check does not tell
+                // them apart; it only costs time)
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(worst > thr) != 0ull, 0)) {
+                    *redo0 = 1;
+                    *redo1 = 1;
+                }
             }
             if constexpr (PHASE == 1)  // C' * (A .* B) of the previous step (:155)
                 if (t - 1 > t0) pair_pdf_sums(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane);

@@ -150,6 +150,34 @@ __device__ __forceinline__ float grp_sum_last(float v, int lg) {
     return v;
 }
 
+// The same for the two utterances of a pair workgroup, with ONE wave-uniform branch per level that is still needed
+// (a branch costs a wave about three VALU instructions of issue time on gfx950; grp_sum_last() called twice tests
+// every level for both values).  The steps commute (I + shift^k), so the nesting order is free.
+__device__ __forceinline__ void grp_sum_last2(float &a, float &b, int lg) {
+    a = dpp_add<0x111, 0xF>(a);
+    b = dpp_add<0x111, 0xF>(b);
+    if (lg >= 2) {
+        a = dpp_add<0x112, 0xF>(a);
+        b = dpp_add<0x112, 0xF>(b);
+        if (lg >= 3) {
+            a = dpp_add<0x114, 0xF>(a);
+            b = dpp_add<0x114, 0xF>(b);
+            if (lg >= 4) {
+                a = dpp_add<0x118, 0xF>(a);
+                b = dpp_add<0x118, 0xF>(b);
+                if (lg >= 5) {
+                    a = dpp_add<0x142, 0xA>(a);
+                    b = dpp_add<0x142, 0xA>(b);
+                    if (lg >= 6) {
+                        a = dpp_add<0x143, 0xC>(a);
+                        b = dpp_add<0x143, 0xC>(b);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Service wave: log2 of the maximum of the linear vector at LDS byte address pbase (n4 float4s, n4 <= 64 * NB); -inf if
 // nothing is alive.  (The log2 vector itself is not kept in LDS: one store per finish less.)  All loads are issued
 // before the first maximum (clamped indices: a duplicate changes no maximum): a loop with one load per trip costs the

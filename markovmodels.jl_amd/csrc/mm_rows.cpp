@@ -177,7 +177,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     g.trash = int(nrows);
     g.slot_words = (backward || opt.pair) ? 2 : 1;
     g.scale = opt.pair ? 8 : 4;
-    g.ncopy = opt.pair ? 1 : 2;
+    g.ncopy = opt.copies ? opt.copies : (opt.pair ? 1 : 2);
     const uint32_t SC = uint32_t(g.scale);
     const bool want_q = backward || opt.pair;  // pdf-major positions
     g.maxcost = best.maxcost;

@@ -88,6 +88,7 @@ struct RowPackOpts {
     // has two words in both directions: word 1 = 4 * (position in the OTHER direction's numbering) |
     // (8 * position in pdf-major order) << 16 (set_partner() fills the forward form's once the backward form exists).
     bool pair = false;
+    int copies = 0;       // copies of the linear vector the addresses may use (0: 2 for the row form, 1 for the pair form)
     // register windows the kernels are instantiated for: KA is rounded up to one of them (0-terminated; empty: any even KA)
     int ka_choices[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };

@@ -152,6 +152,8 @@ struct DebugOpts {
     int kernel = K_AUTO;
     int kq = 0, nwaves = 0, nitems = -1;
     bool no_xcsr = false, verbose = false;
+    int finish_cost = 0;            // MM_FINISH_COST: cost model of the pair forms (0: default)
+    float group_speed[4] = {0, 0, 0, 0};  // MM_GROUP_SPEED=a,b,c,d
 };
 static DebugOpts read_debug_opts() {
     DebugOpts d;
@@ -165,6 +167,8 @@ static DebugOpts read_debug_opts() {
     if (const char *e = getenv("MM_NITEMS")) d.nitems = atoi(e);
     d.no_xcsr = getenv("MM_NO_XCSR") != nullptr;
     d.verbose = getenv("MM_VERBOSE") != nullptr;
+    if (const char *e = getenv("MM_FINISH_COST")) d.finish_cost = atoi(e);
+    if (const char *e = getenv("MM_GROUP_SPEED")) sscanf(e, "%f,%f,%f,%f", &d.group_speed[0], &d.group_speed[1], &d.group_speed[2], &d.group_speed[3]);
     return d;
 }
 
@@ -353,35 +357,37 @@ static int launch_rows(mm_batch_t h, const RunParams &p, void *stream) {
 
 // The pair kernels (mm_kernel_pairs.hip): phase A and phase B, each as a forward-agent and a backward-agent launch
 // that run concurrently (the caller's stream and the batch's side stream, joined by events).
-template <int KA, int PHASE, int DIR>
+#define MM_PAIR_KA 44  // arc slots per lane of the pair kernels
+// (NJ: 64-lane passes over the pdfs in the service wave, 2 for P + 1 <= 128, else 4)
+template <int NJ, int PHASE, int DIR>
 __global__ void __launch_bounds__(1024) mm_fbp_kernel_dir(RunParams p) {
-    pair_agent<KA, MM_ROW_RS, PHASE, DIR>(p, blockIdx.x);
+    pair_agent<MM_PAIR_KA, MM_ROW_RS, PHASE, DIR, NJ>(p, blockIdx.x);
 }
-template <int KA, int PHASE, int DIR>
+template <int NJ, int PHASE, int DIR>
 static int launch_pair_one(mm_batch_t h, const RunParams &p, hipStream_t st) {
     const size_t lds = pair_lds_bytes(MM_ROW_RS, PHASE, h->pair_slotrows);
     if (lds > 160 * 1024) return fail(MM_ERR_UNSUPPORTED, "pair kernel: LDS");
-    auto kernel = mm_fbp_kernel_dir<KA, PHASE, DIR>;
+    auto kernel = mm_fbp_kernel_dir<NJ, PHASE, DIR>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
     const unsigned npairs = unsigned((h->B + 1) / 2);
     hipLaunchKernelGGL(kernel, dim3(npairs), dim3(64 * (h->pair_nwc + 1)), lds, st, p);
     HIP_TRY(hipGetLastError());
     return MM_OK;
 }
-template <int KA>
+template <int NJ>
 static int launch_pairs_ka(mm_batch_t h, const RunParams &p, hipStream_t s0) {
     hipStream_t s1 = h->side;
     HIP_TRY(hipEventRecord(h->ev[0], s0));  // fork
     HIP_TRY(hipStreamWaitEvent(s1, h->ev[0], 0));
-    int rc = launch_pair_one<KA, 0, 0>(h, p, s0);
-    if (!rc) rc = launch_pair_one<KA, 0, 1>(h, p, s1);
+    int rc = launch_pair_one<NJ, 0, 0>(h, p, s0);
+    if (!rc) rc = launch_pair_one<NJ, 0, 1>(h, p, s1);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev[1], s0));  // phase B of either direction needs phase A of both
     HIP_TRY(hipEventRecord(h->ev[2], s1));
     HIP_TRY(hipStreamWaitEvent(s0, h->ev[2], 0));
     HIP_TRY(hipStreamWaitEvent(s1, h->ev[1], 0));
-    rc = launch_pair_one<KA, 1, 0>(h, p, s0);
-    if (!rc) rc = launch_pair_one<KA, 1, 1>(h, p, s1);
+    rc = launch_pair_one<NJ, 1, 0>(h, p, s0);
+    if (!rc) rc = launch_pair_one<NJ, 1, 1>(h, p, s1);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev[3], s1));  // join
     HIP_TRY(hipStreamWaitEvent(s0, h->ev[3], 0));
@@ -391,9 +397,8 @@ static int launch_pairs_ka(mm_batch_t h, const RunParams &p, hipStream_t s0) {
 }
 static int launch_pairs(mm_batch_t h, const RunParams &p, void *stream) {
     hipStream_t s0 = static_cast<hipStream_t>(stream);
-    if (h->pair_ka <= 40) return launch_pairs_ka<40>(h, p, s0);
-    if (h->pair_ka <= 44) return launch_pairs_ka<44>(h, p, s0);
-    return MM_ERR_UNSUPPORTED;
+    if (h->pair_ka > MM_PAIR_KA) return MM_ERR_UNSUPPORTED;
+    return h->max_P1 <= 128 ? launch_pairs_ka<2>(h, p, s0) : launch_pairs_ka<4>(h, p, s0);
 }
 
 namespace {
@@ -690,15 +695,21 @@ static int upload_row_variant(mm_fsm_t f, RowVariant *v, int dir, float thr) {
 
 // the pair variants of the row-lane forms (same schedule rules; 8-byte positions, one copy of the vector, the other
 // direction's numbering in the slot table)
-static int pair_variants(mm_fsm_t f, bool verbose, bool *ok) {
+static int pair_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
+    const bool verbose = dbg.verbose;
     *ok = f->prows[0] && f->prows[1];
     if (*ok || !f->rows[0] || !f->rows[1]) return MM_OK;  // (only FSMs that fit the row forms are tried)
     RowPackOpts opt;
     opt.rs = MM_ROW_RS;
-    opt.ka_max = 44;
+    opt.ka_max = MM_PAIR_KA;
     opt.pair = true;
-    opt.ka_choices[0] = 40;
-    opt.ka_choices[1] = 44;
+    // (the pair kernels' waves lower their priority as they advance: the waves of a SIMD progress together, no wave is
+    // "slower" than another)
+    for (float &x : opt.group_speed) x = 1.f;
+    if (dbg.finish_cost > 0) opt.finish_cost = dbg.finish_cost;
+    if (dbg.group_speed[0] > 0)
+        for (int i = 0; i < 4; ++i) opt.group_speed[i] = dbg.group_speed[i];
+    opt.ka_choices[0] = MM_PAIR_KA;
     RowVariant *rv[2] = {new RowVariant(), new RowVariant()};
     const std::vector<int32_t> none;
     bool fits = make_rows(f->S1, f->qmat[0].rowptr, f->qmat[0].col, f->qmat[0].val, f->s2p, f->P1, false, none, opt, rv[0]->g) &&
@@ -993,7 +1004,7 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     for (int64_t b = 1; b < B && h->pairs_ok; ++b) h->pairs_ok = fsms[b] == fsms[0];
     if (h->pairs_ok) {
         bool ok = false;
-        int rc = pair_variants(fsms[0], h->dbg.verbose, &ok);
+        int rc = pair_variants(fsms[0], h->dbg, &ok);
         if (rc) {
             delete h;
             return rc;
@@ -1003,7 +1014,7 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             h->pair_ka = std::max(fsms[0]->prows[0]->g.KA, fsms[0]->prows[1]->g.KA);
             h->pair_nwc = std::max(fsms[0]->prows[0]->g.NWC, fsms[0]->prows[1]->g.NWC);
             h->pair_slotrows = std::max(fsms[0]->prows[0]->g.nslotrows, fsms[0]->prows[1]->g.nslotrows);
-            h->pairs_ok = h->pair_ka <= 44 && pair_lds_bytes(MM_ROW_RS, 1, h->pair_slotrows) <= 160 * 1024;
+            h->pairs_ok = h->pair_ka <= MM_PAIR_KA && pair_lds_bytes(MM_ROW_RS, 1, h->pair_slotrows) <= 160 * 1024;
         }
     }
     for (int64_t b = 0; b < B; ++b) {
@@ -1106,7 +1117,7 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
                                              std::to_string(h->geo_kq[1]) + ",*,1>"
                                        : std::string("mm_log_kernel<MODE_FB> (forward, backward)");
         if (h->pairs_ok) {
-            const std::string k = std::to_string(h->pair_ka <= 40 ? 40 : 44);
+            const std::string k = std::to_string(h->max_P1 <= 128 ? 2 : 4);
             s = "mm_fbp_kernel_dir<" + k + ",A,fwd> || <" + k + ",A,bwd>, then <" + k + ",B,fwd> || <" + k +
                 ",B,bwd>, mm_pair_finish_kernel, then for marked utterances only " + exact;
         } else if (h->rows_ok) {

@@ -67,10 +67,11 @@ struct PairUtt {  // one utterance of the pair (scalar registers)
 
 // emissions of one frame for utterance u of the pair: raw values from LDS (DMA), log2 domain relative to the frame's
 // maximum E (row_stage_em for interleaved pairs).  Returns E.
+template <int NJ>  // NJ * 64 >= P + 1
 __device__ __forceinline__ float pair_stage_em(unsigned dst, unsigned rawsrc, int u, int n, int len, int P, int lane) {
-    float v[4], E = MM_NINF;
+    float v[NJ], E = MM_NINF;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int q = lane + 64 * j;
         v[j] = em_value(ldsr(rawsrc + 256u * j + 4u * lane), n, len, P, q);
         if (q < P) E = max_nc(E, v[j]);
@@ -78,7 +79,7 @@ __device__ __forceinline__ float pair_stage_em(unsigned dst, unsigned rawsrc, in
     E = wave_max_rl(E);
     if (!(E > MM_NINF)) E = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int q = lane + 64 * j;
         if (q <= P) ldsw(dst + 8u * q + 4u * u, v[j] - E);
     }
@@ -126,12 +127,13 @@ __device__ __forceinline__ float wave_sum_rl(float v) {
 
 // one wave, both utterances of the pair: per-frame sums over the pdfs (psum pairs [pdf][2]), divide, store gamma
 // (src/inference.jl:156-160); lt[u] = log2 of the sum (-inf, and gamma = 0, if nothing is alive)
+template <int NJ>  // NJ * 64 >= P + 1
 __device__ __forceinline__ void pair_finish_frames(unsigned psum, int P1, int P, int lane, float *gp0, float *gp1, long long gsp,
                                                    bool store0, bool store1, float (&lt)[2]) {
-    mm_f32x2 s[4];
+    mm_f32x2 s[NJ];
     float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int q = lane + 64 * j;
         s[j] = ldsr2(psum + 8u * (q < P1 ? q : 0));
         if (q < P1) {
@@ -143,7 +145,7 @@ __device__ __forceinline__ void pair_finish_frames(unsigned psum, int P1, int P,
     t1 = wave_sum_rl(t1);
     const float i0 = t0 > 0.f ? 1.f / t0 : 0.f, i1 = t1 > 0.f ? 1.f / t1 : 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int q = lane + 64 * j;
         if (q < P) {
             if (store0) gp0[q * gsp] = s[j].x * i0;
@@ -198,6 +200,10 @@ __device__ __forceinline__ void pk_fma_whi(mm_f32x2 &acc, const mm_f32x2 &w2, co
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w2), "v"(x));
 }
 
+__device__ __forceinline__ void pk_mul_wlo(mm_f32x2 &acc, const mm_f32x2 &w2, const mm_f32x2 &x) {
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(acc) : "v"(w2), "v"(x));
+}
+
 template <int KA>
 struct PairRegs {  // what a compute wave keeps across the steps
     mm_f32x2 w2[KA / 2];
@@ -222,13 +228,58 @@ __device__ __forceinline__ void pair_one(const mm_f32x2 (&wr)[KA / 2], const uns
         x[s0 + 1] = ldsr2(ar[2 * (K2 + D) + 1] + rdoff);
     }
 }
-#define MM_PAIR_ONE(k)                                                                               \
-    if constexpr (2 * (k) < KA) {                                                                    \
-        pair_one<(2 * (k) < KA ? (k) : 0), KA, D, PHASE == 0>(rg.w2, rg.a, x, accA, accB, rdoff);    \
-        if ((((k) < 32 ? em_lo : em_hi) >> ((k) & 31)) & 1u) finish();                               \
+// Two pairs whose products are all in straight-line code: pair K2 goes to the running sums, pair K2 + 1 to sums of
+// its own (accN), which the caller adds to the running sums unless a segment ends between the two.
+template <int K2, int KA, int D>
+__device__ __forceinline__ void pair_two(const mm_f32x2 (&wr)[KA / 2], const unsigned (&ar)[KA], mm_f32x2 (&x)[2 * D], mm_f32x2 &accA,
+                                         mm_f32x2 &accN, unsigned rdoff) {
+    constexpr int s0 = (2 * K2) % (2 * D), s1 = (2 * K2 + 2) % (2 * D);
+    pk_fma_wlo(accA, wr[K2], x[s0]);
+    pk_mul_wlo(accN, wr[K2 + 1], x[s1]);
+    pk_fma_whi(accA, wr[K2], x[s0 + 1]);
+    pk_fma_whi(accN, wr[K2 + 1], x[s1 + 1]);
+    if constexpr (2 * (K2 + D) < KA) {
+        x[s0] = ldsr2(ar[2 * (K2 + D)] + rdoff);
+        x[s0 + 1] = ldsr2(ar[2 * (K2 + D) + 1] + rdoff);
     }
-#define MM_PAIR_CASES(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) \
-    M(20) M(21) M(22) M(23)
+    if constexpr (2 * (K2 + 1 + D) < KA) {
+        x[s1] = ldsr2(ar[2 * (K2 + 1 + D)] + rdoff);
+        x[s1 + 1] = ldsr2(ar[2 * (K2 + 1 + D) + 1] + rdoff);
+    }
+}
+#define MM_PAIR_FMA(k) pair_one<(2 * (k) < KA ? (k) : 0), KA, D, PHASE == 0>(rg.w2, rg.a, x, accA, accB, rdoff);
+#define MM_PAIR_END(k) ((((k) < 32 ? em_lo : em_hi) >> ((k) & 31)) & 1u)
+#define MM_PAIR_ONE(k)                   \
+    if constexpr (2 * (k) < KA) {        \
+        MM_PAIR_FMA(k)                   \
+        if (MM_PAIR_END(k)) finish();    \
+    }
+// Two pairs per wave-uniform test of the end mask (a taken branch costs a wave about 30 cycles with its bit test, as
+// much as the pair's gathers): the bits are looked at one by one only when one of the two pairs ends a segment.
+#define MM_PAIR_TWO(k)                                                                                       \
+    if constexpr (2 * (k) + 2 < KA && MM_PAIR_DOUBLE) {                                                      \
+        pair_two<(2 * (k) + 2 < KA ? (k) : 0), KA, D>(rg.w2, rg.a, x, accA, accN, rdoff);                    \
+        if (__builtin_expect(((((k) < 32 ? em_lo : em_hi) >> ((k) & 31)) & 3u) != 0u, 0)) {                  \
+            if (MM_PAIR_END(k)) finish();                                                                    \
+            accA += accN;                                                                                    \
+            accN = mm_f32x2{0.f, 0.f};                                                                       \
+            if (MM_PAIR_END((k) + 1)) finish();                                                              \
+        }                                                                                                    \
+        accA += accN;                                                                                        \
+    } else {                                                                                                 \
+        MM_PAIR_ONE(k)                                                                                       \
+        MM_PAIR_ONE((k) + 1)                                                                                 \
+    }
+// A wave lowers its issue priority as it advances through the step (MM_PAIR_PRIO): the arbiter serves the highest
+// priority, then the OLDEST wave, so with equal priorities the four waves of a SIMD finish one after the other and the
+// youngest runs the tail of the step alone, latency bound, while the LDS idles; with priorities that fall with the
+// progress a wave that is ahead yields to the ones behind and all reach the barrier together.
+#ifndef MM_PAIR_PRIO_A
+#define MM_PAIR_PRIO_A 8
+#define MM_PAIR_PRIO_B 16
+#endif
+#define MM_PAIR_PRIO(k, lvl) if constexpr (2 * (k) < KA) __builtin_amdgcn_s_setprio(lvl);
+#define MM_PAIR_CASES(M) M(0) M(2) M(4) M(6) MM_PAIR_PRIO(MM_PAIR_PRIO_A, 1) M(8) M(10) M(12) M(14) MM_PAIR_PRIO(MM_PAIR_PRIO_B, 0) M(16) M(18) M(20) M(22)
 
 struct PairHand {  // what an agent hands from phase A to phase B, per utterance
     float m_prev, s_cur, s_prev, cbar;
@@ -237,13 +288,14 @@ struct PairHand {  // what an agent hands from phase A to phase B, per utterance
 };
 
 // One agent: direction DIR (0: forward / alpha, 1: backward / beta) of pair `pair`, phase PHASE (0: A, 1: B).
-template <int KA, int RS, int PHASE, int DIR>
+template <int KA, int RS, int PHASE, int DIR, int NJ>
 __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
     extern __shared__ float lds[];
     using L = PairLay<RS, PHASE>;
 #ifndef MM_PAIR_DA
 #define MM_PAIR_DA 3
 #endif
+    constexpr bool MM_PAIR_DOUBLE = true;
     constexpr int D = PHASE ? 3 : MM_PAIR_DA;  // gather pairs in flight ahead of the FMAs
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, NWC = NW - 1;
@@ -349,7 +401,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
         auto dma_raw = [&](int t) {  // raw emissions of step t (clamped) -> RAW(t & 3, u)
             const int tt = t < 1 ? 1 : (t > tEnd ? tEnd : t);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) row_dma_em(L::RAW(0, u) + 2048u * (t & 3), U[u].Vb, p.vsn, frame_of(tt), p.N, P, lane);
+            for (int u = 0; u < 2; ++u) row_dma_em<NJ>(L::RAW(0, u) + 2048u * (t & 3), U[u].Vb, p.vsn, frame_of(tt), p.N, P, lane);
         };
         auto dma_partner = [&](int t) {  // the other agent's vector + offset of step t's frame -> AL(t % 3, u), POFF(t & 3, u)
             const int tt = t < 1 ? 1 : (t > tEnd ? tEnd : t);
@@ -369,13 +421,13 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                 dma_b32(reinterpret_cast<const unsigned *>(U[u].offs + f) + (lane & 1), L::POFF(0, u) + 512u * (t & 7));
             }
         };
-        constexpr int NDMA = 8 + (PHASE ? 2 * ((RS / 4 + 255) / 256) + 2 : 0);  // DMAs issued per step (a lower bound of the VMEM operations)
+        constexpr int NDMA = 2 * NJ + (PHASE ? 2 * ((RS / 4 + 255) / 256) + 2 : 0);  // DMAs issued per step (a lower bound of the VMEM operations)
         // stage the emissions of step t into EM(t & 1) and account its offsets; S = the normaliser the step subtracts
         auto stage = [&](int t, const float (&S)[2]) {
             float E[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                E[u] = pair_stage_em(L::EM(t & 1), L::RAW(0, u) + 2048u * (t & 3), u, frame_of(t), U[u].len, P, lane);
+                E[u] = pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, u) + 2048u * (t & 3), u, frame_of(t), U[u].len, P, lane);
                 cum[u] += (double)S[u] + (double)E[u];
             }
             if (lane == 0) {
@@ -409,7 +461,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
         if (PHASE == 0 || DIR == 1) {  // emissions of the starting step: the initial alpha needs them, and so does
             float E[2];                // rebuilding the backward agent's linear vector from its stored beta~
 #pragma unroll
-            for (int u = 0; u < 2; ++u) E[u] = pair_stage_em(L::EM(t0 & 1), L::RAW(0, u) + 2048u * (t0 & 3), u, frame_of(t0), U[u].len, P, lane);
+            for (int u = 0; u < 2; ++u) E[u] = pair_stage_em<NJ>(L::EM(t0 & 1), L::RAW(0, u) + 2048u * (t0 & 3), u, frame_of(t0), U[u].len, P, lane);
             if (PHASE == 0) {  // step 1 subtracts nothing but E
 #pragma unroll
                 for (int u = 0; u < 2; ++u) cum[u] = (double)E[u];
@@ -431,7 +483,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
             const int f = frame_of(ts);
             const bool live0 = f >= 1 && f <= U[0].len, live1 = f >= 1 && f <= U[1].len;
             float lt[2];
-            pair_finish_frames(psum, P1, P, lane, p.gamma + (long long)U[0].b * p.gsb + (long long)(f - 1) * p.gsn,
+            pair_finish_frames<NJ>(psum, P1, P, lane, p.gamma + (long long)U[0].b * p.gsb + (long long)(f - 1) * p.gsn,
                                p.gamma + (long long)U[1].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp, live0 && U[0].valid,
                                live1 && U[1].valid, lt);
 #pragma unroll
@@ -447,20 +499,26 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
             constexpr int RD = decltype(RDc)::value, WR = 1 - RD;  // RD = parity of steps t - 1 and t + 1
             // emissions of step t + 1 (requested at step t - 2: the DMAs of step t - 1 may still be in flight)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            MM_STAMP(2);
             // the normaliser of step t + 1 from the maxima of step t - 1 (complete since the last barrier)
             float mx[2];
             pair_scan_max<(RS / 8 + 63) / 64>(L::PP(RD), (S1 + 2) >> 1, lane, mx[0], mx[1]);
+            MM_STAMP(3);
             if (t + 1 <= tEnd) {
                 const float S[2] = {norm[0].next(mx[0]), norm[1].next(mx[1])};
                 if (t + 1 <= t1) stage(t + 1, S);
             }
+            MM_STAMP(4);
             dma_raw(t + 4);
             if constexpr (PHASE == 1) {
                 dma_partner(t + 2);
+                MM_STAMP(5);
                 // gamma of step t - 2: its per-pdf sums were completed in the previous step
                 if (t - 2 > t0) frames_of_step(t - 2, L::PSUM(WR));
+                MM_STAMP(6);
                 // the partner vector of step t + 1 (requested at step t - 1) must be in LDS when the compute waves leave the barrier
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+                MM_STAMP(7);
             }
             MM_STAMP(0);
             MM_STEP_SYNC();
@@ -563,17 +621,13 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                 float *row0 = U[0].rows + (long long)(f <= p.N ? f : 0) * S1p, *row1 = U[1].rows + (long long)(f <= p.N ? f : 0) * S1p;
                 // even / odd arcs (phase B has no registers to spare: one chain there)
                 float worst = 0.f;
-                mm_f32x2 accA = {0.f, 0.f}, accB_ = {0.f, 0.f};
-                mm_f32x2 &accB = PHASE ? accA : accB_;
+                mm_f32x2 accA = {0.f, 0.f}, accN = {0.f, 0.f};
+                mm_f32x2 &accB = accA;
                 unsigned long long lgw = lgw0;
                 auto finish = [&]() {
                     const int lg = (int)(lgw & 15ull);
                     lgw >>= 4;
                     float s0 = accA.x, s1 = accA.y;
-                    if constexpr (PHASE == 0) {
-                        s0 += accB.x;
-                        s1 += accB.y;
-                    }
                     if (lg) {
                         if constexpr (PHASE == 0) {
                             grp_sum_last2(s0, s1, lg);
@@ -599,7 +653,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                     } else {
                         ldsw2((info2 >> 16) + L::Q(WR), fast_exp2(st0 + al0), fast_exp2(st1 + al1));  // A .* B   (:154)
                     }
-                    accA = accB_ = mm_f32x2{0.f, 0.f};
+                    accA = mm_f32x2{0.f, 0.f};
                     sa += 512u;
                     // (a plain copy is coalesced away and paid for with register moves on the no-finish path of EVERY pair)
                     asm volatile("v_mov_b32 %0, %1" : "=v"(info) : "v"(infoN));
@@ -613,7 +667,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                     }
                 };
                 asm volatile("" : "+s"(em_lo), "+s"(em_hi));
-                MM_PAIR_CASES(MM_PAIR_ONE)
+                __builtin_amdgcn_s_setprio(2);
+                MM_PAIR_CASES(MM_PAIR_TWO)
                 // out of the linear range somewhere: both utterances go to the exact kernels (the check does not tell
                 // them apart; it only costs time)
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(worst > thr) != 0ull, 0)) {
@@ -644,14 +699,10 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
 #ifdef MM_STAMPS
     if (p.dbg && lane == 0)  // [pair][wave][phase * 2 + dir][work, barrier]
         for (int k = 0; k < 2; ++k) p.dbg[(((long long)pair * MM_MAX_WAVES + wave) * 4 + PHASE * 2 + DIR) * 2 + k] = stamp_acc[k];
+    if (p.dbg && lane == 0 && service)  // the service wave's sections, behind the per-wave table: [pair][phase * 2 + dir][section]
+        for (int k = 0; k < 8; ++k)
+            p.dbg[(long long)((p.B + 1) / 2) * MM_MAX_WAVES * 8 + ((long long)pair * 4 + PHASE * 2 + DIR) * 8 + k] = stamp_acc[k];
 #endif
-}
-
-template <int KA, int RS, int PHASE>
-__global__ void __launch_bounds__(1024) mm_fbp_kernel(RunParams p) {  // (both agents in one launch: spills; kept for reference)
-    const int pair = blockIdx.x >> 1;
-    if (blockIdx.x & 1) pair_agent<KA, RS, PHASE, 1>(p, pair);
-    else pair_agent<KA, RS, PHASE, 0>(p, pair);
 }
 
 // ttl = min over the frames of the per-frame log-normaliser (src/inference.jl:159); zeros beyond the sequence lengths

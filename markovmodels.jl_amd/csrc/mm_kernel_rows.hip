@@ -109,11 +109,12 @@ __device__ __forceinline__ void dma_b128(const void *gsrc, unsigned lds_dst) {
 #define MM_ROW_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // raw emissions of frame n (clamped to a valid frame and pdf: expand() decides later what they mean): always 4 DMAs
 // of 256 bytes, so that the number of outstanding operations per step is a constant
+template <int NJ = 4>  // NJ * 64 >= P + 1
 __device__ __forceinline__ void row_dma_em(unsigned dst, const float *Vb, long long vsn, int n, int N, int P, int lane) {
     const int nn = n < 1 ? 1 : (n > N ? N : n);
     const float *row = Vb + (long long)(nn - 1) * vsn;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int q = lane + 64 * j;
         dma_b32(row + (q < P ? q : P - 1), dst + 256u * j);
     }

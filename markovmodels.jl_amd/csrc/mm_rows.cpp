@@ -67,6 +67,13 @@ struct Banks {
         for (auto &v : bank) m = std::max(m, v.size());
         return int(m);
     }
+    // smooth objective of the local search: every resolved conflict lowers it, also where the maximum (cycles())
+    // is held by several banks at once and no single move lowers that
+    int sq() const {
+        int q = 0;
+        for (auto &v : bank) q += int(v.size() * v.size());
+        return q;
+    }
     bool conflicted(uint32_t a) const { return bank[of(a)].size() > 1; }
     int least_loaded() const {
         int b = 0;
@@ -90,9 +97,9 @@ Plan plan_for(int64_t nrows, const std::vector<int64_t> &rowptr, int acap, const
     for (int64_t r = 0; r < nrows; ++r) {
         const int d = int(rowptr[r + 1] - rowptr[r]);
         int g = 1;
-        while ((std::max(d, 1) + g - 1) / g > acap && g < 64) g *= 2;
+        while ((std::max(d, 1) + g - 1) / g > acap / opt.a_round * opt.a_round && g < 64) g *= 2;
         int A = (std::max(d, 1) + g - 1) / g;
-        A = (A + 1) & ~1;
+        A = (A + opt.a_round - 1) / opt.a_round * opt.a_round;
         units.push_back(Unit{int32_t(r), g, A, d});
     }
     for (int g = 1; g <= 64; g *= 2) {
@@ -153,6 +160,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     g = RowGraph();
     if (nrows < 1 || (nrows + 1) * (opt.pair ? 8 : 4) > (opt.pair ? 2 : 1) * opt.rs || (nrows + 1) * 8 > 65528 || P1 > 8000)
         return false;
+    if (opt.copy_perm && ((nrows + 1 + 31) & ~int64_t(31)) * 4 > opt.rs) return false;  // (copy 1 scrambles inside blocks of 32)
     // ---- schedule: the cap on arcs per lane of one row decides how many rows are split over lane groups; take
     // the cap whose most loaded wave is cheapest
     Plan best;
@@ -242,8 +250,20 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     g.slots.assign(size_t(g.nslotrows) * 64 * g.slot_words, 0);
     g.w.assign(size_t(KA) * NT, 0.f);
     g.addr.assign(size_t(KA) * NT, 0u);
-    const uint32_t copy1 = uint32_t(opt.rs + 64);
+    // model addresses (4 bytes per position): copy cp of position c, and back
+    const uint32_t copy1 = uint32_t(opt.copy_perm ? opt.rs : opt.rs + 64);
     const uint32_t ncopy = uint32_t(g.ncopy);
+    const bool perm = opt.copy_perm;
+    g.copy1 = (opt.pair ? 2u : 1u) * copy1;
+    g.perm = perm;
+    auto enc = [&](uint32_t c, uint32_t cp) { return cp ? copy1 + 4u * (perm ? (c ^ ((c >> 5) & 31u)) : c) : 4u * c; };
+    auto other = [&](uint32_t a) {
+        if (a >= copy1) {
+            const uint32_t s = (a - copy1) / 4u;
+            return 4u * (perm ? (s ^ ((s >> 5) & 31u)) : s);
+        }
+        return enc(a / 4u, 1);
+    };
     // (bank model: a 4-byte read occupies bank (a / 4) % 32; an 8-byte read of the pair form the bank pair
     // (a / 8) % 32 -- the same structure, so the pair addresses are modelled as a / 2)
     double cyc_naive = 0, cyc_sched = 0;
@@ -306,7 +326,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                         for (size_t i = 0; i < la[l].arcs.size() && bcost > 0; ++i) {
                             if (used[i]) continue;
                             for (uint32_t cp = 0; cp < ncopy; ++cp) {
-                                const uint32_t a = uint32_t(4 * g.col[la[l].arcs[i]]) + cp * copy1;
+                                const uint32_t a = enc(uint32_t(g.col[la[l].arcs[i]]), cp);
                                 const int c = tab[k].cost_of(a);
                                 if (c < bcost) {
                                     bcost = c;
@@ -329,19 +349,20 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                         tab[k].add(ad[l][k]);
                     }
                 }
-                // local search: flip the copy of a conflicting slot, or swap it with another slot of the lane
-                for (int pass = 0; pass < 4; ++pass) {
+                // local search on the sum of squared bank loads: flip the copy of a conflicting slot, or swap it with another
+                // slot of the lane (in either copy)
+                for (int pass = 0; pass < 12; ++pass) {
                     bool improved = false;
                     for (int l = 0; l < 32; ++l)
                         for (int k = 0; k < s.A; ++k) {
                             uint32_t a = ad[l][k];
                             if (!tab[k].conflicted(a)) continue;
                             if (wt[l][k] != 0.f && ncopy > 1) {
-                                const uint32_t alt = a >= copy1 ? a - copy1 : a + copy1;
-                                const int before = tab[k].cycles();
+                                const uint32_t alt = other(a);
+                                const int before = tab[k].sq();
                                 tab[k].remove(a);
                                 tab[k].add(alt);
-                                if (tab[k].cycles() < before || (tab[k].cycles() == before && !tab[k].conflicted(alt))) {
+                                if (tab[k].sq() < before) {
                                     ad[l][k] = a = alt;
                                     improved = true;
                                     if (!tab[k].conflicted(a)) continue;
@@ -350,22 +371,43 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                                     tab[k].add(a);
                                 }
                             }
+                            // (the lanes of one row are interchangeable: an arc may trade places with any arc of its row in
+                            // this half-wave)
+                            const int gl = std::min(s.g, 32), l_lo = l / gl * gl;
+                            bool moved = false;
+                            for (int l2 = l_lo; l2 < l_lo + gl && !moved; ++l2)
                             for (int k2 = 0; k2 < s.A; ++k2) {
                                 if (k2 == k) continue;
-                                const uint32_t b = ad[l][k2];
-                                const int before = tab[k].cycles() + tab[k2].cycles();
+                                const uint32_t b = ad[l2][k2];
+                                const int before = tab[k].sq() + tab[k2].sq();
                                 tab[k].remove(a);
                                 tab[k2].remove(b);
-                                tab[k].add(b);
-                                tab[k2].add(a);
-                                if (tab[k].cycles() + tab[k2].cycles() < before) {
-                                    std::swap(ad[l][k], ad[l][k2]);
-                                    std::swap(wt[l][k], wt[l][k2]);
-                                    improved = true;
+                                // the best of the copies of each arc in its new slot
+                                uint32_t na = a, nb = b;
+                                int best = 1 << 30;
+                                for (uint32_t ca = 0; ca < (wt[l][k] != 0.f ? ncopy : 1u); ++ca)
+                                    for (uint32_t cb = 0; cb < (wt[l2][k2] != 0.f ? ncopy : 1u); ++cb) {
+                                        const uint32_t xa = ca ? other(a) : a, xb = cb ? other(b) : b;
+                                        tab[k].add(xb);
+                                        tab[k2].add(xa);
+                                        const int q = tab[k].sq() + tab[k2].sq();
+                                        tab[k].remove(xb);
+                                        tab[k2].remove(xa);
+                                        if (q < best) {
+                                            best = q;
+                                            na = xa;
+                                            nb = xb;
+                                        }
+                                    }
+                                if (best < before) {
+                                    tab[k].add(nb);
+                                    tab[k2].add(na);
+                                    ad[l][k] = nb;
+                                    ad[l2][k2] = na;
+                                    std::swap(wt[l][k], wt[l2][k2]);
+                                    improved = moved = true;
                                     break;
                                 }
-                                tab[k].remove(b);
-                                tab[k2].remove(a);
                                 tab[k].add(a);
                                 tab[k2].add(b);
                             }
@@ -416,7 +458,6 @@ void set_partner(RowGraph &g, const std::vector<int32_t> &partner_pos) {
 
 void eval_rows(const RowGraph &g, const float *in_lin, float *out_lin) {
     const int NT = 64 * g.NWC;
-    const uint32_t copy1 = uint32_t(g.rs + 64);
     for (int w = 0; w < g.NWC; ++w) {
         const RowSched &sc = g.sched[w];
         float acc[64];
@@ -426,9 +467,12 @@ void eval_rows(const RowGraph &g, const float *in_lin, float *out_lin) {
             for (int k = 2 * k2; k < 2 * k2 + 2; ++k)
                 for (int l = 0; l < 64; ++l) {
                     const size_t e = size_t(k) * NT + size_t(w) * 64 + l;
-                    uint32_t a = g.addr[e];
-                    if (g.ncopy > 1 && a >= copy1) a -= copy1;
-                    acc[l] = std::fmaf(g.w[e], in_lin[a / uint32_t(g.scale)], acc[l]);
+                    uint32_t a = g.addr[e], c = a / uint32_t(g.scale);
+                    if (g.ncopy > 1 && a >= g.copy1) {
+                        c = (a - g.copy1) / uint32_t(g.scale);
+                        if (g.perm) c ^= (c >> 5) & 31u;
+                    }
+                    acc[l] = std::fmaf(g.w[e], in_lin[c], acc[l]);
                 }
             if (!((sc.endmask >> k2) & 1)) continue;
             const int lg = int((sc.lg >> (4 * slot)) & 15), gsz = 1 << lg;

@@ -59,6 +59,8 @@ struct RowGraph {
     int slot_words = 1;
     int scale = 4;      // bytes per position in the addresses and slot-table fields (8: pair form)
     int ncopy = 2;      // copies of the linear vector the addresses refer to
+    uint32_t copy1 = 0; // address of copy 1 relative to copy 0 (in the units of `addr`)
+    bool perm = false;  // copy 1 holds position c at slot c ^ ((c >> 5) & 31) (see RowPackOpts::copy_perm)
     std::vector<RowSched> sched;  // [NWC]
     std::vector<uint16_t> rowpdf; // [rows] pdf of the row at each position
     // CSR in internal numbering with log2-domain weights: the exact fallback walks these
@@ -88,7 +90,14 @@ struct RowPackOpts {
     // has two words in both directions: word 1 = 4 * (position in the OTHER direction's numbering) |
     // (8 * position in pdf-major order) << 16 (set_partner() fills the forward form's once the backward form exists).
     bool pair = false;
-    int copies = 0;       // copies of the linear vector the addresses may use (0: 2 for the row form, 1 for the pair form)
+    int a_round = 2;      // arc slots per lane of a segment are a multiple of this (2, 4 or 8: the kernels test for the end
+                          // of a segment only after every a_round / 2 pairs)
+    int copies = 0;
+    // Second copy: false = the same order, rotated by half the banks (copy 1 at rs + 64 bytes: two states that share a
+    // bank in copy 0 share one in copy 1 as well); true = position c at slot c ^ ((c >> 5) & 31) of copy 1 (at rs): the
+    // low five bits -- the bank -- are scrambled with the next five, so states that collide in copy 0 mostly do not in
+    // copy 1 (two independent choices per arc)
+    bool copy_perm = false;       // copies of the linear vector the addresses may use (0: 2 for the row form, 1 for the pair form)
     // register windows the kernels are instantiated for: KA is rounded up to one of them (0-terminated; empty: any even KA)
     int ka_choices[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };

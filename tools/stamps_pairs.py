@@ -36,3 +36,8 @@ for ph, pn in enumerate(("phase A", "phase B")):
         print(pn, dn, "cycles per step: total %.0f" % (work + wait).mean())
         print("  work per wave   :", " ".join(f"{v:5.0f}" for v in work))
         print("  barrier per wave:", " ".join(f"{v:5.0f}" for v in wait))
+sv = out[(B // 2) * 16 * 8 : (B // 2) * 16 * 8 + (B // 2) * 32].reshape(B // 2, 2, 2, 8).astype(np.float64) / (N / 2)
+names = ["rest", "barrier", "wait DMA", "scan max", "norm+stage", "DMA issue", "gamma frames", "wait partner"]
+for ph, pn in enumerate(("phase A", "phase B")):
+    for d, dn in enumerate(("forward", "backward")):
+        print(pn, dn, "service wave:", ", ".join(f"{names[k]} {sv[:, ph, d, k].mean():.0f}" for k in range(8)))

@@ -280,23 +280,52 @@ __device__ __forceinline__ void pdf_sums_rest(unsigned qbase, unsigned pdfse_bas
     }
 }
 
-// The arcs of a compute wave, two at a time, statically unrolled (the graph registers need static indices);
-// a segment may end after any pair (wave-uniform bit test).  The gathers run D pairs ahead of the FMAs.
+// The arcs of a compute wave, statically unrolled (the graph registers need static indices); a segment may end after
+// any pair of arcs.  The gathers run D pairs ahead of the FMAs.  Two pairs share ONE wave-uniform test of the end mask
+// (a branch costs a wave 12-25 cycles of issue time, as much as a pair's gathers): the products of the second pair go
+// to a side sum that joins the running sum unless a segment ends between the two; all products are in straight-line
+// code, only the rare path (a segment ends here) looks at the bits one by one.  Every wave runs the whole window: the
+// pairs behind its last segment have weight 0.
+// The wave lowers its issue priority as it advances (s_setprio 2, 1, 0 by thirds of the window): the arbiter serves the
+// highest priority, then the OLDEST wave, so with equal priorities the four waves of a SIMD finish one after the other
+// and the youngest runs the tail of the step alone, latency bound, while the LDS idles; with priorities that fall with
+// the progress a wave that is ahead yields to the ones behind and all reach the step's barrier together.
 template <int K2, int KA, int D, unsigned RDOFF, class F>
 __device__ __forceinline__ void row_pairs(const float (&wr)[KA], const unsigned (&ar)[KA], float (&x)[2 * D], float &acc,
-                                          unsigned em_lo, unsigned em_hi, int &slots_left, F &&finish) {
+                                          unsigned em_lo, unsigned em_hi, F &&finish) {
+    constexpr int NP = KA / 2, T1 = ((NP + 2) / 3 + 1) & ~1, T2 = ((2 * NP + 2) / 3 + 1) & ~1;
+    if constexpr (K2 == 0) __builtin_amdgcn_s_setprio(2);
+    if constexpr (K2 == T1 && T1 > 0) __builtin_amdgcn_s_setprio(1);
+    if constexpr (K2 == T2 && T2 > T1) __builtin_amdgcn_s_setprio(0);
     constexpr int s0 = (2 * K2) % (2 * D);
-    acc = fmaf(wr[2 * K2], x[s0], acc);
-    acc = fmaf(wr[2 * K2 + 1], x[s0 + 1], acc);
-    if constexpr (2 * (K2 + D) < KA) {
-        x[s0] = ldsr(ar[2 * (K2 + D)] + RDOFF);
-        x[s0 + 1] = ldsr(ar[2 * (K2 + D) + 1] + RDOFF);
+    const unsigned em = K2 < 32 ? em_lo : em_hi;
+    if constexpr (K2 + 1 < NP) {
+        constexpr int s1 = (2 * K2 + 2) % (2 * D);
+        acc = fmaf(wr[2 * K2], x[s0], acc);
+        float accN = wr[2 * K2 + 2] * x[s1];
+        acc = fmaf(wr[2 * K2 + 1], x[s0 + 1], acc);
+        accN = fmaf(wr[2 * K2 + 3], x[s1 + 1], accN);
+        if constexpr (2 * (K2 + D) < KA) {
+            x[s0] = ldsr(ar[2 * (K2 + D)] + RDOFF);
+            x[s0 + 1] = ldsr(ar[2 * (K2 + D) + 1] + RDOFF);
+        }
+        if constexpr (2 * (K2 + 1 + D) < KA) {
+            x[s1] = ldsr(ar[2 * (K2 + 1 + D)] + RDOFF);
+            x[s1 + 1] = ldsr(ar[2 * (K2 + 1 + D) + 1] + RDOFF);
+        }
+        if (__builtin_expect(((em >> (K2 & 31)) & 3u) != 0u, 0)) {
+            if ((em >> (K2 & 31)) & 1u) finish();  // (zeroes acc)
+            acc += accN;
+            accN = 0.f;
+            if ((em >> ((K2 + 1) & 31)) & 1u) finish();
+        }
+        acc += accN;
+        if constexpr (K2 + 2 < NP) row_pairs<K2 + 2, KA, D, RDOFF>(wr, ar, x, acc, em_lo, em_hi, finish);
+    } else {
+        acc = fmaf(wr[2 * K2], x[s0], acc);
+        acc = fmaf(wr[2 * K2 + 1], x[s0 + 1], acc);
+        if ((em >> (K2 & 31)) & 1u) finish();
     }
-    if (((K2 < 32 ? em_lo : em_hi) >> (K2 & 31)) & 1u) {
-        finish();
-        if (--slots_left == 0) return;
-    }
-    if constexpr (K2 + 1 < KA / 2) row_pairs<K2 + 1, KA, D, RDOFF>(wr, ar, x, acc, em_lo, em_hi, slots_left, finish);
 }
 
 // A value that is the same in every lane, moved to scalar registers.  (The utterance descriptor is read through an
@@ -530,7 +559,7 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                     float *wsAn = wsA + (long long)(n <= len ? n : 0) * S1p;
                     float acc = 0.f;
                     unsigned long long lgw = lgw0;
-                    int left = nslots;
+                    float worst = 0.f;  // largest finite |value| of the lane in this step: range check at its end
                     auto finish = [&]() {
                         const int lg = (int)(lgw & 15ull);
                         lgw >>= 4;
@@ -538,7 +567,7 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                         if (lg) s = grp_sum_last(s, lg);
                         const unsigned pos4 = info & 0xffffu;
                         const float v = fast_log2(s) + e - M;  // (T' alpha_{n-1}) (*) lhs[:,n]   (src/inference.jl:70-71)
-                        if (__builtin_expect(row_out_of_range(v, thr), 0)) *redo = 1;
+                        worst = __builtin_fmaxf(worst, __builtin_fmaf(__builtin_fabsf(v), 0.f, __builtin_fabsf(v)));  // (NaN for -inf: ignored)
                         const float pv = fast_exp2(v);
                         ldsw(pos4 + L::P(WR, 0), pv);
                         ldsw(pos4 + L::P(WR, 1), pv);
@@ -551,7 +580,8 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                     // (opaque per step: hoisted out of the frame loop, the bit tests of all pairs would each occupy a scalar
                     // register pair for the whole loop)
                     asm volatile("" : "+s"(em_lo), "+s"(em_hi));
-                    row_pairs<0, KA, D, L::P(RD, 0)>(rg.w, rg.a, x, acc, em_lo, em_hi, left, finish);
+                    row_pairs<0, KA, D, L::P(RD, 0)>(rg.w, rg.a, x, acc, em_lo, em_hi, finish);
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(worst > thr) != 0ull, 0)) *redo = 1;
                 }
                 MM_STAMP(0);
                 MM_STEP_SYNC();
@@ -674,7 +704,7 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                     unsigned info = ldsru(sa), info2 = ldsru(sa + 4u);
                     float e = ldsr((info >> 16) + L::EM(WR));
                     float al = ldsr((info2 & 0xffffu) + alb);
-                    int left = nslots;
+                    float worst = 0.f;  // largest finite |value| of the lane in this step: range check at its end
                     auto finish = [&]() {
                         const int lg = (int)(lgw & 15ull);
                         lgw >>= 4;
@@ -684,7 +714,7 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                         const float beta = fast_log2(s) - M;  // T (B[:,n+1] (*) lhs[:,n+1])  (src/inference.jl:106-107)
                         ldsw((info2 >> 16) + L::Q(WR), fast_exp2(al + beta - kappa));
                         const float y = beta + e;
-                        if (__builtin_expect(row_out_of_range(y, thr), 0)) *redo = 1;
+                        worst = __builtin_fmaxf(worst, __builtin_fmaf(__builtin_fabsf(y), 0.f, __builtin_fabsf(y)));  // (NaN for -inf: ignored)
                         const float py = fast_exp2(y);
                         ldsw(pos4 + L::P(WR, 0), py);
                         ldsw(pos4 + L::P(WR, 1), py);
@@ -696,7 +726,8 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                         al = ldsr((info2 & 0xffffu) + alb);
                     };
                     asm volatile("" : "+s"(em_lo), "+s"(em_hi));
-                    row_pairs<0, KA, D, L::P(RD, 0)>(rg.w, rg.a, x, acc, em_lo, em_hi, left, finish);
+                    row_pairs<0, KA, D, L::P(RD, 0)>(rg.w, rg.a, x, acc, em_lo, em_hi, finish);
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(worst > thr) != 0ull, 0)) *redo = 1;
                 }
                 if (n < len) {
                     pdf_finish(pq, pl, L::Q(RD), L::PSUM(RD));

@@ -167,6 +167,24 @@ int mm_viterbi_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t
  * weight one is the accumulator) for n + 1 frames.  n >= 1; out: device float[B], natural log. */
 int mm_totalsum_f32(mm_batch_t batch, int64_t n, int cumulative, float *out, void *stream);
 
+/* ---- multi-GPU boundary (one process per GPU, RCCL over xGMI) -------------------------------------------------
+ * The batch is block diagonal (src/fsmops.jl:28-36, src/inference.jl:28-36): utterances shard over the ranks with no
+ * collective on the data path.  The only exchange is the total log-likelihood the LF-MMI loss consumes
+ * (examples/test_cuda.jl:140-152 sums ttl_num / ttl_den over the utterances), offered here over RCCL so that a host
+ * binding without torch.distributed (julia/MarkovModelsAMD.jl) has it too.
+ * comm: an ncclComm_t of the calling process.  The library does not link RCCL: it resolves ncclAllReduce /
+ * ncclAllGather in the RCCL the process has loaded already (the one `comm` came from), else in librccl.so.
+ * Both calls are asynchronous on `stream`; MM_ERR_UNSUPPORTED if no RCCL can be found, MM_ERR_HIP if RCCL fails. */
+
+/* sum (device double[1]) = sum over ALL ranks of sum_b ttl[b], b < B_local (device float[B_local], the ttl output of
+ * mm_pdfposteriors_f32), accumulated in float64: a one-block reduction and a one-element all-reduce. */
+int mm_allreduce_logz(void *comm, const float *ttl, int64_t B_local, double *sum, void *stream);
+
+/* all (device float[world * B_max]) = the ttl vectors of all ranks, rank r at all + r * B_max.  Every rank passes
+ * the same B_max >= its B_local and a ttl buffer of B_max floats (pad with -inf: ranks may hold shards of different
+ * sizes). */
+int mm_allgather_ttl(void *comm, const float *ttl, int64_t B_max, float *all, void *stream);
+
 /* Test aid (host only, no GPU): evaluate one semiring product out = M (x) in
  * THROUGH THE PACKED FORM the kernels consume, direction 0: M = T_hat'
  * (forward), 1: M = T_hat (backward).  in/out: host float[S1], natural log.

@@ -176,4 +176,27 @@ end
 MarkovModels.totalsum(b::ROCBatch, n::Integer) = _totalsum(b, n, false)
 MarkovModels.totalcumsum(b::ROCBatch, n::Integer) = _totalsum(b, n, true)
 
+"""
+    allreduce_logz(comm, ttl::ROCVector{Float32}) -> Float64
+    allgather_ttl(comm, ttl::ROCVector{Float32}, Bmax) -> Vector{Float32}
+
+The only exchange of a sharded batch (utterances are independent: src/fsmops.jl:28-36): the total log-likelihood
+the LF-MMI loss consumes (examples/test_cuda.jl:140-152).  `comm` is an RCCL communicator handle (ncclComm_t) of this
+process, one process per GPU.
+"""
+function allreduce_logz(comm::Ptr{Cvoid}, ttl::ROCVector{Float32})
+    s = ROCArray{Float64}(undef, 1)
+    check(ccall((:mm_allreduce_logz, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64, Ptr{Float64}, Ptr{Cvoid}),
+        comm, pointer(ttl), length(ttl), pointer(s), AMDGPU.stream().stream))
+    Array(s)[1]
+end
+function allgather_ttl(comm::Ptr{Cvoid}, ttl::ROCVector{Float32}, Bmax::Integer, world::Integer)
+    pad = ROCArray(fill(-Inf32, Bmax))
+    copyto!(pad, 1, ttl, 1, length(ttl))
+    out = ROCArray{Float32}(undef, world * Bmax)
+    check(ccall((:mm_allgather_ttl, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64, Ptr{Float32}, Ptr{Cvoid}),
+        comm, pointer(pad), Bmax, pointer(out), AMDGPU.stream().stream))
+    reshape(Array(out), Bmax, world)
+end
+
 end # module

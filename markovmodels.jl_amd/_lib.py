@@ -36,6 +36,8 @@ SYMBOLS = [
     "mm_maxstateposteriors_f32",
     "mm_viterbi_f32",
     "mm_totalsum_f32",
+    "mm_allreduce_logz",
+    "mm_allgather_ttl",
     "mm_debug_packed_product",
     "mm_debug_quad_product",
     "mm_debug_row_product",
@@ -98,6 +100,10 @@ def _load():
     lib.mm_viterbi_f32.argtypes = [vp, fp, i64, i64, vp, i64, vp, i64, fp, vp, i64, vp]
     lib.mm_totalsum_f32.restype = C.c_int
     lib.mm_totalsum_f32.argtypes = [vp, i64, C.c_int, fp, vp]
+    lib.mm_allreduce_logz.restype = C.c_int
+    lib.mm_allreduce_logz.argtypes = [vp, vp, i64, vp, vp]
+    lib.mm_allgather_ttl.restype = C.c_int
+    lib.mm_allgather_ttl.argtypes = [vp, vp, i64, vp, vp]
     lib.mm_debug_packed_product.restype = C.c_int
     lib.mm_debug_packed_product.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.mm_debug_reach_distance.restype = C.c_int

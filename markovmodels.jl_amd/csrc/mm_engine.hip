@@ -1,6 +1,7 @@
 // mm_engine.hip -- C ABI (include/markovmodels_amd.h) over the gfx950 kernels.
 // Handles, host-side compile (packing), workspace management, launches.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -190,8 +191,11 @@ struct mm_batch_s {
     int row_ka[2] = {0, 0}, row_nwc[2] = {1, 1}, row_slotrows[2] = {0, 0};
     bool pairs_ok = false;                       // one FSM shared by all utterances, in pair form: the pair kernels can run
     int pair_ka = 0, pair_nwc = 1, pair_slotrows = 0;
-    hipStream_t side = nullptr;                  // the backward agents of the pair kernels run beside the forward ones
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // the forward and the backward agents of the pair kernels run side by side on two streams of the library (a
+    // process-wide pair that was SEEN to run kernels concurrently, concurrent_streams()); the caller's stream forks into
+    // them and joins them
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int device = -1;
     int n_cus = 256;  // compute units of the device
     UttDesc *d_utts = nullptr;
@@ -376,21 +380,29 @@ static int launch_pair_one(mm_batch_t h, const RunParams &p, hipStream_t st) {
 }
 template <int NJ>
 static int launch_pairs_ka(mm_batch_t h, const RunParams &p, hipStream_t s0) {
-    hipStream_t s1 = h->side;
+    hipStream_t sf = h->side[0], sb = h->side[1];
+    // (inside a stream capture the forward agents stay on the caller's stream: ending a capture whose origin stream only
+    // forks and joins crashed in hipStreamEndCapture -- ROCm 7.0; how the branches of the graph share the queues is the
+    // graph executor's business then)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s0, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) sf = s0;
     HIP_TRY(hipEventRecord(h->ev[0], s0));  // fork
-    HIP_TRY(hipStreamWaitEvent(s1, h->ev[0], 0));
-    int rc = launch_pair_one<NJ, 0, 0>(h, p, s0);
-    if (!rc) rc = launch_pair_one<NJ, 0, 1>(h, p, s1);
+    HIP_TRY(hipStreamWaitEvent(sf, h->ev[0], 0));
+    HIP_TRY(hipStreamWaitEvent(sb, h->ev[0], 0));
+    int rc = launch_pair_one<NJ, 0, 0>(h, p, sf);
+    if (!rc) rc = launch_pair_one<NJ, 0, 1>(h, p, sb);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(h->ev[1], s0));  // phase B of either direction needs phase A of both
-    HIP_TRY(hipEventRecord(h->ev[2], s1));
-    HIP_TRY(hipStreamWaitEvent(s0, h->ev[2], 0));
-    HIP_TRY(hipStreamWaitEvent(s1, h->ev[1], 0));
-    rc = launch_pair_one<NJ, 1, 0>(h, p, s0);
-    if (!rc) rc = launch_pair_one<NJ, 1, 1>(h, p, s1);
+    HIP_TRY(hipEventRecord(h->ev[1], sf));  // phase B of either direction needs phase A of both
+    HIP_TRY(hipEventRecord(h->ev[2], sb));
+    HIP_TRY(hipStreamWaitEvent(sf, h->ev[2], 0));
+    HIP_TRY(hipStreamWaitEvent(sb, h->ev[1], 0));
+    rc = launch_pair_one<NJ, 1, 0>(h, p, sf);
+    if (!rc) rc = launch_pair_one<NJ, 1, 1>(h, p, sb);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(h->ev[3], s1));  // join
+    HIP_TRY(hipEventRecord(h->ev[3], sf));  // join
+    HIP_TRY(hipEventRecord(h->ev[4], sb));
     HIP_TRY(hipStreamWaitEvent(s0, h->ev[3], 0));
+    HIP_TRY(hipStreamWaitEvent(s0, h->ev[4], 0));
     hipLaunchKernelGGL(mm_pair_finish_kernel, dim3(unsigned(h->B)), dim3(256), 0, s0, p);
     HIP_TRY(hipGetLastError());
     return MM_OK;
@@ -399,6 +411,67 @@ static int launch_pairs(mm_batch_t h, const RunParams &p, void *stream) {
     hipStream_t s0 = static_cast<hipStream_t>(stream);
     if (h->pair_ka > MM_PAIR_KA) return MM_ERR_UNSUPPORTED;
     return h->max_P1 <= 128 ? launch_pairs_ka<2>(h, p, s0) : launch_pairs_ka<4>(h, p, s0);
+}
+
+// Two streams whose kernels really run at the same time.  HIP multiplexes its streams over a few hardware queues and
+// two streams that share a queue run their kernels one after the other (seen: with an RCCL communicator in the process
+// the caller's stream and a fresh one shared a queue, and the two agents of the pair kernels took turns -- 5.7 ms per
+// call instead of 3.3).  So the pair is probed once per process and device: a kernel on one stream waits (up to
+// 0.5 ms) for a flag that a kernel launched afterwards on the other stream sets; fresh streams are tried until a pair
+// passes.  Without such a pair (sf == sb) the agents run one after the other: slower, same results.
+__global__ void mm_probe_wait_kernel(int *flag, int *seen) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    int ok = 0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < 50000ull) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            ok = 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    *seen = ok;
+}
+__global__ void mm_probe_set_kernel(int *flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+static bool concurrent_streams(int device, hipStream_t out[2]) {
+    struct Pair {
+        hipStream_t s[2] = {nullptr, nullptr};
+        bool tried = false;
+    };
+    static std::map<int, Pair> cache;
+    Pair &pr = cache[device];
+    if (!pr.tried) {
+        pr.tried = true;
+        int *dbuf = nullptr;
+        hipStream_t a = nullptr;
+        if (hipMalloc(&dbuf, 2 * sizeof(int)) == hipSuccess && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) == hipSuccess) {
+            std::vector<hipStream_t> rejected;
+            for (int attempt = 0; attempt < 8 && !pr.s[1]; ++attempt) {
+                hipStream_t b = nullptr;
+                if (hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess) break;
+                int seen = 0;
+                bool ok = hipMemset(dbuf, 0, 2 * sizeof(int)) == hipSuccess;
+                if (ok) {
+                    hipLaunchKernelGGL(mm_probe_wait_kernel, dim3(1), dim3(1), 0, a, dbuf, dbuf + 1);
+                    hipLaunchKernelGGL(mm_probe_set_kernel, dim3(1), dim3(1), 0, b, dbuf);
+                    ok = hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess &&
+                         hipMemcpy(&seen, dbuf + 1, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+                }
+                if (ok && seen) {
+                    pr.s[0] = a;
+                    pr.s[1] = b;
+                } else {
+                    rejected.push_back(b);  // (kept until the search ends: a destroyed stream's queue slot would be handed out again)
+                }
+            }
+            for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+            if (!pr.s[1]) pr.s[0] = pr.s[1] = a;  // no concurrent pair: one stream, the agents take turns
+        }
+        if (dbuf) (void)hipFree(dbuf);
+    }
+    out[0] = pr.s[0];
+    out[1] = pr.s[1];
+    return pr.s[0] != nullptr;
 }
 
 namespace {
@@ -1072,8 +1145,8 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         return fail(MM_ERR_HIP, "mm_batch_create: device allocation failed");
     }
     if (h->pairs_ok) {
-        bool good = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
-        for (int i = 0; i < 4 && good; ++i) good = hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming) == hipSuccess;
+        bool good = concurrent_streams(h->device, h->side);
+        for (int i = 0; i < 5 && good; ++i) good = hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming) == hipSuccess;
         if (!good) h->pairs_ok = false;
     }
     if (h->fast_ok && h->geo_kq[0] <= 3 && h->geo_kq[1] <= 3 && !h->dbg.no_xcsr) {
@@ -1097,7 +1170,6 @@ int mm_debug_read_stamps(unsigned long long *out, int64_t n) {
 
 int mm_batch_destroy(mm_batch_t h) {
     if (!h) return MM_OK;
-    if (h->side) (void)hipStreamDestroy(h->side);
     for (hipEvent_t e : h->ev)
         if (e) (void)hipEventDestroy(e);
     if (h->d_utts) (void)hipFree(h->d_utts);
@@ -1119,7 +1191,8 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
         if (h->pairs_ok) {
             const std::string k = std::to_string(h->max_P1 <= 128 ? 2 : 4);
             s = "mm_fbp_kernel_dir<" + k + ",A,fwd> || <" + k + ",A,bwd>, then <" + k + ",B,fwd> || <" + k +
-                ",B,bwd>, mm_pair_finish_kernel, then for marked utterances only " + exact;
+                ",B,bwd>, mm_pair_finish_kernel, then for marked utterances only " + exact +
+                (h->side[0] == h->side[1] ? " [no concurrent stream pair found: the two agents take turns]" : "");
         } else if (h->rows_ok) {
             auto ka = [&](int d) {
                 for (int k : kRowKA)
@@ -1320,6 +1393,52 @@ int mm_maxstateposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t
     return MM_OK;
 }
 
+// ---- RCCL (resolved at run time: the communicator belongs to the RCCL of the calling process) ----
+namespace {
+typedef int (*nccl_allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*nccl_allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+enum { MM_NCCL_SUM = 0, MM_NCCL_FLOAT32 = 7, MM_NCCL_FLOAT64 = 8 };  // rccl.h: ncclSum, ncclFloat32, ncclFloat64
+void *rccl_symbol(const char *name) {
+    if (void *f = dlsym(RTLD_DEFAULT, name)) return f;  // the RCCL already in the process (torch's, AMDGPU.jl's, ...)
+    static void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    return lib ? dlsym(lib, name) : nullptr;
+}
+__global__ void mm_sum_f64_kernel(const float *x, long long n, double *out) {
+    __shared__ double part[16];
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) s += (double)x[i];
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (unsigned w = 0; w < blockDim.x / 64; ++w) t += part[w];  // (fixed order: the same sum on every run)
+        *out = t;
+    }
+}
+}  // namespace
+
+int mm_allreduce_logz(void *comm, const float *ttl, int64_t B_local, double *sum, void *stream) {
+    if (!comm || !sum || B_local < 0 || (B_local > 0 && !ttl)) return fail(MM_ERR_INVALID, "mm_allreduce_logz: bad argument");
+    static nccl_allreduce_fn allreduce = reinterpret_cast<nccl_allreduce_fn>(rccl_symbol("ncclAllReduce"));
+    if (!allreduce) return fail(MM_ERR_UNSUPPORTED, "mm_allreduce_logz: no RCCL in this process and no librccl.so");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mm_sum_f64_kernel, dim3(1), dim3(1024), 0, st, ttl, (long long)B_local, sum);
+    HIP_TRY(hipGetLastError());
+    if (allreduce(sum, sum, 1, MM_NCCL_FLOAT64, MM_NCCL_SUM, comm, st) != 0) return fail(MM_ERR_HIP, "mm_allreduce_logz: ncclAllReduce failed");
+    return MM_OK;
+}
+
+int mm_allgather_ttl(void *comm, const float *ttl, int64_t B_max, float *all, void *stream) {
+    if (!comm || !ttl || !all || B_max < 1) return fail(MM_ERR_INVALID, "mm_allgather_ttl: bad argument");
+    static nccl_allgather_fn allgather = reinterpret_cast<nccl_allgather_fn>(rccl_symbol("ncclAllGather"));
+    if (!allgather) return fail(MM_ERR_UNSUPPORTED, "mm_allgather_ttl: no RCCL in this process and no librccl.so");
+    if (allgather(ttl, all, size_t(B_max), MM_NCCL_FLOAT32, comm, static_cast<hipStream_t>(stream)) != 0)
+        return fail(MM_ERR_HIP, "mm_allgather_ttl: ncclAllGather failed");
+    return MM_OK;
+}
+
 int mm_totalsum_f32(mm_batch_t h, int64_t n, int cumulative, float *out, void *stream) {
     static const float dummy = 0.f;
     int rc = check_run(h, "mm_totalsum_f32", &dummy, n, -1);
@@ -1358,6 +1477,7 @@ int mm_viterbi_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const
         if (rc) return rc;
         bp = static_cast<int32_t *>(h->ws);
         bp_stride_n = h->total_states;
+        p.stop_at_len = 1;  // nobody reads the back-pointers of the frames beyond len_b + 1
     } else if (bp_stride_n < h->total_states) {
         return fail(MM_ERR_DIM, "mm_viterbi_f32: bp_stride_n < total states");
     }

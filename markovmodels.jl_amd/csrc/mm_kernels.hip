@@ -103,6 +103,7 @@ struct RunParams {
     long long out_stride_n;
     int *bp;  // viterbi
     long long bp_stride_n;
+    int stop_at_len;  // viterbi without an export of the back-pointers: frames beyond len_b + 1 are not computed
     int *path;
     long long path_stride_b;
     float *score;
@@ -840,7 +841,9 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
     load_item_regs<NI>(rg, gf, wave, NW, lane);
     __syncthreads();
     if (len == 0 && tid == 0 && p.score) p.score[b] = buf[1 * S1p + S1 - 1];
-    for (int n = 2; n <= NF; ++n) {
+    // (the best path ends in the phony final state at frame len + 1; later frames matter to an export only)
+    const int n_end = (p.stop_at_len && !p.out && len + 1 < NF) ? (len + 1 < 1 ? 1 : len + 1) : NF;
+    for (int n = 2; n <= n_end; ++n) {
         const float *ap = buf + ((n - 1) & 1) * S1p;
         float *an = buf + (n & 1) * S1p;
         int *bpn = bpbuf + (n & 1) * S1p;
@@ -909,9 +912,9 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
         __syncthreads();
         if (n == len + 1 && tid == 0 && p.score) p.score[b] = an[S1 - 1];
     }
-    if (bpb && NF >= 2) {
-        const int *src = bpbuf + (NF & 1) * S1p;
-        int *dst = bpb + (long long)(NF - 1) * p.bp_stride_n;
+    if (bpb && n_end >= 2) {
+        const int *src = bpbuf + (n_end & 1) * S1p;
+        int *dst = bpb + (long long)(n_end - 1) * p.bp_stride_n;
         for (int s = tid; s < S1; s += NT) dst[s] = src[s];
     }
 }

@@ -437,3 +437,20 @@ def test_tropical_beta_and_maxstateposteriors(mm, wl, oracle, torch):
             assert np.allclose(m_b.max(axis=0), 0.0, atol=1e-4)  # some best path passes every frame
             for n, s in enumerate(paths[b]):  # ... and the Viterbi path is one of them
                 assert abs(m_b[s, n]) <= 1e-4, (g.name, b, n, s, m_b[s, n])
+
+
+@pytest.mark.gpu
+def test_c_abi_collectives_one_rank(mm, torch):
+    """mm_allreduce_logz / mm_allgather_ttl (include/markovmodels_amd.h) over an RCCL communicator of one rank: the
+    float64 sum and the gather of the local ttl (several ranks need several GPUs: the driver's scaling run)."""
+    uid = mm.dist.RcclComm.unique_id()
+    comm = mm.dist.RcclComm(1, 0, uid)
+    try:
+        ttl = torch.tensor([-10.5, -3.25, float(np.float32(-1e-3)), -700.0], device="cuda")
+        total = comm.allreduce_logz(ttl)
+        allttl = comm.allgather_ttl(ttl, [4])
+        torch.cuda.synchronize()
+        assert total.dtype == torch.float64 and float(total) == float(ttl.double().sum())
+        assert torch.equal(allttl, ttl)
+    finally:
+        comm.close()

@@ -120,16 +120,20 @@ class FSM:
         ``i j pdf pdf -log(T_ij)`` (pdf of the destination), ``i -log(omega)``.
         Returns (fsm, state2pdf[S] 0-based, number of pdfs)."""
         init, arcs, final, pdf, S = [], [], [], {}, 0
+
+        def num(tok: str) -> float:  # (Julia prints a Float32 with an exponent as 1.0f-5)
+            return float(tok.replace("f", "e"))
+
         for line in text.splitlines():
             t = line.split()
             if not t:
                 continue
             if len(t) <= 2:
                 i = int(t[0])
-                final.append((i - 1, -float(t[1]) if len(t) == 2 else 0.0))
+                final.append((i - 1, -num(t[1]) if len(t) == 2 else 0.0))
                 S = max(S, i)
                 continue
-            i, j, p, w = int(t[0]), int(t[1]), int(t[2]), -float(t[4]) if len(t) > 4 else 0.0
+            i, j, p, w = int(t[0]), int(t[1]), int(t[2]), -num(t[4]) if len(t) > 4 else 0.0
             pdf[j - 1] = p - 1
             S = max(S, i, j)
             if i == 0:
@@ -141,6 +145,39 @@ class FSM:
             s2p[s] = p
         fsm = cls(init, arcs, final, list(range(S)), semiring=semiring, dtype=dtype)
         return fsm, s2p, int(max(pdf.values())) + 1
+
+    def arc_lists(self):
+        """(init_idx, init_w, src, dst, w, final_idx, final_w) of the real states, 0-based, in the order findnz gives
+        them in the reference (initial states ascending; arcs by destination, then source; final states ascending):
+        alpha_hat[1:end-1], T_hat[1:end-1, 1:end-1] and omega = T_hat[1:end-1, end] (src/fsm.jl:19-28)."""
+        S = self.S1 - 1
+        keep = self.alpha_idx < S
+        dst_all = np.repeat(np.arange(self.S1, dtype=np.int64), np.diff(self.colptr))
+        real = (dst_all < S) & (self.rowval < S)
+        fin = (dst_all == S) & (self.rowval < S)
+        return (self.alpha_idx[keep], self.alpha_val[keep], self.rowval[real], dst_all[real], self.nzval[real],
+                self.rowval[fin], self.nzval[fin])
+
+    def to_openfst_text(self, state2pdf) -> str:
+        """The text form misc/benchmark/generatefsm.jl:42-57 writes (and from_openfst_text reads): one line per
+        initial state ``0 i pdf pdf -w``, per arc ``i j pdf pdf -w`` (pdf of the destination) and per final state
+        ``i -w``; states and pdfs 1-based, weights as negated natural logs in their shortest float32 form."""
+        s2p = np.asarray(state2pdf)
+        ii, iw, src, dst, w, fi, fw = self.arc_lists()
+
+        def num(x) -> str:
+            return str(self.dtype.type(-x))  # (numpy prints the shortest digits that give the value back)
+
+        out = []
+        for i, v in zip(ii, iw):
+            p = int(s2p[i]) + 1
+            out.append(f"0 {i + 1} {p} {p} {num(v)}")
+        for i, j, v in zip(src, dst, w):
+            p = int(s2p[j]) + 1
+            out.append(f"{i + 1} {j + 1} {p} {p} {num(v)}")
+        for i, v in zip(fi, fw):
+            out.append(f"{i + 1} {num(v)}")
+        return "\n".join(out) + "\n"
 
     # -- accessors ---------------------------------------------------------------
     @property

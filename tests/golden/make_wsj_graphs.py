@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Converts the reference's graph fixtures misc/benchmark/{den,num}_fsm_wsj.txt
 (OpenFst text written by misc/benchmark/generatefsm.jl:42-57; MIT licence) into
-compact .npz arc lists, and writes oracle outputs on them.
+compact .npz arc lists -- read by the PRODUCT reader (FSM.from_openfst_text), checked against the oracle's parser
+and the product writer -- and writes oracle outputs on them.
 
 Needs /root/reference (build container only); the .npz files are committed.
 Run: python tests/golden/make_wsj_graphs.py
@@ -29,16 +30,23 @@ def main():
 
     wl = importlib.import_module(mm.__name__ + ".workloads")
     for name in ("den_fsm_wsj", "num_fsm_wsj"):
-        S, init, arcs, final, s2p, P = o.parse_openfst_text(open(os.path.join(REF, name + ".txt")).read())
+        text = open(os.path.join(REF, name + ".txt")).read()
+        # through the PRODUCT reader (markovmodels.jl_amd/fsm.py: FSM.from_openfst_text); the oracle's parser must agree
+        fsm, s2p, P = mm.FSM.from_openfst_text(text)
+        ii, iw, src, dst, w, fi, fw = fsm.arc_lists()
+        S = fsm.S1 - 1
+        So, init, arcs, final, s2p_o, P_o = o.parse_openfst_text(text)
+        assert (S, P) == (So, P_o) and np.array_equal(s2p, s2p_o)
+        assert np.array_equal(ii, [s for s, _ in init]) and np.array_equal(iw, np.array([x for _, x in init], dtype=np.float32))
+        assert np.array_equal(src, [a[0][0] for a in arcs]) and np.array_equal(dst, [a[0][1] for a in arcs])
+        assert np.array_equal(w, np.array([a[1] for a in arcs], dtype=np.float32))
+        assert np.array_equal(fi, [s for s, _ in final]) and np.array_equal(fw, np.array([x for _, x in final], dtype=np.float32))
+        assert fsm.to_openfst_text(s2p) == text  # the product writer gives the reference's file back, byte for byte
         np.savez_compressed(
             os.path.join(HERE, name + ".npz"), S=S, P=P,
-            init_idx=np.array([s for s, _ in init], dtype=np.int32),
-            init_w=np.array([w for _, w in init], dtype=np.float32),
-            src=np.array([a[0][0] for a in arcs], dtype=np.int32),
-            dst=np.array([a[0][1] for a in arcs], dtype=np.int32),
-            w=np.array([a[1] for a in arcs], dtype=np.float32),
-            final_idx=np.array([s for s, _ in final], dtype=np.int32),
-            final_w=np.array([w for _, w in final], dtype=np.float32),
+            init_idx=ii.astype(np.int32), init_w=iw.astype(np.float32),
+            src=src.astype(np.int32), dst=dst.astype(np.int32), w=w.astype(np.float32),
+            final_idx=fi.astype(np.int32), final_w=fw.astype(np.float32),
             state2pdf=s2p.astype(np.int16),
         )
         g = wl.load_npz_graph(os.path.join(HERE, name + ".npz"))

@@ -138,3 +138,46 @@ def test_wsj_oracle_golden_reproduces(oracle, wl):
     gam, ttl = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, z["V"], z["lens"], dtype=np.float64)
     assert np.allclose(gam, z["gamma"], atol=1e-6, equal_nan=True) and np.allclose(ttl, z["ttl"], equal_nan=True)
     assert np.isfinite(gam[:2]).all() and np.isnan(gam[2, 0]).all()  # utterance 2 (150 frames) has no accepting path
+
+
+@pytest.mark.parametrize("gname", ["random", "lexicon", "l2r"])
+def test_openfst_text_round_trip(mm, wl, gname):
+    """FSM.to_openfst_text (the form misc/benchmark/generatefsm.jl:42-57 writes) read back by FSM.from_openfst_text
+    gives the same FSM, state map and pdf count."""
+    g = {"random": lambda: wl.random_fsm(60, 7, 3.0, seed=11), "lexicon": lambda: wl.lexicon_fsm(120, 9, seed=2),
+         "l2r": lambda: wl.l2r_hmm(3)}[gname]()
+    f = wl.to_fsm(mm, g)
+    text = f.to_openfst_text(g.state2pdf)
+    f2, s2p, P = mm.FSM.from_openfst_text(text)
+    assert np.array_equal(s2p, g.state2pdf) and P == int(np.max(g.state2pdf)) + 1
+    for a, b in zip(f.arc_lists(), f2.arc_lists()):
+        assert np.array_equal(a, b)
+    assert np.array_equal(f.colptr, f2.colptr) and np.array_equal(f.rowval, f2.rowval) and np.array_equal(f.nzval, f2.nzval)
+    assert f2.to_openfst_text(s2p) == text
+
+
+@pytest.mark.parametrize("name", ["den_fsm_wsj", "num_fsm_wsj"])
+def test_product_reader_equals_oracle_parser_on_wsj_graphs(mm, wl, oracle, name):
+    """The committed WSJ fixtures (tests/golden/*.npz, made by tests/golden/make_wsj_graphs.py through the PRODUCT
+    reader): written as text by the product writer, the product reader and the oracle's parser give the same arrays
+    -- those of the fixture.  In the build container the text is also compared with the reference's own file,
+    byte for byte."""
+    o, _ = oracle
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    g = wl.load_npz_graph(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    text = wl.to_fsm(mm, g).to_openfst_text(g.state2pdf)
+    ref = os.path.join("/root/reference/misc/benchmark", name + ".txt")
+    if os.path.exists(ref):
+        assert open(ref).read() == text
+    f, s2p, P = mm.FSM.from_openfst_text(text)
+    ii, iw, src, dst, w, fi, fw = f.arc_lists()
+    S, init, arcs, final, s2p_o, P_o = o.parse_openfst_text(text)
+    assert (f.S1 - 1, P) == (S, P_o) == (int(z["S"]), int(z["P"]))
+    assert np.array_equal(s2p, s2p_o) and np.array_equal(s2p, z["state2pdf"])
+    assert np.array_equal(ii, [s for s, _ in init]) and np.array_equal(ii, z["init_idx"])
+    assert np.array_equal(iw, np.array([x for _, x in init], dtype=np.float32)) and np.array_equal(iw, z["init_w"])
+    assert np.array_equal(src, [a[0][0] for a in arcs]) and np.array_equal(src, z["src"])
+    assert np.array_equal(dst, [a[0][1] for a in arcs]) and np.array_equal(dst, z["dst"])
+    assert np.array_equal(w, np.array([a[1] for a in arcs], dtype=np.float32)) and np.array_equal(w, z["w"])
+    assert np.array_equal(fi, [s for s, _ in final]) and np.array_equal(fi, z["final_idx"])
+    assert np.array_equal(fw, np.array([x for _, x in final], dtype=np.float32)) and np.array_equal(fw, z["final_w"])

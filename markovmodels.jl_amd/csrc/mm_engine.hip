@@ -153,6 +153,7 @@ struct DebugOpts {
     int kernel = K_AUTO;
     int kq = 0, nwaves = 0, nitems = -1;
     bool no_xcsr = false, verbose = false;
+    bool bigv = false;              // MM_BIGV: item / tropical kernels with the state vectors in global memory whatever the size
     int finish_cost = 0;            // MM_FINISH_COST: cost model of the pair forms (0: default)
     float group_speed[4] = {0, 0, 0, 0};  // MM_GROUP_SPEED=a,b,c,d
 };
@@ -168,6 +169,7 @@ static DebugOpts read_debug_opts() {
     if (const char *e = getenv("MM_NITEMS")) d.nitems = atoi(e);
     d.no_xcsr = getenv("MM_NO_XCSR") != nullptr;
     d.verbose = getenv("MM_VERBOSE") != nullptr;
+    d.bigv = getenv("MM_BIGV") != nullptr;
     if (const char *e = getenv("MM_FINISH_COST")) d.finish_cost = atoi(e);
     if (const char *e = getenv("MM_GROUP_SPEED")) sscanf(e, "%f,%f,%f,%f", &d.group_speed[0], &d.group_speed[1], &d.group_speed[2], &d.group_speed[3]);
     return d;
@@ -195,6 +197,7 @@ struct mm_batch_s {
     // process-wide pair that was SEEN to run kernels concurrently, concurrent_streams()); the caller's stream forks into
     // them and joins them
     hipStream_t side[2] = {nullptr, nullptr};
+    float *ws_big = nullptr;  // [B][4 * max_S1p]: state vectors of FSMs beyond the LDS (launch())
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int device = -1;
     int n_cus = 256;  // compute units of the device
@@ -217,16 +220,26 @@ static Geometry pick_geometry(mm_batch_t h) {
     g.NW = std::max(1, std::min(MM_MAX_WAVES, it + 1));  // + one wave without items: it normalises the frames (FB)
     if (h->dbg.nwaves >= 1 && h->dbg.nwaves <= MM_MAX_WAVES) g.NW = h->dbg.nwaves;
     if (h->dbg.nitems == 0 || h->dbg.nitems == 8) g.NI = h->dbg.nitems;
+    if (h->max_S1p > 65534) g.NI = 0;  // (resident items hold 16-bit state indices)
     return g;
 }
 
+// item / tropical kernels: `kernel` keeps the state vectors in LDS; `big` is the same kernel with the vectors in global
+// memory, for FSMs beyond the LDS (the reference has no size limit: src/linalg.jl:170-181)
 template <typename K>
-static int launch(K kernel, mm_batch_t h, const RunParams &p, bool with_stage, int NW, void *stream) {
+static int launch(K kernel, K big, mm_batch_t h, const RunParams &p0, bool with_stage, int NW, void *stream) {
     const int P1p = (h->max_P1 + 3) & ~3;
-    const LdsPlan L = lds_plan(h->max_S1p, P1p, with_stage);
+    RunParams p = p0;
+    LdsPlan L = lds_plan(h->max_S1p, P1p, with_stage);
+    if (size_t(L.total) * 4 > 160 * 1024 || h->dbg.bigv) {
+        if (!h->ws_big) return fail(MM_ERR_UNSUPPORTED, "FSM too large for the LDS and no global-memory vectors were allocated");
+        L = lds_plan(0, P1p, with_stage);
+        if (size_t(L.total) * 4 > 160 * 1024) return fail(MM_ERR_UNSUPPORTED, "too many pdfs for the LDS: " + std::to_string(h->max_P1));
+        kernel = big;
+        p.ws_big = h->ws_big;
+        p.big_stride = 4ll * h->max_S1p;
+    }
     const size_t lds = size_t(L.total) * 4;
-    if (lds > 160 * 1024)
-        return fail(MM_ERR_UNSUPPORTED, "FSM too large: " + std::to_string(lds) + " B of LDS needed, 163840 available");
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 int(lds)));
     hipLaunchKernelGGL(kernel, dim3(unsigned(h->B)), dim3(64 * NW), lds, static_cast<hipStream_t>(stream), p);
@@ -234,18 +247,18 @@ static int launch(K kernel, mm_batch_t h, const RunParams &p, bool with_stage, i
     return MM_OK;
 }
 
-template <int MODE>
+template <int MODE, bool TROP = false>
 static int launch_log(mm_batch_t h, const RunParams &p, void *stream) {
     const Geometry g = pick_geometry(h);
     const bool st = MODE == MODE_FB;
     if (MODE == MODE_FB && g.NI != 0) {  // forward kernel, then backward kernel on the same stream
-        int rc = launch(mm_log_kernel<MODE, 8, 1>, h, p, st, g.NW, stream);
+        int rc = launch(mm_log_kernel<MODE, 8, 1, TROP, false>, mm_log_kernel<MODE, 8, 1, TROP, true>, h, p, st, g.NW, stream);
         if (rc) return rc;
-        return launch(mm_log_kernel<MODE, 8, 2>, h, p, st, g.NW, stream);
+        return launch(mm_log_kernel<MODE, 8, 2, TROP, false>, mm_log_kernel<MODE, 8, 2, TROP, true>, h, p, st, g.NW, stream);
     }
     switch (g.NI) {
-        case 0: return launch(mm_log_kernel<MODE, 0>, h, p, st, g.NW, stream);
-        default: return launch(mm_log_kernel<MODE, 8>, h, p, st, g.NW, stream);
+        case 0: return launch(mm_log_kernel<MODE, 0, 0, TROP, false>, mm_log_kernel<MODE, 0, 0, TROP, true>, h, p, st, g.NW, stream);
+        default: return launch(mm_log_kernel<MODE, 8, 0, TROP, false>, mm_log_kernel<MODE, 8, 0, TROP, true>, h, p, st, g.NW, stream);
     }
 }
 
@@ -325,9 +338,9 @@ static int launch_tropical(mm_batch_t h, const RunParams &p, void *stream) {
     if (g.NI == 8 && h->max_items <= 8 * MM_MAX_WAVES) {  // as many waves as there is work for (latency), at most 8 items each
         int NW = std::min(MM_MAX_WAVES, std::max(g.NW, (h->max_items + 3) / 4));
         if (h->dbg.nwaves >= g.NW && h->dbg.nwaves <= MM_MAX_WAVES) NW = h->dbg.nwaves;
-        return launch(mm_tropical_kernel<8>, h, p, true, NW, stream);
+        return launch(mm_tropical_kernel<8, false>, mm_tropical_kernel<8, true>, h, p, true, NW, stream);
     }
-    return launch(mm_tropical_kernel<0>, h, p, true, 16, stream);
+    return launch(mm_tropical_kernel<0, false>, mm_tropical_kernel<0, true>, h, p, true, 16, stream);
 }
 
 // The row kernels (mm_kernel_rows.hip): KA register-resident arcs per lane, NWC compute waves + 1 service wave.
@@ -1144,6 +1157,16 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         delete h;
         return fail(MM_ERR_HIP, "mm_batch_create: device allocation failed");
     }
+    {   // FSMs whose state vectors do not fit the LDS: the item / tropical kernels keep them in global memory
+        const int P1p = (h->max_P1 + 3) & ~3;
+        if (size_t(lds_plan(h->max_S1p, P1p, true).total) * 4 > 160 * 1024 || h->dbg.bigv) {
+            if (hipMalloc(&h->ws_big, size_t(B) * 4 * size_t(h->max_S1p) * sizeof(float)) != hipSuccess) {
+                (void)hipFree(h->d_utts);
+                delete h;
+                return fail(MM_ERR_HIP, "mm_batch_create: device allocation failed");
+            }
+        }
+    }
     if (h->pairs_ok) {
         bool good = concurrent_streams(h->device, h->side);
         for (int i = 0; i < 5 && good; ++i) good = hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming) == hipSuccess;
@@ -1173,6 +1196,7 @@ int mm_batch_destroy(mm_batch_t h) {
     for (hipEvent_t e : h->ev)
         if (e) (void)hipEventDestroy(e);
     if (h->d_utts) (void)hipFree(h->d_utts);
+    if (h->ws_big) (void)hipFree(h->ws_big);
     if (h->ws) (void)hipFree(h->ws);
     delete h;
     return MM_OK;
@@ -1350,8 +1374,8 @@ static int run_export(mm_batch_t h, int mode, const float *V, int64_t vsb, int64
     if (h->semiring == MM_TROPICAL) {
         if (mode == MODE_ALPHA) return launch_tropical(h, p, stream);
         const Geometry g = pick_geometry(h);
-        if (g.NI == 0) return launch(mm_log_kernel<MODE_BETA, 0, 0, true>, h, p, false, g.NW, stream);
-        return launch(mm_log_kernel<MODE_BETA, 8, 0, true>, h, p, false, g.NW, stream);
+        if (g.NI == 0) return launch(mm_log_kernel<MODE_BETA, 0, 0, true, false>, mm_log_kernel<MODE_BETA, 0, 0, true, true>, h, p, false, g.NW, stream);
+        return launch(mm_log_kernel<MODE_BETA, 8, 0, true, false>, mm_log_kernel<MODE_BETA, 8, 0, true, true>, h, p, false, g.NW, stream);
     }
     if (mode == MODE_ALPHA) return launch_log<MODE_ALPHA>(h, p, stream);
     return launch_log<MODE_BETA>(h, p, stream);

@@ -104,6 +104,9 @@ struct RunParams {
     int *bp;  // viterbi
     long long bp_stride_n;
     int stop_at_len;  // viterbi without an export of the back-pointers: frames beyond len_b + 1 are not computed
+    // FSMs whose state vectors do not fit the LDS (item / tropical kernels, BIGV): [B][big_stride] floats of global memory
+    float *ws_big;
+    long long big_stride;
     int *path;
     long long path_stride_b;
     float *score;
@@ -500,7 +503,7 @@ __device__ __forceinline__ void for_items(const ItemRegs<NI> &rg, const GraphDev
 // gets its own register allocation and schedule.
 // TROP (MODE_BETA only): the tropical semiring's beta-recursion -- max instead of log-sum-exp, natural-log
 // values, no normalisation (float adds only, like the Viterbi kernel).
-template <int MODE, int NI, int PASS = 0, bool TROP = false>
+template <int MODE, int NI, int PASS = 0, bool TROP = false, bool BIGV = false>
 __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p) {
     extern __shared__ float lds[];
     const int b = p.order ? p.order[blockIdx.x] : blockIdx.x;
@@ -516,8 +519,17 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
     // frames are 1-based n = 1 .. N+1 as in the reference; FB stops at len+1,
     // where only the phony final state is alive (everything after is constant)
     const int NF = (MODE == MODE_FB) ? len + 1 : p.N + 1;
-    const LdsPlan L = lds_plan(S1p, P1p, MODE == MODE_FB);
-    float *buf = lds + L.buf, *stage = lds + L.stage, *em = lds + L.em, *bins = lds + L.bins, *part = lds + L.part;
+    const LdsPlan L = lds_plan(BIGV ? 0 : S1p, P1p, MODE == MODE_FB);
+    // BIGV (FSMs whose state vectors do not fit the LDS): the vectors live in global memory (L2), visible to the other
+    // waves of the workgroup through a release / acquire fence pair around every barrier -- the same code, slower gathers
+    float *em = lds + L.em, *bins = lds + L.bins, *part = lds + L.part;
+    float *buf = BIGV ? p.ws_big + (long long)b * p.big_stride : lds + L.buf;
+    float *stage = BIGV ? buf + 2 * S1p : lds + L.stage;
+    auto vsync = [&]() {
+        if constexpr (BIGV) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if constexpr (BIGV) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    };
     const float *Vb = p.free_run ? nullptr : p.V + (long long)b * p.vsb;
     float *wsA = p.ws_alpha ? p.ws_alpha + u.s1p_prefix * (long long)(p.N + 1) : nullptr;
     double *wsC = p.ws_c ? p.ws_c + (long long)b * (p.N + 2) : nullptr;
@@ -529,7 +541,7 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
         // ---------------- forward: alpha-recursion ----------------
         stage_em(em + 1 * P1p, Vb, p.vsn, 1, len, P, tid, NT, MM_LOG2E);
         for (int q = tid; q < 2 * S1p; q += NT) buf[q] = MM_NINF;
-        __syncthreads();
+        vsync();
         {   // frame 1: alpha_hat (*) lhs[:,1]   (src/inference.jl:68)
             float wm = MM_NINF;
             float *a1 = buf + 1 * S1p;
@@ -544,7 +556,7 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
             if (NF >= 2) stage_em(em + 0 * P1p, Vb, p.vsn, 2, len, P, tid, NT, MM_LOG2E);
             if (tid == 0 && wsC) wsC[1] = 0.0;
         }
-        __syncthreads();
+        vsync();
         load_item_regs<NI>(rg, gf, wave, NW, lane);
         double C = 0.0, Cprev = 0.0;
         // the emissions travel one frame ahead in a register: loaded during step n-1, stored to LDS at the top
@@ -586,7 +598,7 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
             MM_STAMP(2);
             part_put(part + (n & 1) * MM_MAX_WAVES, wave, lane, wm);
             MM_STAMP(3);
-            __syncthreads();
+            vsync();
             MM_STAMP(4);
         }
 #ifdef MM_STAMPS
@@ -605,7 +617,7 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
             for (int s = tid; s < S1; s += NT) dst[s] = (alast[s] + c) * MM_LN2;
             return;
         }
-        __syncthreads();
+        vsync();
     }
 
     if (MODE == MODE_FB && PASS != 1) {
@@ -621,7 +633,7 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
         // frame len+1: B (*) lhs = one for the final state only (src/inference.jl:104,106 + expand)
         for (int q = tid; q < 2 * S1p; q += NT) buf[q] = MM_NINF;
         for (int q = tid; q < 2 * P1p; q += NT) bins[q] = 0.f;
-        __syncthreads();
+        vsync();
         if (tid == 0) buf[(NF & 1) * S1p + fstate] = 0.f;
         if (len >= 1) {
             stage_em(em + (len & 1) * P1p, Vb, p.vsn, len, len, P, tid, NT, MM_LOG2E);
@@ -629,7 +641,7 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
             float4 *dst = reinterpret_cast<float4 *>(stage + (len & 1) * S1p);
             for (int q = tid; q < (S1p >> 2); q += NT) dst[q] = src[q];
         }
-        __syncthreads();
+        vsync();
         load_item_regs<NI>(rg, gb, wave, NW, lane);
         double D = 0.0;
         float tmin = (float)logZ2;
@@ -698,7 +710,7 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
                 wm = max_nc(wm, y);
             });
             part_put(part + (n & 1) * MM_MAX_WAVES, wave, lane, wm);
-            __syncthreads();
+            vsync();
         }
         // finalise frame 1, zero the frames beyond len, reduce ttl
         if (len >= 1 && wave == 0) {
@@ -713,9 +725,9 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
         }
         for (long long q = tid; q < (long long)(p.N - len) * P; q += NT)
             p.gamma[gbase + (len + q / P) * p.gsn + (q % P) * p.gsp] = 0.f;
-        __syncthreads();  // part[] is free again
+        vsync();  // part[] is free again
         if (lane == 0) part[wave] = tmin;
-        __syncthreads();
+        vsync();
         if (tid == 0) {
             float t = part[0];
             for (int w = 1; w < NW; ++w) t = fminf(t, part[w]);
@@ -727,7 +739,7 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
         // beta-recursion export (src/inference.jl:99-110): all N+1 frames, B[:,N+1] = one
         for (int q = tid; q < 2 * S1p; q += NT) buf[q] = MM_NINF;
         stage_em(em + (NF & 1) * P1p, Vb, p.vsn, NF, len, P, tid, NT, (TROP ? 1.0f : MM_LOG2E));
-        __syncthreads();
+        vsync();
         {
             float *yl = buf + (NF & 1) * S1p;
             const float *el = em + (NF & 1) * P1p;
@@ -743,7 +755,7 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
             if (lane == 0) part[(NF & 1) * MM_MAX_WAVES + wave] = wm;
             if (NF - 1 >= 1) stage_em(em + ((NF - 1) & 1) * P1p, Vb, p.vsn, NF - 1, len, P, tid, NT, (TROP ? 1.0f : MM_LOG2E));
         }
-        __syncthreads();
+        vsync();
         load_item_regs<NI>(rg, gb, wave, NW, lane);
         double D = 0.0;
         for (int n = NF - 1; n >= 1; --n) {
@@ -765,7 +777,7 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
             });
             wm = wave_max(wm);
             if (lane == 0) part[(n & 1) * MM_MAX_WAVES + wave] = wm;
-            __syncthreads();
+            vsync();
         }
     }
 }
@@ -802,7 +814,7 @@ __device__ __forceinline__ void trop_grp_reduce(float &best, int &arg, int log2g
 
 // NI items per wave live in registers for the whole time loop (ItemRegs), the rest is streamed.
 // Back-pointers are collected in LDS and leave the chip as whole rows one frame later.
-template <int NI>
+template <int NI, bool BIGV = false>
 __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
     extern __shared__ float lds[];
     const int b = blockIdx.x;
@@ -814,9 +826,15 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
     len = len < 0 ? 0 : (len > p.N ? p.N : len);
     if (p.free_run == 2) len = 0;
     const int NF = p.N + 1;
-    const LdsPlan L = lds_plan(S1p, P1p, true);
-    float *buf = lds + L.buf, *em = lds + L.em;
-    int *bpbuf = reinterpret_cast<int *>(lds + L.stage);  // [2][S1p]
+    const LdsPlan L = lds_plan(BIGV ? 0 : S1p, P1p, true);
+    float *em = lds + L.em;
+    float *buf = BIGV ? p.ws_big + (long long)b * p.big_stride : lds + L.buf;  // (BIGV: see mm_log_kernel)
+    auto vsync = [&]() {
+        if constexpr (BIGV) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if constexpr (BIGV) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    };
+    int *bpbuf = reinterpret_cast<int *>(BIGV ? buf + 2 * S1p : lds + L.stage);  // [2][S1p]
     const float *Vb = p.free_run ? nullptr : p.V + (long long)b * p.vsb;
     const GraphDev gf = u.g[0];
     int *bpb = p.bp ? p.bp + u.state_off : nullptr;
@@ -827,7 +845,7 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
         buf[q] = MM_NINF;
         bpbuf[q] = -1;
     }
-    __syncthreads();
+    vsync();
     {
         float *a1 = buf + 1 * S1p;
         const float *e1 = em + 1 * P1p;
@@ -839,7 +857,7 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
         if (NF >= 2) stage_em(em + 0 * P1p, Vb, p.vsn, 2, len, P, tid, NT, 1.0f);
     }
     load_item_regs<NI>(rg, gf, wave, NW, lane);
-    __syncthreads();
+    vsync();
     if (len == 0 && tid == 0 && p.score) p.score[b] = buf[1 * S1p + S1 - 1];
     // (the best path ends in the phony final state at frame len + 1; later frames matter to an export only)
     const int n_end = (p.stop_at_len && !p.out && len + 1 < NF) ? (len + 1 < 1 ? 1 : len + 1) : NF;
@@ -909,7 +927,7 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
             }
             if (P >= NT) stage_em(em + ((n + 1) & 1) * P1p + NT, Vb ? Vb + NT : nullptr, p.vsn, n + 1, len, P - NT, tid, NT, 1.0f);
         }
-        __syncthreads();
+        vsync();
         if (n == len + 1 && tid == 0 && p.score) p.score[b] = an[S1 - 1];
     }
     if (bpb && n_end >= 2) {

@@ -339,10 +339,12 @@ def test_lfmmi_loss_and_gradient(mm, wl, oracle, torch):
 
 @pytest.mark.parametrize("env", [{"MM_KERNEL": "item"}, {"MM_KERNEL": "quad"}, {"MM_KERNEL": "row"},
                                  {"MM_KERNEL": "quad", "MM_KQ": "1"}, {"MM_KERNEL": "quad", "MM_KQ": "2", "MM_NWAVES": "3"},
-                                 {"MM_KERNEL": "quad", "MM_KQ": "15"}, {"MM_KERNEL": "quad", "MM_KQ": "7"}])
+                                 {"MM_KERNEL": "quad", "MM_KQ": "15"}, {"MM_KERNEL": "quad", "MM_KQ": "7"},
+                                 {"MM_KERNEL": "item", "MM_BIGV": "1"}, {"MM_KERNEL": "item", "MM_BIGV": "1", "MM_NITEMS": "0"}])
 def test_kernel_variants_agree(mm, wl, oracle, torch, env):
     """The general (item) kernel, the row kernel, the quad kernel with a streamed overflow (virtual lanes: KQ
-    too small for the graph), an 8-wave geometry and a 16-wave one all give the oracle's posteriors.  (The
+    too small for the graph), an 8-wave geometry and a 16-wave one, and the item kernel with its state vectors in
+    global memory (MM_BIGV: the path of FSMs beyond the LDS) all give the oracle's posteriors.  (The
     switches are test aids: read once at batch creation, and only under MM_DEBUG.)"""
     o, oc = oracle
     g = wl.lfmmi_denominator(600, 40, seed=5)
@@ -454,3 +456,39 @@ def test_c_abi_collectives_one_rank(mm, torch):
         assert torch.equal(allttl, ttl)
     finally:
         comm.close()
+
+
+@pytest.mark.gpu
+def test_fsm_beyond_the_lds(mm, wl, oracle, torch):
+    """An FSM whose state vectors do not fit the LDS (the reference has no size limit, src/linalg.jl:170-181): the item
+    and tropical kernels keep the vectors in global memory.  pdfposteriors against the float64 oracle, Viterbi against
+    the float32 one (bit exact), alpha / beta exports against each other through log Z."""
+    o, oc = oracle
+    g = wl.lexicon_fsm(24000, 50, seed=3)  # 16 B/state of LDS would need 384 KB
+    rng = np.random.default_rng(5)
+    B, N = 2, 12
+    V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+    lens = np.array([12, 9], dtype=np.int32)
+    g_ref, t_ref = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V, lens, dtype=np.float64)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(cf, cf)
+    assert "mm_log_kernel" in bf.kernels("log")
+    Vd, ld = torch.from_numpy(V).cuda(), torch.from_numpy(lens).cuda()
+    gam, ttl = bf.pdfposteriors(Vd, ld)
+    torch.cuda.synchronize()
+    check_gamma(gam.cpu().numpy(), g_ref, lens)
+    assert np.allclose(ttl.cpu().numpy(), t_ref, rtol=1e-5, atol=1e-4)
+    A, Bm = bf.alpharecursion(Vd, ld).cpu().numpy(), bf.betarecursion(Vd, ld).cpu().numpy()
+    S1 = g.S + 1
+    for b in range(B):
+        for n in (0, int(lens[b]) // 2, int(lens[b])):
+            z = np.logaddexp.reduce((A[b * S1:(b + 1) * S1, n] + Bm[b * S1:(b + 1) * S1, n]).astype(np.float64))
+            assert abs(z - t_ref[b]) <= 1e-3 * max(1.0, abs(t_ref[b])), (b, n, z, t_ref[b])
+    ct = mm.compile(wl.to_fsm(mm, g, "tropical"), mm.statemap(g.state2pdf, g.P))
+    bt = mm.batch(ct, ct)
+    path, score = bt.viterbi(Vd, ld)
+    torch.cuda.synchronize()
+    for b in range(B):
+        p_ref, s_ref, _ = oc.viterbi(graphs.to_oracle(o, g, "tropical", np.float32), g.state2pdf, g.P, V[b], int(lens[b]),
+                                     dtype=np.float32)
+        assert np.array_equal(path[b, : lens[b]].cpu().numpy(), p_ref[: lens[b]]) and float(score[b]) == float(np.ravel(s_ref)[0])

@@ -204,6 +204,12 @@ __device__ __forceinline__ void pk_mul_wlo(mm_f32x2 &acc, const mm_f32x2 &w2, co
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(acc) : "v"(w2), "v"(x));
 }
 
+#ifndef MM_EXP_QADDR
+#define MM_EXP_QADDR (info2 >> 16)
+#endif
+#ifndef MM_EXP_ALADDR
+#define MM_EXP_ALADDR (info2 & 0xffffu)
+#endif
 template <int KA>
 struct PairRegs {  // what a compute wave keeps across the steps
     mm_f32x2 w2[KA / 2];
@@ -615,8 +621,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                 const unsigned alb = L::AL(0, 0) + (unsigned)(t % 3) * 2u * RS;
                 float al0 = 0.f, al1 = 0.f;
                 if constexpr (PHASE == 1) {
-                    al0 = ldsr((info2 & 0xffffu) + alb);
-                    al1 = ldsr((info2 & 0xffffu) + alb + RS);
+                    al0 = ldsr(MM_EXP_ALADDR + alb);
+                    al1 = ldsr(MM_EXP_ALADDR + alb + RS);
                 }
                 float *row0 = U[0].rows + (long long)(f <= p.N ? f : 0) * S1p, *row1 = U[1].rows + (long long)(f <= p.N ? f : 0) * S1p;
                 // even / odd arcs (phase B has no registers to spare: one chain there)
@@ -651,7 +657,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                         *reinterpret_cast<float *>(reinterpret_cast<char *>(row0) + (pos8 >> 1)) = st0;
                         *reinterpret_cast<float *>(reinterpret_cast<char *>(row1) + (pos8 >> 1)) = st1;
                     } else {
-                        ldsw2((info2 >> 16) + L::Q(WR), fast_exp2(st0 + al0), fast_exp2(st1 + al1));  // A .* B   (:154)
+                        ldsw2(MM_EXP_QADDR + L::Q(WR), fast_exp2(st0 + al0), fast_exp2(st1 + al1));  // A .* B   (:154)
                     }
                     accA = mm_f32x2{0.f, 0.f};
                     sa += 512u;
@@ -661,8 +667,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                     infoN = ldsru(sa + 512u);
                     if constexpr (PHASE == 1) {
                         asm volatile("v_mov_b32 %0, %1" : "=v"(info2) : "v"(info2N));
-                        al0 = ldsr((info2 & 0xffffu) + alb);
-                        al1 = ldsr((info2 & 0xffffu) + alb + RS);
+                        al0 = ldsr(MM_EXP_ALADDR + alb);
+                        al1 = ldsr(MM_EXP_ALADDR + alb + RS);
                         info2N = ldsru(sa + 516u);
                     }
                 };

@@ -224,6 +224,37 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
             g.pdfse[2 * p] = uint16_t(first[p] < 0 ? 0 : first[p]);
             g.pdfse[2 * p + 1] = uint16_t(first[p] < 0 ? 0 : last[p] + 1);
         }
+        // Inside a pdf's range the order is free: a finish stores the posteriors of its 64 / g rows to their q
+        // positions in one LDS store (lane groups of 32 for 4-byte entries, of 16 for the pair form's 8-byte entries;
+        // bank = position mod 32), so the rows that share such a group get positions in distinct banks where their
+        // ranges allow it (measured on config 3 with conflict-free stores: -3 % in the phase that combines).
+        std::vector<char> taken(size_t(nrows), 0);
+        std::fill(qpos.begin(), qpos.end(), -1);
+        const int G = opt.pair ? 16 : 32;
+        const int trash_bank = int(nrows % 32);  // (the lanes that finish nothing store to the position behind the last)
+        for (int w = 0; w < NWC; ++w)
+            for (int si : best.wave_segs[w]) {
+                const Segment &sg = best.segs[si];
+                for (int l0 = 0; l0 < 64; l0 += G) {
+                    unsigned used = (sg.g > 1 || int(sg.rows.size()) * sg.g < 64) ? 1u << trash_bank : 0u;
+                    for (int l = l0; l < l0 + G; ++l) {
+                        if (l % sg.g != sg.g - 1 || l / sg.g >= int(sg.rows.size())) continue;
+                        const int32_t r = sg.rows[l / sg.g], pd = row2pdf[r];
+                        int64_t pick = -1;
+                        for (int64_t q = first[pd]; q <= last[pd]; ++q)
+                            if (!taken[q]) {
+                                if (pick < 0) pick = q;
+                                if (!((used >> (q % 32)) & 1u)) {
+                                    pick = q;
+                                    break;
+                                }
+                            }
+                        taken[pick] = 1;
+                        used |= 1u << (pick % 32);
+                        qpos[r] = int32_t(pick);
+                    }
+                }
+            }
     }
     // ---- CSR in internal numbering (exact fallback)
     g.rowptr.assign(size_t(nrows) + 1, 0);

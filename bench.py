@@ -9,7 +9,7 @@ is B = 2048 over 8 GPUs = 256 per GPU).  At N > 1 GPUs the utterances are
 sharded (they are independent: block-diagonal batch) and each step ends with
 the one real exchange of the path, the total-log-likelihood all-reduce (RCCL).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (see the task contract), including
@@ -127,8 +127,8 @@ def host_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="lfmmi_den")
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default: the config's)")
     ap.add_argument("--frames", type=int, default=0)

@@ -167,6 +167,13 @@ int mm_viterbi_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t
  * weight one is the accumulator) for n + 1 frames.  n >= 1; out: device float[B], natural log. */
 int mm_totalsum_f32(mm_batch_t batch, int64_t n, int cumulative, float *out, void *stream);
 
+/* Deterministic mode (default off).  Every kernel but one reduces in a fixed order; the general ("item") kernel -- the
+ * path of small deep graphs such as LF-MMI numerators -- adds a pdf's state posteriors with LDS float atomics, so the
+ * last bits of its gamma can differ between runs.  on != 0 makes it sum over per-pdf state lists in a fixed order
+ * instead (one more workgroup barrier per frame: ~20 % slower on such graphs).  The reference has no such switch: its
+ * CPU path is deterministic, its CUDA path (src/linalg.jl:213-233) reduces in warp-shuffle order, also fixed. */
+int mm_batch_set_deterministic(mm_batch_t batch, int on);
+
 /* ---- multi-GPU boundary (one process per GPU, RCCL over xGMI) -------------------------------------------------
  * The batch is block diagonal (src/fsmops.jl:28-36, src/inference.jl:28-36): utterances shard over the ranks with no
  * collective on the data path.  The only exchange is the total log-likelihood the LF-MMI loss consumes

@@ -30,6 +30,7 @@ SYMBOLS = [
     "mm_batch_workspace_bytes",
     "mm_batch_kernels",
     "mm_batch_reserve",
+    "mm_batch_set_deterministic",
     "mm_pdfposteriors_f32",
     "mm_alpharecursion_f32",
     "mm_betarecursion_f32",
@@ -88,6 +89,8 @@ def _load():
     lib.mm_batch_workspace_bytes.argtypes = [vp, i64]
     lib.mm_batch_reserve.restype = C.c_int
     lib.mm_batch_reserve.argtypes = [vp, i64]
+    lib.mm_batch_set_deterministic.restype = C.c_int
+    lib.mm_batch_set_deterministic.argtypes = [vp, C.c_int]
     lib.mm_batch_kernels.restype = C.c_int
     lib.mm_batch_kernels.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
     lib.mm_pdfposteriors_f32.restype = C.c_int

@@ -142,6 +142,7 @@ struct mm_fsm_s {
     GraphDev gdev[2];
     const float *d_init = nullptr;
     const int *d_s2p = nullptr;
+    const int *d_pdf_ptr = nullptr, *d_pdf_rows = nullptr;  // pdf -> states (CSR)
 };
 
 // Test/diagnostic switches.  Read from the environment ONCE, at mm_batch_create, and only when MM_DEBUG is
@@ -197,6 +198,7 @@ struct mm_batch_s {
     // process-wide pair that was SEEN to run kernels concurrently, concurrent_streams()); the caller's stream forks into
     // them and joins them
     hipStream_t side[2] = {nullptr, nullptr};
+    bool deterministic = false;  // mm_batch_set_deterministic(): no float atomics in the item kernel
     float *ws_big = nullptr;  // [B][4 * max_S1p]: state vectors of FSMs beyond the LDS (launch())
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int device = -1;
@@ -230,6 +232,7 @@ template <typename K>
 static int launch(K kernel, K big, mm_batch_t h, const RunParams &p0, bool with_stage, int NW, void *stream) {
     const int P1p = (h->max_P1 + 3) & ~3;
     RunParams p = p0;
+    p.deterministic = h->deterministic ? 1 : 0;
     LdsPlan L = lds_plan(h->max_S1p, P1p, with_stage);
     if (size_t(L.total) * 4 > 160 * 1024 || h->dbg.bigv) {
         if (!h->ws_big) return fail(MM_ERR_UNSUPPORTED, "FSM too large for the LDS and no global-memory vectors were allocated");
@@ -661,6 +664,15 @@ static int fsm_to_device(mm_fsm_t f) {
         o_slots[d] = bl.add(f->packed[d].slots);
     }
     const size_t o_init = bl.add(f->init), o_s2p = bl.add(f->s2p);
+    // pdf -> states (CSR): in deterministic mode the item kernel sums a pdf's state posteriors over this list, in this order
+    std::vector<int32_t> pdf_ptr(size_t(f->P1) + 1, 0), pdf_rows(size_t(f->S1), 0);
+    for (int64_t s = 0; s < f->S1; ++s) ++pdf_ptr[size_t(f->s2p[s]) + 1];
+    for (int32_t q = 0; q < f->P1; ++q) pdf_ptr[q + 1] += pdf_ptr[q];
+    {
+        std::vector<int32_t> fill(pdf_ptr.begin(), pdf_ptr.end() - 1);
+        for (int64_t s = 0; s < f->S1; ++s) pdf_rows[size_t(fill[f->s2p[s]]++)] = int32_t(s);
+    }
+    const size_t o_pptr = bl.add(pdf_ptr), o_prows = bl.add(pdf_rows);
     void *blob = nullptr;
     int rc = upload(bl, &blob);
     if (rc) return rc;
@@ -675,6 +687,8 @@ static int fsm_to_device(mm_fsm_t f) {
     }
     f->d_init = reinterpret_cast<const float *>(base + o_init);
     f->d_s2p = reinterpret_cast<const int *>(base + o_s2p);
+    f->d_pdf_ptr = reinterpret_cast<const int *>(base + o_pptr);
+    f->d_pdf_rows = reinterpret_cast<const int *>(base + o_prows);
     f->dev_blob = blob;
     f->dev_bytes = bl.host.size();
     f->device = dev;
@@ -1133,6 +1147,8 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             }
         u.init = f->d_init;
         u.s2p = f->d_s2p;
+        u.pdf_ptr = f->d_pdf_ptr;
+        u.pdf_rows = f->d_pdf_rows;
         u.S1 = int(f->S1);
         u.S1p = f->S1p;
         u.P1 = f->P1;
@@ -1203,6 +1219,12 @@ int mm_batch_destroy(mm_batch_t h) {
 }
 
 int64_t mm_batch_total_states(mm_batch_t h) { return h ? h->total_states : -1; }
+
+int mm_batch_set_deterministic(mm_batch_t h, int on) {
+    if (!h) return fail(MM_ERR_INVALID, "mm_batch_set_deterministic: NULL batch");
+    h->deterministic = on != 0;
+    return MM_OK;
+}
 
 int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
     if (!h || !buf || n < 2) return fail(MM_ERR_INVALID, "mm_batch_kernels: bad argument");

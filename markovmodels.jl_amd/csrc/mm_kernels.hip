@@ -83,6 +83,7 @@ struct UttDesc {
     const unsigned short *map_bf;   // backward position -> forward position
     const float *init;  // dense alpha_hat [S1] (log2 domain for MM_LOG, natural for MM_TROPICAL)
     const int *s2p;     // state -> pdf [S1]
+    const int *pdf_ptr, *pdf_rows;  // pdf -> states, CSR [P1 + 1], [S1]
     int S1, S1p, P1, pad;
     long long state_off;   // offset of this FSM in the block-diagonal state space
     long long s1p_prefix;  // sum of S1p of the utterances before this one
@@ -107,6 +108,7 @@ struct RunParams {
     // FSMs whose state vectors do not fit the LDS (item / tropical kernels, BIGV): [B][big_stride] floats of global memory
     float *ws_big;
     long long big_stride;
+    int deterministic;  // item kernel: per-pdf sums over the pdf -> states lists in a fixed order instead of LDS float atomics
     int *path;
     long long path_stride_b;
     float *score;
@@ -643,6 +645,7 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
         }
         vsync();
         load_item_regs<NI>(rg, gb, wave, NW, lane);
+        const bool det = __builtin_amdgcn_readfirstlane(p.deterministic) != 0;
         double D = 0.0;
         float tmin = (float)logZ2;
         // frame n-1 (emissions, alpha, C) travels in registers: loaded during step n+1, stored to LDS at the
@@ -664,7 +667,7 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
         for (int n = len; n >= 1; --n) {
             const float *yp = buf + ((n + 1) & 1) * S1p;
             float *yn = buf + (n & 1) * S1p;
-            const float *ast = stage + (n & 1) * S1p;
+            float *ast = stage + (n & 1) * S1p;  // alpha~ of frame n (deterministic mode: replaced by the posteriors as they are made)
             const float *emn = em + (n & 1) * P1p;
             float *bn = bins + (n & 1) * P1p;
             const float M = (n == len) ? 0.f : part_max_dpp(part + ((n + 1) & 1) * MM_MAX_WAVES, NW, lane);
@@ -704,13 +707,31 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
             for_items<NI>(rg, gb, wave, NW, lane, yp, emn, [&](float v, int row, int pdf, float e) {
                 const float beta = v - M;  // T (B[:,n+1] (*) lhs[:,n+1])   (src/inference.jl:106-107)
                 const float q = fast_exp2(ast[row] + beta - kappa);  // state_A .* state_B / Z
-                if (q > 0.f) atomicAdd(&bn[pdf], q);
+                if (det) ast[row] = q;
+                else if (q > 0.f) atomicAdd(&bn[pdf], q);
                 const float y = beta + e;
                 yn[row] = y;
                 wm = max_nc(wm, y);
             });
             part_put(part + (n & 1) * MM_MAX_WAVES, wave, lane, wm);
             vsync();
+            if (det) {
+                // C' * (A .* B) (:155) without atomics: a pdf's states are listed in pdf_rows; 8 lanes per pdf add their
+                // posteriors in a fixed order, a 3-step DPP reduction ends it: the same bits on every run.  The second
+                // barrier also guards the buffer (the next step stages alpha~ of frame n - 2 over the posteriors).  Costs a
+                // small deep graph ~20 % (WSJ numerator x128: 2.14 -> 2.6 ms), hence opt-in like PyTorch's deterministic mode.
+                for (int p0 = wave * 8; p0 < P1; p0 += NW * 8) {
+                    const int pdf = p0 + (lane >> 3);
+                    float sacc = 0.f;
+                    if (pdf < P1) {
+                        const int e0 = u.pdf_ptr[pdf], e1 = u.pdf_ptr[pdf + 1];
+                        for (int k = e0 + (lane & 7); k < e1; k += 8) sacc += ast[u.pdf_rows[k]];
+                    }
+                    sacc = grp_sum(sacc, 3);
+                    if (pdf < P1 && (lane & 7) == 0) bn[pdf] = sacc;
+                }
+                vsync();
+            }
         }
         // finalise frame 1, zero the frames beyond len, reduce ttl
         if (len >= 1 && wave == 0) {

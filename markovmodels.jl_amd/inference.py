@@ -207,6 +207,11 @@ class BatchedFSM:
         a hipGraph -- never reallocate)."""
         check(lib.mm_batch_reserve(self._h, int(N)))
 
+    def set_deterministic(self, on: bool = True):
+        """No float atomics in the general kernel: bit-identical gamma on every run (slower on small deep graphs)."""
+        check(lib.mm_batch_set_deterministic(self._h, 1 if on else 0))
+        return self
+
     def kernels(self, semiring: str = "log") -> str:
         """The kernels the engine launches for this batch (informational)."""
         import ctypes

@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle
 on the same seeded inputs.  Tolerances follow BASELINE.json's north_star:
 log-posteriors within 1e-4 relative, Viterbi back-pointers bit exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -492,3 +494,23 @@ def test_fsm_beyond_the_lds(mm, wl, oracle, torch):
         p_ref, s_ref, _ = oc.viterbi(graphs.to_oracle(o, g, "tropical", np.float32), g.state2pdf, g.P, V[b], int(lens[b]),
                                      dtype=np.float32)
         assert np.array_equal(path[b, : lens[b]].cpu().numpy(), p_ref[: lens[b]]) and float(score[b]) == float(np.ravel(s_ref)[0])
+
+
+@pytest.mark.gpu
+def test_deterministic_mode_of_the_item_kernel(mm, wl, torch):
+    """mm_batch_set_deterministic: the general kernel -- the numerator path -- sums a pdf's state posteriors over a
+    fixed list instead of LDS float atomics: identical bits on every run, and the committed oracle values."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "num_fsm_wsj_oracle.npz"))
+    g = wl.load_npz_graph(os.path.join(os.path.dirname(__file__), "golden", "num_fsm_wsj.npz"))
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    V, lens = torch.from_numpy(z["V"]).cuda(), torch.from_numpy(z["lens"]).cuda()
+    bf = mm.batch(*([cf] * V.shape[0])).set_deterministic(True)
+    assert "mm_log_kernel" in bf.kernels("log")
+    runs = [bf.pdfposteriors(V, lens) for _ in range(4)]
+    torch.cuda.synchronize()
+    for gam, ttl in runs[1:]:
+        assert torch.equal(gam, runs[0][0]) and torch.equal(ttl, runs[0][1])
+    ok = np.isfinite(z["ttl"])
+    gam = runs[0][0].cpu().numpy()
+    check_gamma(gam[ok], z["gamma"][ok].astype(np.float64), z["lens"][ok])
+    assert (gam[~ok] == 0).all()

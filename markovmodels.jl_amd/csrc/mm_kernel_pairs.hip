@@ -634,14 +634,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                     const int lg = (int)(lgw & 15ull);
                     lgw >>= 4;
                     float s0 = accA.x, s1 = accA.y;
-                    if (lg) {
-                        if constexpr (PHASE == 0) {
-                            grp_sum_last2(s0, s1, lg);
-                        } else {
-                            s0 = grp_sum_last(s0, lg);
-                            s1 = grp_sum_last(s1, lg);
-                        }
-                    }
+                    if (lg) grp_sum_last2(s0, s1, lg);
                     const unsigned pos8 = info & 0xffffu;
                     // forward: (T' alpha) (*) lhs (src/inference.jl:70-71); backward: T (B (*) lhs) (:106-107), the emission is
                     // added for the next step's product only

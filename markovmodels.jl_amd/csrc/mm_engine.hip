@@ -803,9 +803,7 @@ static int pair_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
     opt.rs = MM_ROW_RS;
     opt.ka_max = MM_PAIR_KA;
     opt.pair = true;
-    // (the pair kernels' waves lower their priority as they advance: the waves of a SIMD progress together, no wave is
-    // "slower" than another)
-    for (float &x : opt.group_speed) x = 1.f;
+    for (float &x : opt.group_speed) x = 1.f;  // (the waves of a SIMD progress together: mm_rows.h)
     if (dbg.finish_cost > 0) opt.finish_cost = dbg.finish_cost;
     if (dbg.group_speed[0] > 0)
         for (int i = 0; i < 4; ++i) opt.group_speed[i] = dbg.group_speed[i];

@@ -185,11 +185,11 @@ __device__ __forceinline__ void pair_pdf_sums(unsigned qbase, unsigned pdfse_bas
     }
 }
 
-// The arcs of a compute wave, two at a time, for two utterances (8-byte gathers, D pairs ahead of the FMAs), statically
-// unrolled (the graph registers need static indices).  A segment may end after any pair (wave-uniform bit test).  Every
-// wave runs the whole window: the pairs behind its last segment have weight 0 (a few wasted gathers); leaving early
-// costs more -- however it is written, the compiler keeps a "done" flag that every pair re-tests (3 scalar
-// instructions per pair).
+// The arcs of a compute wave for two utterances (8-byte gathers, D pairs of arcs ahead of the FMAs), statically unrolled
+// (the graph registers need static indices).  A segment may end after any pair of arcs; pair_two() / MM_PAIR_TWO test
+// the end mask once per TWO pairs.  Every wave runs the whole window: the pairs behind its last segment have weight 0
+// (a few wasted gathers); leaving early costs more -- a `goto` out of the rare path made the compiler add an
+// s_cbranch_execz to every test.
 // acc += w (broadcast) * x for the two utterances in ONE packed FMA (v_pk_fma_f32 issues at the rate of v_fma_f32 on
 // gfx950): the weights of an arc pair share an aligned register pair, op_sel picks the half that both lanes of the
 // packed operation use.

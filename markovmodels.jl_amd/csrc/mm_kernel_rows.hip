@@ -401,8 +401,8 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
     MM_STAMP_DECL;
     // Issue arbitration between the four waves of a SIMD goes by priority, then age.  The service wave is the youngest
     // of its SIMD and would get the leftover slots only (measured with cycle stamps: its ~300 instructions took a whole
-    // frame); its work is short, so it goes first.  (Among the compute waves age stays: the segments are dealt out so
-    // that the older waves get more, mm_rows.h RowPackOpts::group_speed.)
+    // frame); its work is short, so it goes first.  (The compute waves lower their own priority as they advance
+    // through a step, row_pairs(): the four waves of a SIMD then progress together whatever their age.)
     if (service) __builtin_amdgcn_s_setprio(3);
 
     // ---- set-up common to both directions

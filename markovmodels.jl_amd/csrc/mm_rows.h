@@ -79,10 +79,11 @@ struct RowPackOpts {
     int rs = 8192;        // LDS region stride in bytes
     int finish_cost = 8;  // cost of one finish in units of one arc (gather + FMA)
     int group_cost = 2;   // extra cost per butterfly level of a grouped (g > 1) segment
-    // Relative speed of waves 4k..4k+3 of the workgroup.  The four waves of a SIMD (one of each such group) are
-    // arbitrated oldest first, so with equal work the later waves of a workgroup reach the frame's barrier last
-    // and spend the tail of the frame alone, latency bound (measured with cycle stamps: +30 % for the last group).
-    // The segments are dealt so that load / speed is level.
+    // Relative speed of waves 4k..4k+3 of the workgroup (load / speed is levelled).  The four waves of a SIMD (one of
+    // each such group) are arbitrated by priority, then oldest first.  With plain oldest-first arbitration the youngest
+    // group was 30 % slower (cycle stamps); since the waves lower their own priority as they advance through a step
+    // they progress together: the pair forms use speeds of 1 (mm_engine.hip), the row kernels -- whose service wave
+    // is the longest of a step -- still measure best with the old weights (config 3 forced: 4.5 against 4.6 ms).
     float group_speed[4] = {1.0f, 0.92f, 0.80f, 0.70f};
     // Pair form (mm_kernel_pairs.hip: two utterances per workgroup share the graph registers; the linear vector holds
     // their values side by side, 8 bytes per state, fetched by one ds_read_b64): addresses and slot-table fields are

@@ -199,7 +199,7 @@ struct mm_batch_s {
     // them and joins them
     hipStream_t side[2] = {nullptr, nullptr};
     bool deterministic = false;  // mm_batch_set_deterministic(): no float atomics in the item kernel
-    float *ws_big = nullptr;  // [B][6 * max_S1p]: state vectors of FSMs beyond the LDS (launch())
+    float *ws_big = nullptr;  // [B][4 * max_S1p]: state vectors of FSMs beyond the LDS (launch())
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int device = -1;
     int n_cus = 256;  // compute units of the device
@@ -229,20 +229,18 @@ static Geometry pick_geometry(mm_batch_t h) {
 // item / tropical kernels: `kernel` keeps the state vectors in LDS; `big` is the same kernel with the vectors in global
 // memory, for FSMs beyond the LDS (the reference has no size limit: src/linalg.jl:170-181)
 template <typename K>
-static int launch(K kernel, K big, mm_batch_t h, const RunParams &p0, bool with_stage, int NW, void *stream,
-                  int extra_vectors = 0) {  // (extra_vectors: more [S1p] arrays behind the LDS plan -- the Viterbi ancestors)
+static int launch(K kernel, K big, mm_batch_t h, const RunParams &p0, bool with_stage, int NW, void *stream) {
     const int P1p = (h->max_P1 + 3) & ~3;
     RunParams p = p0;
     p.deterministic = h->deterministic ? 1 : 0;
     LdsPlan L = lds_plan(h->max_S1p, P1p, with_stage);
-    L.total += extra_vectors * h->max_S1p;
     if (size_t(L.total) * 4 > 160 * 1024 || h->dbg.bigv) {
         if (!h->ws_big) return fail(MM_ERR_UNSUPPORTED, "FSM too large for the LDS and no global-memory vectors were allocated");
         L = lds_plan(0, P1p, with_stage);
         if (size_t(L.total) * 4 > 160 * 1024) return fail(MM_ERR_UNSUPPORTED, "too many pdfs for the LDS: " + std::to_string(h->max_P1));
         kernel = big;
         p.ws_big = h->ws_big;
-        p.big_stride = 6ll * h->max_S1p;
+        p.big_stride = 4ll * h->max_S1p;
     }
     const size_t lds = size_t(L.total) * 4;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -343,9 +341,9 @@ static int launch_tropical(mm_batch_t h, const RunParams &p, void *stream) {
     if (g.NI == 8 && h->max_items <= 8 * MM_MAX_WAVES) {  // as many waves as there is work for (latency), at most 8 items each
         int NW = std::min(MM_MAX_WAVES, std::max(g.NW, (h->max_items + 3) / 4));
         if (h->dbg.nwaves >= g.NW && h->dbg.nwaves <= MM_MAX_WAVES) NW = h->dbg.nwaves;
-        return launch(mm_tropical_kernel<8, false>, mm_tropical_kernel<8, true>, h, p, true, NW, stream, 2);
+        return launch(mm_tropical_kernel<8, false>, mm_tropical_kernel<8, true>, h, p, true, NW, stream);
     }
-    return launch(mm_tropical_kernel<0, false>, mm_tropical_kernel<0, true>, h, p, true, 16, stream, 2);
+    return launch(mm_tropical_kernel<0, false>, mm_tropical_kernel<0, true>, h, p, true, 16, stream);
 }
 
 // The row kernels (mm_kernel_rows.hip): KA register-resident arcs per lane, NWC compute waves + 1 service wave.
@@ -1179,8 +1177,8 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     }
     {   // FSMs whose state vectors do not fit the LDS: the item / tropical kernels keep them in global memory
         const int P1p = (h->max_P1 + 3) & ~3;
-        if ((size_t(lds_plan(h->max_S1p, P1p, true).total) + 2 * size_t(h->max_S1p)) * 4 > 160 * 1024 || h->dbg.bigv) {
-            if (hipMalloc(&h->ws_big, size_t(B) * 6 * size_t(h->max_S1p) * sizeof(float)) != hipSuccess) {
+        if (size_t(lds_plan(h->max_S1p, P1p, true).total) * 4 > 160 * 1024 || h->dbg.bigv) {
+            if (hipMalloc(&h->ws_big, size_t(B) * 4 * size_t(h->max_S1p) * sizeof(float)) != hipSuccess) {
                 (void)hipFree(h->d_utts);
                 delete h;
                 return fail(MM_ERR_HIP, "mm_batch_create: device allocation failed");
@@ -1302,12 +1300,8 @@ int mm_batch_reserve(mm_batch_t h, int64_t N) {
     int dev = -1;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != h->device) return fail(MM_ERR_INVALID, "mm_batch_reserve: batch lives on another device");
-    // (the Viterbi back-pointers -- with the ancestors and the path at the checkpoints behind them -- and the total-sum
-    // rows share the workspace: [N + 1][total states] words)
-    const size_t vit = align_up(size_t(h->total_states) * size_t(N + 1) * 4, 256) +
-                       align_up(size_t(h->total_states) * size_t(N / MM_ANC_K + 3) * 4, 256) +
-                       align_up(size_t(h->B) * size_t(N / MM_ANC_K + 2) * 4, 256);
-    return ensure_ws(h, std::max(mm_batch_workspace_bytes(h, N), vit));
+    // (the Viterbi back-pointers and the total-sum rows share the workspace: [N + 1][total states] words)
+    return ensure_ws(h, std::max(mm_batch_workspace_bytes(h, N), align_up(size_t(h->total_states) * size_t(N + 1) * 4, 256)));
 }
 
 static int check_run(mm_batch_t h, const char *who, const float *V, int64_t N, int want_semiring) {
@@ -1526,22 +1520,15 @@ int mm_viterbi_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const
     if (!path || !score) return fail(MM_ERR_INVALID, "mm_viterbi_f32: path/score is NULL");
     if (path_stride_b < N) return fail(MM_ERR_DIM, "mm_viterbi_f32: path_stride_b < N");
     RunParams p{};
-    // workspace: [back-pointers unless the caller exports them][ancestors at the checkpoints][best path at the checkpoints]
-    const size_t bp_bytes = bp ? 0 : align_up(size_t(h->total_states) * size_t(N + 1) * 4, 256);
-    const size_t anc_bytes = align_up(size_t(h->total_states) * size_t(N / MM_ANC_K + 3) * 4, 256);
-    const size_t cps_bytes = align_up(size_t(h->B) * size_t(N / MM_ANC_K + 2) * 4, 256);
-    rc = ensure_ws(h, bp_bytes + anc_bytes + cps_bytes, stream);
-    if (rc) return rc;
     if (!bp) {
+        rc = ensure_ws(h, align_up(size_t(h->total_states) * size_t(N + 1) * 4, 256), stream);
+        if (rc) return rc;
         bp = static_cast<int32_t *>(h->ws);
         bp_stride_n = h->total_states;
         p.stop_at_len = 1;  // nobody reads the back-pointers of the frames beyond len_b + 1
     } else if (bp_stride_n < h->total_states) {
         return fail(MM_ERR_DIM, "mm_viterbi_f32: bp_stride_n < total states");
     }
-    p.anc = reinterpret_cast<int *>(static_cast<char *>(h->ws) + bp_bytes);
-    p.anc_stride_n = h->total_states;
-    p.cps = reinterpret_cast<int *>(static_cast<char *>(h->ws) + bp_bytes + anc_bytes);
     p.utts = h->d_utts;
     p.V = V;
     p.vsb = vsb;
@@ -1556,7 +1543,9 @@ int mm_viterbi_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const
     p.score = score;
     rc = launch_tropical(h, p, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(mm_backtrace_kernel, dim3(unsigned(h->B)), dim3(64), 0, static_cast<hipStream_t>(stream), p);
+    const int bt = 64;
+    hipLaunchKernelGGL(mm_backtrace_kernel, dim3(unsigned((h->B + bt - 1) / bt)), dim3(bt), 0,
+                       static_cast<hipStream_t>(stream), p);
     HIP_TRY(hipGetLastError());
     return MM_OK;
 }

@@ -33,7 +33,6 @@ namespace mm {
 #define MM_LOG2E 1.4426950408889634f
 #define MM_LN2 0.6931471805599453f
 #define MM_MAX_WAVES 16
-#define MM_ANC_K 32  // frames between two ancestor checkpoints of the Viterbi kernel
 
 enum { MODE_FB = 0, MODE_ALPHA = 1, MODE_BETA = 2 };
 
@@ -106,13 +105,6 @@ struct RunParams {
     int *bp;  // viterbi
     long long bp_stride_n;
     int stop_at_len;  // viterbi without an export of the back-pointers: frames beyond len_b + 1 are not computed
-    // viterbi: ancestors at the checkpoint frames 1, 1 + K, 1 + 2K, ... (K = MM_ANC_K) of every state's best path, so
-    // that the back-trace is not one chain of N dependent loads: anc [N / K + 3][anc_stride_n] (row j >= 1: for the states
-    // of frame 1 + j K their ancestor at frame 1 + (j - 1) K; row 0: for the states of frame len_b + 1 their ancestor at
-    // the last checkpoint below it), cps [B][N / K + 2] the best path's states at the checkpoints
-    int *anc;
-    long long anc_stride_n;
-    int *cps;
     // FSMs whose state vectors do not fit the LDS (item / tropical kernels, BIGV): [B][big_stride] floats of global memory
     float *ws_big;
     long long big_stride;
@@ -864,8 +856,6 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
         if constexpr (BIGV) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     };
     int *bpbuf = reinterpret_cast<int *>(BIGV ? buf + 2 * S1p : lds + L.stage);  // [2][S1p]
-    int *ancbuf = reinterpret_cast<int *>(BIGV ? buf + 4 * S1p : lds + L.total);  // [2][S1p] (behind the plan: launch_tropical)
-    int *ancg = p.anc ? p.anc + u.state_off : nullptr;
     const float *Vb = p.free_run ? nullptr : p.V + (long long)b * p.vsb;
     const GraphDev gf = u.g[0];
     int *bpb = p.bp ? p.bp + u.state_off : nullptr;
@@ -909,21 +899,10 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
             int *dst = bpb + (long long)(n - 2) * p.bp_stride_n;
             for (int s = tid; s < S1; s += NT) dst[s] = src[s];
         }
-        // ancestors at the last checkpoint frame c < n: the best predecessor itself if frame n - 1 is the checkpoint
-        const int *ancp = ancbuf + ((n - 1) & 1) * S1p;
-        int *ancn = ancbuf + (n & 1) * S1p;
-        const bool prev_is_cp = ((n - 2) % MM_ANC_K) == 0;
-        int pend_row = -1, pend_val = -1;
         auto finish = [&](float best, int arg, int row, int pdf) {
             const float v = best + emn[pdf];
             an[row] = v;
             bpn[row] = arg;
-            if (ancg) {  // (the gather is issued now, its value stored with the NEXT finish: no item waits for it)
-                const int g = (arg < 0 || prev_is_cp) ? arg : ancp[arg];
-                if (pend_row >= 0) ancn[pend_row] = pend_val;
-                pend_row = row;
-                pend_val = g;
-            }
             if (p.out) p.out[(long long)(n - 1) * p.out_stride_n + u.state_off + row] = v;
         };
         static_for<0, NI>([&](auto I) {
@@ -961,7 +940,6 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
             trop_grp_reduce(best, arg, im.log2g);
             if (ri.row >= 0 && (lane & ((1 << im.log2g) - 1)) == 0) finish(best, arg, ri.row, ri.pdf);
         }
-        if (pend_row >= 0) ancn[pend_row] = pend_val;
         if (n + 1 <= NF) {
             if (tid <= P) {
                 float *dst = em + ((n + 1) & 1) * P1p;
@@ -972,14 +950,6 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
         }
         vsync();
         if (n == len + 1 && tid == 0 && p.score) p.score[b] = an[S1 - 1];
-        if (ancg) {  // (read after the barrier, rewritten two steps later)
-            if ((n - 1) % MM_ANC_K == 0) {  // frame n = 1 + j K
-                int *dst = ancg + (long long)((n - 1) / MM_ANC_K) * p.anc_stride_n;
-                for (int s = tid; s < S1; s += NT) dst[s] = ancn[s];
-            }
-            if (n == len + 1)
-                for (int s = tid; s < S1; s += NT) ancg[s] = ancn[s];
-        }
     }
     if (bpb && n_end >= 2) {
         const int *src = bpbuf + (n_end & 1) * S1p;
@@ -988,46 +958,22 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
     }
 }
 
-// back-trace (historical bestpath, examples/demo.ipynb cell 23), one 64-thread workgroup per utterance.  Following
-// the back-pointers from the phony final state at frame len + 1 is a chain of len dependent loads from HBM (0.6 us
-// each: 0.6 ms for 1000 frames, a fifth of a Viterbi call).  The forward kernel therefore also leaves the ancestors
-// at the checkpoint frames 1 + j K (RunParams::anc): thread 0 hops from checkpoint to checkpoint (len / K loads), then
-// every chunk between two checkpoints is walked by its own thread (K loads), all chunks at once.
+// back-trace: one lane per utterance follows the back-pointers from the phony
+// final state at frame len+1 (historical bestpath, examples/demo.ipynb cell 23)
 __global__ void mm_backtrace_kernel(RunParams p) {
-    const int b = blockIdx.x;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= p.B) return;
     const UttDesc &u = p.utts[b];
     int len = p.lens ? p.lens[b] : p.N;
     len = len < 0 ? 0 : (len > p.N ? p.N : len);
     int *path = p.path + (long long)b * p.path_stride_b;
-    const int tid = threadIdx.x;
-    for (int n = len + tid; n < p.N; n += blockDim.x) path[n] = -1;
+    for (int n = len; n < p.N; ++n) path[n] = -1;
     const bool ok = p.score[b] > MM_NINF;
-    if (!ok || len == 0) {
-        for (int n = tid; n < len; n += blockDim.x) path[n] = -1;
-        return;
-    }
+    int s = u.S1 - 1;
     const int *bpb = p.bp + u.state_off;
-    const int *anc = p.anc + u.state_off;
-    int *cps = p.cps + (long long)b * (p.N / MM_ANC_K + 2);
-    const int L = len + 1, J = (L - 1) / MM_ANC_K;  // the path ends at frame L; checkpoints at frames 1 + j K, j <= J
-    if (tid == 0) {
-        int s = u.S1 - 1;
-        if (L != 1 + J * MM_ANC_K) s = anc[s];  // row 0: ancestors of the states of frame L at checkpoint J
-        cps[J] = s;
-        for (int j = J; j >= 1; --j) {
-            s = anc[(long long)j * p.anc_stride_n + s];
-            cps[j - 1] = s;
-        }
-    }
-    __syncthreads();
-    for (int j = tid; j <= J; j += blockDim.x) {
-        // frames hi - 1 .. lo of chunk j, starting from the known state at frame hi
-        const int lo = 1 + j * MM_ANC_K, hi = (j == J) ? L : lo + MM_ANC_K;
-        int s = (j == J) ? u.S1 - 1 : cps[j + 1];
-        for (int n = hi - 1; n >= lo; --n) {  // row n holds the back-pointers of frame n + 1
-            s = bpb[(long long)n * p.bp_stride_n + s];
-            path[n - 1] = s;
-        }
+    for (int n = len; n >= 1; --n) {
+        if (ok) s = bpb[(long long)n * p.bp_stride_n + s];
+        path[n - 1] = ok ? s : -1;
     }
 }
 

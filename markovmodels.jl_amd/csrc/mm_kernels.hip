@@ -475,7 +475,10 @@ __device__ __forceinline__ void for_items(const ItemRegs<NI> &rg, const GraphDev
         constexpr int i = decltype(I)::value;
         const int meta = rg.meta[i];
         if (meta != 0) {
-            const int R = meta & 0xff, lg = meta >> 8;
+            int R = meta & 0xff, lg = meta >> 8;
+            // (opaque per frame: hoisted out of the time loop, the comparisons with R and lg of all items become ~100
+            // scalar-register pairs that are spilled to VGPR lanes and read back with v_readlane every frame)
+            asm volatile("" : "+s"(R), "+s"(lg));
             const unsigned row = rg.ri[i] & 0xffffu;
             const float e = emn[row != 0xffffu ? (rg.ri[i] >> 16) : 0u];
             const float v = TROP ? max_regs(rg.w[i][0], rg.w[i][1], rg.w[i][2], rg.w[i][3], rg.c[i][0], rg.c[i][1], R, lg, a)
@@ -909,7 +912,8 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
             constexpr int i = decltype(I)::value;
             const int meta = rg.meta[i];
             if (meta != 0) {
-                const int R = meta & 0xff, lg = meta >> 8;
+                int R = meta & 0xff, lg = meta >> 8;
+                asm volatile("" : "+s"(R), "+s"(lg));  // (see for_items)
                 float best = MM_NINF;
                 int arg = -1;
                 const int c0 = rg.c[i][0] & 0xffffu, c1 = rg.c[i][0] >> 16;

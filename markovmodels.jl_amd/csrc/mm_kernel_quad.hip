@@ -111,11 +111,7 @@ __device__ __forceinline__ void load_quad_regs(QuadRegs<KQ> &rg, const QuadDev &
 // The unpacking of the 16-bit LDS offsets and the sign test are loop invariant; hoisted out of the time
 // loop they would cost 2 VGPRs + 2 SGPRs per quad, which do not exist.  They are therefore written as asm
 // that also reads `vz`, a zero the compiler cannot see through (one instruction per address, no copies).
-typedef __attribute__((address_space(3))) const float *lds_cfptr;
 __device__ __forceinline__ float lds_abs(unsigned addr) { return *(lds_cfptr)(__UINTPTR_TYPE__)addr; }
-__device__ __forceinline__ unsigned lds_addr_of(const float *p) {
-    return (unsigned)(__UINTPTR_TYPE__)(lds_cfptr)p;
-}
 __device__ __forceinline__ unsigned unpack_lo(unsigned packed, unsigned vz) {
     unsigned r;
     asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"

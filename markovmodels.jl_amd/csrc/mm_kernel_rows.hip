@@ -96,16 +96,6 @@ __device__ __forceinline__ float row_stage_em(unsigned dst, const float (&raw)[4
 // LDS-DMA (cdna_hip_programming.md 5.7): one wave instruction moves 4 or 16 bytes per lane from per-lane global
 // addresses straight into the LDS block [dst + 64 * lane-size): no destination register, so nothing the compiler
 // would make the wave wait for; completion is counted by vmcnt, which the service wave waits on by hand.
-__device__ __forceinline__ void dma_b32(const void *gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void dma_b128(const void *gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
 #define MM_ROW_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // raw emissions of frame n (clamped to a valid frame and pdf: expand() decides later what they mean): always 4 DMAs
 // of 256 bytes, so that the number of outstanding operations per step is a constant

@@ -154,6 +154,24 @@ struct RunParams {
 #define MM_STAMP_RESET do { } while (0)
 #endif
 
+typedef __attribute__((address_space(3))) const float *lds_cfptr;
+__device__ __forceinline__ unsigned lds_addr_of(const float *p) {
+    return (unsigned)(__UINTPTR_TYPE__)(lds_cfptr)p;
+}
+// LDS-DMA (cdna_hip_programming.md 5.7): one wave instruction moves 4 or 16 bytes per ACTIVE lane from per-lane global
+// addresses straight into the LDS block [lds_dst + lane * size): no destination register, so nothing the compiler
+// would make the wave wait for (or spill); completion is counted by vmcnt, which the caller waits on by hand.
+__device__ __forceinline__ void dma_b32(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma_b128(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // LDS carve (in floats) shared by host (size) and device (offsets).
 struct LdsPlan {
     int buf, stage, em, bins, part, total;
@@ -660,11 +678,22 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
         double Cn = len >= 1 ? __hip_atomic_load(&wsC[len], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0, Cpre = 0.0;
         auto prefetch = [&](int f) {  // frame f >= 1
             evp = em_load_raw(Vb, p.vsn, f, p.N, P, tid);
-            const float4 *src = reinterpret_cast<const float4 *>(wsA + (long long)f * S1p);
+            if constexpr (BIGV) {
+                const float4 *src = reinterpret_cast<const float4 *>(wsA + (long long)f * S1p);
 #pragma unroll
-            for (int k = 0; k < AK; ++k)
-                if (tid + k * NT < n4) apre[k] = src[tid + k * NT];
+                for (int k = 0; k < AK; ++k)
+                    if (tid + k * NT < n4) apre[k] = src[tid + k * NT];
+            }
             Cpre = __hip_atomic_load(&wsC[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        // alpha~ of frame f straight into its staging buffer by LDS-DMA (the buffer's previous tenant, frame f + 2, is done;
+        // the wave waits for its own DMAs before the barrier that ends the step).  Carried in registers, as the emissions
+        // are, the rows were spilled to scratch in the loop: every reload waited for ALL outstanding loads.
+        auto dma_alpha = [&](int f) {
+            const float4 *src = reinterpret_cast<const float4 *>(wsA + (long long)f * S1p);
+            const unsigned dst = lds_addr_of(stage + (f & 1) * S1p);
+            for (int q0 = wave * 64; q0 < n4; q0 += NT)
+                if (q0 + lane < n4) dma_b128(src + q0 + lane, dst + 16u * (unsigned)q0);
         };
         if (len >= 2) prefetch(len - 1);
         for (int n = len; n >= 1; --n) {
@@ -695,13 +724,17 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
             if (n - 1 >= 1) {  // frame n-1 from the registers into the buffers frame n+1 has left
                 if (tid <= P) em[((n - 1) & 1) * P1p + tid] = em_value(evp, n - 1, len, P, tid);
                 if (P >= NT) stage_em(em + ((n - 1) & 1) * P1p + NT, Vb + NT, p.vsn, n - 1, len, P - NT, tid, NT, MM_LOG2E);
-                float4 *dst = reinterpret_cast<float4 *>(stage + ((n - 1) & 1) * S1p);
+                if constexpr (BIGV) {
+                    float4 *dst = reinterpret_cast<float4 *>(stage + ((n - 1) & 1) * S1p);
 #pragma unroll
-                for (int k = 0; k < AK; ++k)
-                    if (tid + k * NT < n4) dst[tid + k * NT] = apre[k];
-                if (n4 > AK * NT) {
-                    const float4 *src = reinterpret_cast<const float4 *>(wsA + (long long)(n - 1) * S1p);
-                    for (int q = tid + AK * NT; q < n4; q += NT) dst[q] = src[q];
+                    for (int k = 0; k < AK; ++k)
+                        if (tid + k * NT < n4) dst[tid + k * NT] = apre[k];
+                    if (n4 > AK * NT) {
+                        const float4 *src = reinterpret_cast<const float4 *>(wsA + (long long)(n - 1) * S1p);
+                        for (int q = tid + AK * NT; q < n4; q += NT) dst[q] = src[q];
+                    }
+                } else {
+                    dma_alpha(n - 1);
                 }
                 Cn = Cpre;
                 if (n - 2 >= 1) prefetch(n - 2);
@@ -717,6 +750,7 @@ __global__ void __launch_bounds__(NI > 8 ? 512 : 1024) mm_log_kernel(RunParams p
                 wm = max_nc(wm, y);
             });
             part_put(part + (n & 1) * MM_MAX_WAVES, wave, lane, wm);
+            if constexpr (!BIGV) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of alpha~ of frame n - 1 is in LDS
             vsync();
             if (det) {
                 // C' * (A .* B) (:155) without atomics: a pdf's states are listed in pdf_rows; 8 lanes per pdf add their

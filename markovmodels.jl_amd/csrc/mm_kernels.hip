@@ -946,8 +946,7 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
             constexpr int i = decltype(I)::value;
             const int meta = rg.meta[i];
             if (meta != 0) {
-                int R = meta & 0xff, lg = meta >> 8;
-                asm volatile("" : "+s"(R), "+s"(lg));  // (see for_items)
+                const int R = meta & 0xff, lg = meta >> 8;  // (not opaque as in for_items: measured 1.5 % slower here)
                 float best = MM_NINF;
                 int arg = -1;
                 const int c0 = rg.c[i][0] & 0xffffu, c1 = rg.c[i][0] >> 16;

@@ -212,6 +212,10 @@ int mm_debug_quad_product(mm_fsm_t fsm, int direction, int KQ, const float *in, 
  * cost of the most loaded wave, of the least loaded one, modelled LDS cycles per gather instruction with arcs in
  * CSR order, the same after the bank-aware placement}.  Returns MM_ERR_UNSUPPORTED if the FSM does not fit the form. */
 int mm_debug_row_product(mm_fsm_t fsm, int direction, const float *in, float *out, double stats[8]);
+/* The same with the packer's options: flags bit 0 = the pair form of the pair kernels (8-byte positions, its cost model),
+ * bits 1-2 = copies of the linear vector the arcs may read (0: the form's default, 1, 2), bit 3 = the second copy
+ * scrambles the low five position bits with the next five instead of rotating by half the banks. */
+int mm_debug_row_product_ex(mm_fsm_t fsm, int direction, int flags, const float *in, float *out, double stats[8]);
 
 /* Test aid (host only, no GPU): the static bound the fast kernels use to recognise dead rows without a walk --
  * the fewest arcs from an initial state to every state (direction 0) or from every state to the phony final

@@ -42,6 +42,7 @@ SYMBOLS = [
     "mm_debug_packed_product",
     "mm_debug_quad_product",
     "mm_debug_row_product",
+    "mm_debug_row_product_ex",
     "mm_debug_reach_distance",
 ]
 
@@ -115,6 +116,8 @@ def _load():
     lib.mm_debug_quad_product.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     lib.mm_debug_row_product.restype = C.c_int
     lib.mm_debug_row_product.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.mm_debug_row_product_ex.restype = C.c_int
+    lib.mm_debug_row_product_ex.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     return lib
 
 

@@ -1006,11 +1006,26 @@ int mm_debug_quad_product(mm_fsm_t f, int direction, int KQ, const float *in, fl
 }
 
 int mm_debug_row_product(mm_fsm_t f, int direction, const float *in, float *out, double stats[8]) {
-    if (!f || !in || !out || direction < 0 || direction > 1) return fail(MM_ERR_INVALID, "mm_debug_row_product: bad argument");
+    return mm_debug_row_product_ex(f, direction, 0, in, out, stats);
+}
+
+int mm_debug_row_product_ex(mm_fsm_t f, int direction, int flags, const float *in, float *out, double stats[8]) {
+    if (!f || !in || !out || direction < 0 || direction > 1 || flags < 0 || flags > 15)
+        return fail(MM_ERR_INVALID, "mm_debug_row_product: bad argument");
     if (f->semiring != MM_LOG) return fail(MM_ERR_INVALID, "mm_debug_row_product: log-semiring FSMs only");
     RowPackOpts opt;
     opt.rs = MM_ROW_RS;
     opt.ka_max = kRowKA[sizeof(kRowKA) / sizeof(kRowKA[0]) - 1];
+    if (flags & 1) {  // the pair form as pair_variants() builds it
+        opt.pair = true;
+        opt.ka_max = MM_PAIR_KA;
+        opt.ka_choices[0] = MM_PAIR_KA;
+        for (float &x : opt.group_speed) x = 1.f;
+        if (direction == 1) opt.finish_cost = 24;
+    }
+    opt.copies = (flags >> 1) & 3;
+    opt.copy_perm = (flags & 8) != 0;
+    if (opt.copies > 2) return fail(MM_ERR_INVALID, "mm_debug_row_product: at most two copies");
     RowGraph gf, g;
     const std::vector<int32_t> none;
     const Csr &mf = f->mat[0], &m = f->mat[direction];

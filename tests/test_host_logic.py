@@ -253,3 +253,26 @@ def test_reach_distance_bounds_the_support_of_alpha_and_beta(mm, wl, oracle):
             alive_b = np.nonzero(np.isfinite(Bm[s, :N]))[0]
             assert alive_b.size and (N - alive_b[-1]) >= db[s], (g.name, s)
             assert (N - alive_b[-1]) == db[s], (g.name, s)  # tight: beta reaches s exactly db arcs before the end
+
+
+@pytest.mark.parametrize("pair,copies,scrambled", [(True, 0, False), (True, 2, False), (True, 2, True), (False, 1, False),
+                                                   (False, 2, True)])
+def test_row_form_variants(mm, wl, pair, copies, scrambled):
+    """The pair variant of the row-lane form (what the pair kernels load) and the placement's copy options: the
+    products are those of the item form whatever the layout; a second, scrambled copy of the vector lowers the
+    modelled bank conflicts of the gathers below those of a single copy."""
+    g = wl.lfmmi_denominator(2000, 84)
+    f = wl.to_fsm(mm, g)
+    cf = mm.compile(f, mm.statemap(g.state2pdf, g.P))
+    rng = np.random.default_rng(8)
+    x = (3 * rng.standard_normal(f.S1)).astype(np.float32)
+    x[rng.random(f.S1) < 0.1] = -np.inf
+    for d in (0, 1):
+        ref, _ = cf.packed_product(x, d)
+        out, stats = cf.row_product(x, d, pair=pair, copies=copies, scrambled=scrambled)
+        m = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(out), m) and np.allclose(out[m], ref[m], rtol=1e-5, atol=2e-5)
+        _, one = cf.row_product(x, d, pair=pair, copies=1)
+        assert stats[7] <= one[7] + 1e-9 if copies != 1 else stats[7] == one[7]
+        if copies == 2 and scrambled:
+            assert stats[7] < 1.2 and stats[7] < one[7] - 0.1, (d, stats[7], one[7])

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -455,6 +456,8 @@ static bool concurrent_streams(int device, hipStream_t out[2]) {
         bool tried = false;
     };
     static std::map<int, Pair> cache;
+    static std::mutex lock;  // (batches may be created from several host threads)
+    std::lock_guard<std::mutex> guard(lock);
     Pair &pr = cache[device];
     if (!pr.tried) {
         pr.tried = true;

@@ -60,7 +60,6 @@ inline size_t pair_lds_bytes(int RS, int phase, int nslotrows) {
 
 struct PairUtt {  // one utterance of the pair (scalar registers)
     const float *Vb;
-    float *rows;      // [N + 2][S1p] state vectors of the frames (alpha~ up to the split, beta~ beyond)
     double *offs;     // [N + 2] cumulative offset of the stored vector of every frame
     int b, len, valid;
 };
@@ -204,12 +203,6 @@ __device__ __forceinline__ void pk_mul_wlo(mm_f32x2 &acc, const mm_f32x2 &w2, co
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(acc) : "v"(w2), "v"(x));
 }
 
-#ifndef MM_EXP_QADDR
-#define MM_EXP_QADDR (info2 >> 16)
-#endif
-#ifndef MM_EXP_ALADDR
-#define MM_EXP_ALADDR (info2 & 0xffffu)
-#endif
 template <int KA>
 struct PairRegs {  // what a compute wave keeps across the steps
     mm_f32x2 w2[KA / 2];
@@ -323,10 +316,13 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
         U[u].len = len;
         U[u].valid = valid;
         U[u].Vb = p.V + (long long)b * p.vsb;
-        U[u].rows = p.ws_alpha + (long long)slot * (long long)(p.N + 2) * p.pair_s1p;
         U[u].offs = p.ws_c + (long long)slot * (p.N + 2);
         NFp = len + 1 > NFp ? len + 1 : NFp;
     }
+    // state vectors of the pair's frames (alpha~ up to the split, beta~ beyond), the two utterances side by side like
+    // in LDS: [N + 2][S1p][2] -- one 8-byte store per finish in phase A, and in phase B ONE ds_read_b64 fetches both
+    // partner values of a row (two 4-byte reads at the partner's scattered positions cost the backward agent 9 % of a step)
+    float *rowsP = p.ws_alpha + (long long)pair * (long long)(p.N + 2) * 2 * p.pair_s1p;
     const UttDesc &ud = p.utts[U[0].b];
     const RowU r = uni(ud.rp[DIR]);
     const int S1 = r.rows, S1p = p.pair_s1p, P1 = uni(ud.P1), P = P1 - 1, P1p = (P1 + 3) & ~3;
@@ -413,19 +409,18 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
             const int tt = t < 1 ? 1 : (t > tEnd ? tEnd : t);
             int f = frame_of(tt);
             f = f > p.N ? p.N : f;  // (frame N+1 is never combined)
-            const int n4 = S1p >> 2;
+            const int n4 = S1p >> 1;  // float4s of the row of pairs
             constexpr int NA = (RS / 4 + 255) / 256;
+            const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(rowsP + (long long)f * 2 * S1p);
+            const unsigned dst = L::AL(0, 0) + (unsigned)(tt % 3) * 2u * RS;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(U[u].rows + (long long)f * S1p);
-                const unsigned dst = L::AL(0, u) + (unsigned)(tt % 3) * 2u * RS;
-#pragma unroll
-                for (int j = 0; j < NA; ++j) {
-                    const int q = lane + 64 * j;
-                    dma_b128(src + (q < n4 ? q : 0), dst + 1024u * j);
-                }
-                dma_b32(reinterpret_cast<const unsigned *>(U[u].offs + f) + (lane & 1), L::POFF(0, u) + 512u * (t & 7));
+            for (int j = 0; j < 2 * NA; ++j) {
+                const int q = lane + 64 * j;
+                dma_b128(src + (q < n4 ? q : 0), dst + 1024u * j);
             }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                dma_b32(reinterpret_cast<const unsigned *>(U[u].offs + f) + (lane & 1), L::POFF(0, u) + 512u * (t & 7));
         };
         constexpr int NDMA = 2 * NJ + (PHASE ? 2 * ((RS / 4 + 255) / 256) + 2 : 0);  // DMAs issued per step (a lower bound of the VMEM operations)
         // stage the emissions of step t into EM(t & 1) and account its offsets; S = the normaliser the step subtracts
@@ -581,15 +576,15 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                 if (row_out_of_range(v0, thr)) *redo0 = 1;
                 if (row_out_of_range(v1, thr)) *redo1 = 1;
                 ldsw2(L::PP(1) + 8u * i, fast_exp2(v0), fast_exp2(v1));
-                U[0].rows[(long long)1 * S1p + i] = v0;
-                U[1].rows[(long long)1 * S1p + i] = v1;
+                *reinterpret_cast<mm_f32x2 *>(rowsP + ((long long)1 * S1p + i) * 2) = mm_f32x2{v0, v1};
             }
         } else if (DIR == 1 && t0 == 1) {  // B[:, N+1] = one at the final state   (src/inference.jl:104)
             if (tid == 0) ldsw2(L::PP(1) + 8u * r.fpos, 1.f, 1.f);
         } else {  // phase B: the vector this agent stored at the end of phase A
             const int f = frame_of(t0);
             for (int i = tid; i < S1; i += 64 * NWC) {
-                float v0 = U[0].rows[(long long)f * S1p + i], v1 = U[1].rows[(long long)f * S1p + i];
+                const mm_f32x2 vv = *reinterpret_cast<const mm_f32x2 *>(rowsP + ((long long)f * S1p + i) * 2);
+                float v0 = vv.x, v1 = vv.y;
                 if (DIR == 1) {  // beta~ is stored without the frame's emission
                     const mm_f32x2 e = ldsr2(L::EM(t0 & 1) + 8u * as_global(r.rowpdf)[i]);
                     v0 += e.x;
@@ -619,12 +614,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                 mm_f32x2 e = ldsr2((info >> 16) + L::EM(WR));
                 const int f = frame_of(t);
                 const unsigned alb = L::AL(0, 0) + (unsigned)(t % 3) * 2u * RS;
-                float al0 = 0.f, al1 = 0.f;
-                if constexpr (PHASE == 1) {
-                    al0 = ldsr(MM_EXP_ALADDR + alb);
-                    al1 = ldsr(MM_EXP_ALADDR + alb + RS);
-                }
-                float *row0 = U[0].rows + (long long)(f <= p.N ? f : 0) * S1p, *row1 = U[1].rows + (long long)(f <= p.N ? f : 0) * S1p;
+                mm_f32x2 al = {0.f, 0.f};
+                if constexpr (PHASE == 1) al = ldsr2((info2 & 0xffffu) + alb);
+                float *rowP = rowsP + (long long)(f <= p.N ? f : 0) * 2 * S1p;
                 // even / odd arcs (phase B has no registers to spare: one chain there)
                 float worst = 0.f;
                 mm_f32x2 accA = {0.f, 0.f}, accN = {0.f, 0.f};
@@ -647,10 +639,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                     ldsw2(pos8 + L::PP(WR), fast_exp2(y0), fast_exp2(y1));
                     const float st0 = DIR ? b0 : y0, st1 = DIR ? b1 : y1;  // the vector that is stored / combined
                     if constexpr (PHASE == 0) {
-                        *reinterpret_cast<float *>(reinterpret_cast<char *>(row0) + (pos8 >> 1)) = st0;
-                        *reinterpret_cast<float *>(reinterpret_cast<char *>(row1) + (pos8 >> 1)) = st1;
+                        *reinterpret_cast<mm_f32x2 *>(reinterpret_cast<char *>(rowP) + pos8) = mm_f32x2{st0, st1};
                     } else {
-                        ldsw2(MM_EXP_QADDR + L::Q(WR), fast_exp2(st0 + al0), fast_exp2(st1 + al1));  // A .* B   (:154)
+                        ldsw2((info2 >> 16) + L::Q(WR), fast_exp2(st0 + al.x), fast_exp2(st1 + al.y));  // A .* B   (:154)
                     }
                     accA = mm_f32x2{0.f, 0.f};
                     sa += 512u;
@@ -660,8 +651,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                     infoN = ldsru(sa + 512u);
                     if constexpr (PHASE == 1) {
                         asm volatile("v_mov_b32 %0, %1" : "=v"(info2) : "v"(info2N));
-                        al0 = ldsr(MM_EXP_ALADDR + alb);
-                        al1 = ldsr(MM_EXP_ALADDR + alb + RS);
+                        al = ldsr2((info2 & 0xffffu) + alb);
                         info2N = ldsru(sa + 516u);
                     }
                 };

@@ -322,7 +322,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                     const int32_t r = s.rows[grp];
                     g.slots[e] = uint32_t(SC * g.pos[r]) | (uint32_t(SC * row2pdf[r]) << 16);
                     if (g.slot_words == 2)
-                        g.slots[e + 1] = uint32_t(4 * (fwd_pos.empty() ? 0 : fwd_pos[r])) | (uint32_t(SC * qpos[r]) << 16);
+                        g.slots[e + 1] = uint32_t((opt.pair ? 8 : 4) * (fwd_pos.empty() ? 0 : fwd_pos[r])) | (uint32_t(SC * qpos[r]) << 16);
                 } else {
                     g.slots[e] = uint32_t(SC * g.trash) | (uint32_t(SC * zero_pdf) << 16);
                     if (g.slot_words == 2) g.slots[e + 1] = 0u | (uint32_t(SC * g.trash) << 16);
@@ -483,7 +483,7 @@ void set_partner(RowGraph &g, const std::vector<int32_t> &partner_pos) {
     for (size_t e = 0; e < g.slots.size(); e += 2) {
         const uint32_t p = (g.slots[e] & 0xffffu) / SC;
         if (int(p) == g.trash) continue;
-        g.slots[e + 1] = (g.slots[e + 1] & 0xffff0000u) | uint32_t(4 * partner_pos[g.order[p]]);
+        g.slots[e + 1] = (g.slots[e + 1] & 0xffff0000u) | uint32_t(SC * partner_pos[g.order[p]]);
     }
 }
 

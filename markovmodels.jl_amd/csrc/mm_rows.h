@@ -88,7 +88,7 @@ struct RowPackOpts {
     // Pair form (mm_kernel_pairs.hip: two utterances per workgroup share the graph registers; the linear vector holds
     // their values side by side, 8 bytes per state, fetched by one ds_read_b64): addresses and slot-table fields are
     // 8 * position / 8 * pdf, ONE copy of the vector (the pair kernels are not bound by the LDS), and the slot table
-    // has two words in both directions: word 1 = 4 * (position in the OTHER direction's numbering) |
+    // has two words in both directions: word 1 = 8 * (position in the OTHER direction's numbering) |
     // (8 * position in pdf-major order) << 16 (set_partner() fills the forward form's once the backward form exists).
     bool pair = false;
     int a_round = 2;      // arc slots per lane of a segment are a multiple of this (2, 4 or 8: the kernels test for the end

@@ -691,7 +691,11 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                     float acc = 0.f;
                     unsigned long long lgw = lgw0;
                     unsigned sa = slot_base;
-                    unsigned info = ldsru(sa), info2 = ldsru(sa + 4u);
+                    // (both words of a slot in one 8-byte read; an integer vector type: see mm_kernel_pairs.hip ldsr2u)
+                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                    auto slot2 = [](unsigned a) { return *(__attribute__((address_space(3))) const u32x2_t *)(__UINTPTR_TYPE__)a; };
+                    const u32x2_t w0 = slot2(sa);
+                    unsigned info = w0.x, info2 = w0.y;
                     float e = ldsr((info >> 16) + L::EM(WR));
                     float al = ldsr((info2 & 0xffffu) + alb);
                     float worst = 0.f;  // largest finite |value| of the lane in this step: range check at its end
@@ -710,8 +714,9 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
                         ldsw(pos4 + L::P(WR, 1), py);
                         acc = 0.f;
                         sa += 512u;
-                        info = ldsru(sa);
-                        info2 = ldsru(sa + 4u);
+                        const u32x2_t w1 = slot2(sa);
+                        info = w1.x;
+                        info2 = w1.y;
                         e = ldsr((info >> 16) + L::EM(WR));
                         al = ldsr((info2 & 0xffffu) + alb);
                     };

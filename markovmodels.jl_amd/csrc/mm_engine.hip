@@ -817,6 +817,10 @@ static int pair_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
     // ones, its phase B is the longest kernel of a call: 8 / 24 against 8 / 8 shortens it by 4 %)
     RowPackOpts optb = opt;
     if (dbg.finish_cost <= 0) optb.finish_cost = 24;
+    if (dbg.group_speed[0] <= 0) {  // (the backward agent's younger waves still lag a little: stamps, -1..2 % with these weights)
+        const float sp[4] = {1.08f, 1.04f, 0.97f, 0.92f};
+        for (int i = 0; i < 4; ++i) optb.group_speed[i] = sp[i];
+    }
     bool fits = make_rows(f->S1, f->qmat[0].rowptr, f->qmat[0].col, f->qmat[0].val, f->s2p, f->P1, false, none, opt, rv[0]->g) &&
                 make_rows(f->S1, f->qmat[1].rowptr, f->qmat[1].col, f->qmat[1].val, f->s2p, f->P1, true, rv[0]->g.pos, optb, rv[1]->g);
     if (fits) set_partner(rv[0]->g, rv[1]->g.pos);

@@ -174,6 +174,14 @@ int mm_totalsum_f32(mm_batch_t batch, int64_t n, int cumulative, float *out, voi
  * CPU path is deterministic, its CUDA path (src/linalg.jl:213-233) reduces in warp-shuffle order, also fixed. */
 int mm_batch_set_deterministic(mm_batch_t batch, int on);
 
+/* How many utterances of the LAST mm_pdfposteriors_f32 call on this batch the fast (linear-domain) kernels handed to
+ * the exact kernels ("flag and redo": a value left the range in which float32 products are exact enough; results are
+ * the log semiring's either way, only the time differs -- a redone utterance is computed twice).  Reads the marks the
+ * call left in the batch's workspace: synchronises `stream` (the stream of that call), nothing on the hot path.
+ * *n = 0 for batches that run on the exact kernels only, or before the first call.  The reference has no such
+ * path (src/inference.jl:145-161 runs one algorithm for every input); this is an observability hook. */
+int mm_batch_last_redo_count(mm_batch_t batch, void *stream, int64_t *n);
+
 /* ---- multi-GPU boundary (one process per GPU, RCCL over xGMI) -------------------------------------------------
  * The batch is block diagonal (src/fsmops.jl:28-36, src/inference.jl:28-36): utterances shard over the ranks with no
  * collective on the data path.  The only exchange is the total log-likelihood the LF-MMI loss consumes
@@ -216,6 +224,12 @@ int mm_debug_row_product(mm_fsm_t fsm, int direction, const float *in, float *ou
  * bits 1-2 = copies of the linear vector the arcs may read (0: the form's default, 1, 2), bit 3 = the second copy
  * scrambles the low five position bits with the next five instead of rotating by half the banks. */
 int mm_debug_row_product_ex(mm_fsm_t fsm, int direction, int flags, const float *in, float *out, double stats[8]);
+
+/* Test aid (host only, no GPU): the product evaluated THROUGH THE SPLIT FORMS of the team kernels (mm_rows.h
+ * make_rows_split: the rows cut into H sets, one row-lane form per set whose arcs read the whole team's vector).
+ * stats (may be NULL) receives {arc slots per lane, positions of the team's vector, segments, real arcs / arc slots,
+ * cost of the most / least loaded wave, modelled LDS cycles per gather before / after the bank-aware placement}. */
+int mm_debug_split_product(mm_fsm_t fsm, int H, int direction, const float *in, float *out, double stats[8]);
 
 /* Test aid (host only, no GPU): the static bound the fast kernels use to recognise dead rows without a walk --
  * the fewest arcs from an initial state to every state (direction 0) or from every state to the phony final

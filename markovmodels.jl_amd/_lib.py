@@ -31,6 +31,7 @@ SYMBOLS = [
     "mm_batch_kernels",
     "mm_batch_reserve",
     "mm_batch_set_deterministic",
+    "mm_batch_last_redo_count",
     "mm_pdfposteriors_f32",
     "mm_alpharecursion_f32",
     "mm_betarecursion_f32",
@@ -43,6 +44,7 @@ SYMBOLS = [
     "mm_debug_quad_product",
     "mm_debug_row_product",
     "mm_debug_row_product_ex",
+    "mm_debug_split_product",
     "mm_debug_reach_distance",
 ]
 
@@ -92,6 +94,8 @@ def _load():
     lib.mm_batch_reserve.argtypes = [vp, i64]
     lib.mm_batch_set_deterministic.restype = C.c_int
     lib.mm_batch_set_deterministic.argtypes = [vp, C.c_int]
+    lib.mm_batch_last_redo_count.restype = C.c_int
+    lib.mm_batch_last_redo_count.argtypes = [vp, vp, C.POINTER(i64)]
     lib.mm_batch_kernels.restype = C.c_int
     lib.mm_batch_kernels.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
     lib.mm_pdfposteriors_f32.restype = C.c_int
@@ -116,6 +120,8 @@ def _load():
     lib.mm_debug_quad_product.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     lib.mm_debug_row_product.restype = C.c_int
     lib.mm_debug_row_product.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.mm_debug_split_product.restype = C.c_int
+    lib.mm_debug_split_product.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     lib.mm_debug_row_product_ex.restype = C.c_int
     lib.mm_debug_row_product_ex.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     return lib

@@ -18,27 +18,25 @@
 #include "mm_kernels.hip"
 #include "mm_kernel_quad.hip"
 #include "mm_kernel_rows.hip"
-#include "mm_kernel_pairs.hip"
+#include "mm_internal.h"
 #include "mm_pack.h"
 #include "mm_rows.h"
 
 using namespace mm;
 
 namespace {
-
-thread_local std::string g_err;
-
-int fail(int code, const std::string &msg) {
-    g_err = msg;
+thread_local std::string g_err_store;
+}
+namespace mm {
+int mm_fail(int code, const std::string &msg) {
+    g_err_store = msg;
     return code;
 }
+}  // namespace mm
 
-#define HIP_TRY(expr)                                                                         \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess)                                                                 \
-            return fail(MM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
-    } while (0)
+namespace {
+
+int fail(int code, const std::string &msg) { return mm::mm_fail(code, msg); }
 
 int64_t rd_index(const void *p, int bytes, int64_t i) {
     return bytes == 4 ? int64_t(static_cast<const int32_t *>(p)[i]) : static_cast<const int64_t *>(p)[i];
@@ -135,6 +133,10 @@ struct mm_fsm_s {
     RowVariant *rows[2] = {nullptr, nullptr};  // row-lane forms (built on first use; rows_tried: do not retry)
     bool rows_tried = false;
     RowVariant *prows[2] = {nullptr, nullptr};  // ... and their pair variants (mm_kernel_pairs.hip)
+    // split pair forms (mm_rows.h make_rows_split): [direction][set], for FSMs beyond the registers / LDS of one compute unit
+    RowVariant *srows[2][MM_SPLIT_HMAX] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+    SplitInfo split;
+    bool split_tried = false;
     std::vector<float> init;  // dense alpha_hat, engine domain
     std::vector<int32_t> s2p;
     int device = -1;
@@ -155,8 +157,10 @@ struct DebugOpts {
     int kernel = K_AUTO;
     int kq = 0, nwaves = 0, nitems = -1;
     bool no_xcsr = false, verbose = false;
+    bool no_redo = false;           // MM_NO_REDO: the exact kernels do not run after the fast ones (what the fast path alone computes)
     bool bigv = false;              // MM_BIGV: item / tropical kernels with the state vectors in global memory whatever the size
     int finish_cost = 0;            // MM_FINISH_COST: cost model of the pair forms (0: default)
+    int x_sleep = 8;                // MM_SPLIT_SLEEP: split kernels, 64-clock units the exchange wave sleeps before a step's first poll
     float group_speed[4] = {0, 0, 0, 0};  // MM_GROUP_SPEED=a,b,c,d
 };
 static DebugOpts read_debug_opts() {
@@ -172,7 +176,9 @@ static DebugOpts read_debug_opts() {
     d.no_xcsr = getenv("MM_NO_XCSR") != nullptr;
     d.verbose = getenv("MM_VERBOSE") != nullptr;
     d.bigv = getenv("MM_BIGV") != nullptr;
+    d.no_redo = getenv("MM_NO_REDO") != nullptr;
     if (const char *e = getenv("MM_FINISH_COST")) d.finish_cost = atoi(e);
+    if (const char *e = getenv("MM_SPLIT_SLEEP")) d.x_sleep = atoi(e);
     if (const char *e = getenv("MM_GROUP_SPEED")) sscanf(e, "%f,%f,%f,%f", &d.group_speed[0], &d.group_speed[1], &d.group_speed[2], &d.group_speed[3]);
     return d;
 }
@@ -195,6 +201,8 @@ struct mm_batch_s {
     int row_ka[2] = {0, 0}, row_nwc[2] = {1, 1}, row_slotrows[2] = {0, 0};
     bool pairs_ok = false;                       // one FSM shared by all utterances, in pair form: the pair kernels can run
     int pair_ka = 0, pair_nwc = 1, pair_slotrows = 0;
+    int pair_H = 1;        // workgroups per team: 1 = the pair kernels proper, > 1 = the split pair kernels
+    int split_s1p = 0;     // floats / 2 of a stored vector of the split kernels (positions of the team's vector, padded)
     // the forward and the backward agents of the pair kernels run side by side on two streams of the library (a
     // process-wide pair that was SEEN to run kernels concurrently, concurrent_streams()); the caller's stream forks into
     // them and joins them
@@ -207,6 +215,7 @@ struct mm_batch_s {
     UttDesc *d_utts = nullptr;
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    const int *last_redo = nullptr;  // redo marks of the last pdfposteriors call (inside ws; mm_batch_last_redo_count)
 };
 
 // Launch geometry of the item kernels: NW waves per workgroup, NI register-resident items per wave
@@ -274,25 +283,6 @@ static size_t quad_lds_bytes(mm_batch_t h, int dir) {
     return (size_t(lds_plan_q(h->max_S1p, P1p, std::max(vl, 64 * NW) * KQ).total) + size_t(h->xcsr)) * 4;
 }
 
-template <int KQ, int RPT, int PASS>
-static int launch_quad_kq_rpt(mm_batch_t h, const RunParams &p, void *stream) {
-    const size_t lds = quad_lds_bytes(h, PASS);
-    auto kernel = mm_fbq_kernel<KQ, RPT, PASS>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                int(lds)));
-    hipLaunchKernelGGL(kernel, dim3(unsigned(h->B)), dim3(64 * h->geo_nw[PASS]), lds, static_cast<hipStream_t>(stream), p);
-    HIP_TRY(hipGetLastError());
-    return MM_OK;
-}
-
-template <int KQ, int PASS>
-static int launch_quad_kq(mm_batch_t h, const RunParams &p, void *stream) {
-    // rows per thread = ceil(max S1 / threads): 2 register-carried rows when that is enough
-    const int NT = 64 * h->geo_nw[PASS], rows = (h->max_S1p + NT - 1) / NT;
-    if (rows <= 2) return launch_quad_kq_rpt<KQ, 2, PASS>(h, p, stream);
-    return launch_quad_kq_rpt<KQ, 3, PASS>(h, p, stream);
-}
-
 static bool quad_kernel_usable(mm_batch_t h) {
     if (h->dbg.kernel == DebugOpts::K_ITEM) return false;
     if (!h->fast_ok || h->geo_kq[0] < 1 || h->geo_kq[1] < 1) return false;
@@ -302,30 +292,16 @@ static bool quad_kernel_usable(mm_batch_t h) {
     return quad_lds_bytes(h, 0) <= 160 * 1024 && quad_lds_bytes(h, 1) <= 160 * 1024;
 }
 
+// (the quad kernels' instances live in mm_quad_tu.hip)
 template <int PASS>
 static int launch_quad_pass(mm_batch_t h, const RunParams &p, void *stream) {
-    switch (h->geo_kq[PASS]) {
-        case 1: return launch_quad_kq<1, PASS>(h, p, stream);
-        case 2: return launch_quad_kq<2, PASS>(h, p, stream);
-        case 3: return launch_quad_kq<3, PASS>(h, p, stream);
-        case 5: return launch_quad_kq<5, PASS>(h, p, stream);
-        case 6: return launch_quad_kq<6, PASS>(h, p, stream);
-        case 7: return launch_quad_kq<7, PASS>(h, p, stream);
-        case 9: return launch_quad_kq<9, PASS>(h, p, stream);
-        case 10: return launch_quad_kq<10, PASS>(h, p, stream);
-        case 11: return launch_quad_kq<11, PASS>(h, p, stream);
-        case 13: return launch_quad_kq<13, PASS>(h, p, stream);
-        // 8-wave geometries: twice the quads per lane in twice the registers (more gathers in flight)
-        case 15: return launch_quad_kq<15, PASS>(h, p, stream);
-        case 17: return launch_quad_kq<17, PASS>(h, p, stream);
-        case 19: return launch_quad_kq<19, PASS>(h, p, stream);
-        case 21: return launch_quad_kq<21, PASS>(h, p, stream);
-        case 23: return launch_quad_kq<23, PASS>(h, p, stream);
-        case 25: return launch_quad_kq<25, PASS>(h, p, stream);
-        case 27: return launch_quad_kq<27, PASS>(h, p, stream);
-        case 29: return launch_quad_kq<29, PASS>(h, p, stream);
-        default: return MM_ERR_UNSUPPORTED;
-    }
+    QuadLaunch ql;
+    ql.B = h->B;
+    ql.kq = h->geo_kq[PASS];
+    ql.nw = h->geo_nw[PASS];
+    ql.max_S1p = h->max_S1p;
+    ql.lds = quad_lds_bytes(h, PASS);
+    return mm_launch_quad_pass(PASS, ql, p, static_cast<hipStream_t>(stream));
 }
 
 // forward kernel, then backward kernel on the same stream: alpha, the per-frame normalisers and log Z travel
@@ -348,7 +324,6 @@ static int launch_tropical(mm_batch_t h, const RunParams &p, void *stream) {
 }
 
 // The row kernels (mm_kernel_rows.hip): KA register-resident arcs per lane, NWC compute waves + 1 service wave.
-#define MM_ROW_RS 8192
 static const int kRowKA[] = {24, 40, 42, 44};  // instantiated register windows (48 arcs per lane spill)
 
 template <int KA, int PASS>
@@ -376,58 +351,19 @@ static int launch_rows(mm_batch_t h, const RunParams &p, void *stream) {
     return launch_row_pass<1>(h, p, stream);
 }
 
-// The pair kernels (mm_kernel_pairs.hip): phase A and phase B, each as a forward-agent and a backward-agent launch
-// that run concurrently (the caller's stream and the batch's side stream, joined by events).
-#define MM_PAIR_KA 44  // arc slots per lane of the pair kernels
-// (NJ: 64-lane passes over the pdfs in the service wave, 2 for P + 1 <= 128, else 4)
-template <int NJ, int PHASE, int DIR>
-__global__ void __launch_bounds__(1024) mm_fbp_kernel_dir(RunParams p) {
-    pair_agent<MM_PAIR_KA, MM_ROW_RS, PHASE, DIR, NJ>(p, blockIdx.x);
-}
-template <int NJ, int PHASE, int DIR>
-static int launch_pair_one(mm_batch_t h, const RunParams &p, hipStream_t st) {
-    const size_t lds = pair_lds_bytes(MM_ROW_RS, PHASE, h->pair_slotrows);
-    if (lds > 160 * 1024) return fail(MM_ERR_UNSUPPORTED, "pair kernel: LDS");
-    auto kernel = mm_fbp_kernel_dir<NJ, PHASE, DIR>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-    const unsigned npairs = unsigned((h->B + 1) / 2);
-    hipLaunchKernelGGL(kernel, dim3(npairs), dim3(64 * (h->pair_nwc + 1)), lds, st, p);
-    HIP_TRY(hipGetLastError());
-    return MM_OK;
-}
-template <int NJ>
-static int launch_pairs_ka(mm_batch_t h, const RunParams &p, hipStream_t s0) {
-    hipStream_t sf = h->side[0], sb = h->side[1];
-    // (inside a stream capture the forward agents stay on the caller's stream: ending a capture whose origin stream only
-    // forks and joins crashed in hipStreamEndCapture -- ROCm 7.0; how the branches of the graph share the queues is the
-    // graph executor's business then)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s0, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) sf = s0;
-    HIP_TRY(hipEventRecord(h->ev[0], s0));  // fork
-    HIP_TRY(hipStreamWaitEvent(sf, h->ev[0], 0));
-    HIP_TRY(hipStreamWaitEvent(sb, h->ev[0], 0));
-    int rc = launch_pair_one<NJ, 0, 0>(h, p, sf);
-    if (!rc) rc = launch_pair_one<NJ, 0, 1>(h, p, sb);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(h->ev[1], sf));  // phase B of either direction needs phase A of both
-    HIP_TRY(hipEventRecord(h->ev[2], sb));
-    HIP_TRY(hipStreamWaitEvent(sf, h->ev[2], 0));
-    HIP_TRY(hipStreamWaitEvent(sb, h->ev[1], 0));
-    rc = launch_pair_one<NJ, 1, 0>(h, p, sf);
-    if (!rc) rc = launch_pair_one<NJ, 1, 1>(h, p, sb);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(h->ev[3], sf));  // join
-    HIP_TRY(hipEventRecord(h->ev[4], sb));
-    HIP_TRY(hipStreamWaitEvent(s0, h->ev[3], 0));
-    HIP_TRY(hipStreamWaitEvent(s0, h->ev[4], 0));
-    hipLaunchKernelGGL(mm_pair_finish_kernel, dim3(unsigned(h->B)), dim3(256), 0, s0, p);
-    HIP_TRY(hipGetLastError());
-    return MM_OK;
-}
+// The pair kernels live in a translation unit of their own (mm_pairs_tu.hip)
 static int launch_pairs(mm_batch_t h, const RunParams &p, void *stream) {
-    hipStream_t s0 = static_cast<hipStream_t>(stream);
-    if (h->pair_ka > MM_PAIR_KA) return MM_ERR_UNSUPPORTED;
-    return h->max_P1 <= 128 ? launch_pairs_ka<2>(h, p, s0) : launch_pairs_ka<4>(h, p, s0);
+    PairLaunch pl;
+    pl.B = h->B;
+    pl.nwc = h->pair_nwc;
+    pl.slotrows = h->pair_slotrows;
+    pl.max_P1 = h->max_P1;
+    pl.pair_ka = h->pair_ka;
+    pl.H = h->pair_H;
+    pl.side[0] = h->side[0];
+    pl.side[1] = h->side[1];
+    for (int i = 0; i < 5; ++i) pl.ev[i] = h->ev[i];
+    return h->pair_H > 1 ? mm_launch_split(pl, p, static_cast<hipStream_t>(stream)) : mm_launch_pairs(pl, p, static_cast<hipStream_t>(stream));
 }
 
 // Two streams whose kernels really run at the same time.  HIP multiplexes its streams over a few hardware queues and
@@ -510,7 +446,7 @@ struct Blob {
 extern "C" {
 
 int mm_abi_version(void) { return MM_ABI_VERSION; }
-const char *mm_last_error(void) { return g_err.c_str(); }
+const char *mm_last_error(void) { return g_err_store.c_str(); }
 
 int mm_fsm_create(int semiring, int64_t S1, int64_t nnz, int layout, int index_bytes, int index_base, int val_bytes,
                   const void *ptr, const void *idx, const void *val, int64_t n_init, const void *init_idx,
@@ -796,6 +732,20 @@ static int upload_row_variant(mm_fsm_t f, RowVariant *v, int dir, float thr) {
     return MM_OK;
 }
 
+// options of the split pair forms (mm_rows.h make_rows_split; the kernels: mm_kernel_pairs.hip with H > 1)
+static void split_pack_opts(const DebugOpts &dbg, RowPackOpts &opt, RowPackOpts &optb) {
+    opt = RowPackOpts();
+    opt.rs = MM_SPLIT_RS;
+    opt.ka_max = MM_SPLIT_KA;
+    opt.nwc_max = MM_SPLIT_NWC;
+    opt.pair = true;
+    for (float &x : opt.group_speed) x = 1.f;
+    if (dbg.finish_cost > 0) opt.finish_cost = dbg.finish_cost;
+    opt.ka_choices[0] = MM_SPLIT_KA;
+    optb = opt;
+    if (dbg.finish_cost <= 0) optb.finish_cost = 24;
+}
+
 // the pair variants of the row-lane forms (same schedule rules; 8-byte positions, one copy of the vector, the other
 // direction's numbering in the slot table)
 static int pair_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
@@ -850,6 +800,65 @@ static int pair_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
     return MM_OK;
 }
 
+// the split pair forms of an FSM for teams of H workgroups (built once; *ok = false if it does not fit them)
+static int split_variants(mm_fsm_t f, const DebugOpts &dbg, int H, bool *ok) {
+    *ok = f->split.H == H && f->srows[0][0] != nullptr;
+    if (*ok || f->split_tried) return MM_OK;
+    f->split_tried = true;
+    if (f->semiring != MM_LOG || !f->fast_ok || f->P1 > 250 || H > MM_SPLIT_HMAX) return MM_OK;
+    RowPackOpts opt, optb;
+    split_pack_opts(dbg, opt, optb);
+    std::vector<RowGraph> gs;
+    SplitInfo info;
+    if (!make_rows_split(H, f->S1, f->qmat[0].rowptr, f->qmat[0].col, f->qmat[0].val, f->qmat[1].rowptr, f->qmat[1].col,
+                         f->qmat[1].val, f->s2p, f->P1, opt, optb, gs, info))
+        return MM_OK;
+    float wmin = 0.f;
+    for (const RowGraph &g : gs) wmin = std::min(wmin, g.wmin_log2);
+    if (wmin < -60.f) return MM_OK;  // (as for the row forms: too little of the float range would be left to the values)
+    for (int h = 0; h < H; ++h)
+        if (size_t(info.count[h] + 1) * 8 > MM_SPLIT_RSH) return MM_OK;
+    const float NINF = -std::numeric_limits<float>::infinity();
+    int rc = MM_OK;
+    for (int d = 0; d < 2 && !rc; ++d) {
+        // rowpdf / init by position of the TEAM's vector (0xffff / -inf at the alignment padding between the regions)
+        std::vector<uint16_t> rowpdf_g(size_t(info.total) + 1, uint16_t(0xffff));
+        std::vector<float> init_g(size_t(info.total) + 1, NINF);
+        for (int64_t r = 0; r < f->S1; ++r) {
+            rowpdf_g[size_t(info.gpos[d][size_t(r)])] = uint16_t(f->s2p[size_t(r)]);
+            if (d == 0) init_g[size_t(info.gpos[d][size_t(r)])] = f->init[size_t(r)];
+        }
+        for (int h = 0; h < H && !rc; ++h) {
+            RowVariant *v = new RowVariant();
+            v->g = std::move(gs[size_t(d * H + h)]);
+            if (dbg.verbose)
+                fprintf(stderr, "[mm] split form dir %d set %d/%d: %d rows at %d, KA %d, %d compute waves, %d segments, arcs/slots %.3f, "
+                                "cost %d..%d, LDS cycles/gather (bank model) %.2f -> %.2f\n",
+                        d, h, H, info.count[h], info.base[h], v->g.KA, v->g.NWC, v->g.nslotrows - 2, v->g.pad_eff, v->g.mincost,
+                        v->g.maxcost, v->g.conflict_before, v->g.conflict_after);
+            v->g.rowpdf = rowpdf_g;
+            v->init = init_g;
+            rc = upload_row_variant(f, v, d, 125.f + wmin);
+            v->rdev.rows = info.total;
+            v->rdev.fpos = info.gpos[d][size_t(f->S1 - 1)];
+            f->srows[d][h] = v;
+        }
+    }
+    if (rc) {
+        for (int d = 0; d < 2; ++d)
+            for (int h = 0; h < H; ++h)
+                if (f->srows[d][h]) {
+                    if (f->srows[d][h]->blob) (void)hipFree(f->srows[d][h]->blob);
+                    delete f->srows[d][h];
+                    f->srows[d][h] = nullptr;
+                }
+        return rc;
+    }
+    f->split = std::move(info);
+    *ok = true;
+    return MM_OK;
+}
+
 // build (once) and upload the row-lane forms of both directions of an FSM; *ok = false if it does not fit them
 static int row_variants(mm_fsm_t f, bool verbose, bool *ok) {
     *ok = f->rows[0] && f->rows[1];
@@ -871,7 +880,6 @@ static int row_variants(mm_fsm_t f, bool verbose, bool *ok) {
         delete rv[1];
         return MM_OK;
     }
-    const float NINF = -std::numeric_limits<float>::infinity();
     for (int dir = 0; dir < 2; ++dir) {
         RowVariant *v = rv[dir];
         if (verbose)
@@ -914,7 +922,8 @@ int mm_fsm_destroy(mm_fsm_t f) {
         if (kv.second->blob) (void)hipFree(kv.second->blob);
         delete kv.second;
     }
-    for (RowVariant *rv : {f->rows[0], f->rows[1], f->prows[0], f->prows[1]})
+    for (RowVariant *rv : {f->rows[0], f->rows[1], f->prows[0], f->prows[1], f->srows[0][0], f->srows[0][1], f->srows[0][2], f->srows[0][3],
+                           f->srows[1][0], f->srows[1][1], f->srows[1][2], f->srows[1][3]})
         if (rv) {
             if (rv->blob) (void)hipFree(rv->blob);
             delete rv;
@@ -1065,6 +1074,49 @@ int mm_debug_row_product_ex(mm_fsm_t f, int direction, int flags, const float *i
     return MM_OK;
 }
 
+int mm_debug_split_product(mm_fsm_t f, int H, int direction, const float *in, float *out, double stats[8]) {
+    if (!f || !in || !out || direction < 0 || direction > 1 || H < 2 || H > 8)
+        return fail(MM_ERR_INVALID, "mm_debug_split_product: bad argument");
+    if (f->semiring != MM_LOG) return fail(MM_ERR_INVALID, "mm_debug_split_product: log-semiring FSMs only");
+    RowPackOpts opt, optb;
+    split_pack_opts(DebugOpts(), opt, optb);
+    std::vector<RowGraph> gs;
+    SplitInfo info;
+    if (!make_rows_split(H, f->S1, f->mat[0].rowptr, f->mat[0].col, f->mat[0].val, f->mat[1].rowptr, f->mat[1].col,
+                         f->mat[1].val, f->s2p, f->P1, opt, optb, gs, info))
+        return fail(MM_ERR_UNSUPPORTED, "mm_debug_split_product: the FSM does not fit the split forms");
+    const int64_t S1 = f->S1;
+    float mx = -std::numeric_limits<float>::infinity();
+    for (int64_t s = 0; s < S1; ++s) mx = std::max(mx, in[s] * MM_LOG2E);
+    if (!(mx > -std::numeric_limits<float>::infinity())) mx = 0.f;
+    std::vector<float> pl(size_t(info.total) + 1, 0.f), ol(size_t(info.total) + 1, 0.f);
+    for (int64_t r = 0; r < S1; ++r) pl[size_t(info.gpos[direction][size_t(r)])] = std::exp2(in[r] * MM_LOG2E - mx);
+    double ka = 0, segs = 0, eff = 0, maxc = 0, minc = 1e30, cb = 0, ca = 0;
+    for (int h = 0; h < H; ++h) {
+        const RowGraph &g = gs[size_t(direction * H + h)];
+        eval_rows(g, pl.data(), ol.data());
+        ka = std::max(ka, double(g.KA));
+        segs += g.nslotrows - 2;
+        eff += g.pad_eff / H;
+        maxc = std::max(maxc, double(g.maxcost));
+        minc = std::min(minc, double(g.mincost));
+        cb += g.conflict_before / H;
+        ca += g.conflict_after / H;
+    }
+    for (int64_t r = 0; r < S1; ++r) out[r] = (std::log2(ol[size_t(info.gpos[direction][size_t(r)])]) + mx) * MM_LN2;
+    if (stats) {
+        stats[0] = ka;
+        stats[1] = double(info.total);
+        stats[2] = segs;
+        stats[3] = eff;
+        stats[4] = maxc;
+        stats[5] = minc;
+        stats[6] = cb;
+        stats[7] = ca;
+    }
+    return MM_OK;
+}
+
 int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     if (!out) return fail(MM_ERR_INVALID, "mm_batch_create: out is NULL");
     *out = nullptr;
@@ -1138,7 +1190,40 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             h->pair_ka = std::max(fsms[0]->prows[0]->g.KA, fsms[0]->prows[1]->g.KA);
             h->pair_nwc = std::max(fsms[0]->prows[0]->g.NWC, fsms[0]->prows[1]->g.NWC);
             h->pair_slotrows = std::max(fsms[0]->prows[0]->g.nslotrows, fsms[0]->prows[1]->g.nslotrows);
-            h->pairs_ok = h->pair_ka <= MM_PAIR_KA && pair_lds_bytes(MM_ROW_RS, 1, h->pair_slotrows) <= 160 * 1024;
+            h->pairs_ok = h->pair_ka <= MM_PAIR_KA && mm_pair_lds_bytes(1, h->pair_slotrows) <= 160 * 1024;
+        }
+    }
+    // split pair kernels: one shared FSM that is too large for the pair kernels proper (more arcs than the registers of a
+    // compute unit hold, more states than half its LDS) -- teams of 2 workgroups per utterance pair and direction
+    if (!h->pairs_ok && h->fast_ok && B >= 2 && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD &&
+        h->dbg.kernel != DebugOpts::K_ROW &&
+        !(h->max_depth >= 64 && nq_max[0] <= 3 * 1024 && nq_max[1] <= 3 * 1024 && h->dbg.kernel == DebugOpts::K_AUTO)) {
+        bool same = true;
+        for (int64_t b = 1; b < B && same; ++b) same = fsms[b] == fsms[0];
+        if (same) {
+            bool ok = false;
+            int rc = split_variants(fsms[0], h->dbg, 2, &ok);
+            if (rc) {
+                delete h;
+                return rc;
+            }
+            if (ok) {
+                const mm_fsm_t f0 = fsms[0];
+                h->pair_H = f0->split.H;
+                h->pair_ka = 0;
+                h->pair_nwc = 1;
+                h->pair_slotrows = 0;
+                for (int d = 0; d < 2; ++d)
+                    for (int s = 0; s < h->pair_H; ++s) {
+                        h->pair_ka = std::max(h->pair_ka, f0->srows[d][s]->g.KA);
+                        h->pair_nwc = std::max(h->pair_nwc, f0->srows[d][s]->g.NWC);
+                        h->pair_slotrows = std::max(h->pair_slotrows, f0->srows[d][s]->g.nslotrows);
+                    }
+                h->split_s1p = (f0->split.total + 2 + 3) & ~3;
+                h->pairs_ok = h->pair_ka <= MM_SPLIT_KA && h->pair_nwc <= MM_SPLIT_NWC &&
+                              mm_split_lds_bytes(1, h->pair_slotrows) <= 160 * 1024;
+                if (!h->pairs_ok) h->pair_H = 1;
+            }
         }
     }
     for (int64_t b = 0; b < B; ++b) {
@@ -1160,8 +1245,11 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             u.init_f = qv[0]->d_init_f;
             u.map_bf = qv[1]->d_map_bf;
         }
-        if (h->pairs_ok)
+        if (h->pairs_ok && h->pair_H == 1)
             for (int d = 0; d < 2; ++d) u.rp[d] = f->prows[d]->rdev;
+        if (h->pairs_ok && h->pair_H > 1)
+            for (int d = 0; d < 2; ++d)
+                for (int s = 0; s < h->pair_H; ++s) u.rps[d][s] = f->srows[d][s]->rdev;
         if (h->rows_ok)
             for (int d = 0; d < 2; ++d) {
                 u.r[d] = f->rows[d]->rdev;
@@ -1250,6 +1338,17 @@ int mm_batch_set_deterministic(mm_batch_t h, int on) {
     return MM_OK;
 }
 
+int mm_batch_last_redo_count(mm_batch_t h, void *stream, int64_t *n) {
+    if (!h || !n) return fail(MM_ERR_INVALID, "mm_batch_last_redo_count: bad argument");
+    *n = 0;
+    if (!h->last_redo) return MM_OK;
+    std::vector<int> marks(size_t(h->B), 0);
+    HIP_TRY(hipMemcpyAsync(marks.data(), h->last_redo, size_t(h->B) * sizeof(int), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    for (int m : marks) *n += m != 0;
+    return MM_OK;
+}
+
 int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
     if (!h || !buf || n < 2) return fail(MM_ERR_INVALID, "mm_batch_kernels: bad argument");
     std::string s;
@@ -1258,7 +1357,12 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
         const std::string exact = quad ? "mm_fbq_kernel<" + std::to_string(h->geo_kq[0]) + ",*,0> + mm_fbq_kernel<" +
                                              std::to_string(h->geo_kq[1]) + ",*,1>"
                                        : std::string("mm_log_kernel<MODE_FB> (forward, backward)");
-        if (h->pairs_ok) {
+        if (h->pairs_ok && h->pair_H > 1) {
+            const std::string k = std::to_string(h->max_P1 <= 128 ? 2 : 4);
+            s = "mm_fbs_kernel_dir<" + k + ",A,fwd> || <" + k + ",A,bwd>, then <" + k + ",B,fwd> || <" + k +
+                ",B,bwd> (teams of " + std::to_string(h->pair_H) + " workgroups), mm_pair_finish_kernel, then for marked utterances only " + exact +
+                (h->side[0] == h->side[1] ? " [no concurrent stream pair found: the two agents take turns]" : "");
+        } else if (h->pairs_ok) {
             const std::string k = std::to_string(h->max_P1 <= 128 ? 2 : 4);
             s = "mm_fbp_kernel_dir<" + k + ",A,fwd> || <" + k + ",A,bwd>, then <" + k + ",B,fwd> || <" + k +
                 ",B,bwd>, mm_pair_finish_kernel, then for marked utterances only " + exact +
@@ -1285,13 +1389,21 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
 
 // (the pair kernels keep N + 2 vectors per utterance and one workspace slot more than utterances)
 static size_t ws_alpha_bytes(mm_batch_t h, int64_t N) {
-    if (h->pairs_ok) return align_up(size_t(h->B + 1) * size_t(h->max_S1p) * size_t(N + 2) * 4, 256);
+    if (h->pairs_ok) return align_up(size_t(h->B + 1) * size_t(h->pair_H > 1 ? h->split_s1p : h->max_S1p) * size_t(N + 2) * 4, 256);
     return align_up(size_t(h->total_s1p) * size_t(N + 1) * 4, 256);
 }
 static size_t ws_c_bytes(mm_batch_t h, int64_t N) { return align_up(size_t(h->B + 1) * size_t(N + 2) * 8, 256); }
-static size_t ws_tail_bytes(mm_batch_t h) {  // longest-first order, redo marks, pair hand-over, per-direction log Z minima
-    return 2 * align_up(size_t(h->B + 1) * 4, 256) + align_up(size_t(h->B + 1) * 2 * sizeof(PairHand), 256) +
-           align_up(size_t(h->B) * 2 * 8, 256);
+// (split kernels) what the workgroups of a team send each other: [2 phases][pairs][2 directions][H sets][2 slots][2 * split_s1p]
+// floats of rows, then [pairs][2][H][4 slots][512] floats of per-pdf partial sums; zeroed before every call
+static size_t ws_x_rows_bytes(mm_batch_t h) {
+    return h->pair_H > 1 ? size_t(2) * size_t((h->B + 1) / 2) * 2 * size_t(h->pair_H) * 2 * (2 * size_t(h->split_s1p)) * 4 : 0;
+}
+static size_t ws_x_bytes(mm_batch_t h) {
+    return h->pair_H > 1 ? align_up(ws_x_rows_bytes(h) + size_t((h->B + 1) / 2) * 2 * size_t(h->pair_H) * 4 * 512 * 4, 256) : 0;
+}
+static size_t ws_tail_bytes(mm_batch_t h) {  // longest-first order, redo marks, pair hand-over, per-direction log Z minima, team buffers
+    return 2 * align_up(size_t(h->B + 1) * 4, 256) + align_up(size_t(h->B + 1) * 2 * mm_pair_hand_bytes(), 256) +
+           align_up(size_t(h->B) * 4 * 8, 256) + ws_x_bytes(h);
 }
 
 size_t mm_batch_workspace_bytes(mm_batch_t h, int64_t N) {
@@ -1311,6 +1423,7 @@ static int ensure_ws(mm_batch_t h, size_t bytes, void *stream = nullptr) {
         HIP_TRY(hipFree(h->ws));  // synchronises: only on growth
         h->ws = nullptr;
         h->ws_bytes = 0;
+        h->last_redo = nullptr;
     }
     HIP_TRY(hipMalloc(&h->ws, bytes));
     h->ws_bytes = bytes;
@@ -1343,6 +1456,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     int rc = check_run(h, "mm_pdfposteriors_f32", V, N, MM_LOG);
     if (rc) return rc;
     if (!gamma || !ttl) return fail(MM_ERR_INVALID, "mm_pdfposteriors_f32: gamma/ttl is NULL");
+    h->last_redo = nullptr;
     // more utterances than CUs and different lengths: hand the workgroups out longest first; the pair kernels also
     // pair the utterances in that order (the two of a pair run the same number of frames)
     const bool ordered = lens && (h->B > h->n_cus || h->pairs_ok) && h->B <= 8192;
@@ -1378,20 +1492,38 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     }
     p.dbg = g_dbg;
 #endif
-    if (h->rows_ok) {
+    if (h->rows_ok || h->pairs_ok) {
         // the pair or row kernels, then -- for the utterances they marked (linear sums outside the trusted range),
         // normally none: every workgroup then leaves at once -- the exact kernels
         char *tail = static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N);
         p.redo = reinterpret_cast<int *>(tail + align_up(size_t(h->B + 1) * 4, 256));
+        // (zeroed here, on the caller's stream, before the fork: the forward and the backward agents of the pair kernels run
+        // concurrently and either may mark an utterance first)
+        HIP_TRY(hipMemsetAsync(p.redo, 0, size_t(h->B + 1) * 4, static_cast<hipStream_t>(stream)));
+        h->last_redo = p.redo;
         if (h->pairs_ok) {
-            p.pair_s1p = h->max_S1p;
+            p.pair_s1p = h->pair_H > 1 ? h->split_s1p : h->max_S1p;
             p.pair_hand = tail + 2 * align_up(size_t(h->B + 1) * 4, 256);
-            p.pair_zmin = reinterpret_cast<double *>(static_cast<char *>(p.pair_hand) + align_up(size_t(h->B + 1) * 2 * sizeof(PairHand), 256));
+            p.pair_zmin = reinterpret_cast<double *>(static_cast<char *>(p.pair_hand) + align_up(size_t(h->B + 1) * 2 * mm_pair_hand_bytes(), 256));
+            if (h->pair_H > 1) {
+                const SplitInfo &si = h->fsms[0]->split;
+                for (int s = 0; s < h->pair_H; ++s) {
+                    p.sp_base[s] = si.base[s];
+                    p.sp_cnt[s] = si.count[s];
+                }
+                p.xbuf = reinterpret_cast<float *>(reinterpret_cast<char *>(p.pair_zmin) + align_up(size_t(h->B) * 4 * 8, 256));
+                p.xps = reinterpret_cast<float *>(reinterpret_cast<char *>(p.xbuf) + ws_x_rows_bytes(h));
+                p.x_slot = 2ll * h->split_s1p;
+                p.x_phase = (long long)(ws_x_rows_bytes(h) / 8);
+                p.x_sleep = h->dbg.x_sleep;
+                HIP_TRY(hipMemsetAsync(p.xbuf, 0, ws_x_bytes(h), static_cast<hipStream_t>(stream)));
+            }
             rc = launch_pairs(h, p, stream);
         } else {
             rc = launch_rows(h, p, stream);
         }
         if (rc) return rc;
+        if (h->dbg.no_redo) return MM_OK;
     }
     if (quad_kernel_usable(h)) {
         rc = launch_quad(h, p, stream);

@@ -1,0 +1,59 @@
+// mm_internal.h -- what the translation units of the engine share on the host side (not part of the C ABI).
+// mm_engine.hip holds the C ABI, the handles and the item / quad / row kernels; kernel families with many template
+// instances live in translation units of their own (compiled in parallel, see Makefile) behind plain launch functions.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "../../include/markovmodels_amd.h"
+
+namespace mm {
+
+struct RunParams;  // mm_kernels.hip
+
+// records the message mm_last_error() returns on this thread; returns `code`
+int mm_fail(int code, const std::string &msg);
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return ::mm::mm_fail(MM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+#define MM_ROW_RS 8192  // LDS bytes of one copy of the linear vector (row kernels) / half a pair vector (pair kernels)
+#define MM_PAIR_KA 44   // arc slots per lane of the pair kernels
+// split pair kernels (teams of H workgroups per utterance pair and direction): bytes of half a pair vector, arc slots per
+// lane, compute waves (+ a service wave and an exchange wave)
+#define MM_SPLIT_RS 12288
+#define MM_SPLIT_RSH 14336  // LDS bytes of the rows ONE workgroup of a team finishes
+#define MM_SPLIT_KA 36
+#define MM_SPLIT_NWC 14
+
+// ---- pair kernels (mm_pairs_tu.hip)
+struct PairLaunch {
+    int64_t B = 0;
+    int nwc = 1, slotrows = 0, max_P1 = 0, pair_ka = 0, H = 1;
+    hipStream_t side[2] = {nullptr, nullptr};  // the two library streams the agents run on
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+int mm_launch_pairs(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
+size_t mm_pair_lds_bytes(int phase, int nslotrows);
+size_t mm_pair_hand_bytes();
+// ---- split pair kernels (mm_split_tu.hip): teams of pl.H workgroups
+int mm_launch_split(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
+size_t mm_split_lds_bytes(int phase, int nslotrows);
+
+
+// ---- quad kernels (mm_quad_tu.hip)
+struct QuadLaunch {
+    int64_t B = 0;
+    int kq = 0, nw = 1, max_S1p = 0;
+    size_t lds = 0;
+};
+int mm_launch_quad_pass(int pass, const QuadLaunch &ql, const RunParams &p, hipStream_t stream);
+
+}  // namespace mm

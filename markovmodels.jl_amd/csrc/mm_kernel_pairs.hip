@@ -40,8 +40,10 @@ __device__ __forceinline__ void ldsw2(unsigned addr, float a, float b) {
     *(__attribute__((address_space(3))) mm_f32x2 *)(__UINTPTR_TYPE__)addr = v;
 }
 
-// LDS byte layout of the pair kernels (absolute addresses).  RS2 = bytes of one pair vector.
-template <int RS, int PHASE>
+// LDS byte layout of the pair kernels (absolute addresses).  RS2 = bytes of one pair vector; RSH = bytes of the rows ONE
+// workgroup finishes (all of them: RS2; a set of them in the split kernels, H > 1) -- what the partner-row ring and the q
+// vector hold.
+template <int RS, int PHASE, int RSH = 2 * RS>
 struct PairLay {
     static constexpr unsigned RS2 = 2 * RS;
     static constexpr unsigned PP(int par) { return unsigned(par) * RS2; }                          // p pairs [pos][2]
@@ -49,17 +51,95 @@ struct PairLay {
     static constexpr unsigned EM(int par) { return 2 * RS2 + 8192u + unsigned(par) * 2048u; }      // [pdf][2] pairs
     static constexpr unsigned MS(int par) { return 2 * RS2 + 12288u + unsigned(par) * 64u; }       // {S_0, S_1} of a step
     static constexpr unsigned OWN(int k) { return 2 * RS2 + 12288u + 128u + unsigned(k) * 16u; }   // own offsets, k < 4: 2 doubles
+    static constexpr unsigned XFLAG = 2 * RS2 + 12288u + 192u;  // split kernels: != 0 when the whole team runs on one XCD
     static constexpr unsigned POFF(int k, int u) { return 2 * RS2 + 12288u + 256u + unsigned(2 * k + u) * 256u; }  // partner offsets, k < 8
     static constexpr unsigned PSUM(int par) { return 2 * RS2 + 12288u + 256u + 4096u + unsigned(par) * 2048u; }   // [pdf][2]
     static constexpr unsigned PDFSE = 2 * RS2 + 12288u + 256u + 4096u + 4096u;                     // u16 [2 * P1]
     static constexpr unsigned FIX = PDFSE + 1024u;
-    static constexpr unsigned AL(int k, int u) { return FIX + unsigned(2 * k + u) * RS; }          // partner rows (phase B), k < 3
-    static constexpr unsigned Q(int par) { return FIX + 6u * RS + unsigned(par) * RS2; }           // q pairs [qpos][2] (phase B)
-    static constexpr unsigned SLOTS = PHASE ? FIX + 6u * RS + 2 * RS2 : FIX;
+    static constexpr unsigned AL(int k) { return FIX + unsigned(k) * RSH; }                        // partner rows (phase B), k < 3
+    static constexpr unsigned Q(int par) { return FIX + 3u * RSH + unsigned(par) * RSH; }          // q pairs [qpos][2] (phase B)
+    static constexpr unsigned SLOTS = PHASE ? FIX + 5u * RSH : FIX;
 };
-inline size_t pair_lds_bytes(int RS, int phase, int nslotrows) {
+inline size_t pair_lds_bytes(int RS, int phase, int nslotrows, int RSH = 0) {
     const size_t fix = size_t(4 * RS) + 12288 + 256 + 4096 + 4096 + 1024;
-    return fix + (phase ? size_t(6 * RS) + size_t(4 * RS) : 0) + size_t(nslotrows) * 64 * 8;
+    return fix + (phase ? size_t(5) * size_t(RSH ? RSH : 2 * RS) : 0) + size_t(nslotrows) * 64 * 8;
+}
+
+// ---- split kernels (H > 1): a TEAM of H workgroups computes one direction of an utterance pair; workgroup h finishes the
+// rows of set h (mm_rows.h make_rows_split) and the team exchanges its rows once per step through global memory:
+//   * every finish also stores the pair of linear values of its row as ONE 8-byte write-through (sc1) store -- a granule
+//     whose data is its own flag: the sign bits carry the step's tag (linear values are >= 0; exp2(-inf) = +0 becomes -0);
+//   * the EXCHANGE wave of a workgroup (one more service wave) polls the other sets' slots with sc1 loads until every
+//     granule carries the tag of the step, strips the signs and writes the values into the workgroup's own LDS vector; the
+//     step's barrier then releases the compute waves with the complete vector.  No flags, no fences, no ordering between
+//     the stores (cdna_hip_programming.md guideline 16, form R2);
+//   * slots alternate by the parity of the step, the tag flips with every reuse of a slot: a slot still holding the step
+//     before last shows the other tag.  A workgroup cannot be more than one step ahead of its team (it needs the others'
+//     rows of every step), so two slots suffice.  The buffers are zeroed before every call (tag 0, first tag used: 1);
+//   * a poll gives up after MM_SPLIT_TIMEOUT (the team is not co-resident, e.g. a foreign kernel holds the compute
+//     units): the utterances are marked for the exact kernels and the workgroup runs on without waiting.
+typedef unsigned long long mm_u64;
+typedef __attribute__((address_space(1))) mm_u64 mm_gu64;
+#ifndef MM_SPLIT_TIMEOUT
+#define MM_SPLIT_TIMEOUT 10000000ull  // ticks of s_memrealtime (100 MHz): 0.1 s
+#endif
+__device__ __forceinline__ void granule_store(float *base, unsigned byte_off, float a, float b) {
+    const mm_u64 v = ((mm_u64)__builtin_bit_cast(unsigned, b) << 32) | __builtin_bit_cast(unsigned, a);
+    __hip_atomic_store((mm_gu64 *)(__UINTPTR_TYPE__)(reinterpret_cast<char *>(base) + byte_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ mm_u64 granule_load(const float *base, unsigned byte_off) {
+    return __hip_atomic_load((mm_gu64 *)(__UINTPTR_TYPE__)(reinterpret_cast<const char *>(base) + byte_off), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+}
+// tag of step t (steps of a launch are numbered from t0 + 1) for a ring of 1 << LG slots: 1 for the first use of a slot
+__device__ __forceinline__ unsigned split_tag(int t, int t0, int LG) { return (((unsigned)(t - t0 - 1) >> LG) & 1u) ^ 1u; }
+
+// Exchange wave: the rows of set g of step t -> LDS.  src: that set's slot of the step (n granules), dst: LDS byte address of
+// the set's region in the vector being written.  Sweeps the granules that have not arrived -- two per lane and load (16-byte
+// sc1 loads: half the memory instructions of 8-byte ones, and what the hand-off costs sits in this compute unit's memory
+// queue) -- until all carry `tag`.  Returns false on timeout.  NG2 = 16-byte loads per lane (128 * NG2 >= n).
+template <int NG2>
+__device__ __forceinline__ bool split_receive(const float *src, int n, unsigned dst, unsigned tag, int lane, unsigned first_sleep) {
+    typedef unsigned mm_u32x4 __attribute__((ext_vector_type(4)));
+    mm_u32x4 v[NG2];
+    unsigned pending = 0;  // bit j: the granules 2 (lane + 64 j), + 1 of this lane have not both arrived
+#pragma unroll
+    for (int j = 0; j < NG2; ++j) {
+        v[j] = mm_u32x4{0u, 0u, 0u, 0u};
+        if (2 * (lane + 64 * j) < n) pending |= 1u << j;
+    }
+    for (unsigned i = 0; i < first_sleep; ++i) __builtin_amdgcn_s_sleep(1);
+    const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+#pragma unroll
+        for (int j = 0; j < NG2; ++j)
+            if ((pending >> j) & 1u)
+                asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(v[j]) : "v"(16u * (unsigned)(lane + 64 * j)), "s"(src) : "memory");
+        // (the loads are inline asm: the wait carries every destination, so that no use is scheduled in front of it)
+#pragma unroll
+        for (int j = 0; j < NG2; ++j) asm volatile("" : "+v"(v[j]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < NG2; ++j) asm volatile("" : "+v"(v[j]));
+#pragma unroll
+        for (int j = 0; j < NG2; ++j)
+            if ((pending >> j) & 1u) {
+                const bool second = 2 * (lane + 64 * j) + 1 < n;
+                // (one store wrote both floats of a granule: one sign tells)
+                if ((v[j].x >> 31) == tag && (!second || (v[j].z >> 31) == tag)) {
+                    mm_f32x4 w;
+                    w.x = __builtin_bit_cast(float, v[j].x & 0x7fffffffu);
+                    w.y = __builtin_bit_cast(float, v[j].y & 0x7fffffffu);
+                    w.z = second ? __builtin_bit_cast(float, v[j].z & 0x7fffffffu) : 0.f;
+                    w.w = second ? __builtin_bit_cast(float, v[j].w & 0x7fffffffu) : 0.f;
+                    *(__attribute__((address_space(3))) mm_f32x4 *)(__UINTPTR_TYPE__)(dst + 16u * (unsigned)(lane + 64 * j)) = w;
+                    pending &= ~(1u << j);
+                }
+            }
+        if (__builtin_amdgcn_ballot_w64(pending != 0u) == 0ull) return true;
+        if (__builtin_amdgcn_s_memrealtime() - tstart > MM_SPLIT_TIMEOUT) return false;
+        __builtin_amdgcn_s_sleep(4);
+    }
 }
 
 struct PairUtt {  // one utterance of the pair (scalar registers)
@@ -130,15 +210,60 @@ __device__ __forceinline__ float wave_sum_rl(float v) {
 
 // one wave, both utterances of the pair: per-frame sums over the pdfs (psum pairs [pdf][2]), divide, store gamma
 // (src/inference.jl:156-160); lt[u] = log2 of the sum (-inf, and gamma = 0, if nothing is alive)
-template <int NJ>  // NJ * 64 >= P + 1
-__device__ __forceinline__ void pair_finish_frames(unsigned psum, int P1, int P, int lane, float *gp0, float *gp1, long long gsp,
-                                                   bool store0, bool store1, float (&lt)[2]) {
+// (split kernels: xp[g] = the slot of the step in which set g of the team published its partial sums, NULL for the own
+// set; the sum of a pdf is the sum of the sets' partial sums in the order of the sets -- the same bits in every workgroup)
+template <int NJ, int H = 1>  // NJ * 64 >= P + 1
+__device__ __forceinline__ bool pair_finish_frames(unsigned psum, int P1, int P, int lane, float *gp0, float *gp1, long long gsp,
+                                                   bool store0, bool store1, float (&lt)[2], const float *const *xp = nullptr,
+                                                   unsigned tag = 0u, unsigned long long tmo = MM_SPLIT_TIMEOUT) {
     mm_f32x2 s[NJ];
     float t0 = 0.f, t1 = 0.f;
+    bool arrived = true;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int q = lane + 64 * j;
         s[j] = ldsr2(psum + 8u * (q < P1 ? q : 0));
+    }
+    if constexpr (H > 1) {
+        mm_f32x2 tot[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) tot[j] = mm_f32x2{0.f, 0.f};
+        for (int g = 0; g < H; ++g) {
+            if (xp[g] == nullptr) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) tot[j] += s[j];
+                continue;
+            }
+            mm_u64 v[NJ];
+            const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int q = lane + 64 * j;
+                    v[j] = granule_load(xp[g], 8u * (unsigned)(q < P1 ? q : 0));
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) ok = ok && ((unsigned)(v[j] >> 31) % 2u == tag);
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                if (__builtin_amdgcn_s_memrealtime() - tstart >= tmo) {
+                    arrived = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                tot[j].x += __builtin_bit_cast(float, (unsigned)v[j] & 0x7fffffffu);
+                tot[j].y += __builtin_bit_cast(float, (unsigned)(v[j] >> 32) & 0x7fffffffu);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) s[j] = tot[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = lane + 64 * j;
         if (q < P1) {
             t0 += s[j].x;
             t1 += s[j].y;
@@ -157,10 +282,13 @@ __device__ __forceinline__ void pair_finish_frames(unsigned psum, int P1, int P,
     }
     lt[0] = fast_log2(t0);
     lt[1] = fast_log2(t1);
+    return arrived;
 }
 
 // pdf sums of both utterances (q pairs in pdf-major order): 8 pdfs per wave and pass, 8 lanes per pdf
-__device__ __forceinline__ void pair_pdf_sums(unsigned qbase, unsigned pdfse_base, unsigned psum_base, int P1, int wave, int NWC, int lane) {
+// (split kernels: xs = the slot the partial sums are published in for the team, sg = +-1 carrying the tag)
+__device__ __forceinline__ void pair_pdf_sums(unsigned qbase, unsigned pdfse_base, unsigned psum_base, int P1, int wave, int NWC, int lane,
+                                              float *xs = nullptr, float sg = 1.f) {
     for (int p0 = wave * 8; p0 < P1; p0 += NWC * 8) {
         const int pdf = p0 + (lane >> 3);
         float s0 = 0.f, s1 = 0.f;
@@ -184,7 +312,10 @@ __device__ __forceinline__ void pair_pdf_sums(unsigned qbase, unsigned pdfse_bas
         }
         s0 = grp_sum(s0, 3);
         s1 = grp_sum(s1, 3);
-        if (pdf < P1 && (lane & 7) == 0) ldsw2(psum_base + 8u * pdf, s0, s1);
+        if (pdf < P1 && (lane & 7) == 0) {
+            ldsw2(psum_base + 8u * pdf, s0, s1);
+            if (xs) granule_store(xs, 8u * (unsigned)pdf, s0 * sg, s1 * sg);
+        }
     }
 }
 
@@ -302,19 +433,21 @@ struct PairHand {  // what an agent hands from phase A to phase B, per utterance
 };
 
 // One agent: direction DIR (0: forward / alpha, 1: backward / beta) of pair `pair`, phase PHASE (0: A, 1: B).
-template <int KA, int RS, int PHASE, int DIR, int NJ>
-__device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
+// H > 1 (split kernels): the agent is a team of H workgroups, this one finishes the rows of set `hset`.
+template <int KA, int RS, int PHASE, int DIR, int NJ, int H = 1, int RSH = 2 * RS>
+__device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hset = 0) {
     extern __shared__ float lds[];
-    using L = PairLay<RS, PHASE>;
+    using L = PairLay<RS, PHASE, RSH>;
 #ifndef MM_PAIR_DA
 #define MM_PAIR_DA 3
 #endif
     constexpr bool MM_PAIR_DOUBLE = true;
     constexpr int D = PHASE ? 3 : MM_PAIR_DA;  // gather pairs in flight ahead of the FMAs
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, NWC = NW - 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, NWC = NW - (H > 1 ? 2 : 1);
     const bool service = wave == NWC;
-    if (service) __builtin_amdgcn_s_setprio(3);
+    const bool xwave = H > 1 && wave == NWC + 1;  // the exchange wave of a team's workgroup
+    if (service || xwave) __builtin_amdgcn_s_setprio(3);
     // ---- the two utterances
     PairUtt U[2];
     int NFp = 1;
@@ -339,7 +472,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
     // partner values of a row (two 4-byte reads at the partner's scattered positions cost the backward agent 9 % of a step)
     float *rowsP = p.ws_alpha + (long long)pair * (long long)(p.N + 2) * 2 * p.pair_s1p;
     const UttDesc &ud = p.utts[U[0].b];
-    const RowU r = uni(ud.rp[DIR]);
+    const RowU r = uni(H > 1 ? ud.rps[DIR][hset] : ud.rp[DIR]);
     const int S1 = r.rows, S1p = p.pair_s1p, P1 = uni(ud.P1), P = P1 - 1, P1p = (P1 + 3) & ~3;
     const float thr = r.thr;
     // split: forward steps 1..m are phase A, backward steps 1..NFp-m
@@ -354,7 +487,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
     // ---- LDS set-up
     for (unsigned q = tid * 4u; q < 2u * L::RS2; q += NT * 4u) ldsw(L::PP(0) + q, 0.f);
     if constexpr (PHASE == 1)
-        for (unsigned q = tid * 4u; q < 2u * L::RS2; q += NT * 4u) ldsw(L::Q(0) + q, 0.f);
+        for (unsigned q = tid * 4u; q < 2u * RSH; q += NT * 4u) ldsw(L::Q(0) + q, 0.f);
     if (tid < 32) ldsw(L::MS(0) + 4u * tid, 0.f);
     if (tid < 4) ldsw(L::EM(tid >> 1) + 8u * P1p + 4u * (tid & 1), MM_NINF);  // the emission slot of lanes without a row
     const int nslotwords = r.nslotrows * 128;
@@ -362,9 +495,24 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
     if constexpr (PHASE == 1)
         for (int q = tid; q < P1; q += NT) ldswu(L::PDFSE + 4u * q, as_global(reinterpret_cast<const unsigned *>(r.pdfse))[q]);
     int *redo0 = p.redo + U[0].b, *redo1 = p.redo + (U[1].valid ? U[1].b : p.B);
-    if (PHASE == 0 && DIR == 0 && tid == 0) {
-        *redo0 = 0;
-        *redo1 = 0;
+    // ---- the team (split kernels): own set's region, own / others' slots of this launch
+    const int xbase = H > 1 ? p.sp_base[hset] : 0, xcnt = H > 1 ? p.sp_cnt[hset] : 0;
+    float *xsend = nullptr, *xps_send = nullptr;
+    // The whole team on ONE XCD (found out at the start of the launch, see the exchange wave): plain stores reach the L2
+    // that the team's sc1 polls read, and they leave the compute unit as whole lines instead of one fabric write per lane
+    // (measured on the WSJ graph: 2.8 against 3.3 ms per call).  Anything else: write-through (sc1) granules.
+    bool xplain = false;
+    const float *xrecv[H], *xps_recv[H];
+    if constexpr (H > 1) {
+        float *xb = p.xbuf + (long long)PHASE * p.x_phase + ((long long)pair * 2 + DIR) * H * 2 * p.x_slot;
+        float *xq = p.xps + ((long long)pair * 2 + DIR) * H * 4 * 512;
+#pragma unroll
+        for (int g = 0; g < H; ++g) {
+            xrecv[g] = g == hset ? nullptr : xb + (long long)g * 2 * p.x_slot;
+            xps_recv[g] = g == hset ? nullptr : xq + (long long)g * 4 * 512;
+        }
+        xsend = xb + (long long)hset * 2 * p.x_slot;
+        xps_send = xq + (long long)hset * 4 * 512;
     }
     unsigned long long endmask = 0, lgw0 = 0;
     int nslots = 0, start2 = 0;
@@ -414,41 +562,48 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
 
     if (service) {
         // ================= service wave =================
+        // (split kernels: `sl` is made opaque at the top of every step, so that nothing derived from the lane index is
+        // hoisted out of the step loop -- with the 24 KB vectors of those kernels the hoisted LDS addresses did not fit the
+        // registers, and every reload of a spilled one is a scratch load whose wait also waits for the LDS-DMAs in flight)
+        int sl = lane;
         RowNorm norm[2];
         double cum[2] = {0.0, 0.0};
-        double zmin[2] = {__builtin_inf(), __builtin_inf()};
+        double zmin[2] = {__builtin_inf(), __builtin_inf()}, zmax[2] = {-__builtin_inf(), -__builtin_inf()};
+        bool xdead = H > 1 && (p.x_sleep & 0x300) != 0;  // (split kernels) a poll of the team's partial sums timed out
         auto dma_raw = [&](int t) {  // raw emissions of step t (clamped) -> RAW(t & 3, u)
             const int tt = t < 1 ? 1 : (t > tEnd ? tEnd : t);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) row_dma_em<NJ>(L::RAW(0, u) + 2048u * (t & 3), U[u].Vb, p.vsn, frame_of(tt), p.N, P, lane);
+            for (int u = 0; u < 2; ++u) row_dma_em<NJ>(L::RAW(0, u) + 2048u * (t & 3), U[u].Vb, p.vsn, frame_of(tt), p.N, P, sl);
         };
         auto dma_partner = [&](int t) {  // the other agent's vector + offset of step t's frame -> AL(t % 3, u), POFF(t & 3, u)
             const int tt = t < 1 ? 1 : (t > tEnd ? tEnd : t);
             int f = frame_of(tt);
             f = f > p.N ? p.N : f;  // (frame N+1 is never combined)
-            const int n4 = S1p >> 1;  // float4s of the row of pairs
-            constexpr int NA = (RS / 4 + 255) / 256;
-            const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(rowsP + (long long)f * 2 * S1p);
-            const unsigned dst = L::AL(0, 0) + (unsigned)(tt % 3) * 2u * RS;
+            // (split kernels: the rows of the own set only -- the other direction's workgroup of the same set stored them,
+            // contiguously, at the set's base)
+            const int n4 = H > 1 ? (xcnt + 1) >> 1 : S1p >> 1;  // float4s of the row of pairs
+            constexpr int NDM = RSH / 1024;
+            const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(rowsP + (long long)f * 2 * S1p + 2 * xbase);
+            const unsigned dst = L::AL(0) + (unsigned)(tt % 3) * (unsigned)RSH;
 #pragma unroll
-            for (int j = 0; j < 2 * NA; ++j) {
-                const int q = lane + 64 * j;
+            for (int j = 0; j < NDM; ++j) {
+                const int q = sl + 64 * j;
                 dma_b128(src + (q < n4 ? q : 0), dst + 1024u * j);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u)
-                dma_b32(reinterpret_cast<const unsigned *>(U[u].offs + f) + (lane & 1), L::POFF(0, u) + 512u * (t & 7));
+                dma_b32(reinterpret_cast<const unsigned *>(U[u].offs + f) + (sl & 1), L::POFF(0, u) + 512u * (t & 7));
         };
-        constexpr int NDMA = 2 * NJ + (PHASE ? 2 * ((RS / 4 + 255) / 256) + 2 : 0);  // DMAs issued per step (a lower bound of the VMEM operations)
+        constexpr int NDMA = 2 * NJ + (PHASE ? RSH / 1024 + 2 : 0);  // DMAs issued per step (a lower bound of the VMEM operations)
         // stage the emissions of step t into EM(t & 1) and account its offsets; S = the normaliser the step subtracts
         auto stage = [&](int t, const float (&S)[2]) {
             float E[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                E[u] = pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, u) + 2048u * (t & 3), u, frame_of(t), U[u].len, P, lane);
+                E[u] = pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, u) + 2048u * (t & 3), u, frame_of(t), U[u].len, P, sl);
                 cum[u] += (double)S[u] + (double)E[u];
             }
-            if (lane == 0) {
+            if (sl == 0) {
                 ldsw2(L::MS(t & 1), S[0], S[1]);
                 // the offset that turns the step's stored vector into log2 values: forward alpha~ includes the emission
 #pragma unroll
@@ -479,11 +634,11 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
         if (PHASE == 0 || DIR == 1) {  // emissions of the starting step: the initial alpha needs them, and so does
             float E[2];                // rebuilding the backward agent's linear vector from its stored beta~
 #pragma unroll
-            for (int u = 0; u < 2; ++u) E[u] = pair_stage_em<NJ>(L::EM(t0 & 1), L::RAW(0, u) + 2048u * (t0 & 3), u, frame_of(t0), U[u].len, P, lane);
+            for (int u = 0; u < 2; ++u) E[u] = pair_stage_em<NJ>(L::EM(t0 & 1), L::RAW(0, u) + 2048u * (t0 & 3), u, frame_of(t0), U[u].len, P, sl);
             if (PHASE == 0) {  // step 1 subtracts nothing but E
 #pragma unroll
                 for (int u = 0; u < 2; ++u) cum[u] = (double)E[u];
-                if (DIR == 0 && lane == 0) {
+                if (DIR == 0 && sl == 0) {
                     U[0].offs[1] = cum[0];
                     U[1].offs[1] = cum[1];
                 }
@@ -501,9 +656,20 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
             const int f = frame_of(ts);
             const bool live0 = f >= 1 && f <= U[0].len, live1 = f >= 1 && f <= U[1].len;
             float lt[2];
-            pair_finish_frames<NJ>(psum, P1, P, lane, p.gamma + (long long)U[0].b * p.gsb + (long long)(f - 1) * p.gsn,
-                               p.gamma + (long long)U[1].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp, live0 && U[0].valid,
-                               live1 && U[1].valid, lt);
+            const float *xp[H];
+#pragma unroll
+            for (int g = 0; g < H; ++g) xp[g] = (H > 1 && g != hset) ? xps_recv[g] + (ts & 3) * 512 : nullptr;
+            const bool writer = H == 1 || hset == 0;  // (every workgroup of a team has the sums of all pdfs: the first stores gamma)
+            if (!pair_finish_frames<NJ, H>(psum, P1, P, sl, p.gamma + (long long)U[0].b * p.gsb + (long long)(f - 1) * p.gsn,
+                                           p.gamma + (long long)U[1].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp,
+                                           live0 && U[0].valid && writer, live1 && U[1].valid && writer, lt, xp, split_tag(ts, t0, 2),
+                                           xdead ? 0ull : MM_SPLIT_TIMEOUT)) {
+                if (sl == 0) {
+                    *redo0 = 2;  // (the team is not running together: the exact kernels compute these utterances)
+                    *redo1 = 2;
+                }
+                xdead = true;  // ... and nothing is waited for any more
+            }
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 if (u ? live1 : live0) {
@@ -511,16 +677,18 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                     const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 512u * (ts & 7));
                     const double z = (double)lt[u] + own + oth;
                     zmin[u] = z < zmin[u] ? z : zmin[u];
+                    zmax[u] = z > zmax[u] ? z : zmax[u];  // (NaN: neither comparison holds; the finish kernel tests zmin <= zmax)
                 }
         };
         auto step = [&](auto RDc, int t) {
             constexpr int RD = decltype(RDc)::value, WR = 1 - RD;  // RD = parity of steps t - 1 and t + 1
+            if constexpr (H > 1) asm volatile("" : "+v"(sl));
             // emissions of step t + 1 (requested at step t - 2: the DMAs of step t - 1 may still be in flight)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
             MM_STAMP(2);
             // the normaliser of step t + 1 from the maxima of step t - 1 (complete since the last barrier)
             float mx[2];
-            pair_scan_max<(RS / 8 + 63) / 64>(L::PP(RD), (S1 + 2) >> 1, lane, mx[0], mx[1]);
+            pair_scan_max<(RS / 8 + 63) / 64>(L::PP(RD), (S1 + 2) >> 1, sl, mx[0], mx[1]);
             MM_STAMP(3);
             if (t + 1 <= tEnd) {
                 const float S[2] = {norm[0].next(mx[0]), norm[1].next(mx[1])};
@@ -552,7 +720,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
             }
         }
         if constexpr (PHASE == 0) {
-            if (lane == 0) {
+            if (sl == 0) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     PairHand h;
@@ -574,19 +742,78 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                 if (k == 0) __syncthreads();  // (a)
                 if (t > t0) frames_of_step(t, L::PSUM(t & 1));
             }
-            if (lane == 0) {
+            if (sl == 0) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
-                    if (U[u].valid) p.pair_zmin[(long long)U[u].b * 2 + DIR] = zmin[u];
+                    if (U[u].valid) {
+                        p.pair_zmin[(long long)U[u].b * 4 + DIR] = zmin[u];
+                        p.pair_zmin[(long long)U[u].b * 4 + 2 + DIR] = zmax[u];
+                    }
             }
         }
+    } else if (xwave) {
+        // ================= exchange wave (split kernels) =================
+        __syncthreads();  // (1)
+        bool dead = (p.x_sleep & 0x200) != 0;
+        {   // which XCD is the team on?  Every workgroup publishes the id of its own (a granule in the unused tail of
+            // psum slot PHASE of its set) and reads the others'; workgroup -> XCD placement is the hardware's business,
+            // only what the workgroups SEE decides how they store.
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 15u;
+            if (lane == 0) granule_store(xps_send + PHASE * 512, 8u * 255u, __builtin_bit_cast(float, xcc + 1u), 0.f);
+            bool same = true;
+            const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+            for (int g = 0; g < H; ++g) {
+                if (g == hset) continue;
+                unsigned other = 0u;
+                while (!dead) {
+                    other = (unsigned)granule_load(xps_recv[g] + PHASE * 512, 8u * 255u);
+                    if (other != 0u) break;
+                    if (__builtin_amdgcn_s_memrealtime() - tstart > MM_SPLIT_TIMEOUT) dead = true;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                same = same && other == xcc + 1u;
+            }
+            if (dead && lane == 0) {
+                *redo0 = 2;
+                *redo1 = 2;
+            }
+            if (lane == 0) ldswu(L::XFLAG, (same && !dead && !(p.x_sleep & 0x800)) ? 1u : 0u);
+        }
+        __syncthreads();  // (2)
+        constexpr int NG2 = (RSH / 16 + 63) / 64;
+        MM_STAMP_RESET;
+        for (int t = t0 + 1; t <= t1; ++t) {
+            if (!dead) {
+#pragma unroll
+                for (int g = 0; g < H; ++g) {
+                    if (g == hset) continue;
+                    if (!split_receive<NG2>(xrecv[g] + (long long)(t & 1) * p.x_slot, p.sp_cnt[g], L::PP(t & 1) + 8u * (unsigned)p.sp_base[g],
+                                           split_tag(t, t0, 1), lane, (unsigned)p.x_sleep & 0xffu)) {
+                        dead = true;  // the team is not running together: mark the utterances for the exact kernels, wait no more
+                        if (lane == 0) {
+                            *redo0 = 2;
+                            *redo1 = 2;
+                        }
+                    }
+                }
+            }
+            MM_STAMP(0);
+            MM_STEP_SYNC();
+            MM_STAMP(1);
+        }
+        if constexpr (PHASE == 1) __syncthreads();  // (a)
     } else {
         // ================= compute waves =================
         __syncthreads();  // (1)
         // the starting vector (step t0)
         if (PHASE == 0 && DIR == 0) {  // alpha_hat (*) lhs[:,1]   (src/inference.jl:68)
             for (int i = tid; i < S1; i += 64 * NWC) {
-                const unsigned e8 = 8u * as_global(r.rowpdf)[i];
+                unsigned pdfi = as_global(r.rowpdf)[i];
+                if (H > 1 && pdfi == 0xffffu) pdfi = (unsigned)P1p;  // (alignment padding between the sets' regions: init = -inf)
+                const unsigned e8 = 8u * pdfi;
                 const mm_f32x2 e = ldsr2(L::EM(1) + e8);
                 const float a = as_global(r.init)[i];
                 const float v0 = a + e.x, v1 = a + e.y;
@@ -602,16 +829,19 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
             for (int i = tid; i < S1; i += 64 * NWC) {
                 const mm_f32x2 vv = *reinterpret_cast<const mm_f32x2 *>(rowsP + ((long long)f * S1p + i) * 2);
                 float v0 = vv.x, v1 = vv.y;
+                const unsigned pdfi = as_global(r.rowpdf)[i];
                 if (DIR == 1) {  // beta~ is stored without the frame's emission
-                    const mm_f32x2 e = ldsr2(L::EM(t0 & 1) + 8u * as_global(r.rowpdf)[i]);
+                    const mm_f32x2 e = ldsr2(L::EM(t0 & 1) + 8u * (H > 1 && pdfi == 0xffffu ? (unsigned)P1p : pdfi));
                     v0 += e.x;
                     v1 += e.y;
                 }
+                if (H > 1 && pdfi == 0xffffu) v0 = v1 = MM_NINF;  // (padding: never stored)
                 ldsw2(L::PP(t0 & 1) + 8u * i, fast_exp2(v0), fast_exp2(v1));
             }
         }
         load_graph();
         __syncthreads();  // (2)
+        if constexpr (H > 1) xplain = __builtin_amdgcn_readfirstlane(ldsru(L::XFLAG)) != 0u;
         auto step = [&](auto RDc, int t) {
             constexpr int RD = decltype(RDc)::value, WR = 1 - RD;
             if (nslots > 0) {
@@ -639,8 +869,11 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                 const mm_f32x2 S = ldsr2(L::MS(WR));  // the step's normalisers, posted by the service wave
                 mm_f32x2 e = ldsr2((info >> 16) + L::EM(WR));
                 const int f = frame_of(t);
-                const unsigned alb = L::AL(0, 0) + (unsigned)(t % 3) * 2u * RS;
+                const unsigned alb = L::AL(0) + (unsigned)(t % 3) * (unsigned)RSH;
                 mm_f32x2 al = {0.f, 0.f};
+                // (split kernels) where the team reads this step's rows, and the step's tag as a sign
+                float *xw = H > 1 ? xsend + (long long)(t & 1) * p.x_slot - 2 * xbase : nullptr;
+                const float xsg = (H > 1 && split_tag(t, t0, 1)) ? -1.f : 1.f;
                 if constexpr (PHASE == 1) al = ldsr2((info2 & 0xffffu) + alb);
                 float *rowP = rowsP + (long long)(f <= p.N ? f : 0) * 2 * S1p;
                 // even / odd arcs (phase B has no registers to spare: one chain there)
@@ -662,7 +895,12 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                     // for -inf (the semiring's zero: in range) and v_max ignores NaN operands.
                     worst = __builtin_fmaxf(worst, __builtin_fmaxf(__builtin_fmaf(__builtin_fabsf(y0), 0.f, __builtin_fabsf(y0)),
                                                                    __builtin_fmaf(__builtin_fabsf(y1), 0.f, __builtin_fabsf(y1))));
-                    ldsw2(pos8 + L::PP(WR), fast_exp2(y0), fast_exp2(y1));
+                    const float p0 = fast_exp2(y0), p1 = fast_exp2(y1);
+                    ldsw2(pos8 + L::PP(WR), p0, p1);
+                    if constexpr (H > 1) {
+                        if (xplain) *reinterpret_cast<mm_f32x2 *>(reinterpret_cast<char *>(xw) + pos8) = mm_f32x2{p0 * xsg, p1 * xsg};
+                        else granule_store(xw, pos8, p0 * xsg, p1 * xsg);
+                    }
                     const float st0 = DIR ? b0 : y0, st1 = DIR ? b1 : y1;  // the vector that is stored / combined
                     if constexpr (PHASE == 0) {
                         *reinterpret_cast<mm_f32x2 *>(reinterpret_cast<char *>(rowP) + pos8) = mm_f32x2{st0, st1};
@@ -695,7 +933,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
                 }
             }
             if constexpr (PHASE == 1)  // C' * (A .* B) of the previous step (:155)
-                if (t - 1 > t0) pair_pdf_sums(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane);
+                if (t - 1 > t0)
+                    pair_pdf_sums(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane, H > 1 ? xps_send + ((t - 1) & 3) * 512 : nullptr,
+                                  (H > 1 && split_tag(t - 1, t0, 2)) ? -1.f : 1.f);
             MM_STAMP(0);
             MM_STEP_SYNC();
             MM_STAMP(1);
@@ -710,7 +950,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
             }
         }
         if constexpr (PHASE == 1) {
-            if (t1 > t0) pair_pdf_sums(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane);
+            if (t1 > t0)
+                pair_pdf_sums(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane, H > 1 ? xps_send + (t1 & 3) * 512 : nullptr,
+                              (H > 1 && split_tag(t1, t0, 2)) ? -1.f : 1.f);
             __syncthreads();  // (a)
         }
     }
@@ -723,16 +965,32 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair) {
 #endif
 }
 
-// ttl = min over the frames of the per-frame log-normaliser (src/inference.jl:159); zeros beyond the sequence lengths
-__global__ void mm_pair_finish_kernel(RunParams p) {
+// ttl = min over the frames of the per-frame log-normaliser (src/inference.jl:159); zeros beyond the sequence lengths.
+//
+// Also decides what a range mark (redo[b] == 1: some finished value of the linear-domain kernels was finite but outside
+// the range in which float32 products keep every term) means for the utterance.  The linear path loses such a value's
+// mass at most (sums of non-negative terms: flushing can only remove mass); in exact arithmetic the per-frame normaliser
+// z_n = log sum_s alpha_n(s) beta_n(s) is the SAME for every frame (= log Z), and frame n lacks exactly the mass of the
+// paths that met a flushed value (forward at a frame <= n, backward at a frame >= n).  So the spread of z_n over the frames
+// measures what was lost: below MM_Z_SPREAD_TOL the marked values carried no mass that matters -- states of a component
+// that decays against the rest of the graph (the initial contexts of the reference's WSJ denominator graph fall 2 log2 per
+// frame behind: 2^-1400 after 700 frames) -- and the result stands; otherwise (or if z is not finite) the mark stays and the
+// exact kernels compute the utterance again.  Marks of value 2 (a team of the split kernels did not run together) stay.
+#ifndef MM_Z_SPREAD_TOL
+#define MM_Z_SPREAD_TOL 1e-4  // log2 units: 7e-5 nats on log Z (the parity bar on ttl is 1e-5 relative of O(10..1000) nats)
+#endif
+static __global__ void mm_pair_finish_kernel(RunParams p) {
     const int b = blockIdx.x;
     int len = p.lens ? p.lens[b] : p.N;
     len = len < 0 ? 0 : (len > p.N ? p.N : len);
     const int P = p.utts[b].P1 - 1;
     if (threadIdx.x == 0) {
-        const double z0 = p.pair_zmin[2 * b], z1 = p.pair_zmin[2 * b + 1];
+        const double z0 = p.pair_zmin[4 * b], z1 = p.pair_zmin[4 * b + 1];
         const double z = z0 < z1 ? z0 : z1;
+        const double y0 = p.pair_zmin[4 * b + 2], y1 = p.pair_zmin[4 * b + 3];
+        const double zM = y0 > y1 ? y0 : y1;
         p.ttl[b] = (z < __builtin_inf()) ? (float)(z * (double)MM_LN2) : MM_NINF;  // (no frame: no path of length 0)
+        if (p.redo[b] == 1 && z > -__builtin_inf() && zM < __builtin_inf() && zM - z <= MM_Z_SPREAD_TOL) p.redo[b] = 0;
     }
     const long long gbase = (long long)b * p.gsb;
     for (long long q = threadIdx.x; q < (long long)(p.N - len) * P; q += blockDim.x)

@@ -397,9 +397,7 @@ __global__ void __launch_bounds__(1024) mm_fbr_kernel(RunParams p) {
 
     // ---- set-up common to both directions
     const int fpos = r.fpos;
-    if constexpr (PASS == 0) {
-        if (tid == 0) p.redo[b] = 0;
-    } else {
+    if constexpr (PASS == 1) {
         if (uni(p.redo[b])) return;  // marked by the forward kernel: the exact kernels compute this utterance
         const double logZ2 = hand[1];
         if (!(logZ2 > -1e300)) {  // no accepting path: gamma = 0, ttl = -inf

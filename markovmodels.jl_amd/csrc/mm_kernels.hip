@@ -33,6 +33,7 @@ namespace mm {
 #define MM_LOG2E 1.4426950408889634f
 #define MM_LN2 0.6931471805599453f
 #define MM_MAX_WAVES 16
+#define MM_SPLIT_HMAX 4  // workgroups of a team (split pair kernels)
 
 enum { MODE_FB = 0, MODE_ALPHA = 1, MODE_BETA = 2 };
 
@@ -79,6 +80,8 @@ struct UttDesc {
     QuadDev q[2];   // same two matrices in quad form (log semiring only)
     RowDev r[2];    // ... and in row-lane form (log semiring only; KA == 0: not available)
     RowDev rp[2];   // ... and in the pair variant of the row-lane form (mm_rows.h RowPackOpts::pair)
+    RowDev rps[2][MM_SPLIT_HMAX];  // ... and the split pair forms [direction][set] (mm_rows.h make_rows_split): rowpdf / init /
+                                   // rows / fpos refer to the TEAM's vector (all sets; rowpdf 0xffff = alignment padding)
     const float *init_f;            // alpha_hat in forward numbering
     const unsigned short *map_bf;   // backward position -> forward position
     const float *init;  // dense alpha_hat [S1] (log2 domain for MM_LOG, natural for MM_TROPICAL)
@@ -130,6 +133,15 @@ struct RunParams {
     int pair_s1p;
     void *pair_hand;
     double *pair_zmin;
+    // Split pair kernels (teams of H workgroups per utterance pair and direction): set h computes sp_cnt[h] rows, at
+    // positions sp_base[h].. of the team's vector.  xbuf: what the workgroups of a team send each other --
+    // [phase][pair][direction][set][2 slots][x_slot floats] linear values of the set's rows of a step, 8-byte granules
+    // {utterance 0, utterance 1} tagged in the sign bits; xps: [pair][direction][set][4 slots][512 floats] per-pdf partial
+    // sums (phase B).  Both are zeroed before every call (a zero granule = not yet arrived).
+    int sp_base[MM_SPLIT_HMAX], sp_cnt[MM_SPLIT_HMAX];
+    float *xbuf, *xps;
+    long long x_slot, x_phase;  // floats per slot; floats of one phase's area
+    int x_sleep;                // the exchange wave sleeps this many x 64 clocks before its first poll of a step
 };
 
 // In-kernel cycle stamps (diagnostic build only; the shipped library executes none).
@@ -995,6 +1007,7 @@ __global__ void __launch_bounds__(1024) mm_tropical_kernel(RunParams p) {
     }
 }
 
+#ifndef MM_SECONDARY_TU  // (plain kernels: defined once, in the translation unit of mm_engine.hip)
 // back-trace: one lane per utterance follows the back-pointers from the phony
 // final state at frame len+1 (historical bestpath, examples/demo.ipynb cell 23)
 __global__ void mm_backtrace_kernel(RunParams p) {
@@ -1045,5 +1058,7 @@ __global__ void mm_length_order_kernel(const int *lens, int B, int N, int *order
     }
     order[rank] = i;
 }
+
+#endif  // MM_SECONDARY_TU
 
 }  // namespace mm

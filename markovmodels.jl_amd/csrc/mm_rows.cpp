@@ -90,11 +90,11 @@ struct Plan {
     bool ok = false;
 };
 
-Plan plan_for(int64_t nrows, const std::vector<int64_t> &rowptr, int acap, const RowPackOpts &opt) {
+Plan plan_for(const std::vector<int32_t> &rows, const std::vector<int64_t> &rowptr, int acap, const RowPackOpts &opt) {
     Plan p;
     std::vector<Unit> units;
-    units.reserve(size_t(nrows));
-    for (int64_t r = 0; r < nrows; ++r) {
+    units.reserve(rows.size());
+    for (int32_t r : rows) {
         const int d = int(rowptr[r + 1] - rowptr[r]);
         int g = 1;
         while ((std::max(d, 1) + g - 1) / g > acap / opt.a_round * opt.a_round && g < 64) g *= 2;
@@ -158,15 +158,25 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                const std::vector<float> &val, const std::vector<int32_t> &row2pdf, int32_t P1, bool backward,
                const std::vector<int32_t> &fwd_pos, const RowPackOpts &opt, RowGraph &g) {
     g = RowGraph();
-    if (nrows < 1 || (nrows + 1) * (opt.pair ? 8 : 4) > (opt.pair ? 2 : 1) * opt.rs || (nrows + 1) * 8 > 65528 || P1 > 8000)
+    // the rows this form computes (all, or a subset: split forms) and the positions of the vector its arcs read
+    std::vector<int32_t> myrows;
+    if (opt.subset) {
+        myrows = *opt.subset;
+    } else {
+        myrows.resize(size_t(nrows));
+        std::iota(myrows.begin(), myrows.end(), 0);
+    }
+    const int64_t nsub = int64_t(myrows.size());
+    const int64_t ntot = opt.gtrash >= 0 ? opt.gtrash : nrows;  // positions of the vector (the trash position follows them)
+    if (nrows < 1 || nsub < 1 || (ntot + 1) * (opt.pair ? 8 : 4) > (opt.pair ? 2 : 1) * opt.rs || (ntot + 1) * 8 > 65528 || P1 > 8000)
         return false;
-    if (opt.copy_perm && ((nrows + 1 + 31) & ~int64_t(31)) * 4 > opt.rs) return false;  // (copy 1 scrambles inside blocks of 32)
+    if (opt.copy_perm && ((ntot + 1 + 31) & ~int64_t(31)) * 4 > opt.rs) return false;  // (copy 1 scrambles inside blocks of 32)
     // ---- schedule: the cap on arcs per lane of one row decides how many rows are split over lane groups; take
     // the cap whose most loaded wave is cheapest
     Plan best;
     for (int acap : {12, 16, 24, 32, 48, 64}) {
         if (acap > opt.ka_max) continue;
-        Plan p = plan_for(nrows, rowptr, acap, opt);
+        Plan p = plan_for(myrows, rowptr, acap, opt);
         if (!p.ok) continue;
         if (!best.ok || p.maxcost < best.maxcost || (p.maxcost == best.maxcost && p.KA < best.KA)) best = std::move(p);
     }
@@ -182,7 +192,10 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     g.KA = KA;
     g.NWC = NWC;
     g.rs = opt.rs;
-    g.trash = int(nrows);
+    g.trash = int(ntot);
+    g.pos_base = opt.pos_base;
+    g.nrows = int(nsub);
+    g.qtrash = int(nsub);
     g.slot_words = (backward || opt.pair) ? 2 : 1;
     g.scale = opt.pair ? 8 : 4;
     g.ncopy = opt.copies ? opt.copies : (opt.pair ? 1 : 2);
@@ -191,7 +204,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     g.maxcost = best.maxcost;
     g.mincost = best.mincost;
     // ---- numbering: the order in which the rows are finished
-    g.order.assign(size_t(nrows), -1);
+    g.order.assign(size_t(nsub), -1);
     g.pos.assign(size_t(nrows), -1);
     {
         int32_t next = 0;
@@ -202,19 +215,22 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                     g.order[next] = r;
                     ++next;
                 }
-        if (next != nrows) return false;
+        if (next != nsub) return false;
     }
-    g.rowpdf.resize(size_t(nrows));
-    for (int64_t i = 0; i < nrows; ++i) g.rowpdf[i] = uint16_t(row2pdf[g.order[i]]);
+    if (opt.plan_only) return true;
+    // position of a source state in the vector the arcs read
+    auto gp = [&](int32_t r) { return opt.gpos ? (*opt.gpos)[size_t(r)] : g.pos[size_t(r)]; };
+    g.rowpdf.resize(size_t(nsub));
+    for (int64_t i = 0; i < nsub; ++i) g.rowpdf[i] = uint16_t(row2pdf[g.order[i]]);
     // pdf-major order of the rows (backward: the posterior of a pdf is a sum over contiguous entries)
     std::vector<int32_t> qpos(size_t(nrows), 0);
     if (want_q) {
-        std::vector<int32_t> byp(static_cast<size_t>(nrows));
-        std::iota(byp.begin(), byp.end(), 0);
+        std::vector<int32_t> byp(myrows);
+        std::sort(byp.begin(), byp.end());
         std::stable_sort(byp.begin(), byp.end(), [&](int32_t a, int32_t b) { return row2pdf[a] < row2pdf[b]; });
         g.pdfse.assign(2 * size_t(P1), 0);
         std::vector<int64_t> first(P1, -1), last(P1, -1);
-        for (int64_t i = 0; i < nrows; ++i) {
+        for (int64_t i = 0; i < nsub; ++i) {
             qpos[byp[i]] = int32_t(i);
             const int32_t p = row2pdf[byp[i]];
             if (first[p] < 0) first[p] = i;
@@ -228,10 +244,10 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
         // positions in one LDS store (lane groups of 32 for 4-byte entries, of 16 for the pair form's 8-byte entries;
         // bank = position mod 32), so the rows that share such a group get positions in distinct banks where their
         // ranges allow it (measured on config 3 with conflict-free stores: -3 % in the phase that combines).
-        std::vector<char> taken(size_t(nrows), 0);
+        std::vector<char> taken(size_t(nsub), 0);
         std::fill(qpos.begin(), qpos.end(), -1);
         const int G = opt.pair ? 16 : 32;
-        const int trash_bank = int(nrows % 32);  // (the lanes that finish nothing store to the position behind the last)
+        const int trash_bank = int(nsub % 32);  // (the lanes that finish nothing store to the position behind the last)
         for (int w = 0; w < NWC; ++w)
             for (int si : best.wave_segs[w]) {
                 const Segment &sg = best.segs[si];
@@ -257,20 +273,20 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
             }
     }
     // ---- CSR in internal numbering (exact fallback)
-    g.rowptr.assign(size_t(nrows) + 1, 0);
-    g.col.resize(col.size());
-    g.cw.resize(val.size());
+    g.rowptr.assign(size_t(nsub) + 1, 0);
+    g.col.clear();
+    g.cw.clear();
     {
         int64_t a_out = 0;
-        for (int64_t i = 0; i < nrows; ++i) {
+        for (int64_t i = 0; i < nsub; ++i) {
             const int64_t r = g.order[i];
             g.rowptr[i] = int32_t(a_out);
             for (int64_t a = rowptr[r]; a < rowptr[r + 1]; ++a, ++a_out) {
-                g.col[a_out] = g.pos[col[a]];
-                g.cw[a_out] = val[a];
+                g.col.push_back(gp(col[a]));
+                g.cw.push_back(val[a]);
             }
         }
-        g.rowptr[nrows] = int32_t(a_out);
+        g.rowptr[nsub] = int32_t(a_out);
     }
     // ---- schedules, slot table
     const int zero_pdf = (P1 + 3) & ~3;  // emission slot that always holds zero(K)
@@ -320,12 +336,12 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                 // the LAST lane of a row's group holds the group sum and finishes the row; the others finish nothing
                 if (grp < int(s.rows.size()) && l % s.g == s.g - 1) {
                     const int32_t r = s.rows[grp];
-                    g.slots[e] = uint32_t(SC * g.pos[r]) | (uint32_t(SC * row2pdf[r]) << 16);
+                    g.slots[e] = uint32_t(SC * (g.pos_base + g.pos[r])) | (uint32_t(SC * row2pdf[r]) << 16);
                     if (g.slot_words == 2)
                         g.slots[e + 1] = uint32_t((opt.pair ? 8 : 4) * (fwd_pos.empty() ? 0 : fwd_pos[r])) | (uint32_t(SC * qpos[r]) << 16);
                 } else {
                     g.slots[e] = uint32_t(SC * g.trash) | (uint32_t(SC * zero_pdf) << 16);
-                    if (g.slot_words == 2) g.slots[e + 1] = 0u | (uint32_t(SC * g.trash) << 16);
+                    if (g.slot_words == 2) g.slots[e + 1] = 0u | (uint32_t(SC * g.qtrash) << 16);
                 }
             }
             // arcs of the segment: every lane of a row's group takes every g-th arc; inside its A slots the
@@ -345,7 +361,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                 // naive placement (CSR order, copy 0) for the statistics
                 for (int l = 0; l < 32; ++l)
                     for (int k = 0; k < s.A; ++k)
-                        tabn[k].add(k < int(la[l].arcs.size()) ? uint32_t(4 * g.col[la[l].arcs[k]]) : uint32_t(4 * (l % int(nrows))));  // (model units)
+                        tabn[k].add(k < int(la[l].arcs.size()) ? uint32_t(4 * g.col[la[l].arcs[k]]) : uint32_t(4 * (l % int(ntot))));  // (model units)
                 // greedy: lane after lane, slot after slot, the remaining arc / copy that is cheapest there
                 std::vector<std::vector<uint32_t>> ad(32, std::vector<uint32_t>(s.A, 0u));
                 std::vector<std::vector<float>> wt(32, std::vector<float>(s.A, 0.f));
@@ -374,7 +390,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                             ++real_arcs;
                         } else {  // padding: weight 0, an address that costs nothing
                             const int bnk = tab[k].least_loaded();
-                            ad[l][k] = uint32_t(4 * (bnk < nrows ? bnk : 0));
+                            ad[l][k] = uint32_t(4 * (bnk < ntot ? bnk : 0));
                             wt[l][k] = 0.f;
                         }
                         tab[k].add(ad[l][k]);
@@ -466,7 +482,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
         for (int l = 0; l < 64; ++l) {
             const size_t e = (size_t(slotrow + pr) * 64 + l) * g.slot_words;
             g.slots[e] = uint32_t(SC * g.trash) | (uint32_t(SC * zero_pdf) << 16);
-            if (g.slot_words == 2) g.slots[e + 1] = 0u | (uint32_t(SC * g.trash) << 16);
+            if (g.slot_words == 2) g.slots[e + 1] = 0u | (uint32_t(SC * g.qtrash) << 16);
         }
     g.conflict_before = n_instr ? cyc_naive / double(n_instr) : 0;
     g.conflict_after = n_instr ? cyc_sched / double(n_instr) : 0;
@@ -477,13 +493,98 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     return true;
 }
 
+bool make_rows_split(int H, int64_t nrows, const std::vector<int64_t> &fwd_ptr, const std::vector<int32_t> &fwd_col,
+                     const std::vector<float> &fwd_val, const std::vector<int64_t> &bwd_ptr, const std::vector<int32_t> &bwd_col,
+                     const std::vector<float> &bwd_val, const std::vector<int32_t> &row2pdf, int32_t P1, const RowPackOpts &opt_f,
+                     const RowPackOpts &opt_b, std::vector<RowGraph> &out, SplitInfo &info) {
+    if (H < 2 || H > 8 || nrows < 2 * H) return false;
+    info = SplitInfo();
+    info.H = H;
+    // ---- the sets: the same in both directions (what workgroup h of the other direction stored for a frame is then exactly
+    // what workgroup h of this direction combines with).  Longest-processing-time first on the pair (forward cost, backward
+    // cost) of every state, cost = arcs + a finish; a state goes to the set whose larger relative load stays smallest.
+    const std::vector<int64_t> *ptr[2] = {&fwd_ptr, &bwd_ptr};
+    const RowPackOpts *opts[2] = {&opt_f, &opt_b};
+    std::vector<int32_t> idx(static_cast<size_t>(nrows));
+    std::iota(idx.begin(), idx.end(), 0);
+    auto cost = [&](int d, int32_t r) { return double((*ptr[d])[r + 1] - (*ptr[d])[r]) + double(opts[d]->finish_cost); };
+    double tot[2] = {0, 0};
+    for (int32_t r : idx)
+        for (int d = 0; d < 2; ++d) tot[d] += cost(d, r);
+    std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) {
+        return cost(0, a) / tot[0] + cost(1, a) / tot[1] > cost(0, b) / tot[0] + cost(1, b) / tot[1];
+    });
+    std::vector<double> load[2] = {std::vector<double>(H, 0.0), std::vector<double>(H, 0.0)};
+    std::vector<int> cnt(H, 0);
+    const int cap = int((nrows + H - 1) / H) + int(nrows / (8 * H)) + 1;  // (the sets' regions are sized alike: keep the counts close)
+    info.part.assign(size_t(nrows), 0);
+    for (int32_t r : idx) {
+        int best = -1;
+        double bl = 0;
+        for (int h = 0; h < H; ++h) {
+            if (cnt[h] >= cap) continue;
+            const double l = std::max((load[0][h] + cost(0, r)) / tot[0], (load[1][h] + cost(1, r)) / tot[1]);
+            if (best < 0 || l < bl || (l == bl && cnt[h] < cnt[best])) {
+                best = h;
+                bl = l;
+            }
+        }
+        if (best < 0) return false;
+        info.part[size_t(r)] = best;
+        for (int d = 0; d < 2; ++d) load[d][best] += cost(d, r);
+        ++cnt[best];
+    }
+    std::vector<std::vector<int32_t>> sets(H);
+    for (int64_t r = 0; r < nrows; ++r) sets[info.part[size_t(r)]].push_back(int32_t(r));
+    int next = 0;
+    for (int h = 0; h < H; ++h) {
+        if (sets[h].empty()) return false;
+        info.base[h] = next;
+        info.count[h] = int(sets[h].size());
+        next = (next + info.count[h] + 1) & ~1;  // (regions start at even positions: 16-byte rows of pairs)
+    }
+    info.total = next;
+    // ---- pass 1: the numbering of every (direction, set); pass 2: the forms, their arcs reading the team's vector
+    out.assign(size_t(2 * H), RowGraph());
+    const std::vector<int32_t> none;
+    std::vector<int32_t> lpos[2];  // original row -> position inside its set's region
+    for (int d = 0; d < 2; ++d) {
+        info.gpos[d].assign(size_t(nrows), -1);
+        lpos[d].assign(size_t(nrows), -1);
+        for (int h = 0; h < H; ++h) {
+            RowPackOpts o = *opts[d];
+            o.subset = &sets[h];
+            o.gtrash = info.total;
+            o.plan_only = true;
+            RowGraph tmp;
+            if (!make_rows(nrows, *ptr[d], d ? bwd_col : fwd_col, d ? bwd_val : fwd_val, row2pdf, P1, d == 1, none, o, tmp)) return false;
+            for (int32_t r : sets[h]) {
+                lpos[d][size_t(r)] = tmp.pos[size_t(r)];
+                info.gpos[d][size_t(r)] = info.base[h] + tmp.pos[size_t(r)];
+            }
+        }
+    }
+    for (int d = 0; d < 2; ++d)
+        for (int h = 0; h < H; ++h) {
+            RowPackOpts o = *opts[d];
+            o.subset = &sets[h];
+            o.gpos = &info.gpos[d];
+            o.pos_base = info.base[h];
+            o.gtrash = info.total;
+            if (!make_rows(nrows, *ptr[d], d ? bwd_col : fwd_col, d ? bwd_val : fwd_val, row2pdf, P1, d == 1, lpos[1 - d], o,
+                           out[size_t(d * H + h)]))
+                return false;
+        }
+    return true;
+}
+
 void set_partner(RowGraph &g, const std::vector<int32_t> &partner_pos) {
     if (g.slot_words != 2) return;
     const uint32_t SC = uint32_t(g.scale);
     for (size_t e = 0; e < g.slots.size(); e += 2) {
         const uint32_t p = (g.slots[e] & 0xffffu) / SC;
         if (int(p) == g.trash) continue;
-        g.slots[e + 1] = (g.slots[e + 1] & 0xffff0000u) | uint32_t(SC * partner_pos[g.order[p]]);
+        g.slots[e + 1] = (g.slots[e + 1] & 0xffff0000u) | uint32_t(SC * partner_pos[g.order[p - uint32_t(g.pos_base)]]);
     }
 }
 

@@ -46,7 +46,10 @@ struct RowGraph {
     int rs = 0;         // byte stride between the LDS regions the addresses refer to (copy 1 of the linear vector
                         // lives rs + 64 bytes above copy 0: rotated by 16 banks)
     int nslotrows = 0;  // rows of the slot table (sum of the waves' segments) + 1 padding row
-    int trash = 0;      // position written by lanes that finish no row (= number of rows)
+    int trash = 0;      // position written by lanes that finish no row (= number of rows; split forms: beyond all regions)
+    int pos_base = 0;   // split forms: position of the form's first row in the team's vector
+    int nrows = 0;      // rows this form computes
+    int qtrash = 0;     // pdf-major position written by lanes that finish no row (= nrows)
     std::vector<int32_t> order;   // position -> original row
     std::vector<int32_t> pos;     // original row -> position
     std::vector<float> w;         // [KA][64 * NWC] linear weights (2^log2 weight; 0 = padding)
@@ -101,6 +104,15 @@ struct RowPackOpts {
     bool copy_perm = false;       // copies of the linear vector the addresses may use (0: 2 for the row form, 1 for the pair form)
     // register windows the kernels are instantiated for: KA is rounded up to one of them (0-terminated; empty: any even KA)
     int ka_choices[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // Split forms (make_rows_split): this form computes only the rows of `subset` (original ids), while its arcs read a
+    // linear vector that holds ALL rows -- the rows of the other workgroups of the team included -- at the positions
+    // `gpos` (original row -> position).  The form's own rows occupy positions pos_base .. pos_base + |subset| - 1 of that
+    // vector, in finishing order; lanes that finish no row write position `gtrash`.
+    const std::vector<int32_t> *subset = nullptr;
+    const std::vector<int32_t> *gpos = nullptr;
+    int pos_base = 0;
+    int gtrash = -1;
+    bool plan_only = false;  // stop after the numbering (order / pos): the first pass of make_rows_split
 };
 
 // rowptr/col/val_log2: 0-based CSR of M (out[r] = (+)_k val[k] (*) in[col[k]]), square, nrows rows.
@@ -109,6 +121,27 @@ struct RowPackOpts {
 bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &col,
                const std::vector<float> &val_log2, const std::vector<int32_t> &row2pdf, int32_t P1, bool backward,
                const std::vector<int32_t> &fwd_pos, const RowPackOpts &opt, RowGraph &out);
+
+// Split forms: the rows of an FSM cut into H sets, the same sets in both directions, one form per (direction, set).
+// A team of H workgroups computes one direction of an utterance pair: workgroup h finishes the rows of set h and
+// receives the others' rows once per frame (mm_kernel_pairs.hip, template parameter H).  For graphs whose arcs do not
+// fit the registers of one compute unit (the reference's WSJ denominator graph, misc/benchmark/den_fsm_wsj.txt: 52 k
+// arcs against ~42 k arc slots), and for the reference's unlimited matrix sizes (src/linalg.jl:170-181) in general.
+struct SplitInfo {
+    int H = 0;
+    int total = 0;                  // positions of the team's vector (regions + alignment padding)
+    int base[8] = {0};              // first position of set h (even), the same in both directions
+    int count[8] = {0};             // rows of set h
+    std::vector<int32_t> part;      // original row -> set
+    std::vector<int32_t> gpos[2];   // per direction: original row -> position in the team's vector
+};
+// fwd_* / bwd_*: CSR of the forward (T_hat') and the backward (T_hat) product.  out[d * H + h]: direction d, set h.
+// The slot tables' word 1 refers to the OTHER direction's numbering relative to the set's base (what workgroup h of the
+// other direction stored for these rows is a contiguous range).
+bool make_rows_split(int H, int64_t nrows, const std::vector<int64_t> &fwd_ptr, const std::vector<int32_t> &fwd_col,
+                     const std::vector<float> &fwd_val, const std::vector<int64_t> &bwd_ptr, const std::vector<int32_t> &bwd_col,
+                     const std::vector<float> &bwd_val, const std::vector<int32_t> &row2pdf, int32_t P1, const RowPackOpts &opt_f,
+                     const RowPackOpts &opt_b, std::vector<RowGraph> &out, SplitInfo &info);
 
 // Pair forms: write the other direction's numbering into word 1 of the slot table (partner_pos: original row ->
 // position in the other direction).

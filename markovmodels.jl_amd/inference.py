@@ -214,6 +214,15 @@ class BatchedFSM:
         check(lib.mm_batch_set_deterministic(self._h, 1 if on else 0))
         return self
 
+    def last_redo_count(self) -> int:
+        """Utterances of the last pdfposteriors call that the fast kernels handed to the exact ones (0 = the whole
+        batch ran on the fast path).  Synchronises the current stream."""
+        import ctypes
+
+        n = ctypes.c_int64(0)
+        check(lib.mm_batch_last_redo_count(self._h, self._stream(_torch()), ctypes.byref(n)))
+        return int(n.value)
+
     def kernels(self, semiring: str = "log") -> str:
         """The kernels the engine launches for this batch (informational)."""
         import ctypes

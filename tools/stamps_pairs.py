@@ -18,13 +18,17 @@ mm = ge.load_package()
 wl = importlib.import_module(mm.__name__ + ".workloads")
 L = importlib.import_module(mm.__name__ + "._lib")
 g, B = wl.lfmmi_denominator(2000, 84, seed=0), 256
+if os.environ.get("WL") == "wsj_den":
+    g, B = wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "den_fsm_wsj.npz")), 128
 N = int(os.environ.get("N", 300))
 cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
 bf = mm.batch(*([cf] * B))
 V = torch.randn(B, N, g.P, device="cuda")
+print(bf.kernels())
 bf.pdfposteriors(V)
 bf.pdfposteriors(V)
 torch.cuda.synchronize()
+print("redo", bf.last_redo_count())
 n = B * 16 * 16
 out = np.zeros(n, dtype=np.uint64)
 L.lib.mm_debug_read_stamps.argtypes = [C.c_void_p, C.c_int64]

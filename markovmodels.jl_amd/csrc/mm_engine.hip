@@ -216,6 +216,7 @@ struct mm_batch_s {
     void *ws = nullptr;
     size_t ws_bytes = 0;
     const int *last_redo = nullptr;  // redo marks of the last pdfposteriors call (inside ws; mm_batch_last_redo_count)
+    const double *last_z = nullptr;  // ... and the pair kernels' per-utterance normaliser statistics
 };
 
 // Launch geometry of the item kernels: NW waves per workgroup, NI register-resident items per wave
@@ -1346,6 +1347,18 @@ int mm_batch_last_redo_count(mm_batch_t h, void *stream, int64_t *n) {
     HIP_TRY(hipMemcpyAsync(marks.data(), h->last_redo, size_t(h->B) * sizeof(int), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
     HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     for (int m : marks) *n += m != 0;
+    if (h->dbg.verbose && h->last_z) {  // what mm_pair_finish_kernel decided on
+        std::vector<double> z(size_t(h->B) * 6);
+        HIP_TRY(hipMemcpy(z.data(), h->last_z, z.size() * 8, hipMemcpyDeviceToHost));
+        double sp = 0, lm = 0;
+        int worst_b = -1;
+        for (int64_t b = 0; b < h->B; ++b) {
+            const double zmin = std::min(z[6 * b], z[6 * b + 1]), zmax = std::max(z[6 * b + 2], z[6 * b + 3]);
+            if (zmax - zmin > sp) sp = zmax - zmin, worst_b = int(b);
+            lm = std::min(lm, std::min(z[6 * b + 4], z[6 * b + 5]));
+        }
+        fprintf(stderr, "[mm] per-frame log2 normalisers: largest spread %.3g (utterance %d), smallest overlap term %.3g\n", sp, worst_b, lm);
+    }
     return MM_OK;
 }
 
@@ -1403,12 +1416,17 @@ static size_t ws_x_bytes(mm_batch_t h) {
 }
 static size_t ws_tail_bytes(mm_batch_t h) {  // longest-first order, redo marks, pair hand-over, per-direction log Z minima, team buffers
     return 2 * align_up(size_t(h->B + 1) * 4, 256) + align_up(size_t(h->B + 1) * 2 * mm_pair_hand_bytes(), 256) +
-           align_up(size_t(h->B) * 4 * 8, 256) + ws_x_bytes(h);
+           align_up(size_t(h->B) * 6 * 8, 256) + ws_x_bytes(h);
 }
 
+// (quad kernels) the emissions shifted by their per-frame maxima [B][N][P], and the maxima [B][N]
+static size_t ws_shift_bytes(mm_batch_t h, int64_t N) {
+    if (!h->fast_ok) return 0;
+    return align_up(size_t(h->B) * size_t(N) * size_t(h->max_P1 - 1) * 4, 256) + align_up(size_t(h->B) * size_t(N) * 4, 256);
+}
 size_t mm_batch_workspace_bytes(mm_batch_t h, int64_t N) {
     if (!h || N < 0) return 0;
-    return ws_alpha_bytes(h, N) + ws_c_bytes(h, N) + ws_tail_bytes(h);
+    return ws_alpha_bytes(h, N) + ws_c_bytes(h, N) + ws_tail_bytes(h) + ws_shift_bytes(h, N);
 }
 
 
@@ -1424,6 +1442,8 @@ static int ensure_ws(mm_batch_t h, size_t bytes, void *stream = nullptr) {
         h->ws = nullptr;
         h->ws_bytes = 0;
         h->last_redo = nullptr;
+    h->last_z = nullptr;
+        h->last_z = nullptr;
     }
     HIP_TRY(hipMalloc(&h->ws, bytes));
     h->ws_bytes = bytes;
@@ -1457,6 +1477,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     if (rc) return rc;
     if (!gamma || !ttl) return fail(MM_ERR_INVALID, "mm_pdfposteriors_f32: gamma/ttl is NULL");
     h->last_redo = nullptr;
+    h->last_z = nullptr;
     // more utterances than CUs and different lengths: hand the workgroups out longest first; the pair kernels also
     // pair the utterances in that order (the two of a pair run the same number of frames)
     const bool ordered = lens && (h->B > h->n_cus || h->pairs_ok) && h->B <= 8192;
@@ -1511,13 +1532,14 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
                     p.sp_base[s] = si.base[s];
                     p.sp_cnt[s] = si.count[s];
                 }
-                p.xbuf = reinterpret_cast<float *>(reinterpret_cast<char *>(p.pair_zmin) + align_up(size_t(h->B) * 4 * 8, 256));
+                p.xbuf = reinterpret_cast<float *>(reinterpret_cast<char *>(p.pair_zmin) + align_up(size_t(h->B) * 6 * 8, 256));
                 p.xps = reinterpret_cast<float *>(reinterpret_cast<char *>(p.xbuf) + ws_x_rows_bytes(h));
                 p.x_slot = 2ll * h->split_s1p;
                 p.x_phase = (long long)(ws_x_rows_bytes(h) / 8);
                 p.x_sleep = h->dbg.x_sleep;
                 HIP_TRY(hipMemsetAsync(p.xbuf, 0, ws_x_bytes(h), static_cast<hipStream_t>(stream)));
             }
+            h->last_z = p.pair_zmin;
             rc = launch_pairs(h, p, stream);
         } else {
             rc = launch_rows(h, p, stream);
@@ -1526,8 +1548,29 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
         if (h->dbg.no_redo) return MM_OK;
     }
     if (quad_kernel_usable(h)) {
-        rc = launch_quad(h, p, stream);
-        if (rc != MM_ERR_UNSUPPORTED) return rc;
+        // the quad kernels run on emissions shifted by their per-frame maxima (see mm_shift_em_kernel)
+        bool same_P = true;
+        for (int64_t b = 1; b < h->B && same_P; ++b) same_P = h->fsms[b]->P1 == h->fsms[0]->P1;
+        RunParams q = p;
+        float *Vs = nullptr, *E = nullptr;
+        if (same_P) {
+            char *base = static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N) + ws_tail_bytes(h);
+            Vs = reinterpret_cast<float *>(base);
+            E = reinterpret_cast<float *>(base + align_up(size_t(h->B) * size_t(N) * size_t(h->max_P1 - 1) * 4, 256));
+            hipLaunchKernelGGL(mm_shift_em_kernel, dim3(unsigned(h->B), 8), dim3(256), 0, static_cast<hipStream_t>(stream), p, Vs, E);
+            HIP_TRY(hipGetLastError());
+            q.V = Vs;
+            q.vsb = N * int64_t(h->max_P1 - 1);
+            q.vsn = h->max_P1 - 1;
+        }
+        rc = launch_quad(h, q, stream);
+        if (rc != MM_ERR_UNSUPPORTED) {
+            if (!rc && same_P) {
+                hipLaunchKernelGGL(mm_shift_ttl_kernel, dim3(unsigned(h->B)), dim3(256), 0, static_cast<hipStream_t>(stream), p, E);
+                HIP_TRY(hipGetLastError());
+            }
+            return rc;
+        }
     }
     return launch_log<MODE_FB>(h, p, stream);
 }

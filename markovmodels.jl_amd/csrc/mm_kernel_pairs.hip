@@ -475,6 +475,11 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
     const RowU r = uni(H > 1 ? ud.rps[DIR][hset] : ud.rp[DIR]);
     const int S1 = r.rows, S1p = p.pair_s1p, P1 = uni(ud.P1), P = P1 - 1, P1p = (P1 + 3) & ~3;
     const float thr = r.thr;
+    // (Steering the frame maxima to 2^(thr - 20) instead of 2^0 -- to use the upper half of the float exponent range and keep
+    // states up to ~190 log2 below the maximum on the linear path -- was tried and dropped: v_log_f32 returns log2 of sums
+    // near 2^87 as floats 7.6e-6 apart, the per-frame normalisers of one utterance then scatter by 2e-4..7e-4 log2 instead of
+    // ~1e-5, and the sharp emissions it was meant for -- log-softmax of 10 N(0,1) -- need 160 log2 in the COMBINE, which no
+    // level gives: those inputs go to the exact kernels, mm_pair_finish_kernel.)
     // split: forward steps 1..m are phase A, backward steps 1..NFp-m
     int m = NFp / 2;
     m = m < 1 ? 1 : m;
@@ -569,6 +574,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         RowNorm norm[2];
         double cum[2] = {0.0, 0.0};
         double zmin[2] = {__builtin_inf(), __builtin_inf()}, zmax[2] = {-__builtin_inf(), -__builtin_inf()};
+        float ltmin[2] = {__builtin_inff(), __builtin_inff()};  // smallest log2 of a frame's sum of 2^(a~ + b~) (see mm_pair_finish_kernel)
         bool xdead = H > 1 && (p.x_sleep & 0x300) != 0;  // (split kernels) a poll of the team's partial sums timed out
         auto dma_raw = [&](int t) {  // raw emissions of step t (clamped) -> RAW(t & 3, u)
             const int tt = t < 1 ? 1 : (t > tEnd ? tEnd : t);
@@ -678,6 +684,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                     const double z = (double)lt[u] + own + oth;
                     zmin[u] = z < zmin[u] ? z : zmin[u];
                     zmax[u] = z > zmax[u] ? z : zmax[u];  // (NaN: neither comparison holds; the finish kernel tests zmin <= zmax)
+                    ltmin[u] = lt[u] < ltmin[u] ? lt[u] : ltmin[u];
                 }
         };
         auto step = [&](auto RDc, int t) {
@@ -746,8 +753,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     if (U[u].valid) {
-                        p.pair_zmin[(long long)U[u].b * 4 + DIR] = zmin[u];
-                        p.pair_zmin[(long long)U[u].b * 4 + 2 + DIR] = zmax[u];
+                        p.pair_zmin[(long long)U[u].b * 6 + DIR] = zmin[u];
+                        p.pair_zmin[(long long)U[u].b * 6 + 2 + DIR] = zmax[u];
+                        p.pair_zmin[(long long)U[u].b * 6 + 4 + DIR] = (double)ltmin[u];
                     }
             }
         }
@@ -976,8 +984,15 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
 // that decays against the rest of the graph (the initial contexts of the reference's WSJ denominator graph fall 2 log2 per
 // frame behind: 2^-1400 after 700 frames) -- and the result stands; otherwise (or if z is not finite) the mark stays and the
 // exact kernels compute the utterance again.  Marks of value 2 (a team of the split kernels did not run together) stay.
+// Second condition, for the parity bar on SMALL posteriors (log gamma within 1e-4 relative wherever gamma > 1e-30): a term
+// that dropped out of the linear path was below 2^-126 (times the few log2 the predicted normalisers are off by) of its
+// frame's scale, so the posterior it would have had is below 2^(-120 - L_n), L_n = log2 sum_s 2^(a~_n(s) + b~_n(s)) as the
+// kernels compute it (both factors on their own frame scale: L_n is far below 0 when the forward and the backward mass
+// sit on different states, as under a sharp acoustic model -- log-softmax of 10 N(0,1): -160).  With L_n >= MM_LT_FLOOR in
+// every frame nothing above 2^-100 < 1e-30 can have been lost.
 #ifndef MM_Z_SPREAD_TOL
-#define MM_Z_SPREAD_TOL 1e-4  // log2 units: 7e-5 nats on log Z (the parity bar on ttl is 1e-5 relative of O(10..1000) nats)
+#define MM_Z_SPREAD_TOL 2e-4  // log2 units (1.4e-4 nats on log Z); unmarked utterances of 1500 frames scatter by 2e-5..5e-5
+#define MM_LT_FLOOR (-20.0)
 #endif
 static __global__ void mm_pair_finish_kernel(RunParams p) {
     const int b = blockIdx.x;
@@ -985,12 +1000,14 @@ static __global__ void mm_pair_finish_kernel(RunParams p) {
     len = len < 0 ? 0 : (len > p.N ? p.N : len);
     const int P = p.utts[b].P1 - 1;
     if (threadIdx.x == 0) {
-        const double z0 = p.pair_zmin[4 * b], z1 = p.pair_zmin[4 * b + 1];
+        const double z0 = p.pair_zmin[6 * b], z1 = p.pair_zmin[6 * b + 1];
         const double z = z0 < z1 ? z0 : z1;
-        const double y0 = p.pair_zmin[4 * b + 2], y1 = p.pair_zmin[4 * b + 3];
+        const double y0 = p.pair_zmin[6 * b + 2], y1 = p.pair_zmin[6 * b + 3];
         const double zM = y0 > y1 ? y0 : y1;
+        const double l0 = p.pair_zmin[6 * b + 4], l1 = p.pair_zmin[6 * b + 5];
+        const double lm = l0 < l1 ? l0 : l1;
         p.ttl[b] = (z < __builtin_inf()) ? (float)(z * (double)MM_LN2) : MM_NINF;  // (no frame: no path of length 0)
-        if (p.redo[b] == 1 && z > -__builtin_inf() && zM < __builtin_inf() && zM - z <= MM_Z_SPREAD_TOL) p.redo[b] = 0;
+        if (p.redo[b] == 1 && z > -__builtin_inf() && zM < __builtin_inf() && zM - z <= MM_Z_SPREAD_TOL && lm >= MM_LT_FLOOR) p.redo[b] = 0;
     }
     const long long gbase = (long long)b * p.gsb;
     for (long long q = threadIdx.x; q < (long long)(p.N - len) * P; q += blockDim.x)

@@ -1059,6 +1059,47 @@ __global__ void mm_length_order_kernel(const int *lens, int B, int N, int *order
     order[rank] = i;
 }
 
+// Emission shift for the quad kernels (they normalise by a lagged state maximum only: log-likelihoods far from 0 -- GMM
+// scores around -300 nats -- push every row off their linear path and onto the exact per-row fallback, 30x slower).
+// Posteriors do not change when a frame's log-likelihoods are shifted by a constant, and log Z changes by the sum of the
+// shifts: Vs[b][n][:] = V[b][n][:] - E[b][n], E = the frame's maximum over the real pdfs (0 if none is finite), for the
+// utterances the quad kernels will compute (all, or the marked ones); mm_shift_ttl_kernel adds sum_n E back to ttl.
+__global__ void mm_shift_em_kernel(RunParams p, float *Vs, float *E) {
+    const int b = blockIdx.x;
+    if (p.redo && !p.redo[b]) return;
+    const int P = p.utts[b].P1 - 1;
+    int len = p.lens ? p.lens[b] : p.N;
+    len = len < 0 ? 0 : (len > p.N ? p.N : len);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+    for (int n = blockIdx.y * NW + wave; n < len; n += gridDim.y * NW) {  // one wave per frame
+        const float *row = p.V + (long long)b * p.vsb + (long long)n * p.vsn;
+        float m = MM_NINF;
+        for (int q = lane; q < P; q += 64) m = fmaxf(m, row[q]);
+        m = wave_max(m);
+        if (!(m > MM_NINF) || !(m < __builtin_inff())) m = 0.f;
+        float *out = Vs + ((long long)b * p.N + n) * P;
+        for (int q = lane; q < P; q += 64) out[q] = row[q] - m;
+        if (lane == 0) E[(long long)b * p.N + n] = m;
+    }
+}
+__global__ void mm_shift_ttl_kernel(RunParams p, const float *E) {
+    const int b = blockIdx.x;
+    if (p.redo && !p.redo[b]) return;
+    int len = p.lens ? p.lens[b] : p.N;
+    len = len < 0 ? 0 : (len > p.N ? p.N : len);
+    __shared__ double part[4];
+    double s = 0.0;
+    for (int n = threadIdx.x; n < len; n += blockDim.x) s += (double)E[(long long)b * p.N + n];
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (unsigned w = 0; w < blockDim.x / 64; ++w) t += part[w];  // (fixed order)
+        if (p.ttl[b] > MM_NINF) p.ttl[b] = (float)((double)p.ttl[b] + t);
+    }
+}
+
 #endif  // MM_SECONDARY_TU
 
 }  // namespace mm

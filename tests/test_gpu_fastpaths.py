@@ -1,0 +1,219 @@
+"""GPU tests of the fast (linear-domain) kernels ALONE and of the flag-and-redo machinery around them.
+
+The parity tests elsewhere compare the final result of a call; a fast kernel that is wrong but marks its
+utterances for the exact kernels would still pass them.  Here the exact kernels are switched off
+(MM_NO_REDO under MM_DEBUG: what the fast path computed is what is compared), the kernel that ran is
+asserted by name (BatchedFSM.kernels()), and the redo count is part of the contract."""
+import os
+
+import numpy as np
+import pytest
+
+import graphs
+from test_gpu_parity import _with_env, check_gamma
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    assert torch.cuda.is_available()
+    return torch
+
+
+def oracle64(oracle, g, V, lens):
+    o, oc = oracle
+    return oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V, lens, dtype=np.float64, nthreads=4)
+
+
+def run_fast_alone(mm, wl, g, V, lens, env=None):
+    """pdfposteriors with the exact kernels switched off; returns (gamma, ttl, kernels, redo count)."""
+    def run():
+        cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+        bf = mm.batch(*([cf] * V.shape[0]))
+        gam, ttl = bf.pdfposteriors(V, lens)
+        return gam, ttl, bf.kernels(), bf.last_redo_count()
+
+    return _with_env(dict(env or {}, MM_DEBUG="1", MM_NO_REDO="1"), run)
+
+
+def wsj_den(wl):
+    return wl.load_npz_graph(os.path.join(HERE, "golden", "den_fsm_wsj.npz"))
+
+
+@pytest.mark.parametrize("mode", ["auto", "write_through"])
+def test_split_kernels_on_the_reference_wsj_denominator(mm, wl, oracle, torch, mode):
+    """The reference's own benchmark graph (misc/benchmark/den_fsm_wsj.txt: 3032 states, 52 k arcs -- more than the
+    registers of one compute unit hold) runs on the split pair kernels: teams of two workgroups that exchange their
+    rows every step.  Odd batch, different lengths, an utterance of one frame; `write_through` forces the exchange
+    form for teams that do not share an XCD (sc1 granules), `auto` lets the workgroups find out."""
+    g = wsj_den(wl)
+    rng = np.random.default_rng(17)
+    B, N = 7, 70
+    V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+    lens = np.array([70, 70, 41, 70, 1, 33, 64], dtype=np.int32)
+    env = {"MM_SPLIT_SLEEP": str(8 | 0x800)} if mode == "write_through" else {}
+    gam, ttl, kernels, redo = run_fast_alone(mm, wl, g, V, lens, env)
+    assert "mm_fbs_kernel_dir" in kernels and "teams of 2" in kernels
+    assert redo == 0
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    ok = np.isfinite(t_ref)  # (the one-frame utterance has no accepting path: the reference's 0/0)
+    assert ok.sum() == B - 1 and (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()
+    check_gamma(gam[ok], g_ref[ok], lens[ok])
+    assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-4)
+
+
+def test_split_kernels_long_utterances_keep_their_range_marks_harmless(mm, wl, oracle, torch):
+    """On the WSJ graph the states of the initial contexts fall ~2 log2 per frame behind the rest: after ~55 frames they
+    leave the float range of the linear path and the kernels mark the utterance.  The per-frame normalisers agree
+    (nothing that matters was lost), so the marks are dropped: no utterance is computed twice, and the result is the
+    oracle's."""
+    g = wsj_den(wl)
+    rng = np.random.default_rng(3)
+    B, N = 4, 260
+    V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+    lens = np.array([260, 260, 199, 120], dtype=np.int32)
+    gam, ttl, kernels, redo = run_fast_alone(mm, wl, g, V, lens)
+    assert "mm_fbs_kernel_dir" in kernels and redo == 0
+    g_ref, t_ref = oracle64(oracle, g, V[:2], lens[:2])
+    check_gamma(gam[:2], g_ref, lens[:2])
+    assert np.allclose(ttl[:2], t_ref, rtol=1e-5, atol=1e-3)
+    # size-independent properties on all of them
+    for b, L in enumerate(lens):
+        assert np.allclose(gam[b, :L].sum(-1), 1.0, atol=1e-5) and (gam[b, L:] == 0).all()
+
+
+def test_range_marks_that_matter_are_redone(mm, wl, torch):
+    """A left-to-right graph forced onto the pair kernels (the engine would never pick them: depth rule): the values of
+    one frame span far more than the float range and the states that fall out of it carry the paths that reach the end.
+    The per-frame normalisers then disagree, the marks stay, and the exact kernels compute those utterances again:
+    the final result is the committed float64 oracle's, and the redo count says what happened."""
+    g = wl.load_npz_graph(os.path.join(HERE, "golden", "num_fsm_wsj.npz"))
+    z = np.load(os.path.join(HERE, "golden", "num_fsm_wsj_oracle.npz"))
+    V, lens = np.concatenate([z["V"], z["V"][:1]]), np.concatenate([z["lens"], z["lens"][:1]])
+
+    def run():
+        cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+        bf = mm.batch(*([cf] * V.shape[0]))
+        gam, ttl = bf.pdfposteriors(V, lens)
+        return gam, ttl, bf.kernels(), bf.last_redo_count()
+
+    gam, ttl, kernels, redo = _with_env({"MM_DEBUG": "1", "MM_KERNEL": "pair"}, run)
+    assert "mm_fbp_kernel_dir" in kernels
+    assert redo >= 1
+    ok = np.isfinite(z["ttl"])
+    check_gamma(gam[:3][ok], z["gamma"][ok].astype(np.float64), lens[:3][ok])
+    assert np.allclose(ttl[:3][ok], z["ttl"][ok], rtol=1e-5, atol=5e-4)
+    assert np.array_equal(gam[3], gam[0]) and ttl[3] == ttl[0]  # the same utterance twice: the same bits
+
+
+def test_redo_count_is_zero_on_the_benchmark_inputs_and_reported_on_peaky_ones(mm, wl, oracle, torch):
+    """Config 3's graph: N(0,1) log-likelihoods never leave the fast path (what bench.py measures is the fast path);
+    a sharp acoustic model (log-softmax of 10 N(0,1)) may: the count is reported, the result is
+    the oracle's either way."""
+    g = wl.lfmmi_denominator(2000, 84, seed=0)
+    rng = np.random.default_rng(23)
+    B, N = 6, 120
+    lens = np.array([120, 120, 87, 120, 45, 120], dtype=np.int32)
+    V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(*([cf] * B))
+    assert bf.last_redo_count() == 0  # before the first call
+    gam, ttl = bf.pdfposteriors(V, lens)
+    assert "mm_fbp_kernel_dir" in bf.kernels() and bf.last_redo_count() == 0
+    Vp = 10.0 * V
+    Vp = Vp - np.log(np.exp(Vp - Vp.max(-1, keepdims=True)).sum(-1, keepdims=True)) - Vp.max(-1, keepdims=True)
+    gam, ttl = bf.pdfposteriors(Vp.astype(np.float32), lens)
+    redo = bf.last_redo_count()
+    assert 0 <= redo <= B
+    g_ref, t_ref = oracle64(oracle, g, Vp.astype(np.float32), lens)
+    check_gamma(gam, g_ref, lens)
+    assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-2)
+    print(f"peaky emissions: {redo} of {B} utterances redone")
+
+
+@pytest.mark.parametrize("P", [130, 249])
+def test_pair_kernels_with_many_pdfs(mm, wl, oracle, torch, P):
+    """P + 1 in 129..250: the service wave of the pair kernels runs four 64-lane passes over the pdfs
+    (mm_fbp_kernel_dir<4, ...>), an instance no other test reaches."""
+    g = wl.lfmmi_denominator(1200, P - (P % 2), seed=4)
+    rng = np.random.default_rng(P)
+    B, N = 5, 40
+    V = (1.3 * rng.standard_normal((B, N, g.P))).astype(np.float32)
+    lens = np.array([40, 40, 23, 40, 9], dtype=np.int32)
+    gam, ttl, kernels, redo = run_fast_alone(mm, wl, g, V, lens)
+    assert "mm_fbp_kernel_dir<4" in kernels and redo == 0
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    check_gamma(gam, g_ref, lens)
+    assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("S,deg", [(300, 2.0), (900, 12.0), (1500, 16.0), (1900, 16.5)])
+def test_row_kernel_register_windows(mm, wl, oracle, torch, S, deg):
+    """Per-utterance graphs of different sizes land on the different register windows of the row kernels
+    (mm_fbr_kernel<24 | 40 | 42 | 44, ...>); the fast path alone against the oracle."""
+    o, oc = oracle
+    gs = [wl.random_fsm(S, 30, deg, seed=s, p_final=0.2) for s in (1, 2)]
+    rng = np.random.default_rng(S)
+    N = 30
+    V = rng.standard_normal((2, N, 30)).astype(np.float32)
+    lens = np.array([30, 17], dtype=np.int32)
+
+    def run():
+        cfs = [mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P)) for g in gs]
+        bf = mm.batch(*cfs)
+        gam, ttl = bf.pdfposteriors(V, lens)
+        return gam, ttl, bf.kernels(), bf.last_redo_count()
+
+    gam, ttl, kernels, redo = _with_env({"MM_DEBUG": "1", "MM_NO_REDO": "1"}, run)
+    assert "mm_fbr_kernel" in kernels and redo == 0, kernels
+    for b, g in enumerate(gs):
+        g_ref, t_ref = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V[b : b + 1], lens[b : b + 1], dtype=np.float64)
+        check_gamma(gam[b : b + 1], g_ref, lens[b : b + 1])
+        assert np.allclose(ttl[b], t_ref[0], rtol=1e-5, atol=1e-4)
+
+
+def test_odd_batch_beyond_the_compute_units_on_the_pair_kernels(mm, wl, oracle, torch):
+    """B = 515 utterances (odd, > 2 x 256 CUs) of different lengths on the pair kernels: pairing by length, the
+    unpaired last utterance, several workgroups per compute unit in turn."""
+    g = wl.lfmmi_denominator(400, 20, seed=9)
+    rng = np.random.default_rng(8)
+    B, N = 515, 14
+    V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+    lens = rng.integers(0, N + 1, size=B).astype(np.int32)
+    gam, ttl, kernels, redo = run_fast_alone(mm, wl, g, V, lens)
+    assert "mm_fbp_kernel_dir" in kernels and redo == 0
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    ok = np.isfinite(t_ref)
+    check_gamma(gam[ok], g_ref[ok], lens[ok])
+    assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-4)
+    assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()
+
+
+def test_batch_beyond_the_ordered_limit(mm, wl, oracle, torch):
+    """B = 8200 > 8192: the longest-first order is skipped (mm_engine.hip), the utterances run in batch order."""
+    g = wl.random_fsm(24, 4, 2.5, seed=3)
+    rng = np.random.default_rng(2)
+    B, N = 8200, 6
+    V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+    lens = rng.integers(1, N + 1, size=B).astype(np.int32)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    gam, ttl = mm.batch(*([cf] * B)).pdfposteriors(V, lens)
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    ok = np.isfinite(t_ref)
+    check_gamma(gam[ok], g_ref[ok], lens[ok])
+    assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-4)
+
+
+def test_fuzz_pairs_one_seed(mm, wl, oracle, torch):
+    """One seed of tools/fuzz_pairs.py: the pair and the row kernels against the item kernel (an independent
+    implementation) on 7 graphs x batch sizes x frame counts x length patterns, the degenerate ones included."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("fuzz_pairs", os.path.join(os.path.dirname(HERE), "tools", "fuzz_pairs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(1) == 0

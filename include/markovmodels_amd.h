@@ -231,6 +231,12 @@ int mm_debug_row_product_ex(mm_fsm_t fsm, int direction, int flags, const float 
  * cost of the most / least loaded wave, modelled LDS cycles per gather before / after the bank-aware placement}. */
 int mm_debug_split_product(mm_fsm_t fsm, int H, int direction, const float *in, float *out, double stats[8]);
 
+/* Test aid (host only, no GPU): the product evaluated THROUGH THE WAVE FORM of the wave kernel (one wave per direction:
+ * segments of 64 / g rows, at most 4 arcs per lane and segment, log2 weights, lane-group log-sum-exp).  stats (may be
+ * NULL) receives {arc slots per lane, segments, real arcs / arc slots, modelled LDS cycles per gather}.
+ * MM_ERR_UNSUPPORTED if the FSM does not fit the form (more than 16 segments). */
+int mm_debug_wave_product(mm_fsm_t fsm, int direction, const float *in, float *out, double stats[4]);
+
 /* Test aid (host only, no GPU): the static bound the fast kernels use to recognise dead rows without a walk --
  * the fewest arcs from an initial state to every state (direction 0) or from every state to the phony final
  * state (direction 1), on the pruned graph; -1 = unreachable (such states are dropped).  out: host int32[S1].

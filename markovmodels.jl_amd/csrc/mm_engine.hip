@@ -137,6 +137,8 @@ struct mm_fsm_s {
     RowVariant *srows[2][MM_SPLIT_HMAX] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
     SplitInfo split;
     bool split_tried = false;
+    RowVariant *wrows[2] = {nullptr, nullptr};  // wave forms (mm_kernel_wave.hip)
+    bool wave_tried = false;
     std::vector<float> init;  // dense alpha_hat, engine domain
     std::vector<int32_t> s2p;
     int device = -1;
@@ -153,7 +155,7 @@ struct mm_fsm_s {
 // MM_KQ / MM_NWAVES / MM_NITEMS force a geometry, MM_NO_XCSR keeps the exact-fallback CSR out of LDS,
 // MM_VERBOSE prints the packing statistics.
 struct DebugOpts {
-    enum { K_AUTO = 0, K_ITEM, K_QUAD, K_ROW, K_PAIR };
+    enum { K_AUTO = 0, K_ITEM, K_QUAD, K_ROW, K_PAIR, K_WAVE };
     int kernel = K_AUTO;
     int kq = 0, nwaves = 0, nitems = -1;
     bool no_xcsr = false, verbose = false;
@@ -169,7 +171,7 @@ static DebugOpts read_debug_opts() {
     if (!on || !*on || !strcmp(on, "0")) return d;
     if (const char *e = getenv("MM_KERNEL"))
         d.kernel = !strcmp(e, "item") ? DebugOpts::K_ITEM : !strcmp(e, "quad") ? DebugOpts::K_QUAD
-                 : !strcmp(e, "row") ? DebugOpts::K_ROW : !strcmp(e, "pair") ? DebugOpts::K_PAIR : DebugOpts::K_AUTO;
+                 : !strcmp(e, "row") ? DebugOpts::K_ROW : !strcmp(e, "pair") ? DebugOpts::K_PAIR : !strcmp(e, "wave") ? DebugOpts::K_WAVE : DebugOpts::K_AUTO;
     if (const char *e = getenv("MM_KQ")) d.kq = atoi(e);
     if (const char *e = getenv("MM_NWAVES")) d.nwaves = atoi(e);
     if (const char *e = getenv("MM_NITEMS")) d.nitems = atoi(e);
@@ -201,6 +203,8 @@ struct mm_batch_s {
     int row_ka[2] = {0, 0}, row_nwc[2] = {1, 1}, row_slotrows[2] = {0, 0};
     bool pairs_ok = false;                       // one FSM shared by all utterances, in pair form: the pair kernels can run
     int pair_ka = 0, pair_nwc = 1, pair_slotrows = 0;
+    bool wave_ok = false;  // every FSM has its wave forms: the wave kernel can run (small graphs that are off the linear paths)
+    int wave_nseg = 0;
     int pair_H = 1;        // workgroups per team: 1 = the pair kernels proper, > 1 = the split pair kernels
     int split_s1p = 0;     // floats / 2 of a stored vector of the split kernels (positions of the team's vector, padded)
     // the forward and the backward agents of the pair kernels run side by side on two streams of the library (a
@@ -701,11 +705,13 @@ static int quad_variant(mm_fsm_t f, int dir, int KQ, bool verbose, QuadVariant *
     return MM_OK;
 }
 
-static int upload_row_variant(mm_fsm_t f, RowVariant *v, int dir, float thr) {
+static int upload_row_variant(mm_fsm_t f, RowVariant *v, int dir, float thr, bool pad = true) {
     Blob bl;
     // (zero rows up to MM_ROW_KA_PAD arc slots: the kernels load their whole register window unconditionally)
-    v->g.w.resize(size_t(MM_ROW_KA_PAD) * 64 * v->g.NWC, 0.f);
-    v->g.addr.resize(size_t(MM_ROW_KA_PAD) * 64 * v->g.NWC, 0u);
+    if (pad) {
+        v->g.w.resize(size_t(MM_ROW_KA_PAD) * 64 * v->g.NWC, 0.f);
+        v->g.addr.resize(size_t(MM_ROW_KA_PAD) * 64 * v->g.NWC, 0u);
+    }
     const size_t o_w = bl.add(v->g.w), o_a = bl.add(v->g.addr), o_s = bl.add(v->g.slots), o_sc = bl.add(v->g.sched);
     const size_t o_ptr = bl.add(v->g.rowptr), o_col = bl.add(v->g.col), o_cw = bl.add(v->g.cw);
     const size_t o_pdf = bl.add(v->g.rowpdf), o_pse = bl.add(v->g.pdfse), o_init = bl.add(v->init);
@@ -797,6 +803,53 @@ static int pair_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
     }
     f->prows[0] = rv[0];
     f->prows[1] = rv[1];
+    *ok = true;
+    return MM_OK;
+}
+
+// the wave forms of an FSM (built once; *ok = false if it does not fit them: more than 16 segments of 64 rows, ...)
+static int wave_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
+    *ok = f->wrows[0] && f->wrows[1];
+    if (*ok || f->wave_tried) return MM_OK;
+    f->wave_tried = true;
+    if (f->semiring != MM_LOG || f->P1 > 256 || f->qmat[0].rowptr.empty()) return MM_OK;
+    RowPackOpts opt;
+    opt.rs = MM_WAVE_RS;
+    opt.nwc_max = MM_WAVE_WAVES;
+    opt.ka_max = 16;  // (4 segments of 4 slots per wave)
+    opt.copies = 1;
+    opt.acap_force = 4;
+    opt.seg_stride = 4;
+    opt.log_weights = true;
+    opt.want_partner = true;
+    opt.spread_pdf = true;
+    opt.finish_cost = 4;
+    for (float &x : opt.group_speed) x = 1.f;
+    RowVariant *rv[2] = {new RowVariant(), new RowVariant()};
+    const std::vector<int32_t> none;
+    bool fits = make_rows(f->S1, f->qmat[0].rowptr, f->qmat[0].col, f->qmat[0].val, f->s2p, f->P1, false, none, opt, rv[0]->g) &&
+                make_rows(f->S1, f->qmat[1].rowptr, f->qmat[1].col, f->qmat[1].val, f->s2p, f->P1, true, rv[0]->g.pos, opt, rv[1]->g);
+    int rc = MM_OK;
+    if (fits) {
+        set_partner(rv[0]->g, rv[1]->g.pos);
+        rv[0]->init.resize(size_t(f->S1));
+        for (int64_t i = 0; i < f->S1; ++i) rv[0]->init[i] = f->init[rv[0]->g.order[i]];
+        for (int d = 0; d < 2 && !rc; ++d) {
+            if (dbg.verbose)
+                fprintf(stderr, "[mm] wave form dir %d: %d segments, arcs/slots %.3f, LDS cycles/gather (bank model) %.2f -> %.2f\n", d,
+                        rv[d]->g.nslotrows - 2, rv[d]->g.pad_eff, rv[d]->g.conflict_before, rv[d]->g.conflict_after);
+            rc = upload_row_variant(f, rv[d], d, 0.f, false);
+        }
+    }
+    if (!fits || rc) {
+        for (RowVariant *x : rv) {
+            if (x->blob) (void)hipFree(x->blob);
+            delete x;
+        }
+        return rc;
+    }
+    f->wrows[0] = rv[0];
+    f->wrows[1] = rv[1];
     *ok = true;
     return MM_OK;
 }
@@ -923,7 +976,7 @@ int mm_fsm_destroy(mm_fsm_t f) {
         if (kv.second->blob) (void)hipFree(kv.second->blob);
         delete kv.second;
     }
-    for (RowVariant *rv : {f->rows[0], f->rows[1], f->prows[0], f->prows[1], f->srows[0][0], f->srows[0][1], f->srows[0][2], f->srows[0][3],
+    for (RowVariant *rv : {f->rows[0], f->rows[1], f->prows[0], f->prows[1], f->wrows[0], f->wrows[1], f->srows[0][0], f->srows[0][1], f->srows[0][2], f->srows[0][3],
                            f->srows[1][0], f->srows[1][1], f->srows[1][2], f->srows[1][3]})
         if (rv) {
             if (rv->blob) (void)hipFree(rv->blob);
@@ -1071,6 +1124,41 @@ int mm_debug_row_product_ex(mm_fsm_t f, int direction, int flags, const float *i
         stats[5] = g.mincost;
         stats[6] = g.conflict_before;
         stats[7] = g.conflict_after;
+    }
+    return MM_OK;
+}
+
+int mm_debug_wave_product(mm_fsm_t f, int direction, const float *in, float *out, double stats[4]) {
+    if (!f || !in || !out || direction < 0 || direction > 1) return fail(MM_ERR_INVALID, "mm_debug_wave_product: bad argument");
+    if (f->semiring != MM_LOG) return fail(MM_ERR_INVALID, "mm_debug_wave_product: log-semiring FSMs only");
+    RowPackOpts opt;
+    opt.rs = MM_WAVE_RS;
+    opt.nwc_max = MM_WAVE_WAVES;
+    opt.ka_max = 16;
+    opt.finish_cost = 4;
+    opt.copies = 1;
+    opt.acap_force = 4;
+    opt.seg_stride = 4;
+    opt.log_weights = true;
+    opt.want_partner = true;
+    opt.spread_pdf = true;
+    for (float &x : opt.group_speed) x = 1.f;
+    RowGraph gf, g;
+    const std::vector<int32_t> none;
+    if (!make_rows(f->S1, f->mat[0].rowptr, f->mat[0].col, f->mat[0].val, f->s2p, f->P1, false, none, opt, gf) ||
+        (direction == 1 && !make_rows(f->S1, f->mat[1].rowptr, f->mat[1].col, f->mat[1].val, f->s2p, f->P1, true, gf.pos, opt, g)))
+        return fail(MM_ERR_UNSUPPORTED, "mm_debug_wave_product: the FSM does not fit the wave form");
+    if (direction == 0) g = gf;
+    const float NINF = -std::numeric_limits<float>::infinity();
+    std::vector<float> x(size_t(f->S1) + 1, NINF), y(size_t(f->S1) + 1, NINF);
+    for (int64_t i = 0; i < f->S1; ++i) x[size_t(i)] = in[g.order[size_t(i)]] * MM_LOG2E;
+    eval_rows_log(g, 4, x.data(), y.data());
+    for (int64_t i = 0; i < f->S1; ++i) out[g.order[size_t(i)]] = y[size_t(i)] * MM_LN2;
+    if (stats) {
+        stats[0] = g.KA;
+        stats[1] = g.nslotrows - 2;
+        stats[2] = g.pad_eff;
+        stats[3] = g.conflict_after;
     }
     return MM_OK;
 }
@@ -1227,6 +1315,23 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             }
         }
     }
+    // wave kernel: small graphs that none of the linear-domain kernels takes (deep left-to-right graphs: numerators)
+    if (h->semiring == MM_LOG && !h->rows_ok && !h->pairs_ok &&
+        (h->dbg.kernel == DebugOpts::K_WAVE ||
+         (h->dbg.kernel == DebugOpts::K_AUTO && (!h->fast_ok || (h->max_depth >= 64 && h->geo_kq[0] <= 3 && h->geo_kq[1] <= 3))))) {
+        // (= where the item kernel would run: quad_kernel_usable() says no for these; see there)
+        h->wave_ok = true;
+        for (int64_t b = 0; b < B && h->wave_ok; ++b) {
+            bool ok = false;
+            int rc = wave_variants(fsms[b], h->dbg, &ok);
+            if (rc) {
+                delete h;
+                return rc;
+            }
+            h->wave_ok = ok;
+            if (ok) h->wave_nseg = std::max(h->wave_nseg, std::max(fsms[b]->wrows[0]->g.KA, fsms[b]->wrows[1]->g.KA) / 4);
+        }
+    }
     for (int64_t b = 0; b < B; ++b) {
         mm_fsm_t f = fsms[b];
         int rc = fsm_to_device(f);
@@ -1246,6 +1351,8 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             u.init_f = qv[0]->d_init_f;
             u.map_bf = qv[1]->d_map_bf;
         }
+        if (h->wave_ok)
+            for (int d = 0; d < 2; ++d) u.rw[d] = f->wrows[d]->rdev;
         if (h->pairs_ok && h->pair_H == 1)
             for (int d = 0; d < 2; ++d) u.rp[d] = f->prows[d]->rdev;
         if (h->pairs_ok && h->pair_H > 1)
@@ -1370,7 +1477,9 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
         const std::string exact = quad ? "mm_fbq_kernel<" + std::to_string(h->geo_kq[0]) + ",*,0> + mm_fbq_kernel<" +
                                              std::to_string(h->geo_kq[1]) + ",*,1>"
                                        : std::string("mm_log_kernel<MODE_FB> (forward, backward)");
-        if (h->pairs_ok && h->pair_H > 1) {
+        if (h->wave_ok) {
+            s = "mm_wave_kernel<" + std::to_string(h->wave_nseg <= 2 ? 2 : 4) + "," + std::to_string(h->max_P1 <= 128 ? 2 : 4) + ">";
+        } else if (h->pairs_ok && h->pair_H > 1) {
             const std::string k = std::to_string(h->max_P1 <= 128 ? 2 : 4);
             s = "mm_fbs_kernel_dir<" + k + ",A,fwd> || <" + k + ",A,bwd>, then <" + k + ",B,fwd> || <" + k +
                 ",B,bwd> (teams of " + std::to_string(h->pair_H) + " workgroups), mm_pair_finish_kernel, then for marked utterances only " + exact +
@@ -1513,6 +1622,15 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     }
     p.dbg = g_dbg;
 #endif
+    if (h->wave_ok) {
+        char *tail = static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N);
+        p.pair_zmin = reinterpret_cast<double *>(tail + 2 * align_up(size_t(h->B + 1) * 4, 256) + align_up(size_t(h->B + 1) * 2 * mm_pair_hand_bytes(), 256));
+        WaveLaunch wlc;
+        wlc.B = h->B;
+        wlc.nseg = h->wave_nseg;
+        wlc.max_P1 = h->max_P1;
+        return mm_launch_wave(wlc, p, static_cast<hipStream_t>(stream));
+    }
     if (h->rows_ok || h->pairs_ok) {
         // the pair or row kernels, then -- for the utterances they marked (linear sums outside the trusted range),
         // normally none: every workgroup then leaves at once -- the exact kernels

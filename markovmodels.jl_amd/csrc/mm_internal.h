@@ -48,6 +48,15 @@ int mm_launch_split(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
 size_t mm_split_lds_bytes(int phase, int nslotrows);
 
 
+// ---- wave kernel (mm_wave_tu.hip)
+#define MM_WAVE_RS 4352  // LDS bytes of one state vector of the wave kernel
+#define MM_WAVE_WAVES 4  // waves per agent (direction) of the wave kernel
+struct WaveLaunch {
+    int64_t B = 0;
+    int nseg = 0, max_P1 = 0;
+};
+int mm_launch_wave(const WaveLaunch &wl, const RunParams &p, hipStream_t stream);
+
 // ---- quad kernels (mm_quad_tu.hip)
 struct QuadLaunch {
     int64_t B = 0;

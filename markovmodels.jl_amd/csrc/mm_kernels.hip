@@ -80,6 +80,7 @@ struct UttDesc {
     QuadDev q[2];   // same two matrices in quad form (log semiring only)
     RowDev r[2];    // ... and in row-lane form (log semiring only; KA == 0: not available)
     RowDev rp[2];   // ... and in the pair variant of the row-lane form (mm_rows.h RowPackOpts::pair)
+    RowDev rw[2];   // ... and in the wave form (mm_kernel_wave.hip: one wave per direction, log domain)
     RowDev rps[2][MM_SPLIT_HMAX];  // ... and the split pair forms [direction][set] (mm_rows.h make_rows_split): rowpdf / init /
                                    // rows / fpos refer to the TEAM's vector (all sets; rowpdf 0xffff = alignment padding)
     const float *init_f;            // alpha_hat in forward numbering

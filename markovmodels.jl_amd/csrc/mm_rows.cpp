@@ -90,7 +90,8 @@ struct Plan {
     bool ok = false;
 };
 
-Plan plan_for(const std::vector<int32_t> &rows, const std::vector<int64_t> &rowptr, int acap, const RowPackOpts &opt) {
+Plan plan_for(const std::vector<int32_t> &rows, const std::vector<int64_t> &rowptr, int acap, const RowPackOpts &opt,
+              const std::vector<int32_t> *row2pdf = nullptr) {
     Plan p;
     std::vector<Unit> units;
     units.reserve(rows.size());
@@ -109,6 +110,31 @@ Plan plan_for(const std::vector<int32_t> &rows, const std::vector<int64_t> &rowp
         if (us.empty()) continue;
         std::stable_sort(us.begin(), us.end(), [](const Unit &a, const Unit &b) { return a.A > b.A; });
         const size_t per = size_t(64 / g);
+        if (opt.spread_pdf && row2pdf) {
+            // rows of one pdf go to DIFFERENT segments where the class has several of the same length: the wave kernel adds
+            // the posteriors of a segment's rows to their pdfs with one LDS float add, and lanes that hit the same pdf are
+            // served one after the other
+            for (size_t i0 = 0; i0 < us.size();) {
+                size_t i1 = i0;
+                while (i1 < us.size() && us[i1].A == us[i0].A) ++i1;
+                const size_t n = i1 - i0, nseg = (n + per - 1) / per;
+                if (nseg > 1) {
+                    std::vector<Unit> run(us.begin() + i0, us.begin() + i1), out(n);
+                    std::stable_sort(run.begin(), run.end(), [&](const Unit &a, const Unit &b) { return (*row2pdf)[a.row] < (*row2pdf)[b.row]; });
+                    // deal the pdf-sorted rows round robin over the segments of the run (the last segment may be shorter)
+                    std::vector<size_t> fill(nseg, 0), cap(nseg, per);
+                    cap[nseg - 1] = n - per * (nseg - 1);
+                    size_t sgm = 0;
+                    for (size_t j = 0; j < n; ++j) {
+                        while (fill[sgm] >= cap[sgm]) sgm = (sgm + 1) % nseg;
+                        out[sgm * per + fill[sgm]++] = run[j];
+                        sgm = (sgm + 1) % nseg;
+                    }
+                    std::copy(out.begin(), out.end(), us.begin() + i0);
+                }
+                i0 = i1;
+            }
+        }
         for (size_t i = 0; i < us.size(); i += per) {
             Segment s;
             s.g = g;
@@ -174,15 +200,21 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     // ---- schedule: the cap on arcs per lane of one row decides how many rows are split over lane groups; take
     // the cap whose most loaded wave is cheapest
     Plan best;
-    for (int acap : {12, 16, 24, 32, 48, 64}) {
-        if (acap > opt.ka_max) continue;
-        Plan p = plan_for(myrows, rowptr, acap, opt);
+    for (int acap : {4, 12, 16, 24, 32, 48, 64}) {
+        if (opt.acap_force ? acap != opt.acap_force : (acap == 4 || acap > opt.ka_max)) continue;
+        Plan p = plan_for(myrows, rowptr, acap, opt, &row2pdf);
         if (!p.ok) continue;
         if (!best.ok || p.maxcost < best.maxcost || (p.maxcost == best.maxcost && p.KA < best.KA)) best = std::move(p);
     }
     if (!best.ok) return false;
     const int NWC = int(best.wave_segs.size());
     int KA = std::max(2, (best.KA + 1) & ~1);
+    if (opt.seg_stride) {
+        size_t most = 0;
+        for (auto &ws : best.wave_segs) most = std::max(most, ws.size());
+        KA = opt.seg_stride * int(most);
+        if (KA > opt.ka_max) return false;
+    }
     for (int c : opt.ka_choices)
         if (c >= KA) {
             KA = c;
@@ -196,11 +228,11 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     g.pos_base = opt.pos_base;
     g.nrows = int(nsub);
     g.qtrash = int(nsub);
-    g.slot_words = (backward || opt.pair) ? 2 : 1;
+    g.slot_words = (backward || opt.pair || opt.want_partner) ? 2 : 1;
     g.scale = opt.pair ? 8 : 4;
     g.ncopy = opt.copies ? opt.copies : (opt.pair ? 1 : 2);
     const uint32_t SC = uint32_t(g.scale);
-    const bool want_q = backward || opt.pair;  // pdf-major positions
+    const bool want_q = backward || opt.pair || opt.want_partner;  // pdf-major positions
     g.maxcost = best.maxcost;
     g.mincost = best.mincost;
     // ---- numbering: the order in which the rows are finished
@@ -295,7 +327,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     for (int w = 0; w < NWC; ++w) nslots += int(best.wave_segs[w].size());
     g.nslotrows = nslots + 2;  // + two padding rows: the prefetch after a wave's last finishes reads up to two rows ahead
     g.slots.assign(size_t(g.nslotrows) * 64 * g.slot_words, 0);
-    g.w.assign(size_t(KA) * NT, 0.f);
+    g.w.assign(size_t(KA) * NT, opt.log_weights ? -std::numeric_limits<float>::infinity() : 0.f);
     g.addr.assign(size_t(KA) * NT, 0u);
     // model addresses (4 bytes per position): copy cp of position c, and back
     const uint32_t copy1 = uint32_t(opt.copy_perm ? opt.rs : opt.rs + 64);
@@ -327,6 +359,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
         for (int si : best.wave_segs[w]) {
             const Segment &s = best.segs[si];
             const int lg = log2i(s.g);
+            if (opt.seg_stride) k0 = opt.seg_stride * sidx;
             sc.lg |= uint64_t(lg) << (4 * sidx);
             sc.endmask |= uint64_t(1) << ((k0 + s.A) / 2 - 1);
             // slot table row
@@ -386,16 +419,17 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                         if (bi >= 0) {
                             used[bi] = 1;
                             ad[l][k] = baddr;
-                            wt[l][k] = std::exp2(g.cw[la[l].arcs[bi]]);
+                            wt[l][k] = opt.log_weights ? g.cw[la[l].arcs[bi]] : std::exp2(g.cw[la[l].arcs[bi]]);
                             ++real_arcs;
                         } else {  // padding: weight 0, an address that costs nothing
                             const int bnk = tab[k].least_loaded();
                             ad[l][k] = uint32_t(4 * (bnk < ntot ? bnk : 0));
-                            wt[l][k] = 0.f;
+                            wt[l][k] = opt.log_weights ? -std::numeric_limits<float>::infinity() : 0.f;
                         }
                         tab[k].add(ad[l][k]);
                     }
                 }
+                auto real = [&](float w) { return opt.log_weights ? w > -std::numeric_limits<float>::infinity() : w != 0.f; };
                 // local search on the sum of squared bank loads: flip the copy of a conflicting slot, or swap it with another
                 // slot of the lane (in either copy)
                 for (int pass = 0; pass < 12; ++pass) {
@@ -404,7 +438,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                         for (int k = 0; k < s.A; ++k) {
                             uint32_t a = ad[l][k];
                             if (!tab[k].conflicted(a)) continue;
-                            if (wt[l][k] != 0.f && ncopy > 1) {
+                            if (real(wt[l][k]) && ncopy > 1) {
                                 const uint32_t alt = other(a);
                                 const int before = tab[k].sq();
                                 tab[k].remove(a);
@@ -432,8 +466,8 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                                 // the best of the copies of each arc in its new slot
                                 uint32_t na = a, nb = b;
                                 int best = 1 << 30;
-                                for (uint32_t ca = 0; ca < (wt[l][k] != 0.f ? ncopy : 1u); ++ca)
-                                    for (uint32_t cb = 0; cb < (wt[l2][k2] != 0.f ? ncopy : 1u); ++cb) {
+                                for (uint32_t ca = 0; ca < (real(wt[l][k]) ? ncopy : 1u); ++ca)
+                                    for (uint32_t cb = 0; cb < (real(wt[l2][k2]) ? ncopy : 1u); ++cb) {
                                         const uint32_t xa = ca ? other(a) : a, xb = cb ? other(b) : b;
                                         tab[k].add(xb);
                                         tab[k2].add(xa);
@@ -585,6 +619,38 @@ void set_partner(RowGraph &g, const std::vector<int32_t> &partner_pos) {
         const uint32_t p = (g.slots[e] & 0xffffu) / SC;
         if (int(p) == g.trash) continue;
         g.slots[e + 1] = (g.slots[e + 1] & 0xffff0000u) | uint32_t(SC * partner_pos[g.order[p - uint32_t(g.pos_base)]]);
+    }
+}
+
+void eval_rows_log(const RowGraph &g, int seg_stride, const float *in_log2, float *out_log2) {
+    const int NT = 64 * g.NWC;
+    for (int w = 0; w < g.NWC; ++w) {
+        const RowSched &sc = g.sched[w];
+        const int nseg = int(sc.nslots & 0xffffu);
+        for (int i = 0; i < nseg; ++i) {
+            const int A = ((sc.endmask >> (seg_stride * i / 2 + 1)) & 1) ? 4 : 2;
+            const int lg = int((sc.lg >> (4 * i)) & 15), gsz = 1 << lg;
+            double m[64], sum[64];
+            for (int l = 0; l < 64; ++l) {  // the lane's (max, scaled sum) over its <= 4 arcs
+                double x[4], mx = -std::numeric_limits<double>::infinity();
+                for (int k = 0; k < A; ++k) {
+                    const size_t e = size_t(seg_stride * i + k) * NT + size_t(w) * 64 + l;
+                    x[k] = double(g.w[e]) + double(in_log2[g.addr[e] / uint32_t(g.scale)]);
+                    mx = std::max(mx, x[k]);
+                }
+                m[l] = mx;
+                sum[l] = 0;
+                for (int k = 0; k < A; ++k) sum[l] += mx > -std::numeric_limits<double>::infinity() ? std::exp2(x[k] - mx) : 0.0;
+            }
+            for (int l0 = 0; l0 < 64; l0 += gsz) {
+                double M = -std::numeric_limits<double>::infinity(), S = 0;
+                for (int l = l0; l < l0 + gsz; ++l) M = std::max(M, m[l]);
+                for (int l = l0; l < l0 + gsz; ++l) S += M > -std::numeric_limits<double>::infinity() ? sum[l] * std::exp2(m[l] - M) : 0.0;
+                const uint32_t info = g.slots[(size_t(sc.slot0 + i) * 64 + l0 + gsz - 1) * g.slot_words];
+                const int p = int(info & 0xffffu) / g.scale;
+                if (p != g.trash) out_log2[p] = float(M + std::log2(S));
+            }
+        }
     }
 }
 

@@ -113,6 +113,16 @@ struct RowPackOpts {
     int pos_base = 0;
     int gtrash = -1;
     bool plan_only = false;  // stop after the numbering (order / pos): the first pass of make_rows_split
+    // Wave form (mm_kernel_wave.hip: ONE wave computes a whole direction of an utterance in the log domain): at most
+    // `acap_force` arcs per lane and row (longer rows get lane groups), every segment owns `seg_stride` arc slots of the
+    // lane (segment i at slots seg_stride * i ..: statically unrolled code), the weights are kept as log2 values
+    // (padding: -inf) and word 1 of the slot table (other direction's position | pdf-major position) exists in both
+    // directions.
+    int acap_force = 0;
+    int seg_stride = 0;
+    bool log_weights = false;
+    bool want_partner = false;
+    bool spread_pdf = false;  // rows of one pdf go to different segments where possible (fewer LDS add conflicts)
 };
 
 // rowptr/col/val_log2: 0-based CSR of M (out[r] = (+)_k val[k] (*) in[col[k]]), square, nrows rows.
@@ -150,5 +160,9 @@ void set_partner(RowGraph &g, const std::vector<int32_t> &partner_pos);
 // Host evaluation of one product through the row form exactly as a workgroup walks it (lane by lane, segment
 // by segment, group sums), in the linear domain: in_lin[position] -> out_lin[position].  Test aid.
 void eval_rows(const RowGraph &g, const float *in_lin, float *out_lin);
+
+// The same for the wave form (log2 weights, segments of seg_stride slots, <= 4 arcs per lane and segment, lane-group
+// log-sum-exp): in_log2[position] -> out_log2[position].
+void eval_rows_log(const RowGraph &g, int seg_stride, const float *in_log2, float *out_log2);
 
 }  // namespace mm

@@ -111,6 +111,25 @@ class CompiledFSM:
         check(lib.mm_debug_row_product_ex(self._h, direction, flags, x.ctypes.data, out.ctypes.data, stats.ctypes.data))
         return out, stats
 
+    def split_product(self, x: np.ndarray, direction: int = 0, H: int = 2):
+        """Host evaluation of the product through the split pair forms (teams of H workgroups; test aid).  Returns
+        (out, stats = [KA, positions of the team's vector, segments, arcs / arc slots, max / min wave cost, LDS
+        cycles/gather naive, after placement])."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty(self.S1, dtype=np.float32)
+        stats = np.zeros(8, dtype=np.float64)
+        check(lib.mm_debug_split_product(self._h, int(H), direction, x.ctypes.data, out.ctypes.data, stats.ctypes.data))
+        return out, stats
+
+    def wave_product(self, x: np.ndarray, direction: int = 0):
+        """Host evaluation of the product through the wave form (one wave per direction, log domain; test aid).
+        Returns (out, stats = [arc slots per lane, segments, arcs / arc slots, LDS cycles/gather])."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty(self.S1, dtype=np.float32)
+        stats = np.zeros(4, dtype=np.float64)
+        check(lib.mm_debug_wave_product(self._h, direction, x.ctypes.data, out.ctypes.data, stats.ctypes.data))
+        return out, stats
+
 
 def compile(fsm: FSM, C_hat) -> CompiledFSM:  # noqa: A001 - the reference's name
     """compile(fsm, C_hat) (src/inference.jl:11-12)."""

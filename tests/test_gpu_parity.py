@@ -257,7 +257,7 @@ def _with_env(env, fn):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("kernel", ["quad", "row", "item"])
+@pytest.mark.parametrize("kernel", ["quad", "row", "item", "wave"])
 def test_wsj_numerator_forced_kernels(mm, wl, torch, kernel):
     """The reference's numerator graph (left-to-right, depth 165: the values of one frame span far more
     than the float range) forced through each pdfposteriors kernel: on the linear-domain kernels most rows
@@ -504,7 +504,7 @@ def test_deterministic_mode_of_the_item_kernel(mm, wl, torch):
     g = wl.load_npz_graph(os.path.join(os.path.dirname(__file__), "golden", "num_fsm_wsj.npz"))
     cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
     V, lens = torch.from_numpy(z["V"]).cuda(), torch.from_numpy(z["lens"]).cuda()
-    bf = mm.batch(*([cf] * V.shape[0])).set_deterministic(True)
+    bf = _with_env({"MM_DEBUG": "1", "MM_KERNEL": "item"}, lambda: mm.batch(*([cf] * V.shape[0]))).set_deterministic(True)
     assert "mm_log_kernel" in bf.kernels("log")
     runs = [bf.pdfposteriors(V, lens) for _ in range(4)]
     torch.cuda.synchronize()
@@ -514,3 +514,35 @@ def test_deterministic_mode_of_the_item_kernel(mm, wl, torch):
     gam = runs[0][0].cpu().numpy()
     check_gamma(gam[ok], z["gamma"][ok].astype(np.float64), z["lens"][ok])
     assert (gam[~ok] == 0).all()
+
+
+@pytest.mark.gpu
+def test_wave_kernel_is_the_numerator_path_and_deterministic(mm, wl, oracle, torch):
+    """Small deep graphs (LF-MMI numerators, examples/test_cuda.jl:78) run on the wave kernel by default: different
+    graphs per utterance, different lengths, identical bits on every run (its per-pdf sums have a fixed order), the
+    oracle's posteriors."""
+    o, oc = oracle
+    here = os.path.dirname(os.path.abspath(__file__))
+    g0 = wl.load_npz_graph(os.path.join(here, "golden", "num_fsm_wsj.npz"))
+    gs = [g0, wl.lexicon_fsm(300, 20, seed=2, hubs=1), g0, wl.lexicon_fsm(700, 84, seed=5, hubs=2)]
+    rng = np.random.default_rng(77)
+    N = 210
+    lens = np.array([210, 60, 181, 140], dtype=np.int32)
+    Pm = max(g.P for g in gs)
+    cfs = [mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, Pm)) for g in gs]
+    V = rng.standard_normal((len(gs), N, Pm)).astype(np.float32)
+    bf = mm.batch(*cfs)
+    assert "mm_wave_kernel" in bf.kernels("log"), bf.kernels("log")
+    Vt, lt = torch.from_numpy(V).cuda(), torch.from_numpy(lens).cuda()
+    runs = [bf.pdfposteriors(Vt, lt) for _ in range(4)]
+    torch.cuda.synchronize()
+    for gam, ttl in runs[1:]:
+        assert torch.equal(gam, runs[0][0]) and torch.equal(ttl, runs[0][1])
+    gam, ttl = runs[0][0].cpu().numpy(), runs[0][1].cpu().numpy()
+    for b, g in enumerate(gs):
+        g_ref, t_ref = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, Pm, V[b : b + 1], lens[b : b + 1], dtype=np.float64)
+        if np.isfinite(t_ref[0]):
+            check_gamma(gam[b : b + 1], g_ref, lens[b : b + 1])
+            assert np.allclose(ttl[b], t_ref[0], rtol=1e-5, atol=5e-4)
+        else:
+            assert (gam[b] == 0).all() and np.isneginf(ttl[b])

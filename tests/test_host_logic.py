@@ -276,3 +276,56 @@ def test_row_form_variants(mm, wl, pair, copies, scrambled):
         assert stats[7] <= one[7] + 1e-9 if copies != 1 else stats[7] == one[7]
         if copies == 2 and scrambled:
             assert stats[7] < 1.2 and stats[7] < one[7] - 0.1, (d, stats[7], one[7])
+
+
+@pytest.mark.parametrize("gname,H", [("den_wsj", 2), ("den_wsj", 4), ("lfmmi", 2), ("lfmmi600", 2), ("wide", 2)])
+def test_split_form_products(mm, wl, gname, H):
+    """The split pair forms (mm_rows.h make_rows_split: the rows cut into H sets, the same sets in both directions, one
+    row-lane form per set whose arcs read the whole team's vector at its positions) preserve both products, fit the
+    registers of the split kernels on the reference's WSJ denominator graph, and cut the arcs about evenly."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = {"den_wsj": lambda: wl.load_npz_graph(os.path.join(here, "golden", "den_fsm_wsj.npz")),
+         "lfmmi": lambda: wl.lfmmi_denominator(2000, 84), "lfmmi600": lambda: wl.lfmmi_denominator(600, 40, seed=5),
+         "wide": lambda: wl.wide_row_fsm()}[gname]()
+    f = wl.to_fsm(mm, g)
+    cf = mm.compile(f, mm.statemap(g.state2pdf, g.P))
+    rng = np.random.default_rng(4)
+    x = (3 * rng.standard_normal(f.S1)).astype(np.float32)
+    x[rng.random(f.S1) < 0.1] = -np.inf
+    for d in (0, 1):
+        ref, _ = cf.packed_product(x, d)
+        out, stats = cf.split_product(x, d, H)
+        m = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(out), m), (gname, d)
+        assert np.allclose(out[m], ref[m], rtol=1e-5, atol=2e-5), (gname, d)
+        ka, total, nseg, eff, cmax, cmin = stats[:6]
+        assert ka <= 36 and f.S1 <= total <= f.S1 + H
+        assert stats[7] <= stats[6] * 1.15 + 0.05
+        if gname == "den_wsj" and H == 2:  # (the kernels run teams of 2)
+            assert eff > 0.8 and cmax <= 1.4 * cmin + 8, (d, eff, cmax, cmin)
+
+
+@pytest.mark.parametrize("gname", ["l2r", "rand", "num_wsj", "lfmmi600", "wide"])
+def test_wave_form_products(mm, wl, gname):
+    """The wave form (one wave per direction: segments of 64 / g rows, at most 4 arcs per lane and segment, log2
+    weights, lane-group log-sum-exp) preserves both products -- also rows of more than 256 arcs (`wide`)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = {"l2r": lambda: wl.l2r_hmm(3), "rand": lambda: wl.random_fsm(40, 6, 3.0, seed=1),
+         "lfmmi600": lambda: wl.lfmmi_denominator(600, 40, seed=5), "wide": lambda: wl.wide_row_fsm(),
+         "num_wsj": lambda: wl.load_npz_graph(os.path.join(here, "golden", "num_fsm_wsj.npz"))}[gname]()
+    f = wl.to_fsm(mm, g)
+    cf = mm.compile(f, mm.statemap(g.state2pdf, g.P))
+    rng = np.random.default_rng(5)
+    x = (3 * rng.standard_normal(f.S1)).astype(np.float32)
+    x[rng.random(f.S1) < 0.1] = -np.inf
+    for d in (0, 1):
+        ref, _ = cf.packed_product(x, d)
+        try:
+            out, stats = cf.wave_product(x, d)
+        except mm.MarkovModelsAMDError:
+            assert gname in ("lfmmi600", "wide")  # more than 16 segments of 64 rows, or rows beyond 64 x 4 arcs: not this kernel's graphs
+            continue
+        m = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(out), m), (gname, d)
+        assert np.allclose(out[m], ref[m], rtol=1e-5, atol=2e-5), (gname, d)
+        assert stats[0] <= 16 and stats[1] <= 16  # (at most 4 segments of 4 slots per wave, 4 waves)

@@ -54,7 +54,7 @@ enum mm_status {
     MM_ERR_NOMEM = -5
 };
 
-enum mm_semiring { MM_LOG = 0, MM_TROPICAL = 1 }; /* Semirings.jl LogSemiring / TropicalSemiring */
+enum mm_semiring { MM_LOG = 0, MM_TROPICAL = 1, MM_PROB = 2 }; /* Semirings.jl LogSemiring / TropicalSemiring / ProbSemiring */
 enum mm_layout { MM_CSC = 0, MM_CSR = 1 };        /* how T_hat is handed over */
 
 typedef struct mm_fsm_s *mm_fsm_t;     /* one compiled FSM   ~ CompiledFSM   (src/inference.jl:3-12)  */
@@ -166,6 +166,30 @@ int mm_viterbi_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t
  * Runs the emission-free alpha-recursion on the extended system (the phony final state's self loop of
  * weight one is the accumulator) for n + 1 frames.  n >= 1; out: device float[B], natural log. */
 int mm_totalsum_f32(mm_batch_t batch, int64_t n, int cumulative, float *out, void *stream);
+
+/* ---- the generic entry: pdfposteriors(fsm, V_hats, C_hats) as the reference declares it (src/inference.jl:145-161) ----
+ * Any semiring the FSMs were created with (MM_LOG, MM_TROPICAL, MM_PROB: the function is generic in K), float32 or
+ * float64 (FSM{LogSemiring{Float64}} is what the reference's tests build: test/test_fsms.jl:3-7), any sparse state map
+ * C_hat (not only the one-hot map of examples/prepare-lfmmi-graphs.jl:15-23), any (P+1) x (N+1) matrices V_hat (not
+ * only those expand() makes).  Correctness first: a plain kernel that materialises alpha and beta like the reference;
+ * allocates its workspace per call and returns when the result is there.  The fast kernels are behind
+ * mm_pdfposteriors_f32.
+ *   maps     NULL (every FSM's own one-hot state map), or B handles (NULL entries: the FSM's own)
+ *   val_bytes 4 / 8: the type of Vhat, gamma, ttl
+ *   Vhat     device; element (b, n, p) of V_hat_b at Vhat[b*v_stride_b + n*v_stride_n + p], n = 0..N1-1 (N1 = N + 1 columns),
+ *            p = 0..P1-1 (P1 = P + 1 rows: the last is the phony pdf); values in the semiring's own domain
+ *   gamma    device, out: element (b, n, p), n < N1 - 1, p < P1 - 1 (the reference drops the last row and column, :160);
+ *            exp() of the quotient for MM_LOG / MM_TROPICAL, the quotient itself for MM_PROB
+ *   ttl      device [B], out: the minimum over ALL N1 columns of the per-column sum (:159), in the semiring's domain
+ * Z = 0 yields gamma = 0 and ttl = zero(K) (the reference: 0/0). */
+typedef struct mm_statemap_s *mm_statemap_t;
+/* C_hat (S1 x P1) as CSR: rowptr[S1+1], colidx / val [nnz]; host pointers, not retained. */
+int mm_statemap_create(int semiring, int64_t S1, int32_t P1, int64_t nnz, int index_bytes, int index_base, int val_bytes,
+                       const void *rowptr, const void *colidx, const void *val, mm_statemap_t *out);
+int mm_statemap_destroy(mm_statemap_t map);
+int mm_pdfposteriors_ex(mm_batch_t batch, const mm_statemap_t *maps, int val_bytes, const void *Vhat, int64_t v_stride_b,
+                        int64_t v_stride_n, int64_t N1, void *gamma, int64_t g_stride_b, int64_t g_stride_n, int64_t g_stride_p,
+                        void *ttl, void *stream);
 
 /* Deterministic mode (default off).  Every kernel but one reduces in a fixed order; the general ("item") kernel -- the
  * path of small deep graphs such as LF-MMI numerators -- adds a pdf's state posteriors with LDS float atomics, so the

@@ -7,7 +7,7 @@ The directory name contains a dot, so load it with
 ``__graft_entry__.load_package()`` (importlib) rather than a plain import.
 """
 from ._lib import LIB_PATH, SYMBOLS, DimensionMismatch, MarkovModelsAMDError  # noqa: F401
-from .fsm import FSM, StateMap, nstates, rawunion, statemap  # noqa: F401
+from .fsm import FSM, GeneralStateMap, StateMap, nstates, rawunion, statemap  # noqa: F401
 from .inference import (  # noqa: F401
     BatchedFSM,
     CompiledFSM,

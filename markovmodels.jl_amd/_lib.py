@@ -13,9 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MM_AMD_LIB", os.path.join(_HERE, "libmarkovmodels_amd.so"))  # override: diagnostic builds
 
 MM_OK = 0
-MM_LOG, MM_TROPICAL = 0, 1
+MM_LOG, MM_TROPICAL, MM_PROB = 0, 1, 2
 MM_CSC, MM_CSR = 0, 1
-SEMIRING_ID = {"log": MM_LOG, "tropical": MM_TROPICAL}
+SEMIRING_ID = {"log": MM_LOG, "tropical": MM_TROPICAL, "prob": MM_PROB}
 
 #: every symbol include/markovmodels_amd.h declares
 SYMBOLS = [
@@ -33,6 +33,9 @@ SYMBOLS = [
     "mm_batch_set_deterministic",
     "mm_batch_last_redo_count",
     "mm_pdfposteriors_f32",
+    "mm_pdfposteriors_ex",
+    "mm_statemap_create",
+    "mm_statemap_destroy",
     "mm_alpharecursion_f32",
     "mm_betarecursion_f32",
     "mm_maxstateposteriors_f32",
@@ -99,6 +102,12 @@ def _load():
     lib.mm_batch_last_redo_count.argtypes = [vp, vp, C.POINTER(i64)]
     lib.mm_batch_kernels.restype = C.c_int
     lib.mm_batch_kernels.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
+    lib.mm_statemap_create.restype = C.c_int
+    lib.mm_statemap_create.argtypes = [C.c_int, i64, i32, i64, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.POINTER(vp)]
+    lib.mm_statemap_destroy.restype = C.c_int
+    lib.mm_statemap_destroy.argtypes = [vp]
+    lib.mm_pdfposteriors_ex.restype = C.c_int
+    lib.mm_pdfposteriors_ex.argtypes = [vp, vp, C.c_int, vp, i64, i64, i64, vp, i64, i64, i64, vp, vp]
     lib.mm_pdfposteriors_f32.restype = C.c_int
     lib.mm_pdfposteriors_f32.argtypes = [vp, fp, i64, i64, vp, i64, fp, i64, i64, i64, fp, vp]
     for name in ("mm_alpharecursion_f32", "mm_betarecursion_f32", "mm_maxstateposteriors_f32"):

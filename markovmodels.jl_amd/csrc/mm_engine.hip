@@ -139,6 +139,12 @@ struct mm_fsm_s {
     bool split_tried = false;
     RowVariant *wrows[2] = {nullptr, nullptr};  // wave forms (mm_kernel_wave.hip)
     bool wave_tried = false;
+    // what the generic path (mm_generic.hip: any semiring, float32 or float64) works on: both matrices and alpha_hat as
+    // they were handed over, in double, natural units (log weights for Log / Tropical, probabilities for Prob)
+    FsmGenView gen;
+    std::vector<int64_t> gen_ptr[2];
+    std::vector<int32_t> gen_col[2];
+    std::vector<double> gen_val[2], gen_init;
     std::vector<float> init;  // dense alpha_hat, engine domain
     std::vector<int32_t> s2p;
     int device = -1;
@@ -458,7 +464,7 @@ int mm_fsm_create(int semiring, int64_t S1, int64_t nnz, int layout, int index_b
                   const void *init_val, const int32_t *state2pdf, int32_t P1, mm_fsm_t *out) {
     if (!out) return fail(MM_ERR_INVALID, "mm_fsm_create: out is NULL");
     *out = nullptr;
-    if (semiring != MM_LOG && semiring != MM_TROPICAL) return fail(MM_ERR_INVALID, "mm_fsm_create: unknown semiring");
+    if (semiring != MM_LOG && semiring != MM_TROPICAL && semiring != MM_PROB) return fail(MM_ERR_INVALID, "mm_fsm_create: unknown semiring");
     if (layout != MM_CSC && layout != MM_CSR) return fail(MM_ERR_INVALID, "mm_fsm_create: unknown layout");
     if ((index_bytes != 4 && index_bytes != 8) || (val_bytes != 4 && val_bytes != 8) ||
         (index_base != 0 && index_base != 1))
@@ -519,6 +525,64 @@ int mm_fsm_create(int semiring, int64_t S1, int64_t nnz, int layout, int index_b
             return fail(MM_ERR_DIM, "mm_fsm_create: initial state out of range");
         }
         f->init[s] = rd_val(init_val, val_bytes, k) * scale;
+    }
+    {   // the generic path's copy: double, natural units, rows sorted by column like the matrices above
+        const double zero = semiring == MM_PROB ? 0.0 : -std::numeric_limits<double>::infinity();
+        std::vector<int64_t> gptr(given.rowptr);
+        std::vector<int32_t> gcol(static_cast<size_t>(nnz));
+        std::vector<double> gval(static_cast<size_t>(nnz));
+        for (int64_t k = 0; k < nnz; ++k) {
+            gcol[size_t(k)] = int32_t(rd_index(idx, index_bytes, k) - index_base);
+            gval[size_t(k)] = val_bytes == 4 ? double(static_cast<const float *>(val)[k]) : static_cast<const double *>(val)[k];
+        }
+        std::vector<std::pair<int32_t, double>> tmp;
+        for (int64_t r = 0; r < S1; ++r) {
+            tmp.clear();
+            for (int64_t k = gptr[r]; k < gptr[r + 1]; ++k) tmp.push_back({gcol[size_t(k)], gval[size_t(k)]});
+            std::stable_sort(tmp.begin(), tmp.end(), [](auto &x, auto &y) { return x.first < y.first; });
+            for (int64_t k = gptr[r]; k < gptr[r + 1]; ++k) {
+                gcol[size_t(k)] = tmp[size_t(k - gptr[r])].first;
+                gval[size_t(k)] = tmp[size_t(k - gptr[r])].second;
+            }
+        }
+        std::vector<int64_t> tptr(size_t(S1) + 1, 0);
+        std::vector<int32_t> tcol(static_cast<size_t>(nnz));
+        std::vector<double> tval(static_cast<size_t>(nnz));
+        for (int64_t k = 0; k < nnz; ++k) tptr[size_t(gcol[size_t(k)]) + 1]++;
+        for (int64_t i = 0; i < S1; ++i) tptr[size_t(i) + 1] += tptr[size_t(i)];
+        std::vector<int64_t> cur(tptr.begin(), tptr.end() - 1);
+        for (int64_t r = 0; r < S1; ++r)
+            for (int64_t k = gptr[r]; k < gptr[r + 1]; ++k) {
+                const int64_t d = cur[size_t(gcol[size_t(k)])]++;
+                tcol[size_t(d)] = int32_t(r);
+                tval[size_t(d)] = gval[size_t(k)];
+            }
+        const int gi = layout == MM_CSC ? 0 : 1;  // (as above: the given matrix is the forward one when it came as CSC(T_hat))
+        f->gen_ptr[gi] = std::move(gptr);
+        f->gen_col[gi] = std::move(gcol);
+        f->gen_val[gi] = std::move(gval);
+        f->gen_ptr[1 - gi] = std::move(tptr);
+        f->gen_col[1 - gi] = std::move(tcol);
+        f->gen_val[1 - gi] = std::move(tval);
+        f->gen_init.assign(size_t(S1), zero);
+        for (int64_t k = 0; k < n_init; ++k) {
+            const int64_t s = rd_index(init_idx, index_bytes, k) - index_base;
+            f->gen_init[size_t(s)] = val_bytes == 4 ? double(static_cast<const float *>(init_val)[k]) : static_cast<const double *>(init_val)[k];
+        }
+        f->gen.semiring = semiring;
+        f->gen.S1 = S1;
+        f->gen.P1 = P1;
+        for (int d = 0; d < 2; ++d) {
+            f->gen.ptr[d] = f->gen_ptr[d].data();
+            f->gen.col[d] = f->gen_col[d].data();
+            f->gen.val[d] = f->gen_val[d].data();
+        }
+        f->gen.init = f->gen_init.data();
+        f->gen.s2p = f->s2p.data();
+    }
+    if (semiring == MM_PROB) {  // (the generic path only: mm_pdfposteriors_ex)
+        *out = f;
+        return MM_OK;
     }
     f->packed[0] = pack_rows(S1, fwd.rowptr, fwd.col, fwd.val, f->s2p, NINF);
     f->packed[1] = pack_rows(S1, bwd.rowptr, bwd.col, bwd.val, f->s2p, NINF);
@@ -971,6 +1035,11 @@ static int row_variants(mm_fsm_t f, bool verbose, bool *ok) {
 
 int mm_fsm_destroy(mm_fsm_t f) {
     if (!f) return MM_OK;
+    for (void *&d : f->gen.dev)
+        if (d) {
+            mm_generic_free(d);
+            d = nullptr;
+        }
     if (f->dev_blob) (void)hipFree(f->dev_blob);
     for (auto &kv : f->variants) {
         if (kv.second->blob) (void)hipFree(kv.second->blob);
@@ -1220,6 +1289,18 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     h->B = B;
     h->semiring = fsms[0]->semiring;
     h->fsms.assign(fsms, fsms + B);
+    if (hipGetDevice(&h->device) != hipSuccess) {
+        delete h;
+        return fail(MM_ERR_HIP, "mm_batch_create: no device");
+    }
+    if (h->semiring == MM_PROB) {  // the generic path only (mm_pdfposteriors_ex): no kernel forms, no descriptors
+        for (int64_t b = 0; b < B; ++b) {
+            h->total_states += fsms[b]->S1;
+            h->max_P1 = std::max(h->max_P1, int(fsms[b]->P1));
+        }
+        *out = h;
+        return MM_OK;
+    }
     std::vector<UttDesc> utts(B);
     // quad kernels: one geometry (quads per lane, waves) per direction for the whole batch
     int64_t nq_max[2] = {0, 0};
@@ -1440,6 +1521,20 @@ int mm_batch_destroy(mm_batch_t h) {
 
 int64_t mm_batch_total_states(mm_batch_t h) { return h ? h->total_states : -1; }
 
+}  // extern "C"
+namespace mm {
+FsmGenView *mm_fsm_gen_view(mm_fsm_t f) { return f ? &f->gen : nullptr; }
+int mm_batch_gen_view(mm_batch_t h, int64_t *B, const mm_fsm_t **fsms, int *semiring, int *device) {
+    if (!h) return MM_ERR_INVALID;
+    *B = h->B;
+    *fsms = h->fsms.data();
+    *semiring = h->semiring;
+    *device = h->device;
+    return MM_OK;
+}
+}  // namespace mm
+extern "C" {
+
 int mm_batch_set_deterministic(mm_batch_t h, int on) {
     if (!h) return fail(MM_ERR_INVALID, "mm_batch_set_deterministic: NULL batch");
     h->deterministic = on != 0;
@@ -1574,6 +1669,8 @@ static int check_run(mm_batch_t h, const char *who, const float *V, int64_t N, i
     if (N < 1 || N > (int64_t(1) << 30)) return fail(MM_ERR_DIM, std::string(who) + ": need N >= 1");
     if (want_semiring >= 0 && h->semiring != want_semiring)
         return fail(MM_ERR_INVALID, std::string(who) + ": batch was built for another semiring");
+    if (h->semiring == MM_PROB)
+        return fail(MM_ERR_UNSUPPORTED, std::string(who) + ": ProbSemiring batches run through mm_pdfposteriors_ex");
     int dev = -1;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != h->device) return fail(MM_ERR_INVALID, std::string(who) + ": batch lives on another device");

@@ -1,0 +1,432 @@
+// mm_generic.hip -- the GENERIC pdfposteriors path: any semiring (Log, Tropical, Prob), float32 or float64, any sparse
+// state map C_hat, any (P+1) x (N+1) matrices V_hat -- the reference's pdfposteriors(fsm, V_hats, C_hats) as it is
+// declared (src/inference.jl:145-161: generic in K; FSM{LogSemiring{Float64}} is what its tests build, test/test_fsms.jl:3-7;
+// its linear algebra is tested for 3 semirings x 2 float types, test/test_linalg.jl:88-108).
+//
+// Correctness first: one workgroup per utterance, a thread per CSR row and frame, alpha and beta materialised in the
+// workspace like the reference does (:152-153), every reduction in a fixed order.  The fast kernels (float32, Log /
+// Tropical, one-hot C_hat, V_hat of expand()'s form) are elsewhere; this path is what makes the entry a drop-in for the
+// rest of the reference's argument space.  Z = 0 gives gamma = 0 and ttl = zero(K) (the reference: 0/0 = NaN, :158).
+#define MM_SECONDARY_TU
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "mm_internal.h"
+
+namespace mm {
+
+struct mm_statemap_view {  // device CSR of C_hat (S1 x P1) and of its transpose, in T
+    int64_t S1;
+    int32_t P1;
+    const int *cptr, *ccol;    // C_hat rows: state -> (pdf, weight)
+    const void *cval;
+    const int *tptr, *tcol;    // C_hat' rows: pdf -> (state, weight)
+    const void *tval;
+};
+
+template <typename T>
+struct GenFsmDev {  // one FSM on the device in T
+    int S1, P1;
+    const int *ptr[2], *col[2];
+    const T *val[2];
+    const T *init;
+    mm_statemap_view own;  // the FSM's one-hot state map
+};
+
+template <typename T>
+struct GenUtt {
+    GenFsmDev<T> f;
+    mm_statemap_view c;
+    long long ws_off;  // offset of the utterance's alpha / beta arrays in the workspace (elements)
+};
+
+template <typename T, int SR>
+struct Sem {
+    static __device__ __forceinline__ T zero() { return SR == MM_PROB ? T(0) : -std::numeric_limits<T>::infinity(); }
+    static __device__ __forceinline__ T one() { return SR == MM_PROB ? T(1) : T(0); }
+    static __device__ __forceinline__ T mul(T a, T b) {
+        if (SR == MM_PROB) return a * b;
+        if (a == zero() || b == zero()) return zero();  // (zero annihilates: never -inf + inf)
+        return a + b;
+    }
+    static __device__ __forceinline__ T add(T a, T b) {
+        if (SR == MM_PROB) return a + b;
+        if (SR == MM_TROPICAL) return a > b ? a : b;
+        const T m = a > b ? a : b;
+        if (m == zero()) return zero();
+        const T d = a > b ? b - a : a - b;  // -|a - b|
+        return m + T(log1p(exp((double)d)));
+    }
+    static __device__ __forceinline__ T div(T a, T b) { return SR == MM_PROB ? a / b : a - b; }
+    static __device__ __forceinline__ T out(T a) { return SR == MM_PROB ? a : T(exp((double)a)); }  // (:160 exp for the log-like semirings)
+};
+// (float32 Log: log1p / exp in double keep the path within rounding of the float64 oracle; speed is not this path's business)
+
+template <typename T, int SR>
+__global__ void __launch_bounds__(256) mm_generic_kernel(const GenUtt<T> *utts, const T *V, long long vsb, long long vsn, int N1, T *ws,
+                                                         T *gamma, long long gsb, long long gsn, long long gsp, T *ttl) {
+    using K = Sem<T, SR>;
+    const GenUtt<T> &u = utts[blockIdx.x];
+    const int S1 = u.f.S1, P1 = u.c.P1, P = P1 - 1, N = N1 - 1, tid = threadIdx.x, NT = blockDim.x;
+    const T *Vb = V + (long long)blockIdx.x * vsb;
+    T *A = ws + u.ws_off, *Bv = A + (long long)N1 * S1;
+    extern __shared__ char smem[];
+    T *zp = reinterpret_cast<T *>(smem);  // [P1] per-pdf sums of a frame, then [1] the frame's sum
+    // state-level emission (C_hat * V_hat)[s, n]   (src/inference.jl:150)
+    auto em = [&](int s, int n) {
+        const T *cv = static_cast<const T *>(u.c.cval);
+        T acc = K::zero();
+        for (int k = u.c.cptr[s]; k < u.c.cptr[s + 1]; ++k) acc = K::add(acc, K::mul(cv[k], Vb[(long long)n * vsn + u.c.ccol[k]]));
+        return acc;
+    };
+    // ---- alpha-recursion (src/inference.jl:62-74)
+    for (int s = tid; s < S1; s += NT) A[s] = K::mul(u.f.init[s], em(s, 0));
+    __syncthreads();
+    for (int n = 1; n < N1; ++n) {
+        const T *prev = A + (long long)(n - 1) * S1;
+        T *cur = A + (long long)n * S1;
+        for (int j = tid; j < S1; j += NT) {
+            T acc = K::zero();
+            for (int k = u.f.ptr[0][j]; k < u.f.ptr[0][j + 1]; ++k) acc = K::add(acc, K::mul(prev[u.f.col[0][k]], u.f.val[0][k]));
+            cur[j] = K::mul(acc, em(j, n));
+        }
+        __syncthreads();
+    }
+    // ---- beta-recursion (:99-110): B[:, N+1] = one, B[:, n] = T_hat (B[:, n+1] (*) lhs[:, n+1])
+    for (int s = tid; s < S1; s += NT) Bv[(long long)(N1 - 1) * S1 + s] = K::one();
+    __syncthreads();
+    for (int n = N1 - 2; n >= 0; --n) {
+        const T *nxt = Bv + (long long)(n + 1) * S1;
+        T *cur = Bv + (long long)n * S1;
+        for (int i = tid; i < S1; i += NT) {
+            T acc = K::zero();
+            for (int k = u.f.ptr[1][i]; k < u.f.ptr[1][i + 1]; ++k) {
+                const int j = u.f.col[1][k];
+                acc = K::add(acc, K::mul(u.f.val[1][k], K::mul(nxt[j], em(j, n + 1))));
+            }
+            cur[i] = acc;
+        }
+        __syncthreads();
+    }
+    // ---- A .* B, C_hat' * AB, per-frame sum, divide, minimum, exp   (:154-160)
+    T tmin = std::numeric_limits<T>::infinity();
+    const T *tv = static_cast<const T *>(u.c.tval);
+    for (int n = 0; n < N1; ++n) {
+        for (int q = tid; q < P1; q += NT) {
+            T acc = K::zero();
+            for (int k = u.c.tptr[q]; k < u.c.tptr[q + 1]; ++k) {
+                const int s = u.c.tcol[k];
+                acc = K::add(acc, K::mul(tv[k], K::mul(A[(long long)n * S1 + s], Bv[(long long)n * S1 + s])));
+            }
+            zp[q] = acc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            T s = K::zero();
+            for (int q = 0; q < P1; ++q) s = K::add(s, zp[q]);
+            zp[P1] = s;
+        }
+        __syncthreads();
+        const T sum = zp[P1];
+        tmin = sum < tmin ? sum : tmin;
+        if (n < N)
+            for (int q = tid; q < P; q += NT)
+                gamma[(long long)blockIdx.x * gsb + (long long)n * gsn + (long long)q * gsp] = sum == K::zero() ? T(0) : K::out(K::div(zp[q], sum));
+        __syncthreads();
+    }
+    if (tid == 0) ttl[blockIdx.x] = tmin;
+}
+
+// ---- host side
+namespace {
+
+struct DevFsm {  // owns the device copy of one FSM in one precision
+    void *blob = nullptr;
+    int S1 = 0, P1 = 0;
+    size_t off_ptr[2], off_col[2], off_val[2], off_init, off_cptr, off_ccol, off_cval, off_tptr, off_tcol, off_tval;
+};
+
+template <typename T>
+void push(std::vector<char> &h, size_t &off, const std::vector<T> &v) {
+    off = (h.size() + 255) / 256 * 256;
+    h.resize(off + v.size() * sizeof(T));
+    if (!v.empty()) memcpy(h.data() + off, v.data(), v.size() * sizeof(T));
+}
+
+// C_hat as CSR + its transpose, values in T
+template <typename T>
+void statemap_arrays(int64_t S1, int32_t P1, const std::vector<int64_t> &ptr, const std::vector<int32_t> &col, const std::vector<double> &val,
+                     std::vector<int> &cptr, std::vector<int> &ccol, std::vector<T> &cval, std::vector<int> &tptr, std::vector<int> &tcol,
+                     std::vector<T> &tval) {
+    cptr.assign(ptr.begin(), ptr.end());
+    ccol.assign(col.begin(), col.end());
+    cval.resize(val.size());
+    for (size_t k = 0; k < val.size(); ++k) cval[k] = T(val[k]);
+    tptr.assign(size_t(P1) + 1, 0);
+    for (int32_t c : col) tptr[size_t(c) + 1]++;
+    for (int32_t q = 0; q < P1; ++q) tptr[size_t(q) + 1] += tptr[size_t(q)];
+    std::vector<int> cur(tptr.begin(), tptr.end() - 1);
+    tcol.resize(col.size());
+    tval.resize(col.size());
+    for (int64_t s = 0; s < S1; ++s)
+        for (int64_t k = ptr[size_t(s)]; k < ptr[size_t(s) + 1]; ++k) {
+            const int d = cur[size_t(col[size_t(k)])]++;
+            tcol[size_t(d)] = int(s);
+            tval[size_t(d)] = T(val[size_t(k)]);
+        }
+}
+
+template <typename T>
+int fsm_to_device(FsmGenView *g, DevFsm **out) {
+    const int slot = sizeof(T) == 4 ? 0 : 1;
+    if (g->dev[slot]) {
+        *out = static_cast<DevFsm *>(g->dev[slot]);
+        return MM_OK;
+    }
+    DevFsm *d = new DevFsm();
+    d->S1 = int(g->S1);
+    d->P1 = int(g->P1);
+    std::vector<char> h;
+    for (int dir = 0; dir < 2; ++dir) {
+        const int64_t nnz = g->ptr[dir][g->S1];
+        std::vector<int> ptr(g->ptr[dir], g->ptr[dir] + g->S1 + 1), col(g->col[dir], g->col[dir] + nnz);
+        std::vector<T> val(static_cast<size_t>(nnz));
+        for (int64_t k = 0; k < nnz; ++k) val[size_t(k)] = T(g->val[dir][k]);
+        push(h, d->off_ptr[dir], ptr);
+        push(h, d->off_col[dir], col);
+        push(h, d->off_val[dir], val);
+    }
+    std::vector<T> init(static_cast<size_t>(g->S1));
+    for (int64_t s = 0; s < g->S1; ++s) init[size_t(s)] = T(g->init[s]);
+    push(h, d->off_init, init);
+    // the FSM's own one-hot state map: row s = {(pdf(s), one)}
+    std::vector<int64_t> optr(size_t(g->S1) + 1);
+    std::vector<int32_t> ocol(g->s2p, g->s2p + g->S1);
+    std::vector<double> oval(size_t(g->S1), g->semiring == MM_PROB ? 1.0 : 0.0);
+    for (int64_t s = 0; s <= g->S1; ++s) optr[size_t(s)] = s;
+    std::vector<int> cptr, ccol, tptr, tcol;
+    std::vector<T> cval, tval;
+    statemap_arrays<T>(g->S1, g->P1, optr, ocol, oval, cptr, ccol, cval, tptr, tcol, tval);
+    push(h, d->off_cptr, cptr);
+    push(h, d->off_ccol, ccol);
+    push(h, d->off_cval, cval);
+    push(h, d->off_tptr, tptr);
+    push(h, d->off_tcol, tcol);
+    push(h, d->off_tval, tval);
+    if (hipMalloc(&d->blob, h.size()) != hipSuccess || hipMemcpy(d->blob, h.data(), h.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        if (d->blob) (void)hipFree(d->blob);
+        delete d;
+        return mm_fail(MM_ERR_HIP, "mm_pdfposteriors_ex: device allocation failed");
+    }
+    g->dev[slot] = d;
+    *out = d;
+    return MM_OK;
+}
+
+mm_statemap_view view_of(const DevFsm *d, int val_bytes) {
+    const char *b = static_cast<const char *>(d->blob);
+    (void)val_bytes;
+    mm_statemap_view v;
+    v.S1 = d->S1;
+    v.P1 = d->P1;
+    v.cptr = reinterpret_cast<const int *>(b + d->off_cptr);
+    v.ccol = reinterpret_cast<const int *>(b + d->off_ccol);
+    v.cval = b + d->off_cval;
+    v.tptr = reinterpret_cast<const int *>(b + d->off_tptr);
+    v.tcol = reinterpret_cast<const int *>(b + d->off_tcol);
+    v.tval = b + d->off_tval;
+    return v;
+}
+
+}  // namespace
+
+void mm_generic_free(void *dev) {
+    DevFsm *d = static_cast<DevFsm *>(dev);
+    if (!d) return;
+    if (d->blob) (void)hipFree(d->blob);
+    delete d;
+}
+
+}  // namespace mm
+
+using namespace mm;
+
+// a general sparse state map C_hat (S1 x P1), handed over as CSR
+struct mm_statemap_s {
+    int semiring;
+    int64_t S1;
+    int32_t P1;
+    std::vector<int64_t> ptr;
+    std::vector<int32_t> col;
+    std::vector<double> val;
+    DevFsm *dev[2] = {nullptr, nullptr};  // device copies (float32, float64): only the C_hat parts of DevFsm are used
+};
+
+template <typename T>
+static int statemap_to_device(mm_statemap_s *m, DevFsm **out) {
+    const int slot = sizeof(T) == 4 ? 0 : 1;
+    if (m->dev[slot]) {
+        *out = m->dev[slot];
+        return MM_OK;
+    }
+    DevFsm *d = new DevFsm();
+    d->S1 = int(m->S1);
+    d->P1 = int(m->P1);
+    std::vector<char> h;
+    std::vector<int> cptr, ccol, tptr, tcol;
+    std::vector<T> cval, tval;
+    statemap_arrays<T>(m->S1, m->P1, m->ptr, m->col, m->val, cptr, ccol, cval, tptr, tcol, tval);
+    push(h, d->off_cptr, cptr);
+    push(h, d->off_ccol, ccol);
+    push(h, d->off_cval, cval);
+    push(h, d->off_tptr, tptr);
+    push(h, d->off_tcol, tcol);
+    push(h, d->off_tval, tval);
+    if (hipMalloc(&d->blob, h.size() ? h.size() : 256) != hipSuccess ||
+        hipMemcpy(d->blob, h.data(), h.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        if (d->blob) (void)hipFree(d->blob);
+        delete d;
+        return mm_fail(MM_ERR_HIP, "mm_pdfposteriors_ex: device allocation failed");
+    }
+    m->dev[slot] = d;
+    *out = d;
+    return MM_OK;
+}
+
+template <typename T, int SR>
+static int run_generic(int64_t B, const mm_fsm_t *fsms, const mm_statemap_t *maps, const T *V, int64_t vsb, int64_t vsn, int64_t N1, T *gamma,
+                       int64_t gsb, int64_t gsn, int64_t gsp, T *ttl, hipStream_t stream) {
+    std::vector<GenUtt<T>> utts(static_cast<size_t>(B));
+    long long ws_elems = 0;
+    int maxP1 = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        FsmGenView *g = mm_fsm_gen_view(fsms[b]);
+        DevFsm *d = nullptr;
+        int rc = fsm_to_device<T>(g, &d);
+        if (rc) return rc;
+        const char *base = static_cast<const char *>(d->blob);
+        GenUtt<T> &u = utts[size_t(b)];
+        u.f.S1 = d->S1;
+        u.f.P1 = d->P1;
+        for (int dir = 0; dir < 2; ++dir) {
+            u.f.ptr[dir] = reinterpret_cast<const int *>(base + d->off_ptr[dir]);
+            u.f.col[dir] = reinterpret_cast<const int *>(base + d->off_col[dir]);
+            u.f.val[dir] = reinterpret_cast<const T *>(base + d->off_val[dir]);
+        }
+        u.f.init = reinterpret_cast<const T *>(base + d->off_init);
+        u.f.own = view_of(d, sizeof(T));
+        u.c = u.f.own;
+        if (maps && maps[b]) {
+            mm_statemap_s *m = maps[b];
+            if (m->S1 != g->S1) return mm_fail(MM_ERR_DIM, "mm_pdfposteriors_ex: a state map's rows do not match its FSM's states");
+            DevFsm *md = nullptr;
+            rc = statemap_to_device<T>(m, &md);
+            if (rc) return rc;
+            u.c = view_of(md, sizeof(T));
+        }
+        if (b && u.c.P1 != utts[0].c.P1) return mm_fail(MM_ERR_DIM, "mm_pdfposteriors_ex: all state maps must have the same number of pdfs");
+        maxP1 = std::max(maxP1, int(u.c.P1));
+        u.ws_off = ws_elems;
+        ws_elems += 2ll * N1 * d->S1;
+    }
+    GenUtt<T> *d_utts = nullptr;
+    T *ws = nullptr;
+    HIP_TRY(hipMalloc(&d_utts, sizeof(GenUtt<T>) * size_t(B)));
+    hipError_t e1 = hipMalloc(&ws, sizeof(T) * size_t(ws_elems));
+    if (e1 != hipSuccess) {
+        (void)hipFree(d_utts);
+        return mm_fail(MM_ERR_HIP, "mm_pdfposteriors_ex: workspace allocation failed");
+    }
+    hipError_t e2 = hipMemcpyAsync(d_utts, utts.data(), sizeof(GenUtt<T>) * size_t(B), hipMemcpyHostToDevice, stream);
+    if (e2 == hipSuccess) {
+        hipLaunchKernelGGL((mm_generic_kernel<T, SR>), dim3(unsigned(B)), dim3(256), size_t(maxP1 + 1) * sizeof(T), stream, d_utts, V,
+                           (long long)vsb, (long long)vsn, int(N1), ws, gamma, (long long)gsb, (long long)gsn, (long long)gsp, ttl);
+        e2 = hipGetLastError();
+    }
+    // (this path allocates per call and waits for its kernel: correctness first)
+    hipError_t e3 = hipStreamSynchronize(stream);
+    (void)hipFree(ws);
+    (void)hipFree(d_utts);
+    if (e2 != hipSuccess) return mm_fail(MM_ERR_HIP, std::string("mm_pdfposteriors_ex: ") + hipGetErrorString(e2));
+    if (e3 != hipSuccess) return mm_fail(MM_ERR_HIP, std::string("mm_pdfposteriors_ex: ") + hipGetErrorString(e3));
+    return MM_OK;
+}
+
+extern "C" {
+
+int mm_statemap_create(int semiring, int64_t S1, int32_t P1, int64_t nnz, int index_bytes, int index_base, int val_bytes, const void *rowptr,
+                       const void *colidx, const void *val, mm_statemap_t *out) {
+    if (!out) return mm_fail(MM_ERR_INVALID, "mm_statemap_create: out is NULL");
+    *out = nullptr;
+    if (semiring < MM_LOG || semiring > MM_PROB || (index_bytes != 4 && index_bytes != 8) || (val_bytes != 4 && val_bytes != 8) ||
+        (index_base != 0 && index_base != 1) || S1 < 1 || P1 < 1 || nnz < 0 || !rowptr || (nnz && (!colidx || !val)))
+        return mm_fail(MM_ERR_INVALID, "mm_statemap_create: bad argument");
+    auto rd = [&](const void *p, int64_t i) {
+        return index_bytes == 4 ? int64_t(static_cast<const int32_t *>(p)[i]) : static_cast<const int64_t *>(p)[i];
+    };
+    mm_statemap_s *m = new mm_statemap_s();
+    m->semiring = semiring;
+    m->S1 = S1;
+    m->P1 = P1;
+    m->ptr.resize(size_t(S1) + 1);
+    for (int64_t i = 0; i <= S1; ++i) {
+        m->ptr[size_t(i)] = rd(rowptr, i) - index_base;
+        if (m->ptr[size_t(i)] < 0 || m->ptr[size_t(i)] > nnz || (i && m->ptr[size_t(i)] < m->ptr[size_t(i) - 1])) {
+            delete m;
+            return mm_fail(MM_ERR_DIM, "mm_statemap_create: rowptr is not monotone within [0, nnz]");
+        }
+    }
+    m->col.resize(size_t(nnz));
+    m->val.resize(size_t(nnz));
+    for (int64_t k = 0; k < nnz; ++k) {
+        const int64_t c = rd(colidx, k) - index_base;
+        if (c < 0 || c >= P1) {
+            delete m;
+            return mm_fail(MM_ERR_DIM, "mm_statemap_create: pdf index out of range");
+        }
+        m->col[size_t(k)] = int32_t(c);
+        m->val[size_t(k)] = val_bytes == 4 ? double(static_cast<const float *>(val)[k]) : static_cast<const double *>(val)[k];
+    }
+    *out = m;
+    return MM_OK;
+}
+
+int mm_statemap_destroy(mm_statemap_t m) {
+    if (!m) return MM_OK;
+    for (DevFsm *d : m->dev) mm_generic_free(d);
+    delete m;
+    return MM_OK;
+}
+
+int mm_pdfposteriors_ex(mm_batch_t batch, const mm_statemap_t *maps, int val_bytes, const void *Vhat, int64_t v_stride_b, int64_t v_stride_n,
+                        int64_t N1, void *gamma, int64_t g_stride_b, int64_t g_stride_n, int64_t g_stride_p, void *ttl, void *stream) {
+    int64_t B = 0;
+    const mm_fsm_t *fsms = nullptr;
+    int semiring = 0, device = -1, dev = -1;
+    if (mm_batch_gen_view(batch, &B, &fsms, &semiring, &device)) return mm_fail(MM_ERR_INVALID, "mm_pdfposteriors_ex: NULL batch");
+    if (!Vhat || !gamma || !ttl || (val_bytes != 4 && val_bytes != 8)) return mm_fail(MM_ERR_INVALID, "mm_pdfposteriors_ex: bad argument");
+    if (N1 < 2) return mm_fail(MM_ERR_DIM, "mm_pdfposteriors_ex: V_hat needs at least two columns (N + 1)");
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != device) return mm_fail(MM_ERR_INVALID, "mm_pdfposteriors_ex: batch lives on another device");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define MM_GEN_CASE(T, SR)                                                                                                          \
+    return run_generic<T, SR>(B, fsms, maps, static_cast<const T *>(Vhat), v_stride_b, v_stride_n, N1, static_cast<T *>(gamma), g_stride_b, \
+                              g_stride_n, g_stride_p, static_cast<T *>(ttl), st)
+    if (val_bytes == 4) {
+        if (semiring == MM_LOG) MM_GEN_CASE(float, MM_LOG);
+        if (semiring == MM_TROPICAL) MM_GEN_CASE(float, MM_TROPICAL);
+        MM_GEN_CASE(float, MM_PROB);
+    }
+    if (semiring == MM_LOG) MM_GEN_CASE(double, MM_LOG);
+    if (semiring == MM_TROPICAL) MM_GEN_CASE(double, MM_TROPICAL);
+    MM_GEN_CASE(double, MM_PROB);
+#undef MM_GEN_CASE
+}
+
+}  // extern "C"

@@ -33,6 +33,22 @@ int mm_fail(int code, const std::string &msg);
 #define MM_SPLIT_KA 36
 #define MM_SPLIT_NWC 14
 
+// ---- generic path (mm_generic.hip): any semiring, float32 or float64, any C_hat / V_hat
+struct FsmGenView {   // host copies of one FSM in double, natural units; [0]: CSR of T_hat' (forward), [1]: of T_hat (backward)
+    int semiring = 0;
+    int64_t S1 = 0;
+    int32_t P1 = 0;
+    const int64_t *ptr[2] = {nullptr, nullptr};
+    const int32_t *col[2] = {nullptr, nullptr};
+    const double *val[2] = {nullptr, nullptr};
+    const double *init = nullptr;   // dense alpha_hat [S1]
+    const int32_t *s2p = nullptr;   // the FSM's one-hot state map [S1]
+    void *dev[2] = {nullptr, nullptr};  // device copies made by the generic path (float32, float64); freed by mm_generic_free
+};
+FsmGenView *mm_fsm_gen_view(mm_fsm_t f);
+int mm_batch_gen_view(mm_batch_t h, int64_t *B, const mm_fsm_t **fsms, int *semiring, int *device);
+void mm_generic_free(void *dev);
+
 // ---- pair kernels (mm_pairs_tu.hip)
 struct PairLaunch {
     int64_t B = 0;

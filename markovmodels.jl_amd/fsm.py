@@ -11,8 +11,8 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-_ZERO = {"log": -np.inf, "tropical": -np.inf}
-_ONE = {"log": 0.0, "tropical": 0.0}
+_ZERO = {"log": -np.inf, "tropical": -np.inf, "prob": 0.0}
+_ONE = {"log": 0.0, "tropical": 0.0, "prob": 1.0}
 
 
 def _oplus_at(semiring: str, out: np.ndarray, idx: np.ndarray, vals: np.ndarray) -> None:
@@ -20,6 +20,8 @@ def _oplus_at(semiring: str, out: np.ndarray, idx: np.ndarray, vals: np.ndarray)
     if semiring == "log":
         with np.errstate(invalid="ignore", divide="ignore"):
             np.logaddexp.at(out, idx, vals)
+    elif semiring == "prob":
+        np.add.at(out, idx, vals)
     else:
         np.maximum.at(out, idx, vals)
 
@@ -32,7 +34,9 @@ def semiring_name(s: str) -> str:
         return "tropical"
     if "log" in t:
         return "log"
-    raise ValueError(f"unsupported semiring {s!r}: the engine implements LogSemiring and TropicalSemiring")
+    if "prob" in t:
+        return "prob"
+    raise ValueError(f"unsupported semiring {s!r}: the engine implements LogSemiring, TropicalSemiring and ProbSemiring")
 
 
 class FSM:
@@ -300,3 +304,32 @@ class StateMap:
 
 def statemap(state2pdf, numpdf: int) -> StateMap:
     return StateMap(state2pdf, numpdf)
+
+
+class GeneralStateMap:
+    """Any sparse C_hat ((S+1) x (P+1), semiring values; src/inference.jl:145-150 takes whatever the caller built): kept
+    as CSR.  Only the generic entry (``pdfposteriors`` -> mm_pdfposteriors_ex) accepts it; the fast kernels need the
+    one-hot ``StateMap``."""
+
+    def __init__(self, matrix, semiring: str = "log"):
+        self.semiring = semiring_name(semiring)
+        zero = _ZERO[self.semiring]
+        if hasattr(matrix, "tocsr"):
+            m = matrix.tocsr()
+            self.shape = tuple(m.shape)
+            self.indptr, self.indices, self.data = m.indptr.astype(np.int64), m.indices.astype(np.int64), np.asarray(m.data, dtype=np.float64)
+        else:
+            M = np.asarray(matrix, dtype=np.float64)
+            self.shape = M.shape
+            nz = M != zero
+            self.indptr = np.concatenate([[0], np.cumsum(nz.sum(axis=1))]).astype(np.int64)
+            self.indices = np.nonzero(nz)[1].astype(np.int64)
+            self.data = M[nz]
+        self.numpdf = self.shape[1] - 1
+
+    def one_hot(self):
+        """The equivalent StateMap if every row holds exactly one entry of weight one(K) (and the last row maps to the
+        last pdf), else None."""
+        if (np.diff(self.indptr) != 1).any() or (self.data != _ONE[self.semiring]).any() or self.indices[-1] != self.numpdf:
+            return None
+        return StateMap(self.indices[:-1], self.numpdf)

@@ -22,9 +22,11 @@ import numpy as np
 
 from . import _lib
 from ._lib import SEMIRING_ID, check, lib
-from .fsm import FSM, StateMap, split_blocks, statemap
+from .fsm import FSM, GeneralStateMap, StateMap, split_blocks, statemap
 
 _ZERO = -np.inf
+_SEM_ZERO = {"log": -np.inf, "tropical": -np.inf, "prob": 0.0}
+_SEM_ONE = {"log": 0.0, "tropical": 0.0, "prob": 1.0}
 
 
 def _torch():
@@ -204,6 +206,49 @@ class BatchedFSM:
             return gamma.cpu().numpy(), ttl.cpu().numpy()
         return gamma, ttl
 
+    def pdfposteriors_generic(self, Vhats, Chats=None, dtype=None):
+        """The generic entry (mm_pdfposteriors_ex): any semiring of the batch (log / tropical / prob), float32 or
+        float64, any sparse state maps (``GeneralStateMap``; None: every FSM's own), any (P+1) x (N+1) matrices V_hat.
+        Returns NumPy (gamma[B, P, N], ttl[B]) like the reference (src/inference.jl:145-161)."""
+        import ctypes
+
+        torch = _torch()
+        Vh = [np.asarray(v.cpu() if hasattr(v, "cpu") else v) for v in Vhats]
+        if len(Vh) != self.B or any(v.shape != Vh[0].shape for v in Vh):
+            raise _lib.DimensionMismatch(-2, "need B matrices V_hat of one (P+1) x (N+1) shape")
+        P1, N1 = Vh[0].shape
+        dt = np.dtype(dtype) if dtype is not None else (np.dtype(np.float64) if Vh[0].dtype == np.float64 else np.dtype(np.float32))
+        V = torch.from_numpy(np.ascontiguousarray(np.stack([v.T for v in Vh]), dtype=dt)).cuda()  # [B][N1][P1]
+        gamma = torch.zeros((self.B, N1 - 1, P1 - 1), dtype=V.dtype, device=V.device)
+        ttl = torch.zeros(self.B, dtype=V.dtype, device=V.device)
+        handles, keep = None, []
+        if Chats is not None:
+            arr = (ctypes.c_void_p * self.B)()
+            cache = {}
+            for b, c in enumerate(Chats):
+                if c is None or isinstance(c, StateMap):
+                    arr[b] = None
+                    continue
+                if c.shape != (self.cfsms[b].S1, P1):
+                    raise _lib.DimensionMismatch(-2, f"C_hat {b} is {c.shape}, expected {(self.cfsms[b].S1, P1)}")
+                if id(c) not in cache:
+                    hm = ctypes.c_void_p()
+                    ip, ix, dv = (np.ascontiguousarray(c.indptr, dtype=np.int64), np.ascontiguousarray(c.indices, dtype=np.int64),
+                                  np.ascontiguousarray(c.data, dtype=np.float64))
+                    check(lib.mm_statemap_create(SEMIRING_ID[self.semiring], c.shape[0], c.shape[1], ix.shape[0], 8, 0, 8,
+                                                 ip.ctypes.data, ix.ctypes.data, dv.ctypes.data, ctypes.byref(hm)))
+                    cache[id(c)] = hm
+                    keep.append(hm)
+                arr[b] = cache[id(c)]
+            handles = arr
+        try:
+            check(lib.mm_pdfposteriors_ex(self._h, handles, dt.itemsize, V.data_ptr(), V.stride(0), V.stride(1), N1, gamma.data_ptr(),
+                                          gamma.stride(0), gamma.stride(1), gamma.stride(2), ttl.data_ptr(), self._stream(torch)))
+        finally:
+            for hm in keep:
+                lib.mm_statemap_destroy(hm)
+        return np.ascontiguousarray(gamma.cpu().numpy().transpose(0, 2, 1)), ttl.cpu().numpy()
+
     def _export(self, fn, V, lens):
         torch, Vt, lt, as_numpy = self._prep(V, lens)
         B, N, P = Vt.shape
@@ -281,23 +326,23 @@ def batch(*cfsms: CompiledFSM) -> BatchedFSM:
     return BatchedFSM(cfsms)
 
 
-def expand(lhs, seqlength: Optional[int] = None):
-    """expand(V, seqlength) (src/inference.jl:54-60): the P x N log-likelihoods
-    become (P+1) x (N+1): a phony pdf row (zero up to seqlength, one after) and
-    an extra frame; real pdfs are zero beyond seqlength.  zero = -inf, one = 0
-    (Log/Tropical semirings)."""
+def expand(lhs, seqlength: Optional[int] = None, semiring: str = "log"):
+    """expand(V, seqlength) (src/inference.jl:54-60): the P x N likelihoods
+    become (P+1) x (N+1): a phony pdf row (zero(K) up to seqlength, one(K) after) and
+    an extra frame; real pdfs are zero(K) beyond seqlength.  zero = -inf, one = 0 for the
+    Log/Tropical semirings, 0 and 1 for ProbSemiring."""
     a = np.asarray(lhs)
     P, N = a.shape
     L = N if seqlength is None else int(seqlength)
-    out = np.full((P + 1, N + 1), _ZERO, dtype=a.dtype if a.dtype.kind == "f" else np.float32)
+    out = np.full((P + 1, N + 1), _SEM_ZERO[semiring], dtype=a.dtype if a.dtype.kind == "f" else np.float32)
     out[:P, :L] = a[:, :L]
-    out[P, L:] = 0.0
+    out[P, L:] = _SEM_ONE[semiring]
     return out
 
 
 def _unexpand(Vhats: Sequence[np.ndarray]):
-    """Recover (V[B, N, P], lens) from matrices made by ``expand``; anything that
-    is not of that form is rejected (the engine implements expand's semantics)."""
+    """Recover (V[B, N, P], lens) from matrices made by ``expand`` (what the fast kernels take: they implement expand's
+    semantics themselves); None if a matrix is not of that form -- the caller then takes the generic path."""
     Vh = [np.asarray(v.cpu() if hasattr(v, "cpu") else v) for v in Vhats]
     shp = Vh[0].shape
     if any(v.shape != shp for v in Vh):
@@ -309,11 +354,18 @@ def _unexpand(Vhats: Sequence[np.ndarray]):
         L = int(np.argmax(ph == 0)) if (ph == 0).any() else N1
         ok = np.all(np.isneginf(ph[:L])) and np.all(ph[L:] == 0) and np.all(np.isneginf(v[: P1 - 1, L:])) and L <= N1 - 1
         if not ok:
-            raise ValueError("V_hat is not of the form expand(V, seqlength) produces")
+            return None
         lens.append(L)
     V = np.stack([v[: P1 - 1, : N1 - 1].T for v in Vh]).astype(np.float32)
     V[~np.isfinite(V) & (V < 0)] = -np.inf
     return np.ascontiguousarray(V), np.asarray(lens, dtype=np.int32)
+
+
+def _need_expanded(Vhats):
+    un = _unexpand(Vhats)
+    if un is None:
+        raise ValueError("V_hat is not of the form expand(V, seqlength) produces (only pdfposteriors takes arbitrary V_hat)")
+    return un
 
 
 def _as_batch(fsm, Chats) -> BatchedFSM:
@@ -323,7 +375,10 @@ def _as_batch(fsm, Chats) -> BatchedFSM:
         return BatchedFSM([fsm])
     if Chats is None:
         raise TypeError("pdfposteriors(fsm::FSM, V_hats, C_hats) needs the state maps")
-    Cs = [c if isinstance(c, StateMap) else StateMap.from_matrix(c) for c in Chats]
+    # (a general sparse C_hat rides along as an argument of the generic entry; its FSM handle gets a placeholder map)
+    Cs = [c if isinstance(c, StateMap) else
+          (StateMap(np.zeros(c.shape[0] - 1, dtype=np.int64), c.numpdf) if isinstance(c, GeneralStateMap) else StateMap.from_matrix(c))
+          for c in Chats]
     parts = split_blocks(fsm, [c.shape[0] for c in Cs])
     cache, cf = {}, []
     for part, c in zip(parts, Cs):
@@ -339,8 +394,16 @@ def pdfposteriors(fsm, Vhats, Chats=None):
     rawunion of the batch -- or pdfposteriors2(cfsm, V_hats) (:164-180) when
     given a BatchedFSM/CompiledFSM.  Returns (gamma[B, P, N] probabilities,
     ttl[B]) as NumPy arrays, like the reference returns fresh arrays."""
+    Vh = [np.asarray(v.cpu() if hasattr(v, "cpu") else v) for v in Vhats]
+    if Chats is not None:  # general sparse maps that are one-hot after all take the fast kernels
+        Chats = [(c.one_hot() or c) if isinstance(c, GeneralStateMap) else c for c in Chats]
     bf = _as_batch(fsm, Chats)
-    V, lens = _unexpand(Vhats)
+    general_c = Chats is not None and any(isinstance(c, GeneralStateMap) for c in Chats)
+    un = None if (general_c or bf.semiring == "prob" or Vh[0].dtype == np.float64) else _unexpand(Vh)
+    if un is None:
+        # float64, ProbSemiring, a general C_hat, or V_hat that expand() did not make: the generic entry
+        return bf.pdfposteriors_generic(Vh, Chats if general_c else None)
+    V, lens = un
     g, ttl = bf.pdfposteriors(V, lens)
     return np.ascontiguousarray(g.transpose(0, 2, 1)), ttl
 
@@ -349,14 +412,14 @@ def alpharecursion(fsm, Vhats, Chats=None):
     """alpha-recursion (src/inference.jl:62-74) on C_hat * V_hat as pdfposteriors calls
     it (:150-152): the (sum S1) x (N+1) matrix state_A."""
     bf = _as_batch(fsm, Chats)
-    V, lens = _unexpand(Vhats)
+    V, lens = _need_expanded(Vhats)
     return bf.alpharecursion(V, lens)
 
 
 def betarecursion(fsm, Vhats, Chats=None):
     """beta-recursion (src/inference.jl:99-110): state_B."""
     bf = _as_batch(fsm, Chats)
-    V, lens = _unexpand(Vhats)
+    V, lens = _need_expanded(Vhats)
     return bf.betarecursion(V, lens)
 
 
@@ -364,7 +427,7 @@ def bestpath(fsm, Vhats, Chats=None):
     """bestpath (docs/src/inference.md:6; historical examples/demo.ipynb cell 23):
     per utterance the 0-based state sequence of the best path and its weight."""
     bf = _as_batch(fsm, Chats)
-    V, lens = _unexpand(Vhats)
+    V, lens = _need_expanded(Vhats)
     path, score = bf.viterbi(V, lens)
     return [path[b, : lens[b]].copy() for b in range(bf.B)], score
 
@@ -378,7 +441,7 @@ def maxstateposteriors(fsm, Vhats, Chats=None):
     bf = _as_batch(fsm, Chats)
     if bf.semiring != "tropical":
         raise TypeError("maxstateposteriors needs TropicalSemiring FSMs")
-    V, lens = _unexpand(Vhats)
+    V, lens = _need_expanded(Vhats)
     return bf.maxstateposteriors(V, lens)
 
 

@@ -37,7 +37,7 @@ def to_fsm(mm, g: GraphSpec, semiring: str = "log", dtype=np.float32):
     S = g.S
     I = np.concatenate([g.src, g.final_idx, [S]]).astype(np.int64)
     J = np.concatenate([g.dst, np.full(g.final_idx.size, S), [S]]).astype(np.int64)
-    V = np.concatenate([g.w, g.final_w, [0.0]]).astype(dtype)
+    V = np.concatenate([g.w, g.final_w, [1.0 if semiring == "prob" else 0.0]]).astype(dtype)  # (the final self loop: one(K))
     f = mm.FSM.__new__(mm.FSM)
     f.semiring = semiring
     f.labels = list(range(S))

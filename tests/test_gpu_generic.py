@@ -1,0 +1,116 @@
+"""GPU tests of the generic entry (mm_pdfposteriors_ex): the reference's pdfposteriors(fsm, V_hats, C_hats) over its whole
+argument space -- three semirings x two float types (test/test_linalg.jl:88-108), FSM{LogSemiring{Float64}}
+(test/test_fsms.jl:3-7), any sparse C_hat, any V_hat -- against the oracle's restatement of src/inference.jl:145-161."""
+import os
+
+import numpy as np
+import pytest
+
+import graphs
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    assert torch.cuda.is_available()
+    return torch
+
+
+def lin(g):
+    """a GraphSpec with probabilities in place of log-probabilities (ProbSemiring)"""
+    import copy
+
+    h = copy.copy(g)
+    h.init_w, h.w, h.final_w = np.exp(g.init_w), np.exp(g.w), np.exp(g.final_w)
+    return h
+
+
+def oracle_run(o, g, semiring, dtype, lhs, lens, s2p, P):
+    K = o.SEMIRINGS[semiring]
+    f = graphs.to_oracle(o, lin(g) if semiring == "prob" else g, semiring, dtype)
+    return o.pdfposteriors_batch(f, list(s2p), P, [l.astype(dtype) for l in lhs], [int(x) for x in lens]), K
+
+
+@pytest.mark.parametrize("semiring", ["log", "tropical", "prob"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_three_semirings_two_float_types(mm, wl, oracle, torch, semiring, dtype):
+    o, _ = oracle
+    g = wl.random_fsm(40, 6, 3.0, seed=1)
+    rng = np.random.default_rng(12)
+    B, N = 3, 11
+    lens = [11, 7, 4]
+    lhs = [rng.standard_normal((g.P, N)) for _ in range(B)]
+    if semiring == "prob":
+        lhs = [np.exp(x) for x in lhs]
+    (g_ref, t_ref), K = oracle_run(o, g, semiring, np.float64, lhs, lens, g.state2pdf, g.P)
+    gg = lin(g) if semiring == "prob" else g
+    fsm = wl.to_fsm(mm, gg, semiring, dtype)
+    cf = mm.compile(fsm, mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(*([cf] * B))
+    Vh = [mm.expand(x.astype(dtype), L, semiring) for x, L in zip(lhs, lens)]
+    gam, ttl = bf.pdfposteriors_generic(Vh)
+    assert gam.dtype == dtype and ttl.dtype == dtype
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    assert np.allclose(gam, g_ref, rtol=tol, atol=tol)
+    assert np.allclose(ttl, t_ref, rtol=tol, atol=tol)
+    for b, L in enumerate(lens):
+        assert (gam[b][:, L:] == 0).all()
+    # ... and through the reference's call shape, which picks the generic entry for float64 / prob by itself
+    if dtype == np.float64 or semiring == "prob":
+        g2, t2 = mm.pdfposteriors(bf, Vh)
+        assert np.array_equal(g2, gam) and np.array_equal(t2, ttl)
+
+
+@pytest.mark.parametrize("name", ["l2r3", "rand30", "rand30m"])
+def test_float64_against_the_dense_reference_fixtures(mm, wl, torch, name):
+    """FSM{LogSemiring{Float64}} on the device against the committed dense forward/backward numbers
+    (tests/golden/pin_*.npz: the reference test suite's own independent implementation, random emissions)."""
+    path = os.path.join(HERE, "golden", f"pin_{name}.npz")
+    z = np.load(path)
+    g = wl.load_npz_graph(path)
+    s2p, P = z["state2pdf"].astype(np.int32), int(z["P"])
+    cf = mm.compile(wl.to_fsm(mm, g, "log", np.float64), mm.statemap(s2p, P))
+    B = z["lhs"].shape[0]
+    Vh = [mm.expand(z["lhs"][b], int(z["lens"][b]), "log") for b in range(B)]
+    gam, ttl = mm.pdfposteriors(mm.batch(*([cf] * B)), Vh)
+    assert gam.dtype == np.float64
+    assert np.allclose(gam, z["gamma"], rtol=1e-9, atol=1e-12) and np.allclose(ttl, z["ttl"], rtol=1e-10)
+
+
+def test_general_state_map_and_arbitrary_vhat(mm, wl, oracle, torch):
+    """A C_hat with several weighted entries per row (a state that emits a mixture of pdfs) and matrices V_hat that
+    expand() did not make (finite values in the phony row, no padding): src/inference.jl:145-161 takes both."""
+    import scipy.sparse as sp
+
+    o, _ = oracle
+    K = o.LOG
+    g = wl.random_fsm(25, 5, 2.5, seed=4)
+    S1, P1, N1 = g.S + 1, g.P + 1, 9
+    rng = np.random.default_rng(3)
+    # C_hat: every state reads its own pdf with weight one and a second pdf with a random log weight; the final state the phony pdf
+    rows, cols, vals = [], [], []
+    for s in range(g.S):
+        rows += [s, s]
+        cols += [int(g.state2pdf[s]), int((g.state2pdf[s] + 1 + s % 3) % g.P)]
+        vals += [0.0, float(-rng.random() - 0.3)]
+        if cols[-1] == cols[-2]:
+            rows.pop(), cols.pop(), vals.pop()
+    rows.append(g.S), cols.append(g.P), vals.append(0.0)
+    Vh = [rng.standard_normal((P1, N1)) for _ in range(2)]
+    f = graphs.to_oracle(o, g)
+    C_or = o.csc_from_coo(rows, cols, np.asarray(vals), (S1, P1), K)
+    g_ref, t_ref = o.pdfposteriors(o.rawunion([f, f]), Vh, [C_or, C_or])
+    Cm = mm.GeneralStateMap(sp.csr_matrix((vals, (rows, cols)), shape=(S1, P1)), "log")
+    assert Cm.one_hot() is None
+    fsm = wl.to_fsm(mm, g, "log", np.float64)
+    for dtype, tol in ((np.float64, 1e-10), (np.float32, 3e-5)):
+        gam, ttl = mm.pdfposteriors(mm.rawunion(fsm, fsm), [v.astype(dtype) for v in Vh], [Cm, Cm])
+        assert gam.dtype == dtype
+        assert np.allclose(gam, g_ref, rtol=tol, atol=tol) and np.allclose(ttl, t_ref, rtol=tol, atol=tol)
+    # a general map that is one-hot after all is recognised and takes the fast kernels (float32, expand()'s V_hat)
+    one = mm.GeneralStateMap(sp.csr_matrix((np.zeros(S1), (np.arange(S1), np.append(g.state2pdf, g.P))), shape=(S1, P1)), "log")
+    assert one.one_hot() is not None

@@ -217,3 +217,48 @@ def test_fuzz_pairs_one_seed(mm, wl, oracle, torch):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main(1) == 0
+
+
+def test_engine_under_a_live_rccl_process_group(mm, wl, oracle, torch):
+    """The HIP engine inside a torch.distributed process ("nccl" = RCCL, one rank: what every rank of bench.py --gpus N
+    is): with an RCCL communicator alive HIP maps streams to hardware queues differently, and the two agents of the
+    pair kernels once shared a queue (5.7 instead of 3.2 ms per call).  The batch must still find a concurrent stream
+    pair, the step (pdfposteriors + the logZ all-reduce) must give the oracle's numbers.  Runs in a child process: the
+    process group must not leak into the other tests."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(HERE)
+    code = r"""
+import os, sys, importlib
+import numpy as np
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", RANK="0", WORLD_SIZE="1")
+import torch, torch.distributed as dist
+import __graft_entry__ as ge, graphs
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+x = torch.ones(4, device="cuda"); dist.all_reduce(x); torch.cuda.synchronize()
+mm = ge.load_package(); o, oc = ge.load_oracle()
+wl = importlib.import_module(mm.__name__ + ".workloads")
+g = wl.lfmmi_denominator(600, 40, seed=5)
+rng = np.random.default_rng(2)
+B, N = 6, 50
+V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+lens = np.array([50, 50, 31, 50, 12, 44], dtype=np.int32)
+cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+bf = mm.batch(*([cf] * B))
+k = bf.kernels()
+assert "mm_fbp_kernel_dir" in k and "no concurrent stream pair" not in k, k
+gam, ttl = bf.pdfposteriors(torch.from_numpy(V).cuda(), torch.from_numpy(lens).cuda())
+total = mm.dist.allreduce_logz(ttl)
+torch.cuda.synchronize()
+g_ref, t_ref = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V, lens, dtype=np.float64)
+assert np.abs(gam.cpu().numpy() - g_ref).max() < 2e-5
+assert np.allclose(ttl.cpu().numpy(), t_ref, rtol=1e-5, atol=1e-4)
+assert abs(float(total) - float(t_ref.sum())) < 1e-3
+dist.destroy_process_group()
+print("OK-DIST")
+""".replace("ROOT", repr(root))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK-DIST" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

@@ -118,6 +118,10 @@ size_t mm_batch_workspace_bytes(mm_batch_t batch, int64_t N);
  * An utterance with no accepting path (Z = 0) yields gamma = 0, ttl = -inf
  * (the reference yields NaN: src/inference.jl:158; guarded only in the dead
  * code at :198-200). */
+/* Streams: the call is asynchronous on `stream`.  Some batches run two kernels side by side (the forward and the backward
+ * agents of the pair kernels): they fork from `stream` into ONE pair of library-owned streams per process and device and
+ * join back into it -- two batches driven from two caller streams therefore take turns on that pair (ordering stays
+ * correct; independent calls on different streams do not overlap each other on these batches). */
 int mm_pdfposteriors_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t v_stride_n,
                          const int32_t *lens, int64_t N, float *gamma, int64_t g_stride_b, int64_t g_stride_n,
                          int64_t g_stride_p, float *ttl, void *stream);
@@ -211,9 +215,14 @@ int mm_batch_last_redo_count(mm_batch_t batch, void *stream, int64_t *n);
  * collective on the data path.  The only exchange is the total log-likelihood the LF-MMI loss consumes
  * (examples/test_cuda.jl:140-152 sums ttl_num / ttl_den over the utterances), offered here over RCCL so that a host
  * binding without torch.distributed (julia/MarkovModelsAMD.jl) has it too.
- * comm: an ncclComm_t of the calling process.  The library does not link RCCL: it resolves ncclAllReduce /
- * ncclAllGather in the RCCL the process has loaded already (the one `comm` came from), else in librccl.so.
- * Both calls are asynchronous on `stream`; MM_ERR_UNSUPPORTED if no RCCL can be found, MM_ERR_HIP if RCCL fails. */
+ * comm: an ncclComm_t of the calling process.  The library does not link RCCL and never opens one of its own (an
+ * ncclComm_t belongs to the RCCL build that made it): it resolves ncclAllReduce / ncclAllGather in the library handed
+ * over with mm_set_rccl, else among the process's global symbols.  Both calls are asynchronous on `stream`;
+ * MM_ERR_UNSUPPORTED if RCCL is not visible, MM_ERR_HIP if RCCL fails. */
+
+/* dl_handle: what dlopen() returned for the RCCL `comm` was made with (PyTorch loads its bundled librccl.so with local
+ * visibility; Libdl.dlopen in Julia likewise), or NULL to go back to the process's global symbols. */
+int mm_set_rccl(void *dl_handle);
 
 /* sum (device double[1]) = sum over ALL ranks of sum_b ttl[b], b < B_local (device float[B_local], the ttl output of
  * mm_pdfposteriors_f32), accumulated in float64: a one-block reduction and a one-element all-reduce. */

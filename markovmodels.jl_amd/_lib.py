@@ -41,6 +41,7 @@ SYMBOLS = [
     "mm_maxstateposteriors_f32",
     "mm_viterbi_f32",
     "mm_totalsum_f32",
+    "mm_set_rccl",
     "mm_allreduce_logz",
     "mm_allgather_ttl",
     "mm_debug_packed_product",
@@ -118,6 +119,8 @@ def _load():
     lib.mm_viterbi_f32.argtypes = [vp, fp, i64, i64, vp, i64, vp, i64, fp, vp, i64, vp]
     lib.mm_totalsum_f32.restype = C.c_int
     lib.mm_totalsum_f32.argtypes = [vp, i64, C.c_int, fp, vp]
+    lib.mm_set_rccl.restype = C.c_int
+    lib.mm_set_rccl.argtypes = [vp]
     lib.mm_allreduce_logz.restype = C.c_int
     lib.mm_allreduce_logz.argtypes = [vp, vp, i64, vp, vp]
     lib.mm_allgather_ttl.restype = C.c_int

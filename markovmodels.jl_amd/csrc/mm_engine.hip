@@ -1858,11 +1858,16 @@ namespace {
 typedef int (*nccl_allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef int (*nccl_allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
 enum { MM_NCCL_SUM = 0, MM_NCCL_FLOAT32 = 7, MM_NCCL_FLOAT64 = 8 };  // rccl.h: ncclSum, ncclFloat32, ncclFloat64
+// The RCCL the caller's communicators belong to: handed over with mm_set_rccl (a dlopen handle), else whatever the
+// process exposes globally.  The library never opens an RCCL of its own: an ncclComm_t made by one build of RCCL passed
+// to another is undefined behaviour.
+void *g_rccl_handle = nullptr;
+std::mutex g_rccl_lock;
 void *rccl_symbol(const char *name) {
-    if (void *f = dlsym(RTLD_DEFAULT, name)) return f;  // the RCCL already in the process (torch's, AMDGPU.jl's, ...)
-    static void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    return lib ? dlsym(lib, name) : nullptr;
+    std::lock_guard<std::mutex> guard(g_rccl_lock);
+    if (g_rccl_handle)
+        if (void *f = dlsym(g_rccl_handle, name)) return f;
+    return dlsym(RTLD_DEFAULT, name);
 }
 __global__ void mm_sum_f64_kernel(const float *x, long long n, double *out) {
     __shared__ double part[16];
@@ -1879,10 +1884,16 @@ __global__ void mm_sum_f64_kernel(const float *x, long long n, double *out) {
 }
 }  // namespace
 
+int mm_set_rccl(void *dl_handle) {
+    std::lock_guard<std::mutex> guard(g_rccl_lock);
+    g_rccl_handle = dl_handle;
+    return MM_OK;
+}
+
 int mm_allreduce_logz(void *comm, const float *ttl, int64_t B_local, double *sum, void *stream) {
     if (!comm || !sum || B_local < 0 || (B_local > 0 && !ttl)) return fail(MM_ERR_INVALID, "mm_allreduce_logz: bad argument");
-    static nccl_allreduce_fn allreduce = reinterpret_cast<nccl_allreduce_fn>(rccl_symbol("ncclAllReduce"));
-    if (!allreduce) return fail(MM_ERR_UNSUPPORTED, "mm_allreduce_logz: no RCCL in this process and no librccl.so");
+    const nccl_allreduce_fn allreduce = reinterpret_cast<nccl_allreduce_fn>(rccl_symbol("ncclAllReduce"));
+    if (!allreduce) return fail(MM_ERR_UNSUPPORTED, "mm_allreduce_logz: RCCL is not visible in this process: call mm_set_rccl with the handle of the RCCL `comm` came from");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(mm_sum_f64_kernel, dim3(1), dim3(1024), 0, st, ttl, (long long)B_local, sum);
     HIP_TRY(hipGetLastError());
@@ -1892,8 +1903,8 @@ int mm_allreduce_logz(void *comm, const float *ttl, int64_t B_local, double *sum
 
 int mm_allgather_ttl(void *comm, const float *ttl, int64_t B_max, float *all, void *stream) {
     if (!comm || !ttl || !all || B_max < 1) return fail(MM_ERR_INVALID, "mm_allgather_ttl: bad argument");
-    static nccl_allgather_fn allgather = reinterpret_cast<nccl_allgather_fn>(rccl_symbol("ncclAllGather"));
-    if (!allgather) return fail(MM_ERR_UNSUPPORTED, "mm_allgather_ttl: no RCCL in this process and no librccl.so");
+    const nccl_allgather_fn allgather = reinterpret_cast<nccl_allgather_fn>(rccl_symbol("ncclAllGather"));
+    if (!allgather) return fail(MM_ERR_UNSUPPORTED, "mm_allgather_ttl: RCCL is not visible in this process: call mm_set_rccl with the handle of the RCCL `comm` came from");
     if (allgather(ttl, all, size_t(B_max), MM_NCCL_FLOAT32, comm, static_cast<hipStream_t>(stream)) != 0)
         return fail(MM_ERR_HIP, "mm_allgather_ttl: ncclAllGather failed");
     return MM_OK;

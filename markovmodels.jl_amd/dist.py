@@ -101,6 +101,9 @@ class RcclComm:
             _fields_ = [("internal", C.c_char * self.UID_BYTES)]
 
         self._lib = self._rccl()
+        from . import _lib
+
+        _lib.check(_lib.lib.mm_set_rccl(C.c_void_p(self._lib._handle)))  # the engine's collectives use THIS RCCL
         self._lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
         self.world, self.rank = int(world), int(rank)
         u = Uid()

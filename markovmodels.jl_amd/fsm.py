@@ -7,6 +7,7 @@ OpenFst-text readers convert from the reference's 1-based files.
 from __future__ import annotations
 
 import json
+import re
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -125,8 +126,8 @@ class FSM:
         Returns (fsm, state2pdf[S] 0-based, number of pdfs)."""
         init, arcs, final, pdf, S = [], [], [], {}, 0
 
-        def num(tok: str) -> float:  # (Julia prints a Float32 with an exponent as 1.0f-5)
-            return float(tok.replace("f", "e"))
+        def num(tok: str) -> float:  # (Julia prints a Float32 with an exponent as 1.0f-5, infinities as Inf / -Inf)
+            return float(re.sub(r"(?<=\d)f(?=[-+]?\d)", "e", tok))
 
         for line in text.splitlines():
             t = line.split()
@@ -170,7 +171,20 @@ class FSM:
         ii, iw, src, dst, w, fi, fw = self.arc_lists()
 
         def num(x) -> str:
-            return str(self.dtype.type(-x))  # (numpy prints the shortest digits that give the value back)
+            # numpy prints the shortest digits that give the value back, like Julia; the spellings that differ are mapped to
+            # Julia's: a Float32 with an exponent is 1.0f-5 (numpy: 1e-05), infinities are Inf / -Inf
+            v = self.dtype.type(-x)
+            if not np.isfinite(v):
+                return "NaN" if np.isnan(v) else ("Inf" if v > 0 else "-Inf")
+            s = str(v)
+            if "e" not in s and abs(v) >= 1e6:  # (Julia switches to the exponent form at 1e6, numpy at 1e16)
+                s = np.format_float_scientific(v, unique=True, trim="0")
+            if "e" in s:
+                mant, ex = s.split("e")
+                if "." not in mant:
+                    mant += ".0"
+                s = mant + ("f" if self.dtype == np.float32 else "e") + str(int(ex))
+            return s
 
         out = []
         for i, v in zip(ii, iw):

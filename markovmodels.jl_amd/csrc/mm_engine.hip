@@ -139,6 +139,8 @@ struct mm_fsm_s {
     bool split_tried = false;
     RowVariant *wrows[2] = {nullptr, nullptr};  // wave forms (mm_kernel_wave.hip)
     bool wave_tried = false;
+    RowVariant *vrow = nullptr;                 // Viterbi form (mm_kernel_vit.hip)
+    bool vit_tried = false;
     // what the generic path (mm_generic.hip: any semiring, float32 or float64) works on: both matrices and alpha_hat as
     // they were handed over, in double, natural units (log weights for Log / Tropical, probabilities for Prob)
     FsmGenView gen;
@@ -209,6 +211,8 @@ struct mm_batch_s {
     int row_ka[2] = {0, 0}, row_nwc[2] = {1, 1}, row_slotrows[2] = {0, 0};
     bool pairs_ok = false;                       // one FSM shared by all utterances, in pair form: the pair kernels can run
     int pair_ka = 0, pair_nwc = 1, pair_slotrows = 0;
+    bool vit_ok = false;   // every FSM has its Viterbi form: mm_vit_kernel + mm_vit_backtrace_kernel can run
+    int vit_nseg = 0, vit_arcs = 0;
     bool wave_ok = false;  // every FSM has its wave forms: the wave kernel can run (small graphs that are off the linear paths)
     int wave_nseg = 0;
     int pair_H = 1;        // workgroups per team: 1 = the pair kernels proper, > 1 = the split pair kernels
@@ -778,7 +782,7 @@ static int upload_row_variant(mm_fsm_t f, RowVariant *v, int dir, float thr, boo
     }
     const size_t o_w = bl.add(v->g.w), o_a = bl.add(v->g.addr), o_s = bl.add(v->g.slots), o_sc = bl.add(v->g.sched);
     const size_t o_ptr = bl.add(v->g.rowptr), o_col = bl.add(v->g.col), o_cw = bl.add(v->g.cw);
-    const size_t o_pdf = bl.add(v->g.rowpdf), o_pse = bl.add(v->g.pdfse), o_init = bl.add(v->init);
+    const size_t o_pdf = bl.add(v->g.rowpdf), o_pse = bl.add(v->g.pdfse), o_init = bl.add(v->init), o_ord = bl.add(v->g.order);
     int rc = upload(bl, &v->blob);
     if (rc) return rc;
     char *base = static_cast<char *>(v->blob);
@@ -793,6 +797,7 @@ static int upload_row_variant(mm_fsm_t f, RowVariant *v, int dir, float thr, boo
     d.rowpdf = reinterpret_cast<const unsigned short *>(base + o_pdf);
     d.pdfse = reinterpret_cast<const unsigned short *>(base + o_pse);
     d.init = reinterpret_cast<const float *>(base + o_init);
+    d.order = reinterpret_cast<const int *>(base + o_ord);
     d.KA = v->g.KA;
     d.NWC = v->g.NWC;
     d.nslotrows = v->g.nslotrows;
@@ -867,6 +872,45 @@ static int pair_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
     }
     f->prows[0] = rv[0];
     f->prows[1] = rv[1];
+    *ok = true;
+    return MM_OK;
+}
+
+// the Viterbi form of a tropical FSM (built once; *ok = false if it does not fit: a row of more than 255 arcs, more than 8
+// segments per wave, more than 16382 states)
+static int vit_variant(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
+    *ok = f->vrow != nullptr;
+    if (*ok || f->vit_tried) return MM_OK;
+    f->vit_tried = true;
+    if (f->semiring != MM_TROPICAL || f->P1 > 256) return MM_OK;
+    RowPackOpts opt;
+    opt.rs = 65536;
+    opt.nwc_max = 15;
+    opt.ka_max = 24;  // (6 segments per wave: 8 do not fit the registers of a 16-wave workgroup without spills)
+    opt.copies = 1;
+    opt.acap_force = 4;
+    opt.seg_stride = 4;
+    opt.log_weights = true;
+    opt.keep_order = true;
+    opt.finish_cost = 4;
+    for (float &x : opt.group_speed) x = 1.f;
+    RowVariant *v = new RowVariant();
+    const std::vector<int32_t> none;
+    if (!make_rows(f->S1, f->mat[0].rowptr, f->mat[0].col, f->mat[0].val, f->s2p, f->P1, false, none, opt, v->g)) {
+        delete v;
+        return MM_OK;
+    }
+    v->init.resize(size_t(f->S1));
+    for (int64_t i = 0; i < f->S1; ++i) v->init[i] = f->init[v->g.order[i]];
+    if (dbg.verbose)
+        fprintf(stderr, "[mm] Viterbi form: %d waves, %d segments (at most %d per wave), arcs/slots %.3f\n", v->g.NWC, v->g.nslotrows - 2,
+                v->g.KA / 4, v->g.pad_eff);
+    int rc = upload_row_variant(f, v, 0, 0.f, false);
+    if (rc) {
+        delete v;
+        return rc;
+    }
+    f->vrow = v;
     *ok = true;
     return MM_OK;
 }
@@ -1045,7 +1089,7 @@ int mm_fsm_destroy(mm_fsm_t f) {
         if (kv.second->blob) (void)hipFree(kv.second->blob);
         delete kv.second;
     }
-    for (RowVariant *rv : {f->rows[0], f->rows[1], f->prows[0], f->prows[1], f->wrows[0], f->wrows[1], f->srows[0][0], f->srows[0][1], f->srows[0][2], f->srows[0][3],
+    for (RowVariant *rv : {f->rows[0], f->rows[1], f->prows[0], f->prows[1], f->wrows[0], f->wrows[1], f->vrow, f->srows[0][0], f->srows[0][1], f->srows[0][2], f->srows[0][3],
                            f->srows[1][0], f->srows[1][1], f->srows[1][2], f->srows[1][3]})
         if (rv) {
             if (rv->blob) (void)hipFree(rv->blob);
@@ -1396,6 +1440,22 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             }
         }
     }
+    if (h->semiring == MM_TROPICAL && h->dbg.kernel != DebugOpts::K_ITEM) {
+        h->vit_ok = true;
+        for (int64_t b = 0; b < B && h->vit_ok; ++b) {
+            bool ok = false;
+            int rc = vit_variant(fsms[b], h->dbg, &ok);
+            if (rc) {
+                delete h;
+                return rc;
+            }
+            h->vit_ok = ok;
+            if (ok) {
+                h->vit_nseg = std::max(h->vit_nseg, fsms[b]->vrow->g.KA / 4);
+                h->vit_arcs = std::max(h->vit_arcs, int(fsms[b]->vrow->g.col.size()));
+            }
+        }
+    }
     // wave kernel: small graphs that none of the linear-domain kernels takes (deep left-to-right graphs: numerators)
     if (h->semiring == MM_LOG && !h->rows_ok && !h->pairs_ok &&
         (h->dbg.kernel == DebugOpts::K_WAVE ||
@@ -1432,6 +1492,7 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             u.init_f = qv[0]->d_init_f;
             u.map_bf = qv[1]->d_map_bf;
         }
+        if (h->vit_ok) u.rv = f->vrow->rdev;
         if (h->wave_ok)
             for (int d = 0; d < 2; ++d) u.rw[d] = f->wrows[d]->rdev;
         if (h->pairs_ok && h->pair_H == 1)
@@ -1596,7 +1657,8 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
             s = exact;
         }
     } else if (entry == 1) {  // mm_viterbi_f32
-        s = "mm_tropical_kernel + mm_backtrace_kernel";
+        s = h->vit_ok ? "mm_vit_kernel + mm_vit_backtrace_kernel (mm_tropical_kernel + mm_backtrace_kernel when the int32 back-pointers are asked for)"
+                      : "mm_tropical_kernel + mm_backtrace_kernel";
     } else {
         return fail(MM_ERR_INVALID, "mm_batch_kernels: unknown entry");
     }
@@ -1944,7 +2006,9 @@ int mm_viterbi_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const
     if (path_stride_b < N) return fail(MM_ERR_DIM, "mm_viterbi_f32: path_stride_b < N");
     RunParams p{};
     if (!bp) {
-        rc = ensure_ws(h, align_up(size_t(h->total_states) * size_t(N + 1) * 4, 256), stream);
+        // (int32 rows for the item kernel, or one-byte rows padded to 1 KB for the row-lane kernels)
+        rc = ensure_ws(h, std::max(align_up(size_t(h->total_states) * size_t(N + 1) * 4, 256),
+                                   size_t(h->B) * size_t(N + 1) * size_t((h->max_S1p + 1023) & ~1023)), stream);
         if (rc) return rc;
         bp = static_cast<int32_t *>(h->ws);
         bp_stride_n = h->total_states;
@@ -1964,6 +2028,18 @@ int mm_viterbi_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const
     p.path = path;
     p.path_stride_b = path_stride_b;
     p.score = score;
+    if (h->vit_ok && p.stop_at_len) {  // (internal back-pointers: the compact form)
+        VitLaunch vl;
+        vl.B = h->B;
+        vl.nseg = h->vit_nseg;
+        vl.max_P1 = h->max_P1;
+        vl.max_S1p = h->max_S1p;
+        vl.max_arcs = h->vit_arcs;
+        vl.bp_row = (h->max_S1p + 1023) & ~1023;  // bytes of a row of one-byte back-pointers, padded to 1 KB
+        RunParams q = p;
+        q.bp_stride_n = vl.bp_row;
+        return mm_launch_viterbi(vl, q, static_cast<hipStream_t>(stream));
+    }
     rc = launch_tropical(h, p, stream);
     if (rc) return rc;
     const int bt = 64;

@@ -73,6 +73,13 @@ struct WaveLaunch {
 };
 int mm_launch_wave(const WaveLaunch &wl, const RunParams &p, hipStream_t stream);
 
+// ---- Viterbi on the row-lane form (mm_vit_tu.hip)
+struct VitLaunch {
+    int64_t B = 0;
+    int nseg = 0, max_P1 = 0, max_S1p = 0, max_arcs = 0, bp_row = 0;
+};
+int mm_launch_viterbi(const VitLaunch &vl, const RunParams &p, hipStream_t stream);
+
 // ---- quad kernels (mm_quad_tu.hip)
 struct QuadLaunch {
     int64_t B = 0;

@@ -1,0 +1,237 @@
+// mm_kernel_vit.hip -- Viterbi for gfx950 on the row-lane form: the tropical alpha-recursion (src/inference.jl:62-74 with
+// K = TropicalSemiring) with compact back-pointers, and a back-trace that streams them through LDS.  bestpath is
+// documented (docs/src/inference.md:6) and absent from src/ at this commit (src/MarkovModels.jl:56-57; historical use
+// examples/demo.ipynb cell 23); the specification of the back-pointers is the oracle's: the lowest source state among
+// the maximisers, none (-1) if the maximum is zero(K).
+//
+// Against the item kernel (mm_tropical_kernel, mm_kernels.hip: 2.66 ms on BASELINE config 5 + 0.61 ms for a back-trace in
+// which one lane chased 1000 pointers through HBM):
+//   * the graph sits in registers in the row-lane form of mm_rows.h (RowPackOpts::acap_force / seg_stride / keep_order:
+//     at most 4 arcs of a row per lane and segment, in the order of the row), 15 compute waves + a service wave for the
+//     emissions, ONE workgroup barrier per frame; a max-plus row is 4 gathers, 4 adds, 3 compare-selects -- no
+//     transcendental, no normaliser (the reference's plain float adds: the scores are bit-identical to the CPU
+//     restatement), for rows of more than 4 arcs a lane-group reduction by DPP under the same tie rule;
+//   * a back-pointer is the NUMBER OF THE ARC in its row (rows have their arcs by ascending source state, so the first
+//     maximum is the one the tie rule wants): one byte per state and frame, 255 = none -- a quarter of the int32 rows,
+//     which were the algorithmic traffic of this path;
+//   * back-trace: one workgroup per utterance streams the byte rows through a double-buffered LDS ring, 8 KB per hop of the
+//     chase hidden behind the copy of the next chunk; the hop itself is three LDS reads (arc number, row pointer, source).
+// Graphs with a row of more than 256 arcs, more than 8 segments per wave or more than 16383 states stay on the item kernel,
+// and so does a call that asks for the int32 back-pointer table (mm_viterbi_f32 with bp != NULL).
+#pragma once
+#include "mm_kernel_rows.hip"
+
+namespace mm {
+
+#define MM_VIT_NWC 15
+#define MM_VIT_ESZ 1056u  // bytes of an emission buffer (256 pdfs + the "no row" slot)
+
+template <int NSEG, int NJ, int VSZ>  // NSEG segments per wave in registers; NJ * 64 >= P + 1; VSZ bytes of a state vector
+__global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
+    extern __shared__ float lds[];
+    constexpr int KA = 4 * NSEG;
+    constexpr unsigned EMB = 2u * VSZ;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool service = wave == MM_VIT_NWC;
+    const int b = blockIdx.x;
+    const UttDesc &u = p.utts[b];
+    const RowU r = uni(u.rv);
+    const int S1 = r.rows, P1 = uni(u.P1), P = P1 - 1;
+    int len = uni(p.lens ? p.lens[b] : p.N);
+    len = len < 0 ? 0 : (len > p.N ? p.N : len);
+    const int NF = len + 1;
+    const float *Vb = p.V + (long long)b * p.vsb;
+    // [utterance][frame - 1][bp_stride_n bytes] arc numbers (rows padded to 256 bytes: a chunk of frames is one aligned block)
+    unsigned char *bpk = reinterpret_cast<unsigned char *>(p.bp) + (long long)b * (p.N + 1) * p.bp_stride_n;
+    if (lds_addr_of(lds) != 0u) __builtin_trap();
+
+    // ---- the wave's rows: registers
+    float w[KA];
+    unsigned a[KA], s0[NSEG];
+    const bool mine_w = !service && wave < r.NWC;
+    const RowSched &sc = r.sched[mine_w ? wave : 0];
+    const unsigned long long lgw =
+        mine_w ? ((unsigned long long)(unsigned)uni((int)(sc.lg >> 32)) << 32) | (unsigned)uni((int)sc.lg) : 0ull;
+    const int nseg = mine_w ? uni((int)(sc.nslots & 0xffffu)) : 0, slot0 = mine_w ? uni((int)sc.slot0) : 0;
+    {
+        const auto wp = as_global(r.w);
+        const auto ap = as_global(r.addr);
+        const auto sp = as_global(r.slots);
+        const int nt = 64 * r.NWC, col = (mine_w ? wave : 0) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < KA; ++k) {
+            const bool have = mine_w && k < r.KA;
+            w[k] = have ? wp[k * nt + col] : MM_NINF;
+            a[k] = have ? ap[k * nt + col] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < NSEG; ++i)  // (segments the wave does not have: the "no row" position and emission slot)
+            s0[i] = i < nseg ? sp[(slot0 + i) * 64 + lane] : (4u * (unsigned)S1) | ((4u * (unsigned)((P1 + 3) & ~3)) << 16);
+    }
+    const unsigned sub = (unsigned)lane & ((1u << 6) - 1u);
+    for (unsigned q = 4u * tid; q < 2u * VSZ + 2u * MM_VIT_ESZ + 4u * NJ * 256u; q += 4096u) ldsw(q, MM_NINF);
+    const unsigned trash4 = 4u * (unsigned)S1;
+    // emissions (expand(), src/inference.jl:54-60; natural log like the reference's tropical values), by the service wave:
+    // raw values by LDS-DMA FOUR frames ahead (a frame is ~0.5 us, a load from HBM 1-2 us: fetched one frame ahead the
+    // whole workgroup waited for the service wave's load every frame), staged a frame ahead
+    constexpr unsigned RAWB = EMB + 2u * MM_VIT_ESZ;  // [4][NJ * 256 bytes]
+    auto em_fetch = [&](int f) __attribute__((always_inline)) { row_dma_em<NJ>(RAWB + (unsigned)(f & 3) * (NJ * 256u), Vb, p.vsn, f, p.N, P, lane); };
+    auto em_stage = [&](int f, int par) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int q = lane + 64 * j;
+            const float rawv = ldsr(RAWB + (unsigned)(f & 3) * (NJ * 256u) + 256u * j + 4u * lane);
+            float v;
+            if (q < P) v = f <= len ? rawv : MM_NINF;
+            else v = f <= len ? MM_NINF : 0.f;
+            if (q <= P) ldsw(EMB + (unsigned)par * MM_VIT_ESZ + 4u * q, v);
+        }
+    };
+    __syncthreads();
+    if (service) {
+        for (int f = 1; f <= 4; ++f) em_fetch(f);
+        MM_ROW_VMCNT(0);
+        em_stage(1, 1);
+        em_fetch(5);
+    }
+    __syncthreads();
+    // frame 1: alpha_hat (*) lhs[:,1]   (src/inference.jl:68)
+    for (int i = tid; i < S1; i += 1024)
+        ldsw(VSZ + 4u * i, as_global(r.init)[i] + ldsr(EMB + MM_VIT_ESZ + 4u * as_global(r.rowpdf)[i]));
+    if (service) {
+        em_stage(2, 0);
+        em_fetch(6);
+    }
+    __syncthreads();
+
+    auto step = [&](auto RDc, int n) __attribute__((always_inline)) {
+        constexpr int RD = decltype(RDc)::value, WR = 1 - RD;  // RD = parity of frame n - 1
+        if (service) {
+            // frame n + 1 was requested at step n - 3: at most the NJ DMAs of each of the 3 later requests are in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NJ) : "memory");
+            em_stage(n + 1, RD);
+            em_fetch(n + 5);  // (its buffer, frame (n + 1) & 3, has just been read)
+        } else {
+            unsigned char *row = bpk + (long long)(n - 1) * p.bp_stride_n;
+            // a block of segments at a time: its gathers and emission reads in flight together, then straight-line code
+            // (all 8 at once need more registers than a wave of a 16-wave workgroup has)
+            constexpr int BS = NSEG % 4 == 0 ? 4 : 3;  // segments of a block (NSEG = 4, 6, 8)
+            static_for<0, NSEG / BS>([&](auto H) __attribute__((always_inline)) {
+                constexpr int h0 = BS * decltype(H)::value;
+                float xs[4 * BS], es[BS];
+#pragma unroll
+                for (int i = 0; i < BS; ++i) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xs[4 * i + q] = ldsr(a[4 * (h0 + i) + q] + (unsigned)RD * VSZ);
+                    es[i] = ldsr(EMB + (unsigned)WR * MM_VIT_ESZ + (s0[h0 + i] >> 16));
+                }
+                float best[BS];
+                int arg[BS];
+#pragma unroll
+                for (int i = 0; i < BS; ++i) {
+                    // T_hat[i, j] (*) A[i, n-1], strict '>' over ascending source states: the lowest source among the maximisers
+                    float bv = xs[4 * i] + w[4 * (h0 + i)];
+                    int bk = 0;
+#pragma unroll
+                    for (int q = 1; q < 4; ++q) {
+                        const float v = xs[4 * i + q] + w[4 * (h0 + i) + q];
+                        bk = v > bv ? q : bk;
+                        bv = v > bv ? v : bv;
+                    }
+                    best[i] = bv;
+                    arg[i] = bk;
+                }
+                if (((lgw >> (4 * h0)) & ((1ull << (4 * BS)) - 1ull)) != 0ull) {  // rows split over 1 << lg lanes: lane `s` of the group holds arcs s, s + g, ...
+#pragma unroll
+                    for (int i = 0; i < BS; ++i) {
+                        const int lg = (int)((lgw >> (4 * (h0 + i))) & 15ull);
+                        if (lg) {
+                            arg[i] = (int)(sub & ((1u << lg) - 1u)) + (arg[i] << lg);
+                            trop_grp_reduce(best[i], arg[i], lg);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < BS; ++i) {
+                    const unsigned pos4 = s0[h0 + i] & 0xffffu;
+                    ldsw(pos4 + (unsigned)WR * VSZ, best[i] + es[i]);  // (*) lhs[:, n]   (:70-71)
+                    if (pos4 != trash4) row[pos4 >> 2] = best[i] > MM_NINF ? (unsigned char)arg[i] : (unsigned char)255;
+                }
+            });
+        }
+        __syncthreads();
+    };
+    for (int n = 2; n <= NF; n += 2) {
+        step(std::integral_constant<int, 1>{}, n);
+        if (n + 1 <= NF) step(std::integral_constant<int, 0>{}, n + 1);
+    }
+    if (tid == 0) p.score[b] = ldsr((unsigned)(NF & 1) * VSZ + 4u * (unsigned)r.fpos);
+}
+
+// Back-trace: from the phony final state at frame len + 1 (historical bestpath, examples/demo.ipynb cell 23).  The byte
+// rows of the frames travel to LDS in chunks of R frames, double buffered, by LDS-DMA of waves 1..7 (everything of a chunk
+// in flight at once: the copy is bound by bandwidth, not by the latency of a load); wave 0 chases the chunk that is
+// there.  CSRL: the graph's row pointers and sources (positions) are in LDS as well, a hop is three LDS reads.
+// LDS: ring [2][R][RSB] bytes (RSB = the row padded to 256 bytes), then [rowptr (S1 + 1) u32][col (arcs) u16].
+template <bool CSRL>
+__global__ void __launch_bounds__(512) mm_vit_backtrace_kernel(RunParams p, int R, int RSB) {
+    extern __shared__ float lds[];
+    const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6;
+    const UttDesc &u = p.utts[b];
+    const RowDev &r = u.rv;
+    const int S1 = r.rows;
+    int len = p.lens ? p.lens[b] : p.N;
+    len = len < 0 ? 0 : (len > p.N ? p.N : len);
+    int *path = p.path + (long long)b * p.path_stride_b;
+    for (int n = len + tid; n < p.N; n += NT) path[n] = -1;
+    if (!(p.score[b] > MM_NINF)) {
+        for (int n = tid; n < len; n += NT) path[n] = -1;
+        return;
+    }
+    if (lds_addr_of(lds) != 0u) __builtin_trap();
+    const unsigned char *bpk = reinterpret_cast<const unsigned char *>(p.bp) + (long long)b * (p.N + 1) * p.bp_stride_n;  // (bp_stride_n == RSB)
+    const int arcs = r.rowptr[S1];
+    const unsigned ringb = 2u * (unsigned)R * (unsigned)RSB;
+    unsigned *lrp = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(lds) + ringb);
+    unsigned short *lcol = reinterpret_cast<unsigned short *>(lrp + S1 + 1);
+    if (CSRL) {
+        for (int i = tid; i <= S1; i += NT) lrp[i] = (unsigned)r.rowptr[i];
+        for (int i = tid; i < arcs; i += NT) lcol[i] = (unsigned short)r.col[i];
+    }
+    // chunk `hi` holds frames hi - R + 1 .. hi (frame f at row f - 1 of bpk: ONE block of R * RSB bytes, a multiple of 1 KB)
+    // in slot buf of the ring, frame f at ring row f - (hi - R + 1); rows of frames < 1 are not copied
+    auto copy_chunk = [&](int hi, int buf) {
+        if (wave == 0) return;
+        const int lo = hi - R + 1 < 1 ? 1 : hi - R + 1;  // first frame whose row exists
+        const unsigned char *src0 = bpk + (long long)(lo - 1) * RSB;
+        const unsigned dst0 = (unsigned)buf * (unsigned)R * (unsigned)RSB + (unsigned)(lo - (hi - R + 1)) * (unsigned)RSB;
+        const int nd = (hi - lo + 1) * (RSB >> 10) + ((((hi - lo + 1) * RSB) & 1023) ? 1 : 0);  // 1 KB DMAs (RSB is a multiple of 256)
+        for (int d = wave - 1; d < nd; d += NW - 1) dma_b128(src0 + 1024ll * d + 16 * lane, dst0 + 1024u * (unsigned)d);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    int s = r.fpos;  // position (internal numbering) of the current state; the chase starts at frame len + 1
+    copy_chunk(len + 1, 0);
+    __syncthreads();
+    int cidx = 0;
+    for (int hi = len + 1; hi >= 2; hi -= R, ++cidx) {
+        if (hi - R >= 2) copy_chunk(hi - R, (cidx + 1) & 1);
+        if (tid == 0) {
+            const unsigned char *cur = reinterpret_cast<const unsigned char *>(lds) + (size_t)(cidx & 1) * R * RSB;
+            for (int k = 0; k < R; ++k) {
+                const int f = hi - k;  // the frame whose back-pointer is followed: state at f -> state at f - 1
+                if (f < 2) break;
+                const unsigned kk = cur[(R - 1 - k) * RSB + s];
+                const unsigned rp = CSRL ? lrp[s] : (unsigned)r.rowptr[s];
+                s = CSRL ? (int)lcol[rp + kk] : r.col[rp + kk];
+                path[f - 2] = s;  // (the POSITION: a store the chase does not wait for; a load of order[s] here stalled every hop)
+            }
+        }
+        __syncthreads();
+    }
+    // positions -> original states, by everybody
+    for (int n = tid; n < len; n += NT) path[n] = r.order[path[n]];
+}
+
+}  // namespace mm

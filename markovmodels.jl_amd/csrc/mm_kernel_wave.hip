@@ -42,7 +42,8 @@ namespace mm {
 #define MM_WAVE_OFF(buf) (MM_WAVE_UM(4) + (unsigned)(buf) * 16u)                                                 // {own, partner} offsets of a step (doubles)
 #define MM_WAVE_SYNC MM_WAVE_OFF(4)
 #define MM_WAVE_ZZ (MM_WAVE_SYNC + 16u)   // the waves' minima of the per-frame log2 normalisers (doubles)
-#define MM_WAVE_SLICE (MM_WAVE_ZZ + 8u * MM_WAVE_NWD + 16u)
+#define MM_WAVE_RAW(k) (MM_WAVE_ZZ + 8u * MM_WAVE_NWD + 16u + (unsigned)(k) * 1024u)  // raw emissions of 4 frames in flight (LDS-DMA)
+#define MM_WAVE_SLICE MM_WAVE_RAW(4)
 
 __device__ __forceinline__ float wave_sum_fixed(float v) {  // the same tree in every run and in every lane's view
     v += dpp_mov<MM_DPP_XOR1>(v);
@@ -150,25 +151,24 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 1)) mm_wave_kernel(RunPar
     const int tA = DIR ? NF - m : m;
     auto frame_of = [&](int t) __attribute__((always_inline)) { return DIR ? NF + 1 - t : t; };
     // emissions of frame f into EM(par): expand() (src/inference.jl:54-60) in the log2 domain, zero(K) = MM_WAVE_NEG
-    float raw[NJ];
-    auto em_fetch = [&](int f) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) raw[j] = em_load_raw(Vb, p.vsn, f, p.N, P, lane + 64 * j);
-    };
+    // (service wave) raw values by LDS-DMA FOUR steps ahead -- a step is ~1 us, a load from HBM up to 2: fetched one step
+    // ahead, the agent waited for the service wave's load every step -- staged a step ahead
+    auto em_fetch = [&](int f) __attribute__((always_inline)) { row_dma_em<NJ>(base + MM_WAVE_RAW(f & 3), Vb, p.vsn, f, p.N, P, lane); };
     auto em_stage = [&](int f, int par) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int q = lane + 64 * j;
-            float v = em_value(raw[j], f, len, P, q);
+            float v = em_value(ldsr(base + MM_WAVE_RAW(f & 3) + 256u * j + 4u * lane), f, len, P, q);
             v = v > MM_WAVE_NEG ? v : MM_WAVE_NEG;
             if (q <= P) ldsw(base + MM_WAVE_EM(par) + 4u * q, v);
         }
     };
     // ---- step 1: the initial vector (the emissions are staged by the agent's first wave)
     if (service) {
-        em_fetch(frame_of(1));
+        for (int t = 1; t <= 4; ++t) em_fetch(frame_of(t));
+        MM_ROW_VMCNT(0);
         em_stage(frame_of(1), 1);
-        em_fetch(frame_of(2));
+        em_fetch(frame_of(5));
     }
     agent_sync();
     double cum = 0.0;     // C_t (forward) / D_t (backward): what the vector of step t lacks to its log2 value
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 1)) mm_wave_kernel(RunPar
     }
     if (service) {
         em_stage(frame_of(2), 0);
-        em_fetch(frame_of(3));
+        em_fetch(frame_of(6));
     }
     agent_sync();
     Mprev = vec_max(MM_WAVE_YM(1));
@@ -288,8 +288,11 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 1)) mm_wave_kernel(RunPar
         if (service) {
             // (what was fetched during the previous step is consumed BEFORE anything new goes to memory: the compiler waits
             // for vmcnt(0) at the first use in a loop iteration, which would include stores issued just before)
+            // (the frame of step t + 1 was requested at step t - 3: of what is in flight only the youngest 3 NJ operations
+            // may be newer -- the other memory operations of this wave in between only make the wait stricter)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NJ) : "memory");
             em_stage(frame_of(t + 1), RD);  // emissions of step t + 1
-            em_fetch(frame_of(t + 2));
+            em_fetch(frame_of(t + 5));
             if constexpr (PHASE == 1) partner_fetch(t + 1);
             if (lane == 0) {
                 ldsw(base + MM_WAVE_YM(WR) + 4u * sub, MM_WAVE_NEG);

@@ -71,6 +71,7 @@ struct RowDev {  // one direction in row-lane form, internal numbering (mm_rows.
     const unsigned short *rowpdf; // [rows] pdf of the row at each position
     const unsigned short *pdfse;  // [2 * P1] (first, end) of each pdf in pdf-major order (backward only)
     const float *init;            // [rows] alpha_hat by position, log2 domain (forward only)
+    const int *order;             // [rows] position -> original state (Viterbi form: the path is reported in original states)
     int KA, NWC, nslotrows, fpos, rows;
     float thr;  // |normalised log2 value| beyond which the linear path is not trusted (mm_kernel_rows.hip)
 };
@@ -80,6 +81,7 @@ struct UttDesc {
     QuadDev q[2];   // same two matrices in quad form (log semiring only)
     RowDev r[2];    // ... and in row-lane form (log semiring only; KA == 0: not available)
     RowDev rp[2];   // ... and in the pair variant of the row-lane form (mm_rows.h RowPackOpts::pair)
+    RowDev rv;      // the forward matrix in the Viterbi form (mm_kernel_vit.hip; tropical semiring)
     RowDev rw[2];   // ... and in the wave form (mm_kernel_wave.hip: one wave per direction, log domain)
     RowDev rps[2][MM_SPLIT_HMAX];  // ... and the split pair forms [direction][set] (mm_rows.h make_rows_split): rowpdf / init /
                                    // rows / fpos refer to the TEAM's vector (all sets; rowpdf 0xffff = alignment padding)

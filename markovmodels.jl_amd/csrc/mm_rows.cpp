@@ -156,14 +156,14 @@ Plan plan_for(const std::vector<int32_t> &rows, const std::vector<int64_t> &rowp
         const int c = cost(p.segs[i]);
         for (int w = 0; w < nwc; ++w) {
             if (int(p.wave_segs[w].size()) >= MM_ROW_MAX_SLOTS) continue;
-            if (arcs[w] + p.segs[i].A > opt.ka_max) continue;
+            if (arcs[w] + std::max(p.segs[i].A, opt.seg_stride) > opt.ka_max) continue;  // (a segment owns seg_stride slots)
             if (best < 0 || level(w, c) < level(best, c) || (level(w, c) == level(best, c) && arcs[w] < arcs[best])) best = w;
         }
         if (best < 0) return p;  // more than MM_ROW_MAX_SLOTS segments per wave
         p.segs[i].wave = best;
         p.wave_segs[best].push_back(i);
         load[best] += cost(p.segs[i]);
-        arcs[best] += p.segs[i].A;
+        arcs[best] += std::max(p.segs[i].A, opt.seg_stride);
     }
     for (auto &ws : p.wave_segs)
         std::stable_sort(ws.begin(), ws.end(), [&](int a, int b) { return p.segs[a].A > p.segs[b].A; });
@@ -194,7 +194,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     }
     const int64_t nsub = int64_t(myrows.size());
     const int64_t ntot = opt.gtrash >= 0 ? opt.gtrash : nrows;  // positions of the vector (the trash position follows them)
-    if (nrows < 1 || nsub < 1 || (ntot + 1) * (opt.pair ? 8 : 4) > (opt.pair ? 2 : 1) * opt.rs || (ntot + 1) * 8 > 65528 || P1 > 8000)
+    if (nrows < 1 || nsub < 1 || (ntot + 1) * (opt.pair ? 8 : 4) > (opt.pair ? 2 : 1) * opt.rs || (ntot + 1) * (opt.pair ? 8 : 4) > 65528 || P1 > 8000)
         return false;
     if (opt.copy_perm && ((ntot + 1 + 31) & ~int64_t(31)) * 4 > opt.rs) return false;  // (copy 1 scrambles inside blocks of 32)
     // ---- schedule: the cap on arcs per lane of one row decides how many rows are split over lane groups; take
@@ -214,6 +214,11 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
         for (auto &ws : best.wave_segs) most = std::max(most, ws.size());
         KA = opt.seg_stride * int(most);
         if (KA > opt.ka_max) return false;
+        for (auto &sg : best.segs)
+            if (sg.A > opt.seg_stride) return false;  // (a row of more than 64 x seg_stride arcs)
+        if (opt.keep_order)  // (a back-pointer is the number of the arc in its row, one byte, 255 = none)
+            for (int32_t r : myrows)
+                if (rowptr[r + 1] - rowptr[r] > 255) return false;
     }
     for (int c : opt.ka_choices)
         if (c >= KA) {
@@ -405,6 +410,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                         uint32_t baddr = 0;
                         for (size_t i = 0; i < la[l].arcs.size() && bcost > 0; ++i) {
                             if (used[i]) continue;
+                            if (opt.keep_order && i != size_t(k)) continue;  // (slot k holds the lane's k-th arc)
                             for (uint32_t cp = 0; cp < ncopy; ++cp) {
                                 const uint32_t a = enc(uint32_t(g.col[la[l].arcs[i]]), cp);
                                 const int c = tab[k].cost_of(a);
@@ -432,7 +438,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                 auto real = [&](float w) { return opt.log_weights ? w > -std::numeric_limits<float>::infinity() : w != 0.f; };
                 // local search on the sum of squared bank loads: flip the copy of a conflicting slot, or swap it with another
                 // slot of the lane (in either copy)
-                for (int pass = 0; pass < 12; ++pass) {
+                for (int pass = 0; pass < (opt.keep_order ? 0 : 12); ++pass) {
                     bool improved = false;
                     for (int l = 0; l < 32; ++l)
                         for (int k = 0; k < s.A; ++k) {

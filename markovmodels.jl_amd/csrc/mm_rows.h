@@ -123,6 +123,10 @@ struct RowPackOpts {
     bool log_weights = false;
     bool want_partner = false;
     bool spread_pdf = false;  // rows of one pdf go to different segments where possible (fewer LDS add conflicts)
+    // Viterbi form (mm_kernel_vit.hip): the arcs of a lane stay in the order of the row (ascending source state, every g-th
+    // arc of a row split over g lanes): the first maximum a lane meets is then the one with the lowest source state, the
+    // tie rule of the back-pointers, and "arc number in the row" is what a back-pointer stores.  No bank-aware placement.
+    bool keep_order = false;
 };
 
 // rowptr/col/val_log2: 0-based CSR of M (out[r] = (+)_k val[k] (*) in[col[k]]), square, nrows rows.

@@ -185,12 +185,17 @@ def test_viterbi_bit_exact(mm, wl, oracle, torch, name):
     cf = mm.compile(f, mm.statemap(g.state2pdf, g.P))
     bf = mm.batch(*([cf] * len(lens)))
     path, score, bp = bf.viterbi(Vs, np.asarray(lens, dtype=np.int32), return_backpointers=True)
+    # ... and without the int32 table: the row-lane kernels with their one-byte back-pointers (mm_vit_kernel +
+    # mm_vit_backtrace_kernel) where the graph fits them (`wide` has a row of more than 255 arcs: it does not)
+    path2, score2 = bf.viterbi(Vs, np.asarray(lens, dtype=np.int32))
+    assert ("mm_vit_kernel" in bf.kernels("tropical")) == (name != "wide")
     S1 = g.S + 1
     for b, L in enumerate(lens):
         pr, sr, bpr = oc.viterbi(of, g.state2pdf, g.P, Vs[b], L, dtype=np.float32)
         assert np.array_equal(path[b], pr), (b, path[b], pr)
         assert score[b] == sr
         assert np.array_equal(bp[:, b * S1:(b + 1) * S1], bpr)
+        assert np.array_equal(path2[b], pr) and score2[b] == sr, (b, path2[b], pr)
     if name == "chain":
         assert path[0].tolist() == [0, 1, 2, 3]
 

@@ -141,6 +141,7 @@ struct mm_fsm_s {
     bool wave_tried = false;
     RowVariant *vrow = nullptr;                 // Viterbi form (mm_kernel_vit.hip)
     bool vit_tried = false;
+    int vit_n4 = 0, vit_n2 = 0;                 // its layout: positions of 4 / of 2 arc slots per wave
     // what the generic path (mm_generic.hip: any semiring, float32 or float64) works on: both matrices and alpha_hat as
     // they were handed over, in double, natural units (log weights for Log / Tropical, probabilities for Prob)
     FsmGenView gen;
@@ -212,7 +213,7 @@ struct mm_batch_s {
     bool pairs_ok = false;                       // one FSM shared by all utterances, in pair form: the pair kernels can run
     int pair_ka = 0, pair_nwc = 1, pair_slotrows = 0;
     bool vit_ok = false;   // every FSM has its Viterbi form: mm_vit_kernel + mm_vit_backtrace_kernel can run
-    int vit_nseg = 0, vit_arcs = 0;
+    int vit_n4 = 0, vit_n2 = 0, vit_arcs = 0;
     bool wave_ok = false;  // every FSM has its wave forms: the wave kernel can run (small graphs that are off the linear paths)
     int wave_nseg = 0;
     int pair_H = 1;        // workgroups per team: 1 = the pair kernels proper, > 1 = the split pair kernels
@@ -886,25 +887,37 @@ static int vit_variant(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
     RowPackOpts opt;
     opt.rs = 65536;
     opt.nwc_max = 15;
-    opt.ka_max = 24;  // (6 segments per wave: 8 do not fit the registers of a 16-wave workgroup without spills)
     opt.copies = 1;
     opt.acap_force = 4;
-    opt.seg_stride = 4;
     opt.log_weights = true;
     opt.keep_order = true;
     opt.finish_cost = 4;
     for (float &x : opt.group_speed) x = 1.f;
     RowVariant *v = new RowVariant();
     const std::vector<int32_t> none;
-    if (!make_rows(f->S1, f->mat[0].rowptr, f->mat[0].col, f->mat[0].val, f->s2p, f->P1, false, none, opt, v->g)) {
+    // per wave N4 positions of 4 arc slots and N2 of 2: the cheapest layout the graph fits (the kernel's instances)
+    static const int shapes[3][2] = {{1, 5}, {2, 4}, {6, 0}};
+    bool fits = false;
+    for (const auto &sh : shapes) {
+        opt.mix_n4 = sh[0];
+        opt.mix_n2 = sh[1];
+        opt.ka_max = 4 * sh[0] + 2 * sh[1];
+        if (make_rows(f->S1, f->mat[0].rowptr, f->mat[0].col, f->mat[0].val, f->s2p, f->P1, false, none, opt, v->g)) {
+            fits = true;
+            f->vit_n4 = sh[0];
+            f->vit_n2 = sh[1];
+            break;
+        }
+    }
+    if (!fits) {
         delete v;
         return MM_OK;
     }
     v->init.resize(size_t(f->S1));
     for (int64_t i = 0; i < f->S1; ++i) v->init[i] = f->init[v->g.order[i]];
     if (dbg.verbose)
-        fprintf(stderr, "[mm] Viterbi form: %d waves, %d segments (at most %d per wave), arcs/slots %.3f\n", v->g.NWC, v->g.nslotrows - 2,
-                v->g.KA / 4, v->g.pad_eff);
+        fprintf(stderr, "[mm] Viterbi form: %d waves, %d segments, %d x 4 + %d x 2 arc slots per lane, arcs/slots %.3f\n", v->g.NWC,
+                v->g.nslotrows - 2, f->vit_n4, f->vit_n2, v->g.pad_eff);
     int rc = upload_row_variant(f, v, 0, 0.f, false);
     if (rc) {
         delete v;
@@ -1450,8 +1463,12 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
                 return rc;
             }
             h->vit_ok = ok;
-            if (ok) {
-                h->vit_nseg = std::max(h->vit_nseg, fsms[b]->vrow->g.KA / 4);
+            if (ok) {  // (one layout per batch: the first FSM's; an FSM that needed another one keeps the batch on the item kernel)
+                if (b == 0) {
+                    h->vit_n4 = fsms[b]->vit_n4;
+                    h->vit_n2 = fsms[b]->vit_n2;
+                }
+                h->vit_ok = fsms[b]->vit_n4 == h->vit_n4 && fsms[b]->vit_n2 == h->vit_n2;
                 h->vit_arcs = std::max(h->vit_arcs, int(fsms[b]->vrow->g.col.size()));
             }
         }
@@ -2031,7 +2048,8 @@ int mm_viterbi_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const
     if (h->vit_ok && p.stop_at_len) {  // (internal back-pointers: the compact form)
         VitLaunch vl;
         vl.B = h->B;
-        vl.nseg = h->vit_nseg;
+        vl.n4 = h->vit_n4;
+        vl.n2 = h->vit_n2;
         vl.max_P1 = h->max_P1;
         vl.max_S1p = h->max_S1p;
         vl.max_arcs = h->vit_arcs;

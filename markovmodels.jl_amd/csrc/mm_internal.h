@@ -76,7 +76,7 @@ int mm_launch_wave(const WaveLaunch &wl, const RunParams &p, hipStream_t stream)
 // ---- Viterbi on the row-lane form (mm_vit_tu.hip)
 struct VitLaunch {
     int64_t B = 0;
-    int nseg = 0, max_P1 = 0, max_S1p = 0, max_arcs = 0, bp_row = 0;
+    int n4 = 0, n2 = 0, max_P1 = 0, max_S1p = 0, max_arcs = 0, bp_row = 0;  // n4 x n2: wide / narrow positions per wave
 };
 int mm_launch_viterbi(const VitLaunch &vl, const RunParams &p, hipStream_t stream);
 

@@ -26,10 +26,13 @@ namespace mm {
 #define MM_VIT_NWC 15
 #define MM_VIT_ESZ 1056u  // bytes of an emission buffer (256 pdfs + the "no row" slot)
 
-template <int NSEG, int NJ, int VSZ>  // NSEG segments per wave in registers; NJ * 64 >= P + 1; VSZ bytes of a state vector
+// N4 positions of 4 arc slots + N2 positions of 2 per wave (RowPackOpts::mix_n4 / mix_n2: most rows of a lexicon or an
+// HMM chain have 2 arcs, and a 4-slot position costs them twice the gathers and compares); NJ * 64 >= P + 1; VSZ bytes of
+// a state vector
+template <int N4, int N2, int NJ, int VSZ>
 __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
     extern __shared__ float lds[];
-    constexpr int KA = 4 * NSEG;
+    constexpr int KA = 4 * N4 + 2 * N2, NSEG = N4 + N2;
     constexpr unsigned EMB = 2u * VSZ;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -54,6 +57,7 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
     const unsigned long long lgw =
         mine_w ? ((unsigned long long)(unsigned)uni((int)(sc.lg >> 32)) << 32) | (unsigned)uni((int)sc.lg) : 0ull;
     const int nseg = mine_w ? uni((int)(sc.nslots & 0xffffu)) : 0, slot0 = mine_w ? uni((int)sc.slot0) : 0;
+    const int n4w = mine_w ? uni((int)(sc.nslots >> 16)) : 0, n2w = nseg - n4w;  // segments in wide / narrow positions
     {
         const auto wp = as_global(r.w);
         const auto ap = as_global(r.addr);
@@ -65,10 +69,20 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
             w[k] = have ? wp[k * nt + col] : MM_NINF;
             a[k] = have ? ap[k * nt + col] : 0u;
         }
+        // position i < N4 (wide) holds the wave's segment i, position N4 + j (narrow) its segment n4w + j; positions without
+        // a segment: the "no row" position and emission slot
+        const unsigned none = (4u * (unsigned)S1) | ((4u * (unsigned)((P1 + 3) & ~3)) << 16);
 #pragma unroll
-        for (int i = 0; i < NSEG; ++i)  // (segments the wave does not have: the "no row" position and emission slot)
-            s0[i] = i < nseg ? sp[(slot0 + i) * 64 + lane] : (4u * (unsigned)S1) | ((4u * (unsigned)((P1 + 3) & ~3)) << 16);
+        for (int i = 0; i < N4; ++i) s0[i] = i < n4w ? sp[(slot0 + i) * 64 + lane] : none;
+#pragma unroll
+        for (int j = 0; j < N2; ++j) s0[N4 + j] = j < n2w ? sp[(slot0 + n4w + j) * 64 + lane] : none;
     }
+    // log2 of the lanes per row of every position (4 bits each, in the order of the positions)
+    unsigned long long lgp = 0ull;
+#pragma unroll
+    for (int i = 0; i < N4; ++i) lgp |= (i < n4w ? ((lgw >> (4 * i)) & 15ull) : 0ull) << (4 * i);
+#pragma unroll
+    for (int j = 0; j < N2; ++j) lgp |= (j < n2w ? ((lgw >> (4 * (n4w + j))) & 15ull) : 0ull) << (4 * (N4 + j));
     const unsigned sub = (unsigned)lane & ((1u << 6) - 1u);
     for (unsigned q = 4u * tid; q < 2u * VSZ + 2u * MM_VIT_ESZ + 4u * NJ * 256u; q += 4096u) ldsw(q, MM_NINF);
     const unsigned trash4 = 4u * (unsigned)S1;
@@ -114,38 +128,37 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
             em_fetch(n + 5);  // (its buffer, frame (n + 1) & 3, has just been read)
         } else {
             unsigned char *row = bpk + (long long)(n - 1) * p.bp_stride_n;
-            // a block of segments at a time: its gathers and emission reads in flight together, then straight-line code
-            // (all 8 at once need more registers than a wave of a 16-wave workgroup has)
-            constexpr int BS = NSEG % 4 == 0 ? 4 : 3;  // segments of a block (NSEG = 4, 6, 8)
-            static_for<0, NSEG / BS>([&](auto H) __attribute__((always_inline)) {
-                constexpr int h0 = BS * decltype(H)::value;
-                float xs[4 * BS], es[BS];
+            // a block of positions at a time: its gathers and emission reads in flight together, then straight-line code.
+            // W arc slots per position, NB positions from position h0 on, their slots from k0 on.
+            auto block = [&](auto Wc, auto NBc, auto H0c, auto K0c) __attribute__((always_inline)) {
+                constexpr int W = decltype(Wc)::value, NB = decltype(NBc)::value, h0 = decltype(H0c)::value, k0 = decltype(K0c)::value;
+                float xs[W * NB], es[NB];
 #pragma unroll
-                for (int i = 0; i < BS; ++i) {
+                for (int i = 0; i < NB; ++i) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) xs[4 * i + q] = ldsr(a[4 * (h0 + i) + q] + (unsigned)RD * VSZ);
+                    for (int q = 0; q < W; ++q) xs[W * i + q] = ldsr(a[k0 + W * i + q] + (unsigned)RD * VSZ);
                     es[i] = ldsr(EMB + (unsigned)WR * MM_VIT_ESZ + (s0[h0 + i] >> 16));
                 }
-                float best[BS];
-                int arg[BS];
+                float best[NB];
+                int arg[NB];
 #pragma unroll
-                for (int i = 0; i < BS; ++i) {
+                for (int i = 0; i < NB; ++i) {
                     // T_hat[i, j] (*) A[i, n-1], strict '>' over ascending source states: the lowest source among the maximisers
-                    float bv = xs[4 * i] + w[4 * (h0 + i)];
+                    float bv = xs[W * i] + w[k0 + W * i];
                     int bk = 0;
 #pragma unroll
-                    for (int q = 1; q < 4; ++q) {
-                        const float v = xs[4 * i + q] + w[4 * (h0 + i) + q];
+                    for (int q = 1; q < W; ++q) {
+                        const float v = xs[W * i + q] + w[k0 + W * i + q];
                         bk = v > bv ? q : bk;
                         bv = v > bv ? v : bv;
                     }
                     best[i] = bv;
                     arg[i] = bk;
                 }
-                if (((lgw >> (4 * h0)) & ((1ull << (4 * BS)) - 1ull)) != 0ull) {  // rows split over 1 << lg lanes: lane `s` of the group holds arcs s, s + g, ...
+                if (((lgp >> (4 * h0)) & ((1ull << (4 * NB)) - 1ull)) != 0ull) {  // rows split over 1 << lg lanes: lane `s` of the group holds arcs s, s + g, ...
 #pragma unroll
-                    for (int i = 0; i < BS; ++i) {
-                        const int lg = (int)((lgw >> (4 * (h0 + i))) & 15ull);
+                    for (int i = 0; i < NB; ++i) {
+                        const int lg = (int)((lgp >> (4 * (h0 + i))) & 15ull);
                         if (lg) {
                             arg[i] = (int)(sub & ((1u << lg) - 1u)) + (arg[i] << lg);
                             trop_grp_reduce(best[i], arg[i], lg);
@@ -153,12 +166,18 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < BS; ++i) {
+                for (int i = 0; i < NB; ++i) {
                     const unsigned pos4 = s0[h0 + i] & 0xffffu;
                     ldsw(pos4 + (unsigned)WR * VSZ, best[i] + es[i]);  // (*) lhs[:, n]   (:70-71)
                     if (pos4 != trash4) row[pos4 >> 2] = best[i] > MM_NINF ? (unsigned char)arg[i] : (unsigned char)255;
                 }
-            });
+            };
+            using std::integral_constant;
+            // wide positions in blocks of <= 3, narrow ones in blocks of <= 4
+            if constexpr (N4 > 0) block(integral_constant<int, 4>{}, integral_constant<int, (N4 < 3 ? N4 : 3)>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+            if constexpr (N4 > 3) block(integral_constant<int, 4>{}, integral_constant<int, N4 - 3>{}, integral_constant<int, 3>{}, integral_constant<int, 12>{});
+            if constexpr (N2 > 0) block(integral_constant<int, 2>{}, integral_constant<int, (N2 < 4 ? N2 : 4)>{}, integral_constant<int, N4>{}, integral_constant<int, 4 * N4>{});
+            if constexpr (N2 > 4) block(integral_constant<int, 2>{}, integral_constant<int, N2 - 4>{}, integral_constant<int, N4 + 4>{}, integral_constant<int, 4 * N4 + 8>{});
         }
         __syncthreads();
     };

@@ -88,6 +88,7 @@ struct Plan {
     std::vector<std::vector<int>> wave_segs;  // per wave: indices into segs, in execution order
     int KA = 0, maxcost = 0, mincost = 0;
     bool ok = false;
+    std::vector<int> n4;  // mixed layout: segments of a wave that sit in 4-slot positions (the first ones)
 };
 
 Plan plan_for(const std::vector<int32_t> &rows, const std::vector<int64_t> &rowptr, int acap, const RowPackOpts &opt,
@@ -148,15 +149,21 @@ Plan plan_for(const std::vector<int32_t> &rows, const std::vector<int64_t> &rowp
     std::vector<int> idx(p.segs.size());
     std::iota(idx.begin(), idx.end(), 0);
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost(p.segs[a]) > cost(p.segs[b]); });
-    std::vector<int> load(nwc, 0), arcs(nwc, 0);
+    std::vector<int> load(nwc, 0), arcs(nwc, 0), used4(nwc, 0), used2(nwc, 0);
     p.wave_segs.assign(nwc, {});
+    p.n4.assign(nwc, 0);
     auto level = [&](int w, int extra) { return float(load[w] + extra) / opt.group_speed[std::min(w >> 2, 3)]; };
     for (int i : idx) {
         int best = -1;
         const int c = cost(p.segs[i]);
         for (int w = 0; w < nwc; ++w) {
             if (int(p.wave_segs[w].size()) >= MM_ROW_MAX_SLOTS) continue;
-            if (arcs[w] + std::max(p.segs[i].A, opt.seg_stride) > opt.ka_max) continue;  // (a segment owns seg_stride slots)
+            if (opt.mix_n4 >= 0) {  // N4 positions of 4 slots, N2 of 2 per wave: a segment of <= 2 arcs takes a narrow one first
+                const bool narrow = p.segs[i].A <= 2 && used2[w] < opt.mix_n2;
+                if (!narrow && used4[w] >= opt.mix_n4) continue;
+            } else if (arcs[w] + std::max(p.segs[i].A, opt.seg_stride) > opt.ka_max) {
+                continue;  // (a segment owns seg_stride slots)
+            }
             if (best < 0 || level(w, c) < level(best, c) || (level(w, c) == level(best, c) && arcs[w] < arcs[best])) best = w;
         }
         if (best < 0) return p;  // more than MM_ROW_MAX_SLOTS segments per wave
@@ -164,9 +171,15 @@ Plan plan_for(const std::vector<int32_t> &rows, const std::vector<int64_t> &rowp
         p.wave_segs[best].push_back(i);
         load[best] += cost(p.segs[i]);
         arcs[best] += std::max(p.segs[i].A, opt.seg_stride);
+        if (opt.mix_n4 >= 0) {
+            if (p.segs[i].A <= 2 && used2[best] < opt.mix_n2) ++used2[best];
+            else ++used4[best];
+        }
     }
     for (auto &ws : p.wave_segs)
         std::stable_sort(ws.begin(), ws.end(), [&](int a, int b) { return p.segs[a].A > p.segs[b].A; });
+    if (opt.mix_n4 >= 0)
+        for (int w = 0; w < nwc; ++w) p.n4[w] = used4[w];  // (sorted by A: the wide positions' occupants come first)
     p.KA = *std::max_element(arcs.begin(), arcs.end());
     p.maxcost = 0;
     p.mincost = 1 << 30;
@@ -209,7 +222,14 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     if (!best.ok) return false;
     const int NWC = int(best.wave_segs.size());
     int KA = std::max(2, (best.KA + 1) & ~1);
-    if (opt.seg_stride) {
+    if (opt.mix_n4 >= 0) {
+        KA = 4 * opt.mix_n4 + 2 * opt.mix_n2;
+        for (auto &sg : best.segs)
+            if (sg.A > 4) return false;
+        if (opt.keep_order)
+            for (int32_t r : myrows)
+                if (rowptr[r + 1] - rowptr[r] > 255) return false;
+    } else if (opt.seg_stride) {
         size_t most = 0;
         for (auto &ws : best.wave_segs) most = std::max(most, ws.size());
         KA = opt.seg_stride * int(most);
@@ -361,10 +381,12 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
         (void)arcs_w;
         int k0 = 0, sidx = 0;  // left-aligned: the wave leaves the pair sequence after its last segment
         sc.nslots = uint32_t(best.wave_segs[w].size()) | (uint32_t(k0 / 2) << 16);
+        if (opt.mix_n4 >= 0) sc.nslots = uint32_t(best.wave_segs[w].size()) | (uint32_t(best.n4[w]) << 16);
         for (int si : best.wave_segs[w]) {
             const Segment &s = best.segs[si];
             const int lg = log2i(s.g);
             if (opt.seg_stride) k0 = opt.seg_stride * sidx;
+            if (opt.mix_n4 >= 0) k0 = sidx < best.n4[w] ? 4 * sidx : 4 * opt.mix_n4 + 2 * (sidx - best.n4[w]);
             sc.lg |= uint64_t(lg) << (4 * sidx);
             sc.endmask |= uint64_t(1) << ((k0 + s.A) / 2 - 1);
             // slot table row

@@ -127,6 +127,10 @@ struct RowPackOpts {
     // arc of a row split over g lanes): the first maximum a lane meets is then the one with the lowest source state, the
     // tie rule of the back-pointers, and "arc number in the row" is what a back-pointer stores.  No bank-aware placement.
     bool keep_order = false;
+    // Mixed layout (Viterbi form): a wave has mix_n4 positions of 4 arc slots followed by mix_n2 positions of 2; segments of
+    // up to 2 arcs per lane take the narrow positions first.  RowSched::nslots = segments | (those in wide positions) << 16;
+    // the wave's segments are ordered wide positions first.  mix_n4 < 0: off.
+    int mix_n4 = -1, mix_n2 = 0;
 };
 
 // rowptr/col/val_log2: 0-based CSR of M (out[r] = (+)_k val[k] (*) in[col[k]]), square, nrows rows.

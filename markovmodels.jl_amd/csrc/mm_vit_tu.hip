@@ -5,26 +5,29 @@
 
 namespace mm {
 
-template <int NSEG, int NJ, int VSZ>
+template <int N4, int N2, int NJ, int VSZ>
 static int launch_vit(const VitLaunch &vl, const RunParams &p, hipStream_t stream) {
     const size_t lds = 2 * size_t(VSZ) + 2 * size_t(MM_VIT_ESZ) + 4 * size_t(NJ) * 256;
-    auto kernel = mm_vit_kernel<NSEG, NJ, VSZ>;
+    auto kernel = mm_vit_kernel<N4, N2, NJ, VSZ>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
     hipLaunchKernelGGL(kernel, dim3(unsigned(vl.B)), dim3(1024), lds, stream, p);
     HIP_TRY(hipGetLastError());
     return MM_OK;
 }
-template <int NSEG, int NJ>
-static int launch_vit_vsz(const VitLaunch &vl, const RunParams &p, hipStream_t stream) {
-    if (size_t(vl.max_S1p) * 4 <= 24576) return launch_vit<NSEG, NJ, 24576>(vl, p, stream);
-    return launch_vit<NSEG, NJ, 65536>(vl, p, stream);
+template <int N4, int N2>
+static int launch_vit_shape(const VitLaunch &vl, const RunParams &p, hipStream_t stream) {
+    const bool small = size_t(vl.max_S1p) * 4 <= 24576;
+    if (vl.max_P1 <= 128) return small ? launch_vit<N4, N2, 2, 24576>(vl, p, stream) : launch_vit<N4, N2, 2, 65536>(vl, p, stream);
+    return small ? launch_vit<N4, N2, 4, 24576>(vl, p, stream) : launch_vit<N4, N2, 4, 65536>(vl, p, stream);
 }
 int mm_launch_viterbi(const VitLaunch &vl, const RunParams &p, hipStream_t stream) {
-    if (vl.nseg > 8 || vl.max_P1 > 256 || size_t(vl.max_S1p) * 4 > 65536) return mm_fail(MM_ERR_UNSUPPORTED, "Viterbi kernel: graph too large");
+    if (vl.max_P1 > 256 || size_t(vl.max_S1p) * 4 > 65536) return mm_fail(MM_ERR_UNSUPPORTED, "Viterbi kernel: graph too large");
     int rc;
-    if (vl.nseg <= 4) rc = vl.max_P1 <= 128 ? launch_vit_vsz<4, 2>(vl, p, stream) : launch_vit_vsz<4, 4>(vl, p, stream);
-    else if (vl.nseg <= 6) rc = vl.max_P1 <= 128 ? launch_vit_vsz<6, 2>(vl, p, stream) : launch_vit_vsz<6, 4>(vl, p, stream);
-    else rc = vl.max_P1 <= 128 ? launch_vit_vsz<8, 2>(vl, p, stream) : launch_vit_vsz<8, 4>(vl, p, stream);
+    // (the layouts the forms are built for, mm_engine.hip vit_variant: wide x narrow positions per wave)
+    if (vl.n4 == 1 && vl.n2 == 5) rc = launch_vit_shape<1, 5>(vl, p, stream);
+    else if (vl.n4 == 2 && vl.n2 == 4) rc = launch_vit_shape<2, 4>(vl, p, stream);
+    else if (vl.n4 == 6 && vl.n2 == 0) rc = launch_vit_shape<6, 0>(vl, p, stream);
+    else return mm_fail(MM_ERR_UNSUPPORTED, "Viterbi kernel: no instance for this layout");
     if (rc) return rc;
     // back-trace: a double-buffered ring of R byte rows (each padded to 256 bytes) and, when they leave room for at least
     // 2 x 4 rows, the graph's row pointers and sources

@@ -164,7 +164,7 @@ struct mm_fsm_s {
 // MM_KQ / MM_NWAVES / MM_NITEMS force a geometry, MM_NO_XCSR keeps the exact-fallback CSR out of LDS,
 // MM_VERBOSE prints the packing statistics.
 struct DebugOpts {
-    enum { K_AUTO = 0, K_ITEM, K_QUAD, K_ROW, K_PAIR, K_WAVE };
+    enum { K_AUTO = 0, K_ITEM, K_QUAD, K_ROW, K_PAIR, K_WAVE, K_SPLIT };
     int kernel = K_AUTO;
     int kq = 0, nwaves = 0, nitems = -1;
     bool no_xcsr = false, verbose = false;
@@ -180,7 +180,7 @@ static DebugOpts read_debug_opts() {
     if (!on || !*on || !strcmp(on, "0")) return d;
     if (const char *e = getenv("MM_KERNEL"))
         d.kernel = !strcmp(e, "item") ? DebugOpts::K_ITEM : !strcmp(e, "quad") ? DebugOpts::K_QUAD
-                 : !strcmp(e, "row") ? DebugOpts::K_ROW : !strcmp(e, "pair") ? DebugOpts::K_PAIR : !strcmp(e, "wave") ? DebugOpts::K_WAVE : DebugOpts::K_AUTO;
+                 : !strcmp(e, "row") ? DebugOpts::K_ROW : !strcmp(e, "pair") ? DebugOpts::K_PAIR : !strcmp(e, "wave") ? DebugOpts::K_WAVE : !strcmp(e, "split") ? DebugOpts::K_SPLIT : DebugOpts::K_AUTO;
     if (const char *e = getenv("MM_KQ")) d.kq = atoi(e);
     if (const char *e = getenv("MM_NWAVES")) d.nwaves = atoi(e);
     if (const char *e = getenv("MM_NITEMS")) d.nitems = atoi(e);
@@ -1403,7 +1403,7 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         h->rows_ok = ok;
     }
     // pair kernels: all utterances on ONE FSM (the graph registers are shared by the two utterances of a workgroup)
-    h->pairs_ok = h->rows_ok && B >= 2 && h->dbg.kernel != DebugOpts::K_ROW;
+    h->pairs_ok = h->rows_ok && B >= 2 && h->dbg.kernel != DebugOpts::K_ROW && h->dbg.kernel != DebugOpts::K_SPLIT;
     for (int64_t b = 1; b < B && h->pairs_ok; ++b) h->pairs_ok = fsms[b] == fsms[0];
     if (h->pairs_ok) {
         bool ok = false;

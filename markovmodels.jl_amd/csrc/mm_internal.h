@@ -29,7 +29,8 @@ int mm_fail(int code, const std::string &msg);
 // split pair kernels (teams of H workgroups per utterance pair and direction): bytes of half a pair vector, arc slots per
 // lane, compute waves (+ a service wave and an exchange wave)
 #define MM_SPLIT_RS 12288
-#define MM_SPLIT_RSH 14336  // LDS bytes of the rows ONE workgroup of a team finishes
+#define MM_SPLIT_RSH 13312  // LDS bytes of the rows ONE workgroup of a team finishes (the sets are balanced by arcs: their row
+                            // counts differ by a few per cent; 1663 rows leave 51 slot rows of LDS in phase B)
 #define MM_SPLIT_KA 36
 #define MM_SPLIT_NWC 14
 

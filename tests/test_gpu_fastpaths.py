@@ -135,6 +135,27 @@ def test_redo_count_is_zero_on_the_benchmark_inputs_and_reported_on_peaky_ones(m
     print(f"peaky emissions: {redo} of {B} utterances redone")
 
 
+@pytest.mark.parametrize("S,P", [(6000, 300), (2900, 120), (1000, 640)])
+def test_graph_beyond_the_fast_paths(mm, wl, oracle, torch, S, P):
+    """The reference's products have no size limit (src/linalg.jl:170-181).  6000 states x 300 pdfs and 1000 states x
+    640 pdfs are beyond the pair kernels (2047 states, 250 pdfs) and the teams of two (3070 states): they run on the quad
+    kernels; a 2900-state graph of config 3's family takes the teams.  Same results either way."""
+    g = wl.lfmmi_denominator(S, P, seed=S)
+    rng = np.random.default_rng(S + P)
+    B, N = 5, 36
+    V = (1.3 * rng.standard_normal((B, N, g.P))).astype(np.float32)
+    lens = np.array([36, 36, 20, 35, 7], dtype=np.int32)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(*([cf] * B))
+    gam, ttl = bf.pdfposteriors(V, lens)
+    kernels = bf.kernels()
+    assert ("mm_fbs_kernel_dir" in kernels) == (S == 2900), kernels
+    assert bf.last_redo_count() == 0 or "mm_fbs_kernel_dir" not in kernels
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    check_gamma(gam, g_ref, lens)
+    assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)
+
+
 @pytest.mark.parametrize("P", [130, 249])
 def test_pair_kernels_with_many_pdfs(mm, wl, oracle, torch, P):
     """P + 1 in 129..250: the service wave of the pair kernels runs four 64-lane passes over the pdfs

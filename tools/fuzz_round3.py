@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Diagnostic: the kernels added in round 3 against the item kernel (an independent implementation in the log domain)
+on random graphs, batch sizes, frame counts and length patterns, including the degenerate ones:
+
+  * split pair kernels (teams of two workgroups): graphs beyond the pair kernels, odd and large batches (more teams
+    than compute units), one or two frames, empty utterances;
+  * wave kernel: batches of DIFFERENT small deep graphs, run twice (identical bits);
+  * Viterbi on the row-lane form: paths and scores must be bit-identical to the item form's.
+
+GPU only.  SEED=n python tools/fuzz_round3.py; the switches are read at batch creation (MM_DEBUG)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+import torch  # noqa: E402
+
+mm = ge.load_package()
+wl = importlib.import_module(mm.__name__ + ".workloads")
+
+
+def set_kernel(kernel):
+    os.environ["MM_DEBUG"] = "1"
+    if kernel:
+        os.environ["MM_KERNEL"] = kernel
+    else:
+        os.environ.pop("MM_KERNEL", None)
+
+
+def lens_pattern(rng, B, N):
+    pat = rng.integers(0, 3)
+    lens = np.full(B, N) if pat == 0 else rng.integers(0, N + 1, B) if pat == 1 else rng.integers(max(0, N - 2), N + 1, B)
+    return lens.astype(np.int32)
+
+
+def posterior_error(a_g, a_t, ref_g, ref_t):
+    same_inf = np.isinf(a_t) & np.isinf(ref_t) & (a_t == ref_t)
+    fin = ~same_inf
+    et = (np.abs(a_t[fin] - ref_t[fin]) / np.maximum(1.0, np.abs(ref_t[fin]))).max() if fin.any() else 0.0
+    m = ref_g > 1e-30
+    eg = np.abs(a_g - ref_g).max()
+    if m.any():
+        eg = max(eg, (np.abs(np.log(np.maximum(a_g[m], 1e-300)) - np.log(ref_g[m])) / np.maximum(np.abs(np.log(ref_g[m])), 1)).max())
+    return et, eg
+
+
+def posteriors(cfs, V, lt, kernel):
+    set_kernel(kernel)
+    bf = mm.batch(*cfs)
+    gam, ttl = bf.pdfposteriors(V, lt)
+    torch.cuda.synchronize()
+    return gam.cpu().numpy().astype(np.float64), ttl.cpu().numpy().astype(np.float64), bf.kernels("log"), bf
+
+
+def fuzz_split(rng):
+    bad = n = 0
+    here = os.path.join(ROOT, "tests", "golden", "den_fsm_wsj.npz")
+    graphs = [lambda: wl.load_npz_graph(here), lambda: wl.lfmmi_denominator(2900, 120, seed=int(rng.integers(1 << 30))),
+              lambda: wl.lfmmi_denominator(2400, 200, seed=int(rng.integers(1 << 30)))]
+    for gi, mk in enumerate(graphs):
+        g = mk()
+        cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+        for B, N in ((2, 1), (2, 2), (3, 3), (3, 4), (5, 7), (8, 40), (9, 101), (300, 12), (515, 9)):
+            V = torch.from_numpy((1.5 * rng.standard_normal((B, N, g.P))).astype(np.float32)).cuda()
+            lens = lens_pattern(rng, B, N)
+            lt = torch.from_numpy(lens).cuda()
+            ref_g, ref_t, _, _ = posteriors([cf] * B, V, lt, "item")
+            a_g, a_t, names, bf = posteriors([cf] * B, V, lt, None)
+            n += 1
+            et, eg = posterior_error(a_g, a_t, ref_g, ref_t)
+            ok = np.isfinite(et) and np.isfinite(eg) and et < 1e-4 and eg < 1e-4 and "mm_fbs_kernel_dir" in names
+            if not ok:
+                bad += 1
+                print(f"MISMATCH split graph {gi} B {B} N {N} lens {lens.tolist()[:12]} ({names[:50]}): ttl {et:.2e} gamma {eg:.2e}")
+    return n, bad
+
+
+def fuzz_wave(rng):
+    bad = n = 0
+    num = wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "num_fsm_wsj.npz"))
+    for trial in range(6):
+        B = int(rng.choice([1, 2, 3, 7, 33, 130]))
+        gs = []
+        for b in range(min(B, 6)):
+            k = rng.integers(0, 4)
+            gs.append(num if k == 0 else wl.lexicon_fsm(int(rng.integers(40, 900)), int(rng.integers(5, 200)), seed=int(rng.integers(1 << 30)), hubs=int(rng.integers(1, 3)))
+                      if k < 3 else wl.l2r_hmm(int(rng.integers(3, 60))))
+        Pm = max(g.P for g in gs)
+        cfs = [mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, Pm)) for g in gs]
+        cfs = [cfs[b % len(cfs)] for b in range(B)]
+        for N in (1, 2, 3, 5, 64, 150):
+            V = torch.from_numpy((1.5 * rng.standard_normal((B, N, Pm))).astype(np.float32)).cuda()
+            lens = lens_pattern(rng, B, N)
+            lt = torch.from_numpy(lens).cuda()
+            ref_g, ref_t, _, _ = posteriors(cfs, V, lt, "item")
+            a_g, a_t, names, bf = posteriors(cfs, V, lt, "wave")
+            g2, t2 = bf.pdfposteriors(V, lt)
+            n += 1
+            et, eg = posterior_error(a_g, a_t, ref_g, ref_t)
+            same = np.array_equal(g2.cpu().numpy(), a_g.astype(np.float32)) and np.array_equal(t2.cpu().numpy(), a_t.astype(np.float32))
+            ok = np.isfinite(et) and np.isfinite(eg) and et < 1e-4 and eg < 1e-4 and same
+            if not ok:
+                bad += 1
+                print(f"MISMATCH wave trial {trial} B {B} N {N} lens {lens.tolist()[:12]} ({names[:50]}): ttl {et:.2e} gamma {eg:.2e} same bits {same}")
+    return n, bad
+
+
+def fuzz_viterbi(rng):
+    bad = n = 0
+    for trial in range(8):
+        k = trial % 4
+        g = (wl.lexicon_fsm(int(rng.integers(50, 6000)), int(rng.integers(5, 240)), seed=int(rng.integers(1 << 30)), hubs=int(rng.integers(1, 6))) if k < 2
+             else wl.random_fsm(int(rng.integers(5, 900)), int(rng.integers(2, 60)), float(rng.uniform(1.5, 5.0)), seed=int(rng.integers(1 << 30))) if k == 2
+             else wl.lfmmi_denominator(int(rng.integers(100, 1000)) * 2, 84, seed=int(rng.integers(1 << 30))))
+        cf = mm.compile(wl.to_fsm(mm, g, "tropical"), mm.statemap(g.state2pdf, g.P))
+        for B, N in ((1, 1), (2, 2), (3, 5), (5, 33), (4, 260), (131, 17)):
+            V = torch.from_numpy((2.0 * rng.standard_normal((B, N, g.P))).astype(np.float32)).cuda()
+            lens = lens_pattern(rng, B, N)
+            lt = torch.from_numpy(lens).cuda()
+            out = []
+            for kern in ("item", None):
+                set_kernel(kern)
+                bf = mm.batch(*([cf] * B))
+                path, score = bf.viterbi(V, lt)[:2]
+                torch.cuda.synchronize()
+                out.append((path.cpu().numpy(), score.cpu().numpy(), bf.kernels("tropical")))
+            n += 1
+            same = np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+            if not same:
+                bad += 1
+                print(f"MISMATCH viterbi trial {trial} ({g.name}) B {B} N {N} lens {lens.tolist()[:12]} ({out[1][2][:50]})")
+    return n, bad
+
+
+def main(seed=0, which=("split", "wave", "viterbi")):
+    rng = np.random.default_rng(seed)
+    saved = {k: os.environ.get(k) for k in ("MM_DEBUG", "MM_KERNEL")}
+    total = bad = 0
+    for name in which:
+        n, b = {"split": fuzz_split, "wave": fuzz_wave, "viterbi": fuzz_viterbi}[name](rng)
+        print(f"{name}: {n} comparisons, {b} mismatches", flush=True)
+        total += n
+        bad += b
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(int(os.environ.get("SEED", 0)), tuple(sys.argv[1:]) or ("split", "wave", "viterbi")) else 0)

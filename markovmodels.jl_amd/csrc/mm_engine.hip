@@ -112,6 +112,8 @@ struct QuadVariant {  // the quad form of ONE direction of an FSM for one KQ (qu
 struct RowVariant {
     RowGraph g;
     std::vector<float> init;     // forward: alpha_hat by position
+    std::vector<uint32_t> ptab;  // wave form: [4 waves][2 segments][4 addresses + info][64 lanes] (wave_pdf_table)
+    int pdf_nps = 0;             // ... segments per wave it uses (1 or 2)
     void *blob = nullptr;
     RowDev rdev;
 };
@@ -784,6 +786,7 @@ static int upload_row_variant(mm_fsm_t f, RowVariant *v, int dir, float thr, boo
     const size_t o_w = bl.add(v->g.w), o_a = bl.add(v->g.addr), o_s = bl.add(v->g.slots), o_sc = bl.add(v->g.sched);
     const size_t o_ptr = bl.add(v->g.rowptr), o_col = bl.add(v->g.col), o_cw = bl.add(v->g.cw);
     const size_t o_pdf = bl.add(v->g.rowpdf), o_pse = bl.add(v->g.pdfse), o_init = bl.add(v->init), o_ord = bl.add(v->g.order);
+    const size_t o_pt = bl.add(v->ptab);
     int rc = upload(bl, &v->blob);
     if (rc) return rc;
     char *base = static_cast<char *>(v->blob);
@@ -799,6 +802,7 @@ static int upload_row_variant(mm_fsm_t f, RowVariant *v, int dir, float thr, boo
     d.pdfse = reinterpret_cast<const unsigned short *>(base + o_pse);
     d.init = reinterpret_cast<const float *>(base + o_init);
     d.order = reinterpret_cast<const int *>(base + o_ord);
+    d.ptab = v->ptab.empty() ? nullptr : reinterpret_cast<const unsigned *>(base + o_pt);
     d.KA = v->g.KA;
     d.NWC = v->g.NWC;
     d.nslotrows = v->g.nslotrows;
@@ -928,6 +932,63 @@ static int vit_variant(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
     return MM_OK;
 }
 
+// The per-pdf sums of the wave kernel (C_hat' * (A .* B), src/inference.jl:155) as packed segments of their own: pdf p
+// with n_p states gets a group of L_p = pow2(ceil(n_p / 4)) adjacent lanes, each of which reads 4 of the states' values
+// (byte addresses relative to the vector u in the numbering of `g`: 4 * position; unused slots read the trash position,
+// which holds zero(K)); the lanes of a group combine by a butterfly.  Groups are placed largest first, so every group
+// starts at a multiple of its size; a segment is 64 lanes.  Segment s runs on compute wave 3 - s % 4 as its pdf segment
+// s / 4.  tab[((w * 2 + j) * 5 + k) * 64 + lane]: k < 4 the addresses, k = 4: 4 * pdf of the group's first lane (the lane
+// that stores; others: the trash slot 4 * P1p) | log2(L) << 16.  Returns the segments per wave (1 or 2), 0 if it does not fit.
+static int wave_pdf_table(const RowGraph &g, const std::vector<int32_t> &s2p, int64_t S1, int32_t P1, std::vector<uint32_t> &tab) {
+    std::vector<std::vector<uint32_t>> src{size_t(P1)};
+    std::vector<std::pair<int32_t, int32_t>> bypos;  // (position, pdf): a fixed order of the states of a pdf
+    for (int64_t r = 0; r < S1; ++r) bypos.emplace_back(g.pos[size_t(r)], s2p[size_t(r)]);
+    std::sort(bypos.begin(), bypos.end());
+    for (const auto &pp : bypos) src[size_t(pp.second)].push_back(4u * uint32_t(pp.first));
+    struct Item {
+        int32_t pdf, lg;
+    };
+    std::vector<Item> items;
+    for (int32_t p = 0; p < P1; ++p) {
+        const size_t n = src[size_t(p)].size();
+        if (n == 0) continue;  // (no state emits it: its sum stays zero(K), the buffers start that way)
+        int lg = 0;
+        while ((size_t(4) << lg) < n) ++lg;
+        if (lg > 6) return 0;
+        items.push_back({p, lg});
+    }
+    std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.lg > b.lg; });
+    const uint32_t trash_src = 4u * uint32_t(S1), trash_pdf = 4u * uint32_t((P1 + 3) & ~3);
+    tab.assign(size_t(4) * 2 * 5 * 64, 0u);
+    for (int w = 0; w < 4; ++w)
+        for (int j = 0; j < 2; ++j) {
+            for (int k = 0; k < 4; ++k)
+                for (int l = 0; l < 64; ++l) tab[size_t(((w * 2 + j) * 5 + k) * 64 + l)] = trash_src;
+            for (int l = 0; l < 64; ++l) tab[size_t(((w * 2 + j) * 5 + 4) * 64 + l)] = trash_pdf;
+        }
+    int seg = 0, lane = 0;
+    for (const Item &it : items) {
+        const int L = 1 << it.lg;
+        if (lane + L > 64) {
+            ++seg;
+            lane = 0;
+        }
+        if (seg >= 8) return 0;
+        const int w = 3 - seg % 4, j = seg / 4;  // (the largest groups to the last wave: the first has the widest rows of the graph)
+        const std::vector<uint32_t> &sv = src[size_t(it.pdf)];
+        for (int i = 0; i < L; ++i) {
+            for (int k = 0; k < 4; ++k) {
+                const size_t q = size_t(4 * i + k);
+                if (q < sv.size()) tab[size_t(((w * 2 + j) * 5 + k) * 64 + lane + i)] = sv[q];
+            }
+            tab[size_t(((w * 2 + j) * 5 + 4) * 64 + lane + i)] = (i == 0 ? 4u * uint32_t(it.pdf) : trash_pdf) | (uint32_t(it.lg) << 16);
+        }
+        lane += L;
+    }
+    const int nseg = items.empty() ? 1 : seg + 1;
+    return nseg <= 4 ? 1 : 2;
+}
+
 // the wave forms of an FSM (built once; *ok = false if it does not fit them: more than 16 segments of 64 rows, ...)
 static int wave_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
     *ok = f->wrows[0] && f->wrows[1];
@@ -951,6 +1012,10 @@ static int wave_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
     bool fits = make_rows(f->S1, f->qmat[0].rowptr, f->qmat[0].col, f->qmat[0].val, f->s2p, f->P1, false, none, opt, rv[0]->g) &&
                 make_rows(f->S1, f->qmat[1].rowptr, f->qmat[1].col, f->qmat[1].val, f->s2p, f->P1, true, rv[0]->g.pos, opt, rv[1]->g);
     int rc = MM_OK;
+    for (int d = 0; d < 2 && fits; ++d) {
+        rv[d]->pdf_nps = wave_pdf_table(rv[d]->g, f->s2p, f->S1, f->P1, rv[d]->ptab);
+        fits = rv[d]->pdf_nps > 0;
+    }
     if (fits) {
         set_partner(rv[0]->g, rv[1]->g.pos);
         rv[0]->init.resize(size_t(f->S1));
@@ -1487,7 +1552,10 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
                 return rc;
             }
             h->wave_ok = ok;
-            if (ok) h->wave_nseg = std::max(h->wave_nseg, std::max(fsms[b]->wrows[0]->g.KA, fsms[b]->wrows[1]->g.KA) / 4);
+            // (segments of a wave's registers: the state segments, and twice the pdf segments -- the kernel has NSEG / 2 of those)
+            if (ok)
+                h->wave_nseg = std::max({h->wave_nseg, std::max(fsms[b]->wrows[0]->g.KA, fsms[b]->wrows[1]->g.KA) / 4,
+                                         2 * std::max(fsms[b]->wrows[0]->pdf_nps, fsms[b]->wrows[1]->pdf_nps)});
         }
     }
     for (int64_t b = 0; b < B; ++b) {
@@ -1776,6 +1844,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     p.lens = lens;
     p.N = int(N);
     p.B = int(h->B);
+    p.x_sleep = h->dbg.x_sleep;
     p.ws_alpha = static_cast<float *>(h->ws);
     p.ws_c = reinterpret_cast<double *>(static_cast<char *>(h->ws) + ws_alpha_bytes(h, N));
     p.gamma = gamma;

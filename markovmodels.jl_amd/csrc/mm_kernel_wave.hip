@@ -16,12 +16,19 @@
 //     acap_force / seg_stride / log_weights): up to NSEG segments of 64 / g rows, a lane holds at most 4 arcs of a segment
 //     (log2 weight + LDS byte address of the source), so a segment is straight-line code: <= 4 gathers, a two-pass
 //     log-sum-exp in registers, for rows of more than 4 arcs a lane-group maximum and sum by DPP;
-//   * the state vector of a step lives in the wave's own LDS slice, double buffered by the parity of the step; a wave's LDS
-//     writes are ordered before its own later reads, so no barrier is needed;
-//   * normalisation by the lagged frame maximum (a~_t = a_t - C_t, C_t = sum_{k<t} max_j a~_k[j], C in double) as in the item
-//     kernel; the semiring's zero is the finite sentinel MM_WAVE_NEG (-1e30: -inf - -inf never occurs);
-//   * every reduction has a fixed order: the posteriors of a pdf are summed by ONE lane over the pdf's states in pdf-major
-//     order (no atomics: the kernel is deterministic, unlike the item kernel's default mode).
+//   * the state vector of a step lives in the agent's LDS slice, double buffered by the parity of the step;
+//   * two SERVICE waves per agent do everything that is not on the path from one barrier to the next: wave E the emissions
+//     (LDS-DMA four steps ahead, staged relative to the frame's level E_t) and the offsets; wave P the frame normaliser, the
+//     partner's offsets (LDS-DMA) and the posteriors of a frame two steps after the compute waves produced their terms.
+//     Normalisation: the vector of step t is the log2 vector minus C_t = sum_{k<=t} (M_{k-2} + E_k), M_k = the maximum of
+//     the vector of step k, which wave P finds by scanning that vector during step k + 1 -- two steps of lag, so that no wave
+//     waits for a maximum
+//     (C in double); the semiring's zero is the finite sentinel MM_WAVE_NEG (-1e30: -inf - -inf never occurs);
+//   * every reduction has a fixed order, and all of it stays in the log domain: the rows of phase B write
+//     u = log2(alpha~ beta~) to their pdf-major positions (plain LDS stores), ONE lane per pdf forms the log-sum-exp over
+//     the pdf's states during the next step, the service wave normalises over the pdfs a step later.  No atomics: the
+//     kernel is deterministic (round 3's first version added the rows' terms with LDS float atomics: lanes that share a pdf
+//     serialise, and the LDS serves one wave's conflicts before anybody else's gathers -- phase B took 3x phase A).
 #pragma once
 #include "mm_kernel_rows.hip"
 
@@ -30,20 +37,21 @@ namespace mm {
 #define MM_WAVE_STRIDE 4         // arc slots of a segment
 #define MM_WAVE_NEG (-1.0e30f)   // zero(K) in the log2 domain
 #define MM_WAVE_VSZ 4352u        // bytes of one state vector (1024 states + the "no row" position, padded)
-#define MM_WAVE_ESZ 1056u        // bytes of one emission / pdf-sum buffer (256 pdfs + the "no row" slot)
-// LDS slice of one wave (bytes, relative to the slice)
+#define MM_WAVE_ESZ 1056u        // bytes of one emission / per-pdf buffer (256 pdfs + the "no row" slot)
+#define MM_WAVE_NWD 4            // compute waves per agent
+// LDS slice of one agent (bytes, relative to the slice)
 #define MM_WAVE_VEC(par) ((unsigned)(par) * MM_WAVE_VSZ)
-#define MM_WAVE_EM(par) (2u * MM_WAVE_VSZ + (unsigned)(par) * MM_WAVE_ESZ)
-#define MM_WAVE_NWD 4            // waves per agent
-// (buf = step & 3: the sums of a step are added during the next step and read during the one after)
-#define MM_WAVE_PS(buf, w) (2u * MM_WAVE_VSZ + 2u * MM_WAVE_ESZ + ((unsigned)(buf) * MM_WAVE_NWD + (unsigned)(w)) * MM_WAVE_ESZ)  // per-pdf sums of a wave
-#define MM_WAVE_YM(par) (2u * MM_WAVE_VSZ + (2u + 4u * MM_WAVE_NWD) * MM_WAVE_ESZ + (unsigned)(par) * 32u)        // per-wave maxima of the vector
-#define MM_WAVE_UM(buf) (MM_WAVE_YM(2) + (unsigned)(buf) * 32u)                                                  // ... of a~ + b~
-#define MM_WAVE_OFF(buf) (MM_WAVE_UM(4) + (unsigned)(buf) * 16u)                                                 // {own, partner} offsets of a step (doubles)
+#define MM_WAVE_QV(par) (2u * MM_WAVE_VSZ + (unsigned)(par) * MM_WAVE_VSZ)                     // u of a step, pdf-major
+#define MM_WAVE_EM(par) (4u * MM_WAVE_VSZ + (unsigned)(par) * MM_WAVE_ESZ)
+#define MM_WAVE_PL(par) (4u * MM_WAVE_VSZ + 2u * MM_WAVE_ESZ + (unsigned)(par) * MM_WAVE_ESZ)  // per-pdf log2 sums of a step
+#define MM_WAVE_FILL (4u * MM_WAVE_VSZ + 4u * MM_WAVE_ESZ)                                     // (everything below starts as zero(K))
+#define MM_WAVE_MS(par) (MM_WAVE_FILL + (unsigned)(par) * 16u)                                 // maximum of the vector of step t, t & 1 == par
+#define MM_WAVE_OFF(buf) (MM_WAVE_MS(2) + (unsigned)(buf) * 8u)                                // own offset of a step (double), t & 3
 #define MM_WAVE_SYNC MM_WAVE_OFF(4)
-#define MM_WAVE_ZZ (MM_WAVE_SYNC + 16u)   // the waves' minima of the per-frame log2 normalisers (doubles)
-#define MM_WAVE_RAW(k) (MM_WAVE_ZZ + 8u * MM_WAVE_NWD + 16u + (unsigned)(k) * 1024u)  // raw emissions of 4 frames in flight (LDS-DMA)
-#define MM_WAVE_SLICE MM_WAVE_RAW(4)
+#define MM_WAVE_ZZ (MM_WAVE_SYNC + 16u)   // the agent's minimum of the per-frame log2 normalisers (double)
+#define MM_WAVE_RAW(k) (MM_WAVE_ZZ + 16u + (unsigned)(k) * 1024u)   // raw emissions of 4 frames in flight (LDS-DMA)
+#define MM_WAVE_POFF(k) (MM_WAVE_RAW(4) + (unsigned)(k) * 256u)     // the partner's offsets of 8 steps in flight (LDS-DMA)
+#define MM_WAVE_SLICE MM_WAVE_POFF(8)
 
 __device__ __forceinline__ float wave_sum_fixed(float v) {  // the same tree in every run and in every lane's view
     v += dpp_mov<MM_DPP_XOR1>(v);
@@ -59,16 +67,18 @@ __device__ __forceinline__ float wave_sum_fixed(float v) {  // the same tree in 
 }
 
 template <int NSEG, int NJ>  // NSEG: segments the registers of a wave hold; NJ * 64 >= P + 1
-__global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 1)) mm_wave_kernel(RunParams p) {
+__global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 2)) mm_wave_kernel(RunParams p) {
     extern __shared__ float lds[];
-    constexpr int KA = MM_WAVE_STRIDE * NSEG, NWD = MM_WAVE_NWD, NWA = NWD + 1, NT = 128 * NWA;
+    constexpr int KA = MM_WAVE_STRIDE * NSEG, NWD = MM_WAVE_NWD, NWA = NWD + 2, NT = 128 * NWA;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // 0: forward agent, 1: backward agent; the wave of the agent: NWD compute waves and a SERVICE wave, which stages the
-    // emissions and puts out the posteriors of a frame a step after the compute waves have summed them -- none of that is
-    // on the compute waves' path from one barrier to the next
+    // 0: forward agent, 1: backward agent; the wave of the agent: NWD compute waves and two SERVICE waves -- E stages the
+    // emissions and keeps the offsets, P finds the frame normalisers and puts out the posteriors of a frame two steps after
+    // the compute waves produced their terms: none of that is on the compute waves' path from one barrier to the next (one
+    // service wave for all of it was the longest wave of every step: ~200 instructions of a single wave, 1600 cycles
+    // against the compute waves' 900)
     const int DIR = wv / NWA, sub = wv % NWA;
-    const bool service = sub == NWD;
+    const bool svcE = sub == NWD, svcP = sub == NWD + 1, service = svcE || svcP;
     const int b = uni(p.order ? p.order[blockIdx.x] : (int)blockIdx.x);
     if (p.redo && !uni(p.redo[b])) return;
     const UttDesc &u = p.utts[b];
@@ -99,6 +109,11 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 1)) mm_wave_kernel(RunPar
     const unsigned long long lgw =
         mine_w ? ((unsigned long long)(unsigned)uni((int)(sc.lg >> 32)) << 32) | (unsigned)uni((int)sc.lg) : 0ull;
     const int nseg = mine_w ? uni((int)(sc.nslots & 0xffffu)) : 0, slot0 = mine_w ? uni((int)sc.slot0) : 0;
+    int lgmax = 0;  // largest log2 of the lanes of a row group in this wave's segments
+    for (int i = 0; i < 16; ++i) {
+        const int lgi = (int)((lgw >> (4 * i)) & 15ull);
+        lgmax = lgi > lgmax ? lgi : lgmax;
+    }
     {
         const auto wp = as_global(r.w);
         const auto ap = as_global(r.addr);
@@ -120,12 +135,28 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 1)) mm_wave_kernel(RunPar
         }
     }
     // ---- LDS set-up (the agent's slice, by its waves)
-    for (unsigned q = 4u * (unsigned)(sub * 64 + lane); q < MM_WAVE_SYNC; q += 256u * NWA) ldsw(base + q, MM_WAVE_NEG);
-    if (sub == 0 && lane < 4) ldswu(base + MM_WAVE_SYNC + 4u * lane, 0u);
-    const unsigned trash4 = 4u * (unsigned)S1;  // position written by lanes that finish no row
+    for (unsigned q = 4u * (unsigned)(sub * 64 + lane); q < MM_WAVE_FILL; q += 256u * NWA) ldsw(base + q, MM_WAVE_NEG);
+    if (sub == 0 && lane < 8) ldswu(base + MM_WAVE_MS(0) + 4u * lane, 0u);    // (the normalisers of steps 2 and 3 start from 0)
+    if (sub == 1 && lane < 4) ldswu(base + MM_WAVE_SYNC + 4u * lane, 0u);
+    // (compute waves) the per-pdf sums of phase B as NPS packed segments of this wave (mm_engine.hip wave_pdf_table):
+    // 4 source addresses in the vector u per lane and segment, the pdf the lane's group stores, log2 of the group's lanes
+    constexpr int NPS = NSEG / 2;
+    unsigned aq[4 * NPS], iq[NPS];
+    int qlvmax[NPS];
+    {
+        const auto tp = as_global(uni(u.rw[DIR].ptab));
+#pragma unroll
+        for (int j = 0; j < NPS; ++j) {
+            const int row = ((service ? 0 : sub) * 2 + j) * 5;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) aq[4 * j + q] = tp[(row + q) * 64 + lane] + base;
+            iq[j] = tp[(row + 4) * 64 + lane];
+            qlvmax[j] = __builtin_amdgcn_readfirstlane((int)wave_max_rl((float)(iq[j] >> 16)));
+        }
+    }
     __syncthreads();
     // the agent's own barrier: every wave adds 1 to the counter when its LDS writes of the step are done and waits for
-    // all NWD (LDS operations of a wave complete in order)
+    // all of them (LDS operations of a wave complete in order)
     unsigned epoch = 0;
     auto agent_sync = [&]() __attribute__((always_inline)) {
         epoch += NWA;
@@ -137,112 +168,124 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 1)) mm_wave_kernel(RunPar
                      : "v"(base + MM_WAVE_SYNC), "v"(epoch)
                      : "vcc", "memory");
     };
-    // maximum of the vector of a step: this wave's part to LDS before the barrier, all parts after it
-    auto vec_max = [&](unsigned ym) __attribute__((always_inline)) {
-        float M = ldsr(base + ym);
-#pragma unroll
-        for (int k = 1; k < NWA; ++k) M = fmaxf(M, ldsr(base + ym + 4u * k));
-        M = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, M)));
-        return M > 0.5f * MM_WAVE_NEG ? M : 0.f;
-    };
 
     // steps: step t handles frame t (forward) or NF + 1 - t (backward); steps 1 .. tA are phase A
     const int m = NF / 2;  // (len >= 1: NF >= 2, both agents have at least one step of phase A)
     const int tA = DIR ? NF - m : m;
     auto frame_of = [&](int t) __attribute__((always_inline)) { return DIR ? NF + 1 - t : t; };
-    // emissions of frame f into EM(par): expand() (src/inference.jl:54-60) in the log2 domain, zero(K) = MM_WAVE_NEG
-    // (service wave) raw values by LDS-DMA FOUR steps ahead -- a step is ~1 us, a load from HBM up to 2: fetched one step
-    // ahead, the agent waited for the service wave's load every step -- staged a step ahead
+    // ---- service wave: emissions of frame f into EM(par): expand() (src/inference.jl:54-60) in the log2 domain relative to
+    // the frame's maximum E (returned; zero(K) = MM_WAVE_NEG).  Raw values by LDS-DMA FOUR steps ahead -- a step is ~0.5 us,
+    // a load from HBM up to 2: fetched one step ahead, the agent waited for the service wave's load every step
     auto em_fetch = [&](int f) __attribute__((always_inline)) { row_dma_em<NJ>(base + MM_WAVE_RAW(f & 3), Vb, p.vsn, f, p.N, P, lane); };
     auto em_stage = [&](int f, int par) __attribute__((always_inline)) {
+        float v[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int q = lane + 64 * j;
-            float v = em_value(ldsr(base + MM_WAVE_RAW(f & 3) + 256u * j + 4u * lane), f, len, P, q);
-            v = v > MM_WAVE_NEG ? v : MM_WAVE_NEG;
-            if (q <= P) ldsw(base + MM_WAVE_EM(par) + 4u * q, v);
+            v[j] = em_value(ldsr(base + MM_WAVE_RAW(f & 3) + 256u * j + 4u * lane), f, len, P, q);
+            v[j] = v[j] > MM_WAVE_NEG ? v[j] : MM_WAVE_NEG;  // (also NaN -> zero(K))
         }
+        // E: the level of the frame's emissions.  Any finite number serves (it is accounted in the offsets): the first
+        // pdf's value stands for the frame -- what matters is that a common shift of a frame's scores (GMM-style values
+        // around -300) stays out of the vectors, a wave-wide maximum is ~100 cycles of this wave
+        float E = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v[0])));
+        if (!(E > 0.5f * MM_WAVE_NEG)) E = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int q = lane + 64 * j;
+            if (q <= P) ldsw(base + MM_WAVE_EM(par) + 4u * q, v[j] > 0.5f * MM_WAVE_NEG ? v[j] - E : MM_WAVE_NEG);
+        }
+        return E;
     };
-    // ---- step 1: the initial vector (the emissions are staged by the agent's first wave)
-    if (service) {
+    // ... the offset the partner stored with the frame of step t (a double: lanes 0 and 1 fetch its halves) -> POFF(t & 7)
+    auto poff_fetch = [&](int t) __attribute__((always_inline)) {
+        int f = frame_of(t);
+        f = f < 1 ? 1 : (f > NF ? NF : f);
+        dma_b32(reinterpret_cast<const unsigned *>(offs + f) + (lane & 1), base + MM_WAVE_POFF(t & 7));
+    };
+    // ... the maximum of the vector in VEC(par) (complete: the barrier of its step has been passed): 1024 states = 4 float4 per
+    // lane, all loads issued before the first maximum; clamped indices (a duplicate changes no maximum).  The positions from
+    // S1 to the end of the last float4 hold zero(K): the trash position only ever receives zero(K) (the lanes that write it
+    // have weights of zero(K) and the emission slot of zero(K)), the ones behind it are never written.
+    auto scan_max = [&](int par) __attribute__((always_inline)) {
+        const int n4 = (S1 + 3) >> 2;
+        const unsigned vb = base + MM_WAVE_VEC(par);
+        mm_f32x4 v0 = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(vb + 16u * (unsigned)(lane < n4 ? lane : n4 - 1));
+        mm_f32x4 v1 = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(vb + 16u * (unsigned)(lane + 64 < n4 ? lane + 64 : n4 - 1));
+        float M = fmaxf(fmaxf(fmaxf(v0.x, v0.y), fmaxf(v0.z, v0.w)), fmaxf(fmaxf(v1.x, v1.y), fmaxf(v1.z, v1.w)));
+        if (n4 > 128) {
+            v0 = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(vb + 16u * (unsigned)(lane + 128 < n4 ? lane + 128 : n4 - 1));
+            v1 = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(vb + 16u * (unsigned)(lane + 192 < n4 ? lane + 192 : n4 - 1));
+            M = fmaxf(M, fmaxf(fmaxf(fmaxf(v0.x, v0.y), fmaxf(v0.z, v0.w)), fmaxf(fmaxf(v1.x, v1.y), fmaxf(v1.z, v1.w))));
+        }
+        M = wave_max_rl(M);
+        return M > 0.5f * MM_WAVE_NEG ? M : 0.f;
+    };
+    double cum = 0.0;     // C_t (forward) / D_t (backward): what the vector of step t lacks to its log2 value
+    float Ecur = 0.f, Enext = 0.f;  // (service wave E) emission levels of this step's and the next step's frame
+    double zmin = __builtin_inf();
+    // ---- step 1: the initial vector (the emissions are staged by the agent's service wave)
+    if (svcE) {
         for (int t = 1; t <= 4; ++t) em_fetch(frame_of(t));
         MM_ROW_VMCNT(0);
-        em_stage(frame_of(1), 1);
+        Ecur = em_stage(frame_of(1), 1);
         em_fetch(frame_of(5));
+        cum = (double)Ecur;
+        if (lane == 0) offs[frame_of(1)] = DIR ? 0.0 : cum;  // (backward: the stored vector is without the frame's emission)
     }
     agent_sync();
-    double cum = 0.0;     // C_t (forward) / D_t (backward): what the vector of step t lacks to its log2 value
-    float Mprev = 0.f;    // maximum of the vector of the previous step (what this step subtracts)
-    double zmin = __builtin_inf();
-    {
-        float ymax = MM_WAVE_NEG;
+    if (!service) {
         if (DIR == 0) {  // alpha_hat (*) lhs[:,1]   (src/inference.jl:68)
-            for (int i = sub * 64 + lane; i < S1; i += 64 * NWA) {
+            for (int i = sub * 64 + lane; i < S1; i += 64 * NWD) {
                 const float ai = as_global(r.init)[i];
                 float v = (ai > MM_WAVE_NEG ? ai : MM_WAVE_NEG) + ldsr(base + MM_WAVE_EM(1) + 4u * as_global(r.rowpdf)[i]);
                 v = v > MM_WAVE_NEG ? v : MM_WAVE_NEG;
                 ldsw(base + MM_WAVE_VEC(1) + 4u * i, v);
                 rows[i] = v;  // frame 1
-                ymax = fmaxf(ymax, v);
             }
-            if (sub == 0 && lane == 0) offs[1] = 0.0;
         } else {  // B[:, len+1] = one at the final state   (src/inference.jl:104): y = b~ + lhs, the phony pdf emits one
             if (sub == 0 && lane == 0) ldsw(base + MM_WAVE_VEC(1) + 4u * r.fpos, 0.f);
-            for (int i = sub * 64 + lane; i < S1; i += 64 * NWA) rows[(long long)(NF - 1) * S1p + i] = i == r.fpos ? 0.f : MM_WAVE_NEG;
-            if (sub == 0 && lane == 0) offs[NF] = 0.0;
-            ymax = sub == 0 ? 0.f : MM_WAVE_NEG;
+            for (int i = sub * 64 + lane; i < S1; i += 64 * NWD) rows[(long long)(NF - 1) * S1p + i] = i == r.fpos ? 0.f : MM_WAVE_NEG;
         }
-        ymax = wave_max_rl(ymax);
-        if (lane == 0) ldsw(base + MM_WAVE_YM(1) + 4u * sub, ymax);
-    }
-    if (service) {
-        em_stage(frame_of(2), 0);
+    } else if (svcE) {
+        Enext = em_stage(frame_of(2), 0);
         em_fetch(frame_of(6));
     }
     agent_sync();
-    Mprev = vec_max(MM_WAVE_YM(1));
 
     // partner values of the rows this lane finishes, for the step after the one being computed (phase B)
-    struct uq_t {
-        float v[NSEG];
-    };
     float pv[NSEG], pvn[NSEG];
-    double po = 0.0, pon = 0.0;  // ... and the offset the partner stored with that frame
 #pragma unroll
     for (int i = 0; i < NSEG; ++i) pv[i] = pvn[i] = MM_WAVE_NEG;
     auto partner_fetch = [&](int t) __attribute__((always_inline)) {  // (clamped: an always valid row)
         int f = frame_of(t);
         f = f < 1 ? 1 : (f > NF ? NF : f);
         const float *row = rows + (long long)(f - 1) * S1p;
-        pon = offs[f];
-        if (!service) {
 #pragma unroll
-            for (int i = 0; i < NSEG; ++i) pvn[i] = row[(s1[i] & 0xffffu) >> 2];
-        }
+        for (int i = 0; i < NSEG; ++i) pvn[i] = row[(s1[i] & 0xffffu) >> 2];
     };
-    // Posteriors of the frame of step ts (its per-pdf sums are complete: the agent's barrier of that step has been
-    // passed), by ONE wave of the agent: gamma = sum over the waves of their sums, each on its own scale 2^(max u of the
-    // wave), normalised by the frame's own sum (:155-158); log Z of the frame = log2(sum) + max u + the two offsets (:159).
+    // (service wave) posteriors of the frame of step ts: its per-pdf log2 sums are complete (the compute waves formed them
+    // during step ts + 1).  gamma = 2^(pl - max) normalised by the frame's own sum (:155-158); log Z of the frame =
+    // log2(sum) + max + the two offsets (:159)
     auto frame_out = [&](int ts) __attribute__((always_inline)) {
         const int f = frame_of(ts);
-        const unsigned par = (unsigned)(ts & 3);
-        const double own_off = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(base + MM_WAVE_OFF(par));
-        const double partner_off = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(base + MM_WAVE_OFF(par) + 8u);
-        float um[NWD], mq = MM_WAVE_NEG;
-#pragma unroll
-        for (int k = 0; k < NWD; ++k) {
-            um[k] = ldsr(base + MM_WAVE_UM(par) + 4u * k);
-            mq = fmaxf(mq, um[k]);
-        }
-        const bool alive = mq > 0.5f * MM_WAVE_NEG;  // (nothing alive: no accepting path, gamma = 0)
-        float ps[NJ], tot = 0.f;
+        const double own_off = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(base + MM_WAVE_OFF(ts & 3));
+        const double partner_off = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(base + MM_WAVE_POFF(ts & 7));
+        float pl[NJ], M = MM_WAVE_NEG;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            ps[j] = 0.f;
+            const int q = lane + 64 * j;
+            pl[j] = ldsr(base + MM_WAVE_PL(ts & 1) + 4u * (unsigned)(q < P1 ? q : 0));
+            if (q < P1) M = fmaxf(M, pl[j]);
+        }
+        M = wave_max_rl(M);
+        const bool alive = M > 0.5f * MM_WAVE_NEG;  // (nothing alive: no accepting path, gamma = 0)
+        float tot = 0.f;
 #pragma unroll
-            for (int k = 0; k < NWD; ++k)  // (fixed order)
-                ps[j] += ldsr(base + MM_WAVE_PS(par, k) + 4u * (unsigned)(lane + 64 * j)) * (alive ? fast_exp2(um[k] - mq) : 0.f);
-            tot += (lane + 64 * j) < P1 ? ps[j] : 0.f;
+        for (int j = 0; j < NJ; ++j) {
+            const int q = lane + 64 * j;
+            pl[j] = (alive && q < P1) ? fast_exp2(pl[j] - M) : 0.f;
+            tot += pl[j];
         }
         tot = wave_sum_fixed(tot);
         const float inv = tot > 0.f ? 1.f / tot : 0.f;
@@ -250,73 +293,125 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 1)) mm_wave_kernel(RunPar
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int q = lane + 64 * j;
-            if (q < P) gp[q * p.gsp] = ps[j] * inv;
+            if (q < P) gp[q * p.gsp] = pl[j] * inv;
         }
-        const double z = alive ? (double)fast_log2(tot) + (double)mq + own_off + partner_off : -__builtin_inf();
+        const double z = alive ? (double)fast_log2(tot) + (double)M + own_off + partner_off : -__builtin_inf();
         zmin = z < zmin ? z : zmin;
     };
-    // (compute waves) the frame's posterior terms of the step before, on the scale of the wave's maximum: added into the
-    // wave's per-pdf sums at the start of the next step, BEHIND that step's gathers -- LDS float adds with conflicts take
-    // hundreds of cycles, and the LDS serves a wave's operations in order: issued before the barrier they were the barrier
-    uq_t uq;
-    auto flush_q = [&](int ts) __attribute__((always_inline)) {  // the adds of step ts (> tA)
-        const unsigned bufq = (unsigned)(ts & 3);
+    // log-sum-exp over lane groups: (mx, s) of every lane -> the group's, in all its lanes.  lvl = log2 of the lanes of
+    // this lane's group (per lane or wave-uniform), lvmax = the wave's largest.  Straight-line for groups of up to 16
+    // lanes (a select per level: a branch per level and value costs a wave ~30 cycles each, 300 for a segment).
+    auto group_lse = [&](float &mx, float &s, int lvl, int lvmax) __attribute__((always_inline)) {
+        float M = mx, t;
+        t = fmaxf(M, dpp_mov<MM_DPP_XOR1>(M));
+        M = lvl >= 1 ? t : M;
+        if (lvmax >= 2) {
+            t = fmaxf(M, dpp_mov<MM_DPP_XOR2>(M));
+            M = lvl >= 2 ? t : M;
+            if (lvmax >= 3) {
+                t = fmaxf(M, dpp_mov<MM_DPP_HALF_MIRROR>(M));
+                M = lvl >= 3 ? t : M;
+                t = fmaxf(M, dpp_mov<MM_DPP_MIRROR>(M));
+                M = lvl >= 4 ? t : M;
+                if (lvmax >= 5) {
+                    t = fmaxf(M, __shfl_xor(M, 16));
+                    M = lvl >= 5 ? t : M;
+                    t = fmaxf(M, __shfl_xor(M, 32));
+                    M = lvl >= 6 ? t : M;
+                }
+            }
+        }
+        float v = s * fast_exp2(mx - M);
+        t = v + dpp_mov<MM_DPP_XOR1>(v);
+        v = lvl >= 1 ? t : v;
+        if (lvmax >= 2) {
+            t = v + dpp_mov<MM_DPP_XOR2>(v);
+            v = lvl >= 2 ? t : v;
+            if (lvmax >= 3) {
+                t = v + dpp_mov<MM_DPP_HALF_MIRROR>(v);
+                v = lvl >= 3 ? t : v;
+                t = v + dpp_mov<MM_DPP_MIRROR>(v);
+                v = lvl >= 4 ? t : v;
+                if (lvmax >= 5) {
+                    t = v + __shfl_xor(v, 16);
+                    v = lvl >= 5 ? t : v;
+                    t = v + __shfl_xor(v, 32);
+                    v = lvl >= 6 ? t : v;
+                }
+            }
+        }
+        mx = M;
+        s = v;
+    };
+    // (compute waves) the per-pdf log2 sums of the frame of step ts, whose rows wrote u = log2(alpha~ beta~) to QV during that
+    // step: the wave's pdf segments -- gathers, a lane-local log-sum-exp, the groups' butterflies, one store per pdf; every
+    // order is fixed.  Issued BEHIND the next step's gathers.
+    auto pdf_reduce = [&](int ts) __attribute__((always_inline)) {
+        float x[4 * NPS];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) ldsw(base + MM_WAVE_PS(bufq, sub) + 4u * (unsigned)(lane + 64 * j), 0.f);
-        // one LDS float add per segment into the wave's OWN array: conflicting lanes of one instruction are served in the
-        // hardware's fixed order and the instructions in program order -- the same sums on every run (the item kernel's
-        // atomics race between waves)
+        for (int q = 0; q < 4 * NPS; ++q) x[q] = ldsr(aq[q] + MM_WAVE_QV(ts & 1));
 #pragma unroll
-        for (int i = 0; i < NSEG; ++i) {
-            const unsigned at = base + MM_WAVE_PS(bufq, sub) + (s0[i] >> 16);
-            asm volatile("ds_add_f32 %0, %1" ::"v"(at), "v"(uq.v[i]) : "memory");
+        for (int j = 0; j < NPS; ++j) {
+            float mx = fmaxf(fmaxf(x[4 * j], x[4 * j + 1]), fmaxf(x[4 * j + 2], x[4 * j + 3]));
+            float s = (fast_exp2(x[4 * j] - mx) + fast_exp2(x[4 * j + 1] - mx)) + (fast_exp2(x[4 * j + 2] - mx) + fast_exp2(x[4 * j + 3] - mx));
+            if (qlvmax[j] > 0) group_lse(mx, s, (int)(iq[j] >> 16), qlvmax[j]);
+            const float pl = mx > 0.5f * MM_WAVE_NEG ? mx + fast_log2(s) : MM_WAVE_NEG;
+            ldsw(base + MM_WAVE_PL(ts & 1) + (iq[j] & 0xffffu), pl);
         }
     };
 
     auto step = [&](auto RDc, auto PHc, int t) __attribute__((always_inline)) {
         constexpr int RD = decltype(RDc)::value, WR = 1 - RD, PHASE = decltype(PHc)::value;
         const int f = frame_of(t);
-        float *rowf = rows + (long long)(f - 1) * S1p;
-        float uu[NSEG];
-        float ymax = MM_WAVE_NEG, umax = MM_WAVE_NEG;
-        if constexpr (PHASE == 1) {
-#pragma unroll
-            for (int i = 0; i < NSEG; ++i) pv[i] = pvn[i];
-            po = pon;
-        }
-        cum += (double)Mprev;
-        if (service) {
-            // (what was fetched during the previous step is consumed BEFORE anything new goes to memory: the compiler waits
-            // for vmcnt(0) at the first use in a loop iteration, which would include stores issued just before)
-            // (the frame of step t + 1 was requested at step t - 3: of what is in flight only the youngest 3 NJ operations
-            // may be newer -- the other memory operations of this wave in between only make the wait stricter)
+        if (svcE) {
+            // (the frame of step t + 1 was requested at step t - 4: of what is in flight only the youngest 3 NJ operations may be
+            // newer -- the other memory operations of this wave in between only make the wait stricter)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NJ) : "memory");
-            em_stage(frame_of(t + 1), RD);  // emissions of step t + 1
+            MM_STAMP(2);
+            // the maximum of the vector of step t - 2 (found by wave P during the last step): what this step subtracts
+            const float Muse = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ldsr(base + MM_WAVE_MS(WR)))));
+            cum += (double)Muse + (double)Enext;
+            Ecur = Enext;
+            Enext = em_stage(frame_of(t + 1), RD);  // emissions of step t + 1
             em_fetch(frame_of(t + 5));
-            if constexpr (PHASE == 1) partner_fetch(t + 1);
+            MM_STAMP(3);
             if (lane == 0) {
-                ldsw(base + MM_WAVE_YM(WR) + 4u * sub, MM_WAVE_NEG);
-                if constexpr (PHASE == 0) {
-                    offs[f] = cum;
-                } else {
-                    *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(base + MM_WAVE_OFF(t & 3)) = cum;
-                    *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(base + MM_WAVE_OFF(t & 3) + 8u) = po;
-                }
+                const double off = DIR ? cum - (double)Ecur : cum;  // (backward: the stored / combined vector is without the frame's emission)
+                if constexpr (PHASE == 0) offs[f] = off;
+                else *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(base + MM_WAVE_OFF(t & 3)) = off;
             }
+            MM_STAMP(4);
+            agent_sync();
+            MM_STAMP(1);
+            return;
+        }
+        if (svcP) {
+            // the maximum of the vector of step t - 1: what step t + 1 subtracts
+            const float Mnew = scan_max(RD);
+            if (lane == 0) ldsw(base + MM_WAVE_MS(RD), Mnew);
+            MM_STAMP(2);
             if constexpr (PHASE == 1) {
-                // the frame of the step before last: the compute waves added its sums during the last step
+                // (the partner offset of step t - 2 was requested at step t - 4: at most the 3 requests since are newer)
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                poff_fetch(t + 2);
+                MM_STAMP(3);
+                // the frame of the step before last: the compute waves formed its per-pdf sums during the last step
                 if (t - 2 > tA) {
                     const int fp = frame_of(t - 2);
                     if (fp >= 1 && fp <= len) frame_out(t - 2);
                 }
             }
-            MM_STAMP(0);
+            MM_STAMP(4);
             agent_sync();
             MM_STAMP(1);
-            Mprev = vec_max(MM_WAVE_YM(WR));
             return;
         }
-        if constexpr (PHASE == 1) partner_fetch(t + 1);
+        float *rowf = rows + (long long)(f - 1) * S1p;
+        if constexpr (PHASE == 1) {
+#pragma unroll
+            for (int i = 0; i < NSEG; ++i) pv[i] = pvn[i];
+            partner_fetch(t + 1);
+        }
         // (1) every segment's lane-local log-sum-exp: ONE basic block -- all gathers and emission reads of the step are in
         // flight together; a branch per segment (fewer than NSEG segments, two arcs instead of four) made every segment
         // wait for its own LDS round trips, 8 x ~400 cycles per step.  Unused slots hold weight MM_WAVE_NEG: 2^(-1e30) = 0.
@@ -327,8 +422,10 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 1)) mm_wave_kernel(RunPar
             for (int q = 0; q < 4; ++q) xs[4 * i + q] = ldsr(a[4 * i + q] + MM_WAVE_VEC(RD));
             ems[i] = ldsr(base + MM_WAVE_EM(WR) + (s0[i] >> 16));
         }
+        // the maximum of the vector of step t - 2 (found by the service wave during the last step)
+        const float Muse = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ldsr(base + MM_WAVE_MS(WR)))));
         if constexpr (PHASE == 1)
-            if (t - 1 > tA) flush_q(t - 1);  // (behind the gathers)
+            if (t - 1 > tA) pdf_reduce(t - 1);  // (behind the gathers)
         static_for<0, NSEG>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
             const float x0 = xs[4 * i] + w[4 * i], x1 = xs[4 * i + 1] + w[4 * i + 1];
@@ -338,16 +435,11 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 1)) mm_wave_kernel(RunPar
             sums[i] = (fast_exp2(x0 - mx) + fast_exp2(x1 - mx)) + (fast_exp2(x2 - mx) + fast_exp2(x3 - mx));
         });
         MM_STAMP(2);
-        // (2) rows of more than 4 arcs (rare in the graphs of this kernel): lane-group maximum and sum
+        // (2) rows of more than 4 arcs (few in the graphs of this kernel; the waves that have none skip this)
         if (lgw != 0ull) {
             static_for<0, NSEG>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                const int lg = (int)((lgw >> (4 * i)) & 15ull);
-                if (lg) {
-                    const float M = grp_max(mxs[i], lg);
-                    sums[i] = grp_sum(sums[i] * fast_exp2(mxs[i] - M), lg);
-                    mxs[i] = M;
-                }
+                group_lse(mxs[i], sums[i], (int)((lgw >> (4 * i)) & 15ull), lgmax);
             });
         }
         // (3) finish the rows, again in one block
@@ -356,38 +448,23 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 1)) mm_wave_kernel(RunPar
             const unsigned pos4 = s0[i] & 0xffffu;
             // forward: (T' alpha) (*) lhs (src/inference.jl:70-71); backward: T (B (*) lhs) (:106-107), the emission is
             // added for the next step's product only
-            float bq = mxs[i] + fast_log2(sums[i]) - Mprev;
+            float bq = mxs[i] + fast_log2(sums[i]) - Muse;
             float y = bq + ems[i];
             y = y > MM_WAVE_NEG ? y : MM_WAVE_NEG;
             bq = bq > MM_WAVE_NEG ? bq : MM_WAVE_NEG;
             ldsw(base + MM_WAVE_VEC(WR) + pos4, y);
-            const bool mine = pos4 != trash4;
-            ymax = fmaxf(ymax, mine ? y : MM_WAVE_NEG);
             const float st = DIR ? bq : y;  // the vector that is stored / combined
             if constexpr (PHASE == 0) {
                 *reinterpret_cast<float *>(reinterpret_cast<char *>(rowf) + pos4) = st;
             } else {
-                uu[i] = mine ? st + pv[i] : MM_WAVE_NEG;  // log2 (alpha beta) up to the two offsets   (:154)
-                umax = fmaxf(umax, uu[i]);
+                float uu = st + pv[i];  // log2 (alpha beta) up to the two offsets   (:154)
+                uu = uu > MM_WAVE_NEG ? uu : MM_WAVE_NEG;
+                ldsw(base + MM_WAVE_QV(WR) + pos4, uu);
             }
         });
         MM_STAMP(3);
-        ymax = wave_max_rl(ymax);
-        if (lane == 0) ldsw(base + MM_WAVE_YM(WR) + 4u * sub, ymax);
-        MM_STAMP(4);
-        if constexpr (PHASE == 1) {
-            // this wave's share of the per-pdf sums of the frame, on the scale of its own maximum: q = 2^(u - max u of the
-            // wave); added to the sums at the start of the next step (flush_q)
-            umax = wave_max_rl(umax);
-            if (lane == 0) ldsw(base + MM_WAVE_UM(t & 3) + 4u * sub, umax);
-#pragma unroll
-            for (int i = 0; i < NSEG; ++i) uq.v[i] = umax > 0.5f * MM_WAVE_NEG ? fast_exp2(uu[i] - umax) : 0.f;
-        }
-        MM_STAMP(0);
         agent_sync();
         MM_STAMP(1);
-        Mprev = vec_max(MM_WAVE_YM(WR));
-        MM_STAMP(5);
     };
     auto run = [&](auto PHc, int tfirst, int tlast) __attribute__((always_inline)) {
         for (int t = tfirst; t <= tlast; t += 2) {
@@ -402,19 +479,36 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 1)) mm_wave_kernel(RunPar
     MM_STAMP_RESET;
     run(std::integral_constant<int, 0>{}, 2, tA);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef MM_STAMPS
+    if (p.x_sleep & 0x2000) {  // (report phase A only)
+        if (p.dbg && lane == 0)
+            for (int q = 0; q < 8; ++q) p.dbg[((long long)b * 16 + wv) * 8 + q] = stamp_acc[q];
+        p.dbg = nullptr;
+    }
+    if (p.x_sleep & 0x1000)  // (report phase B only)
+        for (int q = 0; q < 8; ++q) stamp_acc[q] = 0;
+#endif
     __syncthreads();  // the ONE workgroup barrier: phase A of both agents is stored
-    partner_fetch(tA + 1);
+    MM_STAMP_RESET;
+    if (svcP) {
+        poff_fetch(tA + 1);
+        poff_fetch(tA + 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (!service) {
+        partner_fetch(tA + 1);
+    }
     run(std::integral_constant<int, 1>{}, tA + 1, NF);
     // the last two steps' frames (NF is not live for the forward agent: frame len + 1; frame 1 for the backward agent)
     if (NF > tA) {
-        if (service) {
+        if (svcP) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int fp = frame_of(NF - 1);
             if (NF - 1 > tA && fp >= 1 && fp <= len) frame_out(NF - 1);
-        } else {
-            flush_q(NF);
+        } else if (!service) {
+            pdf_reduce(NF);
         }
         agent_sync();
-        if (service) {
+        if (svcP) {
             const int fp = frame_of(NF);
             if (fp >= 1 && fp <= len) frame_out(NF);
         }
@@ -424,7 +518,7 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 1)) mm_wave_kernel(RunPar
         for (int q = 0; q < 8; ++q) p.dbg[((long long)b * 16 + wv) * 8 + q] = stamp_acc[q];
 #endif
     // ---- ttl, zeros beyond the sequence length
-    if (lane == 0 && service) *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(base + MM_WAVE_ZZ) = zmin;
+    if (lane == 0 && svcP) *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(base + MM_WAVE_ZZ) = zmin;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -72,6 +72,7 @@ struct RowDev {  // one direction in row-lane form, internal numbering (mm_rows.
     const unsigned short *pdfse;  // [2 * P1] (first, end) of each pdf in pdf-major order (backward only)
     const float *init;            // [rows] alpha_hat by position, log2 domain (forward only)
     const int *order;             // [rows] position -> original state (Viterbi form: the path is reported in original states)
+    const unsigned *ptab;         // wave form: the per-pdf sums as packed segments (mm_engine.hip wave_pdf_table), else NULL
     int KA, NWC, nslotrows, fpos, rows;
     float thr;  // |normalised log2 value| beyond which the linear path is not trusted (mm_kernel_rows.hip)
 };

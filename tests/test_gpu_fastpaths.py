@@ -66,6 +66,29 @@ def test_split_kernels_on_the_reference_wsj_denominator(mm, wl, oracle, torch, m
     assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-4)
 
 
+def test_split_kernels_team_that_does_not_run_together(mm, wl, oracle, torch):
+    """A team whose workgroups cannot see each other (a foreign kernel holding the compute units; here simulated: the
+    exchange waves give up at once, MM_SPLIT_SLEEP bit 0x200) marks its utterances with 2; the finish kernel keeps such
+    marks whatever the normalisers say and the exact kernels compute every utterance again: same results, B redone."""
+    g = wsj_den(wl)
+    rng = np.random.default_rng(18)
+    B, N = 5, 24
+    V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+    lens = np.array([24, 24, 13, 24, 20], dtype=np.int32)
+
+    def run():
+        cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+        bf = mm.batch(*([cf] * B))
+        gam, ttl = bf.pdfposteriors(V, lens)
+        return gam, ttl, bf.kernels(), bf.last_redo_count()
+
+    gam, ttl, kernels, redo = _with_env({"MM_DEBUG": "1", "MM_SPLIT_SLEEP": str(8 | 0x200)}, run)
+    assert "mm_fbs_kernel_dir" in kernels and redo == B
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    check_gamma(gam, g_ref, lens)
+    assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)
+
+
 def test_split_kernels_long_utterances_keep_their_range_marks_harmless(mm, wl, oracle, torch):
     """On the WSJ graph the states of the initial contexts fall ~2 log2 per frame behind the rest: after ~55 frames they
     leave the float range of the linear path and the kernels mark the utterance.  The per-frame normalisers agree

@@ -29,7 +29,11 @@ n = B * 16 * 16
 out = np.zeros(n, dtype=np.uint64)
 L.lib.mm_debug_read_stamps.argtypes = [C.c_void_p, C.c_int64]
 assert L.lib.mm_debug_read_stamps(out.ctypes.data, n) == 0
-s = out[: B * 16 * 8].reshape(B, 16, 8).astype(np.float64) / N
-names = ["to barrier (0)", "in barrier (1)", "gather+lse (2)", "finish (3)", "wave max (4)", "vec_max (5)"]
-for wv in range(10):
-    print("wave", wv, " ".join(f"{names[k]} {s[:, wv, k].mean():6.0f}" for k in range(6)), " total %.0f" % s[:, wv, :6].sum(-1).mean())
+sel = int(os.environ.get("MM_SPLIT_SLEEP", "0"))  # 0x1000: phase B only, 0x2000: phase A only (read by the kernel under MM_DEBUG)
+s = out[: B * 16 * 8].reshape(B, 16, 8).astype(np.float64) / (N / 2 if sel & 0x3000 else N)
+names = ["-", "in barrier (1)", "gather+lse (2)", "finish (3)", "-", "-"]
+enames = ["-", "in barrier (1)", "wait DMA (2)", "stage+fetch (3)", "offset (4)", "-"]
+pnames = ["-", "in barrier (1)", "scan max (2)", "poff (3)", "frame_out (4)", "-"]
+for wv in range(12):
+    nm = enames if wv % 6 == 4 else pnames if wv % 6 == 5 else names
+    print("wave", wv, " ".join(f"{nm[k]} {s[:, wv, k].mean():6.0f}" for k in range(6)), " total %.0f" % s[:, wv, :6].sum(-1).mean())

@@ -2114,6 +2114,13 @@ int mm_viterbi_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const
     p.path = path;
     p.path_stride_b = path_stride_b;
     p.score = score;
+#ifdef MM_STAMPS
+    if (!g_dbg) {
+        g_dbg_n = size_t(16) * MM_MAX_WAVES * size_t(h->B);
+        (void)hipMalloc(&g_dbg, sizeof(unsigned long long) * g_dbg_n);
+    }
+    p.dbg = g_dbg;
+#endif
     if (h->vit_ok && p.stop_at_len) {  // (internal back-pointers: the compact form)
         VitLaunch vl;
         vl.B = h->B;

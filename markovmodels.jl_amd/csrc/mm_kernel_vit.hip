@@ -12,7 +12,7 @@
 //     transcendental, no normaliser (the reference's plain float adds: the scores are bit-identical to the CPU
 //     restatement), for rows of more than 4 arcs a lane-group reduction by DPP under the same tie rule;
 //   * a back-pointer is the NUMBER OF THE ARC in its row (rows have their arcs by ascending source state, so the first
-//     maximum is the one the tie rule wants): one byte per state and frame, 255 = none -- a quarter of the int32 rows,
+//     maximum is the one the tie rule wants): one byte per state and frame -- a quarter of the int32 rows,
 //     which were the algorithmic traffic of this path;
 //   * back-trace: one workgroup per utterance streams the byte rows through a double-buffered LDS ring, 8 KB per hop of the
 //     chase hidden behind the copy of the next chunk; the hop itself is three LDS reads (arc number, row pointer, source).
@@ -22,6 +22,61 @@
 #include "mm_kernel_rows.hip"
 
 namespace mm {
+
+// (max, lowest arg-max) over an aligned group of 1 << lg lanes (lg wave-uniform), in all its lanes -- a row of 5 to 256
+// arcs: the hub states of a lexicon graph.  Two butterflies of ONE instruction per level instead of one of a dozen (two
+// moves, four compares, two selects per level, as trop_grp_reduce of the item kernel has it): the maximum of the lanes'
+// values, then the minimum of the arc numbers of the lanes whose own value IS that maximum (a lane's own pair already
+// follows the tie rule: strict '>' over ascending arcs; arc numbers grow with the source state).  Across the 16-lane rows
+// through scalar registers, not ds_bpermute (an LDS round trip per value and level).  The four waves that own a hub row
+// were the slowest of every frame by 40 %.
+#define MM_VIT_DPP(op, ctrl) asm("s_nop 1\n\t" op " %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(v))
+__device__ __forceinline__ float vit_grp_max(float v, int lg, int lane) {
+    MM_VIT_DPP("v_max_f32_dpp", "quad_perm:[1,0,3,2]");
+    if (lg >= 2) {
+        MM_VIT_DPP("v_max_f32_dpp", "quad_perm:[2,3,0,1]");
+        if (lg >= 3) {
+            MM_VIT_DPP("v_max_f32_dpp", "row_half_mirror");
+            if (lg >= 4) {
+                MM_VIT_DPP("v_max_f32_dpp", "row_mirror");
+                if (lg >= 5) {
+                    const int iv = __builtin_bit_cast(int, v);
+                    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+                    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+                    float lo = max_nc(r0, r1), hi = max_nc(r2, r3);
+                    if (lg >= 6) lo = hi = max_nc(lo, hi);
+                    v = lane < 32 ? lo : hi;
+                }
+            }
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ int vit_grp_min(int v, int lg, int lane) {
+    MM_VIT_DPP("v_min_i32_dpp", "quad_perm:[1,0,3,2]");
+    if (lg >= 2) {
+        MM_VIT_DPP("v_min_i32_dpp", "quad_perm:[2,3,0,1]");
+        if (lg >= 3) {
+            MM_VIT_DPP("v_min_i32_dpp", "row_half_mirror");
+            if (lg >= 4) {
+                MM_VIT_DPP("v_min_i32_dpp", "row_mirror");
+                if (lg >= 5) {
+                    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+                    const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+                    int lo = r0 < r1 ? r0 : r1, hi = r2 < r3 ? r2 : r3;
+                    if (lg >= 6) lo = hi = lo < hi ? lo : hi;
+                    v = lane < 32 ? lo : hi;
+                }
+            }
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ void vit_grp_reduce(float &best, int &arg, int lg, int lane) {
+    const float M = vit_grp_max(best, lg, lane);
+    arg = vit_grp_min(best == M ? arg : 0x7fffffff, lg, lane);
+    best = M;
+}
 
 #define MM_VIT_NWC 15
 #define MM_VIT_ESZ 1056u  // bytes of an emission buffer (256 pdfs + the "no row" slot)
@@ -48,6 +103,7 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
     // [utterance][frame - 1][bp_stride_n bytes] arc numbers (rows padded to 256 bytes: a chunk of frames is one aligned block)
     unsigned char *bpk = reinterpret_cast<unsigned char *>(p.bp) + (long long)b * (p.N + 1) * p.bp_stride_n;
     if (lds_addr_of(lds) != 0u) __builtin_trap();
+    MM_STAMP_DECL;
 
     // ---- the wave's rows: registers
     float w[KA];
@@ -85,7 +141,6 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
     for (int j = 0; j < N2; ++j) lgp |= (j < n2w ? ((lgw >> (4 * (n4w + j))) & 15ull) : 0ull) << (4 * (N4 + j));
     const unsigned sub = (unsigned)lane & ((1u << 6) - 1u);
     for (unsigned q = 4u * tid; q < 2u * VSZ + 2u * MM_VIT_ESZ + 4u * NJ * 256u; q += 4096u) ldsw(q, MM_NINF);
-    const unsigned trash4 = 4u * (unsigned)S1;
     // emissions (expand(), src/inference.jl:54-60; natural log like the reference's tropical values), by the service wave:
     // raw values by LDS-DMA FOUR frames ahead (a frame is ~0.5 us, a load from HBM 1-2 us: fetched one frame ahead the
     // whole workgroup waited for the service wave's load every frame), staged a frame ahead
@@ -124,9 +179,16 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
         if (service) {
             // frame n + 1 was requested at step n - 3: at most the NJ DMAs of each of the 3 later requests are in flight
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NJ) : "memory");
+            MM_STAMP(2);
             em_stage(n + 1, RD);
             em_fetch(n + 5);  // (its buffer, frame (n + 1) & 3, has just been read)
         } else {
+            // the frame's row of back-pointers: one byte per position, the lanes of a segment store adjacent bytes.  Every
+            // lane stores -- the ones without a row to the "no row" position, a byte of the padded row like any other -- and
+            // dead states store whatever arc won the comparison of -inf values: the back-trace starts from a state that
+            // is alive (or not at all: score = -inf) and a live state's best arc comes from a live state.  (An exec mask
+            // for the lanes without a row and a compare-select per position for the dead ones were a sixth of the vector
+            // instructions of a 2-arc position, in a kernel in which the SIMDs' issue slots and the LDS are both ~90 % busy.)
             unsigned char *row = bpk + (long long)(n - 1) * p.bp_stride_n;
             // a block of positions at a time: its gathers and emission reads in flight together, then straight-line code.
             // W arc slots per position, NB positions from position h0 on, their slots from k0 on.
@@ -161,7 +223,7 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
                         const int lg = (int)((lgp >> (4 * (h0 + i))) & 15ull);
                         if (lg) {
                             arg[i] = (int)(sub & ((1u << lg) - 1u)) + (arg[i] << lg);
-                            trop_grp_reduce(best[i], arg[i], lg);
+                            vit_grp_reduce(best[i], arg[i], lg, lane);
                         }
                     }
                 }
@@ -169,7 +231,7 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
                 for (int i = 0; i < NB; ++i) {
                     const unsigned pos4 = s0[h0 + i] & 0xffffu;
                     ldsw(pos4 + (unsigned)WR * VSZ, best[i] + es[i]);  // (*) lhs[:, n]   (:70-71)
-                    if (pos4 != trash4) row[pos4 >> 2] = best[i] > MM_NINF ? (unsigned char)arg[i] : (unsigned char)255;
+                    row[pos4 >> 2] = (unsigned char)arg[i];
                 }
             };
             using std::integral_constant;
@@ -179,12 +241,19 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
             if constexpr (N2 > 0) block(integral_constant<int, 2>{}, integral_constant<int, (N2 < 4 ? N2 : 4)>{}, integral_constant<int, N4>{}, integral_constant<int, 4 * N4>{});
             if constexpr (N2 > 4) block(integral_constant<int, 2>{}, integral_constant<int, N2 - 4>{}, integral_constant<int, N4 + 4>{}, integral_constant<int, 4 * N4 + 8>{});
         }
+        MM_STAMP(0);
         __syncthreads();
+        MM_STAMP(1);
     };
+    MM_STAMP_RESET;
     for (int n = 2; n <= NF; n += 2) {
         step(std::integral_constant<int, 1>{}, n);
         if (n + 1 <= NF) step(std::integral_constant<int, 0>{}, n + 1);
     }
+#ifdef MM_STAMPS
+    if (p.dbg && lane == 0)
+        for (int q = 0; q < 8; ++q) p.dbg[((long long)b * 16 + wave) * 8 + q] = stamp_acc[q];
+#endif
     if (tid == 0) p.score[b] = ldsr((unsigned)(NF & 1) * VSZ + 4u * (unsigned)r.fpos);
 }
 

@@ -343,6 +343,53 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 2)) mm_wave_kernel(RunPar
         mx = M;
         s = v;
     };
+    // ... the same for a wave-uniform lvl (the state segments: all rows of a segment have groups of one size): no selects, the
+    // combine of a level is ONE instruction (v_max_f32_dpp / v_add_f32_dpp), the 16-lane rows meet in scalar registers
+#define MM_WAVE_DPP(op, ctrl) asm("s_nop 1\n\t" op " %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(v))
+    auto group_lse_uniform = [&](float &mx, float &s, int lvl) __attribute__((always_inline)) {
+        if (lvl == 0) return;
+        float v = mx;
+        MM_WAVE_DPP("v_max_f32_dpp", "quad_perm:[1,0,3,2]");
+        if (lvl >= 2) {
+            MM_WAVE_DPP("v_max_f32_dpp", "quad_perm:[2,3,0,1]");
+            if (lvl >= 3) {
+                MM_WAVE_DPP("v_max_f32_dpp", "row_half_mirror");
+                if (lvl >= 4) {
+                    MM_WAVE_DPP("v_max_f32_dpp", "row_mirror");
+                    if (lvl >= 5) {
+                        const int iv = __builtin_bit_cast(int, v);
+                        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+                        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+                        float lo = fmaxf(r0, r1), hi = fmaxf(r2, r3);
+                        if (lvl >= 6) lo = hi = fmaxf(lo, hi);
+                        v = lane < 32 ? lo : hi;
+                    }
+                }
+            }
+        }
+        const float M = v;
+        v = s * fast_exp2(mx - M);
+        MM_WAVE_DPP("v_add_f32_dpp", "quad_perm:[1,0,3,2]");
+        if (lvl >= 2) {
+            MM_WAVE_DPP("v_add_f32_dpp", "quad_perm:[2,3,0,1]");
+            if (lvl >= 3) {
+                MM_WAVE_DPP("v_add_f32_dpp", "row_half_mirror");
+                if (lvl >= 4) {
+                    MM_WAVE_DPP("v_add_f32_dpp", "row_mirror");
+                    if (lvl >= 5) {
+                        const int iv = __builtin_bit_cast(int, v);
+                        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+                        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+                        float lo = r0 + r1, hi = r2 + r3;
+                        if (lvl >= 6) lo = hi = lo + hi;
+                        v = lane < 32 ? lo : hi;
+                    }
+                }
+            }
+        }
+        mx = M;
+        s = v;
+    };
     // (compute waves) the per-pdf log2 sums of the frame of step ts, whose rows wrote u = log2(alpha~ beta~) to QV during that
     // step: the wave's pdf segments -- gathers, a lane-local log-sum-exp, the groups' butterflies, one store per pdf; every
     // order is fixed.  Issued BEHIND the next step's gathers.
@@ -439,7 +486,7 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 2)) mm_wave_kernel(RunPar
         if (lgw != 0ull) {
             static_for<0, NSEG>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                group_lse(mxs[i], sums[i], (int)((lgw >> (4 * i)) & 15ull), lgmax);
+                group_lse_uniform(mxs[i], sums[i], (int)((lgw >> (4 * i)) & 15ull));
             });
         }
         // (3) finish the rows, again in one block

@@ -1456,7 +1456,7 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     // row kernels: every FSM of the batch needs its row-lane forms.  Small deep (left-to-right) graphs keep states
     // alive whose values differ by more than the float range within one frame, so most of their rows would take the
     // exact fallback of the linear-domain kernels: they run on the item kernel (unless a kernel is forced).
-    h->rows_ok = h->fast_ok && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD &&
+    h->rows_ok = h->fast_ok && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD && h->dbg.kernel != DebugOpts::K_WAVE &&
                  !(h->max_depth >= 64 && nq_max[0] <= 3 * 1024 && nq_max[1] <= 3 * 1024 && h->dbg.kernel == DebugOpts::K_AUTO);
     for (int64_t b = 0; b < B && h->rows_ok; ++b) {
         bool ok = false;
@@ -1488,7 +1488,7 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     // split pair kernels: one shared FSM that is too large for the pair kernels proper (more arcs than the registers of a
     // compute unit hold, more states than half its LDS) -- teams of 2 workgroups per utterance pair and direction
     if (!h->pairs_ok && h->fast_ok && B >= 2 && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD &&
-        h->dbg.kernel != DebugOpts::K_ROW &&
+        h->dbg.kernel != DebugOpts::K_ROW && h->dbg.kernel != DebugOpts::K_WAVE &&
         !(h->max_depth >= 64 && nq_max[0] <= 3 * 1024 && nq_max[1] <= 3 * 1024 && h->dbg.kernel == DebugOpts::K_AUTO)) {
         bool same = true;
         for (int64_t b = 1; b < B && same; ++b) same = fsms[b] == fsms[0];

@@ -551,3 +551,33 @@ def test_wave_kernel_is_the_numerator_path_and_deterministic(mm, wl, oracle, tor
             assert np.allclose(ttl[b], t_ref[0], rtol=1e-5, atol=5e-4)
         else:
             assert (gam[b] == 0).all() and np.isneginf(ttl[b])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,P", [(900, 7), (850, 120), (300, 3), (64, 200)])
+def test_wave_kernel_pdf_segments(mm, wl, oracle, torch, S, P):
+    """The per-pdf sums of the wave kernel are packed segments of their own (mm_engine.hip wave_pdf_table): a pdf with n
+    states gets pow2(ceil(n / 4)) lanes.  900 states on 7 pdfs: groups of 64 lanes (all six butterfly levels, the last two
+    across the 16-lane rows); 850 states on 120 pdfs: 307 lanes, two pdf segments per wave (the 4-segment instance); 300 states on
+    3 pdfs; more pdfs than states (most pdfs empty)."""
+    o, oc = oracle
+    g = wl.lexicon_fsm(S, P, seed=S + P, hubs=1 if P < 4 else 2)
+    rng = np.random.default_rng(S)
+    B, N = 3, 33
+    V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+    lens = np.array([33, 20, 9], dtype=np.int32)
+
+    def run():
+        cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+        bf = mm.batch(*([cf] * B))
+        gam, ttl = bf.pdfposteriors(V, lens)
+        return gam, ttl, bf.kernels("log")
+
+    gam, ttl, kernels = _with_env({"MM_DEBUG": "1", "MM_KERNEL": "wave"}, run)
+    assert "mm_wave_kernel" in kernels and (S != 850 or "mm_wave_kernel<4" in kernels), kernels
+    g_ref, t_ref = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V, lens, dtype=np.float64)
+    ok = np.isfinite(t_ref)
+    assert ok.any()
+    check_gamma(gam[ok], g_ref[ok], lens[ok])
+    assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=5e-4)
+    assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()

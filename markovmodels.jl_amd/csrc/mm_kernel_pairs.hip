@@ -689,7 +689,13 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         };
         auto step = [&](auto RDc, int t) {
             constexpr int RD = decltype(RDc)::value, WR = 1 - RD;  // RD = parity of steps t - 1 and t + 1
-            if constexpr (H > 1) asm volatile("" : "+v"(sl));
+            // (NJ = 4, P + 1 > 128: with the addresses of 8 emission DMAs and 8 gamma stores hoisted the phase B kernels spilled
+            // 24 / 33 VGPRs, and this wave waited for its DMAs at every reload: 4.0 -> 3.6 ms per call on config 3's graph
+            // with 200 pdfs.  NJ = 2 keeps its hoisted addresses: 2.94 against 3.12 ms with the opaque lane -- -DMM_PAIR_OPAQUE_B=1)
+#ifndef MM_PAIR_OPAQUE_B
+#define MM_PAIR_OPAQUE_B 0
+#endif
+            if constexpr (H > 1 || NJ > 2 || (MM_PAIR_OPAQUE_B && PHASE == 1)) asm volatile("" : "+v"(sl));
             // emissions of step t + 1 (requested at step t - 2: the DMAs of step t - 1 may still be in flight)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
             MM_STAMP(2);

@@ -17,7 +17,7 @@ import torch  # noqa: E402
 mm = ge.load_package()
 wl = importlib.import_module(mm.__name__ + ".workloads")
 L = importlib.import_module(mm.__name__ + "._lib")
-g, B = wl.lfmmi_denominator(2000, 84, seed=0), 256
+g, B = wl.lfmmi_denominator(2000, int(os.environ.get("P", 84)), seed=0), 256
 if os.environ.get("WL") == "wsj_den":
     g, B = wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "den_fsm_wsj.npz")), 128
 N = int(os.environ.get("N", 300))

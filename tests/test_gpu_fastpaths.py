@@ -263,6 +263,18 @@ def test_fuzz_pairs_one_seed(mm, wl, oracle, torch):
     assert mod.main(1) == 0
 
 
+def test_fuzz_round3_one_seed(mm, wl, oracle, torch):
+    """One seed of tools/fuzz_round3.py: the split pair kernels, the wave kernel (twice: identical bits) and Viterbi on the
+    row-lane form against the item kernel, on random graphs, batch sizes (more teams than compute units), frame counts
+    and length patterns."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("fuzz_round3", os.path.join(os.path.dirname(HERE), "tools", "fuzz_round3.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(2) == 0
+
+
 def test_engine_under_a_live_rccl_process_group(mm, wl, oracle, torch):
     """The HIP engine inside a torch.distributed process ("nccl" = RCCL, one rank: what every rank of bench.py --gpus N
     is): with an RCCL communicator alive HIP maps streams to hardware queues differently, and the two agents of the

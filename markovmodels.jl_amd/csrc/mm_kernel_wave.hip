@@ -407,10 +407,12 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 2)) mm_wave_kernel(RunPar
         }
     };
 
-    auto step = [&](auto RDc, auto PHc, int t) __attribute__((always_inline)) {
-        constexpr int RD = decltype(RDc)::value, WR = 1 - RD, PHASE = decltype(PHc)::value;
+    // ROLE: 0 compute wave, 1 service wave E, 2 service wave P -- one loop per role (run()): what only one role needs (the
+    // pointers of the emissions and posteriors, the graph registers) does not stay live in the other roles' loops
+    auto step = [&](auto RDc, auto PHc, auto ROLEc, int t) __attribute__((always_inline)) {
+        constexpr int RD = decltype(RDc)::value, WR = 1 - RD, PHASE = decltype(PHc)::value, ROLE = decltype(ROLEc)::value;
         const int f = frame_of(t);
-        if (svcE) {
+        if constexpr (ROLE == 1) {
             // (the frame of step t + 1 was requested at step t - 4: of what is in flight only the youngest 3 NJ operations may be
             // newer -- the other memory operations of this wave in between only make the wait stricter)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NJ) : "memory");
@@ -430,9 +432,8 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 2)) mm_wave_kernel(RunPar
             MM_STAMP(4);
             agent_sync();
             MM_STAMP(1);
-            return;
         }
-        if (svcP) {
+        if constexpr (ROLE == 2) {
             // the maximum of the vector of step t - 1: what step t + 1 subtracts
             const float Mnew = scan_max(RD);
             if (lane == 0) ldsw(base + MM_WAVE_MS(RD), Mnew);
@@ -451,8 +452,8 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 2)) mm_wave_kernel(RunPar
             MM_STAMP(4);
             agent_sync();
             MM_STAMP(1);
-            return;
         }
+        if constexpr (ROLE == 0) {
         float *rowf = rows + (long long)(f - 1) * S1p;
         if constexpr (PHASE == 1) {
 #pragma unroll
@@ -512,16 +513,22 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 2)) mm_wave_kernel(RunPar
         MM_STAMP(3);
         agent_sync();
         MM_STAMP(1);
+        }
     };
-    auto run = [&](auto PHc, int tfirst, int tlast) __attribute__((always_inline)) {
+    auto run_role = [&](auto PHc, auto ROLEc, int tfirst, int tlast) __attribute__((always_inline)) {
         for (int t = tfirst; t <= tlast; t += 2) {
-            if (t & 1) step(std::integral_constant<int, 0>{}, PHc, t);
-            else step(std::integral_constant<int, 1>{}, PHc, t);
+            if (t & 1) step(std::integral_constant<int, 0>{}, PHc, ROLEc, t);
+            else step(std::integral_constant<int, 1>{}, PHc, ROLEc, t);
             if (t + 1 <= tlast) {
-                if ((t + 1) & 1) step(std::integral_constant<int, 0>{}, PHc, t + 1);
-                else step(std::integral_constant<int, 1>{}, PHc, t + 1);
+                if ((t + 1) & 1) step(std::integral_constant<int, 0>{}, PHc, ROLEc, t + 1);
+                else step(std::integral_constant<int, 1>{}, PHc, ROLEc, t + 1);
             }
         }
+    };
+    auto run = [&](auto PHc, int tfirst, int tlast) __attribute__((always_inline)) {
+        if (svcE) run_role(PHc, std::integral_constant<int, 1>{}, tfirst, tlast);
+        else if (svcP) run_role(PHc, std::integral_constant<int, 2>{}, tfirst, tlast);
+        else run_role(PHc, std::integral_constant<int, 0>{}, tfirst, tlast);
     };
     MM_STAMP_RESET;
     run(std::integral_constant<int, 0>{}, 2, tA);

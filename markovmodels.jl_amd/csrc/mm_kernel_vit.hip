@@ -174,9 +174,12 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
     }
     __syncthreads();
 
-    auto step = [&](auto RDc, int n) __attribute__((always_inline)) {
+    // (SVC: the service wave's loop and the compute waves' loop are two loops: what only one role needs -- the emission
+    // pointers, the graph registers -- does not stay live in the other's)
+    auto step = [&](auto RDc, auto SVCc, int n) __attribute__((always_inline)) {
         constexpr int RD = decltype(RDc)::value, WR = 1 - RD;  // RD = parity of frame n - 1
-        if (service) {
+        constexpr bool SVC = decltype(SVCc)::value;
+        if constexpr (SVC) {
             // frame n + 1 was requested at step n - 3: at most the NJ DMAs of each of the 3 later requests are in flight
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NJ) : "memory");
             MM_STAMP(2);
@@ -246,10 +249,14 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
         MM_STAMP(1);
     };
     MM_STAMP_RESET;
-    for (int n = 2; n <= NF; n += 2) {
-        step(std::integral_constant<int, 1>{}, n);
-        if (n + 1 <= NF) step(std::integral_constant<int, 0>{}, n + 1);
-    }
+    auto run = [&](auto SVCc) __attribute__((always_inline)) {
+        for (int n = 2; n <= NF; n += 2) {
+            step(std::integral_constant<int, 1>{}, SVCc, n);
+            if (n + 1 <= NF) step(std::integral_constant<int, 0>{}, SVCc, n + 1);
+        }
+    };
+    if (service) run(std::integral_constant<bool, true>{});
+    else run(std::integral_constant<bool, false>{});
 #ifdef MM_STAMPS
     if (p.dbg && lane == 0)
         for (int q = 0; q < 8; ++q) p.dbg[((long long)b * 16 + wave) * 8 + q] = stamp_acc[q];

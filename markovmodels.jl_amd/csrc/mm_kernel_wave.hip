@@ -17,9 +17,9 @@
 //     (log2 weight + LDS byte address of the source), so a segment is straight-line code: <= 4 gathers, a two-pass
 //     log-sum-exp in registers, for rows of more than 4 arcs a lane-group maximum and sum by DPP;
 //   * the state vector of a step lives in the agent's LDS slice, double buffered by the parity of the step;
-//   * two SERVICE waves per agent do everything that is not on the path from one barrier to the next: wave E the emissions
-//     (LDS-DMA four steps ahead, staged relative to the frame's level E_t) and the offsets; wave P the frame normaliser, the
-//     partner's offsets (LDS-DMA) and the posteriors of a frame two steps after the compute waves produced their terms.
+//   * three SERVICE waves per agent do everything that is not on the path from one barrier to the next: wave E the emissions
+//     (LDS-DMA four steps ahead, staged relative to the frame's level E_t) and the offsets; wave P the frame normaliser; wave
+//     F the partner's offsets (LDS-DMA) and the posteriors of a frame two steps after the compute waves produced their terms.
 //     Normalisation: the vector of step t is the log2 vector minus C_t = sum_{k<=t} (M_{k-2} + E_k), M_k = the maximum of
 //     the vector of step k, which wave P finds by scanning that vector during step k + 1 -- two steps of lag, so that no wave
 //     waits for a maximum
@@ -67,18 +67,18 @@ __device__ __forceinline__ float wave_sum_fixed(float v) {  // the same tree in 
 }
 
 template <int NSEG, int NJ>  // NSEG: segments the registers of a wave hold; NJ * 64 >= P + 1
-__global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 2)) mm_wave_kernel(RunParams p) {
+__global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 3)) mm_wave_kernel(RunParams p) {
     extern __shared__ float lds[];
-    constexpr int KA = MM_WAVE_STRIDE * NSEG, NWD = MM_WAVE_NWD, NWA = NWD + 2, NT = 128 * NWA;
+    constexpr int KA = MM_WAVE_STRIDE * NSEG, NWD = MM_WAVE_NWD, NWA = NWD + 3, NT = 128 * NWA;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // 0: forward agent, 1: backward agent; the wave of the agent: NWD compute waves and two SERVICE waves -- E stages the
-    // emissions and keeps the offsets, P finds the frame normalisers and puts out the posteriors of a frame two steps after
-    // the compute waves produced their terms: none of that is on the compute waves' path from one barrier to the next (one
-    // service wave for all of it was the longest wave of every step: ~200 instructions of a single wave, 1600 cycles
-    // against the compute waves' 900)
+    // 0: forward agent, 1: backward agent; the wave of the agent: NWD compute waves and three SERVICE waves -- E stages the
+    // emissions and keeps the offsets, P finds the frame normalisers, F (phase B) puts out the posteriors of a frame two
+    // steps after the compute waves produced their terms: none of that is on the compute waves' path from one barrier to
+    // the next (one service wave for all of it was the longest wave of every step: ~200 instructions of a single wave,
+    // 1600 cycles against the compute waves' 900; scan + posteriors in one wave were the longest of phase B)
     const int DIR = wv / NWA, sub = wv % NWA;
-    const bool svcE = sub == NWD, svcP = sub == NWD + 1, service = svcE || svcP;
+    const bool svcE = sub == NWD, svcP = sub == NWD + 1, svcF = sub == NWD + 2, service = svcE || svcP || svcF;
     const int b = uni(p.order ? p.order[blockIdx.x] : (int)blockIdx.x);
     if (p.redo && !uni(p.redo[b])) return;
     const UttDesc &u = p.utts[b];
@@ -301,17 +301,18 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 2)) mm_wave_kernel(RunPar
     // log-sum-exp over lane groups: (mx, s) of every lane -> the group's, in all its lanes.  lvl = log2 of the lanes of
     // this lane's group (per lane or wave-uniform), lvmax = the wave's largest.  Straight-line for groups of up to 16
     // lanes (a select per level: a branch per level and value costs a wave ~30 cycles each, 300 for a segment).
+#define MM_WAVE_DPP3(op, ctrl, dst, src) asm("s_nop 1\n\t" op " %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf" : "=&v"(dst) : "v"(src))
     auto group_lse = [&](float &mx, float &s, int lvl, int lvmax) __attribute__((always_inline)) {
         float M = mx, t;
-        t = fmaxf(M, dpp_mov<MM_DPP_XOR1>(M));
+        MM_WAVE_DPP3("v_max_f32_dpp", "quad_perm:[1,0,3,2]", t, M);
         M = lvl >= 1 ? t : M;
         if (lvmax >= 2) {
-            t = fmaxf(M, dpp_mov<MM_DPP_XOR2>(M));
+            MM_WAVE_DPP3("v_max_f32_dpp", "quad_perm:[2,3,0,1]", t, M);
             M = lvl >= 2 ? t : M;
             if (lvmax >= 3) {
-                t = fmaxf(M, dpp_mov<MM_DPP_HALF_MIRROR>(M));
+                MM_WAVE_DPP3("v_max_f32_dpp", "row_half_mirror", t, M);
                 M = lvl >= 3 ? t : M;
-                t = fmaxf(M, dpp_mov<MM_DPP_MIRROR>(M));
+                MM_WAVE_DPP3("v_max_f32_dpp", "row_mirror", t, M);
                 M = lvl >= 4 ? t : M;
                 if (lvmax >= 5) {
                     t = fmaxf(M, __shfl_xor(M, 16));
@@ -322,15 +323,15 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 2)) mm_wave_kernel(RunPar
             }
         }
         float v = s * fast_exp2(mx - M);
-        t = v + dpp_mov<MM_DPP_XOR1>(v);
+        MM_WAVE_DPP3("v_add_f32_dpp", "quad_perm:[1,0,3,2]", t, v);
         v = lvl >= 1 ? t : v;
         if (lvmax >= 2) {
-            t = v + dpp_mov<MM_DPP_XOR2>(v);
+            MM_WAVE_DPP3("v_add_f32_dpp", "quad_perm:[2,3,0,1]", t, v);
             v = lvl >= 2 ? t : v;
             if (lvmax >= 3) {
-                t = v + dpp_mov<MM_DPP_HALF_MIRROR>(v);
+                MM_WAVE_DPP3("v_add_f32_dpp", "row_half_mirror", t, v);
                 v = lvl >= 3 ? t : v;
-                t = v + dpp_mov<MM_DPP_MIRROR>(v);
+                MM_WAVE_DPP3("v_add_f32_dpp", "row_mirror", t, v);
                 v = lvl >= 4 ? t : v;
                 if (lvmax >= 5) {
                     t = v + __shfl_xor(v, 16);
@@ -438,6 +439,10 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 2)) mm_wave_kernel(RunPar
             const float Mnew = scan_max(RD);
             if (lane == 0) ldsw(base + MM_WAVE_MS(RD), Mnew);
             MM_STAMP(2);
+            agent_sync();
+            MM_STAMP(1);
+        }
+        if constexpr (ROLE == 3) {
             if constexpr (PHASE == 1) {
                 // (the partner offset of step t - 2 was requested at step t - 4: at most the 3 requests since are newer)
                 asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -528,6 +533,7 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 2)) mm_wave_kernel(RunPar
     auto run = [&](auto PHc, int tfirst, int tlast) __attribute__((always_inline)) {
         if (svcE) run_role(PHc, std::integral_constant<int, 1>{}, tfirst, tlast);
         else if (svcP) run_role(PHc, std::integral_constant<int, 2>{}, tfirst, tlast);
+        else if (svcF) run_role(PHc, std::integral_constant<int, 3>{}, tfirst, tlast);
         else run_role(PHc, std::integral_constant<int, 0>{}, tfirst, tlast);
     };
     MM_STAMP_RESET;
@@ -544,7 +550,7 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 2)) mm_wave_kernel(RunPar
 #endif
     __syncthreads();  // the ONE workgroup barrier: phase A of both agents is stored
     MM_STAMP_RESET;
-    if (svcP) {
+    if (svcF) {
         poff_fetch(tA + 1);
         poff_fetch(tA + 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -554,7 +560,7 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 2)) mm_wave_kernel(RunPar
     run(std::integral_constant<int, 1>{}, tA + 1, NF);
     // the last two steps' frames (NF is not live for the forward agent: frame len + 1; frame 1 for the backward agent)
     if (NF > tA) {
-        if (svcP) {
+        if (svcF) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int fp = frame_of(NF - 1);
             if (NF - 1 > tA && fp >= 1 && fp <= len) frame_out(NF - 1);
@@ -562,7 +568,7 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 2)) mm_wave_kernel(RunPar
             pdf_reduce(NF);
         }
         agent_sync();
-        if (svcP) {
+        if (svcF) {
             const int fp = frame_of(NF);
             if (fp >= 1 && fp <= len) frame_out(NF);
         }
@@ -572,7 +578,7 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 2)) mm_wave_kernel(RunPar
         for (int q = 0; q < 8; ++q) p.dbg[((long long)b * 16 + wv) * 8 + q] = stamp_acc[q];
 #endif
     // ---- ttl, zeros beyond the sequence length
-    if (lane == 0 && svcP) *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(base + MM_WAVE_ZZ) = zmin;
+    if (lane == 0 && svcF) *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(base + MM_WAVE_ZZ) = zmin;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {

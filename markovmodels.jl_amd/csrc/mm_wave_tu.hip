@@ -11,7 +11,7 @@ static int launch_wave_one(const WaveLaunch &wl, const RunParams &p, hipStream_t
     const size_t lds = 2 * size_t(MM_WAVE_SLICE);
     auto kernel = mm_wave_kernel<NSEG, NJ>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-    hipLaunchKernelGGL(kernel, dim3(unsigned(wl.B)), dim3(128 * (MM_WAVE_NWD + 2)), lds, stream, p);
+    hipLaunchKernelGGL(kernel, dim3(unsigned(wl.B)), dim3(128 * (MM_WAVE_NWD + 3)), lds, stream, p);
     HIP_TRY(hipGetLastError());
     return MM_OK;
 }

@@ -33,7 +33,8 @@ sel = int(os.environ.get("MM_SPLIT_SLEEP", "0"))  # 0x1000: phase B only, 0x2000
 s = out[: B * 16 * 8].reshape(B, 16, 8).astype(np.float64) / (N / 2 if sel & 0x3000 else N)
 names = ["-", "in barrier (1)", "gather+lse (2)", "finish (3)", "-", "-"]
 enames = ["-", "in barrier (1)", "wait DMA (2)", "stage+fetch (3)", "offset (4)", "-"]
-pnames = ["-", "in barrier (1)", "scan max (2)", "poff (3)", "frame_out (4)", "-"]
-for wv in range(12):
-    nm = enames if wv % 6 == 4 else pnames if wv % 6 == 5 else names
+pnames = ["-", "in barrier (1)", "scan max (2)", "-", "-", "-"]
+fnames = ["-", "in barrier (1)", "-", "poff (3)", "frame_out (4)", "-"]
+for wv in range(14):
+    nm = enames if wv % 7 == 4 else pnames if wv % 7 == 5 else fnames if wv % 7 == 6 else names
     print("wave", wv, " ".join(f"{nm[k]} {s[:, wv, k].mean():6.0f}" for k in range(6)), " total %.0f" % s[:, wv, :6].sum(-1).mean())

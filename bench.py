@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--emissions", default="randn", choices=["randn", "peaky", "peaky_offset"],
                     help="randn: N(0,1) log-likelihoods (default); peaky: log-softmax of 10 x N(0,1) (a sharp acoustic model); "
                          "peaky_offset: the same shifted by -300 nats (GMM-like scores)")
+    ap.add_argument("--posterior-floor", type=float, default=0.0,
+                    help="mm_batch_set_posterior_floor (default: the library's 1e-30); 1e-12 keeps sharp emissions on the fast kernels")
     args = ap.parse_args()
 
     import torch
@@ -162,6 +164,8 @@ def main():
     B = args.batch or B
     cf = mm.compile(wl.to_fsm(mm, g, semiring), mm.statemap(g.state2pdf, g.P))
     bf = mm.batch(*([cf] * B))
+    if args.posterior_floor > 0 and semiring == "log":
+        bf.set_posterior_floor(args.posterior_floor)
     gen = torch.Generator(device="cuda").manual_seed(1000 + rank)
     V = torch.randn(B, N, g.P, device="cuda", generator=gen)
     if args.emissions != "randn":
@@ -229,7 +233,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic" if args.emissions == "randn" else f"synthetic ({args.emissions} emissions)",
+            "data": ("synthetic" if args.emissions == "randn" else f"synthetic ({args.emissions} emissions)")
+                    + (f", posterior floor {args.posterior_floor:g}" if args.posterior_floor > 0 else ""),
             "redo_utterances": redo,
             "config": {
                 "workload": f"{g.name}: S={g.S} states, {g.n_arcs} arcs, P={g.P} pdfs, T={N} frames, "

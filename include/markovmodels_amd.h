@@ -202,6 +202,17 @@ int mm_pdfposteriors_ex(mm_batch_t batch, const mm_statemap_t *maps, int val_byt
  * CPU path is deterministic, its CUDA path (src/linalg.jl:213-233) reduces in warp-shuffle order, also fixed. */
 int mm_batch_set_deterministic(mm_batch_t batch, int on);
 
+/* Posterior floor of the fast (linear-domain) kernels, default 1e-30.  Those kernels keep float32 products, so terms more
+ * than ~126 log2 below their frame's scale drop out; an utterance is accepted from them only if every posterior that can
+ * have been lost that way is below the floor (otherwise the exact kernels compute it again, mm_batch_last_redo_count).
+ * With sharp emissions (a trained acoustic model: the forward and the backward mass of a frame sit on different states)
+ * the default sends every utterance to the exact kernels -- 3 to 6 times the time of a call.  A caller to whom posteriors
+ * below, say, 1e-12 are zero (LF-MMI gradients) says so here: results then differ from the reference's by less than the
+ * floor in any posterior (those below it may come out as 0), log Z is unaffected beyond 1e-4 relative as before, and
+ * inputs up to ~6 sigma of logit spread stay on the fast kernels.  floor in [1e-30, 1e-6]; the log-domain kernels (wave,
+ * item, generic) are exact and ignore it.  The reference has no such switch (one algorithm, log domain throughout). */
+int mm_batch_set_posterior_floor(mm_batch_t batch, float floor);
+
 /* How many utterances of the LAST mm_pdfposteriors_f32 call on this batch the fast (linear-domain) kernels handed to
  * the exact kernels ("flag and redo": a value left the range in which float32 products are exact enough; results are
  * the log semiring's either way, only the time differs -- a redone utterance is computed twice).  Reads the marks the

@@ -27,7 +27,7 @@ import MarkovModels: compile, batch, pdfposteriors, αrecursion, βrecursion, to
 
 # what this module adds to the package's API
 export ROCCompiledFSM, ROCBatch, to_device, bestpath, maxstateposteriors, pdfposteriors_generic, last_redo_count,
-       set_deterministic!, set_rccl, allreduce_logz, allgather_ttl
+       set_deterministic!, set_posterior_floor!, set_rccl, allreduce_logz, allgather_ttl
 
 const LIB = get(ENV, "MARKOVMODELS_AMD_LIB", "libmarkovmodels_amd.so")
 
@@ -262,6 +262,16 @@ set_rccl(path::AbstractString) = set_rccl(Libdl.dlopen(path))
 "No float atomics in the item kernel (the wave kernel, the default numerator path, is deterministic anyway): bit-identical γ on every run."
 set_deterministic!(b::ROCBatch, on::Bool = true) =
     (check(ccall((:mm_batch_set_deterministic, LIB), Cint, (Ptr{Cvoid}, Cint), b.handle, on ? 1 : 0)); b)
+
+"""
+    set_posterior_floor!(b::ROCBatch, floor = 1f-30)
+
+Posteriors below `floor` may come out as 0 from the fast (linear-domain) kernels; the default keeps every posterior
+above 1e-30 and sends utterances with sharp emissions to the exact kernels (3-6x the time).  `1f-12` keeps them on the
+fast path (LF-MMI gradients do not see the difference).
+"""
+set_posterior_floor!(b::ROCBatch, floor::Real = 1f-30) =
+    (check(ccall((:mm_batch_set_posterior_floor, LIB), Cint, (Ptr{Cvoid}, Cfloat), b.handle, Float32(floor))); b)
 
 """
     allreduce_logz(comm, ttl::ROCVector{Float32}) -> Float64

@@ -31,6 +31,7 @@ SYMBOLS = [
     "mm_batch_kernels",
     "mm_batch_reserve",
     "mm_batch_set_deterministic",
+    "mm_batch_set_posterior_floor",
     "mm_batch_last_redo_count",
     "mm_pdfposteriors_f32",
     "mm_pdfposteriors_ex",
@@ -99,6 +100,8 @@ def _load():
     lib.mm_batch_reserve.argtypes = [vp, i64]
     lib.mm_batch_set_deterministic.restype = C.c_int
     lib.mm_batch_set_deterministic.argtypes = [vp, C.c_int]
+    lib.mm_batch_set_posterior_floor.restype = C.c_int
+    lib.mm_batch_set_posterior_floor.argtypes = [vp, C.c_float]
     lib.mm_batch_last_redo_count.restype = C.c_int
     lib.mm_batch_last_redo_count.argtypes = [vp, vp, C.POINTER(i64)]
     lib.mm_batch_kernels.restype = C.c_int

@@ -225,6 +225,7 @@ struct mm_batch_s {
     // them and joins them
     hipStream_t side[2] = {nullptr, nullptr};
     bool deterministic = false;  // mm_batch_set_deterministic(): no float atomics in the item kernel
+    float lt_floor = -20.f;      // mm_batch_set_posterior_floor(): smallest accepted log2 overlap of a frame (mm_pair_finish_kernel)
     float *ws_big = nullptr;  // [B][4 * max_S1p]: state vectors of FSMs beyond the LDS (launch())
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int device = -1;
@@ -1681,6 +1682,15 @@ int mm_batch_gen_view(mm_batch_t h, int64_t *B, const mm_fsm_t **fsms, int *semi
 }  // namespace mm
 extern "C" {
 
+int mm_batch_set_posterior_floor(mm_batch_t h, float floor) {
+    if (!h) return fail(MM_ERR_INVALID, "mm_batch_set_posterior_floor: NULL batch");
+    if (!(floor >= 1e-30f && floor <= 1e-6f)) return fail(MM_ERR_INVALID, "mm_batch_set_posterior_floor: floor outside [1e-30, 1e-6]");
+    // a term that dropped out of the linear path would have had a posterior below 2^(-120 - L_n) (mm_pair_finish_kernel):
+    // L_n >= -120 - log2(floor) keeps every loss below the floor (1e-30 -> -20.3, the default -20; 1e-12 -> -80)
+    h->lt_floor = std::min(-20.f, -120.f - std::log2(floor));
+    return MM_OK;
+}
+
 int mm_batch_set_deterministic(mm_batch_t h, int on) {
     if (!h) return fail(MM_ERR_INVALID, "mm_batch_set_deterministic: NULL batch");
     h->deterministic = on != 0;
@@ -1845,6 +1855,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     p.N = int(N);
     p.B = int(h->B);
     p.x_sleep = h->dbg.x_sleep;
+    p.lt_floor = h->lt_floor;
     p.ws_alpha = static_cast<float *>(h->ws);
     p.ws_c = reinterpret_cast<double *>(static_cast<char *>(h->ws) + ws_alpha_bytes(h, N));
     p.gamma = gamma;

@@ -994,8 +994,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
 // that dropped out of the linear path was below 2^-126 (times the few log2 the predicted normalisers are off by) of its
 // frame's scale, so the posterior it would have had is below 2^(-120 - L_n), L_n = log2 sum_s 2^(a~_n(s) + b~_n(s)) as the
 // kernels compute it (both factors on their own frame scale: L_n is far below 0 when the forward and the backward mass
-// sit on different states, as under a sharp acoustic model -- log-softmax of 10 N(0,1): -160).  With L_n >= MM_LT_FLOOR in
-// every frame nothing above 2^-100 < 1e-30 can have been lost.
+// sit on different states, as under a sharp acoustic model -- log-softmax of 10 N(0,1): -160).  With L_n >= the floor (default
+// MM_LT_FLOOR = -20) in every frame nothing above 2^-100 < 1e-30 can have been lost; a caller who accepts a larger posterior
+// floor lowers it (mm_batch_set_posterior_floor: 1e-12 -> -80).
 #ifndef MM_Z_SPREAD_TOL
 #define MM_Z_SPREAD_TOL 2e-4  // log2 units (1.4e-4 nats on log Z); unmarked utterances of 1500 frames scatter by 2e-5..5e-5
 #define MM_LT_FLOOR (-20.0)
@@ -1013,7 +1014,7 @@ static __global__ void mm_pair_finish_kernel(RunParams p) {
         const double l0 = p.pair_zmin[6 * b + 4], l1 = p.pair_zmin[6 * b + 5];
         const double lm = l0 < l1 ? l0 : l1;
         p.ttl[b] = (z < __builtin_inf()) ? (float)(z * (double)MM_LN2) : MM_NINF;  // (no frame: no path of length 0)
-        if (p.redo[b] == 1 && z > -__builtin_inf() && zM < __builtin_inf() && zM - z <= MM_Z_SPREAD_TOL && lm >= MM_LT_FLOOR) p.redo[b] = 0;
+        if (p.redo[b] == 1 && z > -__builtin_inf() && zM < __builtin_inf() && zM - z <= MM_Z_SPREAD_TOL && lm >= (double)p.lt_floor) p.redo[b] = 0;
     }
     const long long gbase = (long long)b * p.gsb;
     for (long long q = threadIdx.x; q < (long long)(p.N - len) * P; q += blockDim.x)

@@ -146,6 +146,7 @@ struct RunParams {
     float *xbuf, *xps;
     long long x_slot, x_phase;  // floats per slot; floats of one phase's area
     int x_sleep;                // the exchange wave sleeps this many x 64 clocks before its first poll of a step
+    float lt_floor;             // mm_pair_finish_kernel: smallest accepted log2 overlap term of a frame (mm_batch_set_posterior_floor)
 };
 
 // In-kernel cycle stamps (diagnostic build only; the shipped library executes none).

@@ -273,6 +273,12 @@ class BatchedFSM:
         a hipGraph -- never reallocate)."""
         check(lib.mm_batch_reserve(self._h, int(N)))
 
+    def set_posterior_floor(self, floor: float = 1e-30):
+        """mm_batch_set_posterior_floor: posteriors below `floor` may come out as 0 from the fast kernels (default 1e-30);
+        a relaxed floor (1e-12) keeps sharp emissions on the fast path.  Returns self."""
+        check(lib.mm_batch_set_posterior_floor(self._h, float(floor)))
+        return self
+
     def set_deterministic(self, on: bool = True):
         """No float atomics in the general kernel: bit-identical gamma on every run (slower on small deep graphs)."""
         check(lib.mm_batch_set_deterministic(self._h, 1 if on else 0))

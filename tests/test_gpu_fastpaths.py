@@ -158,6 +158,40 @@ def test_redo_count_is_zero_on_the_benchmark_inputs_and_reported_on_peaky_ones(m
     print(f"peaky emissions: {redo} of {B} utterances redone")
 
 
+def test_posterior_floor_keeps_sharp_emissions_on_the_fast_kernels(mm, wl, oracle, torch):
+    """mm_batch_set_posterior_floor: with sharp emissions (log-softmax of 5 N(0,1): the forward and the backward mass of a
+    frame sit on different states, the overlap term L_n falls to -40 .. -60 log2) the default floor (1e-30) hands the
+    utterances to the exact kernels; a caller who treats posteriors below 1e-12 as zero keeps them on the fast kernels:
+    no utterance redone, every posterior within the floor of the oracle's, those above it within the usual tolerance,
+    log Z as before."""
+    g = wl.lfmmi_denominator(1000, 84, seed=3)
+    rng = np.random.default_rng(5)
+    B, N = 6, 300
+    x = 5.0 * rng.standard_normal((B, N, g.P))
+    V = (x - np.log(np.exp(x - x.max(-1, keepdims=True)).sum(-1, keepdims=True)) - x.max(-1, keepdims=True)).astype(np.float32)
+    lens = np.array([300, 300, 211, 300, 150, 299], dtype=np.int32)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(*([cf] * B))
+    assert "mm_fbp_kernel_dir" in bf.kernels()
+    g0, t0 = bf.pdfposteriors(V, lens)
+    strict_redone = bf.last_redo_count()
+    assert strict_redone > 0  # (what the default costs on such inputs)
+    with pytest.raises(mm.MarkovModelsAMDError):
+        bf.set_posterior_floor(1e-3)
+    bf.set_posterior_floor(1e-12)
+    g1, t1 = bf.pdfposteriors(V, lens)
+    assert bf.last_redo_count() == 0
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    assert np.allclose(t1, t_ref, rtol=1e-5, atol=1e-4) and np.allclose(t0, t_ref, rtol=1e-5, atol=1e-4)
+    check_gamma(g0, g_ref, lens)  # the default: the usual bar (everything above 1e-30)
+    assert np.abs(g1 - g_ref).max() < 1e-5 and (np.abs(g1 - g_ref)[g_ref < 1e-12] < 1e-12).all()
+    m = g_ref > 1e-10
+    assert (np.abs(np.log(np.maximum(g1[m], 1e-300)) - np.log(g_ref[m])) / np.maximum(np.abs(np.log(g_ref[m])), 1.0)).max() < 1e-4
+    bf.set_posterior_floor(1e-30)
+    bf.pdfposteriors(V, lens)
+    assert bf.last_redo_count() == strict_redone
+
+
 @pytest.mark.parametrize("S,P", [(6000, 300), (2900, 120), (1000, 640)])
 def test_graph_beyond_the_fast_paths(mm, wl, oracle, torch, S, P):
     """The reference's products have no size limit (src/linalg.jl:170-181).  6000 states x 300 pdfs and 1000 states x

@@ -2,7 +2,7 @@
 """How sharp may the emissions be before the linear-domain kernels hand utterances to the exact ones?
 log-softmax of sigma * N(0,1) on config 3 (B = 256, T = 1500) and on the reference's WSJ denominator (B = 128, T = 700)."""
 import importlib, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
 import torch

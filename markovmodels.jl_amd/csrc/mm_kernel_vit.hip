@@ -23,6 +23,8 @@
 
 namespace mm {
 
+typedef float mm_vf32x2 __attribute__((ext_vector_type(2)));
+
 // (max, lowest arg-max) over an aligned group of 1 << lg lanes (lg wave-uniform), in all its lanes -- a row of 5 to 256
 // arcs: the hub states of a lexicon graph.  Two butterflies of ONE instruction per level instead of one of a dozen (two
 // moves, four compares, two selects per level, as trop_grp_reduce of the item kernel has it): the maximum of the lanes'
@@ -106,7 +108,7 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
     MM_STAMP_DECL;
 
     // ---- the wave's rows: registers
-    float w[KA];
+    mm_vf32x2 w2[KA / 2];  // (weights in aligned register pairs: the two arcs of a pair are added by ONE v_pk_add_f32)
     unsigned a[KA], s0[NSEG];
     const bool mine_w = !service && wave < r.NWC;
     const RowSched &sc = r.sched[mine_w ? wave : 0];
@@ -122,7 +124,9 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
 #pragma unroll
         for (int k = 0; k < KA; ++k) {
             const bool have = mine_w && k < r.KA;
-            w[k] = have ? wp[k * nt + col] : MM_NINF;
+            const float wk = have ? wp[k * nt + col] : MM_NINF;
+            if (k & 1) w2[k / 2].y = wk;
+            else w2[k / 2].x = wk;
             a[k] = have ? ap[k * nt + col] : 0u;
         }
         // position i < N4 (wide) holds the wave's segment i, position N4 + j (narrow) its segment n4w + j; positions without
@@ -197,11 +201,16 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
             // W arc slots per position, NB positions from position h0 on, their slots from k0 on.
             auto block = [&](auto Wc, auto NBc, auto H0c, auto K0c) __attribute__((always_inline)) {
                 constexpr int W = decltype(Wc)::value, NB = decltype(NBc)::value, h0 = decltype(H0c)::value, k0 = decltype(K0c)::value;
-                float xs[W * NB], es[NB];
+                static_assert(W % 2 == 0 && k0 % 2 == 0, "arc slots come in pairs");
+                mm_vf32x2 xs[W / 2 * NB];
+                float es[NB];
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
 #pragma unroll
-                    for (int q = 0; q < W; ++q) xs[W * i + q] = ldsr(a[k0 + W * i + q] + (unsigned)RD * VSZ);
+                    for (int q = 0; q < W / 2; ++q) {
+                        xs[W / 2 * i + q].x = ldsr(a[k0 + W * i + 2 * q] + (unsigned)RD * VSZ);
+                        xs[W / 2 * i + q].y = ldsr(a[k0 + W * i + 2 * q + 1] + (unsigned)RD * VSZ);
+                    }
                     es[i] = ldsr(EMB + (unsigned)WR * MM_VIT_ESZ + (s0[h0 + i] >> 16));
                 }
                 float best[NB];
@@ -209,13 +218,21 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     // T_hat[i, j] (*) A[i, n-1], strict '>' over ascending source states: the lowest source among the maximisers
-                    float bv = xs[W * i] + w[k0 + W * i];
+                    // (two arcs per v_pk_add_f32: the same IEEE additions, half the instructions)
+                    float bv = 0.f;
                     int bk = 0;
 #pragma unroll
-                    for (int q = 1; q < W; ++q) {
-                        const float v = xs[W * i + q] + w[k0 + W * i + q];
-                        bk = v > bv ? q : bk;
-                        bv = v > bv ? v : bv;
+                    for (int q = 0; q < W / 2; ++q) {
+                        mm_vf32x2 v;
+                        asm("v_pk_add_f32 %0, %1, %2" : "=v"(v) : "v"(xs[W / 2 * i + q]), "v"(w2[k0 / 2 + W / 2 * i + q]));
+                        if (q == 0) {
+                            bv = v.x;
+                        } else {
+                            bk = v.x > bv ? 2 * q : bk;
+                            bv = v.x > bv ? v.x : bv;
+                        }
+                        bk = v.y > bv ? 2 * q + 1 : bk;
+                        bv = v.y > bv ? v.y : bv;
                     }
                     best[i] = bv;
                     arg[i] = bk;

@@ -1536,6 +1536,7 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
                 }
                 h->vit_ok = fsms[b]->vit_n4 == h->vit_n4 && fsms[b]->vit_n2 == h->vit_n2;
                 h->vit_arcs = std::max(h->vit_arcs, int(fsms[b]->vrow->g.col.size()));
+                h->vit_ok = h->vit_ok && size_t(fsms[b]->S1p) * 4 <= 24576;  // (the kernel's state vectors: mm_vit_tu.hip)
             }
         }
     }

@@ -16,12 +16,12 @@ static int launch_vit(const VitLaunch &vl, const RunParams &p, hipStream_t strea
 }
 template <int N4, int N2>
 static int launch_vit_shape(const VitLaunch &vl, const RunParams &p, hipStream_t stream) {
-    const bool small = size_t(vl.max_S1p) * 4 <= 24576;
-    if (vl.max_P1 <= 128) return small ? launch_vit<N4, N2, 2, 24576>(vl, p, stream) : launch_vit<N4, N2, 2, 65536>(vl, p, stream);
-    return small ? launch_vit<N4, N2, 4, 24576>(vl, p, stream) : launch_vit<N4, N2, 4, 65536>(vl, p, stream);
+    // (15 waves x 6 positions x 64 lanes = 5760 rows at most: a state vector never exceeds 24 KB)
+    if (vl.max_P1 <= 128) return launch_vit<N4, N2, 2, 24576>(vl, p, stream);
+    return launch_vit<N4, N2, 4, 24576>(vl, p, stream);
 }
 int mm_launch_viterbi(const VitLaunch &vl, const RunParams &p, hipStream_t stream) {
-    if (vl.max_P1 > 256 || size_t(vl.max_S1p) * 4 > 65536) return mm_fail(MM_ERR_UNSUPPORTED, "Viterbi kernel: graph too large");
+    if (vl.max_P1 > 256 || size_t(vl.max_S1p) * 4 > 24576) return mm_fail(MM_ERR_UNSUPPORTED, "Viterbi kernel: graph too large");
     int rc;
     // (the layouts the forms are built for, mm_engine.hip vit_variant: wide x narrow positions per wave)
     if (vl.n4 == 1 && vl.n2 == 5) rc = launch_vit_shape<1, 5>(vl, p, stream);

@@ -883,7 +883,7 @@ static int pair_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
 }
 
 // the Viterbi form of a tropical FSM (built once; *ok = false if it does not fit: a row of more than 255 arcs, more than 8
-// segments per wave, more than 16382 states)
+// segments per wave -- 5760 rows at most)
 static int vit_variant(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
     *ok = f->vrow != nullptr;
     if (*ok || f->vit_tried) return MM_OK;

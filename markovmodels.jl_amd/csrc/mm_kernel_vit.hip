@@ -16,7 +16,7 @@
 //     which were the algorithmic traffic of this path;
 //   * back-trace: one workgroup per utterance streams the byte rows through a double-buffered LDS ring, 8 KB per hop of the
 //     chase hidden behind the copy of the next chunk; the hop itself is three LDS reads (arc number, row pointer, source).
-// Graphs with a row of more than 255 arcs, more than 6 segments per wave or more than 16383 states stay on the item kernel,
+// Graphs with a row of more than 255 arcs, more than 6 segments per wave (15 waves x 6 x 64 lanes = 5760 rows at most) stay on the item kernel,
 // and so does a call that asks for the int32 back-pointer table (mm_viterbi_f32 with bp != NULL).
 #pragma once
 #include "mm_kernel_rows.hip"

@@ -4,14 +4,17 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/markovmodels_amd.h"
@@ -140,7 +143,8 @@ struct mm_fsm_s {
     SplitInfo split;
     bool split_tried = false;
     RowVariant *wrows[2] = {nullptr, nullptr};  // wave forms (mm_kernel_wave.hip)
-    bool wave_tried = false;
+    RowVariant *wpend[2] = {nullptr, nullptr};  // ... packed, not yet uploaded (wave_pack)
+    bool wave_tried = false, wave_packed = false;
     RowVariant *vrow = nullptr;                 // Viterbi form (mm_kernel_vit.hip)
     bool vit_tried = false;
     int vit_n4 = 0, vit_n2 = 0;                 // its layout: positions of 4 / of 2 arc slots per wave
@@ -303,7 +307,7 @@ static size_t quad_lds_bytes(mm_batch_t h, int dir) {
 }
 
 static bool quad_kernel_usable(mm_batch_t h) {
-    if (h->dbg.kernel == DebugOpts::K_ITEM) return false;
+    if (h->dbg.kernel == DebugOpts::K_ITEM || h->wave_ok) return false;
     if (!h->fast_ok || h->geo_kq[0] < 1 || h->geo_kq[1] < 1) return false;
     // small deep graphs (numerators): measured on the reference's WSJ numerator graph (depth 165),
     // item kernel 2.3 ms against 2.7 ms; shallow graphs of the same size are 1.6x faster on the quad kernels
@@ -941,7 +945,7 @@ static int vit_variant(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
 // s / 4.  tab[((w * 2 + j) * 5 + k) * 64 + lane]: k < 4 the addresses, k = 4: 4 * pdf of the group's first lane (the lane
 // that stores; others: the trash slot 4 * P1p) | log2(L) << 16.  Returns the segments per wave (1 or 2), 0 if it does not fit.
 static int wave_pdf_table(const RowGraph &g, const std::vector<int32_t> &s2p, int64_t S1, int32_t P1, std::vector<uint32_t> &tab) {
-    std::vector<std::vector<uint32_t>> src{size_t(P1)};
+    std::vector<std::vector<uint32_t>> src(static_cast<size_t>(P1));
     std::vector<std::pair<int32_t, int32_t>> bypos;  // (position, pdf): a fixed order of the states of a pdf
     for (int64_t r = 0; r < S1; ++r) bypos.emplace_back(g.pos[size_t(r)], s2p[size_t(r)]);
     std::sort(bypos.begin(), bypos.end());
@@ -990,12 +994,14 @@ static int wave_pdf_table(const RowGraph &g, const std::vector<int32_t> &s2p, in
     return nseg <= 4 ? 1 : 2;
 }
 
-// the wave forms of an FSM (built once; *ok = false if it does not fit them: more than 16 segments of 64 rows, ...)
-static int wave_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
-    *ok = f->wrows[0] && f->wrows[1];
-    if (*ok || f->wave_tried) return MM_OK;
-    f->wave_tried = true;
-    if (f->semiring != MM_LOG || f->P1 > 256 || f->qmat[0].rowptr.empty()) return MM_OK;
+// host part of the wave forms (no device call: mm_batch_create runs it for the FSMs of a batch on several host threads --
+// an LF-MMI step brings a batch of numerator graphs that were never seen before, and packing them one after the other
+// cost 150 ms per 128 graphs against 0.4 ms of kernel time).  Leaves the packed forms in f->wpend, or nothing if the FSM
+// does not fit them.
+static void wave_pack(mm_fsm_t f) {
+    if (f->wrows[0] || f->wave_tried || f->wave_packed) return;
+    f->wave_packed = true;
+    if (f->semiring != MM_LOG || f->P1 > 256 || f->qmat[0].rowptr.empty()) return;
     RowPackOpts opt;
     opt.rs = MM_WAVE_RS;
     opt.nwc_max = MM_WAVE_WAVES;
@@ -1012,23 +1018,39 @@ static int wave_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
     const std::vector<int32_t> none;
     bool fits = make_rows(f->S1, f->qmat[0].rowptr, f->qmat[0].col, f->qmat[0].val, f->s2p, f->P1, false, none, opt, rv[0]->g) &&
                 make_rows(f->S1, f->qmat[1].rowptr, f->qmat[1].col, f->qmat[1].val, f->s2p, f->P1, true, rv[0]->g.pos, opt, rv[1]->g);
-    int rc = MM_OK;
     for (int d = 0; d < 2 && fits; ++d) {
         rv[d]->pdf_nps = wave_pdf_table(rv[d]->g, f->s2p, f->S1, f->P1, rv[d]->ptab);
         fits = rv[d]->pdf_nps > 0;
     }
-    if (fits) {
-        set_partner(rv[0]->g, rv[1]->g.pos);
-        rv[0]->init.resize(size_t(f->S1));
-        for (int64_t i = 0; i < f->S1; ++i) rv[0]->init[i] = f->init[rv[0]->g.order[i]];
-        for (int d = 0; d < 2 && !rc; ++d) {
-            if (dbg.verbose)
-                fprintf(stderr, "[mm] wave form dir %d: %d segments, arcs/slots %.3f, LDS cycles/gather (bank model) %.2f -> %.2f\n", d,
-                        rv[d]->g.nslotrows - 2, rv[d]->g.pad_eff, rv[d]->g.conflict_before, rv[d]->g.conflict_after);
-            rc = upload_row_variant(f, rv[d], d, 0.f, false);
-        }
+    if (!fits) {
+        delete rv[0];
+        delete rv[1];
+        return;
     }
-    if (!fits || rc) {
+    set_partner(rv[0]->g, rv[1]->g.pos);
+    rv[0]->init.resize(size_t(f->S1));
+    for (int64_t i = 0; i < f->S1; ++i) rv[0]->init[i] = f->init[rv[0]->g.order[i]];
+    f->wpend[0] = rv[0];
+    f->wpend[1] = rv[1];
+}
+
+// the wave forms of an FSM (built once; *ok = false if it does not fit them: more than 16 segments of 64 rows, ...)
+static int wave_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
+    *ok = f->wrows[0] && f->wrows[1];
+    if (*ok || f->wave_tried) return MM_OK;
+    wave_pack(f);
+    f->wave_tried = true;
+    RowVariant *rv[2] = {f->wpend[0], f->wpend[1]};
+    f->wpend[0] = f->wpend[1] = nullptr;
+    if (!rv[0]) return MM_OK;
+    int rc = MM_OK;
+    for (int d = 0; d < 2 && !rc; ++d) {
+        if (dbg.verbose)
+            fprintf(stderr, "[mm] wave form dir %d: %d segments, arcs/slots %.3f, LDS cycles/gather (bank model) %.2f -> %.2f\n", d,
+                    rv[d]->g.nslotrows - 2, rv[d]->g.pad_eff, rv[d]->g.conflict_before, rv[d]->g.conflict_after);
+        rc = upload_row_variant(f, rv[d], d, 0.f, false);
+    }
+    if (rc) {
         for (RowVariant *x : rv) {
             if (x->blob) (void)hipFree(x->blob);
             delete x;
@@ -1168,7 +1190,7 @@ int mm_fsm_destroy(mm_fsm_t f) {
         if (kv.second->blob) (void)hipFree(kv.second->blob);
         delete kv.second;
     }
-    for (RowVariant *rv : {f->rows[0], f->rows[1], f->prows[0], f->prows[1], f->wrows[0], f->wrows[1], f->vrow, f->srows[0][0], f->srows[0][1], f->srows[0][2], f->srows[0][3],
+    for (RowVariant *rv : {f->rows[0], f->rows[1], f->prows[0], f->prows[1], f->wrows[0], f->wrows[1], f->wpend[0], f->wpend[1], f->vrow, f->srows[0][0], f->srows[0][1], f->srows[0][2], f->srows[0][3],
                            f->srows[1][0], f->srows[1][1], f->srows[1][2], f->srows[1][3]})
         if (rv) {
             if (rv->blob) (void)hipFree(rv->blob);
@@ -1402,6 +1424,7 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     if (!out) return fail(MM_ERR_INVALID, "mm_batch_create: out is NULL");
     *out = nullptr;
     if (!fsms || B < 1) return fail(MM_ERR_INVALID, "mm_batch_create: empty batch");
+    const auto tb0 = std::chrono::steady_clock::now();
     for (int64_t b = 0; b < B; ++b) {
         if (!fsms[b]) return fail(MM_ERR_INVALID, "mm_batch_create: NULL FSM handle");
         if (fsms[b]->semiring != fsms[0]->semiring)
@@ -1546,6 +1569,23 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
          (h->dbg.kernel == DebugOpts::K_AUTO && (!h->fast_ok || (h->max_depth >= 64 && h->geo_kq[0] <= 3 && h->geo_kq[1] <= 3))))) {
         // (= where the item kernel would run: quad_kernel_usable() says no for these; see there)
         h->wave_ok = true;
+        {   // pack the forms of the FSMs that are new, on the host's cores
+            std::vector<mm_fsm_t> todo;
+            for (int64_t b = 0; b < B; ++b)
+                if (!fsms[b]->wrows[0] && !fsms[b]->wave_tried && !fsms[b]->wave_packed &&
+                    std::find(todo.begin(), todo.end(), fsms[b]) == todo.end())
+                    todo.push_back(fsms[b]);
+            const size_t nthr = std::min<size_t>({todo.size() / 4, size_t(std::max(1u, std::thread::hardware_concurrency())), size_t(16)});
+            if (nthr > 1) {
+                std::atomic<size_t> next{0};
+                std::vector<std::thread> pool;
+                for (size_t t = 0; t < nthr; ++t)
+                    pool.emplace_back([&]() {
+                        for (size_t i = next.fetch_add(1); i < todo.size(); i = next.fetch_add(1)) wave_pack(todo[i]);
+                    });
+                for (std::thread &t : pool) t.join();
+            }
+        }
         for (int64_t b = 0; b < B && h->wave_ok; ++b) {
             bool ok = false;
             int rc = wave_variants(fsms[b], h->dbg, &ok);
@@ -1564,7 +1604,8 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         mm_fsm_t f = fsms[b];
         int rc = fsm_to_device(f);
         QuadVariant *qv[2] = {nullptr, nullptr};
-        for (int d = 0; d < 2 && !rc && h->fast_ok; ++d) rc = quad_variant(f, d, h->geo_kq[d], h->dbg.verbose, &qv[d]);
+        // (a batch of the wave kernel never runs the quad kernels: their forms are not built)
+        for (int d = 0; d < 2 && !rc && h->fast_ok && !h->wave_ok; ++d) rc = quad_variant(f, d, h->geo_kq[d], h->dbg.verbose, &qv[d]);
         if (rc) {
             delete h;
             return rc;
@@ -1641,6 +1682,8 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         h->xcsr = int((h->max_xcsr + 3) & ~int64_t(3));
         if (h->max_xcsr > 16 * 1024 || quad_lds_bytes(h, 0) > 128 * 1024 || quad_lds_bytes(h, 1) > 128 * 1024) h->xcsr = 0;
     }
+    if (h->dbg.verbose)
+        fprintf(stderr, "[mm] batch of %lld created in %.1f ms\n", (long long)B, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count());
     *out = h;
     return MM_OK;
 }

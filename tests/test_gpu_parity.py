@@ -581,3 +581,30 @@ def test_wave_kernel_pdf_segments(mm, wl, oracle, torch, S, P):
     check_gamma(gam[ok], g_ref[ok], lens[ok])
     assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=5e-4)
     assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()
+
+
+@pytest.mark.gpu
+def test_wave_batch_of_many_new_graphs(mm, wl, oracle, torch):
+    """An LF-MMI step brings a batch of numerator graphs nobody has seen before: mm_batch_create packs their wave forms on
+    several host threads (24 distinct graphs here: 6 threads).  Every utterance against its own single-graph batch, whose
+    forms were packed on the calling thread."""
+    B, N = 24, 40
+    gs = [wl.lexicon_fsm(120 + 17 * b, 30, seed=100 + b, hubs=1 + b % 2) for b in range(B)]
+    rng = np.random.default_rng(8)
+    V = rng.standard_normal((B, N, 30)).astype(np.float32)
+    lens = rng.integers(N // 2, N + 1, B).astype(np.int32)
+    sm = [mm.statemap(g.state2pdf, g.P) for g in gs]
+    force = {"MM_DEBUG": "1", "MM_KERNEL": "wave"}  # (graphs of this size would take the row kernels)
+    bf = _with_env(force, lambda: mm.batch(*[mm.compile(wl.to_fsm(mm, g), m) for g, m in zip(gs, sm)]))
+    assert "mm_wave_kernel" in bf.kernels("log"), bf.kernels("log")
+    gam, ttl = bf.pdfposteriors(V, lens)
+    for b in (0, 5, 11, 23):
+        one = _with_env(force, lambda: mm.batch(mm.compile(wl.to_fsm(mm, gs[b]), sm[b])))
+        g1, t1 = one.pdfposteriors(V[b : b + 1], lens[b : b + 1])
+        assert np.array_equal(g1[0], gam[b]) and np.array_equal(t1, ttl[b : b + 1])
+    o, oc = oracle
+    for b in (3, 17):
+        g_ref, t_ref = oc.batch_shared(graphs.to_oracle(o, gs[b]), gs[b].state2pdf, gs[b].P, V[b : b + 1], lens[b : b + 1], dtype=np.float64)
+        if np.isfinite(t_ref[0]):
+            check_gamma(gam[b : b + 1], g_ref, lens[b : b + 1])
+            assert np.allclose(ttl[b], t_ref[0], rtol=1e-5, atol=5e-4)

@@ -1581,7 +1581,15 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
                 std::vector<std::thread> pool;
                 for (size_t t = 0; t < nthr; ++t)
                     pool.emplace_back([&]() {
-                        for (size_t i = next.fetch_add(1); i < todo.size(); i = next.fetch_add(1)) wave_pack(todo[i]);
+                        // (an exception must not leave a thread: an FSM whose packing failed is packed again, and fails
+                        // again, on the calling thread -- wave_variants below)
+                        for (size_t i = next.fetch_add(1); i < todo.size(); i = next.fetch_add(1)) {
+                            try {
+                                wave_pack(todo[i]);
+                            } catch (...) {
+                                todo[i]->wave_packed = false;
+                            }
+                        }
                     });
                 for (std::thread &t : pool) t.join();
             }

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstring>
 #include <limits>
+#include <new>
 #include <map>
 #include <mutex>
 #include <string>
@@ -466,14 +467,29 @@ struct Blob {
 };
 }  // namespace
 
+// (no C++ exception crosses the C boundary: the functions that build host structures in proportion to their input catch
+// what the standard library throws -- an allocation that fails, a size beyond max_size -- and report it as a status)
+template <class F>
+static int no_throw(const char *what, F &&body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(MM_ERR_NOMEM, std::string(what) + ": out of host memory");
+    } catch (const std::exception &ex) {
+        return fail(MM_ERR_INVALID, std::string(what) + ": " + ex.what());
+    } catch (...) {
+        return fail(MM_ERR_INVALID, std::string(what) + ": unknown exception");
+    }
+}
+
 extern "C" {
 
 int mm_abi_version(void) { return MM_ABI_VERSION; }
 const char *mm_last_error(void) { return g_err_store.c_str(); }
 
-int mm_fsm_create(int semiring, int64_t S1, int64_t nnz, int layout, int index_bytes, int index_base, int val_bytes,
-                  const void *ptr, const void *idx, const void *val, int64_t n_init, const void *init_idx,
-                  const void *init_val, const int32_t *state2pdf, int32_t P1, mm_fsm_t *out) {
+static int fsm_create_impl(int semiring, int64_t S1, int64_t nnz, int layout, int index_bytes, int index_base, int val_bytes,
+                           const void *ptr, const void *idx, const void *val, int64_t n_init, const void *init_idx,
+                           const void *init_val, const int32_t *state2pdf, int32_t P1, mm_fsm_t *out) {
     if (!out) return fail(MM_ERR_INVALID, "mm_fsm_create: out is NULL");
     *out = nullptr;
     if (semiring != MM_LOG && semiring != MM_TROPICAL && semiring != MM_PROB) return fail(MM_ERR_INVALID, "mm_fsm_create: unknown semiring");
@@ -1420,7 +1436,16 @@ int mm_debug_split_product(mm_fsm_t f, int H, int direction, const float *in, fl
     return MM_OK;
 }
 
-int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
+int mm_fsm_create(int semiring, int64_t S1, int64_t nnz, int layout, int index_bytes, int index_base, int val_bytes,
+                  const void *ptr, const void *idx, const void *val, int64_t n_init, const void *init_idx,
+                  const void *init_val, const int32_t *state2pdf, int32_t P1, mm_fsm_t *out) {
+    return no_throw("mm_fsm_create", [&]() {
+        return fsm_create_impl(semiring, S1, nnz, layout, index_bytes, index_base, val_bytes, ptr, idx, val, n_init, init_idx, init_val,
+                               state2pdf, P1, out);
+    });
+}
+
+static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     if (!out) return fail(MM_ERR_INVALID, "mm_batch_create: out is NULL");
     *out = nullptr;
     if (!fsms || B < 1) return fail(MM_ERR_INVALID, "mm_batch_create: empty batch");
@@ -1694,6 +1719,10 @@ int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         fprintf(stderr, "[mm] batch of %lld created in %.1f ms\n", (long long)B, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count());
     *out = h;
     return MM_OK;
+}
+
+int mm_batch_create(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
+    return no_throw("mm_batch_create", [&]() { return batch_create_impl(fsms, B, out); });
 }
 
 #ifdef MM_STAMPS

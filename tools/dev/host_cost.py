@@ -25,5 +25,9 @@ for rep in range(3):
     gam, ttl = bf.pdfposteriors(V)
     torch.cuda.synchronize()
     t5 = time.perf_counter()
+    t6 = time.perf_counter()
+    bf2 = mm.batch(*cfs)
+    t7 = time.perf_counter()
+    print("batch of the same (known) FSMs again %.2f ms;" % (1e3 * (t7 - t6)), end=" ")
     print("FSM objects %.1f ms, compile (upload) %.1f ms, batch (pack + upload) %.1f ms, first call %.1f ms, second call %.2f ms" %
           (1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (t4 - t3), 1e3 * (t5 - t4)), bf.kernels()[:30], flush=True)

@@ -384,6 +384,7 @@ static int launch_pairs(mm_batch_t h, const RunParams &p, void *stream) {
     pl.max_P1 = h->max_P1;
     pl.pair_ka = h->pair_ka;
     pl.H = h->pair_H;
+    pl.small = h->pair_H == 1 && h->max_S1p <= 128;
     pl.side[0] = h->side[0];
     pl.side[1] = h->side[1];
     for (int i = 0; i < 5; ++i) pl.ev[i] = h->ev[i];

@@ -434,7 +434,7 @@ struct PairHand {  // what an agent hands from phase A to phase B, per utterance
 
 // One agent: direction DIR (0: forward / alpha, 1: backward / beta) of pair `pair`, phase PHASE (0: A, 1: B).
 // H > 1 (split kernels): the agent is a team of H workgroups, this one finishes the rows of set `hset`.
-template <int KA, int RS, int PHASE, int DIR, int NJ, int H = 1, int RSH = 2 * RS>
+template <int KA, int RS, int PHASE, int DIR, int NJ, int H = 1, int RSH = 2 * RS, bool SMALL = false>
 __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hset = 0) {
     extern __shared__ float lds[];
     using L = PairLay<RS, PHASE, RSH>;
@@ -576,6 +576,11 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         double zmin[2] = {__builtin_inf(), __builtin_inf()}, zmax[2] = {-__builtin_inf(), -__builtin_inf()};
         float ltmin[2] = {__builtin_inff(), __builtin_inff()};  // smallest log2 of a frame's sum of 2^(a~ + b~) (see mm_pair_finish_kernel)
         bool xdead = H > 1 && (p.x_sleep & 0x300) != 0;  // (split kernels) a poll of the team's partial sums timed out
+        // SMALL (an instance of its own: graphs of up to 127 states, BASELINE config 2): the row of pairs is at most 64 float4 --
+        // one partner DMA per step instead of the region's 16, 4 scan loads per lane instead of 16.  The service wave is the
+        // longest actor of a small graph's step; as run-time branches in the one kernel they cost config 3 3 %.
+        constexpr bool small_graph = SMALL;
+        static_assert(!SMALL || H == 1, "teams are for large graphs");
         auto dma_raw = [&](int t) {  // raw emissions of step t (clamped) -> RAW(t & 3, u)
             const int tt = t < 1 ? 1 : (t > tEnd ? tEnd : t);
 #pragma unroll
@@ -591,16 +596,21 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             constexpr int NDM = RSH / 1024;
             const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(rowsP + (long long)f * 2 * S1p + 2 * xbase);
             const unsigned dst = L::AL(0) + (unsigned)(tt % 3) * (unsigned)RSH;
+            if constexpr (small_graph) {  // (one DMA covers the row: the others would copy element 0 again)
+                dma_b128(src + (sl < n4 ? sl : 0), dst);
+            } else {
 #pragma unroll
-            for (int j = 0; j < NDM; ++j) {
-                const int q = sl + 64 * j;
-                dma_b128(src + (q < n4 ? q : 0), dst + 1024u * j);
+                for (int j = 0; j < NDM; ++j) {
+                    const int q = sl + 64 * j;
+                    dma_b128(src + (q < n4 ? q : 0), dst + 1024u * j);
+                }
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 dma_b32(reinterpret_cast<const unsigned *>(U[u].offs + f) + (sl & 1), L::POFF(0, u) + 512u * (t & 7));
         };
         constexpr int NDMA = 2 * NJ + (PHASE ? RSH / 1024 + 2 : 0);  // DMAs issued per step (a lower bound of the VMEM operations)
+        constexpr int NDMA_SMALL = 2 * NJ + (PHASE ? 1 + 2 : 0);     // ... of a small graph (see dma_partner)
         // stage the emissions of step t into EM(t & 1) and account its offsets; S = the normaliser the step subtracts
         auto stage = [&](int t, const float (&S)[2]) {
             float E[2];
@@ -697,11 +707,16 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
 #endif
             if constexpr (H > 1 || NJ > 2 || (MM_PAIR_OPAQUE_B && PHASE == 1)) asm volatile("" : "+v"(sl));
             // emissions of step t + 1 (requested at step t - 2: the DMAs of step t - 1 may still be in flight)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            // (a small graph issues ONE partner DMA per step, not RSH / 1024: the bound of what may be in flight shrinks with it)
+            if constexpr (small_graph) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA_SMALL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
             MM_STAMP(2);
             // the normaliser of step t + 1 from the maxima of step t - 1 (complete since the last barrier)
             float mx[2];
-            pair_scan_max<(RS / 8 + 63) / 64>(L::PP(RD), (S1 + 2) >> 1, sl, mx[0], mx[1]);
+            // (a graph of up to 511 states: 4 loads per lane instead of the region's 16 -- the service wave is the longest
+            // actor of a small graph's step, BASELINE config 2)
+            if constexpr (small_graph) pair_scan_max<4>(L::PP(RD), (S1 + 2) >> 1, sl, mx[0], mx[1]);
+            else pair_scan_max<(RS / 8 + 63) / 64>(L::PP(RD), (S1 + 2) >> 1, sl, mx[0], mx[1]);
             MM_STAMP(3);
             if (t + 1 <= tEnd) {
                 const float S[2] = {norm[0].next(mx[0]), norm[1].next(mx[1])};
@@ -716,7 +731,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 if (t - 2 > t0) frames_of_step(t - 2, L::PSUM(WR));
                 MM_STAMP(6);
                 // the partner vector of step t + 1 (requested at step t - 1) must be in LDS when the compute waves leave the barrier
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+                if constexpr (small_graph) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA_SMALL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
                 MM_STAMP(7);
             }
             MM_STAMP(0);

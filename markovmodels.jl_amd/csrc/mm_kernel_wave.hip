@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 3)) mm_wave_kernel(RunPar
         }
     };
 
-    // ROLE: 0 compute wave, 1 service wave E, 2 service wave P, 3 service wave F -- one loop per role (run()): what only one role needs (the
+    // ROLE: 0 compute wave, 1 service wave E, 2 service wave P -- one loop per role (run()): what only one role needs (the
     // pointers of the emissions and posteriors, the graph registers) does not stay live in the other roles' loops
     auto step = [&](auto RDc, auto PHc, auto ROLEc, int t) __attribute__((always_inline)) {
         constexpr int RD = decltype(RDc)::value, WR = 1 - RD, PHASE = decltype(PHc)::value, ROLE = decltype(ROLEc)::value;

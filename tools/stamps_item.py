@@ -2,12 +2,16 @@
 import ctypes as C, importlib, os, sys
 import numpy as np
 ROOT='/root/repo'; sys.path.insert(0, ROOT)
-os.environ["MM_AMD_LIB"]=os.path.join(ROOT,"markovmodels.jl_amd","libmarkovmodels_amd_stamps.so")
+os.environ["MM_AMD_LIB"]=os.path.join(ROOT,"gpurun_stamps","libmarkovmodels_amd_stamps.so")
 import __graft_entry__ as ge, torch
 mm=ge.load_package(); wl=importlib.import_module(mm.__name__+".workloads"); L=importlib.import_module(mm.__name__+"._lib")
 g=wl.load_npz_graph(os.path.join(ROOT,"tests","golden","num_fsm_wsj.npz")); B,N=128,700
+if os.environ.get("S"):
+    g=wl.lfmmi_denominator(int(os.environ["S"]), 84, seed=1); B,N=32,200
+    os.environ["MM_DEBUG"]="1"; os.environ["MM_KERNEL"]="item"
 cf=mm.compile(wl.to_fsm(mm,g), mm.statemap(g.state2pdf,g.P)); bf=mm.batch(*([cf]*B))
 V=torch.randn(B,N,g.P,device="cuda")
+print(bf.kernels())
 bf.pdfposteriors(V); bf.pdfposteriors(V); torch.cuda.synchronize()
 n=B*16*16; out=np.zeros(n,dtype=np.uint64)
 L.lib.mm_debug_read_stamps.argtypes=[C.c_void_p,C.c_int64]

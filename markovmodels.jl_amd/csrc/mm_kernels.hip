@@ -240,6 +240,46 @@ __device__ __forceinline__ float grp_sum(float v, int log2g) {
     if (log2g >= 6) v += __shfl_xor(v, 32);
     return v;
 }
+// The same for a log2g known only at run time (the item kernels: one call per item): nested levels -- with the six tests in
+// a row every level a group does NOT have is a taken branch over its code, four of them for a row on 4 lanes -- and the
+// combine of a level as ONE DPP instruction (v_max_f32_dpp / v_add_f32_dpp) instead of a move and an operation.
+#define MM_GRP_DPP(op, ctrl) asm("s_nop 1\n\t" op " %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(v))
+__device__ __forceinline__ float grp_max_rt(float v, int log2g) {
+    if (log2g == 0) return v;
+    MM_GRP_DPP("v_max_f32_dpp", "quad_perm:[1,0,3,2]");
+    if (log2g >= 2) {
+        MM_GRP_DPP("v_max_f32_dpp", "quad_perm:[2,3,0,1]");
+        if (log2g >= 3) {
+            MM_GRP_DPP("v_max_f32_dpp", "row_half_mirror");
+            if (log2g >= 4) {
+                MM_GRP_DPP("v_max_f32_dpp", "row_mirror");
+                if (log2g >= 5) {
+                    v = fmaxf(v, __shfl_xor(v, 16));
+                    if (log2g >= 6) v = fmaxf(v, __shfl_xor(v, 32));
+                }
+            }
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ float grp_sum_rt(float v, int log2g) {
+    if (log2g == 0) return v;
+    MM_GRP_DPP("v_add_f32_dpp", "quad_perm:[1,0,3,2]");
+    if (log2g >= 2) {
+        MM_GRP_DPP("v_add_f32_dpp", "quad_perm:[2,3,0,1]");
+        if (log2g >= 3) {
+            MM_GRP_DPP("v_add_f32_dpp", "row_half_mirror");
+            if (log2g >= 4) {
+                MM_GRP_DPP("v_add_f32_dpp", "row_mirror");
+                if (log2g >= 5) {
+                    v += __shfl_xor(v, 16);
+                    if (log2g >= 6) v += __shfl_xor(v, 32);
+                }
+            }
+        }
+    }
+    return v;
+}
 __device__ __forceinline__ float wave_max(float v) { return grp_max(v, 6); }
 __device__ __forceinline__ float wave_sum(float v) { return grp_sum(v, 6); }
 
@@ -265,12 +305,12 @@ __device__ __forceinline__ float lse_small(const Slot *sp, int log2g, const floa
     float m = x[0];
 #pragma unroll
     for (int k = 1; k < R; ++k) m = fmaxf(m, x[k]);
-    m = grp_max(m, log2g);
+    m = grp_max_rt(m, log2g);
     float m0 = (m > MM_NINF) ? m : 0.f;
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < R; ++k) sum += fast_exp2(x[k] - m0);
-    sum = grp_sum(sum, log2g);
+    sum = grp_sum_rt(sum, log2g);
     return m0 + fast_log2(sum);
 }
 
@@ -292,9 +332,9 @@ __device__ __forceinline__ float lse_long(const Slot *sp, int R, int log2g, cons
         for (int k = 0; k < 4; ++k) sum += fast_exp2(x[k] - mn0);
         m = mn;
     }
-    float M = grp_max(m, log2g);
+    float M = grp_max_rt(m, log2g);
     float M0 = (M > MM_NINF) ? M : 0.f;
-    sum = grp_sum(sum * fast_exp2(m - M0), log2g);
+    sum = grp_sum_rt(sum * fast_exp2(m - M0), log2g);
     return M0 + fast_log2(sum);
 }
 
@@ -318,7 +358,7 @@ __device__ __forceinline__ float max_item(const Slot *slots, const ItemMeta &im,
         const Slot s = load_slot(sp + k * 64);
         m = fmaxf(m, s.w + a[s.col]);
     }
-    return grp_max(m, im.log2g);
+    return grp_max_rt(m, im.log2g);
 }
 
 __device__ __forceinline__ ItemMeta load_item(const ItemMeta *items, int it) {
@@ -485,11 +525,11 @@ __device__ __forceinline__ float lse_regs(float w0, float w1, float w2, float w3
         x3 = w3 + a[c23 >> 16];
     }
     float m = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
-    m = grp_max(m, lg);
+    m = grp_max_rt(m, lg);
     const float m0 = (m > MM_NINF) ? m : 0.f;
     float sum = fast_exp2(x0 - m0) + fast_exp2(x1 - m0);
     if (R > 2) sum += fast_exp2(x2 - m0) + fast_exp2(x3 - m0);
-    sum = grp_sum(sum, lg);
+    sum = grp_sum_rt(sum, lg);
     return m0 + fast_log2(sum);
 }
 
@@ -497,7 +537,7 @@ __device__ __forceinline__ float max_regs(float w0, float w1, float w2, float w3
                                           int lg, const float *a) {
     float m = fmaxf(w0 + a[c01 & 0xffffu], w1 + a[c01 >> 16]);
     if (R > 2) m = fmaxf(m, fmaxf(w2 + a[c23 & 0xffffu], w3 + a[c23 >> 16]));
-    return grp_max(m, lg);
+    return grp_max_rt(m, lg);
 }
 
 // Visit every item of this wave: epi(value, row, pdf) runs on the leader lane of

@@ -142,7 +142,7 @@ struct mm_fsm_s {
     // split pair forms (mm_rows.h make_rows_split): [direction][set], for FSMs beyond the registers / LDS of one compute unit
     RowVariant *srows[2][MM_SPLIT_HMAX] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
     SplitInfo split;
-    bool split_tried = false;
+    int split_tried = 0;  // bit H: the split forms for teams of H have been tried
     RowVariant *wrows[2] = {nullptr, nullptr};  // wave forms (mm_kernel_wave.hip)
     RowVariant *wpend[2] = {nullptr, nullptr};  // ... packed, not yet uploaded (wave_pack)
     bool wave_tried = false, wave_packed = false;
@@ -836,9 +836,9 @@ static int upload_row_variant(mm_fsm_t f, RowVariant *v, int dir, float thr, boo
 }
 
 // options of the split pair forms (mm_rows.h make_rows_split; the kernels: mm_kernel_pairs.hip with H > 1)
-static void split_pack_opts(const DebugOpts &dbg, RowPackOpts &opt, RowPackOpts &optb) {
+static void split_pack_opts(const DebugOpts &dbg, RowPackOpts &opt, RowPackOpts &optb, int H = 2) {
     opt = RowPackOpts();
-    opt.rs = MM_SPLIT_RS;
+    opt.rs = H == 4 ? MM_SPLIT4_RS : MM_SPLIT_RS;
     opt.ka_max = MM_SPLIT_KA;
     opt.nwc_max = MM_SPLIT_NWC;
     opt.pair = true;
@@ -1083,11 +1083,11 @@ static int wave_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
 // the split pair forms of an FSM for teams of H workgroups (built once; *ok = false if it does not fit them)
 static int split_variants(mm_fsm_t f, const DebugOpts &dbg, int H, bool *ok) {
     *ok = f->split.H == H && f->srows[0][0] != nullptr;
-    if (*ok || f->split_tried) return MM_OK;
-    f->split_tried = true;
-    if (f->semiring != MM_LOG || !f->fast_ok || f->P1 > 250 || H > MM_SPLIT_HMAX) return MM_OK;
+    if (*ok || f->srows[0][0] != nullptr || (f->split_tried >> H) & 1) return MM_OK;  // (one team size per FSM: the first that fits)
+    f->split_tried |= 1 << H;
+    if (f->semiring != MM_LOG || !f->fast_ok || f->P1 > (H == 4 ? 128 : 250) || H > MM_SPLIT_HMAX) return MM_OK;
     RowPackOpts opt, optb;
-    split_pack_opts(dbg, opt, optb);
+    split_pack_opts(dbg, opt, optb, H);
     std::vector<RowGraph> gs;
     SplitInfo info;
     if (!make_rows_split(H, f->S1, f->qmat[0].rowptr, f->qmat[0].col, f->qmat[0].val, f->qmat[1].rowptr, f->qmat[1].col,
@@ -1097,7 +1097,7 @@ static int split_variants(mm_fsm_t f, const DebugOpts &dbg, int H, bool *ok) {
     for (const RowGraph &g : gs) wmin = std::min(wmin, g.wmin_log2);
     if (wmin < -60.f) return MM_OK;  // (as for the row forms: too little of the float range would be left to the values)
     for (int h = 0; h < H; ++h)
-        if (size_t(info.count[h] + 1) * 8 > MM_SPLIT_RSH) return MM_OK;
+        if (size_t(info.count[h] + 1) * 8 > size_t(H == 4 ? MM_SPLIT4_RSH : MM_SPLIT_RSH)) return MM_OK;
     const float NINF = -std::numeric_limits<float>::infinity();
     int rc = MM_OK;
     for (int d = 0; d < 2 && !rc; ++d) {
@@ -1399,7 +1399,7 @@ int mm_debug_split_product(mm_fsm_t f, int H, int direction, const float *in, fl
         return fail(MM_ERR_INVALID, "mm_debug_split_product: bad argument");
     if (f->semiring != MM_LOG) return fail(MM_ERR_INVALID, "mm_debug_split_product: log-semiring FSMs only");
     RowPackOpts opt, optb;
-    split_pack_opts(DebugOpts(), opt, optb);
+    split_pack_opts(DebugOpts(), opt, optb, H);
     std::vector<RowGraph> gs;
     SplitInfo info;
     if (!make_rows_split(H, f->S1, f->mat[0].rowptr, f->mat[0].col, f->mat[0].val, f->mat[1].rowptr, f->mat[1].col,
@@ -1545,6 +1545,8 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         if (same) {
             bool ok = false;
             int rc = split_variants(fsms[0], h->dbg, 2, &ok);
+            // (a graph beyond the teams of 2 -- more than 3070 states or 2 x 14 x 64 x 36 arcs: teams of 4)
+            if (!rc && !ok) rc = split_variants(fsms[0], h->dbg, 4, &ok);
             if (rc) {
                 delete h;
                 return rc;
@@ -1563,7 +1565,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
                     }
                 h->split_s1p = (f0->split.total + 2 + 3) & ~3;
                 h->pairs_ok = h->pair_ka <= MM_SPLIT_KA && h->pair_nwc <= MM_SPLIT_NWC &&
-                              mm_split_lds_bytes(1, h->pair_slotrows) <= 160 * 1024;
+                              mm_split_lds_bytes(h->pair_H, 1, h->pair_slotrows) <= 160 * 1024;
                 if (!h->pairs_ok) h->pair_H = 1;
             }
         }

@@ -31,6 +31,9 @@ int mm_fail(int code, const std::string &msg);
 #define MM_SPLIT_RS 12288
 #define MM_SPLIT_RSH 13312  // LDS bytes of the rows ONE workgroup of a team finishes (the sets are balanced by arcs: their row
                             // counts differ by a few per cent; 1663 rows leave 51 slot rows of LDS in phase B)
+// teams of 4: the team's vector of pairs is 32 KB (up to 4094 states), a workgroup finishes a quarter of the rows
+#define MM_SPLIT4_RS 16384
+#define MM_SPLIT4_RSH 9216
 #define MM_SPLIT_KA 36
 #define MM_SPLIT_NWC 14
 
@@ -63,7 +66,7 @@ size_t mm_pair_lds_bytes(int phase, int nslotrows);
 size_t mm_pair_hand_bytes();
 // ---- split pair kernels (mm_split_tu.hip): teams of pl.H workgroups
 int mm_launch_split(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
-size_t mm_split_lds_bytes(int phase, int nslotrows);
+size_t mm_split_lds_bytes(int H, int phase, int nslotrows);
 
 
 // ---- wave kernel (mm_wave_tu.hip)

@@ -66,6 +66,39 @@ def test_split_kernels_on_the_reference_wsj_denominator(mm, wl, oracle, torch, m
     assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("S,mode", [(3400, "auto"), (4000, "auto"), (4000, "write_through"), (4000, "apart")])
+def test_split_kernels_teams_of_four(mm, wl, oracle, torch, S, mode):
+    """Graphs beyond the teams of two (more than 3070 states) run on teams of FOUR workgroups per utterance pair and
+    direction (up to 4094 states, 129 k arcs, 128 pdfs): every workgroup receives the rows of three others each step.
+    `write_through`: the exchange form for teams that do not share an XCD; `apart`: a team that does not run together
+    (the exact kernels -- here the item kernel: the graph is beyond the quad kernels too -- compute every utterance)."""
+    g = wl.lfmmi_denominator(S, 84, seed=S)
+    rng = np.random.default_rng(S)
+    B, N = 7, 48
+    V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+    lens = np.array([48, 48, 31, 48, 2, 40, 17], dtype=np.int32)
+    if mode == "apart":
+        def run():
+            cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+            bf = mm.batch(*([cf] * B))
+            gam, ttl = bf.pdfposteriors(V, lens)
+            return gam, ttl, bf.kernels(), bf.last_redo_count()
+
+        gam, ttl, kernels, redo = _with_env({"MM_DEBUG": "1", "MM_SPLIT_SLEEP": str(8 | 0x200)}, run)
+        assert redo == B
+    else:
+        env = {"MM_SPLIT_SLEEP": str(8 | 0x800)} if mode == "write_through" else {}
+        gam, ttl, kernels, redo = run_fast_alone(mm, wl, g, V, lens, env)
+        assert redo == 0
+    assert "mm_fbs_kernel_dir" in kernels and "teams of 4" in kernels, kernels
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    ok = np.isfinite(t_ref)
+    assert ok.sum() >= B - 1
+    check_gamma(gam[ok], g_ref[ok], lens[ok])
+    assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-4)
+    assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()
+
+
 def test_split_kernels_team_that_does_not_run_together(mm, wl, oracle, torch):
     """A team whose workgroups cannot see each other (a foreign kernel holding the compute units; here simulated: the
     exchange waves give up at once, MM_SPLIT_SLEEP bit 0x200) marks its utterances with 2; the finish kernel keeps such
@@ -195,8 +228,8 @@ def test_posterior_floor_keeps_sharp_emissions_on_the_fast_kernels(mm, wl, oracl
 @pytest.mark.parametrize("S,P", [(6000, 300), (2900, 120), (1000, 640)])
 def test_graph_beyond_the_fast_paths(mm, wl, oracle, torch, S, P):
     """The reference's products have no size limit (src/linalg.jl:170-181).  6000 states x 300 pdfs and 1000 states x
-    640 pdfs are beyond the pair kernels (2047 states, 250 pdfs) and the teams of two (3070 states): they run on the quad
-    kernels; a 2900-state graph of config 3's family takes the teams.  Same results either way."""
+    640 pdfs are beyond the pair kernels (2047 states, 250 pdfs) and the teams (4094 states, 128 pdfs): they run on the
+    quad / item kernels; a 2900-state graph of config 3's family takes the teams of two.  Same results either way."""
     g = wl.lfmmi_denominator(S, P, seed=S)
     rng = np.random.default_rng(S + P)
     B, N = 5, 36

@@ -60,7 +60,8 @@ def fuzz_split(rng):
     bad = n = 0
     here = os.path.join(ROOT, "tests", "golden", "den_fsm_wsj.npz")
     graphs = [lambda: wl.load_npz_graph(here), lambda: wl.lfmmi_denominator(2900, 120, seed=int(rng.integers(1 << 30))),
-              lambda: wl.lfmmi_denominator(2400, 200, seed=int(rng.integers(1 << 30)))]
+              lambda: wl.lfmmi_denominator(2400, 200, seed=int(rng.integers(1 << 30))),
+              lambda: wl.lfmmi_denominator(int(rng.integers(1600, 2040)) * 2, 100, seed=int(rng.integers(1 << 30)))]  # (teams of 4)
     for gi, mk in enumerate(graphs):
         g = mk()
         cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))

@@ -1,4 +1,4 @@
-// mm_split_tu.hip -- translation unit of the SPLIT pair kernels: pair_agent (mm_kernel_pairs.hip) with teams of H = 2
+// mm_split_tu.hip -- translation unit of the SPLIT pair kernels: pair_agent (mm_kernel_pairs.hip) with teams of H = 2 or 4
 // workgroups per utterance pair and direction, for FSMs beyond the registers / LDS of one compute unit (the reference's
 // WSJ denominator graph, misc/benchmark/den_fsm_wsj.txt; the reference itself has no size limit, src/linalg.jl:170-181).
 #define MM_SECONDARY_TU

@@ -1085,7 +1085,7 @@ static int split_variants(mm_fsm_t f, const DebugOpts &dbg, int H, bool *ok) {
     *ok = f->split.H == H && f->srows[0][0] != nullptr;
     if (*ok || f->srows[0][0] != nullptr || (f->split_tried >> H) & 1) return MM_OK;  // (one team size per FSM: the first that fits)
     f->split_tried |= 1 << H;
-    if (f->semiring != MM_LOG || !f->fast_ok || f->P1 > (H == 4 ? 128 : 250) || H > MM_SPLIT_HMAX) return MM_OK;
+    if (f->semiring != MM_LOG || !f->fast_ok || f->P1 > 250 || H > MM_SPLIT_HMAX) return MM_OK;
     RowPackOpts opt, optb;
     split_pack_opts(dbg, opt, optb, H);
     std::vector<RowGraph> gs;

@@ -63,10 +63,7 @@ static int launch_split_nj(const PairLaunch *h, const RunParams &p, hipStream_t 
 }
 int mm_launch_split(const PairLaunch &pl, const RunParams &p, hipStream_t s0) {
     if (pl.pair_ka > MM_SPLIT_KA) return MM_ERR_UNSUPPORTED;
-    if (pl.H == 4) {  // (teams of 4: the instances for up to 128 pdfs only)
-        if (pl.max_P1 > 128) return mm_fail(MM_ERR_UNSUPPORTED, "split kernel: teams of 4 with more than 128 pdfs");
-        return launch_split_nj<2, 4>(&pl, p, s0);
-    }
+    if (pl.H == 4) return pl.max_P1 <= 128 ? launch_split_nj<2, 4>(&pl, p, s0) : launch_split_nj<4, 4>(&pl, p, s0);
     if (pl.H != 2) return mm_fail(MM_ERR_UNSUPPORTED, "split kernel: teams of 2 or 4");
     return pl.max_P1 <= 128 ? launch_split_nj<2, 2>(&pl, p, s0) : launch_split_nj<4, 2>(&pl, p, s0);
 }

@@ -66,13 +66,13 @@ def test_split_kernels_on_the_reference_wsj_denominator(mm, wl, oracle, torch, m
     assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("S,mode", [(3400, "auto"), (4000, "auto"), (4000, "write_through"), (4000, "apart")])
+@pytest.mark.parametrize("S,mode", [(3400, "auto"), (4000, "auto"), (4000, "write_through"), (4000, "apart"), (3600, "pdfs200")])
 def test_split_kernels_teams_of_four(mm, wl, oracle, torch, S, mode):
     """Graphs beyond the teams of two (more than 3070 states) run on teams of FOUR workgroups per utterance pair and
-    direction (up to 4094 states, 129 k arcs, 128 pdfs): every workgroup receives the rows of three others each step.
+    direction (up to 4094 states, 129 k arcs): every workgroup receives the rows of three others each step.
     `write_through`: the exchange form for teams that do not share an XCD; `apart`: a team that does not run together
     (the exact kernels -- here the item kernel: the graph is beyond the quad kernels too -- compute every utterance)."""
-    g = wl.lfmmi_denominator(S, 84, seed=S)
+    g = wl.lfmmi_denominator(S, 200 if mode == "pdfs200" else 84, seed=S)  # (pdfs200: the instances for 129 .. 250 pdfs)
     rng = np.random.default_rng(S)
     B, N = 7, 48
     V = rng.standard_normal((B, N, g.P)).astype(np.float32)

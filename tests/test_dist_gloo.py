@@ -93,3 +93,67 @@ def test_two_rank_logz_allreduce():
     for rank, total, allttl in res:
         assert np.isclose(total, ttl.sum(), rtol=1e-6)
         assert np.allclose(allttl, ttl, rtol=1e-6)
+
+
+def _gpu_worker(rank, world, port, q):
+    """One rank of a sharded pdfposteriors step with the HIP engine: its shard of the batch on the GPU (both ranks share the
+    one GPU of the test box), the total log-likelihood over gloo."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    import __graft_entry__ as ge
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mm = ge.load_package()
+    wl = importlib.import_module(mm.__name__ + ".workloads")
+    g = wl.lfmmi_denominator(600, 40, seed=5)
+    B, N = 11, 60
+    rng = np.random.default_rng(0)
+    V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+    lens = rng.integers(20, N + 1, B).astype(np.int32)
+    lo, hi = mm.dist.shard_range(B, rank, world)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(*([cf] * (hi - lo)))
+    gam, ttl = bf.pdfposteriors(torch.from_numpy(V[lo:hi]).cuda(), torch.from_numpy(lens[lo:hi]).cuda())
+    total = mm.dist.allreduce_logz(ttl.cpu())
+    sizes = [mm.dist.shard_range(B, r, world)[1] - mm.dist.shard_range(B, r, world)[0] for r in range(world)]
+    allttl = mm.dist.allgather_ttl(ttl.cpu(), sizes)
+    q.put((rank, float(total), allttl.numpy().tolist(), bf.kernels()[:20], float(gam.sum())))
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_the_hip_engine():
+    """The N > 1 path with the product on the device: world size 2 over gloo, every rank computes its shard with the HIP
+    engine (pair kernels), the scalar exchange is the same code the RCCL job runs (dist.allreduce_logz / allgather_ttl).
+    Against the oracle on the whole batch."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    import __graft_entry__ as ge
+    import graphs
+
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    mm = ge.load_package()
+    wl = importlib.import_module(mm.__name__ + ".workloads")
+    o, oc = ge.load_oracle()
+    g = wl.lfmmi_denominator(600, 40, seed=5)
+    rng = np.random.default_rng(0)
+    V = rng.standard_normal((11, 60, g.P)).astype(np.float32)
+    lens = rng.integers(20, 61, 11).astype(np.int32)
+    g_ref, ttl = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V, lens, dtype=np.float64)
+    for rank, total, allttl, kernels, gsum in res:
+        assert "mm_fbp_kernel_dir" in kernels
+        assert np.isclose(total, ttl.sum(), rtol=1e-5)
+        assert np.allclose(allttl, ttl, rtol=1e-5, atol=1e-4)
+    assert np.isclose(sum(r[4] for r in res), g_ref.sum(), rtol=1e-4)

@@ -16,6 +16,7 @@ from .inference import (  # noqa: F401
     bestpath,
     betarecursion,
     compile,
+    compile_many,
     expand,
     maxstateposteriors,
     pdfposteriors,

@@ -138,6 +138,31 @@ def compile(fsm: FSM, C_hat) -> CompiledFSM:  # noqa: A001 - the reference's nam
     return CompiledFSM(fsm, C_hat)
 
 
+def compile_many(fsms, C_hats, threads: int = 8):
+    """`compile.(fsms, C_hats)` (the reference broadcasts compile over a mini-batch of numerator graphs,
+    examples/test_cuda.jl:76-78) on several host threads: mm_fsm_create packs and uploads one graph per call, the calls
+    release the interpreter lock.  C_hats: one state map for all, or one per FSM."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    fsms = list(fsms)
+    maps = list(C_hats) if isinstance(C_hats, (list, tuple)) else [C_hats] * len(fsms)
+    if len(maps) != len(fsms):
+        raise ValueError("compile_many: one C_hat per FSM (or one for all)")
+    if threads <= 1 or len(fsms) < 4:
+        return [CompiledFSM(f, m) for f, m in zip(fsms, maps)]
+    import torch
+
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+    def one(fm):
+        if dev is not None:
+            torch.cuda.set_device(dev)  # (the current device is per thread: a rank's graphs belong on the rank's GPU)
+        return CompiledFSM(fm[0], fm[1])
+
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        return list(pool.map(one, zip(fsms, maps)))
+
+
 class BatchedFSM:
     """batch(cfsm...) (src/inference.jl:28-36): B independent compiled FSMs as
     one block-diagonal system.  Repeating one CompiledFSM B times shares its

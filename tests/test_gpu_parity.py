@@ -595,7 +595,8 @@ def test_wave_batch_of_many_new_graphs(mm, wl, oracle, torch):
     lens = rng.integers(N // 2, N + 1, B).astype(np.int32)
     sm = [mm.statemap(g.state2pdf, g.P) for g in gs]
     force = {"MM_DEBUG": "1", "MM_KERNEL": "wave"}  # (graphs of this size would take the row kernels)
-    bf = _with_env(force, lambda: mm.batch(*[mm.compile(wl.to_fsm(mm, g), m) for g, m in zip(gs, sm)]))
+    # (compile_many: mm_fsm_create for the graphs of a mini-batch on several host threads)
+    bf = _with_env(force, lambda: mm.batch(*mm.compile_many([wl.to_fsm(mm, g) for g in gs], sm, threads=4)))
     assert "mm_wave_kernel" in bf.kernels("log"), bf.kernels("log")
     gam, ttl = bf.pdfposteriors(V, lens)
     for b in (0, 5, 11, 23):

@@ -15,7 +15,7 @@ for rep in range(3):
     t0 = time.perf_counter()
     fs = [wl.to_fsm(mm, g) for _ in range(B)]
     t1 = time.perf_counter()
-    cfs = [mm.compile(f, sm) for f in fs]
+    cfs = mm.compile_many(fs, sm) if os.environ.get("MANY") else [mm.compile(f, sm) for f in fs]
     t2 = time.perf_counter()
     bf = mm.batch(*cfs)
     t3 = time.perf_counter()

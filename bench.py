@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 
 def make_workload(wl, name):
     """(graph, frames, utterances per GPU, semiring).  lfmmi_den = BASELINE.json configs[2] (the metric's
     configuration); lexicon5000 = configs[4] (Viterbi); ergodic64 = configs[1]; wsj_den / wsj_num = the reference's
-    own benchmark graphs (misc/benchmark/README.md: T = 700, B = 128)."""
+    own benchmark graphs (misc/benchmark/README.md: T = 700, B = 128); lfmmi_den4000 = a 4000-state graph of config 3's family."""
     if name == "lfmmi_den":
         return wl.lfmmi_denominator(2000, 84, seed=0), 1500, 256, "log"
     if name == "ergodic64":
@@ -50,6 +50,8 @@ def make_workload(wl, name):
         return wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "num_fsm_wsj.npz")), 700, 128, "log"
     if name == "lexicon5000":
         return wl.lexicon_fsm(5000, 84, seed=0), 1000, 128, "tropical"
+    if name == "lfmmi_den4000":  # (config 3's graph family beyond the teams of two: teams of four workgroups)
+        return wl.lfmmi_denominator(4000, 84, seed=1), 700, 128, "log"
     raise SystemExit(f"unknown workload {name}")
 
 

@@ -142,6 +142,87 @@ __device__ __forceinline__ bool split_receive(const float *src, int n, unsigned 
     }
 }
 
+// The same for teams of more than two: the rows of ALL the other sets of the step in ONE pipelined sweep -- the items (set,
+// chunk of 128 granules) are loaded in a fixed order with K loads in flight, each checked and written as it returns; a
+// sweep is repeated until every granule has carried the tag.  One set after the other (split_receive per set) cost a team
+// of 4 three memory round trips per step behind the arrival of the last row: 12 k cycles per step against 2.5 k of
+// arithmetic (cycle stamps).  Every item is loaded in every sweep, pending or not (clamped to the set's first granule
+// where a lane has none): the number of loads in flight is then a constant of the code, which the counted waits need.
+template <int N>
+__device__ __forceinline__ void split_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int NG2, int NP, int K>
+__device__ __forceinline__ bool split_receive_multi(const float *const (&src)[NP], const int (&n)[NP], const unsigned (&dst)[NP], unsigned tag,
+                                                    int lane, unsigned first_sleep) {
+    typedef unsigned mm_u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int I = NP * NG2;
+    static_assert(I <= 32 && K <= I && K <= 12, "pending mask / wait constants");
+    mm_u32x4 v[K];
+    unsigned pending = 0u;  // bit i = item (set i / NG2, chunk i % NG2): the granules 2 (lane + 64 chunk), + 1 of the set have not both arrived
+#pragma unroll
+    for (int i = 0; i < I; ++i)
+        if (2 * (lane + 64 * (i % NG2)) < n[i / NG2]) pending |= 1u << i;
+#pragma unroll
+    for (int s = 0; s < K; ++s) v[s] = mm_u32x4{0u, 0u, 0u, 0u};
+    for (unsigned i = 0; i < first_sleep; ++i) __builtin_amdgcn_s_sleep(1);
+    const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int g = i / NG2, j = i % NG2;
+            const unsigned off = 2 * (lane + 64 * j) < n[g] ? 16u * (unsigned)(lane + 64 * j) : 0u;
+            asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(v[i]) : "v"(off), "s"(src[g]) : "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < I; ++i) {
+            const int g = i / NG2, j = i % NG2, slot = i % K;
+            // loads issued so far: min(i + K, I); item i is the oldest of the ones not yet looked at
+            constexpr int dummy = 0;
+            (void)dummy;
+            if (i + K <= I) {
+                split_wait_vm<K - 1>();
+            } else {
+                switch (I - i - 1) {
+                    case 11: split_wait_vm<11>(); break;
+                    case 10: split_wait_vm<10>(); break;
+                    case 9: split_wait_vm<9>(); break;
+                    case 8: split_wait_vm<8>(); break;
+                    case 7: split_wait_vm<7>(); break;
+                    case 6: split_wait_vm<6>(); break;
+                    case 5: split_wait_vm<5>(); break;
+                    case 4: split_wait_vm<4>(); break;
+                    case 3: split_wait_vm<3>(); break;
+                    case 2: split_wait_vm<2>(); break;
+                    case 1: split_wait_vm<1>(); break;
+                    default: split_wait_vm<0>(); break;
+                }
+            }
+            asm volatile("" : "+v"(v[slot]));
+            if ((pending >> i) & 1u) {
+                const bool second = 2 * (lane + 64 * j) + 1 < n[g];
+                if ((v[slot].x >> 31) == tag && (!second || (v[slot].z >> 31) == tag)) {
+                    mm_f32x4 w;
+                    w.x = __builtin_bit_cast(float, v[slot].x & 0x7fffffffu);
+                    w.y = __builtin_bit_cast(float, v[slot].y & 0x7fffffffu);
+                    w.z = second ? __builtin_bit_cast(float, v[slot].z & 0x7fffffffu) : 0.f;
+                    w.w = second ? __builtin_bit_cast(float, v[slot].w & 0x7fffffffu) : 0.f;
+                    *(__attribute__((address_space(3))) mm_f32x4 *)(__UINTPTR_TYPE__)(dst[g] + 16u * (unsigned)(lane + 64 * j)) = w;
+                    pending &= ~(1u << i);
+                }
+            }
+            if (i + K < I) {  // the slot is free: the next item of the sweep
+                const int g2 = (i + K) / NG2, j2 = (i + K) % NG2;
+                const unsigned off = 2 * (lane + 64 * j2) < n[g2] ? 16u * (unsigned)(lane + 64 * j2) : 0u;
+                asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(v[slot]) : "v"(off), "s"(src[g2]) : "memory");
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(pending != 0u) == 0ull) return true;
+        if (__builtin_amdgcn_s_memrealtime() - tstart > MM_SPLIT_TIMEOUT) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
 struct PairUtt {  // one utterance of the pair (scalar registers)
     const float *Vb;
     double *offs;     // [N + 2] cumulative offset of the stored vector of every frame
@@ -817,12 +898,33 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         MM_STAMP_RESET;
         for (int t = t0 + 1; t <= t1; ++t) {
             if (!dead) {
+                if constexpr (H == 2) {
 #pragma unroll
-                for (int g = 0; g < H; ++g) {
-                    if (g == hset) continue;
-                    if (!split_receive<NG2>(xrecv[g] + (long long)(t & 1) * p.x_slot, p.sp_cnt[g], L::PP(t & 1) + 8u * (unsigned)p.sp_base[g],
-                                           split_tag(t, t0, 1), lane, (unsigned)p.x_sleep & 0xffu)) {
-                        dead = true;  // the team is not running together: mark the utterances for the exact kernels, wait no more
+                    for (int g = 0; g < H; ++g) {
+                        if (g == hset) continue;
+                        if (!split_receive<NG2>(xrecv[g] + (long long)(t & 1) * p.x_slot, p.sp_cnt[g], L::PP(t & 1) + 8u * (unsigned)p.sp_base[g],
+                                               split_tag(t, t0, 1), lane, (unsigned)p.x_sleep & 0xffu)) {
+                            dead = true;  // the team is not running together: mark the utterances for the exact kernels, wait no more
+                            if (lane == 0) {
+                                *redo0 = 2;
+                                *redo1 = 2;
+                            }
+                        }
+                    }
+                } else if constexpr (H > 2) {  // (the other sets' rows in one pipelined sweep: split_receive_multi)
+                    constexpr int NP = H - 1;
+                    const float *src[NP];
+                    int cnt[NP];
+                    unsigned dsts[NP];
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        const int g = q < hset ? q : q + 1;
+                        src[q] = xrecv[g] + (long long)(t & 1) * p.x_slot;
+                        cnt[q] = p.sp_cnt[g];
+                        dsts[q] = L::PP(t & 1) + 8u * (unsigned)p.sp_base[g];
+                    }
+                    if (!split_receive_multi<NG2, NP, 9>(src, cnt, dsts, split_tag(t, t0, 1), lane, (unsigned)p.x_sleep & 0xffu)) {
+                        dead = true;
                         if (lane == 0) {
                             *redo0 = 2;
                             *redo1 = 2;

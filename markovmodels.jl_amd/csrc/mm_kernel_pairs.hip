@@ -898,7 +898,29 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         MM_STAMP_RESET;
         for (int t = t0 + 1; t <= t1; ++t) {
             if (!dead) {
-                if constexpr (H == 2) {
+                // (teams of 2 as well: the chunks of the other set checked and written as they return instead of all loaded, all
+                // awaited, all written -- 2.73 -> 2.30 ms on the reference's WSJ denominator.  Loads in flight, measured on that
+                // graph / on a 4000-state graph with teams of 4: 2: 2.52 / 7.03 ms, 3: 2.29 / 6.00, 4: 2.29 / 5.77, 5: 2.30 / 5.48,
+                // 6: 2.33 / 5.67, 9: 2.46 / 6.10, 12: 2.47 / 6.12 -- what a hand-off costs sits in this compute unit's memory queue)
+#ifndef MM_SPLIT_PIPE2
+#define MM_SPLIT_PIPE2 1
+#endif
+#ifndef MM_SPLIT_K
+#define MM_SPLIT_K 5
+#endif
+                if constexpr (H == 2 && MM_SPLIT_PIPE2) {
+                    const int g = 1 - hset;
+                    const float *src[1] = {xrecv[g] + (long long)(t & 1) * p.x_slot};
+                    const int cnt[1] = {p.sp_cnt[g]};
+                    const unsigned dsts[1] = {L::PP(t & 1) + 8u * (unsigned)p.sp_base[g]};
+                    if (!split_receive_multi<NG2, 1, (NG2 < MM_SPLIT_K ? NG2 : MM_SPLIT_K)>(src, cnt, dsts, split_tag(t, t0, 1), lane, (unsigned)p.x_sleep & 0xffu)) {
+                        dead = true;
+                        if (lane == 0) {
+                            *redo0 = 2;
+                            *redo1 = 2;
+                        }
+                    }
+                } else if constexpr (H == 2) {
 #pragma unroll
                     for (int g = 0; g < H; ++g) {
                         if (g == hset) continue;
@@ -923,7 +945,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                         cnt[q] = p.sp_cnt[g];
                         dsts[q] = L::PP(t & 1) + 8u * (unsigned)p.sp_base[g];
                     }
-                    if (!split_receive_multi<NG2, NP, 9>(src, cnt, dsts, split_tag(t, t0, 1), lane, (unsigned)p.x_sleep & 0xffu)) {
+                    if (!split_receive_multi<NG2, NP, MM_SPLIT_K>(src, cnt, dsts, split_tag(t, t0, 1), lane, (unsigned)p.x_sleep & 0xffu)) {
                         dead = true;
                         if (lane == 0) {
                             *redo0 = 2;

@@ -896,8 +896,11 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         __syncthreads();  // (2)
         constexpr int NG2 = (RSH / 16 + 63) / 64;
         MM_STAMP_RESET;
+#ifndef MM_SPLIT_CWPOLL
+#define MM_SPLIT_CWPOLL 1
+#endif
         for (int t = t0 + 1; t <= t1; ++t) {
-            if (!dead) {
+            if (!dead && !MM_SPLIT_CWPOLL) {
                 // (teams of 2 as well: the chunks of the other set checked and written as they return instead of all loaded, all
                 // awaited, all written -- 2.73 -> 2.30 ms on the reference's WSJ denominator.  Loads in flight, measured on that
                 // graph / on a 4000-state graph with teams of 4: 2: 2.52 / 7.03 ms, 3: 2.29 / 6.00, 4: 2.29 / 5.77, 5: 2.30 / 5.48,
@@ -996,6 +999,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         load_graph();
         __syncthreads();  // (2)
         if constexpr (H > 1) xplain = __builtin_amdgcn_readfirstlane(ldsru(L::XFLAG)) != 0u;
+        bool cdead = H > 1 && (p.x_sleep & 0x200) != 0;  // (split kernels) a poll of this wave timed out: it waits no more
         auto step = [&](auto RDc, int t) {
             constexpr int RD = decltype(RDc)::value, WR = 1 - RD;
             if (nslots > 0) {
@@ -1090,6 +1094,49 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 if (t - 1 > t0)
                     pair_pdf_sums(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane, H > 1 ? xps_send + ((t - 1) & 3) * 512 : nullptr,
                                   (H > 1 && split_tag(t - 1, t0, 2)) ? -1.f : 1.f);
+            if constexpr (H > 1 && MM_SPLIT_CWPOLL) {
+                // The rows of the other sets of this step: chunk j (128 granules) of the q-th other set is item q * NG2 + j, and
+                // compute wave w receives the items w, w + NWC, ... -- all chunks are polled at the same time, one load in flight
+                // per wave, by waves that have nothing else to do until the barrier (one exchange wave sweeping all chunks was
+                // the longest wave of every step: arrival of the last row + a sweep of 13 loads).
+                constexpr int NG2 = (RSH / 16 + 63) / 64, I = (H - 1) * NG2;
+                typedef unsigned mm_u32x4 __attribute__((ext_vector_type(4)));
+                const unsigned tg = split_tag(t, t0, 1);
+                for (int i = wave; i < I; i += NWC) {
+                    const int q = i / NG2, j = i % NG2, g = q < hset ? q : q + 1;
+                    const float *src = xrecv[g] + (long long)(t & 1) * p.x_slot;
+                    const int ng = p.sp_cnt[g];
+                    const unsigned dsta = L::PP(WR) + 8u * (unsigned)p.sp_base[g] + 16u * (unsigned)(lane + 64 * j);
+                    const bool have = 2 * (lane + 64 * j) < ng, second = 2 * (lane + 64 * j) + 1 < ng;
+                    const unsigned off = have ? 16u * (unsigned)(lane + 64 * j) : 0u;
+                    bool pend = have;
+                    if (__builtin_amdgcn_ballot_w64(pend) == 0ull || cdead) continue;
+                    const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
+                    for (;;) {
+                        mm_u32x4 v;
+                        asm volatile("global_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(off), "s"(src) : "memory");
+                        if (pend && (v.x >> 31) == tg && (!second || (v.z >> 31) == tg)) {
+                            mm_f32x4 w;
+                            w.x = __builtin_bit_cast(float, v.x & 0x7fffffffu);
+                            w.y = __builtin_bit_cast(float, v.y & 0x7fffffffu);
+                            w.z = second ? __builtin_bit_cast(float, v.z & 0x7fffffffu) : 0.f;
+                            w.w = second ? __builtin_bit_cast(float, v.w & 0x7fffffffu) : 0.f;
+                            *(__attribute__((address_space(3))) mm_f32x4 *)(__UINTPTR_TYPE__)dsta = w;
+                            pend = false;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
+                        if (__builtin_amdgcn_s_memrealtime() - tstart > MM_SPLIT_TIMEOUT) {
+                            cdead = true;  // the team is not running together: the exact kernels compute these utterances
+                            if (lane == 0) {
+                                *redo0 = 2;
+                                *redo1 = 2;
+                            }
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+            }
             MM_STAMP(0);
             MM_STEP_SYNC();
             MM_STAMP(1);

@@ -809,7 +809,10 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 dma_partner(t + 2);
                 MM_STAMP(5);
                 // gamma of step t - 2: its per-pdf sums were completed in the previous step
-                if (t - 2 > t0) frames_of_step(t - 2, L::PSUM(WR));
+                // (split kernels: by the exchange wave, which has nothing else to do since the compute waves receive the rows --
+                // this wave was the longest actor of phase B, and the other sets' partial sums are a memory round trip each)
+                if constexpr (H == 1)
+                    if (t - 2 > t0) frames_of_step(t - 2, L::PSUM(WR));
                 MM_STAMP(6);
                 // the partner vector of step t + 1 (requested at step t - 1) must be in LDS when the compute waves leave the barrier
                 if constexpr (small_graph) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA_SMALL) : "memory");
@@ -850,9 +853,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             for (int k = 1; k >= 0; --k) {
                 const int t = t1 - k;
                 if (k == 0) __syncthreads();  // (a)
-                if (t > t0) frames_of_step(t, L::PSUM(t & 1));
+                if (H == 1 && t > t0) frames_of_step(t, L::PSUM(t & 1));
             }
-            if (sl == 0) {
+            if (H == 1 && sl == 0) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     if (U[u].valid) {
@@ -895,6 +898,38 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         }
         __syncthreads();  // (2)
         constexpr int NG2 = (RSH / 16 + 63) / 64;
+        // posteriors and per-frame log Z of step ts (phase B; the service wave's frames_of_step for H = 1)
+        double xzmin[2] = {__builtin_inf(), __builtin_inf()}, xzmax[2] = {-__builtin_inf(), -__builtin_inf()};
+        float xltmin[2] = {__builtin_inff(), __builtin_inff()};
+        auto xframes = [&](int ts, unsigned psum) {
+            const int f = frame_of(ts);
+            const bool live0 = f >= 1 && f <= U[0].len, live1 = f >= 1 && f <= U[1].len;
+            float lt[2];
+            const float *xp[H];
+#pragma unroll
+            for (int g = 0; g < H; ++g) xp[g] = g != hset ? xps_recv[g] + (ts & 3) * 512 : nullptr;
+            const bool writer = hset == 0;  // (every workgroup of a team has the sums of all pdfs: the first stores gamma)
+            if (!pair_finish_frames<NJ, H>(psum, P1, P, lane, p.gamma + (long long)U[0].b * p.gsb + (long long)(f - 1) * p.gsn,
+                                           p.gamma + (long long)U[1].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp,
+                                           live0 && U[0].valid && writer, live1 && U[1].valid && writer, lt, xp, split_tag(ts, t0, 2),
+                                           dead ? 0ull : MM_SPLIT_TIMEOUT)) {
+                if (lane == 0) {
+                    *redo0 = 2;  // (the team is not running together: the exact kernels compute these utterances)
+                    *redo1 = 2;
+                }
+                dead = true;  // ... and nothing is waited for any more
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (u ? live1 : live0) {
+                    const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN(ts & 3) + 8u * u);
+                    const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 512u * (ts & 7));
+                    const double z = (double)lt[u] + own + oth;
+                    xzmin[u] = z < xzmin[u] ? z : xzmin[u];
+                    xzmax[u] = z > xzmax[u] ? z : xzmax[u];
+                    xltmin[u] = lt[u] < xltmin[u] ? lt[u] : xltmin[u];
+                }
+        };
         MM_STAMP_RESET;
 #ifndef MM_SPLIT_CWPOLL
 #define MM_SPLIT_CWPOLL 1
@@ -957,11 +992,29 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                     }
                 }
             }
+            if constexpr (PHASE == 1)
+                if (t - 2 > t0) xframes(t - 2, L::PSUM(t & 1));
             MM_STAMP(0);
             MM_STEP_SYNC();
             MM_STAMP(1);
         }
-        if constexpr (PHASE == 1) __syncthreads();  // (a)
+        if constexpr (PHASE == 1) {
+            // the last two steps' posteriors: (a) sums of step t1 by the compute waves, gamma of step t1 - 1 here; (b) gamma of step t1
+            for (int k = 1; k >= 0; --k) {
+                const int t = t1 - k;
+                if (k == 0) __syncthreads();  // (a)
+                if (t > t0) xframes(t, L::PSUM(t & 1));
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (U[u].valid) {
+                        p.pair_zmin[(long long)U[u].b * 6 + DIR] = xzmin[u];
+                        p.pair_zmin[(long long)U[u].b * 6 + 2 + DIR] = xzmax[u];
+                        p.pair_zmin[(long long)U[u].b * 6 + 4 + DIR] = (double)xltmin[u];
+                    }
+            }
+        }
     } else {
         // ================= compute waves =================
         __syncthreads();  // (1)

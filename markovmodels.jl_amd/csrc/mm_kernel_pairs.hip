@@ -69,10 +69,13 @@ inline size_t pair_lds_bytes(int RS, int phase, int nslotrows, int RSH = 0) {
 // rows of set h (mm_rows.h make_rows_split) and the team exchanges its rows once per step through global memory:
 //   * every finish also stores the pair of linear values of its row as ONE 8-byte write-through (sc1) store -- a granule
 //     whose data is its own flag: the sign bits carry the step's tag (linear values are >= 0; exp2(-inf) = +0 becomes -0);
-//   * the EXCHANGE wave of a workgroup (one more service wave) polls the other sets' slots with sc1 loads until every
-//     granule carries the tag of the step, strips the signs and writes the values into the workgroup's own LDS vector; the
-//     step's barrier then releases the compute waves with the complete vector.  No flags, no fences, no ordering between
-//     the stores (cdna_hip_programming.md guideline 16, form R2);
+//   * the receiving workgroup polls the other sets' slots with sc1 loads until every granule carries the tag of the step,
+//     strips the signs and writes the values into its own LDS vector; the step's barrier then releases the compute waves
+//     with the complete vector.  No flags, no fences, no ordering between the stores (cdna_hip_programming.md guideline
+//     16, form R2).  WHO polls: the compute waves, one chunk of 128 granules per wave, after their own arcs (MM_SPLIT_CWPOLL;
+//     an exchange wave sweeping all chunks was the longest wave of every step).  The EXCHANGE wave (one more service wave)
+//     finds out at the start of a launch whether the team shares an XCD, and in phase B puts out the posteriors of a frame
+//     (the other sets' partial pdf sums are a memory round trip it has the time for);
 //   * slots alternate by the parity of the step, the tag flips with every reuse of a slot: a slot still holding the step
 //     before last shows the other tag.  A workgroup cannot be more than one step ahead of its team (it needs the others'
 //     rows of every step), so two slots suffice.  The buffers are zeroed before every call (tag 0, first tag used: 1);

@@ -1158,6 +1158,58 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 constexpr int NG2 = (RSH / 16 + 63) / 64, I = (H - 1) * NG2;
                 typedef unsigned mm_u32x4 __attribute__((ext_vector_type(4)));
                 const unsigned tg = split_tag(t, t0, 1);
+                if constexpr (H > 2) {
+                    // (teams of 4: 27 chunks on 14 waves -- a wave's two chunks are polled together, both loads in flight: one
+                    // after the other, the second cost another round trip behind the first)
+                    static_assert(2 * 14 >= I, "two items per wave");
+                    const float *srcs[2];
+                    unsigned offs2[2], dst2[2];
+                    bool pnd[2], sec[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int i = wave + e * NWC, ic = i < I ? i : 0;
+                        const int q = ic / NG2, j = ic % NG2, g = q < hset ? q : q + 1;
+                        srcs[e] = xrecv[g] + (long long)(t & 1) * p.x_slot;
+                        const int ng = p.sp_cnt[g];
+                        dst2[e] = L::PP(WR) + 8u * (unsigned)p.sp_base[g] + 16u * (unsigned)(lane + 64 * j);
+                        pnd[e] = i < I && 2 * (lane + 64 * j) < ng;
+                        sec[e] = 2 * (lane + 64 * j) + 1 < ng;
+                        offs2[e] = pnd[e] ? 16u * (unsigned)(lane + 64 * j) : 0u;
+                    }
+                    if (!cdead && __builtin_amdgcn_ballot_w64(pnd[0] || pnd[1]) != 0ull) {
+                        const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
+                        for (;;) {
+                            mm_u32x4 v0, v1;
+                            asm volatile("global_load_dwordx4 %0, %2, %3 sc1\n\tglobal_load_dwordx4 %1, %4, %5 sc1\n\ts_waitcnt vmcnt(0)"
+                                         : "=&v"(v0), "=&v"(v1)
+                                         : "v"(offs2[0]), "s"(srcs[0]), "v"(offs2[1]), "s"(srcs[1])
+                                         : "memory");
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const mm_u32x4 v = e ? v1 : v0;
+                                if (pnd[e] && (v.x >> 31) == tg && (!sec[e] || (v.z >> 31) == tg)) {
+                                    mm_f32x4 w;
+                                    w.x = __builtin_bit_cast(float, v.x & 0x7fffffffu);
+                                    w.y = __builtin_bit_cast(float, v.y & 0x7fffffffu);
+                                    w.z = sec[e] ? __builtin_bit_cast(float, v.z & 0x7fffffffu) : 0.f;
+                                    w.w = sec[e] ? __builtin_bit_cast(float, v.w & 0x7fffffffu) : 0.f;
+                                    *(__attribute__((address_space(3))) mm_f32x4 *)(__UINTPTR_TYPE__)dst2[e] = w;
+                                    pnd[e] = false;
+                                }
+                            }
+                            if (__builtin_amdgcn_ballot_w64(pnd[0] || pnd[1]) == 0ull) break;
+                            if (__builtin_amdgcn_s_memrealtime() - tstart > MM_SPLIT_TIMEOUT) {
+                                cdead = true;
+                                if (lane == 0) {
+                                    *redo0 = 2;
+                                    *redo1 = 2;
+                                }
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                } else
                 for (int i = wave; i < I; i += NWC) {
                     const int q = i / NG2, j = i % NG2, g = q < hset ? q : q + 1;
                     const float *src = xrecv[g] + (long long)(t & 1) * p.x_slot;

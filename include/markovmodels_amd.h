@@ -119,9 +119,9 @@ size_t mm_batch_workspace_bytes(mm_batch_t batch, int64_t N);
  * (the reference yields NaN: src/inference.jl:158; guarded only in the dead
  * code at :198-200). */
 /* Streams: the call is asynchronous on `stream`.  Some batches run two kernels side by side (the forward and the backward
- * agents of the pair kernels): they fork from `stream` into ONE pair of library-owned streams per process and device and
- * join back into it -- two batches driven from two caller streams therefore take turns on that pair (ordering stays
- * correct; independent calls on different streams do not overlap each other on these batches). */
+ * agents of the pair kernels): they fork from `stream` into a pair of library-owned streams and join back into it.  Every
+ * batch that is alive has a pair of its own (probed once for really running side by side, reused after mm_batch_destroy):
+ * two batches driven from two caller streams do not wait for each other. */
 int mm_pdfposteriors_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t v_stride_n,
                          const int32_t *lens, int64_t N, float *gamma, int64_t g_stride_b, int64_t g_stride_n,
                          int64_t g_stride_p, float *ttl, void *stream);

@@ -225,8 +225,8 @@ struct mm_batch_s {
     int wave_nseg = 0;
     int pair_H = 1;        // workgroups per team: 1 = the pair kernels proper, > 1 = the split pair kernels
     int split_s1p = 0;     // floats / 2 of a stored vector of the split kernels (positions of the team's vector, padded)
-    // the forward and the backward agents of the pair kernels run side by side on two streams of the library (a
-    // process-wide pair that was SEEN to run kernels concurrently, concurrent_streams()); the caller's stream forks into
+    // the forward and the backward agents of the pair kernels run side by side on two streams of the library (a pair of
+    // this batch's own that was SEEN to run kernels concurrently, acquire_stream_pair()); the caller's stream forks into
     // them and joins them
     hipStream_t side[2] = {nullptr, nullptr};
     bool deterministic = false;  // mm_batch_set_deterministic(): no float atomics in the item kernel
@@ -411,47 +411,73 @@ __global__ void mm_probe_wait_kernel(int *flag, int *seen) {
 }
 __global__ void mm_probe_set_kernel(int *flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-static bool concurrent_streams(int device, hipStream_t out[2]) {
-    struct Pair {
-        hipStream_t s[2] = {nullptr, nullptr};
-        bool tried = false;
-    };
-    static std::map<int, Pair> cache;
-    static std::mutex lock;  // (batches may be created from several host threads)
-    std::lock_guard<std::mutex> guard(lock);
-    Pair &pr = cache[device];
-    if (!pr.tried) {
-        pr.tried = true;
-        int *dbuf = nullptr;
-        hipStream_t a = nullptr;
-        if (hipMalloc(&dbuf, 2 * sizeof(int)) == hipSuccess && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) == hipSuccess) {
-            std::vector<hipStream_t> rejected;
-            for (int attempt = 0; attempt < 8 && !pr.s[1]; ++attempt) {
-                hipStream_t b = nullptr;
-                if (hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess) break;
-                int seen = 0;
-                bool ok = hipMemset(dbuf, 0, 2 * sizeof(int)) == hipSuccess;
-                if (ok) {
-                    hipLaunchKernelGGL(mm_probe_wait_kernel, dim3(1), dim3(1), 0, a, dbuf, dbuf + 1);
-                    hipLaunchKernelGGL(mm_probe_set_kernel, dim3(1), dim3(1), 0, b, dbuf);
-                    ok = hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess &&
-                         hipMemcpy(&seen, dbuf + 1, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
-                }
-                if (ok && seen) {
-                    pr.s[0] = a;
-                    pr.s[1] = b;
-                } else {
-                    rejected.push_back(b);  // (kept until the search ends: a destroyed stream's queue slot would be handed out again)
-                }
+static bool probe_stream_pair(hipStream_t s[2]) {
+    s[0] = s[1] = nullptr;
+    int *dbuf = nullptr;
+    hipStream_t a = nullptr;
+    if (hipMalloc(&dbuf, 2 * sizeof(int)) == hipSuccess && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) == hipSuccess) {
+        std::vector<hipStream_t> rejected;
+        for (int attempt = 0; attempt < 8 && !s[1]; ++attempt) {
+            hipStream_t b = nullptr;
+            if (hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess) break;
+            int seen = 0;
+            bool ok = hipMemset(dbuf, 0, 2 * sizeof(int)) == hipSuccess;
+            if (ok) {
+                hipLaunchKernelGGL(mm_probe_wait_kernel, dim3(1), dim3(1), 0, a, dbuf, dbuf + 1);
+                hipLaunchKernelGGL(mm_probe_set_kernel, dim3(1), dim3(1), 0, b, dbuf);
+                ok = hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess &&
+                     hipMemcpy(&seen, dbuf + 1, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
             }
-            for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
-            if (!pr.s[1]) pr.s[0] = pr.s[1] = a;  // no concurrent pair: one stream, the agents take turns
+            if (ok && seen) {
+                s[0] = a;
+                s[1] = b;
+            } else {
+                rejected.push_back(b);  // (kept until the search ends: a destroyed stream's queue slot would be handed out again)
+            }
         }
-        if (dbuf) (void)hipFree(dbuf);
+        for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+        if (!s[1]) s[0] = s[1] = a;  // no concurrent pair: one stream, the agents take turns
     }
-    out[0] = pr.s[0];
-    out[1] = pr.s[1];
-    return pr.s[0] != nullptr;
+    if (dbuf) (void)hipFree(dbuf);
+    return s[0] != nullptr;
+}
+
+// A pair of side streams for a batch of the pair kernels: every batch that is alive at the same time has a pair of its
+// own (two batches driven from two caller streams do not take turns on one pair); pairs are probed once and reused when
+// their batch is destroyed.
+namespace {
+struct StreamPair {
+    hipStream_t s[2] = {nullptr, nullptr};
+    int users = 0;
+};
+std::map<int, std::vector<StreamPair>> g_stream_pairs;
+std::mutex g_stream_lock;  // (batches may be created from several host threads)
+}  // namespace
+static bool acquire_stream_pair(int device, hipStream_t out[2]) {
+    std::lock_guard<std::mutex> guard(g_stream_lock);
+    std::vector<StreamPair> &pool = g_stream_pairs[device];
+    for (StreamPair &sp : pool)
+        if (sp.users == 0) {
+            sp.users = 1;
+            out[0] = sp.s[0];
+            out[1] = sp.s[1];
+            return true;
+        }
+    StreamPair sp;
+    if (!probe_stream_pair(sp.s)) return false;
+    sp.users = 1;
+    pool.push_back(sp);
+    out[0] = sp.s[0];
+    out[1] = sp.s[1];
+    return true;
+}
+static void release_stream_pair(int device, hipStream_t s0, hipStream_t s1) {
+    std::lock_guard<std::mutex> guard(g_stream_lock);
+    for (StreamPair &sp : g_stream_pairs[device])
+        if (sp.s[0] == s0 && sp.s[1] == s1 && sp.users > 0) {
+            sp.users = 0;
+            return;
+        }
 }
 
 namespace {
@@ -1710,7 +1736,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         }
     }
     if (h->pairs_ok) {
-        bool good = concurrent_streams(h->device, h->side);
+        bool good = acquire_stream_pair(h->device, h->side);
         for (int i = 0; i < 5 && good; ++i) good = hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming) == hipSuccess;
         if (!good) h->pairs_ok = false;
     }
@@ -1741,6 +1767,7 @@ int mm_debug_read_stamps(unsigned long long *out, int64_t n) {
 
 int mm_batch_destroy(mm_batch_t h) {
     if (!h) return MM_OK;
+    if (h->side[0]) release_stream_pair(h->device, h->side[0], h->side[1]);
     for (hipEvent_t e : h->ev)
         if (e) (void)hipEventDestroy(e);
     if (h->d_utts) (void)hipFree(h->d_utts);

@@ -385,3 +385,31 @@ print("OK-DIST")
 """.replace("ROOT", repr(root))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK-DIST" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_two_batches_alive_have_their_own_side_streams(mm, wl, oracle, torch):
+    """Two batches of the pair kernels alive at the same time, driven from two streams of the caller: each forks into a
+    pair of side streams of its own (a pool per device); same results as one after the other, and a destroyed batch's
+    pair is reused."""
+    g = wl.lfmmi_denominator(600, 40, seed=5)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    B, N = 6, 80
+    V = [torch.randn(B, N, g.P, device="cuda") for _ in range(2)]
+    bfs = [mm.batch(*([cf] * B)) for _ in range(2)]
+    assert all("mm_fbp_kernel_dir" in bf.kernels() and "no concurrent stream pair" not in bf.kernels() for bf in bfs)
+    ref = [bf.pdfposteriors(v) for bf, v in zip(bfs, V)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    out = []
+    for _ in range(3):
+        out = []
+        for bf, v, s in zip(bfs, V, streams):
+            with torch.cuda.stream(s):
+                out.append(bf.pdfposteriors(v))
+    torch.cuda.synchronize()
+    for (g0, t0), (g1, t1) in zip(ref, out):
+        assert torch.equal(g0, g1) and torch.equal(t0, t1)
+    del bfs
+    bf3 = mm.batch(*([cf] * B))
+    g3, t3 = bf3.pdfposteriors(V[0])
+    assert torch.equal(g3, ref[0][0])

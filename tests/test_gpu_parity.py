@@ -409,6 +409,55 @@ def test_call_is_capturable_in_a_hip_graph(mm, wl, torch):
     assert torch.equal(gamma, g0) and torch.equal(t0, t1)
 
 
+@pytest.mark.parametrize("kind", ["split", "wave", "viterbi"])
+def test_other_kernel_families_are_capturable(mm, wl, torch, kind):
+    """The same for the kernels the test above does not reach: the teams of the split pair kernels (their exchange buffers
+    are zeroed by a memset node before every replay), the wave kernel on a batch of different graphs, and the Viterbi
+    kernel with its back-trace.  A replay must give the bits of the eager call."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if kind == "split":
+        g = wl.load_npz_graph(os.path.join(here, "den_fsm_wsj.npz"))
+        cfs = [mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))] * 6
+        P, want = g.P, "mm_fbs_kernel_dir"
+    elif kind == "wave":
+        gs = [wl.load_npz_graph(os.path.join(here, "num_fsm_wsj.npz")), wl.lexicon_fsm(300, 20, seed=2, hubs=1), wl.lexicon_fsm(700, 84, seed=5, hubs=2)]
+        P = max(g.P for g in gs)
+        cfs = [mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, P)) for g in gs] * 2
+        want = "mm_wave_kernel"
+    else:
+        g = wl.lexicon_fsm(1500, 60, seed=5, hubs=2)
+        cfs = [mm.compile(wl.to_fsm(mm, g, "tropical"), mm.statemap(g.state2pdf, g.P))] * 6
+        P, want = g.P, "mm_vit_kernel"
+    B, N = len(cfs), 40
+    bf = mm.batch(*cfs)
+    V = torch.randn(B, N, P, device="cuda")
+    lens = torch.tensor([N, N - 3, 5, 1, N, 17], dtype=torch.int32, device="cuda")
+    gamma = torch.empty(B, N, P, device="cuda")
+
+    def call():
+        if kind == "viterbi":
+            return bf.viterbi(V, lens)
+        return bf.pdfposteriors(V, lens, out=gamma)
+
+    a0, b0 = (x.clone() for x in call())
+    assert want in bf.kernels("tropical" if kind == "viterbi" else "log"), bf.kernels()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        call()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        a1, b1 = call()
+    for _ in range(2):
+        a1.zero_()
+        b1.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(a1, a0) and torch.equal(b1, b0)
+    if kind != "viterbi":
+        assert bf.last_redo_count() == 0
+
+
 def test_tropical_beta_and_maxstateposteriors(mm, wl, oracle, torch):
     """beta-recursion with K = TropicalSemiring (src/inference.jl:99-110) and the max-marginals mu = alpha (*) beta
     (/) best (maxstateposteriors, docs/src/inference.md:5): against the NumPy oracle's generic recursions, and

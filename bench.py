@@ -38,12 +38,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 
 
 def make_workload(wl, name):
     """(graph, frames, utterances per GPU, semiring).  lfmmi_den = BASELINE.json configs[2] (the metric's
-    configuration); lexicon5000 = configs[4] (Viterbi); ergodic64 = configs[1]; wsj_den / wsj_num = the reference's
+    configuration); lexicon5000 = configs[4] (Viterbi); ergodic64 = configs[1]; l2r3 = configs[0]; wsj_den / wsj_num = the reference's
     own benchmark graphs (misc/benchmark/README.md: T = 700, B = 128); lfmmi_den4000 = a 4000-state graph of config 3's family."""
     if name == "lfmmi_den":
         return wl.lfmmi_denominator(2000, 84, seed=0), 1500, 256, "log"
     if name == "ergodic64":
         return wl.dense_ergodic(64, seed=0), 500, 32, "log"
+    if name == "l2r3":  # configs[0]: the reference's CPU-runnable plumbing case (one utterance: a latency, not a throughput)
+        return wl.l2r_hmm(3), 100, 1, "log"
     if name == "wsj_den":
         return wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "den_fsm_wsj.npz")), 700, 128, "log"
     if name == "wsj_num":

@@ -1529,10 +1529,73 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             h->max_xcsr = std::max<int64_t>(h->max_xcsr, fsms[b]->S1 + 1 + 2 * std::max(fsms[b]->qmat[0].rowptr[fsms[b]->S1],
                                                                                   fsms[b]->qmat[1].rowptr[fsms[b]->S1]));
     }
+    // The wave forms of every FSM of the batch (packed on the host's cores for the FSMs that are new): h->wave_ok, h->wave_nseg.
+    auto try_wave = [&]() -> int {
+        h->wave_ok = true;
+        {   // pack the forms of the FSMs that are new, on the host's cores
+            std::vector<mm_fsm_t> todo;
+            for (int64_t b = 0; b < B; ++b)
+                if (!fsms[b]->wrows[0] && !fsms[b]->wave_tried && !fsms[b]->wave_packed &&
+                    std::find(todo.begin(), todo.end(), fsms[b]) == todo.end())
+                    todo.push_back(fsms[b]);
+            const size_t nthr = std::min<size_t>({todo.size() / 4, size_t(std::max(1u, std::thread::hardware_concurrency())), size_t(16)});
+            if (nthr > 1) {
+                std::atomic<size_t> next{0};
+                std::vector<std::thread> pool;
+                for (size_t t = 0; t < nthr; ++t)
+                    pool.emplace_back([&]() {
+                        // (an exception must not leave a thread: an FSM whose packing failed is packed again, and fails
+                        // again, on the calling thread -- wave_variants below)
+                        for (size_t i = next.fetch_add(1); i < todo.size(); i = next.fetch_add(1)) {
+                            try {
+                                wave_pack(todo[i]);
+                            } catch (...) {
+                                todo[i]->wave_packed = false;
+                            }
+                        }
+                    });
+                for (std::thread &t : pool) t.join();
+            }
+        }
+        for (int64_t b = 0; b < B && h->wave_ok; ++b) {
+            bool ok = false;
+            int rc = wave_variants(fsms[b], h->dbg, &ok);
+            if (rc) return rc;
+            h->wave_ok = ok;
+            // (segments of a wave's registers: the state segments, and twice the pdf segments -- the kernel has NSEG / 2 of those)
+            if (ok)
+                h->wave_nseg = std::max({h->wave_nseg, std::max(fsms[b]->wrows[0]->g.KA, fsms[b]->wrows[1]->g.KA) / 4,
+                                         2 * std::max(fsms[b]->wrows[0]->pdf_nps, fsms[b]->wrows[1]->pdf_nps)});
+        }
+        return MM_OK;
+    };
+    // The wave kernel FIRST wherever every graph of the batch fits it (up to 1023 states, 16 segments of 64 lanes x 4 arcs
+    // per direction, 250 pdfs): one workgroup per utterance runs both directions at once in the log domain, without the
+    // marks and the exact second pass of the linear-domain kernels -- measured against the row kernels on batches of
+    // different graphs (1.18 -> 0.72 ms: 128 lexicon graphs of 150..400 states, T = 700) and against the pair kernels on one
+    // shared small graph (0.80 -> 0.47 ms: 300 states, B = 256, T = 500; 3-state HMM, B = 1, T = 100: 0.18 -> 0.06 ms).  The
+    // exception: one shared DENSE graph (more than 16 arcs per state) on a batch of more than two utterances per compute
+    // unit, where the pair kernels' two utterances per workgroup win (32-state ergodic HMM, B = 1024: 1.90 against 2.33 ms).
+    bool wave_first_tried = false;
+    if (h->semiring == MM_LOG && h->dbg.kernel == DebugOpts::K_AUTO) {
+        bool small = h->max_P1 <= 250, same = true;
+        for (int64_t b = 0; b < B && small; ++b)
+            small = fsms[b]->S1 <= 1023 && fsms[b]->qmat[0].rowptr[fsms[b]->S1] <= 16 * 64 * 4;
+        for (int64_t b = 1; b < B && same; ++b) same = fsms[b] == fsms[0];
+        const bool dense_many = same && B > 2 * int64_t(h->n_cus) && fsms[0]->qmat[0].rowptr[fsms[0]->S1] > 16 * fsms[0]->S1;
+        if (small && !dense_many) {
+            wave_first_tried = true;
+            int rc = try_wave();
+            if (rc) {
+                delete h;
+                return rc;
+            }
+        }
+    }
     // row kernels: every FSM of the batch needs its row-lane forms.  Small deep (left-to-right) graphs keep states
     // alive whose values differ by more than the float range within one frame, so most of their rows would take the
     // exact fallback of the linear-domain kernels: they run on the item kernel (unless a kernel is forced).
-    h->rows_ok = h->fast_ok && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD && h->dbg.kernel != DebugOpts::K_WAVE &&
+    h->rows_ok = !h->wave_ok && h->fast_ok && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD && h->dbg.kernel != DebugOpts::K_WAVE &&
                  !(h->max_depth >= 64 && nq_max[0] <= 3 * 1024 && nq_max[1] <= 3 * 1024 && h->dbg.kernel == DebugOpts::K_AUTO);
     for (int64_t b = 0; b < B && h->rows_ok; ++b) {
         bool ok = false;
@@ -1563,7 +1626,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     }
     // split pair kernels: one shared FSM that is too large for the pair kernels proper (more arcs than the registers of a
     // compute unit hold, more states than half its LDS) -- teams of 2 workgroups per utterance pair and direction
-    if (!h->pairs_ok && h->fast_ok && B >= 2 && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD &&
+    if (!h->wave_ok && !h->pairs_ok && h->fast_ok && B >= 2 && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD &&
         h->dbg.kernel != DebugOpts::K_ROW && h->dbg.kernel != DebugOpts::K_WAVE &&
         !(h->max_depth >= 64 && nq_max[0] <= 3 * 1024 && nq_max[1] <= 3 * 1024 && h->dbg.kernel == DebugOpts::K_AUTO)) {
         bool same = true;
@@ -1617,49 +1680,16 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             }
         }
     }
-    // wave kernel: small graphs that none of the linear-domain kernels takes (deep left-to-right graphs: numerators)
-    if (h->semiring == MM_LOG && !h->rows_ok && !h->pairs_ok &&
+    // wave kernel, the other case: small graphs that none of the linear-domain kernels takes (deep left-to-right graphs:
+    // numerators), or the kernel is asked for by name
+    if (h->semiring == MM_LOG && !h->wave_ok && !wave_first_tried && !h->rows_ok && !h->pairs_ok &&
         (h->dbg.kernel == DebugOpts::K_WAVE ||
          (h->dbg.kernel == DebugOpts::K_AUTO && (!h->fast_ok || (h->max_depth >= 64 && h->geo_kq[0] <= 3 && h->geo_kq[1] <= 3))))) {
         // (= where the item kernel would run: quad_kernel_usable() says no for these; see there)
-        h->wave_ok = true;
-        {   // pack the forms of the FSMs that are new, on the host's cores
-            std::vector<mm_fsm_t> todo;
-            for (int64_t b = 0; b < B; ++b)
-                if (!fsms[b]->wrows[0] && !fsms[b]->wave_tried && !fsms[b]->wave_packed &&
-                    std::find(todo.begin(), todo.end(), fsms[b]) == todo.end())
-                    todo.push_back(fsms[b]);
-            const size_t nthr = std::min<size_t>({todo.size() / 4, size_t(std::max(1u, std::thread::hardware_concurrency())), size_t(16)});
-            if (nthr > 1) {
-                std::atomic<size_t> next{0};
-                std::vector<std::thread> pool;
-                for (size_t t = 0; t < nthr; ++t)
-                    pool.emplace_back([&]() {
-                        // (an exception must not leave a thread: an FSM whose packing failed is packed again, and fails
-                        // again, on the calling thread -- wave_variants below)
-                        for (size_t i = next.fetch_add(1); i < todo.size(); i = next.fetch_add(1)) {
-                            try {
-                                wave_pack(todo[i]);
-                            } catch (...) {
-                                todo[i]->wave_packed = false;
-                            }
-                        }
-                    });
-                for (std::thread &t : pool) t.join();
-            }
-        }
-        for (int64_t b = 0; b < B && h->wave_ok; ++b) {
-            bool ok = false;
-            int rc = wave_variants(fsms[b], h->dbg, &ok);
-            if (rc) {
-                delete h;
-                return rc;
-            }
-            h->wave_ok = ok;
-            // (segments of a wave's registers: the state segments, and twice the pdf segments -- the kernel has NSEG / 2 of those)
-            if (ok)
-                h->wave_nseg = std::max({h->wave_nseg, std::max(fsms[b]->wrows[0]->g.KA, fsms[b]->wrows[1]->g.KA) / 4,
-                                         2 * std::max(fsms[b]->wrows[0]->pdf_nps, fsms[b]->wrows[1]->pdf_nps)});
+        int rc = try_wave();
+        if (rc) {
+            delete h;
+            return rc;
         }
     }
     for (int64_t b = 0; b < B; ++b) {

@@ -279,7 +279,8 @@ def test_row_kernel_register_windows(mm, wl, oracle, torch, S, deg):
         gam, ttl = bf.pdfposteriors(V, lens)
         return gam, ttl, bf.kernels(), bf.last_redo_count()
 
-    gam, ttl, kernels, redo = _with_env({"MM_DEBUG": "1", "MM_NO_REDO": "1"}, run)
+    # (forced: the graphs of 300 states fit the wave kernel, which the engine prefers)
+    gam, ttl, kernels, redo = _with_env({"MM_DEBUG": "1", "MM_NO_REDO": "1", "MM_KERNEL": "row"}, run)
     assert "mm_fbr_kernel" in kernels and redo == 0, kernels
     for b, g in enumerate(gs):
         g_ref, t_ref = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V[b : b + 1], lens[b : b + 1], dtype=np.float64)
@@ -304,15 +305,23 @@ def test_odd_batch_beyond_the_compute_units_on_the_pair_kernels(mm, wl, oracle, 
     assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()
 
 
-def test_batch_beyond_the_ordered_limit(mm, wl, oracle, torch):
-    """B = 8200 > 8192: the longest-first order is skipped (mm_engine.hip), the utterances run in batch order."""
+@pytest.mark.parametrize("kernel", ["pair", "auto"])
+def test_batch_beyond_the_ordered_limit(mm, wl, oracle, torch, kernel):
+    """B = 8200 > 8192: the longest-first order is skipped (mm_engine.hip), the utterances run in batch order -- on the pair
+    kernels (forced) and on the engine's own choice for a graph this small, the wave kernel."""
     g = wl.random_fsm(24, 4, 2.5, seed=3)
     rng = np.random.default_rng(2)
     B, N = 8200, 6
     V = rng.standard_normal((B, N, g.P)).astype(np.float32)
     lens = rng.integers(1, N + 1, size=B).astype(np.int32)
-    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
-    gam, ttl = mm.batch(*([cf] * B)).pdfposteriors(V, lens)
+
+    def run():
+        cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+        bf = mm.batch(*([cf] * B))
+        return bf.pdfposteriors(V, lens) + (bf.kernels(),)
+
+    gam, ttl, kernels = _with_env({"MM_DEBUG": "1", "MM_KERNEL": kernel}, run)
+    assert ("mm_fbp_kernel_dir" if kernel == "pair" else "mm_wave_kernel") in kernels, kernels
     g_ref, t_ref = oracle64(oracle, g, V, lens)
     ok = np.isfinite(t_ref)
     check_gamma(gam[ok], g_ref[ok], lens[ok])

@@ -344,7 +344,7 @@ def test_lfmmi_loss_and_gradient(mm, wl, oracle, torch):
         assert np.isclose(fd, g_ref[b, n, p], atol=1e-5)
 
 
-@pytest.mark.parametrize("env", [{"MM_KERNEL": "item"}, {"MM_KERNEL": "quad"}, {"MM_KERNEL": "row"},
+@pytest.mark.parametrize("env", [{"MM_KERNEL": "item"}, {"MM_KERNEL": "quad"}, {"MM_KERNEL": "row"}, {"MM_KERNEL": "pair"},
                                  {"MM_KERNEL": "quad", "MM_KQ": "1"}, {"MM_KERNEL": "quad", "MM_KQ": "2", "MM_NWAVES": "3"},
                                  {"MM_KERNEL": "quad", "MM_KQ": "15"}, {"MM_KERNEL": "quad", "MM_KQ": "7"},
                                  {"MM_KERNEL": "item", "MM_BIGV": "1"}, {"MM_KERNEL": "item", "MM_BIGV": "1", "MM_NITEMS": "0"}])
@@ -388,9 +388,11 @@ def test_call_is_capturable_in_a_hip_graph(mm, wl, torch):
     """Once the workspace has its size a pdfposteriors call only launches kernels on the caller's stream:
     it can be captured in a hipGraph and replayed."""
     g = wl.random_fsm(200, 10, 4.0, seed=4)
-    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
     B, N = 8, 30
-    bf = mm.batch(*([cf] * B))
+    # (the pair kernels, with their fork to the side streams: forced -- the engine prefers the wave kernel for a graph this small)
+    bf = _with_env({"MM_DEBUG": "1", "MM_KERNEL": "pair"},
+                   lambda: mm.batch(*([mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))] * B)))
+    assert "mm_fbp_kernel_dir" in bf.kernels(), bf.kernels()
     V = torch.randn(B, N, g.P, device="cuda")
     lens = torch.tensor([N, N - 3, 5, 1, N, 0, 17, N], dtype=torch.int32, device="cuda")
     gamma = torch.empty(B, N, g.P, device="cuda")
@@ -603,6 +605,39 @@ def test_wave_kernel_is_the_numerator_path_and_deterministic(mm, wl, oracle, tor
 
 
 @pytest.mark.gpu
+def test_wave_kernel_first_wherever_the_graphs_fit(mm, wl, oracle, torch):
+    """The engine's choice (mm_batch_create): every graph of the batch within the wave form (up to 1023 states, 4096 arc
+    slots, 250 pdfs) -> the wave kernel, for one shared graph as for different ones and for a single utterance; one shared
+    DENSE graph on more than two utterances per compute unit -> the pair kernels; a graph beyond the form -> as before.
+    Results against the oracle in every case."""
+    o, oc = oracle
+    rng = np.random.default_rng(31)
+    cases = [("shared lexicon", [wl.lexicon_fsm(300, 20, seed=2, hubs=1)] * 5, "mm_wave_kernel"),
+             ("different random graphs", [wl.random_fsm(60 + 40 * b, 12, 3.0, seed=b) for b in range(5)], "mm_wave_kernel"),
+             ("one utterance", [wl.l2r_hmm(3)], "mm_wave_kernel"),
+             ("dense, small batch", [wl.dense_ergodic(20, seed=3)] * 4, "mm_wave_kernel"),
+             ("dense, many utterances", [wl.dense_ergodic(20, seed=3)] * 520, "mm_fbp_kernel_dir"),
+             ("more arcs than the form holds", [wl.lfmmi_denominator(400, 20, seed=9)] * 4, "mm_fbp_kernel_dir")]
+    for name, gs, want in cases:
+        B, N = len(gs), 23
+        P = max(g.P for g in gs)
+        uniq = {}
+        for g in gs:
+            if id(g) not in uniq:
+                uniq[id(g)] = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, P))
+        bf = mm.batch(*[uniq[id(g)] for g in gs])
+        assert want in bf.kernels(), (name, bf.kernels())
+        V = rng.standard_normal((B, N, P)).astype(np.float32)
+        lens = rng.integers(1, N + 1, B).astype(np.int32)
+        gam, ttl = bf.pdfposteriors(V, lens)
+        for b in sorted({0, B // 2, B - 1}):
+            g = gs[b]
+            g_ref, t_ref = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V[b : b + 1, :, : g.P], lens[b : b + 1], dtype=np.float64)
+            if np.isfinite(t_ref[0]):
+                check_gamma(gam[b : b + 1, :, : g.P], g_ref, lens[b : b + 1])
+                assert np.allclose(ttl[b], t_ref[0], rtol=1e-5, atol=1e-4), name
+
+
 @pytest.mark.parametrize("S,P", [(900, 7), (850, 120), (300, 3), (64, 200)])
 def test_wave_kernel_pdf_segments(mm, wl, oracle, torch, S, P):
     """The per-pdf sums of the wave kernel are packed segments of their own (mm_engine.hip wave_pdf_table): a pdf with n

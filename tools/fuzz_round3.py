@@ -81,15 +81,17 @@ def fuzz_split(rng):
 
 
 def fuzz_wave(rng):
-    bad = n = 0
+    bad = n = nwave = 0
     num = wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "num_fsm_wsj.npz"))
     for trial in range(6):
         B = int(rng.choice([1, 2, 3, 7, 33, 130]))
         gs = []
         for b in range(min(B, 6)):
-            k = rng.integers(0, 4)
+            k = rng.integers(0, 7)
             gs.append(num if k == 0 else wl.lexicon_fsm(int(rng.integers(40, 900)), int(rng.integers(5, 200)), seed=int(rng.integers(1 << 30)), hubs=int(rng.integers(1, 3)))
-                      if k < 3 else wl.l2r_hmm(int(rng.integers(3, 60))))
+                      if k < 3 else wl.l2r_hmm(int(rng.integers(3, 60))) if k == 3
+                      else wl.random_fsm(int(rng.integers(5, 400)), int(rng.integers(2, 60)), float(rng.uniform(1.5, 5.0)), seed=int(rng.integers(1 << 30))) if k < 6
+                      else wl.dense_ergodic(int(rng.integers(2, 33)), seed=int(rng.integers(1 << 30))))
         Pm = max(g.P for g in gs)
         cfs = [mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, Pm)) for g in gs]
         cfs = [cfs[b % len(cfs)] for b in range(B)]
@@ -104,9 +106,11 @@ def fuzz_wave(rng):
             et, eg = posterior_error(a_g, a_t, ref_g, ref_t)
             same = np.array_equal(g2.cpu().numpy(), a_g.astype(np.float32)) and np.array_equal(t2.cpu().numpy(), a_t.astype(np.float32))
             ok = np.isfinite(et) and np.isfinite(eg) and et < 1e-4 and eg < 1e-4 and same
+            nwave += "mm_wave_kernel" in names
             if not ok:
                 bad += 1
                 print(f"MISMATCH wave trial {trial} B {B} N {N} lens {lens.tolist()[:12]} ({names[:50]}): ttl {et:.2e} gamma {eg:.2e} same bits {same}")
+    print(f"  ({nwave} of the {n} batches fitted the wave kernel)")
     return n, bad
 
 

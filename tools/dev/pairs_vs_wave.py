@@ -26,11 +26,15 @@ def run(g, B, N, force):
 
 fam = {"l2r 3": wl.l2r_hmm(3), "l2r 30": wl.l2r_hmm(30), "lexicon 300": wl.lexicon_fsm(300, 40, seed=1, hubs=2),
        "lexicon 900": wl.lexicon_fsm(900, 84, seed=2, hubs=2), "random 300 deg 4": wl.random_fsm(300, 40, 4.0, seed=3),
-       "random 120 deg 6": wl.random_fsm(120, 30, 6.0, seed=4), "ergodic 16": wl.dense_ergodic(16, seed=1), "ergodic 32": wl.dense_ergodic(32, seed=1)}
+       "random 120 deg 6": wl.random_fsm(120, 30, 6.0, seed=4), "ergodic 16": wl.dense_ergodic(16, seed=1), "ergodic 32": wl.dense_ergodic(32, seed=1),
+       "lfmmi 250 (16 arcs per state)": wl.lfmmi_denominator(250, 40, seed=2), "random 400 deg 9": wl.random_fsm(400, 40, 9.0, seed=5)}
+only = os.environ.get("ONLY")
 for name, g in fam.items():
-    for B in (32, 256, 1024):
+    if only and only not in name:
+        continue
+    for B in (32, 256, 512, 1024):
         res = []
-        for force in (None, "wave"):
+        for force in ("pair", None, "wave"):
             try:
                 res.append("%s %.3f ms (%s, redo %d)" % (((force or "auto"),) + run(g, B, 500, force)))
             except Exception as e:

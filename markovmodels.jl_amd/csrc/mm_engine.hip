@@ -1574,8 +1574,9 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     // marks and the exact second pass of the linear-domain kernels -- measured against the row kernels on batches of
     // different graphs (1.18 -> 0.72 ms: 128 lexicon graphs of 150..400 states, T = 700) and against the pair kernels on one
     // shared small graph (0.80 -> 0.47 ms: 300 states, B = 256, T = 500; 3-state HMM, B = 1, T = 100: 0.18 -> 0.06 ms).  The
-    // exception: one shared DENSE graph (more than 16 arcs per state) on a batch of more than two utterances per compute
-    // unit, where the pair kernels' two utterances per workgroup win (32-state ergodic HMM, B = 1024: 1.90 against 2.33 ms).
+    // exception: one shared DENSE graph (more than 16 arcs per state, more than 2 segments per wave) on a batch of more than
+    // two utterances per compute unit, where the pair kernels' two utterances per workgroup win (32-state ergodic HMM,
+    // B = 1024: 1.90 against 2.33 ms).
     bool wave_first_tried = false;
     if (h->semiring == MM_LOG && h->dbg.kernel == DebugOpts::K_AUTO) {
         bool small = h->max_P1 <= 250, same = true;
@@ -1583,13 +1584,17 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             small = fsms[b]->S1 <= 1023 && fsms[b]->qmat[0].rowptr[fsms[b]->S1] <= 16 * 64 * 4;
         for (int64_t b = 1; b < B && same; ++b) same = fsms[b] == fsms[0];
         const bool dense_many = same && B > 2 * int64_t(h->n_cus) && fsms[0]->qmat[0].rowptr[fsms[0]->S1] > 16 * fsms[0]->S1;
-        if (small && !dense_many) {
+        if (small) {
             wave_first_tried = true;
             int rc = try_wave();
             if (rc) {
                 delete h;
                 return rc;
             }
+            // (the exception; the forms stay with the FSM.  Graphs of up to 2 segments per wave run the kernel instance of
+            // which two workgroups fit a compute unit and win at every batch size: 16-state ergodic HMM, B = 1024: 1.18
+            // against 1.88 ms)
+            if (h->wave_ok && dense_many && h->wave_nseg > 2) h->wave_ok = false;
         }
     }
     // row kernels: every FSM of the batch needs its row-lane forms.  Small deep (left-to-right) graphs keep states
@@ -1870,7 +1875,8 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
                                              std::to_string(h->geo_kq[1]) + ",*,1>"
                                        : std::string("mm_log_kernel<MODE_FB> (forward, backward)");
         if (h->wave_ok) {
-            s = "mm_wave_kernel<" + std::to_string(h->wave_nseg <= 2 ? 2 : 4) + "," + std::to_string(h->max_P1 <= 128 ? 2 : 4) + ">";
+            s = "mm_wave_kernel<" + std::to_string(h->wave_nseg <= 2 ? 2 : 4) + "," + std::to_string(h->max_P1 <= 128 ? 2 : 4) +
+                (h->wave_nseg <= 2 && h->B > h->n_cus ? ",two per CU>" : ">");
         } else if (h->pairs_ok && h->pair_H > 1) {
             const std::string k = std::to_string(h->max_P1 <= 128 ? 2 : 4);
             s = "mm_fbs_kernel_dir<" + k + ",A,fwd> || <" + k + ",A,bwd>, then <" + k + ",B,fwd> || <" + k +
@@ -2026,6 +2032,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
         wlc.B = h->B;
         wlc.nseg = h->wave_nseg;
         wlc.max_P1 = h->max_P1;
+        wlc.n_cus = h->n_cus;
         return mm_launch_wave(wlc, p, static_cast<hipStream_t>(stream));
     }
     if (h->rows_ok || h->pairs_ok) {

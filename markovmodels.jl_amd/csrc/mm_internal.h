@@ -74,7 +74,7 @@ size_t mm_split_lds_bytes(int H, int phase, int nslotrows);
 #define MM_WAVE_WAVES 4  // waves per agent (direction) of the wave kernel
 struct WaveLaunch {
     int64_t B = 0;
-    int nseg = 0, max_P1 = 0;
+    int nseg = 0, max_P1 = 0, n_cus = 256;
 };
 int mm_launch_wave(const WaveLaunch &wl, const RunParams &p, hipStream_t stream);
 

@@ -66,8 +66,16 @@ __device__ __forceinline__ float wave_sum_fixed(float v) {  // the same tree in 
     return (r0 + r1) + (r2 + r3);
 }
 
-template <int NSEG, int NJ>  // NSEG: segments the registers of a wave hold; NJ * 64 >= P + 1
-__global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 3)) mm_wave_kernel(RunParams p) {
+// (TWO, NSEG = 2 only: 8 waves per SIMD -- at most 64 VGPRs and 96 SGPRs -- so that two workgroups of 14 waves fit a compute unit
+// (4 + 4 + 3 + 3 waves per SIMD each): with the 106 SGPRs the compiler took by itself the second workgroup of a compute
+// unit waited for the first, whatever hipOccupancyMaxActiveBlocksPerMultiprocessor says, and a batch of 512 utterances
+// took twice the time of 256 -- tools/dev/resident_test.hip)
+// TWO: the instance for batches of more utterances than compute units; the 41 spilled SGPRs cost a batch that has a
+// compute unit per utterance 6 % (the WSJ numerators, B = 128: 0.456 against 0.432 ms), two workgroups per compute unit
+// give B = 512 0.45 instead of 0.58 ms.
+template <int NSEG, int NJ, bool TWO = false>  // NSEG: segments the registers of a wave hold; NJ * 64 >= P + 1
+__global__ void __launch_bounds__(128 * (MM_WAVE_NWD + 3)) __attribute__((amdgpu_waves_per_eu(TWO ? 8 : 4, TWO ? 8 : (NSEG <= 2 ? 7 : 4))))
+mm_wave_kernel(RunParams p) {
     extern __shared__ float lds[];
     constexpr int KA = MM_WAVE_STRIDE * NSEG, NWD = MM_WAVE_NWD, NWA = NWD + 3, NT = 128 * NWA;
     const int lane = threadIdx.x & 63;

@@ -608,7 +608,9 @@ def test_wave_kernel_is_the_numerator_path_and_deterministic(mm, wl, oracle, tor
 def test_wave_kernel_first_wherever_the_graphs_fit(mm, wl, oracle, torch):
     """The engine's choice (mm_batch_create): every graph of the batch within the wave form (up to 1023 states, 4096 arc
     slots, 250 pdfs) -> the wave kernel, for one shared graph as for different ones and for a single utterance; one shared
-    DENSE graph on more than two utterances per compute unit -> the pair kernels; a graph beyond the form -> as before.
+    DENSE graph that needs the 4-segment instance on more than two utterances per compute unit -> the pair kernels (more
+    utterances than compute units on the 2-segment instance: the build of which two workgroups fit a compute unit); a
+    graph beyond the form -> as before.
     Results against the oracle in every case."""
     o, oc = oracle
     rng = np.random.default_rng(31)
@@ -616,7 +618,8 @@ def test_wave_kernel_first_wherever_the_graphs_fit(mm, wl, oracle, torch):
              ("different random graphs", [wl.random_fsm(60 + 40 * b, 12, 3.0, seed=b) for b in range(5)], "mm_wave_kernel"),
              ("one utterance", [wl.l2r_hmm(3)], "mm_wave_kernel"),
              ("dense, small batch", [wl.dense_ergodic(20, seed=3)] * 4, "mm_wave_kernel"),
-             ("dense, many utterances", [wl.dense_ergodic(20, seed=3)] * 520, "mm_fbp_kernel_dir"),
+             ("dense, many utterances, 2 segments per wave", [wl.dense_ergodic(16, seed=3)] * 520, "mm_wave_kernel<2,2,two per CU>"),
+             ("dense, many utterances, 4 segments per wave", [wl.dense_ergodic(32, seed=3)] * 520, "mm_fbp_kernel_dir"),
              ("more arcs than the form holds", [wl.lfmmi_denominator(400, 20, seed=9)] * 4, "mm_fbp_kernel_dir")]
     for name, gs, want in cases:
         B, N = len(gs), 23

@@ -84,7 +84,7 @@ def fuzz_wave(rng):
     bad = n = nwave = 0
     num = wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "num_fsm_wsj.npz"))
     for trial in range(6):
-        B = int(rng.choice([1, 2, 3, 7, 33, 130]))
+        B = int(rng.choice([1, 2, 3, 7, 33, 130, 300, 515]))  # (more than 256: the kernel build of which two workgroups share a compute unit)
         gs = []
         for b in range(min(B, 6)):
             k = rng.integers(0, 7)

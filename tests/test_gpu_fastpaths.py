@@ -246,6 +246,30 @@ def test_graph_beyond_the_fast_paths(mm, wl, oracle, torch, S, P):
     assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("which", ["pair", "split"])
+def test_one_utterance_on_the_pair_kernels(mm, wl, oracle, torch, which):
+    """A batch of ONE utterance runs on the pair / split pair kernels too (the pair computes the utterance twice, the copy
+    writes to a workspace slot only): both directions at once instead of two passes of the row kernels (config 3's graph:
+    4.1 -> 2.6 ms; the WSJ denominator: 6.5 -> 1.7 ms).  Full length, a shorter length, one frame, no frame."""
+    g = wl.lfmmi_denominator(1100, 60, seed=2) if which == "pair" else wsj_den(wl)
+    rng = np.random.default_rng(4)
+    N = 57
+    V = (1.3 * rng.standard_normal((1, N, g.P))).astype(np.float32)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(cf)
+    assert ("mm_fbp_kernel_dir" if which == "pair" else "mm_fbs_kernel_dir") in bf.kernels(), bf.kernels()
+    for L in (N, 31, 1, 0):
+        lens = np.array([L], dtype=np.int32)
+        gam, ttl = bf.pdfposteriors(V, lens)
+        g_ref, t_ref = oracle64(oracle, g, V, lens)
+        if L == 0 or not np.isfinite(t_ref[0]):  # (no frame, or no accepting path of that length: gamma = 0, ttl = zero(K))
+            assert (gam == 0).all() and np.isneginf(ttl).all()
+            continue
+        assert bf.last_redo_count() == 0
+        check_gamma(gam, g_ref, lens)
+        assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)
+
+
 @pytest.mark.parametrize("P", [130, 249])
 def test_pair_kernels_with_many_pdfs(mm, wl, oracle, torch, P):
     """P + 1 in 129..250: the service wave of the pair kernels runs four 64-lane passes over the pdfs

@@ -40,7 +40,7 @@ def main(seed=0):
     for gi, mk in enumerate(graphs):
         g = mk()
         cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
-        for B in (2, 3, 5, 8):
+        for B in (1, 2, 3, 5, 8):
             for N in (1, 2, 3, 4, 7, 40, 101):
                 V = torch.from_numpy((2.0 * rng.standard_normal((B, N, g.P))).astype(np.float32)).cuda()
                 pat = rng.integers(0, 3)

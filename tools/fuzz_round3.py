@@ -65,7 +65,7 @@ def fuzz_split(rng):
     for gi, mk in enumerate(graphs):
         g = mk()
         cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
-        for B, N in ((2, 1), (2, 2), (3, 3), (3, 4), (5, 7), (8, 40), (9, 101), (300, 12), (515, 9)):
+        for B, N in ((1, 1), (1, 6), (1, 61), (2, 1), (2, 2), (3, 3), (3, 4), (5, 7), (8, 40), (9, 101), (300, 12), (515, 9)):
             V = torch.from_numpy((1.5 * rng.standard_normal((B, N, g.P))).astype(np.float32)).cuda()
             lens = lens_pattern(rng, B, N)
             lt = torch.from_numpy(lens).cuda()

@@ -10,7 +10,9 @@ sharded (they are independent: block-diagonal batch) and each step ends with
 the one real exchange of the path, the total-log-likelihood all-reduce (RCCL).
 
     python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus N ...        # N > 1 without a launcher: spawns one rank per GPU itself (self_launch)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    MM_BENCH_BACKEND=gloo python bench.py --gpus 2 ...   # ranks share the visible GPUs, scalars travel over gloo (tests)
 
 Prints ONE JSON line on rank 0 (see the task contract), including
   "roofline":     algorithmic bytes per launch / measured kernel time vs 8 TB/s HBM
@@ -128,6 +130,63 @@ def host_cores():
     return n
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher (WORLD_SIZE unset): spawn the N ranks here -- one child
+    process per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly what torch.distributed.run would set --
+    BEFORE this process has touched the GPU (nothing below imports torch), relay the children's output and make rank
+    0's JSON line the last line of stdout.  Exit code: the first non-zero one of the ranks."""
+    import socket
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    import threading
+
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None))
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    # a rank that dies leaves the others waiting in a collective: end them (our own children, by PID) and report
+    failed = 0
+    while any(p.poll() is None for p in procs):
+        bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+        if bad and not failed:
+            failed = bad[0]
+            deadline = time.time() + 10.0
+        if failed and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    reader.join(10.0)
+    codes = [p.returncode for p in procs]
+    out0 = (chunks[0] if chunks else b"").decode(errors="replace")
+    lines = [ln for ln in out0.splitlines() if ln.strip()]
+    json_line = None
+    for ln in reversed(lines):
+        if ln.startswith("{") and ln.rstrip().endswith("}"):
+            json_line = ln
+            break
+    for ln in lines:
+        if ln is not json_line:
+            print(ln, file=sys.stderr)
+    rc = failed or next((c for c in codes if c), 0)
+    if json_line is None and rc == 0:
+        rc = 1
+    sys.stderr.flush()
+    if json_line is not None and rc == 0:
+        print(json_line, flush=True)
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +203,8 @@ def main():
     ap.add_argument("--posterior-floor", type=float, default=0.0,
                     help="mm_batch_set_posterior_floor (default: the library's 1e-30); 1e-12 keeps sharp emissions on the fast kernels")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # (does not return)
 
     import torch
     import torch.distributed as dist
@@ -151,7 +212,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    # MM_BENCH_BACKEND=gloo: the ranks share whatever GPUs are visible (two ranks on the one GPU of a test box) and the
+    # scalar exchange goes over gloo -- the N > 1 code path without N GPUs (tests/test_dist_gloo.py).  Default: RCCL.
+    backend = os.environ.get("MM_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     use_dist = world > 1 or os.environ.get("MM_BENCH_FORCE_DIST") == "1"  # the latter: exercise RCCL with one rank
     if use_dist:
@@ -159,7 +226,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     mm = ge.load_package()
     wl = importlib.import_module(mm.__name__ + ".workloads")
@@ -211,10 +281,11 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     frames_total = frames_local
     if use_dist:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        rdev = "cpu" if backend == "gloo" else "cuda"
+        t = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        f = torch.tensor([frames_local], device="cuda", dtype=torch.float64)
+        f = torch.tensor([frames_local], device=rdev, dtype=torch.float64)
         dist.all_reduce(f, op=dist.ReduceOp.SUM)
         frames_total = int(f.item())
     assert os.environ.get("MM_BENCH_NOCHECK") or torch.isfinite(ttl).all(), "non-finite log-likelihoods"

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 1
+#define MM_ABI_VERSION 2 /* 2: mm_pdfposteriors_ex takes the rows of V_hat (P1); mm_batch_reserve_ex */
 
 enum mm_status {
     MM_OK = 0,
@@ -175,11 +175,16 @@ int mm_totalsum_f32(mm_batch_t batch, int64_t n, int cumulative, float *out, voi
  * Any semiring the FSMs were created with (MM_LOG, MM_TROPICAL, MM_PROB: the function is generic in K), float32 or
  * float64 (FSM{LogSemiring{Float64}} is what the reference's tests build: test/test_fsms.jl:3-7), any sparse state map
  * C_hat (not only the one-hot map of examples/prepare-lfmmi-graphs.jl:15-23), any (P+1) x (N+1) matrices V_hat (not
- * only those expand() makes).  Correctness first: a plain kernel that materialises alpha and beta like the reference;
- * allocates its workspace per call and returns when the result is there.  The fast kernels are behind
- * mm_pdfposteriors_f32.
+ * only those expand() makes).  Correctness first: a plain kernel that materialises alpha and beta like the reference.
+ * Asynchronous on `stream` like every run call: its workspace (alpha and beta, 2 x N1 x sum S1 elements) and the
+ * utterance descriptors live with the batch, grown lazily (growing synchronises; refused while the stream is capturing:
+ * size them with mm_batch_reserve_ex first), so a steady-state call allocates nothing, waits for nothing and can be
+ * captured in a hipGraph.  The fast kernels are behind mm_pdfposteriors_f32.
  *   maps     NULL (every FSM's own one-hot state map), or B handles (NULL entries: the FSM's own)
  *   val_bytes 4 / 8: the type of Vhat, gamma, ttl
+ *   P1       rows of every V_hat_b (P + 1).  Must equal the number of pdfs of the state map in force for every utterance
+ *            (src/inference.jl:146-150: vcat(V_hats...) against blockdiag(C_hats...)'); MM_ERR_DIM otherwise -- e.g. a
+ *            P x N matrix that expand() (:54-60) was not applied to
  *   Vhat     device; element (b, n, p) of V_hat_b at Vhat[b*v_stride_b + n*v_stride_n + p], n = 0..N1-1 (N1 = N + 1 columns),
  *            p = 0..P1-1 (P1 = P + 1 rows: the last is the phony pdf); values in the semiring's own domain
  *   gamma    device, out: element (b, n, p), n < N1 - 1, p < P1 - 1 (the reference drops the last row and column, :160);
@@ -191,9 +196,12 @@ typedef struct mm_statemap_s *mm_statemap_t;
 int mm_statemap_create(int semiring, int64_t S1, int32_t P1, int64_t nnz, int index_bytes, int index_base, int val_bytes,
                        const void *rowptr, const void *colidx, const void *val, mm_statemap_t *out);
 int mm_statemap_destroy(mm_statemap_t map);
-int mm_pdfposteriors_ex(mm_batch_t batch, const mm_statemap_t *maps, int val_bytes, const void *Vhat, int64_t v_stride_b,
-                        int64_t v_stride_n, int64_t N1, void *gamma, int64_t g_stride_b, int64_t g_stride_n, int64_t g_stride_p,
-                        void *ttl, void *stream);
+int mm_pdfposteriors_ex(mm_batch_t batch, const mm_statemap_t *maps, int val_bytes, int32_t P1, const void *Vhat,
+                        int64_t v_stride_b, int64_t v_stride_n, int64_t N1, void *gamma, int64_t g_stride_b, int64_t g_stride_n,
+                        int64_t g_stride_p, void *ttl, void *stream);
+/* Allocate the generic entry's workspace for calls with val_bytes-sized values and up to N1 = N + 1 columns now
+ * (synchronises if it has to grow): call before capturing mm_pdfposteriors_ex in a hipGraph. */
+int mm_batch_reserve_ex(mm_batch_t batch, int val_bytes, int64_t N1);
 
 /* Deterministic mode (default off).  Every kernel but one reduces in a fixed order; the general ("item") kernel -- the
  * path of small deep graphs such as LF-MMI numerators -- adds a pdf's state posteriors with LDS float atomics, so the

@@ -240,6 +240,7 @@ struct mm_batch_s {
     size_t ws_bytes = 0;
     const int *last_redo = nullptr;  // redo marks of the last pdfposteriors call (inside ws; mm_batch_last_redo_count)
     const double *last_z = nullptr;  // ... and the pair kernels' per-utterance normaliser statistics
+    GenScratch gen;                  // the generic entry's workspace and descriptors (mm_generic.hip)
 };
 
 // Launch geometry of the item kernels: NW waves per workgroup, NI register-resident items per wave
@@ -1810,6 +1811,8 @@ int mm_batch_destroy(mm_batch_t h) {
     if (h->d_utts) (void)hipFree(h->d_utts);
     if (h->ws_big) (void)hipFree(h->ws_big);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->gen.ws) (void)hipFree(h->gen.ws);
+    if (h->gen.d_utts) (void)hipFree(h->gen.d_utts);
     delete h;
     return MM_OK;
 }
@@ -1819,6 +1822,7 @@ int64_t mm_batch_total_states(mm_batch_t h) { return h ? h->total_states : -1; }
 }  // extern "C"
 namespace mm {
 FsmGenView *mm_fsm_gen_view(mm_fsm_t f) { return f ? &f->gen : nullptr; }
+GenScratch *mm_batch_gen_scratch(mm_batch_t h) { return h ? &h->gen : nullptr; }
 int mm_batch_gen_view(mm_batch_t h, int64_t *B, const mm_fsm_t **fsms, int *semiring, int *device) {
     if (!h) return MM_ERR_INVALID;
     *B = h->B;
@@ -1952,7 +1956,6 @@ static int ensure_ws(mm_batch_t h, size_t bytes, void *stream = nullptr) {
         h->ws = nullptr;
         h->ws_bytes = 0;
         h->last_redo = nullptr;
-    h->last_z = nullptr;
         h->last_z = nullptr;
     }
     HIP_TRY(hipMalloc(&h->ws, bytes));

@@ -299,9 +299,31 @@ static int statemap_to_device(mm_statemap_s *m, DevFsm **out) {
     return MM_OK;
 }
 
+// workspace elements (of T) of one call: alpha and beta of every utterance, [N1][S1] each
+static size_t generic_ws_elems(int64_t B, const mm_fsm_t *fsms, int64_t N1) {
+    size_t n = 0;
+    for (int64_t b = 0; b < B; ++b) n += size_t(2) * size_t(N1) * size_t(mm_fsm_gen_view(fsms[b])->S1);
+    return n;
+}
+// grow a device buffer of the batch (never while the stream is capturing: the old pointer may be baked into a graph)
+static int grow(void **buf, size_t *have, size_t want, hipStream_t stream) {
+    if (*have >= want) return MM_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return mm_fail(MM_ERR_INVALID, "mm_pdfposteriors_ex: the workspace would have to grow during stream capture: call mm_batch_reserve_ex first");
+    if (*buf) {
+        HIP_TRY(hipFree(*buf));  // synchronises: only on growth
+        *buf = nullptr;
+        *have = 0;
+    }
+    HIP_TRY(hipMalloc(buf, want));
+    *have = want;
+    return MM_OK;
+}
+
 template <typename T, int SR>
-static int run_generic(int64_t B, const mm_fsm_t *fsms, const mm_statemap_t *maps, const T *V, int64_t vsb, int64_t vsn, int64_t N1, T *gamma,
-                       int64_t gsb, int64_t gsn, int64_t gsp, T *ttl, hipStream_t stream) {
+static int run_generic(mm_batch_t batch, int64_t B, const mm_fsm_t *fsms, const mm_statemap_t *maps, int32_t P1, const T *V, int64_t vsb,
+                       int64_t vsn, int64_t N1, T *gamma, int64_t gsb, int64_t gsn, int64_t gsp, T *ttl, hipStream_t stream) {
     std::vector<GenUtt<T>> utts(static_cast<size_t>(B));
     long long ws_elems = 0;
     int maxP1 = 0;
@@ -312,6 +334,7 @@ static int run_generic(int64_t B, const mm_fsm_t *fsms, const mm_statemap_t *map
         if (rc) return rc;
         const char *base = static_cast<const char *>(d->blob);
         GenUtt<T> &u = utts[size_t(b)];
+        memset(&u, 0, sizeof(u));  // (the descriptors are compared bytewise with the last call's: no stray padding)
         u.f.S1 = d->S1;
         u.f.P1 = d->P1;
         for (int dir = 0; dir < 2; ++dir) {
@@ -330,31 +353,32 @@ static int run_generic(int64_t B, const mm_fsm_t *fsms, const mm_statemap_t *map
             if (rc) return rc;
             u.c = view_of(md, sizeof(T));
         }
-        if (b && u.c.P1 != utts[0].c.P1) return mm_fail(MM_ERR_DIM, "mm_pdfposteriors_ex: all state maps must have the same number of pdfs");
+        // the kernel reads P1 rows of V_hat and writes P1 - 1 rows of gamma per utterance, P1 = the columns of the map in force
+        // (src/inference.jl:146-150: vcat(V_hats...) must conform to blockdiag(C_hats...)' -- a DimensionMismatch there)
+        if (u.c.P1 != P1)
+            return mm_fail(MM_ERR_DIM, "mm_pdfposteriors_ex: V_hat has " + std::to_string(P1) + " rows but the state map of utterance " +
+                                           std::to_string(b) + " has " + std::to_string(u.c.P1) + " pdfs (P + 1: was expand() applied?)");
         maxP1 = std::max(maxP1, int(u.c.P1));
         u.ws_off = ws_elems;
         ws_elems += 2ll * N1 * d->S1;
     }
-    GenUtt<T> *d_utts = nullptr;
-    T *ws = nullptr;
-    HIP_TRY(hipMalloc(&d_utts, sizeof(GenUtt<T>) * size_t(B)));
-    hipError_t e1 = hipMalloc(&ws, sizeof(T) * size_t(ws_elems));
-    if (e1 != hipSuccess) {
-        (void)hipFree(d_utts);
-        return mm_fail(MM_ERR_HIP, "mm_pdfposteriors_ex: workspace allocation failed");
+    // workspace and descriptors live with the batch: no allocation, no synchronisation in the steady state
+    GenScratch *sc = mm_batch_gen_scratch(batch);
+    int rc = grow(&sc->ws, &sc->ws_bytes, sizeof(T) * size_t(ws_elems), stream);
+    if (rc) return rc;
+    const size_t ub = sizeof(GenUtt<T>) * size_t(B);
+    if (sc->utts_bytes < ub) sc->host.clear();
+    rc = grow(&sc->d_utts, &sc->utts_bytes, ub, stream);
+    if (rc) return rc;
+    if (sc->host.size() != ub || memcmp(sc->host.data(), utts.data(), ub) != 0) {
+        // (stream-ordered behind the last call's kernel; the source is the batch's own image, alive as long as the batch)
+        sc->host.assign(reinterpret_cast<const char *>(utts.data()), reinterpret_cast<const char *>(utts.data()) + ub);
+        HIP_TRY(hipMemcpyAsync(sc->d_utts, sc->host.data(), ub, hipMemcpyHostToDevice, stream));
     }
-    hipError_t e2 = hipMemcpyAsync(d_utts, utts.data(), sizeof(GenUtt<T>) * size_t(B), hipMemcpyHostToDevice, stream);
-    if (e2 == hipSuccess) {
-        hipLaunchKernelGGL((mm_generic_kernel<T, SR>), dim3(unsigned(B)), dim3(256), size_t(maxP1 + 1) * sizeof(T), stream, d_utts, V,
-                           (long long)vsb, (long long)vsn, int(N1), ws, gamma, (long long)gsb, (long long)gsn, (long long)gsp, ttl);
-        e2 = hipGetLastError();
-    }
-    // (this path allocates per call and waits for its kernel: correctness first)
-    hipError_t e3 = hipStreamSynchronize(stream);
-    (void)hipFree(ws);
-    (void)hipFree(d_utts);
-    if (e2 != hipSuccess) return mm_fail(MM_ERR_HIP, std::string("mm_pdfposteriors_ex: ") + hipGetErrorString(e2));
-    if (e3 != hipSuccess) return mm_fail(MM_ERR_HIP, std::string("mm_pdfposteriors_ex: ") + hipGetErrorString(e3));
+    hipLaunchKernelGGL((mm_generic_kernel<T, SR>), dim3(unsigned(B)), dim3(256), size_t(maxP1 + 1) * sizeof(T), stream,
+                       static_cast<const GenUtt<T> *>(sc->d_utts), V, (long long)vsb, (long long)vsn, int(N1), static_cast<T *>(sc->ws), gamma,
+                       (long long)gsb, (long long)gsn, (long long)gsp, ttl);
+    HIP_TRY(hipGetLastError());
     return MM_OK;
 }
 
@@ -404,20 +428,37 @@ int mm_statemap_destroy(mm_statemap_t m) {
     return MM_OK;
 }
 
-int mm_pdfposteriors_ex(mm_batch_t batch, const mm_statemap_t *maps, int val_bytes, const void *Vhat, int64_t v_stride_b, int64_t v_stride_n,
-                        int64_t N1, void *gamma, int64_t g_stride_b, int64_t g_stride_n, int64_t g_stride_p, void *ttl, void *stream) {
+int mm_batch_reserve_ex(mm_batch_t batch, int val_bytes, int64_t N1) {
+    int64_t B = 0;
+    const mm_fsm_t *fsms = nullptr;
+    int semiring = 0, device = -1, dev = -1;
+    if (mm_batch_gen_view(batch, &B, &fsms, &semiring, &device)) return mm_fail(MM_ERR_INVALID, "mm_batch_reserve_ex: NULL batch");
+    if ((val_bytes != 4 && val_bytes != 8) || N1 < 2) return mm_fail(MM_ERR_INVALID, "mm_batch_reserve_ex: bad argument");
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != device) return mm_fail(MM_ERR_INVALID, "mm_batch_reserve_ex: batch lives on another device");
+    GenScratch *sc = mm_batch_gen_scratch(batch);
+    int rc = grow(&sc->ws, &sc->ws_bytes, size_t(val_bytes) * generic_ws_elems(B, fsms, N1), nullptr);
+    if (rc) return rc;
+    if (sc->utts_bytes < sizeof(GenUtt<double>) * size_t(B)) sc->host.clear();
+    return grow(&sc->d_utts, &sc->utts_bytes, sizeof(GenUtt<double>) * size_t(B), nullptr);
+}
+
+int mm_pdfposteriors_ex(mm_batch_t batch, const mm_statemap_t *maps, int val_bytes, int32_t P1, const void *Vhat, int64_t v_stride_b,
+                        int64_t v_stride_n, int64_t N1, void *gamma, int64_t g_stride_b, int64_t g_stride_n, int64_t g_stride_p, void *ttl,
+                        void *stream) {
     int64_t B = 0;
     const mm_fsm_t *fsms = nullptr;
     int semiring = 0, device = -1, dev = -1;
     if (mm_batch_gen_view(batch, &B, &fsms, &semiring, &device)) return mm_fail(MM_ERR_INVALID, "mm_pdfposteriors_ex: NULL batch");
     if (!Vhat || !gamma || !ttl || (val_bytes != 4 && val_bytes != 8)) return mm_fail(MM_ERR_INVALID, "mm_pdfposteriors_ex: bad argument");
     if (N1 < 2) return mm_fail(MM_ERR_DIM, "mm_pdfposteriors_ex: V_hat needs at least two columns (N + 1)");
+    if (P1 < 2) return mm_fail(MM_ERR_DIM, "mm_pdfposteriors_ex: V_hat needs at least two rows (P + 1)");
     HIP_TRY(hipGetDevice(&dev));
     if (dev != device) return mm_fail(MM_ERR_INVALID, "mm_pdfposteriors_ex: batch lives on another device");
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define MM_GEN_CASE(T, SR)                                                                                                          \
-    return run_generic<T, SR>(B, fsms, maps, static_cast<const T *>(Vhat), v_stride_b, v_stride_n, N1, static_cast<T *>(gamma), g_stride_b, \
-                              g_stride_n, g_stride_p, static_cast<T *>(ttl), st)
+#define MM_GEN_CASE(T, SR)                                                                                                              \
+    return run_generic<T, SR>(batch, B, fsms, maps, P1, static_cast<const T *>(Vhat), v_stride_b, v_stride_n, N1, static_cast<T *>(gamma), \
+                              g_stride_b, g_stride_n, g_stride_p, static_cast<T *>(ttl), st)
     if (val_bytes == 4) {
         if (semiring == MM_LOG) MM_GEN_CASE(float, MM_LOG);
         if (semiring == MM_TROPICAL) MM_GEN_CASE(float, MM_TROPICAL);

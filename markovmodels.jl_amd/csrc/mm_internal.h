@@ -7,6 +7,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "../../include/markovmodels_amd.h"
 
@@ -50,6 +51,17 @@ struct FsmGenView {   // host copies of one FSM in double, natural units; [0]: C
     void *dev[2] = {nullptr, nullptr};  // device copies made by the generic path (float32, float64); freed by mm_generic_free
 };
 FsmGenView *mm_fsm_gen_view(mm_fsm_t f);
+// what the generic entry keeps with the batch between calls (owned and freed by the batch): the alpha / beta workspace,
+// the utterance descriptors on the device and the host image they were uploaded from (a call with the same FSMs, maps
+// and float type uploads nothing)
+struct GenScratch {
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    void *d_utts = nullptr;
+    size_t utts_bytes = 0;
+    std::vector<char> host;  // what d_utts holds
+};
+GenScratch *mm_batch_gen_scratch(mm_batch_t h);
 int mm_batch_gen_view(mm_batch_t h, int64_t *B, const mm_fsm_t **fsms, int *semiring, int *device);
 void mm_generic_free(void *dev);
 

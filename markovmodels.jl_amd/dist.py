@@ -39,7 +39,12 @@ def allreduce_logz(ttl_local, group=None):
 
     s = ttl_local.double().sum().reshape(1)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+        if s.is_cuda and dist.get_backend(group) == "gloo":  # (gloo reduces host tensors: the scalar takes the detour)
+            h = s.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            s = h.to(s.device)
+        else:
+            dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
     return s[0]
 
 
@@ -52,11 +57,13 @@ def allgather_ttl(ttl_local, sizes: Sequence[int], group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return ttl_local.clone()
     m = max(sizes)
-    pad = torch.full((m,), float("-inf"), dtype=ttl_local.dtype, device=ttl_local.device)
+    dev = ttl_local.device
+    host = ttl_local.is_cuda and dist.get_backend(group) == "gloo"  # (gloo gathers host tensors)
+    pad = torch.full((m,), float("-inf"), dtype=ttl_local.dtype, device="cpu" if host else dev)
     pad[: ttl_local.numel()] = ttl_local
     bufs = [torch.empty_like(pad) for _ in sizes]
     dist.all_gather(bufs, pad, group=group)
-    return torch.cat([b[:n] for b, n in zip(bufs, sizes)])
+    return torch.cat([b[:n] for b, n in zip(bufs, sizes)]).to(dev)
 
 
 class RcclComm:

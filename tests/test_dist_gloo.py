@@ -157,3 +157,46 @@ def test_two_ranks_with_the_hip_engine():
         assert np.isclose(total, ttl.sum(), rtol=1e-5)
         assert np.allclose(allttl, ttl, rtol=1e-5, atol=1e-4)
     assert np.isclose(sum(r[4] for r in res), g_ref.sum(), rtol=1e-4)
+
+
+def _run_bench(extra_env, *argv, timeout=600):
+    import subprocess
+
+    env = dict(os.environ, **extra_env)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (what the driver's command looks like): the parent spawns the two
+    ranks before it touches the GPU, both run the HIP engine on the one GPU of the box, the scalars go over gloo, and
+    rank 0's JSON line is the last line of stdout -- BASELINE.json configs[3] (the batch sharded over ranks, logZ
+    all-reduce) end to end, incl. the MAX / SUM reductions of the elapsed time and the frame count."""
+    import json
+
+    r = _run_bench({"MM_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = r.stdout.strip().splitlines()[-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 2
+    assert out["config"]["global_batch"] == 512
+    assert out["scaling"] == "weak"
+    # 2 ranks x 256 utterances x 1500 frames per step
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 2 * 256 * 1500) < 1.0
+    assert "roofline" in out and out["roofline"]["frac"] > 0
+
+
+def test_bench_self_launch_reports_a_failed_rank():
+    """No GPU here: both ranks die at their first device call.  The parent must come back with their exit status (not
+    hang in a rendezvous, not print a JSON line)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    r = _run_bench({"MM_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", timeout=120)
+    assert r.returncode != 0
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())

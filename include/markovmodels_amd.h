@@ -228,6 +228,14 @@ int mm_batch_set_posterior_floor(mm_batch_t batch, float floor);
  * *n = 0 for batches that run on the exact kernels only, or before the first call.  The reference has no such
  * path (src/inference.jl:145-161 runs one algorithm for every input); this is an observability hook. */
 int mm_batch_last_redo_count(mm_batch_t batch, void *stream, int64_t *n);
+/* ... and how many of THOSE the float64 exact kernels (mm_kernel_dpair.hip: the first stop of a marked utterance of a
+ * shared-graph batch) handed on to the log-domain kernels: values beyond the double's range that carry mass -- normally 0. */
+int mm_batch_last_fallback_count(mm_batch_t batch, void *stream, int64_t *n);
+/* 1 if the last mm_pdfposteriors_f32 call on this batch skipped the float32 kernels and ran the float64 exact kernels on
+ * the whole batch (the engine does that while more than a quarter of the utterances of the last finished call were
+ * beyond the float32 kernels -- a sharp acoustic model; mm_batch_last_redo_count then reports the whole batch), else 0.
+ * No synchronisation.  Observability only: results are the same either way. */
+int mm_batch_last_exact_first(mm_batch_t batch);
 
 /* ---- multi-GPU boundary (one process per GPU, RCCL over xGMI) -------------------------------------------------
  * The batch is block diagonal (src/fsmops.jl:28-36, src/inference.jl:28-36): utterances shard over the ranks with no

@@ -30,9 +30,12 @@ SYMBOLS = [
     "mm_batch_workspace_bytes",
     "mm_batch_kernels",
     "mm_batch_reserve",
+    "mm_batch_reserve_ex",
     "mm_batch_set_deterministic",
     "mm_batch_set_posterior_floor",
     "mm_batch_last_redo_count",
+    "mm_batch_last_fallback_count",
+    "mm_batch_last_exact_first",
     "mm_pdfposteriors_f32",
     "mm_pdfposteriors_ex",
     "mm_statemap_create",
@@ -104,6 +107,10 @@ def _load():
     lib.mm_batch_set_posterior_floor.argtypes = [vp, C.c_float]
     lib.mm_batch_last_redo_count.restype = C.c_int
     lib.mm_batch_last_redo_count.argtypes = [vp, vp, C.POINTER(i64)]
+    lib.mm_batch_last_fallback_count.restype = C.c_int
+    lib.mm_batch_last_fallback_count.argtypes = [vp, vp, C.POINTER(i64)]
+    lib.mm_batch_last_exact_first.restype = C.c_int
+    lib.mm_batch_last_exact_first.argtypes = [vp]
     lib.mm_batch_kernels.restype = C.c_int
     lib.mm_batch_kernels.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
     lib.mm_statemap_create.restype = C.c_int
@@ -111,7 +118,9 @@ def _load():
     lib.mm_statemap_destroy.restype = C.c_int
     lib.mm_statemap_destroy.argtypes = [vp]
     lib.mm_pdfposteriors_ex.restype = C.c_int
-    lib.mm_pdfposteriors_ex.argtypes = [vp, vp, C.c_int, vp, i64, i64, i64, vp, i64, i64, i64, vp, vp]
+    lib.mm_pdfposteriors_ex.argtypes = [vp, vp, C.c_int, i32, vp, i64, i64, i64, vp, i64, i64, i64, vp, vp]
+    lib.mm_batch_reserve_ex.restype = C.c_int
+    lib.mm_batch_reserve_ex.argtypes = [vp, C.c_int, i64]
     lib.mm_pdfposteriors_f32.restype = C.c_int
     lib.mm_pdfposteriors_f32.argtypes = [vp, fp, i64, i64, vp, i64, fp, i64, i64, i64, fp, vp]
     for name in ("mm_alpharecursion_f32", "mm_betarecursion_f32", "mm_maxstateposteriors_f32"):

@@ -13,6 +13,7 @@
 #include <limits>
 #include <new>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -176,6 +177,9 @@ struct DebugOpts {
     int kq = 0, nwaves = 0, nitems = -1;
     bool no_xcsr = false, verbose = false;
     bool no_redo = false;           // MM_NO_REDO: the exact kernels do not run after the fast ones (what the fast path alone computes)
+    bool no_dpair = false;          // MM_NO_DPAIR: no float64 pair kernels (marked utterances go straight to the quad / item kernels)
+    bool no_fallback = false;       // MM_NO_FALLBACK: the float64 pair kernels run, the log-domain kernels behind them do not
+    int exact_first = -1;           // MM_EXACT_FIRST=0/1: never / always skip the float32 pair kernels (default: by the last call's marks)
     bool bigv = false;              // MM_BIGV: item / tropical kernels with the state vectors in global memory whatever the size
     int finish_cost = 0;            // MM_FINISH_COST: cost model of the pair forms (0: default)
     int x_sleep = 8;                // MM_SPLIT_SLEEP: split kernels, 64-clock units the exchange wave sleeps before a step's first poll
@@ -195,6 +199,9 @@ static DebugOpts read_debug_opts() {
     d.verbose = getenv("MM_VERBOSE") != nullptr;
     d.bigv = getenv("MM_BIGV") != nullptr;
     d.no_redo = getenv("MM_NO_REDO") != nullptr;
+    d.no_dpair = getenv("MM_NO_DPAIR") != nullptr;
+    d.no_fallback = getenv("MM_NO_FALLBACK") != nullptr;
+    if (const char *e = getenv("MM_EXACT_FIRST")) d.exact_first = atoi(e) != 0;
     if (const char *e = getenv("MM_FINISH_COST")) d.finish_cost = atoi(e);
     if (const char *e = getenv("MM_SPLIT_SLEEP")) d.x_sleep = atoi(e);
     if (const char *e = getenv("MM_GROUP_SPEED")) sscanf(e, "%f,%f,%f,%f", &d.group_speed[0], &d.group_speed[1], &d.group_speed[2], &d.group_speed[3]);
@@ -241,6 +248,16 @@ struct mm_batch_s {
     const int *last_redo = nullptr;  // redo marks of the last pdfposteriors call (inside ws; mm_batch_last_redo_count)
     const double *last_z = nullptr;  // ... and the pair kernels' per-utterance normaliser statistics
     GenScratch gen;                  // the generic entry's workspace and descriptors (mm_generic.hip)
+    // The float64 exact pair kernels (mm_kernel_dpair.hip) take the utterances the float32 pair kernels mark -- and the whole
+    // batch, the float32 kernels skipped, while the inputs are "hard": more than a quarter of the last finished call's
+    // utterances were beyond the float32 kernels (stat_host, written by the finish kernels; read without synchronising).
+    bool dpair_ok = false;
+    int *stat_dev = nullptr;            // {count, ticket}
+    volatile int *stat_host = nullptr;  // pinned: {count of hard utterances, sequence number of the call that counted}
+    int stat_seq = 0;
+    int exact_first = -1;               // MM_EXACT_FIRST (under MM_DEBUG): 0 / 1 force the choice, -1: by the statistics
+    bool last_exact_first = false;      // what the last call did
+    const int *last_redo2 = nullptr;    // marks the float64 kernels left for the log-domain kernels (mm_batch_last_fallback_count)
 };
 
 // Launch geometry of the item kernels: NW waves per workgroup, NI register-resident items per wave
@@ -1058,7 +1075,8 @@ static void wave_pack(mm_fsm_t f) {
     opt.spread_pdf = true;
     opt.finish_cost = 4;
     for (float &x : opt.group_speed) x = 1.f;
-    RowVariant *rv[2] = {new RowVariant(), new RowVariant()};
+    // (owned until they are handed to the FSM: the packer may throw -- an allocation that fails)
+    std::unique_ptr<RowVariant> rv[2] = {std::make_unique<RowVariant>(), std::make_unique<RowVariant>()};
     const std::vector<int32_t> none;
     bool fits = make_rows(f->S1, f->qmat[0].rowptr, f->qmat[0].col, f->qmat[0].val, f->s2p, f->P1, false, none, opt, rv[0]->g) &&
                 make_rows(f->S1, f->qmat[1].rowptr, f->qmat[1].col, f->qmat[1].val, f->s2p, f->P1, true, rv[0]->g.pos, opt, rv[1]->g);
@@ -1066,16 +1084,12 @@ static void wave_pack(mm_fsm_t f) {
         rv[d]->pdf_nps = wave_pdf_table(rv[d]->g, f->s2p, f->S1, f->P1, rv[d]->ptab);
         fits = rv[d]->pdf_nps > 0;
     }
-    if (!fits) {
-        delete rv[0];
-        delete rv[1];
-        return;
-    }
+    if (!fits) return;
     set_partner(rv[0]->g, rv[1]->g.pos);
     rv[0]->init.resize(size_t(f->S1));
     for (int64_t i = 0; i < f->S1; ++i) rv[0]->init[i] = f->init[rv[0]->g.order[i]];
-    f->wpend[0] = rv[0];
-    f->wpend[1] = rv[1];
+    f->wpend[0] = rv[0].release();
+    f->wpend[1] = rv[1].release();
 }
 
 // the wave forms of an FSM (built once; *ok = false if it does not fit them: more than 16 segments of 64 rows, ...)
@@ -1483,21 +1497,23 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         if (fsms[b]->semiring != fsms[0]->semiring)
             return fail(MM_ERR_INVALID, "mm_batch_create: FSMs of one batch must share the semiring (FSM{K})");
     }
-    mm_batch_s *h = new mm_batch_s();
+    // (owned here until it is handed out: every early return and every exception -- the packers allocate -- destroys it)
+    struct Drop {
+        void operator()(mm_batch_s *x) const { (void)mm_batch_destroy(x); }
+    };
+    std::unique_ptr<mm_batch_s, Drop> hold(new mm_batch_s());
+    mm_batch_s *h = hold.get();
     h->dbg = read_debug_opts();
     h->B = B;
     h->semiring = fsms[0]->semiring;
     h->fsms.assign(fsms, fsms + B);
-    if (hipGetDevice(&h->device) != hipSuccess) {
-        delete h;
-        return fail(MM_ERR_HIP, "mm_batch_create: no device");
-    }
+    if (hipGetDevice(&h->device) != hipSuccess) return fail(MM_ERR_HIP, "mm_batch_create: no device");
     if (h->semiring == MM_PROB) {  // the generic path only (mm_pdfposteriors_ex): no kernel forms, no descriptors
         for (int64_t b = 0; b < B; ++b) {
             h->total_states += fsms[b]->S1;
             h->max_P1 = std::max(h->max_P1, int(fsms[b]->P1));
         }
-        *out = h;
+        *out = hold.release();
         return MM_OK;
     }
     std::vector<UttDesc> utts(B);
@@ -1588,10 +1604,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         if (small) {
             wave_first_tried = true;
             int rc = try_wave();
-            if (rc) {
-                delete h;
-                return rc;
-            }
+            if (rc) return rc;
             // (the exception; the forms stay with the FSM.  Graphs of up to 2 segments per wave run the kernel instance of
             // which two workgroups fit a compute unit and win at every batch size: 16-state ergodic HMM, B = 1024: 1.18
             // against 1.88 ms)
@@ -1606,10 +1619,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     for (int64_t b = 0; b < B && h->rows_ok; ++b) {
         bool ok = false;
         int rc = row_variants(fsms[b], h->dbg.verbose, &ok);
-        if (rc) {
-            delete h;
-            return rc;
-        }
+        if (rc) return rc;
         h->rows_ok = ok;
     }
     // pair kernels: all utterances on ONE FSM (the graph registers are shared by the two utterances of a workgroup)
@@ -1620,10 +1630,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     if (h->pairs_ok) {
         bool ok = false;
         int rc = pair_variants(fsms[0], h->dbg, &ok);
-        if (rc) {
-            delete h;
-            return rc;
-        }
+        if (rc) return rc;
         h->pairs_ok = ok;
         if (ok) {
             h->pair_ka = std::max(fsms[0]->prows[0]->g.KA, fsms[0]->prows[1]->g.KA);
@@ -1644,10 +1651,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             int rc = split_variants(fsms[0], h->dbg, 2, &ok);
             // (a graph beyond the teams of 2 -- more than 3070 states or 2 x 14 x 64 x 36 arcs: teams of 4)
             if (!rc && !ok) rc = split_variants(fsms[0], h->dbg, 4, &ok);
-            if (rc) {
-                delete h;
-                return rc;
-            }
+            if (rc) return rc;
             if (ok) {
                 const mm_fsm_t f0 = fsms[0];
                 h->pair_H = f0->split.H;
@@ -1672,10 +1676,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         for (int64_t b = 0; b < B && h->vit_ok; ++b) {
             bool ok = false;
             int rc = vit_variant(fsms[b], h->dbg, &ok);
-            if (rc) {
-                delete h;
-                return rc;
-            }
+            if (rc) return rc;
             h->vit_ok = ok;
             if (ok) {  // (one layout per batch: the first FSM's; an FSM that needed another one keeps the batch on the item kernel)
                 if (b == 0) {
@@ -1695,10 +1696,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
          (h->dbg.kernel == DebugOpts::K_AUTO && (!h->fast_ok || (h->max_depth >= 64 && h->geo_kq[0] <= 3 && h->geo_kq[1] <= 3))))) {
         // (= where the item kernel would run: quad_kernel_usable() says no for these; see there)
         int rc = try_wave();
-        if (rc) {
-            delete h;
-            return rc;
-        }
+        if (rc) return rc;
     }
     for (int64_t b = 0; b < B; ++b) {
         mm_fsm_t f = fsms[b];
@@ -1706,10 +1704,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         QuadVariant *qv[2] = {nullptr, nullptr};
         // (a batch of the wave kernel never runs the quad kernels: their forms are not built)
         for (int d = 0; d < 2 && !rc && h->fast_ok && !h->wave_ok; ++d) rc = quad_variant(f, d, h->geo_kq[d], h->dbg.verbose, &qv[d]);
-        if (rc) {
-            delete h;
-            return rc;
-        }
+        if (rc) return rc;
         UttDesc &u = utts[b];
         memset(&u, 0, sizeof(u));
         u.g[0] = f->gdev[0];
@@ -1759,16 +1754,13 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     }
     if (hipGetDevice(&h->device) != hipSuccess || hipMalloc(&h->d_utts, sizeof(UttDesc) * B) != hipSuccess ||
         hipMemcpy(h->d_utts, utts.data(), sizeof(UttDesc) * B, hipMemcpyHostToDevice) != hipSuccess) {
-        if (h->d_utts) (void)hipFree(h->d_utts);
-        delete h;
         return fail(MM_ERR_HIP, "mm_batch_create: device allocation failed");
     }
     {   // FSMs whose state vectors do not fit the LDS: the item / tropical kernels keep them in global memory
         const int P1p = (h->max_P1 + 3) & ~3;
         if (size_t(lds_plan(h->max_S1p, P1p, true).total) * 4 > 160 * 1024 || h->dbg.bigv) {
             if (hipMalloc(&h->ws_big, size_t(B) * 4 * size_t(h->max_S1p) * sizeof(float)) != hipSuccess) {
-                (void)hipFree(h->d_utts);
-                delete h;
+                h->ws_big = nullptr;
                 return fail(MM_ERR_HIP, "mm_batch_create: device allocation failed");
             }
         }
@@ -1778,13 +1770,24 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         for (int i = 0; i < 5 && good; ++i) good = hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming) == hipSuccess;
         if (!good) h->pairs_ok = false;
     }
+    if (h->pairs_ok && h->pair_H == 1 && !h->dbg.no_dpair) {
+        void *hp = nullptr;
+        if (hipMalloc(&h->stat_dev, 2 * sizeof(int)) == hipSuccess && hipMemset(h->stat_dev, 0, 2 * sizeof(int)) == hipSuccess &&
+            hipHostMalloc(&hp, 2 * sizeof(int), hipHostMallocMapped) == hipSuccess) {
+            h->stat_host = static_cast<volatile int *>(hp);
+            h->stat_host[0] = 0;
+            h->stat_host[1] = 0;
+            h->dpair_ok = true;
+            h->exact_first = h->dbg.exact_first;
+        }
+    }
     if (h->fast_ok && h->geo_kq[0] <= 3 && h->geo_kq[1] <= 3 && !h->dbg.no_xcsr) {
         h->xcsr = int((h->max_xcsr + 3) & ~int64_t(3));
         if (h->max_xcsr > 16 * 1024 || quad_lds_bytes(h, 0) > 128 * 1024 || quad_lds_bytes(h, 1) > 128 * 1024) h->xcsr = 0;
     }
     if (h->dbg.verbose)
         fprintf(stderr, "[mm] batch of %lld created in %.1f ms\n", (long long)B, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count());
-    *out = h;
+    *out = hold.release();
     return MM_OK;
 }
 
@@ -1811,6 +1814,8 @@ int mm_batch_destroy(mm_batch_t h) {
     if (h->d_utts) (void)hipFree(h->d_utts);
     if (h->ws_big) (void)hipFree(h->ws_big);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->stat_dev) (void)hipFree(h->stat_dev);
+    if (h->stat_host) (void)hipHostFree(const_cast<int *>(h->stat_host));
     if (h->gen.ws) (void)hipFree(h->gen.ws);
     if (h->gen.d_utts) (void)hipFree(h->gen.d_utts);
     delete h;
@@ -1840,6 +1845,7 @@ int mm_batch_set_posterior_floor(mm_batch_t h, float floor) {
     // a term that dropped out of the linear path would have had a posterior below 2^(-120 - L_n) (mm_pair_finish_kernel):
     // L_n >= -120 - log2(floor) keeps every loss below the floor (1e-30 -> -20.3, the default -20; 1e-12 -> -80)
     h->lt_floor = std::min(-20.f, -120.f - std::log2(floor));
+    if (h->stat_host) h->stat_host[0] = 0;  // (what was hard under the old floor need not be under the new one: float32 kernels first)
     return MM_OK;
 }
 
@@ -1872,6 +1878,19 @@ int mm_batch_last_redo_count(mm_batch_t h, void *stream, int64_t *n) {
     return MM_OK;
 }
 
+int mm_batch_last_fallback_count(mm_batch_t h, void *stream, int64_t *n) {
+    if (!h || !n) return fail(MM_ERR_INVALID, "mm_batch_last_fallback_count: bad argument");
+    *n = 0;
+    if (!h->last_redo2) return MM_OK;
+    std::vector<int> marks(size_t(h->B), 0);
+    HIP_TRY(hipMemcpyAsync(marks.data(), h->last_redo2, size_t(h->B) * sizeof(int), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    for (int m : marks) *n += m != 0;
+    return MM_OK;
+}
+
+int mm_batch_last_exact_first(mm_batch_t h) { return h && h->last_exact_first ? 1 : 0; }
+
 int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
     if (!h || !buf || n < 2) return fail(MM_ERR_INVALID, "mm_batch_kernels: bad argument");
     std::string s;
@@ -1891,7 +1910,12 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
         } else if (h->pairs_ok) {
             const std::string k = std::to_string(h->max_P1 <= 128 ? 2 : 4);
             s = "mm_fbp_kernel_dir<" + k + ",A,fwd> || <" + k + ",A,bwd>, then <" + k + ",B,fwd> || <" + k +
-                ",B,bwd>, mm_pair_finish_kernel, then for marked utterances only " + exact +
+                ",B,bwd>, mm_pair_finish_kernel, then for marked utterances only " +
+                (h->dpair_ok ? "mm_fbd_kernel_dir<" + k + ",A,fwd> || <" + k + ",A,bwd>, then <" + k + ",B,fwd> || <" + k +
+                                   ",B,bwd> (float64, one utterance per workgroup; FIRST and alone while the inputs are hard), "
+                                   "mm_dpair_finish_kernel, then for what those mark "
+                             : std::string()) +
+                exact +
                 (h->side[0] == h->side[1] ? " [no concurrent stream pair found: the two agents take turns]" : "");
         } else if (h->rows_ok) {
             auto ka = [&](int d) {
@@ -1930,7 +1954,7 @@ static size_t ws_x_bytes(mm_batch_t h) {
 }
 static size_t ws_tail_bytes(mm_batch_t h) {  // longest-first order, redo marks, pair hand-over, per-direction log Z minima, team buffers
     return 2 * align_up(size_t(h->B + 1) * 4, 256) + align_up(size_t(h->B + 1) * 2 * mm_pair_hand_bytes(), 256) +
-           align_up(size_t(h->B) * 6 * 8, 256) + ws_x_bytes(h);
+           align_up(size_t(h->B) * 6 * 8, 256) + ws_x_bytes(h) + align_up(size_t(h->B + 1) * 4, 256);  // (last: redo2)
 }
 
 // (quad kernels) the emissions shifted by their per-frame maxima [B][N][P], and the maxima [B][N]
@@ -1943,6 +1967,14 @@ size_t mm_batch_workspace_bytes(mm_batch_t h, int64_t N) {
     return ws_alpha_bytes(h, N) + ws_c_bytes(h, N) + ws_tail_bytes(h) + ws_shift_bytes(h, N);
 }
 
+
+// Viterbi on the row-lane form (mm_kernel_vit.hip): one-byte back-pointers [B][N + 1][row], rows padded to 256 bytes, + the
+// KB the back-trace's last DMA may read past the end
+static size_t vit_bp_row(mm_batch_t h) { return (size_t(h->max_S1p) + 255) & ~size_t(255); }
+static size_t ws_vit_bytes(mm_batch_t h, int64_t N) {
+    if (h->semiring != MM_TROPICAL) return 0;
+    return h->vit_ok ? size_t(h->B) * size_t(N + 1) * vit_bp_row(h) + 1024 : align_up(size_t(h->total_states) * size_t(N + 1) * 4, 256);
+}
 
 static int ensure_ws(mm_batch_t h, size_t bytes, void *stream = nullptr) {
     if (h->ws_bytes >= bytes) return MM_OK;
@@ -1968,8 +2000,9 @@ int mm_batch_reserve(mm_batch_t h, int64_t N) {
     int dev = -1;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != h->device) return fail(MM_ERR_INVALID, "mm_batch_reserve: batch lives on another device");
-    // (the Viterbi back-pointers and the total-sum rows share the workspace: [N + 1][total states] words)
-    return ensure_ws(h, std::max(mm_batch_workspace_bytes(h, N), align_up(size_t(h->total_states) * size_t(N + 1) * 4, 256)));
+    // (the total-sum rows and the max-marginals share the workspace: [N + 1][total states] words; the Viterbi back-pointers:
+    // one-byte rows for the row-lane kernels, int32 rows for the item kernel)
+    return ensure_ws(h, std::max({mm_batch_workspace_bytes(h, N), align_up(size_t(h->total_states) * size_t(N + 1) * 4, 256), ws_vit_bytes(h, N)}));
 }
 
 static int check_run(mm_batch_t h, const char *who, const float *V, int64_t N, int want_semiring) {
@@ -1983,6 +2016,11 @@ static int check_run(mm_batch_t h, const char *who, const float *V, int64_t N, i
     int dev = -1;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != h->device) return fail(MM_ERR_INVALID, std::string(who) + ": batch lives on another device");
+    // (every run entry reuses the workspace the redo marks of the last pdfposteriors call live in: mm_batch_last_redo_count
+    // must not read what another entry wrote there)
+    h->last_redo = nullptr;
+    h->last_redo2 = nullptr;
+    h->last_z = nullptr;
     return MM_OK;
 }
 
@@ -2049,6 +2087,23 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
         // concurrently and either may mark an utterance first)
         HIP_TRY(hipMemsetAsync(p.redo, 0, size_t(h->B + 1) * 4, static_cast<hipStream_t>(stream)));
         h->last_redo = p.redo;
+        // Which kernels first?  The float32 pair kernels, unless the inputs of the last finished call were beyond them for more
+        // than a quarter of its utterances (a sharp acoustic model: every utterance is marked and computed again): then the
+        // float64 kernels take the whole batch at once.  They keep reporting (how many utterances have an overlap term below the
+        // float32 kernels' floor), so the choice follows the data back as well.  Read without synchronising: the count of
+        // whatever call finished last.
+        bool exact_first = false;
+        if (h->dpair_ok) {
+            exact_first = h->exact_first >= 0 ? h->exact_first != 0 : 4 * int64_t(h->stat_host[0]) > h->B;
+            p.redo2 = reinterpret_cast<int *>(tail + ws_tail_bytes(h) - align_up(size_t(h->B + 1) * 4, 256));
+            HIP_TRY(hipMemsetAsync(p.redo2, 0, size_t(h->B + 1) * 4, static_cast<hipStream_t>(stream)));
+            p.stat_dev = h->stat_dev;
+            p.stat_host = h->stat_host;
+            p.stat_seq = ++h->stat_seq;
+            p.stat_mode = exact_first ? 1 : 0;
+            if (exact_first) HIP_TRY(hipMemsetAsync(p.redo, 1, size_t(h->B) * 4, static_cast<hipStream_t>(stream)));  // (every utterance "marked")
+        }
+        h->last_exact_first = exact_first;
         if (h->pairs_ok) {
             p.pair_s1p = h->pair_H > 1 ? h->split_s1p : h->max_S1p;
             p.pair_hand = tail + 2 * align_up(size_t(h->B + 1) * 4, 256);
@@ -2067,12 +2122,31 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
                 HIP_TRY(hipMemsetAsync(p.xbuf, 0, ws_x_bytes(h), static_cast<hipStream_t>(stream)));
             }
             h->last_z = p.pair_zmin;
-            rc = launch_pairs(h, p, stream);
+            rc = exact_first ? MM_OK : launch_pairs(h, p, stream);
         } else {
             rc = launch_rows(h, p, stream);
         }
         if (rc) return rc;
-        if (h->dbg.no_redo) return MM_OK;
+        if (h->dbg.no_redo && !exact_first) return MM_OK;
+        if (h->dpair_ok) {
+            // the float64 pair kernels for the marked utterances (workgroups of the others leave at once); what THEY mark --
+            // values beyond the double's range that carry mass -- is left in redo2 for the log-domain kernels below
+            PairLaunch pl;
+            pl.B = h->B;
+            pl.nwc = h->pair_nwc;
+            pl.slotrows = h->pair_slotrows;
+            pl.max_P1 = h->max_P1;
+            pl.pair_ka = h->pair_ka;
+            pl.H = 1;
+            pl.side[0] = h->side[0];
+            pl.side[1] = h->side[1];
+            for (int i = 0; i < 5; ++i) pl.ev[i] = h->ev[i];
+            rc = mm_launch_dpairs(pl, p, static_cast<hipStream_t>(stream));
+            if (rc) return rc;
+            h->last_redo2 = p.redo2;
+            p.redo = p.redo2;
+            if (h->dbg.no_redo || h->dbg.no_fallback) return MM_OK;
+        }
     }
     if (quad_kernel_usable(h)) {
         // the quad kernels run on emissions shifted by their per-frame maxima (see mm_shift_em_kernel)
@@ -2256,9 +2330,8 @@ int mm_viterbi_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const
     if (path_stride_b < N) return fail(MM_ERR_DIM, "mm_viterbi_f32: path_stride_b < N");
     RunParams p{};
     if (!bp) {
-        // (int32 rows for the item kernel, or one-byte rows padded to 1 KB for the row-lane kernels)
-        rc = ensure_ws(h, std::max(align_up(size_t(h->total_states) * size_t(N + 1) * 4, 256),
-                                   size_t(h->B) * size_t(N + 1) * size_t((h->max_S1p + 1023) & ~1023)), stream);
+        // (int32 rows for the item kernel, or one-byte rows padded to 256 bytes for the row-lane kernels: what this batch runs)
+        rc = ensure_ws(h, ws_vit_bytes(h, N), stream);
         if (rc) return rc;
         bp = static_cast<int32_t *>(h->ws);
         bp_stride_n = h->total_states;
@@ -2293,7 +2366,7 @@ int mm_viterbi_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const
         vl.max_P1 = h->max_P1;
         vl.max_S1p = h->max_S1p;
         vl.max_arcs = h->vit_arcs;
-        vl.bp_row = (h->max_S1p + 1023) & ~1023;  // bytes of a row of one-byte back-pointers, padded to 1 KB
+        vl.bp_row = int(vit_bp_row(h));  // bytes of a row of one-byte back-pointers, padded to 256
         RunParams q = p;
         q.bp_stride_n = vl.bp_row;
         return mm_launch_viterbi(vl, q, static_cast<hipStream_t>(stream));

@@ -76,6 +76,8 @@ struct PairLaunch {
 int mm_launch_pairs(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
 size_t mm_pair_lds_bytes(int phase, int nslotrows);
 size_t mm_pair_hand_bytes();
+// ---- the float64 exact pair kernels (mm_dpair_tu.hip): one utterance per workgroup, for the utterances marked in p.redo
+int mm_launch_dpairs(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
 // ---- split pair kernels (mm_split_tu.hip): teams of pl.H workgroups
 int mm_launch_split(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
 size_t mm_split_lds_bytes(int H, int phase, int nslotrows);

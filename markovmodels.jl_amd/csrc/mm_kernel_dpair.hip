@@ -1,0 +1,623 @@
+// mm_kernel_dpair.hip -- the EXACT path of the pair kernels (mm_kernel_pairs.hip): the same organisation -- register-resident
+// graph in the pair form, one barrier per step, a service wave for all HBM traffic, a forward and a backward agent per
+// utterance running at the same time, phase A / phase B -- with ONE utterance per workgroup whose linear values are
+// FLOAT64.
+//
+// Why: the pair kernels keep p = 2^a~ as float32.  Every product of an unmarked utterance must stay above 2^-126 of its
+// frame's scale, and a posterior of 1e-30 needs a~ + b~ down to 2^(-100 - L_n); under a sharp acoustic model (a trained
+// network: log-softmax of 10 N(0,1) has L_n = -160) no float32 scale can hold both factors, the utterance is marked and
+// was recomputed by the quad kernels -- one workgroup per utterance, forward THEN backward: 6.5 ms for a single marked
+// utterance of config 3, 18 ms for a batch of them.  A double has 1022 log2 below 1 instead of 126: the same recursion in
+// float64 is exact (in the sense of the parity bar) for every input a float32 emission matrix can reasonably hold, and
+// gfx950 issues v_fma_f64 at the rate of v_fma_f32 (tools/dev/f64_test.hip: 5.1 against 5.3 cycles per wave instruction).
+//
+// What changes against pair_agent:
+//   * the 8 bytes of a state in the LDS vectors (PP, Q, PSUM) hold one double instead of the two floats of a pair: the
+//     pair form of the graph -- addresses in units of 8 bytes, slot tables, bank-aware placement -- is used AS IS;
+//   * an arc is ds_read_b64 + v_cvt_f64_f32 (the weight stays a float in its register: two VGPRs per arc as before) +
+//     v_fma_f64: the LDS traffic of the pair kernels per workgroup, for one utterance instead of two;
+//   * a finish takes log2 of a double as exponent + v_log_f32 of the mantissa and 2^y as v_exp_f32 of the fraction +
+//     v_ldexp_f64; the stored vectors stay float32 log2 values ([N + 2][S1p] per utterance: 4 bytes per state and frame);
+//   * the service wave has one utterance's emissions, normaliser and posteriors per step instead of two (it is the
+//     longest actor of the pair kernels' phase B);
+//   * range marks (|normalised log2 value| > thr + 896) go to a second array (redo2) and are decided by
+//     mm_dpair_finish_kernel with the same two criteria as mm_pair_finish_kernel, scaled to the double range; what stays
+//     marked -- values more than ~1000 log2 below their frame's maximum that carry mass -- goes to the quad / item kernels.
+// Workgroups of utterances that are not marked (redo[b] == 0) leave at once.
+#pragma once
+#include "mm_kernel_pairs.hip"
+
+namespace mm {
+
+__device__ __forceinline__ double ldsr_d(unsigned addr) { return *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)addr; }
+__device__ __forceinline__ void ldsw_d(unsigned addr, double v) { *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)addr = v; }
+
+// 2^y as a double for a float y of any magnitude (-inf -> 0; below -1100 -> 0): the fraction through v_exp_f32, the integer
+// part through v_ldexp_f64
+__device__ __forceinline__ double dexp2(float y) {
+    float fl = __builtin_floorf(y);
+    fl = __builtin_fmaxf(fl, -1100.f);  // (-inf stays -inf in the difference below: 2^-inf = 0)
+    const float m = fast_exp2(y - fl);
+    return __builtin_amdgcn_ldexp((double)m, (int)fl);
+}
+// log2 of a non-negative double as a float: exponent + v_log_f32 of the mantissa (0 -> -inf)
+__device__ __forceinline__ float dlog2(double s) {
+    const int ex = __builtin_amdgcn_frexp_exp(s);
+    const float mf = (float)__builtin_amdgcn_frexp_mant(s);
+    return (float)ex + fast_log2(mf);
+}
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_add_d(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROWMASK, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROWMASK, 0xF, true);
+    return v + __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// sum over aligned groups of 1 << lg lanes, valid in the LAST lane of every group (grp_sum_last for doubles)
+__device__ __forceinline__ double dgrp_sum_last(double v, int lg) {
+    v = dpp_add_d<0x111, 0xF>(v);
+    if (lg >= 2) {
+        v = dpp_add_d<0x112, 0xF>(v);
+        if (lg >= 3) {
+            v = dpp_add_d<0x114, 0xF>(v);
+            if (lg >= 4) {
+                v = dpp_add_d<0x118, 0xF>(v);
+                if (lg >= 5) {
+                    v = dpp_add_d<0x142, 0xA>(v);
+                    if (lg >= 6) v = dpp_add_d<0x143, 0xC>(v);
+                }
+            }
+        }
+    }
+    return v;
+}
+// butterfly sum over aligned groups of 8 lanes, valid in every lane (grp_sum(v, 3) for doubles)
+__device__ __forceinline__ double dgrp_sum8(double v) {
+    v = dpp_add_d<MM_DPP_XOR1, 0xF>(v);
+    v = dpp_add_d<MM_DPP_XOR2, 0xF>(v);
+    v = dpp_add_d<MM_DPP_HALF_MIRROR, 0xF>(v);
+    return v;
+}
+// wave-wide sum (wave_sum_rl for doubles): 16-lane rows by DPP, the 4 row results through readlane
+__device__ __forceinline__ double dwave_sum_rl(double v) {
+    v = dgrp_sum8(v);
+    v = dpp_add_d<MM_DPP_MIRROR, 0xF>(v);
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 16 * k);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 16 * k);
+        r[k] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    }
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, MM_DPP_XOR1, 0xF, 0xF, true));
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, MM_DPP_XOR2, 0xF, 0xF, true));
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, MM_DPP_HALF_MIRROR, 0xF, 0xF, true));
+    v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, MM_DPP_MIRROR, 0xF, 0xF, true));
+    const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return mx(mx(r0, r1), mx(r2, r3));
+}
+
+// service wave: log2 of the maximum of the linear vector of doubles (n2 float4s = 2 states each, n2 <= 64 * NB), to the
+// 20 mantissa bits of the high words (a predictor's input: pair_scan_max for doubles).  Non-negative doubles order like
+// their high words; -inf if nothing is alive (or everything is below 2^-1022).
+template <int NB>
+__device__ __forceinline__ float dpair_scan_max(unsigned pbase, int n2, int lane) {
+    typedef unsigned mm_u32x4 __attribute__((ext_vector_type(4)));
+    unsigned a = 0u;
+#pragma unroll
+    for (int j0 = 0; j0 < NB; j0 += 4) {
+        mm_u32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = lane + 64 * (j0 + j);
+            v[j] = *(__attribute__((address_space(3))) const mm_u32x4 *)(__UINTPTR_TYPE__)(pbase + 16u * (q < n2 ? q : n2 - 1));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned m = v[j].y > v[j].w ? v[j].y : v[j].w;
+            a = a > m ? a : m;
+        }
+    }
+    const unsigned hi = wave_max_u32(a);
+    const int ex = (int)((hi >> 20) & 0x7ffu);
+    if (ex == 0) return MM_NINF;
+    const float mant = __builtin_bit_cast(float, 0x3f800000u | ((hi & 0xfffffu) << 3));  // [1, 2)
+    return (float)(ex - 1023) + fast_log2(mant);
+}
+
+// one wave: per-frame sum over the pdfs (psum doubles [pdf]), divide, store gamma (src/inference.jl:156-160); returns
+// log2 of the sum (-inf, and gamma = 0, if nothing is alive)
+template <int NJ>  // NJ * 64 >= P + 1
+__device__ __forceinline__ float dpair_finish_frame(unsigned psum, int P1, int P, int lane, float *gp, long long gsp, bool store) {
+    double s[NJ], t = 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = lane + 64 * j;
+        s[j] = ldsr_d(psum + 8u * (q < P1 ? q : 0));
+        if (q < P1) t += s[j];
+    }
+    t = dwave_sum_rl(t);
+    // gamma = s / t through floats on the scale of t: s 2^-e / (t 2^-e), e = the exponent of t
+    const int e = __builtin_amdgcn_frexp_exp(t);
+    const float tf = (float)__builtin_amdgcn_ldexp(t, -e);
+    const float inv = tf > 0.f ? 1.f / tf : 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = lane + 64 * j;
+        if (q < P && store) gp[q * gsp] = (float)__builtin_amdgcn_ldexp(s[j], -e) * inv;
+    }
+    return dlog2(t);
+}
+
+// pdf sums (q doubles in pdf-major order): 8 pdfs per wave and pass, 8 lanes per pdf (pair_pdf_sums for doubles)
+__device__ __forceinline__ void dpair_pdf_sums(unsigned qbase, unsigned pdfse_base, unsigned psum_base, int P1, int wave, int NWC, int lane) {
+    for (int p0 = wave * 8; p0 < P1; p0 += NWC * 8) {
+        const int pdf = p0 + (lane >> 3);
+        double s0 = 0.0;
+        if (pdf < P1) {
+            const unsigned se = ldsru(pdfse_base + 4u * pdf);  // first | end << 16
+            const unsigned a0 = 8u * ((se & 0xffffu) + (lane & 7)), a1 = 8u * (se >> 16);
+            double v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = ldsr_d(qbase + (a0 + 64u * k < a1 ? a0 + 64u * k : 0u));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (a0 + 64u * k < a1) s0 += v[k];
+            for (unsigned a = a0 + 256u; a < a1; a += 64u) s0 += ldsr_d(qbase + a);
+        }
+        s0 = dgrp_sum8(s0);
+        if (pdf < P1 && (lane & 7) == 0) ldsw_d(psum_base + 8u * pdf, s0);
+    }
+}
+
+// One arc: acc += (double)w * x.  The conversion sits in the same asm block as the FMA: the weights are loop invariant, and
+// a conversion the compiler can see is hoisted out of the time loop -- KA more register pairs than a wave has.
+__device__ __forceinline__ void d_fma_w(double &acc, float w, const double &x) {
+    double t;
+    asm("v_cvt_f64_f32 %1, %2\n\tv_fma_f64 %0, %1, %3, %0" : "+v"(acc), "=&v"(t) : "v"(w), "v"(x));
+}
+__device__ __forceinline__ void d_mul_w(double &acc, float w, const double &x) {
+    double t;
+    asm("v_cvt_f64_f32 %1, %2\n\tv_mul_f64 %0, %1, %3" : "=v"(acc), "=&v"(t) : "v"(w), "v"(x));
+}
+
+template <int K2, int KA, int D>
+__device__ __forceinline__ void dpair_one(const mm_f32x2 (&wr)[KA / 2], const unsigned (&ar)[KA], double (&x)[2 * D], double &accA, unsigned rdoff) {
+    constexpr int s0 = (2 * K2) % (2 * D);
+    d_fma_w(accA, wr[K2].x, x[s0]);
+    d_fma_w(accA, wr[K2].y, x[s0 + 1]);
+    if constexpr (2 * (K2 + D) < KA) {
+        x[s0] = ldsr_d(ar[2 * (K2 + D)] + rdoff);
+        x[s0 + 1] = ldsr_d(ar[2 * (K2 + D) + 1] + rdoff);
+    }
+}
+// two pairs in straight-line code: pair K2 to the running sum, pair K2 + 1 to a sum of its own (pair_two)
+template <int K2, int KA, int D>
+__device__ __forceinline__ void dpair_two(const mm_f32x2 (&wr)[KA / 2], const unsigned (&ar)[KA], double (&x)[2 * D], double &accA, double &accN,
+                                          unsigned rdoff) {
+    constexpr int s0 = (2 * K2) % (2 * D), s1 = (2 * K2 + 2) % (2 * D);
+    d_fma_w(accA, wr[K2].x, x[s0]);
+    d_mul_w(accN, wr[K2 + 1].x, x[s1]);
+    d_fma_w(accA, wr[K2].y, x[s0 + 1]);
+    d_fma_w(accN, wr[K2 + 1].y, x[s1 + 1]);
+    if constexpr (2 * (K2 + D) < KA) {
+        x[s0] = ldsr_d(ar[2 * (K2 + D)] + rdoff);
+        x[s0 + 1] = ldsr_d(ar[2 * (K2 + D) + 1] + rdoff);
+    }
+    if constexpr (2 * (K2 + 1 + D) < KA) {
+        x[s1] = ldsr_d(ar[2 * (K2 + 1 + D)] + rdoff);
+        x[s1 + 1] = ldsr_d(ar[2 * (K2 + 1 + D) + 1] + rdoff);
+    }
+}
+#define MM_DPAIR_ONE(k)                                                                   \
+    if constexpr (2 * (k) < KA) {                                                         \
+        dpair_one<(2 * (k) < KA ? (k) : 0), KA, D>(rg.w2, rg.a, x, accA, rdoff);          \
+        if (MM_PAIR_END(k)) finish();                                                     \
+    }
+#define MM_DPAIR_TWO(k)                                                                   \
+    if constexpr (2 * (k) + 2 < KA) {                                                     \
+        dpair_two<(2 * (k) + 2 < KA ? (k) : 0), KA, D>(rg.w2, rg.a, x, accA, accN, rdoff); \
+        if (__builtin_expect(((((k) < 32 ? em_lo : em_hi) >> ((k) & 31)) & 3u) != 0u, 0)) { \
+            if (MM_PAIR_END(k)) finish();                                                 \
+            accA += accN;                                                                 \
+            accN = 0.0;                                                                   \
+            if (MM_PAIR_END((k) + 1)) finish();                                           \
+        }                                                                                 \
+        accA += accN;                                                                     \
+    } else {                                                                              \
+        MM_DPAIR_ONE(k)                                                                   \
+        MM_DPAIR_ONE((k) + 1)                                                             \
+    }
+
+#define MM_DPAIR_THR_EXTRA 896.f  // the double's normal range (1022) over the float's (126)
+
+// One agent: direction DIR (0: forward / alpha, 1: backward / beta) of the utterance of rank `ui` (longest first), phase
+// PHASE (0: A, 1: B).  The structure, the step numbering and the LDS layout are pair_agent's (mm_kernel_pairs.hip).
+template <int KA, int RS, int PHASE, int DIR, int NJ>
+__device__ __forceinline__ void dpair_agent(const RunParams &p, int ui) {
+    extern __shared__ float lds[];
+    constexpr int RSH = 2 * RS;
+    using L = PairLay<RS, PHASE, RSH>;
+    constexpr int D = 3;  // gather pairs in flight ahead of the FMAs
+    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, NWC = NW - 1;
+    const bool service = wave == NWC;
+    // ---- the utterance
+    const int b = uni(p.order ? p.order[ui] : ui);
+    if (uni(p.redo[b]) == 0) return;  // (not marked by the float32 kernels: their result stands)
+    if (service) __builtin_amdgcn_s_setprio(3);
+    int len = uni(p.lens ? p.lens[b] : p.N);
+    len = len < 0 ? 0 : (len > p.N ? p.N : len);
+    const float *Vb = p.V + (long long)b * p.vsb;
+    double *offs = p.ws_c + (long long)b * (p.N + 2);  // [N + 2] cumulative offset of the stored vector of every frame
+    const int NFp = len + 1;
+    const UttDesc &ud = p.utts[b];
+    const RowU r = uni(ud.rp[DIR]);
+    const int S1 = r.rows, S1p = p.pair_s1p, P1 = uni(ud.P1), P = P1 - 1, P1p = (P1 + 3) & ~3;
+    // state vectors of the utterance's frames (alpha~ up to the split, beta~ beyond): float32 log2 values [N + 2][S1p]
+    float *rowsP = p.ws_alpha + (long long)b * (long long)(p.N + 2) * S1p;
+    const float thr = r.thr + MM_DPAIR_THR_EXTRA;
+    int m = NFp / 2;
+    m = m < 1 ? 1 : m;
+    const int tA = DIR ? NFp - m : m, tEnd = NFp;
+    auto frame_of = [&](int t) { return DIR ? NFp + 1 - t : t; };
+    PairHand *hand = reinterpret_cast<PairHand *>(p.pair_hand) + ((long long)b * 2 + DIR);
+    if (lds_addr_of(lds) != 0u) __builtin_trap();
+    MM_STAMP_DECL;
+
+    // ---- LDS set-up
+    for (unsigned q = tid * 4u; q < 2u * L::RS2; q += NT * 4u) ldsw(L::PP(0) + q, 0.f);
+    if constexpr (PHASE == 1)
+        for (unsigned q = tid * 4u; q < 2u * RSH; q += NT * 4u) ldsw(L::Q(0) + q, 0.f);
+    if (tid < 32) ldsw(L::MS(0) + 4u * tid, 0.f);
+    if (tid < 4) ldsw(L::EM(tid >> 1) + 8u * P1p + 4u * (tid & 1), MM_NINF);  // the emission slot of lanes without a row
+    const int nslotwords = r.nslotrows * 128;
+    for (int q = tid; q < nslotwords; q += NT) ldswu(L::SLOTS + 4u * q, as_global(r.slots)[q]);
+    if constexpr (PHASE == 1)
+        for (int q = tid; q < P1; q += NT) ldswu(L::PDFSE + 4u * q, as_global(reinterpret_cast<const unsigned *>(r.pdfse))[q]);
+    int *redo2 = p.redo2 + b;
+    unsigned long long endmask = 0, lgw0 = 0;
+    int nslots = 0;
+    unsigned slot_base = 0;
+    if (!service && wave < r.NWC) {
+        const RowSched &sc = r.sched[wave];
+        endmask = sc.endmask;
+        lgw0 = sc.lg;
+        nslots = (int)(sc.nslots & 0xffffu);
+        slot_base = L::SLOTS + (sc.slot0 * 64u + lane) * 8u;
+    }
+    unsigned em_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)endmask);
+    unsigned em_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(endmask >> 32));
+    const int lastp = PHASE ? 63 : (em_hi ? 63 - __builtin_clz(em_hi) : (em_lo ? 31 - __builtin_clz(em_lo) : -1));
+    lgw0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(lgw0 >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((unsigned)lgw0);
+    nslots = __builtin_amdgcn_readfirstlane(nslots);
+    PairRegs<KA> rg;
+    auto load_graph = [&]() {
+        static_assert(KA <= MM_ROW_KA_PAD, "register window larger than the padding of the device arrays");
+        const int nt = 64 * r.NWC;
+        const bool mine = wave < r.NWC;
+        const auto wp = as_global(r.w);
+        const auto ap = as_global(r.addr);
+        const int t0 = mine ? tid : 0;
+#pragma unroll
+        for (int k = 0; k < KA; ++k) {
+            if (k & 1) rg.w2[k / 2].y = wp[k * nt + t0];
+            else rg.w2[k / 2].x = wp[k * nt + t0];
+            rg.a[k] = ap[k * nt + t0];
+        }
+        if (!mine) {
+#pragma unroll
+            for (int k = 0; k < KA; ++k) {
+                if (k & 1) rg.w2[k / 2].y = 0.f;
+                else rg.w2[k / 2].x = 0.f;
+                rg.a[k] = 0u;
+            }
+        }
+    };
+    // steps of this launch: (t0, t1]; the vector of step t0 is the starting point
+    const int t0 = PHASE ? tA : 1, t1 = PHASE ? tEnd : tA;
+    __syncthreads();
+
+    if (service) {
+        // ================= service wave =================
+        int sl = lane;
+        RowNorm norm;
+        double cum = 0.0, zmin = __builtin_inf(), zmax = -__builtin_inf();
+        float ltmin = __builtin_inff();  // smallest log2 of a frame's sum of 2^(a~ + b~) (see mm_dpair_finish_kernel)
+        auto dma_raw = [&](int t) {  // raw emissions of step t (clamped) -> RAW(t & 3, 0)
+            const int tt = t < 1 ? 1 : (t > tEnd ? tEnd : t);
+            row_dma_em<NJ>(L::RAW(0, 0) + 2048u * (t & 3), Vb, p.vsn, frame_of(tt), p.N, P, sl);
+        };
+        constexpr int NDM = RSH / 2048;  // 1 KB DMAs of a row of floats
+        auto dma_partner = [&](int t) {  // the other agent's vector + offset of step t's frame -> AL(t % 3), POFF(t & 7, 0)
+            const int tt = t < 1 ? 1 : (t > tEnd ? tEnd : t);
+            int f = frame_of(tt);
+            f = f > p.N ? p.N : f;  // (frame N+1 is never combined)
+            const int n4 = S1p >> 2;  // float4s of the row
+            const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(rowsP + (long long)f * S1p);
+            const unsigned dst = L::AL(0) + (unsigned)(tt % 3) * (unsigned)RSH;
+#pragma unroll
+            for (int j = 0; j < NDM; ++j) {
+                const int q = sl + 64 * j;
+                dma_b128(src + (q < n4 ? q : 0), dst + 1024u * j);
+            }
+            dma_b32(reinterpret_cast<const unsigned *>(offs + f) + (sl & 1), L::POFF(0, 0) + 512u * (t & 7));
+        };
+        constexpr int NDMA = NJ + (PHASE ? NDM + 1 : 0);  // DMAs issued per step
+        // stage the emissions of step t into EM(t & 1) and account its offset; S = the normaliser the step subtracts
+        auto stage = [&](int t, float S) {
+            const float E = pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, 0) + 2048u * (t & 3), 0, frame_of(t), len, P, sl);
+            cum += (double)S + (double)E;
+            if (sl == 0) {
+                ldsw(L::MS(t & 1), S);
+                // the offset that turns the step's stored vector into log2 values: forward alpha~ includes the emission
+                const double off = DIR ? cum - (double)E : cum;
+                *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(L::OWN(t & 3)) = off;
+                if (PHASE == 0) offs[frame_of(t)] = off;
+            }
+        };
+        // ---- prologue: everything step t0 + 1 needs
+        for (int t = t0; t <= t0 + 3; ++t) dma_raw(t);
+        if constexpr (PHASE == 1) {
+            dma_partner(t0 + 1);
+            dma_partner(t0 + 2);
+            const PairHand h = hand[0];
+            norm.m_prev = h.m_prev;
+            norm.s_cur = h.s_cur;
+            norm.s_prev = h.s_prev;
+            norm.cbar = h.cbar;
+            norm.seen = h.seen;
+            cum = h.cum;
+        }
+        MM_ROW_VMCNT(0);
+        if (PHASE == 0 || DIR == 1) {  // emissions of the starting step
+            const float E = pair_stage_em<NJ>(L::EM(t0 & 1), L::RAW(0, 0) + 2048u * (t0 & 3), 0, frame_of(t0), len, P, sl);
+            if (PHASE == 0) {  // step 1 subtracts nothing but E
+                cum = (double)E;
+                if (DIR == 0 && sl == 0) offs[1] = cum;
+            }
+        }
+        __syncthreads();  // (1) emissions of step t0 staged
+        if (t0 + 1 <= t1) stage(t0 + 1, norm.s_cur);  // (phase A: 0 -- step 2 subtracts nothing but E)
+        dma_raw(t0 + 4);
+        __syncthreads();  // (2) starting vector in LDS, step t0 + 1 prepared
+        // posteriors and per-frame log Z of step ts (its per-pdf sums are complete)
+        auto frames_of_step = [&](int ts, unsigned psum) {
+            const int f = frame_of(ts);
+            const bool live = f >= 1 && f <= len;
+            const float lt = dpair_finish_frame<NJ>(psum, P1, P, sl, p.gamma + (long long)b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp, live);
+            if (live) {
+                const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN(ts & 3));
+                const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, 0) + 512u * (ts & 7));
+                const double z = (double)lt + own + oth;
+                zmin = z < zmin ? z : zmin;
+                zmax = z > zmax ? z : zmax;  // (NaN: neither comparison holds; the finish kernel tests zmin <= zmax)
+                ltmin = lt < ltmin ? lt : ltmin;
+            }
+        };
+        auto step = [&](auto RDc, int t) {
+            constexpr int RD = decltype(RDc)::value, WR = 1 - RD;  // RD = parity of steps t - 1 and t + 1
+            if constexpr (NJ > 2) asm volatile("" : "+v"(sl));
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            MM_STAMP(2);
+            // the normaliser of step t + 1 from the maximum of step t - 1 (complete since the last barrier)
+            const float mx = dpair_scan_max<(RS / 8 + 63) / 64>(L::PP(RD), (S1 + 2) >> 1, sl);
+            MM_STAMP(3);
+            if (t + 1 <= tEnd) {
+                const float S = norm.next(mx);
+                if (t + 1 <= t1) stage(t + 1, S);
+            }
+            MM_STAMP(4);
+            dma_raw(t + 4);
+            if constexpr (PHASE == 1) {
+                dma_partner(t + 2);
+                MM_STAMP(5);
+                if (t - 2 > t0) frames_of_step(t - 2, L::PSUM(WR));  // gamma of step t - 2: its per-pdf sums were completed in the previous step
+                MM_STAMP(6);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");  // the partner vector of step t + 1 (requested at step t - 1)
+                MM_STAMP(7);
+            }
+            MM_STAMP(0);
+            MM_STEP_SYNC();
+            MM_STAMP(1);
+        };
+        MM_STAMP_RESET;
+        for (int t = t0 + 1; t <= t1; t += 2) {
+            if (t & 1) step(std::integral_constant<int, 0>{}, t);
+            else step(std::integral_constant<int, 1>{}, t);
+            if (t + 1 <= t1) {
+                if ((t + 1) & 1) step(std::integral_constant<int, 0>{}, t + 1);
+                else step(std::integral_constant<int, 1>{}, t + 1);
+            }
+        }
+        if constexpr (PHASE == 0) {
+            if (sl == 0) {
+                PairHand h;
+                h.m_prev = norm.m_prev;
+                h.s_cur = norm.s_cur;
+                h.s_prev = norm.s_prev;
+                h.cbar = norm.cbar;
+                h.seen = norm.seen;
+                h.pad = 0;
+                h.cum = cum;
+                hand[0] = h;
+            }
+        } else {
+            // the last two steps' posteriors: (a) sums of step t1 by the compute waves, gamma of step t1 - 1 here; (b) gamma of step t1
+            MM_ROW_VMCNT(0);
+            for (int k = 1; k >= 0; --k) {
+                const int t = t1 - k;
+                if (k == 0) __syncthreads();  // (a)
+                if (t > t0) frames_of_step(t, L::PSUM(t & 1));
+            }
+            if (sl == 0) {
+                p.pair_zmin[(long long)b * 6 + DIR] = zmin;
+                p.pair_zmin[(long long)b * 6 + 2 + DIR] = zmax;
+                p.pair_zmin[(long long)b * 6 + 4 + DIR] = (double)ltmin;
+            }
+        }
+    } else {
+        // ================= compute waves =================
+        __syncthreads();  // (1)
+        // the starting vector (step t0)
+        if (PHASE == 0 && DIR == 0) {  // alpha_hat (*) lhs[:,1]   (src/inference.jl:68)
+            for (int i = tid; i < S1; i += 64 * NWC) {
+                const unsigned pdfi = as_global(r.rowpdf)[i];
+                const float v0 = as_global(r.init)[i] + ldsr(L::EM(1) + 8u * pdfi);
+                if (row_out_of_range(v0, thr)) *redo2 = 1;
+                ldsw_d(L::PP(1) + 8u * i, dexp2(v0));
+                rowsP[(long long)1 * S1p + i] = v0;
+            }
+        } else if (DIR == 1 && t0 == 1) {  // B[:, N+1] = one at the final state   (src/inference.jl:104)
+            if (tid == 0) ldsw_d(L::PP(1) + 8u * r.fpos, 1.0);
+        } else {  // phase B: the vector this agent stored at the end of phase A
+            const int f = frame_of(t0);
+            for (int i = tid; i < S1; i += 64 * NWC) {
+                float v0 = rowsP[(long long)f * S1p + i];
+                if (DIR == 1) v0 += ldsr(L::EM(t0 & 1) + 8u * as_global(r.rowpdf)[i]);  // beta~ is stored without the frame's emission
+                ldsw_d(L::PP(t0 & 1) + 8u * i, dexp2(v0));
+            }
+        }
+        load_graph();
+        __syncthreads();  // (2)
+        auto step = [&](auto RDc, int t) {
+            constexpr int RD = decltype(RDc)::value, WR = 1 - RD;
+            if (nslots > 0) {
+                constexpr unsigned rdoff = L::PP(RD);
+                double x[2 * D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) {  // the first gathers leave before anything else
+                    x[2 * j] = ldsr_d(rg.a[(2 * j < KA) ? 2 * j : 0] + rdoff);
+                    x[2 * j + 1] = ldsr_d(rg.a[(2 * j + 1 < KA) ? 2 * j + 1 : 0] + rdoff);
+                }
+                // the slot table runs one segment ahead (infoN / info2N): see pair_agent
+                unsigned sa = slot_base;
+                unsigned info, info2 = 0u, infoN, info2N = 0u;
+                if constexpr (PHASE == 1) {
+                    const mm_u32x2 w0 = ldsr2u(sa), w1 = ldsr2u(sa + 512u);
+                    info = w0.x;
+                    info2 = w0.y;
+                    infoN = w1.x;
+                    info2N = w1.y;
+                } else {
+                    info = ldsru(sa);
+                    infoN = ldsru(sa + 512u);
+                }
+                const float S = ldsr(L::MS(WR));  // the step's normaliser, posted by the service wave
+                float e = ldsr((info >> 16) + L::EM(WR));
+                const int f = frame_of(t);
+                const unsigned alb = L::AL(0) + (unsigned)(t % 3) * (unsigned)RSH;
+                float al = 0.f;
+                if constexpr (PHASE == 1) al = ldsr(((info2 & 0xffffu) >> 1) + alb);
+                float *rowP = rowsP + (long long)(f <= p.N ? f : 0) * S1p;
+                float worst = 0.f;
+                double accA = 0.0, accN = 0.0;
+                unsigned long long lgw = lgw0;
+                auto finish = [&]() {
+                    const int lg = (int)(lgw & 15ull);
+                    lgw >>= 4;
+                    double s0 = accA;
+                    if (lg) s0 = dgrp_sum_last(s0, lg);
+                    const unsigned pos8 = info & 0xffffu;
+                    // forward: (T' alpha) (*) lhs (src/inference.jl:70-71); backward: T (B (*) lhs) (:106-107), the emission is
+                    // added for the next step's product only
+                    const float b0 = dlog2(s0) - S;
+                    const float y0 = b0 + e;
+                    // range check, deferred to the end of the step: the largest finite |y| of the lane (NaN for -inf: ignored)
+                    worst = __builtin_fmaxf(worst, __builtin_fmaf(__builtin_fabsf(y0), 0.f, __builtin_fabsf(y0)));
+                    ldsw_d(pos8 + L::PP(WR), dexp2(y0));
+                    const float st0 = DIR ? b0 : y0;  // the vector that is stored / combined
+                    if constexpr (PHASE == 0) {
+                        *reinterpret_cast<float *>(reinterpret_cast<char *>(rowP) + (pos8 >> 1)) = st0;
+                    } else {
+                        ldsw_d((info2 >> 16) + L::Q(WR), dexp2(st0 + al));  // A .* B   (:154)
+                    }
+                    accA = 0.0;
+                    sa += 512u;
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(info) : "v"(infoN));
+                    e = ldsr((info >> 16) + L::EM(WR));
+                    if constexpr (PHASE == 1) {
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(info2) : "v"(info2N));
+                        al = ldsr(((info2 & 0xffffu) >> 1) + alb);
+                        const mm_u32x2 w1 = ldsr2u(sa + 512u);
+                        infoN = w1.x;
+                        info2N = w1.y;
+                    } else {
+                        infoN = ldsru(sa + 512u);
+                    }
+                };
+                asm volatile("" : "+s"(em_lo), "+s"(em_hi));
+                __builtin_amdgcn_s_setprio(2);
+                MM_PAIR_CASES(MM_DPAIR_TWO)
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(worst > thr) != 0ull, 0)) *redo2 = 1;
+            }
+            if constexpr (PHASE == 1)  // C' * (A .* B) of the previous step (:155)
+                if (t - 1 > t0) dpair_pdf_sums(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane);
+            MM_STAMP(0);
+            MM_STEP_SYNC();
+            MM_STAMP(1);
+        };
+        MM_STAMP_RESET;
+        for (int t = t0 + 1; t <= t1; t += 2) {
+            if (t & 1) step(std::integral_constant<int, 0>{}, t);
+            else step(std::integral_constant<int, 1>{}, t);
+            if (t + 1 <= t1) {
+                if ((t + 1) & 1) step(std::integral_constant<int, 0>{}, t + 1);
+                else step(std::integral_constant<int, 1>{}, t + 1);
+            }
+        }
+        if constexpr (PHASE == 1) {
+            if (t1 > t0) dpair_pdf_sums(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane);
+            __syncthreads();  // (a)
+        }
+    }
+#ifdef MM_STAMPS
+    if (p.dbg && lane == 0)  // [utterance][wave][phase * 2 + dir][work, barrier]
+        for (int k = 0; k < 2; ++k) p.dbg[(((long long)ui * MM_MAX_WAVES + wave) * 4 + PHASE * 2 + DIR) * 2 + k] = stamp_acc[k];
+#endif
+}
+
+// mm_pair_finish_kernel for the utterances the double kernels computed (redo[b] != 0 on entry): ttl = min over both agents'
+// frames, zeros beyond len_b, and what a range mark of the double kernels (redo2[b]) means -- the same two criteria on the
+// double's range: the per-frame normalisers must agree (nothing that matters for log Z was flushed), and with the smallest
+// overlap term L_n >= floor_d no posterior above the floor can have been lost (a flushed term was below 2^-1022 of its
+// frame's scale).  redo2[b] becomes 0 (the result stands) or stays (the exact log-domain kernels compute the utterance);
+// redo[b] keeps saying which utterances the float64 kernels computed (mm_batch_last_redo_count).
+static __global__ void mm_dpair_finish_kernel(RunParams p) {
+    const int b = blockIdx.x;
+    if (p.redo[b] == 0) {
+        if (p.stat_mode == 1 && threadIdx.x == 0) report_hard(p, 0);
+        return;
+    }
+    int len = p.lens ? p.lens[b] : p.N;
+    len = len < 0 ? 0 : (len > p.N ? p.N : len);
+    const int P = p.utts[b].P1 - 1;
+    if (threadIdx.x == 0) {
+        const double z0 = p.pair_zmin[6 * b], z1 = p.pair_zmin[6 * b + 1];
+        const double z = z0 < z1 ? z0 : z1;
+        const double y0 = p.pair_zmin[6 * b + 2], y1 = p.pair_zmin[6 * b + 3];
+        const double zM = y0 > y1 ? y0 : y1;
+        const double l0 = p.pair_zmin[6 * b + 4], l1 = p.pair_zmin[6 * b + 5];
+        const double lm = l0 < l1 ? l0 : l1;
+        p.ttl[b] = (z < __builtin_inf()) ? (float)(z * (double)MM_LN2) : MM_NINF;  // (no frame: no path of length 0)
+        const bool agree = z > -__builtin_inf() && zM < __builtin_inf() && zM - z <= MM_Z_SPREAD_TOL;
+        // (no mark: the result stands, like an unmarked utterance of the float32 kernels); redo2[b] != 0 afterwards: the
+        // log-domain kernels compute the utterance
+        if (p.redo2[b] != 0 && agree && lm >= (double)p.lt_floor - (double)MM_DPAIR_THR_EXTRA) p.redo2[b] = 0;
+        // (a call that skipped the float32 kernels: would they have coped?  Not with an overlap term below their floor)
+        if (p.stat_mode == 1) report_hard(p, !(lm >= (double)p.lt_floor));
+    }
+    const long long gbase = (long long)b * p.gsb;
+    for (long long q = threadIdx.x; q < (long long)(p.N - len) * P; q += blockDim.x)
+        p.gamma[gbase + (len + q / P) * p.gsn + (q % P) * p.gsp] = 0.f;
+}
+
+}  // namespace mm

@@ -1309,7 +1309,9 @@ static __global__ void mm_pair_finish_kernel(RunParams p) {
         const double l0 = p.pair_zmin[6 * b + 4], l1 = p.pair_zmin[6 * b + 5];
         const double lm = l0 < l1 ? l0 : l1;
         p.ttl[b] = (z < __builtin_inf()) ? (float)(z * (double)MM_LN2) : MM_NINF;  // (no frame: no path of length 0)
-        if (p.redo[b] == 1 && z > -__builtin_inf() && zM < __builtin_inf() && zM - z <= MM_Z_SPREAD_TOL && lm >= (double)p.lt_floor) p.redo[b] = 0;
+        int mark = p.redo[b];
+        if (mark == 1 && z > -__builtin_inf() && zM < __builtin_inf() && zM - z <= MM_Z_SPREAD_TOL && lm >= (double)p.lt_floor) p.redo[b] = mark = 0;
+        if (p.stat_mode == 0) report_hard(p, mark != 0);
     }
     const long long gbase = (long long)b * p.gsb;
     for (long long q = threadIdx.x; q < (long long)(p.N - len) * P; q += blockDim.x)

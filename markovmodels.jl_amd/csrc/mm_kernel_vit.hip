@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(1024) mm_vit_kernel(RunParams p) {
 // rows of the frames travel to LDS in chunks of R frames, double buffered, by LDS-DMA of waves 1..7 (everything of a chunk
 // in flight at once: the copy is bound by bandwidth, not by the latency of a load); wave 0 chases the chunk that is
 // there.  CSRL: the graph's row pointers and sources (positions) are in LDS as well, a hop is three LDS reads.
-// LDS: ring [2][R][RSB] bytes (RSB = the row padded to 256 bytes), then [rowptr (S1 + 1) u32][col (arcs) u16].
+// LDS: ring [2][R * RSB + 1024] bytes (RSB = the row padded to 256 bytes), then [rowptr (S1 + 1) u32][col (arcs) u16].
 template <bool CSRL>
 __global__ void __launch_bounds__(512) mm_vit_backtrace_kernel(RunParams p, int R, int RSB) {
     extern __shared__ float lds[];
@@ -305,7 +305,9 @@ __global__ void __launch_bounds__(512) mm_vit_backtrace_kernel(RunParams p, int 
     if (lds_addr_of(lds) != 0u) __builtin_trap();
     const unsigned char *bpk = reinterpret_cast<const unsigned char *>(p.bp) + (long long)b * (p.N + 1) * p.bp_stride_n;  // (bp_stride_n == RSB)
     const int arcs = r.rowptr[S1];
-    const unsigned ringb = 2u * (unsigned)R * (unsigned)RSB;
+    // (a chunk is copied by 1 KB DMAs and need not end on one -- RSB is a multiple of 256: every buffer of the ring has 1 KB to spare)
+    const unsigned RB = (unsigned)R * (unsigned)RSB + 1024u;
+    const unsigned ringb = 2u * RB;
     unsigned *lrp = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(lds) + ringb);
     unsigned short *lcol = reinterpret_cast<unsigned short *>(lrp + S1 + 1);
     if (CSRL) {
@@ -318,8 +320,9 @@ __global__ void __launch_bounds__(512) mm_vit_backtrace_kernel(RunParams p, int 
         if (wave == 0) return;
         const int lo = hi - R + 1 < 1 ? 1 : hi - R + 1;  // first frame whose row exists
         const unsigned char *src0 = bpk + (long long)(lo - 1) * RSB;
-        const unsigned dst0 = (unsigned)buf * (unsigned)R * (unsigned)RSB + (unsigned)(lo - (hi - R + 1)) * (unsigned)RSB;
-        const int nd = (hi - lo + 1) * (RSB >> 10) + ((((hi - lo + 1) * RSB) & 1023) ? 1 : 0);  // 1 KB DMAs (RSB is a multiple of 256)
+        const unsigned dst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)buf * RB + (unsigned)(lo - (hi - R + 1)) * (unsigned)RSB));
+        const int nd = ((hi - lo + 1) * RSB + 1023) >> 10;  // 1 KB DMAs (the last may run up to 768 bytes past the chunk: the spare KB here, the
+                                                            // next rows of the workspace -- which ends with a spare KB too -- there)
         for (int d = wave - 1; d < nd; d += NW - 1) dma_b128(src0 + 1024ll * d + 16 * lane, dst0 + 1024u * (unsigned)d);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
@@ -330,7 +333,7 @@ __global__ void __launch_bounds__(512) mm_vit_backtrace_kernel(RunParams p, int 
     for (int hi = len + 1; hi >= 2; hi -= R, ++cidx) {
         if (hi - R >= 2) copy_chunk(hi - R, (cidx + 1) & 1);
         if (tid == 0) {
-            const unsigned char *cur = reinterpret_cast<const unsigned char *>(lds) + (size_t)(cidx & 1) * R * RSB;
+            const unsigned char *cur = reinterpret_cast<const unsigned char *>(lds) + (size_t)(cidx & 1) * RB;
             for (int k = 0; k < R; ++k) {
                 const int f = hi - k;  // the frame whose back-pointer is followed: state at f -> state at f - 1
                 if (f < 2) break;

@@ -131,6 +131,17 @@ struct RunParams {
     // Row kernels: redo[b] != 0 marks an utterance whose linear-domain sums left the trusted range; the exact kernels
     // launched after them skip every utterance that is not marked (NULL: run all).
     int *redo;
+    // The float64 exact pair kernels (mm_kernel_dpair.hip) run the utterances marked in `redo` and mark in `redo2` the ones
+    // whose values left the DOUBLE's range; mm_dpair_finish_kernel then clears or keeps redo[b] for the log-domain kernels.
+    int *redo2;
+    // How hard the inputs of this call were for the float32 kernels, for the engine's choice at the NEXT calls (no
+    // synchronisation: the host reads whatever the last finished call left): stat_dev = {count, ticket} device counters,
+    // stat_host = {count, stat_seq} in pinned host memory, written by the last workgroup of the finish kernel that reports --
+    // stat_mode 0: mm_pair_finish_kernel (utterances still marked after its decision), 1: mm_dpair_finish_kernel on a call
+    // that skipped the float32 kernels (utterances whose smallest overlap term is below the float32 kernels' floor).
+    int *stat_dev;
+    volatile int *stat_host;
+    int stat_seq, stat_mode;
     // Pair kernels (mm_kernel_pairs.hip): ws_alpha holds [B + 1][N + 2][pair_s1p] state vectors, ws_c [B + 1][N + 2]
     // cumulative offsets; pair_hand [pairs][2 directions][2 utterances] what phase A hands to phase B; pair_zmin
     // [B][2 directions] the minimum over the frames of the per-frame log2 normaliser.
@@ -148,6 +159,22 @@ struct RunParams {
     int x_sleep;                // the exchange wave sleeps this many x 64 clocks before its first poll of a step
     float lt_floor;             // mm_pair_finish_kernel: smallest accepted log2 overlap term of a frame (mm_batch_set_posterior_floor)
 };
+
+// one thread per workgroup of a finish kernel: add `hard` to the call's count; the last workgroup publishes it to the host
+__device__ __forceinline__ void report_hard(const RunParams &p, int hard) {
+    if (!p.stat_dev) return;
+    atomicAdd(&p.stat_dev[0], hard);
+    __threadfence();
+    if (atomicAdd(&p.stat_dev[1], 1) == (int)gridDim.x - 1) {
+        __threadfence();
+        const int total = atomicAdd(&p.stat_dev[0], 0);
+        p.stat_dev[0] = 0;
+        p.stat_dev[1] = 0;
+        p.stat_host[0] = total;
+        p.stat_host[1] = p.stat_seq;
+        __threadfence_system();
+    }
+}
 
 // In-kernel cycle stamps (diagnostic build only; the shipped library executes none).
 #ifdef MM_STAMPS

@@ -34,12 +34,12 @@ int mm_launch_viterbi(const VitLaunch &vl, const RunParams &p, hipStream_t strea
     const int RSB = vl.bp_row;  // (the row stride the forward kernel wrote with)
     const size_t csr = (size_t(vl.max_S1p + 1) * 4 + size_t(vl.max_arcs) * 2 + 15) & ~size_t(15);
     const size_t budget = 160 * 1024;
-    const bool csrl = csr + 2 * 4 * size_t(RSB) <= budget;
-    const size_t room = budget - (csrl ? csr : 0);
+    const bool csrl = csr + 2 * (4 * size_t(RSB) + 1024) <= budget;
+    const size_t room = budget - (csrl ? csr : 0) - 2 * 1024;  // (every buffer of the ring has a spare KB: mm_vit_backtrace_kernel)
     int R = int(room / (2 * size_t(RSB)));
     R = R > 64 ? 64 : R;
     if (R < 1) return mm_fail(MM_ERR_UNSUPPORTED, "Viterbi back-trace: a row of back-pointers does not fit the LDS");
-    const size_t lds = (csrl ? csr : 0) + 2 * size_t(R) * size_t(RSB);
+    const size_t lds = (csrl ? csr : 0) + 2 * (size_t(R) * size_t(RSB) + 1024);
     if (csrl) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mm_vit_backtrace_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         hipLaunchKernelGGL(mm_vit_backtrace_kernel<true>, dim3(unsigned(vl.B)), dim3(512), lds, stream, p, R, RSB);

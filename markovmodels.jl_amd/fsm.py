@@ -346,4 +346,6 @@ class GeneralStateMap:
         last pdf), else None."""
         if (np.diff(self.indptr) != 1).any() or (self.data != _ONE[self.semiring]).any() or self.indices[-1] != self.numpdf:
             return None
+        if (self.indices[:-1] >= self.numpdf).any():  # (a real state on the phony pdf: not what StateMap describes)
+            return None
         return StateMap(self.indices[:-1], self.numpdf)

@@ -51,6 +51,9 @@ class CompiledFSM:
         self.semiring = fsm.semiring
         self.S1 = fsm.S1
         self.P1 = C_hat.numpdf + 1
+        # K of FSM{K}: the precision of the computation follows the FSM's, like the reference (src/inference.jl:147 converts
+        # V_hat to K)
+        self.dtype = np.dtype(np.float64) if np.asarray(fsm.nzval).dtype == np.float64 else np.dtype(np.float32)
         colptr = np.ascontiguousarray(fsm.colptr, dtype=np.int64)
         rowval = np.ascontiguousarray(fsm.rowval, dtype=np.int64)
         nzval = np.ascontiguousarray(fsm.nzval, dtype=np.float32 if fsm.nzval.dtype != np.float64 else np.float64)
@@ -176,6 +179,7 @@ class BatchedFSM:
         check(lib.mm_batch_create(arr, self.B, C.byref(h)))
         self._h = h
         self.semiring = self.cfsms[0].semiring
+        self.dtype = np.dtype(np.float64) if any(c.dtype == np.float64 for c in self.cfsms) else np.dtype(np.float32)
         self.P = self.cfsms[0].P1 - 1
         if any(c.P1 != self.P + 1 for c in self.cfsms):
             raise _lib.DimensionMismatch(-2, "all FSMs of a batch must share the number of pdfs")
@@ -231,6 +235,33 @@ class BatchedFSM:
             return gamma.cpu().numpy(), ttl.cpu().numpy()
         return gamma, ttl
 
+    def reserve_ex(self, dtype, N1: int):
+        """Size the generic entry's workspace for V_hat of N1 = N + 1 columns (mm_batch_reserve_ex): before capturing
+        ``pdfposteriors_ex`` in a hipGraph."""
+        check(lib.mm_batch_reserve_ex(self._h, np.dtype(dtype).itemsize, int(N1)))
+
+    def pdfposteriors_ex(self, Vhat, maps=None, gamma=None, ttl=None):
+        """The generic entry, device resident and asynchronous like the fast one (mm_pdfposteriors_ex): ``Vhat`` a
+        float32 / float64 tensor [B, N1, P1] on the device (element (b, n, p) = V_hat_b[p, n]), ``maps`` None or a ctypes
+        array of B mm_statemap_t handles the caller keeps alive until the stream has run the call.  Returns the tensors
+        (gamma[B, N, P], ttl[B])."""
+        torch = _torch()
+        if not isinstance(Vhat, torch.Tensor) or not Vhat.is_cuda or Vhat.dtype not in (torch.float32, torch.float64):
+            raise TypeError("Vhat must be a float32 / float64 tensor on the HIP device")
+        if Vhat.dim() != 3 or Vhat.shape[0] != self.B or Vhat.stride(2) != 1:
+            raise _lib.DimensionMismatch(-2, f"Vhat must be [B={self.B}, N + 1, P + 1] with the pdfs contiguous, got {tuple(Vhat.shape)}")
+        _, N1, P1 = Vhat.shape
+        if gamma is None:
+            gamma = torch.zeros((self.B, N1 - 1, P1 - 1), dtype=Vhat.dtype, device=Vhat.device)
+        if ttl is None:
+            ttl = torch.zeros(self.B, dtype=Vhat.dtype, device=Vhat.device)
+        if gamma.dtype != Vhat.dtype or ttl.dtype != Vhat.dtype or tuple(gamma.shape) != (self.B, N1 - 1, P1 - 1) or ttl.numel() != self.B:
+            raise _lib.DimensionMismatch(-2, "gamma must be [B, N, P] and ttl [B] of V_hat's dtype")
+        check(lib.mm_pdfposteriors_ex(self._h, maps, Vhat.element_size(), P1, Vhat.data_ptr(), Vhat.stride(0), Vhat.stride(1), N1,
+                                      gamma.data_ptr(), gamma.stride(0), gamma.stride(1), gamma.stride(2), ttl.data_ptr(),
+                                      self._stream(torch)))
+        return gamma, ttl
+
     def pdfposteriors_generic(self, Vhats, Chats=None, dtype=None):
         """The generic entry (mm_pdfposteriors_ex): any semiring of the batch (log / tropical / prob), float32 or
         float64, any sparse state maps (``GeneralStateMap``; None: every FSM's own), any (P+1) x (N+1) matrices V_hat.
@@ -242,37 +273,45 @@ class BatchedFSM:
         if len(Vh) != self.B or any(v.shape != Vh[0].shape for v in Vh):
             raise _lib.DimensionMismatch(-2, "need B matrices V_hat of one (P+1) x (N+1) shape")
         P1, N1 = Vh[0].shape
-        dt = np.dtype(dtype) if dtype is not None else (np.dtype(np.float64) if Vh[0].dtype == np.float64 else np.dtype(np.float32))
+        # precision: the FSM's K unless asked for (src/inference.jl:147: copyto!(similar(V_hat, K), V_hat))
+        dt = np.dtype(dtype) if dtype is not None else self.dtype
+        if Chats is not None:  # raw matrices (dense / scipy.sparse) become GeneralStateMap; one-hot StateMap = the FSM's own
+            Chats = [c if (c is None or isinstance(c, (StateMap, GeneralStateMap))) else GeneralStateMap(c, self.semiring) for c in Chats]
+            if len(Chats) != self.B:
+                raise _lib.DimensionMismatch(-2, "need one C_hat per utterance")
+        for b in range(self.B):  # rows of V_hat against the pdfs of the map in force (src/inference.jl:146-150)
+            want = self.cfsms[b].P1 if (Chats is None or Chats[b] is None or isinstance(Chats[b], StateMap)) else Chats[b].shape[1]
+            if P1 != want:
+                raise _lib.DimensionMismatch(-2, f"V_hat has {P1} rows, the state map of utterance {b} has {want} pdfs "
+                                                 f"(P + 1: was expand() applied?)")
         V = torch.from_numpy(np.ascontiguousarray(np.stack([v.T for v in Vh]), dtype=dt)).cuda()  # [B][N1][P1]
-        gamma = torch.zeros((self.B, N1 - 1, P1 - 1), dtype=V.dtype, device=V.device)
-        ttl = torch.zeros(self.B, dtype=V.dtype, device=V.device)
         handles, keep = None, []
-        if Chats is not None:
-            arr = (ctypes.c_void_p * self.B)()
-            cache = {}
-            for b, c in enumerate(Chats):
-                if c is None or isinstance(c, StateMap):
-                    arr[b] = None
-                    continue
-                if c.shape != (self.cfsms[b].S1, P1):
-                    raise _lib.DimensionMismatch(-2, f"C_hat {b} is {c.shape}, expected {(self.cfsms[b].S1, P1)}")
-                if id(c) not in cache:
-                    hm = ctypes.c_void_p()
-                    ip, ix, dv = (np.ascontiguousarray(c.indptr, dtype=np.int64), np.ascontiguousarray(c.indices, dtype=np.int64),
-                                  np.ascontiguousarray(c.data, dtype=np.float64))
-                    check(lib.mm_statemap_create(SEMIRING_ID[self.semiring], c.shape[0], c.shape[1], ix.shape[0], 8, 0, 8,
-                                                 ip.ctypes.data, ix.ctypes.data, dv.ctypes.data, ctypes.byref(hm)))
-                    cache[id(c)] = hm
-                    keep.append(hm)
-                arr[b] = cache[id(c)]
-            handles = arr
         try:
-            check(lib.mm_pdfposteriors_ex(self._h, handles, dt.itemsize, V.data_ptr(), V.stride(0), V.stride(1), N1, gamma.data_ptr(),
-                                          gamma.stride(0), gamma.stride(1), gamma.stride(2), ttl.data_ptr(), self._stream(torch)))
+            if Chats is not None:
+                arr = (ctypes.c_void_p * self.B)()
+                cache = {}
+                for b, c in enumerate(Chats):
+                    if c is None or isinstance(c, StateMap):
+                        arr[b] = None
+                        continue
+                    if c.shape != (self.cfsms[b].S1, P1):
+                        raise _lib.DimensionMismatch(-2, f"C_hat {b} is {c.shape}, expected {(self.cfsms[b].S1, P1)}")
+                    if id(c) not in cache:
+                        hm = ctypes.c_void_p()
+                        ip, ix, dv = (np.ascontiguousarray(c.indptr, dtype=np.int64), np.ascontiguousarray(c.indices, dtype=np.int64),
+                                      np.ascontiguousarray(c.data, dtype=np.float64))
+                        check(lib.mm_statemap_create(SEMIRING_ID[self.semiring], c.shape[0], c.shape[1], ix.shape[0], 8, 0, 8,
+                                                     ip.ctypes.data, ix.ctypes.data, dv.ctypes.data, ctypes.byref(hm)))
+                        cache[id(c)] = hm
+                        keep.append(hm)
+                    arr[b] = cache[id(c)]
+                handles = arr
+            gamma, ttl = self.pdfposteriors_ex(V, handles)
+            return np.ascontiguousarray(gamma.cpu().numpy().transpose(0, 2, 1)), ttl.cpu().numpy()  # (waits for the kernel)
         finally:
+            torch.cuda.current_stream().synchronize()  # the call is asynchronous: the maps must outlive it
             for hm in keep:
                 lib.mm_statemap_destroy(hm)
-        return np.ascontiguousarray(gamma.cpu().numpy().transpose(0, 2, 1)), ttl.cpu().numpy()
 
     def _export(self, fn, V, lens):
         torch, Vt, lt, as_numpy = self._prep(V, lens)
@@ -317,6 +356,20 @@ class BatchedFSM:
         n = ctypes.c_int64(0)
         check(lib.mm_batch_last_redo_count(self._h, self._stream(_torch()), ctypes.byref(n)))
         return int(n.value)
+
+    def last_fallback_count(self) -> int:
+        """... and how many of those the float64 exact kernels handed on to the log-domain kernels (normally 0).
+        Synchronises the current stream."""
+        import ctypes
+
+        n = ctypes.c_int64(0)
+        check(lib.mm_batch_last_fallback_count(self._h, self._stream(_torch()), ctypes.byref(n)))
+        return int(n.value)
+
+    def last_exact_first(self) -> bool:
+        """True if the last pdfposteriors call skipped the float32 kernels (the inputs of the call before were hard: the
+        float64 exact kernels then run the whole batch at once)."""
+        return bool(lib.mm_batch_last_exact_first(self._h))
 
     def kernels(self, semiring: str = "log") -> str:
         """The kernels the engine launches for this batch (informational)."""
@@ -430,9 +483,11 @@ def pdfposteriors(fsm, Vhats, Chats=None):
         Chats = [(c.one_hot() or c) if isinstance(c, GeneralStateMap) else c for c in Chats]
     bf = _as_batch(fsm, Chats)
     general_c = Chats is not None and any(isinstance(c, GeneralStateMap) for c in Chats)
-    un = None if (general_c or bf.semiring == "prob" or Vh[0].dtype == np.float64) else _unexpand(Vh)
+    # the precision follows the FSM's K like the reference (src/inference.jl:147 converts V_hat to K): a Float32 FSM computes
+    # in float32 whatever the dtype of V_hat (NumPy's default float64 included), a Float64 FSM in float64
+    un = None if (general_c or bf.semiring == "prob" or bf.dtype == np.float64) else _unexpand(Vh)
     if un is None:
-        # float64, ProbSemiring, a general C_hat, or V_hat that expand() did not make: the generic entry
+        # a Float64 FSM, ProbSemiring, a general C_hat, or V_hat that expand() did not make: the generic entry
         return bf.pdfposteriors_generic(Vh, Chats if general_c else None)
     V, lens = un
     g, ttl = bf.pdfposteriors(V, lens)

@@ -1,0 +1,167 @@
+"""GPU tests of the float64 exact pair kernels (mm_kernel_dpair.hip: mm_fbd_kernel_dir) -- where the utterances go that the
+float32 pair kernels mark (sharp emissions: a trained acoustic model), and what runs FIRST while the inputs stay sharp.
+
+src/inference.jl:145-161 runs one algorithm, in the log domain, for every input; the engine's linear-domain kernels must
+give its result whatever the data.  Here: the kernels are asserted by name, the log-domain kernels behind them are
+switched off (MM_NO_FALLBACK: what the float64 kernels computed is what is compared), and the counts (mm_batch_last_redo_count,
+mm_batch_last_fallback_count, mm_batch_last_exact_first) are part of the contract."""
+import os
+
+import numpy as np
+import pytest
+
+import graphs
+from test_gpu_parity import _with_env, check_gamma
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    assert torch.cuda.is_available()
+    return torch
+
+
+def oracle64(oracle, g, V, lens):
+    o, oc = oracle
+    return oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V, lens, dtype=np.float64, nthreads=4)
+
+
+def peaky(rng, shape, sigma):
+    """log-softmax of sigma N(0,1): the outputs of a sharp acoustic model"""
+    x = sigma * rng.standard_normal(shape)
+    return (x - np.log(np.exp(x - x.max(-1, keepdims=True)).sum(-1, keepdims=True)) - x.max(-1, keepdims=True)).astype(np.float32)
+
+
+def make_batch(mm, wl, g, B, env):
+    return _with_env(dict(env, MM_DEBUG="1"), lambda: mm.batch(*([mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))] * B)))
+
+
+@pytest.mark.parametrize("sigma", [10.0, 25.0])
+def test_sharp_emissions_on_the_float64_kernels_alone(mm, wl, oracle, torch, sigma):
+    """Config 3's graph, sharp emissions: every utterance is marked by the float32 kernels and computed by the float64
+    kernels -- with nothing behind them (MM_NO_FALLBACK), against the float64 oracle.  Odd batch, different lengths (0 and 1
+    included), twice: the second call skips the float32 kernels (the first one's utterances were hard) and must give the
+    same bits."""
+    g = wl.lfmmi_denominator(2000, 84, seed=0)
+    rng = np.random.default_rng(int(sigma))
+    B, N = 7, 130
+    lens = np.array([130, 130, 87, 1, 45, 0, 129], dtype=np.int32)
+    V = peaky(rng, (B, N, g.P), sigma)
+    bf = make_batch(mm, wl, g, B, {"MM_NO_FALLBACK": "1"})
+    assert "mm_fbd_kernel_dir" in bf.kernels(), bf.kernels()
+    g1, t1 = bf.pdfposteriors(V, lens)
+    assert not bf.last_exact_first()
+    redone = bf.last_redo_count()
+    assert redone >= 4 and bf.last_fallback_count() == 0
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    ok = np.isfinite(t_ref)
+    check_gamma(g1[ok], g_ref[ok], lens[ok])
+    assert np.allclose(t1[ok], t_ref[ok], rtol=1e-5, atol=1e-3)
+    assert (g1[~ok] == 0).all() and np.isneginf(t1[~ok]).all()
+    g2, t2 = bf.pdfposteriors(V, lens)
+    assert bf.last_exact_first() and bf.last_redo_count() == B and bf.last_fallback_count() == 0
+    check_gamma(g2[ok], g_ref[ok], lens[ok])
+    assert np.allclose(t2[ok], t_ref[ok], rtol=1e-5, atol=1e-3)
+    m = lens >= 2  # (the utterances both calls computed on the float64 kernels: the same bits)
+    for b in np.nonzero(m)[0]:
+        if redone == B or np.array_equal(g1[b], g2[b]):
+            continue
+        # an utterance the float32 kernels kept in the first call: equal within the bar only
+        check_gamma(g1[b : b + 1], g2[b : b + 1].astype(np.float64), lens[b : b + 1])
+
+
+def test_the_choice_follows_the_data(mm, wl, oracle, torch):
+    """randn -> sharp -> sharp -> randn -> randn: the float32 kernels run first until a call leaves more than a quarter of its
+    utterances marked, the float64 kernels take whole batches while their overlap statistics say the float32 kernels
+    would fail, and the engine goes back when the data does.  Results are the oracle's on every call."""
+    g = wl.lfmmi_denominator(1500, 84, seed=2)
+    rng = np.random.default_rng(3)
+    B, N = 9, 90
+    lens = rng.integers(40, N + 1, B).astype(np.int32)
+    Vr = rng.standard_normal((B, N, g.P)).astype(np.float32)
+    Vs = peaky(rng, (B, N, g.P), 10.0)
+    bf = make_batch(mm, wl, g, B, {})
+    want = [(Vr, False, 0), (Vs, False, None), (Vs, True, B), (Vr, True, B), (Vr, False, 0)]
+    refs = {id(Vr): oracle64(oracle, g, Vr, lens), id(Vs): oracle64(oracle, g, Vs, lens)}
+    for V, first, redo in want:
+        gam, ttl = bf.pdfposteriors(V, lens)
+        assert bf.last_exact_first() == first
+        if redo is not None:
+            assert bf.last_redo_count() == redo
+        else:
+            assert bf.last_redo_count() > B // 4
+        assert bf.last_fallback_count() == 0
+        g_ref, t_ref = refs[id(V)]
+        check_gamma(gam, g_ref, lens)
+        assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-3)
+
+
+def test_float64_kernels_first_on_ordinary_inputs(mm, wl, oracle, torch):
+    """MM_EXACT_FIRST=1: the float64 kernels alone on N(0,1) log-likelihoods, B beyond the compute units' pairs, P + 1 > 128
+    (the 4-pass service wave), against the oracle and against the float32 kernels' result."""
+    g = wl.lfmmi_denominator(1200, 150, seed=5)
+    rng = np.random.default_rng(8)
+    B, N = 11, 70
+    lens = rng.integers(1, N + 1, B).astype(np.int32)
+    V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+    bf = make_batch(mm, wl, g, B, {"MM_EXACT_FIRST": "1", "MM_NO_FALLBACK": "1"})
+    assert "mm_fbd_kernel_dir<4" in bf.kernels(), bf.kernels()
+    gam, ttl = bf.pdfposteriors(V, lens)
+    assert bf.last_exact_first() and bf.last_fallback_count() == 0
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    check_gamma(gam, g_ref, lens)
+    assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)
+    bf32 = make_batch(mm, wl, g, B, {"MM_EXACT_FIRST": "0", "MM_NO_FALLBACK": "1"})
+    g32, t32 = bf32.pdfposteriors(V, lens)
+    assert not bf32.last_exact_first() and bf32.last_redo_count() == 0
+    assert np.allclose(g32, gam, rtol=2e-4, atol=1e-6) and np.allclose(t32, ttl, rtol=1e-6, atol=1e-4)
+
+
+def test_emission_offsets_and_masked_pdfs(mm, wl, oracle, torch):
+    """GMM-like scores (-300 nats), and pdfs masked with -1e4 in some frames (states on them underflow even a double: the marks
+    the float64 kernels raise carry no mass and are cleared by mm_dpair_finish_kernel)."""
+    g = wl.lfmmi_denominator(800, 60, seed=7)
+    rng = np.random.default_rng(4)
+    B, N = 5, 80
+    lens = np.array([80, 64, 80, 33, 80], dtype=np.int32)
+    V = peaky(rng, (B, N, g.P), 8.0) - 300.0
+    V[:, ::3, :7] = -1e4
+    bf = make_batch(mm, wl, g, B, {"MM_EXACT_FIRST": "1", "MM_NO_FALLBACK": "1"})
+    gam, ttl = bf.pdfposteriors(V, lens)
+    assert bf.last_fallback_count() == 0
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    check_gamma(gam, g_ref, lens)
+    assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-2)
+
+
+def test_capturable_in_a_hip_graph(mm, wl, torch):
+    """The chain float32 kernels -> finish -> float64 kernels -> finish is launches and memset nodes on the caller's stream
+    and the batch's side streams: a captured call replays to the bits of the eager one, on sharp inputs (the float64 kernels
+    do the work) as well."""
+    g = wl.lfmmi_denominator(900, 40, seed=1)
+    B, N = 6, 50
+    bf = make_batch(mm, wl, g, B, {"MM_EXACT_FIRST": "0"})
+    x = 10.0 * torch.randn(B, N, g.P, device="cuda")
+    V = torch.log_softmax(x, dim=-1)
+    lens = torch.tensor([N, N - 3, 5, 1, N, 17], dtype=torch.int32, device="cuda")
+    gamma = torch.empty(B, N, g.P, device="cuda")
+    _, t0 = bf.pdfposteriors(V, lens, out=gamma)
+    assert bf.last_redo_count() >= 3
+    g0, t0 = gamma.clone(), t0.clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        bf.pdfposteriors(V, lens, out=gamma)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        _, t1 = bf.pdfposteriors(V, lens, out=gamma)
+    for _ in range(2):
+        gamma.zero_()
+        t1.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(gamma, g0) and torch.equal(t1, t0)

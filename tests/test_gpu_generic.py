@@ -106,11 +106,87 @@ def test_general_state_map_and_arbitrary_vhat(mm, wl, oracle, torch):
     g_ref, t_ref = o.pdfposteriors(o.rawunion([f, f]), Vh, [C_or, C_or])
     Cm = mm.GeneralStateMap(sp.csr_matrix((vals, (rows, cols)), shape=(S1, P1)), "log")
     assert Cm.one_hot() is None
-    fsm = wl.to_fsm(mm, g, "log", np.float64)
     for dtype, tol in ((np.float64, 1e-10), (np.float32, 3e-5)):
-        gam, ttl = mm.pdfposteriors(mm.rawunion(fsm, fsm), [v.astype(dtype) for v in Vh], [Cm, Cm])
+        fsm = wl.to_fsm(mm, g, "log", dtype)  # (the precision follows the FSM's K: src/inference.jl:147)
+        gam, ttl = mm.pdfposteriors(mm.rawunion(fsm, fsm), Vh, [Cm, Cm])
         assert gam.dtype == dtype
         assert np.allclose(gam, g_ref, rtol=tol, atol=tol) and np.allclose(ttl, t_ref, rtol=tol, atol=tol)
     # a general map that is one-hot after all is recognised and takes the fast kernels (float32, expand()'s V_hat)
     one = mm.GeneralStateMap(sp.csr_matrix((np.zeros(S1), (np.arange(S1), np.append(g.state2pdf, g.P))), shape=(S1, P1)), "log")
     assert one.one_hot() is not None
+
+
+def test_unexpanded_vhat_is_a_dimension_mismatch(mm, wl, torch):
+    """A P x N matrix that expand() (src/inference.jl:54-60) was not applied to, or one with a wrong number of pdfs, is the
+    reference's DimensionMismatch (vcat(V_hats...) against blockdiag(C_hats...)', :146-150) -- from the host mirror and
+    from the C entry itself, which reads P1 rows per utterance: never an out-of-bounds read."""
+    g = wl.random_fsm(30, 5, 2.5, seed=2)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(cf, cf)
+    rng = np.random.default_rng(0)
+    raw = [rng.standard_normal((g.P, 12)) for _ in range(2)]  # expand() forgotten
+    with pytest.raises(mm.DimensionMismatch):
+        mm.pdfposteriors(bf, raw)
+    with pytest.raises(mm.DimensionMismatch):
+        bf.pdfposteriors_generic([rng.standard_normal((g.P + 3, 13)) for _ in range(2)])
+    # the C entry: V_hat with P rows handed over directly
+    V = torch.randn(2, 13, g.P, device="cuda")
+    with pytest.raises(mm.DimensionMismatch):
+        bf.pdfposteriors_ex(V)
+
+
+def test_precision_follows_the_fsm(mm, wl, oracle, torch):
+    """src/inference.jl:147 converts V_hat to the FSM's K.  A Float32 FSM given NumPy's default float64 matrices of
+    expand()'s form stays on the fast float32 kernels; a Float64 FSM given float32 matrices computes in float64."""
+    o, oc = oracle
+    g = wl.lfmmi_denominator(300, 20, seed=3)
+    rng = np.random.default_rng(5)
+    B, N = 3, 25
+    lens = [25, 11, 18]
+    lhs = [rng.standard_normal((g.P, N)) for _ in range(B)]  # float64
+    V = np.stack([x.T for x in lhs]).astype(np.float32)
+    g_ref, t_ref = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V, np.asarray(lens, np.int32), dtype=np.float64)
+    Vh = [mm.expand(x, L) for x, L in zip(lhs, lens)]
+    assert Vh[0].dtype == np.float64
+    cf32 = mm.compile(wl.to_fsm(mm, g, "log", np.float32), mm.statemap(g.state2pdf, g.P))
+    bf32 = mm.batch(*([cf32] * B))
+    gam, ttl = mm.pdfposteriors(bf32, Vh)
+    assert gam.dtype == np.float32
+    assert np.allclose(gam.transpose(0, 2, 1), g_ref, rtol=1e-4, atol=2e-5) and np.allclose(ttl, t_ref, rtol=1e-5)
+    cf64 = mm.compile(wl.to_fsm(mm, g, "log", np.float64), mm.statemap(g.state2pdf, g.P))
+    gam64, ttl64 = mm.pdfposteriors(mm.batch(*([cf64] * B)), [v.astype(np.float32) for v in Vh])
+    assert gam64.dtype == np.float64
+    assert np.allclose(gam64.transpose(0, 2, 1), g_ref, rtol=1e-5, atol=1e-6) and np.allclose(ttl64, t_ref, rtol=1e-6)
+
+
+def test_generic_entry_is_asynchronous_and_capturable(mm, wl, oracle, torch):
+    """mm_pdfposteriors_ex keeps its workspace with the batch (mm_batch_reserve_ex): a steady-state call allocates nothing
+    and does not wait -- it can be captured in a hipGraph; a replay gives the bits of the eager call, which match the
+    oracle."""
+    o, _ = oracle
+    g = wl.random_fsm(40, 6, 3.0, seed=1)
+    B, N = 4, 15
+    rng = np.random.default_rng(1)
+    lens = [15, 9, 15, 3]
+    lhs = [rng.standard_normal((g.P, N)) for _ in range(B)]
+    (g_ref, t_ref), _K = oracle_run(o, g, "log", np.float64, lhs, lens, g.state2pdf, g.P)
+    cf = mm.compile(wl.to_fsm(mm, g, "log", np.float64), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(*([cf] * B))
+    Vh = torch.from_numpy(np.ascontiguousarray(np.stack([mm.expand(x, L).T for x, L in zip(lhs, lens)]))).cuda()  # [B][N1][P1] float64
+    bf.reserve_ex(np.float64, N + 1)
+    gam0, ttl0 = (t.clone() for t in bf.pdfposteriors_ex(Vh))
+    assert np.allclose(gam0.cpu().numpy().transpose(0, 2, 1), g_ref, rtol=1e-10, atol=1e-10)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        bf.pdfposteriors_ex(Vh)
+    torch.cuda.synchronize()
+    gam, ttl = torch.zeros_like(gam0), torch.zeros_like(ttl0)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        bf.pdfposteriors_ex(Vh, gamma=gam, ttl=ttl)
+    for _ in range(2):
+        gam.zero_()
+        ttl.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(gam, gam0) and torch.equal(ttl, ttl0)

@@ -44,6 +44,20 @@ __global__ void __launch_bounds__(1024) k(double *out, unsigned long long *cyc, 
                 asm volatile("v_cvt_f32_f64 %0, %4\n\tv_cvt_f32_f64 %1, %5\n\tv_cvt_f32_f64 %2, %6\n\tv_cvt_f32_f64 %3, %7\n\t"
                              "v_cvt_f32_f64 %0, %5\n\tv_cvt_f32_f64 %1, %6\n\tv_cvt_f32_f64 %2, %7\n\tv_cvt_f32_f64 %3, %4"
                              : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+            } else if (MODE == 7) {  // ONE dependent chain: acc = fma(cvt(w), x, acc), 8 arcs
+                double t0d;
+                asm volatile("v_cvt_f64_f32 %1, %2\n\tv_fma_f64 %0, %1, %6, %0\n\tv_cvt_f64_f32 %1, %3\n\tv_fma_f64 %0, %1, %6, %0\n\t"
+                             "v_cvt_f64_f32 %1, %4\n\tv_fma_f64 %0, %1, %6, %0\n\tv_cvt_f64_f32 %1, %5\n\tv_fma_f64 %0, %1, %6, %0"
+                             : "+v"(a0), "=&v"(t0d) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(c));
+            } else if (MODE == 8) {  // TWO chains
+                double t0d, t1d;
+                asm volatile("v_cvt_f64_f32 %2, %4\n\tv_cvt_f64_f32 %3, %5\n\tv_fma_f64 %0, %2, %8, %0\n\tv_fma_f64 %1, %3, %8, %1\n\t"
+                             "v_cvt_f64_f32 %2, %6\n\tv_cvt_f64_f32 %3, %7\n\tv_fma_f64 %0, %2, %8, %0\n\tv_fma_f64 %1, %3, %8, %1"
+                             : "+v"(a0), "+v"(a1), "=&v"(t0d), "=&v"(t1d) : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(c));
+            } else if (MODE == 9) {  // ONE chain of v_fma_f32 for comparison
+                asm volatile("v_fma_f32 %0, %1, %5, %0\n\tv_fma_f32 %0, %2, %5, %0\n\tv_fma_f32 %0, %3, %5, %0\n\tv_fma_f32 %0, %4, %5, %0\n\t"
+                             "v_fma_f32 %0, %1, %5, %0\n\tv_fma_f32 %0, %2, %5, %0\n\tv_fma_f32 %0, %3, %5, %0\n\tv_fma_f32 %0, %4, %5, %0"
+                             : "+v"(f0) : "v"(f1), "v"(f2), "v"(f3), "v"(f1), "v"(f2));
             } else if (MODE == 6) {
                 asm volatile("v_add_f64 %0, %0, %4\n\tv_add_f64 %1, %1, %4\n\tv_add_f64 %2, %2, %4\n\tv_add_f64 %3, %3, %4\n\t"
                              "v_mul_f64 %0, %0, %5\n\tv_mul_f64 %1, %1, %5\n\tv_mul_f64 %2, %2, %5\n\tv_mul_f64 %3, %3, %5"
@@ -76,5 +90,8 @@ int main() {
     run<4>("v_frexp_exp/mant_f64", o, c);
     run<5>("v_cvt_f32_f64", o, c);
     run<6>("v_add_f64 / v_mul_f64", o, c);
+    run<7>("cvt+fma_f64, ONE chain", o, c);
+    run<8>("cvt+fma_f64, TWO chains", o, c);
+    run<9>("v_fma_f32, ONE chain", o, c);
     return 0;
 }

@@ -5,48 +5,28 @@
 
 namespace mm {
 
-// One utterance per workgroup: blockIdx.x = the utterance's rank in the longest-first order.
+// One utterance per workgroup; one launch per phase: the forward agents are the first B workgroups (by rank in the
+// longest-first order), the backward agents the second B (mm_pairs_tu.hip).
 // (NJ: 64-lane passes over the pdfs in the service wave, 2 for P + 1 <= 128, else 4)
-template <int NJ, int PHASE, int DIR>
-__global__ void __launch_bounds__(1024) mm_fbd_kernel_dir(RunParams p) {
-    dpair_agent<MM_PAIR_KA, MM_ROW_RS, PHASE, DIR, NJ>(p, blockIdx.x);
+template <int NJ, int PHASE>
+__global__ void __launch_bounds__(1024) mm_fbd_kernel(RunParams p) {
+    const int dir = (int)blockIdx.x >= p.B;
+    dpair_agent<MM_PAIR_KA, MM_ROW_RS, PHASE, NJ>(p, (int)blockIdx.x - (dir ? p.B : 0), dir);
 }
-template <int NJ, int PHASE, int DIR>
-static int launch_dpair_one(const PairLaunch *h, const RunParams &p, hipStream_t st) {
+template <int NJ, int PHASE>
+static int launch_dpair_phase(const PairLaunch *h, const RunParams &p, hipStream_t st) {
     const size_t lds = pair_lds_bytes(MM_ROW_RS, PHASE, h->slotrows);
     if (lds > 160 * 1024) return mm_fail(MM_ERR_UNSUPPORTED, "exact pair kernel: LDS");
-    auto kernel = mm_fbd_kernel_dir<NJ, PHASE, DIR>;
+    auto kernel = mm_fbd_kernel<NJ, PHASE>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-    hipLaunchKernelGGL(kernel, dim3(unsigned(h->B)), dim3(64 * (h->nwc + 1)), lds, st, p);
+    hipLaunchKernelGGL(kernel, dim3(2 * unsigned(h->B)), dim3(64 * (h->nwc + 1)), lds, st, p);
     HIP_TRY(hipGetLastError());
     return MM_OK;
 }
-// the same fork / join as mm_launch_pairs (mm_pairs_tu.hip): phase A of both agents side by side, then phase B of both
 template <int NJ>
 static int launch_dpairs_nj(const PairLaunch *h, const RunParams &p, hipStream_t s0) {
-    hipStream_t sf = h->side[0], sb = h->side[1];
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s0, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) sf = s0;
-    HIP_TRY(hipEventRecord(h->ev[0], s0));  // fork
-    HIP_TRY(hipStreamWaitEvent(sf, h->ev[0], 0));
-    HIP_TRY(hipStreamWaitEvent(sb, h->ev[0], 0));
-    auto body = [&]() -> int {
-        int rc = launch_dpair_one<NJ, 0, 0>(h, p, sf);
-        if (!rc) rc = launch_dpair_one<NJ, 0, 1>(h, p, sb);
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(h->ev[1], sf));  // phase B of either direction needs phase A of both
-        HIP_TRY(hipEventRecord(h->ev[2], sb));
-        HIP_TRY(hipStreamWaitEvent(sf, h->ev[2], 0));
-        HIP_TRY(hipStreamWaitEvent(sb, h->ev[1], 0));
-        rc = launch_dpair_one<NJ, 1, 0>(h, p, sf);
-        if (!rc) rc = launch_dpair_one<NJ, 1, 1>(h, p, sb);
-        return rc;
-    };
-    const int rc = body();
-    HIP_TRY(hipEventRecord(h->ev[3], sf));  // join (also after a failed launch: see mm_pairs_tu.hip)
-    HIP_TRY(hipEventRecord(h->ev[4], sb));
-    HIP_TRY(hipStreamWaitEvent(s0, h->ev[3], 0));
-    HIP_TRY(hipStreamWaitEvent(s0, h->ev[4], 0));
+    int rc = launch_dpair_phase<NJ, 0>(h, p, s0);
+    if (!rc) rc = launch_dpair_phase<NJ, 1>(h, p, s0);
     if (rc) return rc;
     hipLaunchKernelGGL(mm_dpair_finish_kernel, dim3(unsigned(h->B)), dim3(256), 0, s0, p);
     HIP_TRY(hipGetLastError());

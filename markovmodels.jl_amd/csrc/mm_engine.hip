@@ -232,14 +232,9 @@ struct mm_batch_s {
     int wave_nseg = 0;
     int pair_H = 1;        // workgroups per team: 1 = the pair kernels proper, > 1 = the split pair kernels
     int split_s1p = 0;     // floats / 2 of a stored vector of the split kernels (positions of the team's vector, padded)
-    // the forward and the backward agents of the pair kernels run side by side on two streams of the library (a pair of
-    // this batch's own that was SEEN to run kernels concurrently, acquire_stream_pair()); the caller's stream forks into
-    // them and joins them
-    hipStream_t side[2] = {nullptr, nullptr};
     bool deterministic = false;  // mm_batch_set_deterministic(): no float atomics in the item kernel
     float lt_floor = -20.f;      // mm_batch_set_posterior_floor(): smallest accepted log2 overlap of a frame (mm_pair_finish_kernel)
     float *ws_big = nullptr;  // [B][4 * max_S1p]: state vectors of FSMs beyond the LDS (launch())
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int device = -1;
     int n_cus = 256;  // compute units of the device
     UttDesc *d_utts = nullptr;
@@ -252,6 +247,7 @@ struct mm_batch_s {
     // batch, the float32 kernels skipped, while the inputs are "hard": more than a quarter of the last finished call's
     // utterances were beyond the float32 kernels (stat_host, written by the finish kernels; read without synchronising).
     bool dpair_ok = false;
+    bool quad_built = false;            // the FSMs' quad forms exist (not built for batches whose exact path is the float64 kernels)
     int *stat_dev = nullptr;            // {count, ticket}
     volatile int *stat_host = nullptr;  // pinned: {count of hard utterances, sequence number of the call that counted}
     int stat_seq = 0;
@@ -326,7 +322,7 @@ static size_t quad_lds_bytes(mm_batch_t h, int dir) {
 }
 
 static bool quad_kernel_usable(mm_batch_t h) {
-    if (h->dbg.kernel == DebugOpts::K_ITEM || h->wave_ok) return false;
+    if (h->dbg.kernel == DebugOpts::K_ITEM || h->wave_ok || !h->quad_built) return false;
     if (!h->fast_ok || h->geo_kq[0] < 1 || h->geo_kq[1] < 1) return false;
     // small deep graphs (numerators): measured on the reference's WSJ numerator graph (depth 165),
     // item kernel 2.3 ms against 2.7 ms; shallow graphs of the same size are 1.6x faster on the quad kernels
@@ -403,99 +399,7 @@ static int launch_pairs(mm_batch_t h, const RunParams &p, void *stream) {
     pl.pair_ka = h->pair_ka;
     pl.H = h->pair_H;
     pl.small = h->pair_H == 1 && h->max_S1p <= 128;
-    pl.side[0] = h->side[0];
-    pl.side[1] = h->side[1];
-    for (int i = 0; i < 5; ++i) pl.ev[i] = h->ev[i];
     return h->pair_H > 1 ? mm_launch_split(pl, p, static_cast<hipStream_t>(stream)) : mm_launch_pairs(pl, p, static_cast<hipStream_t>(stream));
-}
-
-// Two streams whose kernels really run at the same time.  HIP multiplexes its streams over a few hardware queues and
-// two streams that share a queue run their kernels one after the other (seen: with an RCCL communicator in the process
-// the caller's stream and a fresh one shared a queue, and the two agents of the pair kernels took turns -- 5.7 ms per
-// call instead of 3.3).  So the pair is probed once per process and device: a kernel on one stream waits (up to
-// 0.5 ms) for a flag that a kernel launched afterwards on the other stream sets; fresh streams are tried until a pair
-// passes.  Without such a pair (sf == sb) the agents run one after the other: slower, same results.
-__global__ void mm_probe_wait_kernel(int *flag, int *seen) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-    int ok = 0;
-    while (__builtin_amdgcn_s_memrealtime() - t0 < 50000ull) {
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            ok = 1;
-            break;
-        }
-        __builtin_amdgcn_s_sleep(32);
-    }
-    *seen = ok;
-}
-__global__ void mm_probe_set_kernel(int *flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-static bool probe_stream_pair(hipStream_t s[2]) {
-    s[0] = s[1] = nullptr;
-    int *dbuf = nullptr;
-    hipStream_t a = nullptr;
-    if (hipMalloc(&dbuf, 2 * sizeof(int)) == hipSuccess && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) == hipSuccess) {
-        std::vector<hipStream_t> rejected;
-        for (int attempt = 0; attempt < 8 && !s[1]; ++attempt) {
-            hipStream_t b = nullptr;
-            if (hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess) break;
-            int seen = 0;
-            bool ok = hipMemset(dbuf, 0, 2 * sizeof(int)) == hipSuccess;
-            if (ok) {
-                hipLaunchKernelGGL(mm_probe_wait_kernel, dim3(1), dim3(1), 0, a, dbuf, dbuf + 1);
-                hipLaunchKernelGGL(mm_probe_set_kernel, dim3(1), dim3(1), 0, b, dbuf);
-                ok = hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess &&
-                     hipMemcpy(&seen, dbuf + 1, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
-            }
-            if (ok && seen) {
-                s[0] = a;
-                s[1] = b;
-            } else {
-                rejected.push_back(b);  // (kept until the search ends: a destroyed stream's queue slot would be handed out again)
-            }
-        }
-        for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
-        if (!s[1]) s[0] = s[1] = a;  // no concurrent pair: one stream, the agents take turns
-    }
-    if (dbuf) (void)hipFree(dbuf);
-    return s[0] != nullptr;
-}
-
-// A pair of side streams for a batch of the pair kernels: every batch that is alive at the same time has a pair of its
-// own (two batches driven from two caller streams do not take turns on one pair); pairs are probed once and reused when
-// their batch is destroyed.
-namespace {
-struct StreamPair {
-    hipStream_t s[2] = {nullptr, nullptr};
-    int users = 0;
-};
-std::map<int, std::vector<StreamPair>> g_stream_pairs;
-std::mutex g_stream_lock;  // (batches may be created from several host threads)
-}  // namespace
-static bool acquire_stream_pair(int device, hipStream_t out[2]) {
-    std::lock_guard<std::mutex> guard(g_stream_lock);
-    std::vector<StreamPair> &pool = g_stream_pairs[device];
-    for (StreamPair &sp : pool)
-        if (sp.users == 0) {
-            sp.users = 1;
-            out[0] = sp.s[0];
-            out[1] = sp.s[1];
-            return true;
-        }
-    StreamPair sp;
-    if (!probe_stream_pair(sp.s)) return false;
-    sp.users = 1;
-    pool.push_back(sp);
-    out[0] = sp.s[0];
-    out[1] = sp.s[1];
-    return true;
-}
-static void release_stream_pair(int device, hipStream_t s0, hipStream_t s1) {
-    std::lock_guard<std::mutex> guard(g_stream_lock);
-    for (StreamPair &sp : g_stream_pairs[device])
-        if (sp.s[0] == s0 && sp.s[1] == s1 && sp.users > 0) {
-            sp.users = 0;
-            return;
-        }
 }
 
 namespace {
@@ -1698,12 +1602,15 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         int rc = try_wave();
         if (rc) return rc;
     }
+    // (a batch of the wave kernel never runs the quad kernels, and one whose marked utterances go to the float64 pair kernels
+    // has the item kernel behind those: their quad forms are not built)
+    const bool want_dpair = h->pairs_ok && h->pair_H == 1 && !h->dbg.no_dpair;
+    h->quad_built = h->fast_ok && !h->wave_ok && !(want_dpair && h->dbg.kernel != DebugOpts::K_QUAD);
     for (int64_t b = 0; b < B; ++b) {
         mm_fsm_t f = fsms[b];
         int rc = fsm_to_device(f);
         QuadVariant *qv[2] = {nullptr, nullptr};
-        // (a batch of the wave kernel never runs the quad kernels: their forms are not built)
-        for (int d = 0; d < 2 && !rc && h->fast_ok && !h->wave_ok; ++d) rc = quad_variant(f, d, h->geo_kq[d], h->dbg.verbose, &qv[d]);
+        for (int d = 0; d < 2 && !rc && h->quad_built; ++d) rc = quad_variant(f, d, h->geo_kq[d], h->dbg.verbose, &qv[d]);
         if (rc) return rc;
         UttDesc &u = utts[b];
         memset(&u, 0, sizeof(u));
@@ -1765,12 +1672,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             }
         }
     }
-    if (h->pairs_ok) {
-        bool good = acquire_stream_pair(h->device, h->side);
-        for (int i = 0; i < 5 && good; ++i) good = hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming) == hipSuccess;
-        if (!good) h->pairs_ok = false;
-    }
-    if (h->pairs_ok && h->pair_H == 1 && !h->dbg.no_dpair) {
+    if (want_dpair) {
         void *hp = nullptr;
         if (hipMalloc(&h->stat_dev, 2 * sizeof(int)) == hipSuccess && hipMemset(h->stat_dev, 0, 2 * sizeof(int)) == hipSuccess &&
             hipHostMalloc(&hp, 2 * sizeof(int), hipHostMallocMapped) == hipSuccess) {
@@ -1808,9 +1710,6 @@ int mm_debug_read_stamps(unsigned long long *out, int64_t n) {
 
 int mm_batch_destroy(mm_batch_t h) {
     if (!h) return MM_OK;
-    if (h->side[0]) release_stream_pair(h->device, h->side[0], h->side[1]);
-    for (hipEvent_t e : h->ev)
-        if (e) (void)hipEventDestroy(e);
     if (h->d_utts) (void)hipFree(h->d_utts);
     if (h->ws_big) (void)hipFree(h->ws_big);
     if (h->ws) (void)hipFree(h->ws);
@@ -1903,20 +1802,17 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
             s = "mm_wave_kernel<" + std::to_string(h->wave_nseg <= 2 ? 2 : 4) + "," + std::to_string(h->max_P1 <= 128 ? 2 : 4) +
                 (h->wave_nseg <= 2 && h->B > h->n_cus ? ",two per CU>" : ">");
         } else if (h->pairs_ok && h->pair_H > 1) {
-            const std::string k = std::to_string(h->max_P1 <= 128 ? 2 : 4);
-            s = "mm_fbs_kernel_dir<" + k + ",A,fwd> || <" + k + ",A,bwd>, then <" + k + ",B,fwd> || <" + k +
-                ",B,bwd> (teams of " + std::to_string(h->pair_H) + " workgroups), mm_pair_finish_kernel, then for marked utterances only " + exact +
-                (h->side[0] == h->side[1] ? " [no concurrent stream pair found: the two agents take turns]" : "");
+            const std::string k = std::to_string(h->max_P1 <= 128 ? 2 : 4), H = std::to_string(h->pair_H);
+            s = "mm_fbs_kernel<" + k + ",A," + H + ">, then <" + k + ",B," + H + "> (forward and backward agents in one grid, teams of " + H +
+                " workgroups), mm_pair_finish_kernel, then for marked utterances only " + exact;
         } else if (h->pairs_ok) {
             const std::string k = std::to_string(h->max_P1 <= 128 ? 2 : 4);
-            s = "mm_fbp_kernel_dir<" + k + ",A,fwd> || <" + k + ",A,bwd>, then <" + k + ",B,fwd> || <" + k +
-                ",B,bwd>, mm_pair_finish_kernel, then for marked utterances only " +
-                (h->dpair_ok ? "mm_fbd_kernel_dir<" + k + ",A,fwd> || <" + k + ",A,bwd>, then <" + k + ",B,fwd> || <" + k +
-                                   ",B,bwd> (float64, one utterance per workgroup; FIRST and alone while the inputs are hard), "
-                                   "mm_dpair_finish_kernel, then for what those mark "
+            s = "mm_fbp_kernel<" + k + ",A>, then <" + k + ",B> (forward and backward agents in one grid), mm_pair_finish_kernel, then for marked "
+                "utterances only " +
+                (h->dpair_ok ? "mm_fbd_kernel<" + k + ",A>, then <" + k + ",B> (float64, one utterance per workgroup; FIRST and alone while the "
+                               "inputs are hard), mm_dpair_finish_kernel, then for what those mark "
                              : std::string()) +
-                exact +
-                (h->side[0] == h->side[1] ? " [no concurrent stream pair found: the two agents take turns]" : "");
+                exact;
         } else if (h->rows_ok) {
             auto ka = [&](int d) {
                 for (int k : kRowKA)
@@ -1959,7 +1855,7 @@ static size_t ws_tail_bytes(mm_batch_t h) {  // longest-first order, redo marks,
 
 // (quad kernels) the emissions shifted by their per-frame maxima [B][N][P], and the maxima [B][N]
 static size_t ws_shift_bytes(mm_batch_t h, int64_t N) {
-    if (!h->fast_ok) return 0;
+    if (!h->fast_ok || !h->quad_built) return 0;
     return align_up(size_t(h->B) * size_t(N) * size_t(h->max_P1 - 1) * 4, 256) + align_up(size_t(h->B) * size_t(N) * 4, 256);
 }
 size_t mm_batch_workspace_bytes(mm_batch_t h, int64_t N) {
@@ -2054,12 +1950,33 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     p.gsp = gsp;
     p.ttl = ttl;
     p.xcsr = h->xcsr;
-    if (ordered) {
-        int *order = reinterpret_cast<int *>(static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N));  // (first of the tail)
-        hipLaunchKernelGGL(mm_length_order_kernel, dim3(unsigned((h->B + 255) / 256)), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), lens, int(h->B), int(N), order);
+    char *const tail0 = static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N);
+    int *const order = ordered ? reinterpret_cast<int *>(tail0) : nullptr;  // (first of the tail)
+    p.order = order;
+    const bool marks = !h->wave_ok && (h->rows_ok || h->pairs_ok);
+    // Which kernels first?  The float32 pair kernels, unless the inputs of the last finished call were beyond them for more
+    // than a quarter of its utterances (a sharp acoustic model: every utterance is marked and computed again): then the
+    // float64 kernels take the whole batch at once.  They keep reporting (how many utterances have an overlap term below the
+    // float32 kernels' floor), so the choice follows the data back as well.  Read without synchronising: the count of
+    // whatever call finished last.
+    bool exact_first = false;
+    if (marks) {
+        p.redo = reinterpret_cast<int *>(tail0 + align_up(size_t(h->B + 1) * 4, 256));
+        if (h->dpair_ok) {
+            exact_first = h->exact_first >= 0 ? h->exact_first != 0 : 4 * int64_t(h->stat_host[0]) > h->B;
+            p.redo2 = reinterpret_cast<int *>(tail0 + ws_tail_bytes(h) - align_up(size_t(h->B + 1) * 4, 256));
+            p.stat_dev = h->stat_dev;
+            p.stat_host = h->stat_host;
+            p.stat_seq = ++h->stat_seq;
+            p.stat_mode = exact_first ? 1 : 0;
+        }
+    }
+    if (ordered || marks) {
+        // (the marks are set here, on the caller's stream, ahead of everything: the forward and the backward agents run
+        // concurrently and either may mark an utterance first)
+        hipLaunchKernelGGL(mm_prologue_kernel, dim3(unsigned((h->B + 1 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           lens, int(h->B), int(N), order, p.redo, p.redo2, exact_first ? 1 : 0);
         HIP_TRY(hipGetLastError());
-        p.order = order;
     }
 #ifdef MM_STAMPS
     if (!g_dbg) {
@@ -2081,28 +1998,8 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     if (h->rows_ok || h->pairs_ok) {
         // the pair or row kernels, then -- for the utterances they marked (linear sums outside the trusted range),
         // normally none: every workgroup then leaves at once -- the exact kernels
-        char *tail = static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N);
-        p.redo = reinterpret_cast<int *>(tail + align_up(size_t(h->B + 1) * 4, 256));
-        // (zeroed here, on the caller's stream, before the fork: the forward and the backward agents of the pair kernels run
-        // concurrently and either may mark an utterance first)
-        HIP_TRY(hipMemsetAsync(p.redo, 0, size_t(h->B + 1) * 4, static_cast<hipStream_t>(stream)));
+        char *tail = tail0;
         h->last_redo = p.redo;
-        // Which kernels first?  The float32 pair kernels, unless the inputs of the last finished call were beyond them for more
-        // than a quarter of its utterances (a sharp acoustic model: every utterance is marked and computed again): then the
-        // float64 kernels take the whole batch at once.  They keep reporting (how many utterances have an overlap term below the
-        // float32 kernels' floor), so the choice follows the data back as well.  Read without synchronising: the count of
-        // whatever call finished last.
-        bool exact_first = false;
-        if (h->dpair_ok) {
-            exact_first = h->exact_first >= 0 ? h->exact_first != 0 : 4 * int64_t(h->stat_host[0]) > h->B;
-            p.redo2 = reinterpret_cast<int *>(tail + ws_tail_bytes(h) - align_up(size_t(h->B + 1) * 4, 256));
-            HIP_TRY(hipMemsetAsync(p.redo2, 0, size_t(h->B + 1) * 4, static_cast<hipStream_t>(stream)));
-            p.stat_dev = h->stat_dev;
-            p.stat_host = h->stat_host;
-            p.stat_seq = ++h->stat_seq;
-            p.stat_mode = exact_first ? 1 : 0;
-            if (exact_first) HIP_TRY(hipMemsetAsync(p.redo, 1, size_t(h->B) * 4, static_cast<hipStream_t>(stream)));  // (every utterance "marked")
-        }
         h->last_exact_first = exact_first;
         if (h->pairs_ok) {
             p.pair_s1p = h->pair_H > 1 ? h->split_s1p : h->max_S1p;
@@ -2138,14 +2035,15 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
             pl.max_P1 = h->max_P1;
             pl.pair_ka = h->pair_ka;
             pl.H = 1;
-            pl.side[0] = h->side[0];
-            pl.side[1] = h->side[1];
-            for (int i = 0; i < 5; ++i) pl.ev[i] = h->ev[i];
             rc = mm_launch_dpairs(pl, p, static_cast<hipStream_t>(stream));
             if (rc) return rc;
             h->last_redo2 = p.redo2;
             p.redo = p.redo2;
             if (h->dbg.no_redo || h->dbg.no_fallback) return MM_OK;
+            // what the float64 kernels hand on (values beyond a double's range that carry mass: normally nothing) goes to the
+            // item kernel, both passes in ONE launch (streamed items: its speed does not matter, the empty launch's does)
+            if (!quad_kernel_usable(h))
+                return launch(mm_log_kernel<MODE_FB, 0, 0, false, false>, mm_log_kernel<MODE_FB, 0, 0, false, true>, h, p, true, pick_geometry(h).NW, stream);
         }
     }
     if (quad_kernel_usable(h)) {

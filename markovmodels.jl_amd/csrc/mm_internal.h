@@ -70,8 +70,6 @@ struct PairLaunch {
     int64_t B = 0;
     int nwc = 1, slotrows = 0, max_P1 = 0, pair_ka = 0, H = 1;
     bool small = false;  // every FSM has at most 127 states: the instance whose service wave copies and scans one row of 64 float4
-    hipStream_t side[2] = {nullptr, nullptr};  // the two library streams the agents run on
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 int mm_launch_pairs(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
 size_t mm_pair_lds_bytes(int phase, int nslotrows);

@@ -238,11 +238,13 @@ __device__ __forceinline__ void dpair_two(const mm_f32x2 (&wr)[KA / 2], const un
 
 #define MM_DPAIR_THR_EXTRA 896.f  // the double's normal range (1022) over the float's (126)
 
-// One agent: direction DIR (0: forward / alpha, 1: backward / beta) of the utterance of rank `ui` (longest first), phase
+// One agent: direction rdir (0: forward / alpha, 1: backward / beta) of the utterance of rank `ui` (longest first), phase
 // PHASE (0: A, 1: B).  The structure, the step numbering and the LDS layout are pair_agent's (mm_kernel_pairs.hip).
-template <int KA, int RS, int PHASE, int DIR, int NJ>
-__device__ __forceinline__ void dpair_agent(const RunParams &p, int ui) {
+// (the direction is a run-time value, the same for the whole workgroup: see pair_agent)
+template <int KA, int RS, int PHASE, int NJ>
+__device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir) {
     extern __shared__ float lds[];
+    const int DIR = __builtin_amdgcn_readfirstlane(rdir);
     constexpr int RSH = 2 * RS;
     using L = PairLay<RS, PHASE, RSH>;
     constexpr int D = 3;  // gather pairs in flight ahead of the FMAs

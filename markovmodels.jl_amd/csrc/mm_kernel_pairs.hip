@@ -518,9 +518,15 @@ struct PairHand {  // what an agent hands from phase A to phase B, per utterance
 
 // One agent: direction DIR (0: forward / alpha, 1: backward / beta) of pair `pair`, phase PHASE (0: A, 1: B).
 // H > 1 (split kernels): the agent is a team of H workgroups, this one finishes the rows of set `hset`.
-template <int KA, int RS, int PHASE, int DIR, int NJ, int H = 1, int RSH = 2 * RS, bool SMALL = false>
-__device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hset = 0) {
+// DIRT: the direction as a template constant, or -1: the direction is `rdir`, a run-time value that is the same for the whole
+// workgroup -- one kernel then holds the forward and the backward agents of a launch (mm_pairs_tu.hip) in ONE body of code
+// and ONE register allocation (the two specialised bodies behind a branch on blockIdx made the register allocator spill 50
+// scalar registers in phase B: the loads of the parameters are hoisted above the branch and stay live through both bodies).
+// What depends on the direction at run time is scalar arithmetic (frame_of, indices) and one select per finished row.
+template <int KA, int RS, int PHASE, int DIRT, int NJ, int H = 1, int RSH = 2 * RS, bool SMALL = false>
+__device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hset = 0, int rdir = 0) {
     extern __shared__ float lds[];
+    const int DIR = DIRT < 0 ? __builtin_amdgcn_readfirstlane(rdir) : DIRT;
     using L = PairLay<RS, PHASE, RSH>;
 #ifndef MM_PAIR_DA
 #define MM_PAIR_DA 3

@@ -1117,18 +1117,33 @@ __global__ void mm_maxmarginal_kernel(const UttDesc *utts, float *A, long long a
     for (int s = threadIdx.x; s < u.S1; s += blockDim.x) a[s] = (bb > MM_NINF) ? a[s] + bt[s] - bb : MM_NINF;
 }
 
-// order[rank] = utterance, by decreasing length (ties by index): O(B) work per thread, B <= a few thousand
-__global__ void mm_length_order_kernel(const int *lens, int B, int N, int *order) {
+// The launch ahead of a pdfposteriors call: order[rank] = utterance, by decreasing length (ties by index; lens / order NULL:
+// none), and the marks of the linear-domain kernels: redo[0..B] = fill (0, or 1 for a call that goes to the exact kernels
+// with the whole batch), redo2[0..B] = 0 (either may be NULL).  One kernel instead of a rank kernel and two or three
+// memset nodes (a memset of B + 1 ints is TWO fill kernels of the runtime: an aligned body and a tail -- 5 us each on the
+// caller's stream, rocprofv3 timeline).  The lengths go through LDS: B loads per thread from global memory took 14 us.
+__global__ void __launch_bounds__(256) mm_prologue_kernel(const int *lens, int B, int N, int *order, int *redo, int *redo2, int fill) {
+    __shared__ int sh[256];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B) return;
-    auto clamp = [&](int l) { return l < 0 ? 0 : (l > N ? N : l); };
-    const int li = clamp(lens[i]);
-    int rank = 0;
-    for (int j = 0; j < B; ++j) {
-        const int lj = clamp(lens[j]);
-        rank += (lj > li) || (lj == li && j < i);
+    if (i <= B) {
+        if (redo) redo[i] = i < B ? fill : 0;
+        if (redo2) redo2[i] = 0;
     }
-    order[rank] = i;
+    if (!lens || !order) return;
+    auto clamp = [&](int l) { return l < 0 ? 0 : (l > N ? N : l); };
+    const int li = i < B ? clamp(lens[i]) : 0;
+    int rank = 0;
+    for (int j0 = 0; j0 < B; j0 += 256) {
+        __syncthreads();
+        sh[threadIdx.x] = j0 + (int)threadIdx.x < B ? clamp(lens[j0 + threadIdx.x]) : -1;
+        __syncthreads();
+        const int n = B - j0 < 256 ? B - j0 : 256;
+        for (int k = 0; k < n; ++k) {
+            const int lj = sh[k], j = j0 + k;
+            rank += (lj > li) || (lj == li && j < i);
+        }
+    }
+    if (i < B) order[rank] = i;
 }
 
 // Emission shift for the quad kernels (they normalise by a lagged state maximum only: log-likelihoods far from 0 -- GMM

@@ -7,55 +7,37 @@
 
 namespace mm {
 
-// Workgroup -> (pair, set).  Workgroups b and b + 8 have been seen to share an XCD (its L2): the workgroups of a team are
+// Workgroup -> (direction, pair, set).  Workgroups b and b + 8 have been seen to share an XCD (its L2): the workgroups of a team are
 // 8 apart, so their exchange stays inside one L2 where that holds (speed only; any placement is correct).
 // (teams of 2: a vector of 24 KB, up to 3070 states; teams of 4: 32 KB, up to 4094 states, a quarter of the rows each)
 template <int H> struct SplitGeo;
 template <> struct SplitGeo<2> { static constexpr int RS = MM_SPLIT_RS, RSH = MM_SPLIT_RSH; };
 template <> struct SplitGeo<4> { static constexpr int RS = MM_SPLIT4_RS, RSH = MM_SPLIT4_RSH; };
-template <int NJ, int PHASE, int DIR, int H>
-__global__ void __launch_bounds__(1024) mm_fbs_kernel_dir(RunParams p) {
-    const int blk = blockIdx.x;
+// One launch per phase: the teams of the forward agents are the first half of the grid, those of the backward agents the
+// second (mm_pairs_tu.hip; a half is a multiple of 8 H workgroups: the block -> XCD pattern is the same in both).
+template <int NJ, int PHASE, int H>
+__global__ void __launch_bounds__(1024) mm_fbs_kernel(RunParams p) {
+    const int half = (int)gridDim.x / 2, dir = (int)blockIdx.x >= half;
+    const int blk = (int)blockIdx.x - (dir ? half : 0);
     const int pair = (blk / (8 * H)) * 8 + (blk & 7), hset = (blk >> 3) % H;
     if (pair >= (p.B + 1) / 2) return;
-    pair_agent<MM_SPLIT_KA, SplitGeo<H>::RS, PHASE, DIR, NJ, H, SplitGeo<H>::RSH>(p, pair, hset);
+    pair_agent<MM_SPLIT_KA, SplitGeo<H>::RS, PHASE, -1, NJ, H, SplitGeo<H>::RSH>(p, pair, hset, dir);
 }
-template <int NJ, int PHASE, int DIR, int H>
-static int launch_split_one(const PairLaunch *h, const RunParams &p, hipStream_t st) {
+template <int NJ, int PHASE, int H>
+static int launch_split_phase(const PairLaunch *h, const RunParams &p, hipStream_t st) {
     const size_t lds = pair_lds_bytes(SplitGeo<H>::RS, PHASE, h->slotrows, SplitGeo<H>::RSH);
     if (lds > 160 * 1024) return mm_fail(MM_ERR_UNSUPPORTED, "split kernel: LDS");
-    auto kernel = mm_fbs_kernel_dir<NJ, PHASE, DIR, H>;
+    auto kernel = mm_fbs_kernel<NJ, PHASE, H>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
     const unsigned npairs = unsigned((h->B + 1) / 2);
-    hipLaunchKernelGGL(kernel, dim3((npairs + 7) / 8 * 8 * H), dim3(64 * (MM_SPLIT_NWC + 2)), lds, st, p);
+    hipLaunchKernelGGL(kernel, dim3(2 * ((npairs + 7) / 8 * 8 * H)), dim3(64 * (MM_SPLIT_NWC + 2)), lds, st, p);
     HIP_TRY(hipGetLastError());
     return MM_OK;
 }
 template <int NJ, int H>
 static int launch_split_nj(const PairLaunch *h, const RunParams &p, hipStream_t s0) {
-    hipStream_t sf = h->side[0], sb = h->side[1];
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s0, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) sf = s0;  // (see mm_pairs_tu.hip)
-    HIP_TRY(hipEventRecord(h->ev[0], s0));  // fork
-    HIP_TRY(hipStreamWaitEvent(sf, h->ev[0], 0));
-    HIP_TRY(hipStreamWaitEvent(sb, h->ev[0], 0));
-    auto body = [&]() -> int {
-        int rc = launch_split_one<NJ, 0, 0, H>(h, p, sf);
-        if (!rc) rc = launch_split_one<NJ, 0, 1, H>(h, p, sb);
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(h->ev[1], sf));  // phase B of either direction needs phase A of both
-        HIP_TRY(hipEventRecord(h->ev[2], sb));
-        HIP_TRY(hipStreamWaitEvent(sf, h->ev[2], 0));
-        HIP_TRY(hipStreamWaitEvent(sb, h->ev[1], 0));
-        rc = launch_split_one<NJ, 1, 0, H>(h, p, sf);
-        if (!rc) rc = launch_split_one<NJ, 1, 1, H>(h, p, sb);
-        return rc;
-    };
-    const int rc = body();
-    HIP_TRY(hipEventRecord(h->ev[3], sf));  // join (also after a failed launch)
-    HIP_TRY(hipEventRecord(h->ev[4], sb));
-    HIP_TRY(hipStreamWaitEvent(s0, h->ev[3], 0));
-    HIP_TRY(hipStreamWaitEvent(s0, h->ev[4], 0));
+    int rc = launch_split_phase<NJ, 0, H>(h, p, s0);
+    if (!rc) rc = launch_split_phase<NJ, 1, H>(h, p, s0);
     if (rc) return rc;
     hipLaunchKernelGGL(mm_pair_finish_kernel, dim3(unsigned(h->B)), dim3(256), 0, s0, p);
     HIP_TRY(hipGetLastError());

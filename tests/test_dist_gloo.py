@@ -153,7 +153,7 @@ def test_two_ranks_with_the_hip_engine():
     lens = rng.integers(20, 61, 11).astype(np.int32)
     g_ref, ttl = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V, lens, dtype=np.float64)
     for rank, total, allttl, kernels, gsum in res:
-        assert "mm_fbp_kernel_dir" in kernels
+        assert "mm_fbp_kernel" in kernels
         assert np.isclose(total, ttl.sum(), rtol=1e-5)
         assert np.allclose(allttl, ttl, rtol=1e-5, atol=1e-4)
     assert np.isclose(sum(r[4] for r in res), g_ref.sum(), rtol=1e-4)

@@ -1,4 +1,4 @@
-"""GPU tests of the float64 exact pair kernels (mm_kernel_dpair.hip: mm_fbd_kernel_dir) -- where the utterances go that the
+"""GPU tests of the float64 exact pair kernels (mm_kernel_dpair.hip: mm_fbd_kernel) -- where the utterances go that the
 float32 pair kernels mark (sharp emissions: a trained acoustic model), and what runs FIRST while the inputs stay sharp.
 
 src/inference.jl:145-161 runs one algorithm, in the log domain, for every input; the engine's linear-domain kernels must
@@ -52,7 +52,7 @@ def test_sharp_emissions_on_the_float64_kernels_alone(mm, wl, oracle, torch, sig
     lens = np.array([130, 130, 87, 1, 45, 0, 129], dtype=np.int32)
     V = peaky(rng, (B, N, g.P), sigma)
     bf = make_batch(mm, wl, g, B, {"MM_NO_FALLBACK": "1"})
-    assert "mm_fbd_kernel_dir" in bf.kernels(), bf.kernels()
+    assert "mm_fbd_kernel" in bf.kernels(), bf.kernels()
     g1, t1 = bf.pdfposteriors(V, lens)
     assert not bf.last_exact_first()
     redone = bf.last_redo_count()
@@ -109,7 +109,7 @@ def test_float64_kernels_first_on_ordinary_inputs(mm, wl, oracle, torch):
     lens = rng.integers(1, N + 1, B).astype(np.int32)
     V = rng.standard_normal((B, N, g.P)).astype(np.float32)
     bf = make_batch(mm, wl, g, B, {"MM_EXACT_FIRST": "1", "MM_NO_FALLBACK": "1"})
-    assert "mm_fbd_kernel_dir<4" in bf.kernels(), bf.kernels()
+    assert "mm_fbd_kernel<4" in bf.kernels(), bf.kernels()
     gam, ttl = bf.pdfposteriors(V, lens)
     assert bf.last_exact_first() and bf.last_fallback_count() == 0
     g_ref, t_ref = oracle64(oracle, g, V, lens)
@@ -139,9 +139,8 @@ def test_emission_offsets_and_masked_pdfs(mm, wl, oracle, torch):
 
 
 def test_capturable_in_a_hip_graph(mm, wl, torch):
-    """The chain float32 kernels -> finish -> float64 kernels -> finish is launches and memset nodes on the caller's stream
-    and the batch's side streams: a captured call replays to the bits of the eager one, on sharp inputs (the float64 kernels
-    do the work) as well."""
+    """The chain prologue -> float32 kernels -> finish -> float64 kernels -> finish -> item kernel is launches on the caller's
+    stream: a captured call replays to the bits of the eager one, on sharp inputs (the float64 kernels do the work) as well."""
     g = wl.lfmmi_denominator(900, 40, seed=1)
     B, N = 6, 50
     bf = make_batch(mm, wl, g, B, {"MM_EXACT_FIRST": "0"})

@@ -57,7 +57,7 @@ def test_split_kernels_on_the_reference_wsj_denominator(mm, wl, oracle, torch, m
     lens = np.array([70, 70, 41, 70, 1, 33, 64], dtype=np.int32)
     env = {"MM_SPLIT_SLEEP": str(8 | 0x800)} if mode == "write_through" else {}
     gam, ttl, kernels, redo = run_fast_alone(mm, wl, g, V, lens, env)
-    assert "mm_fbs_kernel_dir" in kernels and "teams of 2" in kernels
+    assert "mm_fbs_kernel" in kernels and "teams of 2" in kernels
     assert redo == 0
     g_ref, t_ref = oracle64(oracle, g, V, lens)
     ok = np.isfinite(t_ref)  # (the one-frame utterance has no accepting path: the reference's 0/0)
@@ -90,7 +90,7 @@ def test_split_kernels_teams_of_four(mm, wl, oracle, torch, S, mode):
         env = {"MM_SPLIT_SLEEP": str(8 | 0x800)} if mode == "write_through" else {}
         gam, ttl, kernels, redo = run_fast_alone(mm, wl, g, V, lens, env)
         assert redo == 0
-    assert "mm_fbs_kernel_dir" in kernels and "teams of 4" in kernels, kernels
+    assert "mm_fbs_kernel" in kernels and "teams of 4" in kernels, kernels
     g_ref, t_ref = oracle64(oracle, g, V, lens)
     ok = np.isfinite(t_ref)
     assert ok.sum() >= B - 1
@@ -116,7 +116,7 @@ def test_split_kernels_team_that_does_not_run_together(mm, wl, oracle, torch):
         return gam, ttl, bf.kernels(), bf.last_redo_count()
 
     gam, ttl, kernels, redo = _with_env({"MM_DEBUG": "1", "MM_SPLIT_SLEEP": str(8 | 0x200)}, run)
-    assert "mm_fbs_kernel_dir" in kernels and redo == B
+    assert "mm_fbs_kernel" in kernels and redo == B
     g_ref, t_ref = oracle64(oracle, g, V, lens)
     check_gamma(gam, g_ref, lens)
     assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)
@@ -133,7 +133,7 @@ def test_split_kernels_long_utterances_keep_their_range_marks_harmless(mm, wl, o
     V = rng.standard_normal((B, N, g.P)).astype(np.float32)
     lens = np.array([260, 260, 199, 120], dtype=np.int32)
     gam, ttl, kernels, redo = run_fast_alone(mm, wl, g, V, lens)
-    assert "mm_fbs_kernel_dir" in kernels and redo == 0
+    assert "mm_fbs_kernel" in kernels and redo == 0
     g_ref, t_ref = oracle64(oracle, g, V[:2], lens[:2])
     check_gamma(gam[:2], g_ref, lens[:2])
     assert np.allclose(ttl[:2], t_ref, rtol=1e-5, atol=1e-3)
@@ -158,7 +158,7 @@ def test_range_marks_that_matter_are_redone(mm, wl, torch):
         return gam, ttl, bf.kernels(), bf.last_redo_count()
 
     gam, ttl, kernels, redo = _with_env({"MM_DEBUG": "1", "MM_KERNEL": "pair"}, run)
-    assert "mm_fbp_kernel_dir" in kernels
+    assert "mm_fbp_kernel" in kernels
     assert redo >= 1
     ok = np.isfinite(z["ttl"])
     check_gamma(gam[:3][ok], z["gamma"][ok].astype(np.float64), lens[:3][ok])
@@ -179,7 +179,7 @@ def test_redo_count_is_zero_on_the_benchmark_inputs_and_reported_on_peaky_ones(m
     bf = mm.batch(*([cf] * B))
     assert bf.last_redo_count() == 0  # before the first call
     gam, ttl = bf.pdfposteriors(V, lens)
-    assert "mm_fbp_kernel_dir" in bf.kernels() and bf.last_redo_count() == 0
+    assert "mm_fbp_kernel" in bf.kernels() and bf.last_redo_count() == 0
     Vp = 10.0 * V
     Vp = Vp - np.log(np.exp(Vp - Vp.max(-1, keepdims=True)).sum(-1, keepdims=True)) - Vp.max(-1, keepdims=True)
     gam, ttl = bf.pdfposteriors(Vp.astype(np.float32), lens)
@@ -205,7 +205,7 @@ def test_posterior_floor_keeps_sharp_emissions_on_the_fast_kernels(mm, wl, oracl
     lens = np.array([300, 300, 211, 300, 150, 299], dtype=np.int32)
     cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
     bf = mm.batch(*([cf] * B))
-    assert "mm_fbp_kernel_dir" in bf.kernels()
+    assert "mm_fbp_kernel" in bf.kernels()
     g0, t0 = bf.pdfposteriors(V, lens)
     strict_redone = bf.last_redo_count()
     assert strict_redone > 0  # (what the default costs on such inputs)
@@ -239,8 +239,8 @@ def test_graph_beyond_the_fast_paths(mm, wl, oracle, torch, S, P):
     bf = mm.batch(*([cf] * B))
     gam, ttl = bf.pdfposteriors(V, lens)
     kernels = bf.kernels()
-    assert ("mm_fbs_kernel_dir" in kernels) == (S == 2900), kernels
-    assert bf.last_redo_count() == 0 or "mm_fbs_kernel_dir" not in kernels
+    assert ("mm_fbs_kernel" in kernels) == (S == 2900), kernels
+    assert bf.last_redo_count() == 0 or "mm_fbs_kernel" not in kernels
     g_ref, t_ref = oracle64(oracle, g, V, lens)
     check_gamma(gam, g_ref, lens)
     assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)
@@ -257,7 +257,7 @@ def test_one_utterance_on_the_pair_kernels(mm, wl, oracle, torch, which):
     V = (1.3 * rng.standard_normal((1, N, g.P))).astype(np.float32)
     cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
     bf = mm.batch(cf)
-    assert ("mm_fbp_kernel_dir" if which == "pair" else "mm_fbs_kernel_dir") in bf.kernels(), bf.kernels()
+    assert ("mm_fbp_kernel" if which == "pair" else "mm_fbs_kernel") in bf.kernels(), bf.kernels()
     for L in (N, 31, 1, 0):
         lens = np.array([L], dtype=np.int32)
         gam, ttl = bf.pdfposteriors(V, lens)
@@ -273,14 +273,14 @@ def test_one_utterance_on_the_pair_kernels(mm, wl, oracle, torch, which):
 @pytest.mark.parametrize("P", [130, 249])
 def test_pair_kernels_with_many_pdfs(mm, wl, oracle, torch, P):
     """P + 1 in 129..250: the service wave of the pair kernels runs four 64-lane passes over the pdfs
-    (mm_fbp_kernel_dir<4, ...>), an instance no other test reaches."""
+    (mm_fbp_kernel<4, ...>), an instance no other test reaches."""
     g = wl.lfmmi_denominator(1200, P - (P % 2), seed=4)
     rng = np.random.default_rng(P)
     B, N = 5, 40
     V = (1.3 * rng.standard_normal((B, N, g.P))).astype(np.float32)
     lens = np.array([40, 40, 23, 40, 9], dtype=np.int32)
     gam, ttl, kernels, redo = run_fast_alone(mm, wl, g, V, lens)
-    assert "mm_fbp_kernel_dir<4" in kernels and redo == 0
+    assert "mm_fbp_kernel<4" in kernels and redo == 0
     g_ref, t_ref = oracle64(oracle, g, V, lens)
     check_gamma(gam, g_ref, lens)
     assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)
@@ -321,7 +321,7 @@ def test_odd_batch_beyond_the_compute_units_on_the_pair_kernels(mm, wl, oracle, 
     V = rng.standard_normal((B, N, g.P)).astype(np.float32)
     lens = rng.integers(0, N + 1, size=B).astype(np.int32)
     gam, ttl, kernels, redo = run_fast_alone(mm, wl, g, V, lens)
-    assert "mm_fbp_kernel_dir" in kernels and redo == 0
+    assert "mm_fbp_kernel" in kernels and redo == 0
     g_ref, t_ref = oracle64(oracle, g, V, lens)
     ok = np.isfinite(t_ref)
     check_gamma(gam[ok], g_ref[ok], lens[ok])
@@ -345,7 +345,7 @@ def test_batch_beyond_the_ordered_limit(mm, wl, oracle, torch, kernel):
         return bf.pdfposteriors(V, lens) + (bf.kernels(),)
 
     gam, ttl, kernels = _with_env({"MM_DEBUG": "1", "MM_KERNEL": kernel}, run)
-    assert ("mm_fbp_kernel_dir" if kernel == "pair" else "mm_wave_kernel") in kernels, kernels
+    assert ("mm_fbp_kernel" if kernel == "pair" else "mm_wave_kernel") in kernels, kernels
     g_ref, t_ref = oracle64(oracle, g, V, lens)
     ok = np.isfinite(t_ref)
     check_gamma(gam[ok], g_ref[ok], lens[ok])
@@ -378,9 +378,9 @@ def test_fuzz_round3_one_seed(mm, wl, oracle, torch):
 def test_engine_under_a_live_rccl_process_group(mm, wl, oracle, torch):
     """The HIP engine inside a torch.distributed process ("nccl" = RCCL, one rank: what every rank of bench.py --gpus N
     is): with an RCCL communicator alive HIP maps streams to hardware queues differently, and the two agents of the
-    pair kernels once shared a queue (5.7 instead of 3.2 ms per call).  The batch must still find a concurrent stream
-    pair, the step (pdfposteriors + the logZ all-reduce) must give the oracle's numbers.  Runs in a child process: the
-    process group must not leak into the other tests."""
+    pair kernels -- two kernels on two library streams until round 3 -- once shared a queue and took turns (5.7 instead of
+    3.2 ms per call).  They are workgroups of ONE grid now; the step (pdfposteriors + the logZ all-reduce) must give the
+    oracle's numbers.  Runs in a child process: the process group must not leak into the other tests."""
     import subprocess
     import sys
 
@@ -405,7 +405,7 @@ lens = np.array([50, 50, 31, 50, 12, 44], dtype=np.int32)
 cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
 bf = mm.batch(*([cf] * B))
 k = bf.kernels()
-assert "mm_fbp_kernel_dir" in k and "no concurrent stream pair" not in k, k
+assert "mm_fbp_kernel" in k and "in one grid" in k, k
 gam, ttl = bf.pdfposteriors(torch.from_numpy(V).cuda(), torch.from_numpy(lens).cuda())
 total = mm.dist.allreduce_logz(ttl)
 torch.cuda.synchronize()
@@ -420,16 +420,15 @@ print("OK-DIST")
     assert r.returncode == 0 and "OK-DIST" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
-def test_two_batches_alive_have_their_own_side_streams(mm, wl, oracle, torch):
-    """Two batches of the pair kernels alive at the same time, driven from two streams of the caller: each forks into a
-    pair of side streams of its own (a pool per device); same results as one after the other, and a destroyed batch's
-    pair is reused."""
+def test_two_batches_alive_on_two_streams(mm, wl, oracle, torch):
+    """Two batches of the pair kernels alive at the same time, driven from two streams of the caller (each call is a chain
+    of launches on its caller's stream, nothing shared but the FSM): same results as one after the other."""
     g = wl.lfmmi_denominator(600, 40, seed=5)
     cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
     B, N = 6, 80
     V = [torch.randn(B, N, g.P, device="cuda") for _ in range(2)]
     bfs = [mm.batch(*([cf] * B)) for _ in range(2)]
-    assert all("mm_fbp_kernel_dir" in bf.kernels() and "no concurrent stream pair" not in bf.kernels() for bf in bfs)
+    assert all("mm_fbp_kernel" in bf.kernels() for bf in bfs)
     ref = [bf.pdfposteriors(v) for bf, v in zip(bfs, V)]
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream() for _ in range(2)]

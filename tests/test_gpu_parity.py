@@ -389,10 +389,10 @@ def test_call_is_capturable_in_a_hip_graph(mm, wl, torch):
     it can be captured in a hipGraph and replayed."""
     g = wl.random_fsm(200, 10, 4.0, seed=4)
     B, N = 8, 30
-    # (the pair kernels, with their fork to the side streams: forced -- the engine prefers the wave kernel for a graph this small)
+    # (the pair kernels and the float64 exact kernels behind them: forced -- the engine prefers the wave kernel for a graph this small)
     bf = _with_env({"MM_DEBUG": "1", "MM_KERNEL": "pair"},
                    lambda: mm.batch(*([mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))] * B)))
-    assert "mm_fbp_kernel_dir" in bf.kernels(), bf.kernels()
+    assert "mm_fbp_kernel" in bf.kernels(), bf.kernels()
     V = torch.randn(B, N, g.P, device="cuda")
     lens = torch.tensor([N, N - 3, 5, 1, N, 0, 17, N], dtype=torch.int32, device="cuda")
     gamma = torch.empty(B, N, g.P, device="cuda")
@@ -420,7 +420,7 @@ def test_other_kernel_families_are_capturable(mm, wl, torch, kind):
     if kind == "split":
         g = wl.load_npz_graph(os.path.join(here, "den_fsm_wsj.npz"))
         cfs = [mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))] * 6
-        P, want = g.P, "mm_fbs_kernel_dir"
+        P, want = g.P, "mm_fbs_kernel"
     elif kind == "wave":
         gs = [wl.load_npz_graph(os.path.join(here, "num_fsm_wsj.npz")), wl.lexicon_fsm(300, 20, seed=2, hubs=1), wl.lexicon_fsm(700, 84, seed=5, hubs=2)]
         P = max(g.P for g in gs)
@@ -619,8 +619,8 @@ def test_wave_kernel_first_wherever_the_graphs_fit(mm, wl, oracle, torch):
              ("one utterance", [wl.l2r_hmm(3)], "mm_wave_kernel"),
              ("dense, small batch", [wl.dense_ergodic(20, seed=3)] * 4, "mm_wave_kernel"),
              ("dense, many utterances, 2 segments per wave", [wl.dense_ergodic(16, seed=3)] * 520, "mm_wave_kernel<2,2,two per CU>"),
-             ("dense, many utterances, 4 segments per wave", [wl.dense_ergodic(32, seed=3)] * 520, "mm_fbp_kernel_dir"),
-             ("more arcs than the form holds", [wl.lfmmi_denominator(400, 20, seed=9)] * 4, "mm_fbp_kernel_dir")]
+             ("dense, many utterances, 4 segments per wave", [wl.dense_ergodic(32, seed=3)] * 520, "mm_fbp_kernel"),
+             ("more arcs than the form holds", [wl.lfmmi_denominator(400, 20, seed=9)] * 4, "mm_fbp_kernel")]
     for name, gs, want in cases:
         B, N = len(gs), 23
         P = max(g.P for g in gs)

@@ -73,7 +73,7 @@ def fuzz_split(rng):
             a_g, a_t, names, bf = posteriors([cf] * B, V, lt, None)
             n += 1
             et, eg = posterior_error(a_g, a_t, ref_g, ref_t)
-            ok = np.isfinite(et) and np.isfinite(eg) and et < 1e-4 and eg < 1e-4 and "mm_fbs_kernel_dir" in names
+            ok = np.isfinite(et) and np.isfinite(eg) and et < 1e-4 and eg < 1e-4 and "mm_fbs_kernel" in names
             if not ok:
                 bad += 1
                 print(f"MISMATCH split graph {gi} B {B} N {N} lens {lens.tolist()[:12]} ({names[:50]}): ttl {et:.2e} gamma {eg:.2e}")

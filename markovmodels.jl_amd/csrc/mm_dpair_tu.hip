@@ -32,9 +32,46 @@ static int launch_dpairs_nj(const PairLaunch *h, const RunParams &p, hipStream_t
     HIP_TRY(hipGetLastError());
     return MM_OK;
 }
+// ---- teams of H workgroups per utterance and direction (the split kernels' graphs: mm_split_tu.hip)
+template <int H> struct DSplitGeo;
+template <> struct DSplitGeo<2> { static constexpr int RS = MM_SPLIT_RS, RSH = MM_SPLIT_RSH; };
+template <> struct DSplitGeo<4> { static constexpr int RS = MM_SPLIT4_RS, RSH = MM_SPLIT4_RSH; };
+template <int NJ, int PHASE, int H>
+__global__ void __launch_bounds__(1024) mm_fbds_kernel(RunParams p) {
+    const int half = (int)gridDim.x / 2, dir = (int)blockIdx.x >= half;
+    const int blk = (int)blockIdx.x - (dir ? half : 0);
+    const int ui = (blk / (8 * H)) * 8 + (blk & 7), hset = (blk >> 3) % H;  // (the workgroups of a team are 8 apart: mm_split_tu.hip)
+    if (ui >= p.B) return;
+    dpair_agent<MM_SPLIT_KA, DSplitGeo<H>::RS, PHASE, NJ, H, DSplitGeo<H>::RSH>(p, ui, dir, hset);
+}
+template <int NJ, int PHASE, int H>
+static int launch_dsplit_phase(const PairLaunch *h, const RunParams &p, hipStream_t st) {
+    const size_t lds = pair_lds_bytes(DSplitGeo<H>::RS, PHASE, h->slotrows, DSplitGeo<H>::RSH);
+    if (lds > 160 * 1024) return mm_fail(MM_ERR_UNSUPPORTED, "exact split kernel: LDS");
+    auto kernel = mm_fbds_kernel<NJ, PHASE, H>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    hipLaunchKernelGGL(kernel, dim3(2 * ((unsigned(h->B) + 7) / 8 * 8 * H)), dim3(64 * (MM_SPLIT_NWC + 2)), lds, st, p);
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+}
+template <int NJ, int H>
+static int launch_dsplit_nj(const PairLaunch *h, const RunParams &p, hipStream_t s0) {
+    int rc = launch_dsplit_phase<NJ, 0, H>(h, p, s0);
+    if (!rc) rc = launch_dsplit_phase<NJ, 1, H>(h, p, s0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mm_dpair_finish_kernel, dim3(unsigned(h->B)), dim3(256), 0, s0, p);
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+}
 int mm_launch_dpairs(const PairLaunch &pl, const RunParams &p, hipStream_t s0) {
-    if (pl.pair_ka > MM_PAIR_KA || pl.H != 1) return MM_ERR_UNSUPPORTED;
-    return pl.max_P1 <= 128 ? launch_dpairs_nj<2>(&pl, p, s0) : launch_dpairs_nj<4>(&pl, p, s0);
+    if (pl.H == 1) {
+        if (pl.pair_ka > MM_PAIR_KA) return MM_ERR_UNSUPPORTED;
+        return pl.max_P1 <= 128 ? launch_dpairs_nj<2>(&pl, p, s0) : launch_dpairs_nj<4>(&pl, p, s0);
+    }
+    if (pl.pair_ka > MM_SPLIT_KA) return MM_ERR_UNSUPPORTED;
+    if (pl.H == 4) return pl.max_P1 <= 128 ? launch_dsplit_nj<2, 4>(&pl, p, s0) : launch_dsplit_nj<4, 4>(&pl, p, s0);
+    if (pl.H != 2) return mm_fail(MM_ERR_UNSUPPORTED, "exact split kernel: teams of 2 or 4");
+    return pl.max_P1 <= 128 ? launch_dsplit_nj<2, 2>(&pl, p, s0) : launch_dsplit_nj<4, 2>(&pl, p, s0);
 }
 
 }  // namespace mm

@@ -1604,7 +1604,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     }
     // (a batch of the wave kernel never runs the quad kernels, and one whose marked utterances go to the float64 pair kernels
     // has the item kernel behind those: their quad forms are not built)
-    const bool want_dpair = h->pairs_ok && h->pair_H == 1 && !h->dbg.no_dpair;
+    const bool want_dpair = h->pairs_ok && !h->dbg.no_dpair;
     h->quad_built = h->fast_ok && !h->wave_ok && !(want_dpair && h->dbg.kernel != DebugOpts::K_QUAD);
     for (int64_t b = 0; b < B; ++b) {
         mm_fsm_t f = fsms[b];
@@ -1804,7 +1804,11 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
         } else if (h->pairs_ok && h->pair_H > 1) {
             const std::string k = std::to_string(h->max_P1 <= 128 ? 2 : 4), H = std::to_string(h->pair_H);
             s = "mm_fbs_kernel<" + k + ",A," + H + ">, then <" + k + ",B," + H + "> (forward and backward agents in one grid, teams of " + H +
-                " workgroups), mm_pair_finish_kernel, then for marked utterances only " + exact;
+                " workgroups), mm_pair_finish_kernel, then for marked utterances only " +
+                (h->dpair_ok ? "mm_fbds_kernel<" + k + ",A," + H + ">, then <" + k + ",B," + H + "> (float64, one utterance per team; FIRST and "
+                               "alone while the inputs are hard), mm_dpair_finish_kernel, then for what those mark "
+                             : std::string()) +
+                exact;
         } else if (h->pairs_ok) {
             const std::string k = std::to_string(h->max_P1 <= 128 ? 2 : 4);
             s = "mm_fbp_kernel<" + k + ",A>, then <" + k + ",B> (forward and backward agents in one grid), mm_pair_finish_kernel, then for marked "
@@ -1848,9 +1852,16 @@ static size_t ws_x_rows_bytes(mm_batch_t h) {
 static size_t ws_x_bytes(mm_batch_t h) {
     return h->pair_H > 1 ? align_up(ws_x_rows_bytes(h) + size_t((h->B + 1) / 2) * 2 * size_t(h->pair_H) * 4 * 512 * 4, 256) : 0;
 }
+// ... and for the teams of the float64 kernels (one utterance per team: B "pairs")
+static size_t ws_xd_rows_bytes(mm_batch_t h) {
+    return h->pair_H > 1 && h->dpair_ok ? size_t(2) * size_t(h->B) * 2 * size_t(h->pair_H) * 2 * (2 * size_t(h->split_s1p)) * 4 : 0;
+}
+static size_t ws_xd_bytes(mm_batch_t h) {
+    return h->pair_H > 1 && h->dpair_ok ? align_up(ws_xd_rows_bytes(h) + size_t(h->B) * 2 * size_t(h->pair_H) * 4 * 512 * 4, 256) : 0;
+}
 static size_t ws_tail_bytes(mm_batch_t h) {  // longest-first order, redo marks, pair hand-over, per-direction log Z minima, team buffers
     return 2 * align_up(size_t(h->B + 1) * 4, 256) + align_up(size_t(h->B + 1) * 2 * mm_pair_hand_bytes(), 256) +
-           align_up(size_t(h->B) * 6 * 8, 256) + ws_x_bytes(h) + align_up(size_t(h->B + 1) * 4, 256);  // (last: redo2)
+           align_up(size_t(h->B) * 6 * 8, 256) + ws_x_bytes(h) + ws_xd_bytes(h) + align_up(size_t(h->B + 1) * 4, 256);  // (last: redo2)
 }
 
 // (quad kernels) the emissions shifted by their per-frame maxima [B][N][P], and the maxima [B][N]
@@ -2016,7 +2027,13 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
                 p.x_slot = 2ll * h->split_s1p;
                 p.x_phase = (long long)(ws_x_rows_bytes(h) / 8);
                 p.x_sleep = h->dbg.x_sleep;
-                HIP_TRY(hipMemsetAsync(p.xbuf, 0, ws_x_bytes(h), static_cast<hipStream_t>(stream)));
+                p.xbuf_d = reinterpret_cast<float *>(reinterpret_cast<char *>(p.xbuf) + ws_x_bytes(h));
+                p.xps_d = reinterpret_cast<float *>(reinterpret_cast<char *>(p.xbuf_d) + ws_xd_rows_bytes(h));
+                p.x_phase_d = (long long)(ws_xd_rows_bytes(h) / 8);
+                // (one memset node over what this call can touch: a call that goes to the float64 kernels with the whole batch leaves
+                // the float32 kernels' area alone, one that starts with the float32 kernels zeroes both -- marks are not known here)
+                if (exact_first) HIP_TRY(hipMemsetAsync(p.xbuf_d, 0, ws_xd_bytes(h), static_cast<hipStream_t>(stream)));
+                else HIP_TRY(hipMemsetAsync(p.xbuf, 0, ws_x_bytes(h) + ws_xd_bytes(h), static_cast<hipStream_t>(stream)));
             }
             h->last_z = p.pair_zmin;
             rc = exact_first ? MM_OK : launch_pairs(h, p, stream);
@@ -2034,7 +2051,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
             pl.slotrows = h->pair_slotrows;
             pl.max_P1 = h->max_P1;
             pl.pair_ka = h->pair_ka;
-            pl.H = 1;
+            pl.H = h->pair_H;
             rc = mm_launch_dpairs(pl, p, static_cast<hipStream_t>(stream));
             if (rc) return rc;
             h->last_redo2 = p.redo2;

@@ -134,15 +134,55 @@ __device__ __forceinline__ float dpair_scan_max(unsigned pbase, int n2, int lane
 
 // one wave: per-frame sum over the pdfs (psum doubles [pdf]), divide, store gamma (src/inference.jl:156-160); returns
 // log2 of the sum (-inf, and gamma = 0, if nothing is alive)
-template <int NJ>  // NJ * 64 >= P + 1
-__device__ __forceinline__ float dpair_finish_frame(unsigned psum, int P1, int P, int lane, float *gp, long long gsp, bool store) {
+// (teams: xp[g] = the slot of the step in which set g published its partial sums, NULL for the own set; the sum of a pdf is the
+// sum of the sets' parts in the order of the sets -- the same bits in every workgroup; *arrived = false if a poll timed out)
+template <int NJ, int H = 1>  // NJ * 64 >= P + 1
+__device__ __forceinline__ float dpair_finish_frame(unsigned psum, int P1, int P, int lane, float *gp, long long gsp, bool store,
+                                                    const float *const *xp = nullptr, unsigned tag = 0u, unsigned long long tmo = MM_SPLIT_TIMEOUT,
+                                                    bool *arrived = nullptr) {
     double s[NJ], t = 0.0;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int q = lane + 64 * j;
         s[j] = ldsr_d(psum + 8u * (q < P1 ? q : 0));
-        if (q < P1) t += s[j];
     }
+    if constexpr (H > 1) {
+        double tot[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) tot[j] = 0.0;
+        for (int g = 0; g < H; ++g) {
+            if (xp[g] == nullptr) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) tot[j] += s[j];
+                continue;
+            }
+            mm_u64 v[NJ];
+            const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int q = lane + 64 * j;
+                    v[j] = granule_load(xp[g], 8u * (unsigned)(q < P1 ? q : 0));
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) ok = ok && ((unsigned)(v[j] >> 63) == tag);
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                if (__builtin_amdgcn_s_memrealtime() - tstart >= tmo) {
+                    *arrived = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) tot[j] += __builtin_bit_cast(double, v[j] & 0x7fffffffffffffffull);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) s[j] = tot[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (lane + 64 * j < P1) t += s[j];
     t = dwave_sum_rl(t);
     // gamma = s / t through floats on the scale of t: s 2^-e / (t 2^-e), e = the exponent of t
     const int e = __builtin_amdgcn_frexp_exp(t);
@@ -156,8 +196,20 @@ __device__ __forceinline__ float dpair_finish_frame(unsigned psum, int P1, int P
     return dlog2(t);
 }
 
+// ---- teams (H > 1: the split kernels of mm_kernel_pairs.hip): a granule is ONE double whose sign bit carries the step's tag
+// (linear values are >= 0; 2^-inf = +0 becomes -0)
+__device__ __forceinline__ void dgranule_store(float *base, unsigned byte_off, double v) {
+    __hip_atomic_store((mm_gu64 *)(__UINTPTR_TYPE__)(reinterpret_cast<char *>(base) + byte_off), __builtin_bit_cast(mm_u64, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double dsigned(double v, bool neg) {  // v with the tag in its sign bit (v >= 0)
+    return __builtin_bit_cast(double, __builtin_bit_cast(mm_u64, v) | (neg ? 0x8000000000000000ull : 0ull));
+}
+
 // pdf sums (q doubles in pdf-major order): 8 pdfs per wave and pass, 8 lanes per pdf (pair_pdf_sums for doubles)
-__device__ __forceinline__ void dpair_pdf_sums(unsigned qbase, unsigned pdfse_base, unsigned psum_base, int P1, int wave, int NWC, int lane) {
+// (teams: xs = the slot the partial sums are published in, tagged by `neg`)
+__device__ __forceinline__ void dpair_pdf_sums(unsigned qbase, unsigned pdfse_base, unsigned psum_base, int P1, int wave, int NWC, int lane,
+                                               float *xs = nullptr, bool neg = false) {
     for (int p0 = wave * 8; p0 < P1; p0 += NWC * 8) {
         const int pdf = p0 + (lane >> 3);
         double s0 = 0.0;
@@ -173,7 +225,10 @@ __device__ __forceinline__ void dpair_pdf_sums(unsigned qbase, unsigned pdfse_ba
             for (unsigned a = a0 + 256u; a < a1; a += 64u) s0 += ldsr_d(qbase + a);
         }
         s0 = dgrp_sum8(s0);
-        if (pdf < P1 && (lane & 7) == 0) ldsw_d(psum_base + 8u * pdf, s0);
+        if (pdf < P1 && (lane & 7) == 0) {
+            ldsw_d(psum_base + 8u * pdf, s0);
+            if (xs) dgranule_store(xs, 8u * (unsigned)pdf, dsigned(s0, neg));
+        }
     }
 }
 
@@ -241,27 +296,29 @@ __device__ __forceinline__ void dpair_two(const mm_f32x2 (&wr)[KA / 2], const un
 // One agent: direction rdir (0: forward / alpha, 1: backward / beta) of the utterance of rank `ui` (longest first), phase
 // PHASE (0: A, 1: B).  The structure, the step numbering and the LDS layout are pair_agent's (mm_kernel_pairs.hip).
 // (the direction is a run-time value, the same for the whole workgroup: see pair_agent)
-template <int KA, int RS, int PHASE, int NJ>
-__device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir) {
+// H > 1: the agent is a TEAM of H workgroups, this one finishes the rows of set `hset` (the split kernels: graphs beyond the
+// registers / LDS of one compute unit); the exchange is pair_agent's with a granule = one tagged double.
+template <int KA, int RS, int PHASE, int NJ, int H = 1, int RSH = 2 * RS>
+__device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir, int hset = 0) {
     extern __shared__ float lds[];
     const int DIR = __builtin_amdgcn_readfirstlane(rdir);
-    constexpr int RSH = 2 * RS;
     using L = PairLay<RS, PHASE, RSH>;
     constexpr int D = 3;  // gather pairs in flight ahead of the FMAs
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, NWC = NW - 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, NWC = NW - (H > 1 ? 2 : 1);
     const bool service = wave == NWC;
+    const bool xwave = H > 1 && wave == NWC + 1;  // the exchange wave of a team's workgroup
     // ---- the utterance
     const int b = uni(p.order ? p.order[ui] : ui);
     if (uni(p.redo[b]) == 0) return;  // (not marked by the float32 kernels: their result stands)
-    if (service) __builtin_amdgcn_s_setprio(3);
+    if (service || xwave) __builtin_amdgcn_s_setprio(3);
     int len = uni(p.lens ? p.lens[b] : p.N);
     len = len < 0 ? 0 : (len > p.N ? p.N : len);
     const float *Vb = p.V + (long long)b * p.vsb;
     double *offs = p.ws_c + (long long)b * (p.N + 2);  // [N + 2] cumulative offset of the stored vector of every frame
     const int NFp = len + 1;
     const UttDesc &ud = p.utts[b];
-    const RowU r = uni(ud.rp[DIR]);
+    const RowU r = uni(H > 1 ? ud.rps[DIR][hset] : ud.rp[DIR]);
     const int S1 = r.rows, S1p = p.pair_s1p, P1 = uni(ud.P1), P = P1 - 1, P1p = (P1 + 3) & ~3;
     // state vectors of the utterance's frames (alpha~ up to the split, beta~ beyond): float32 log2 values [N + 2][S1p]
     float *rowsP = p.ws_alpha + (long long)b * (long long)(p.N + 2) * S1p;
@@ -285,6 +342,22 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
     if constexpr (PHASE == 1)
         for (int q = tid; q < P1; q += NT) ldswu(L::PDFSE + 4u * q, as_global(reinterpret_cast<const unsigned *>(r.pdfse))[q]);
     int *redo2 = p.redo2 + b;
+    // ---- the team: own set's region, own / others' slots of this launch (the float64 kernels' own exchange area: p.xbuf_d)
+    const int xbase = H > 1 ? p.sp_base[hset] : 0, xcnt = H > 1 ? p.sp_cnt[hset] : 0;
+    float *xsend = nullptr, *xps_send = nullptr;
+    bool xplain = false;
+    const float *xrecv[H], *xps_recv[H];
+    if constexpr (H > 1) {
+        float *xb = p.xbuf_d + (long long)PHASE * p.x_phase_d + ((long long)ui * 2 + DIR) * H * 2 * p.x_slot;
+        float *xq = p.xps_d + ((long long)ui * 2 + DIR) * H * 4 * 512;
+#pragma unroll
+        for (int g = 0; g < H; ++g) {
+            xrecv[g] = g == hset ? nullptr : xb + (long long)g * 2 * p.x_slot;
+            xps_recv[g] = g == hset ? nullptr : xq + (long long)g * 4 * 512;
+        }
+        xsend = xb + (long long)hset * 2 * p.x_slot;
+        xps_send = xq + (long long)hset * 4 * 512;
+    }
     unsigned long long endmask = 0, lgw0 = 0;
     int nslots = 0;
     unsigned slot_base = 0;
@@ -326,6 +399,10 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
     };
     // steps of this launch: (t0, t1]; the vector of step t0 is the starting point
     const int t0 = PHASE ? tA : 1, t1 = PHASE ? tEnd : tA;
+    // (teams) the rows of the own set of a frame, as the partner stored them: floats at rowsP + f * S1p + xbase; the LDS-DMA
+    // moves aligned float4s, so the copy starts at the float4 that holds the first row and a row sits xoff bytes further on
+    const int xal = xbase & ~3;
+    const unsigned xoff = 4u * (unsigned)(xbase - xal);
     __syncthreads();
 
     if (service) {
@@ -338,13 +415,13 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             const int tt = t < 1 ? 1 : (t > tEnd ? tEnd : t);
             row_dma_em<NJ>(L::RAW(0, 0) + 2048u * (t & 3), Vb, p.vsn, frame_of(tt), p.N, P, sl);
         };
-        constexpr int NDM = RSH / 2048;  // 1 KB DMAs of a row of floats
+        constexpr int NDM = (RSH / 2 + 16 + 1023) / 1024;  // 1 KB DMAs of a row of floats (teams: + the alignment shift)
         auto dma_partner = [&](int t) {  // the other agent's vector + offset of step t's frame -> AL(t % 3), POFF(t & 7, 0)
             const int tt = t < 1 ? 1 : (t > tEnd ? tEnd : t);
             int f = frame_of(tt);
             f = f > p.N ? p.N : f;  // (frame N+1 is never combined)
-            const int n4 = S1p >> 2;  // float4s of the row
-            const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(rowsP + (long long)f * S1p);
+            const int n4 = H > 1 ? (int)((xoff / 4u + (unsigned)xcnt + 3u) >> 2) : S1p >> 2;  // float4s of the row
+            const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(rowsP + (long long)f * S1p + xal);
             const unsigned dst = L::AL(0) + (unsigned)(tt % 3) * (unsigned)RSH;
 #pragma unroll
             for (int j = 0; j < NDM; ++j) {
@@ -363,7 +440,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                 // the offset that turns the step's stored vector into log2 values: forward alpha~ includes the emission
                 const double off = DIR ? cum - (double)E : cum;
                 *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(L::OWN(t & 3)) = off;
-                if (PHASE == 0) offs[frame_of(t)] = off;
+                if (PHASE == 0 && (H == 1 || hset == 0)) offs[frame_of(t)] = off;
             }
         };
         // ---- prologue: everything step t0 + 1 needs
@@ -384,14 +461,14 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             const float E = pair_stage_em<NJ>(L::EM(t0 & 1), L::RAW(0, 0) + 2048u * (t0 & 3), 0, frame_of(t0), len, P, sl);
             if (PHASE == 0) {  // step 1 subtracts nothing but E
                 cum = (double)E;
-                if (DIR == 0 && sl == 0) offs[1] = cum;
+                if (DIR == 0 && sl == 0 && (H == 1 || hset == 0)) offs[1] = cum;
             }
         }
         __syncthreads();  // (1) emissions of step t0 staged
         if (t0 + 1 <= t1) stage(t0 + 1, norm.s_cur);  // (phase A: 0 -- step 2 subtracts nothing but E)
         dma_raw(t0 + 4);
         __syncthreads();  // (2) starting vector in LDS, step t0 + 1 prepared
-        // posteriors and per-frame log Z of step ts (its per-pdf sums are complete)
+        // posteriors and per-frame log Z of step ts (its per-pdf sums are complete); H > 1: the exchange wave's job
         auto frames_of_step = [&](int ts, unsigned psum) {
             const int f = frame_of(ts);
             const bool live = f >= 1 && f <= len;
@@ -407,7 +484,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
         };
         auto step = [&](auto RDc, int t) {
             constexpr int RD = decltype(RDc)::value, WR = 1 - RD;  // RD = parity of steps t - 1 and t + 1
-            if constexpr (NJ > 2) asm volatile("" : "+v"(sl));
+            if constexpr (H > 1 || NJ > 2) asm volatile("" : "+v"(sl));
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
             MM_STAMP(2);
             // the normaliser of step t + 1 from the maximum of step t - 1 (complete since the last barrier)
@@ -422,7 +499,8 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             if constexpr (PHASE == 1) {
                 dma_partner(t + 2);
                 MM_STAMP(5);
-                if (t - 2 > t0) frames_of_step(t - 2, L::PSUM(WR));  // gamma of step t - 2: its per-pdf sums were completed in the previous step
+                if constexpr (H == 1)
+                    if (t - 2 > t0) frames_of_step(t - 2, L::PSUM(WR));  // gamma of step t - 2: its per-pdf sums were completed in the previous step
                 MM_STAMP(6);
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");  // the partner vector of step t + 1 (requested at step t - 1)
                 MM_STAMP(7);
@@ -441,7 +519,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             }
         }
         if constexpr (PHASE == 0) {
-            if (sl == 0) {
+            if (sl == 0 && (H == 1 || hset == 0)) {
                 PairHand h;
                 h.m_prev = norm.m_prev;
                 h.s_cur = norm.s_cur;
@@ -458,12 +536,83 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             for (int k = 1; k >= 0; --k) {
                 const int t = t1 - k;
                 if (k == 0) __syncthreads();  // (a)
-                if (t > t0) frames_of_step(t, L::PSUM(t & 1));
+                if (H == 1 && t > t0) frames_of_step(t, L::PSUM(t & 1));
             }
-            if (sl == 0) {
+            if (H == 1 && sl == 0) {
                 p.pair_zmin[(long long)b * 6 + DIR] = zmin;
                 p.pair_zmin[(long long)b * 6 + 2 + DIR] = zmax;
                 p.pair_zmin[(long long)b * 6 + 4 + DIR] = (double)ltmin;
+            }
+        }
+    } else if (xwave) {
+        // ================= exchange wave (teams) =================
+        __syncthreads();  // (1)
+        bool dead = (p.x_sleep & 0x200) != 0;
+        {   // which XCD is the team on?  (pair_agent: a granule in the unused tail of psum slot PHASE of the own set)
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 15u;
+            if (lane == 0) granule_store(xps_send + PHASE * 512, 8u * 255u, __builtin_bit_cast(float, xcc + 1u), 0.f);
+            bool same = true;
+            const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+            for (int g = 0; g < H; ++g) {
+                if (g == hset) continue;
+                unsigned other = 0u;
+                while (!dead) {
+                    other = (unsigned)granule_load(xps_recv[g] + PHASE * 512, 8u * 255u);
+                    if (other != 0u) break;
+                    if (__builtin_amdgcn_s_memrealtime() - tstart > MM_SPLIT_TIMEOUT) dead = true;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                same = same && other == xcc + 1u;
+            }
+            if (dead && lane == 0) *redo2 = 2;
+            if (lane == 0) ldswu(L::XFLAG, (same && !dead && !(p.x_sleep & 0x800)) ? 1u : 0u);
+        }
+        __syncthreads();  // (2)
+        double xzmin = __builtin_inf(), xzmax = -__builtin_inf();
+        float xltmin = __builtin_inff();
+        auto xframes = [&](int ts, unsigned psum) {
+            const int f = frame_of(ts);
+            const bool live = f >= 1 && f <= len;
+            const float *xp[H];
+#pragma unroll
+            for (int g = 0; g < H; ++g) xp[g] = g != hset ? xps_recv[g] + (ts & 3) * 512 : nullptr;
+            bool arrived = true;
+            const float lt = dpair_finish_frame<NJ, H>(psum, P1, P, lane, p.gamma + (long long)b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp,
+                                                       live && hset == 0, xp, split_tag(ts, t0, 2), dead ? 0ull : MM_SPLIT_TIMEOUT, &arrived);
+            if (!arrived) {
+                if (lane == 0) *redo2 = 2;  // (the team is not running together: the log-domain kernels compute the utterance)
+                dead = true;
+            }
+            if (live) {
+                const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN(ts & 3));
+                const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, 0) + 512u * (ts & 7));
+                const double z = (double)lt + own + oth;
+                xzmin = z < xzmin ? z : xzmin;
+                xzmax = z > xzmax ? z : xzmax;
+                xltmin = lt < xltmin ? lt : xltmin;
+            }
+        };
+        MM_STAMP_RESET;
+        for (int t = t0 + 1; t <= t1; ++t) {
+            if constexpr (PHASE == 1)
+                if (t - 2 > t0) xframes(t - 2, L::PSUM(t & 1));
+            MM_STAMP(0);
+            MM_STEP_SYNC();
+            MM_STAMP(1);
+        }
+        if constexpr (PHASE == 1) {
+            for (int k = 1; k >= 0; --k) {
+                const int t = t1 - k;
+                if (k == 0) __syncthreads();  // (a)
+                if (t > t0) xframes(t, L::PSUM(t & 1));
+            }
+            if (lane == 0 && hset == 0) {
+                p.pair_zmin[(long long)b * 6 + DIR] = xzmin;
+                p.pair_zmin[(long long)b * 6 + 2 + DIR] = xzmax;
+                p.pair_zmin[(long long)b * 6 + 4 + DIR] = (double)xltmin;
             }
         }
     } else {
@@ -472,7 +621,8 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
         // the starting vector (step t0)
         if (PHASE == 0 && DIR == 0) {  // alpha_hat (*) lhs[:,1]   (src/inference.jl:68)
             for (int i = tid; i < S1; i += 64 * NWC) {
-                const unsigned pdfi = as_global(r.rowpdf)[i];
+                unsigned pdfi = as_global(r.rowpdf)[i];
+                if (H > 1 && pdfi == 0xffffu) pdfi = (unsigned)P1p;  // (alignment padding between the sets' regions: init = -inf)
                 const float v0 = as_global(r.init)[i] + ldsr(L::EM(1) + 8u * pdfi);
                 if (row_out_of_range(v0, thr)) *redo2 = 1;
                 ldsw_d(L::PP(1) + 8u * i, dexp2(v0));
@@ -484,12 +634,16 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             const int f = frame_of(t0);
             for (int i = tid; i < S1; i += 64 * NWC) {
                 float v0 = rowsP[(long long)f * S1p + i];
-                if (DIR == 1) v0 += ldsr(L::EM(t0 & 1) + 8u * as_global(r.rowpdf)[i]);  // beta~ is stored without the frame's emission
+                const unsigned pdfi = as_global(r.rowpdf)[i];
+                if (DIR == 1) v0 += ldsr(L::EM(t0 & 1) + 8u * (H > 1 && pdfi == 0xffffu ? (unsigned)P1p : pdfi));  // beta~ is stored without the frame's emission
+                if (H > 1 && pdfi == 0xffffu) v0 = MM_NINF;  // (padding: never stored)
                 ldsw_d(L::PP(t0 & 1) + 8u * i, dexp2(v0));
             }
         }
         load_graph();
         __syncthreads();  // (2)
+        if constexpr (H > 1) xplain = __builtin_amdgcn_readfirstlane(ldsru(L::XFLAG)) != 0u;
+        bool cdead = H > 1 && (p.x_sleep & 0x200) != 0;  // (teams) a poll of this wave timed out: it waits no more
         auto step = [&](auto RDc, int t) {
             constexpr int RD = decltype(RDc)::value, WR = 1 - RD;
             if (nslots > 0) {
@@ -516,10 +670,13 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                 const float S = ldsr(L::MS(WR));  // the step's normaliser, posted by the service wave
                 float e = ldsr((info >> 16) + L::EM(WR));
                 const int f = frame_of(t);
-                const unsigned alb = L::AL(0) + (unsigned)(t % 3) * (unsigned)RSH;
+                const unsigned alb = L::AL(0) + (unsigned)(t % 3) * (unsigned)RSH + xoff;
                 float al = 0.f;
                 if constexpr (PHASE == 1) al = ldsr(((info2 & 0xffffu) >> 1) + alb);
                 float *rowP = rowsP + (long long)(f <= p.N ? f : 0) * S1p;
+                // (teams) where the team reads this step's rows, and the step's tag
+                float *xw = H > 1 ? xsend + (long long)(t & 1) * p.x_slot - 2 * xbase : nullptr;
+                const bool xneg = H > 1 && split_tag(t, t0, 1) != 0u;
                 float worst = 0.f;
                 double accA = 0.0, accN = 0.0;
                 unsigned long long lgw = lgw0;
@@ -535,7 +692,12 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                     const float y0 = b0 + e;
                     // range check, deferred to the end of the step: the largest finite |y| of the lane (NaN for -inf: ignored)
                     worst = __builtin_fmaxf(worst, __builtin_fmaf(__builtin_fabsf(y0), 0.f, __builtin_fabsf(y0)));
-                    ldsw_d(pos8 + L::PP(WR), dexp2(y0));
+                    const double p0 = dexp2(y0);
+                    ldsw_d(pos8 + L::PP(WR), p0);
+                    if constexpr (H > 1) {
+                        if (xplain) *reinterpret_cast<double *>(reinterpret_cast<char *>(xw) + pos8) = dsigned(p0, xneg);
+                        else dgranule_store(xw, pos8, dsigned(p0, xneg));
+                    }
                     const float st0 = DIR ? b0 : y0;  // the vector that is stored / combined
                     if constexpr (PHASE == 0) {
                         *reinterpret_cast<float *>(reinterpret_cast<char *>(rowP) + (pos8 >> 1)) = st0;
@@ -562,7 +724,47 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(worst > thr) != 0ull, 0)) *redo2 = 1;
             }
             if constexpr (PHASE == 1)  // C' * (A .* B) of the previous step (:155)
-                if (t - 1 > t0) dpair_pdf_sums(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane);
+                if (t - 1 > t0)
+                    dpair_pdf_sums(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane, H > 1 ? xps_send + ((t - 1) & 3) * 512 : nullptr,
+                                   H > 1 && split_tag(t - 1, t0, 2) != 0u);
+            if constexpr (H > 1) {
+                // The rows of the other sets of this step (pair_agent, MM_SPLIT_CWPOLL): chunk j (128 granules) of the q-th other
+                // set is item q * NG2 + j, compute wave w receives the items w, w + NWC, ...; a granule is one tagged double.
+                constexpr int NG2 = (RSH / 16 + 63) / 64, I = (H - 1) * NG2;
+                typedef unsigned mm_u32x4 __attribute__((ext_vector_type(4)));
+                const unsigned tg = split_tag(t, t0, 1);
+                for (int i = wave; i < I; i += NWC) {
+                    const int q = i / NG2, j = i % NG2, g = q < hset ? q : q + 1;
+                    const float *src = xrecv[g] + (long long)(t & 1) * p.x_slot;
+                    const int ng = p.sp_cnt[g];
+                    const unsigned dsta = L::PP(WR) + 8u * (unsigned)p.sp_base[g] + 16u * (unsigned)(lane + 64 * j);
+                    const bool have = 2 * (lane + 64 * j) < ng, second = 2 * (lane + 64 * j) + 1 < ng;
+                    const unsigned off = have ? 16u * (unsigned)(lane + 64 * j) : 0u;
+                    bool pend = have;
+                    if (__builtin_amdgcn_ballot_w64(pend) == 0ull || cdead) continue;
+                    const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
+                    for (;;) {
+                        mm_u32x4 v;
+                        asm volatile("global_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(off), "s"(src) : "memory");
+                        if (pend && (v.y >> 31) == tg && (!second || (v.w >> 31) == tg)) {
+                            mm_u32x4 w;
+                            w.x = v.x;
+                            w.y = v.y & 0x7fffffffu;
+                            w.z = second ? v.z : 0u;
+                            w.w = second ? v.w & 0x7fffffffu : 0u;
+                            *(__attribute__((address_space(3))) mm_u32x4 *)(__UINTPTR_TYPE__)dsta = w;
+                            pend = false;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
+                        if (__builtin_amdgcn_s_memrealtime() - tstart > MM_SPLIT_TIMEOUT) {
+                            cdead = true;  // the team is not running together: the log-domain kernels compute the utterance
+                            if (lane == 0) *redo2 = 2;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+            }
             MM_STAMP(0);
             MM_STEP_SYNC();
             MM_STAMP(1);
@@ -577,12 +779,14 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             }
         }
         if constexpr (PHASE == 1) {
-            if (t1 > t0) dpair_pdf_sums(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane);
+            if (t1 > t0)
+                dpair_pdf_sums(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane, H > 1 ? xps_send + (t1 & 3) * 512 : nullptr,
+                               H > 1 && split_tag(t1, t0, 2) != 0u);
             __syncthreads();  // (a)
         }
     }
 #ifdef MM_STAMPS
-    if (p.dbg && lane == 0)  // [utterance][wave][phase * 2 + dir][work, barrier]
+    if (p.dbg && lane == 0 && H == 1)  // [utterance][wave][phase * 2 + dir][work, barrier]
         for (int k = 0; k < 2; ++k) p.dbg[(((long long)ui * MM_MAX_WAVES + wave) * 4 + PHASE * 2 + DIR) * 2 + k] = stamp_acc[k];
 #endif
 }
@@ -613,7 +817,8 @@ static __global__ void mm_dpair_finish_kernel(RunParams p) {
         const bool agree = z > -__builtin_inf() && zM < __builtin_inf() && zM - z <= MM_Z_SPREAD_TOL;
         // (no mark: the result stands, like an unmarked utterance of the float32 kernels); redo2[b] != 0 afterwards: the
         // log-domain kernels compute the utterance
-        if (p.redo2[b] != 0 && agree && lm >= (double)p.lt_floor - (double)MM_DPAIR_THR_EXTRA) p.redo2[b] = 0;
+        // (a mark of value 2 -- a team that did not run together -- stays)
+        if (p.redo2[b] == 1 && agree && lm >= (double)p.lt_floor - (double)MM_DPAIR_THR_EXTRA) p.redo2[b] = 0;
         // (a call that skipped the float32 kernels: would they have coped?  Not with an overlap term below their floor)
         if (p.stat_mode == 1) report_hard(p, !(lm >= (double)p.lt_floor));
     }

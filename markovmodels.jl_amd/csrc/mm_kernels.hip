@@ -156,6 +156,10 @@ struct RunParams {
     int sp_base[MM_SPLIT_HMAX], sp_cnt[MM_SPLIT_HMAX];
     float *xbuf, *xps;
     long long x_slot, x_phase;  // floats per slot; floats of one phase's area
+    // ... and the same for the teams of the float64 kernels (mm_kernel_dpair.hip: one utterance per team, so B "pairs"; a granule
+    // is one tagged double): [phase][utterance rank][direction][set][2 slots][x_slot floats], [rank][2][H][4 slots][512 floats]
+    float *xbuf_d, *xps_d;
+    long long x_phase_d;
     int x_sleep;                // the exchange wave sleeps this many x 64 clocks before its first poll of a step
     float lt_floor;             // mm_pair_finish_kernel: smallest accepted log2 overlap term of a frame (mm_batch_set_posterior_floor)
 };

@@ -164,3 +164,27 @@ def test_capturable_in_a_hip_graph(mm, wl, torch):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(gamma, g0) and torch.equal(t1, t0)
+
+
+@pytest.mark.parametrize("which", ["wsj_den", "teams_of_4"])
+def test_sharp_emissions_on_the_float64_team_kernels(mm, wl, oracle, torch, which):
+    """Graphs beyond one compute unit (the reference's WSJ denominator: teams of 2; a 3600-state graph: teams of 4): the float64
+    kernels run as teams too (mm_fbds_kernel: a granule of the exchange is one tagged double).  Sharp emissions, odd batch,
+    different lengths; first behind the float32 team kernels (marked utterances only), then alone on the whole batch."""
+    g = wl.load_npz_graph(os.path.join(HERE, "golden", "den_fsm_wsj.npz")) if which == "wsj_den" else wl.lfmmi_denominator(3600, 84, seed=1)
+    rng = np.random.default_rng(11)
+    B, N = 5, 60
+    lens = np.array([60, 41, 60, 1, 33], dtype=np.int32)
+    V = peaky(rng, (B, N, g.P), 10.0)
+    bf = make_batch(mm, wl, g, B, {"MM_NO_FALLBACK": "1"})
+    assert "mm_fbs_kernel" in bf.kernels() and "mm_fbds_kernel" in bf.kernels(), bf.kernels()
+    assert ("teams of 2" if which == "wsj_den" else "teams of 4") in bf.kernels()
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    ok = np.isfinite(t_ref)  # (one frame is too short for a path through these graphs: Z = 0, the reference's 0 / 0)
+    for call in range(2):
+        gam, ttl = bf.pdfposteriors(V, lens)
+        assert bf.last_exact_first() == (call == 1)
+        assert bf.last_redo_count() >= 3 and bf.last_fallback_count() == 0
+        check_gamma(gam[ok], g_ref[ok], lens[ok])
+        assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-3)
+        assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()

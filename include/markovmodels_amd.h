@@ -81,6 +81,18 @@ int mm_fsm_create(int semiring, int64_t S1, int64_t nnz, int layout, int index_b
                   int val_bytes, const void *ptr, const void *idx, const void *val, int64_t n_init,
                   const void *init_idx, const void *init_val, const int32_t *state2pdf, int32_t P1,
                   mm_fsm_t *out);
+/* `compile.(fsms, C_hats)` for a mini-batch of NEW graphs in one call (examples/test_cuda.jl:74-78 builds a fresh batch of
+ * numerator graphs every training step): the same arguments as mm_fsm_create, one entry per graph (arrays of n pointers /
+ * sizes; semiring, layout and the index / value types are shared).  The graphs are compiled on `threads` host threads
+ * (<= 0: up to 16); small log-semiring graphs (the wave kernel's: <= 1023 states, <= 4096 arcs) get their kernel forms at
+ * once, and the forms of ALL graphs go to the device as ONE allocation and ONE copy (a handle keeps its share alive:
+ * destroy the handles in any order).  out: n handles, each as mm_fsm_create would have made it -- the same results bit for
+ * bit; on error none is created.  (Without a HIP device the forms stay on the host until mm_batch_create, as after
+ * mm_fsm_create.) */
+int mm_fsm_create_many(int64_t n, int semiring, int layout, int index_bytes, int index_base, int val_bytes, const int64_t *S1,
+                       const int64_t *nnz, const void *const *ptr, const void *const *idx, const void *const *val,
+                       const int64_t *n_init, const void *const *init_idx, const void *const *init_val,
+                       const int32_t *const *state2pdf, const int32_t *P1, int threads, mm_fsm_t *out);
 int mm_fsm_destroy(mm_fsm_t fsm);
 /* nstates + sizes (src/fsm.jl:84); any out pointer may be NULL.
  * packed_slots[d] = arc slots of the packed form, d = 0 forward, 1 backward. */

@@ -22,6 +22,7 @@ SYMBOLS = [
     "mm_abi_version",
     "mm_last_error",
     "mm_fsm_create",
+    "mm_fsm_create_many",
     "mm_fsm_destroy",
     "mm_fsm_info",
     "mm_batch_create",
@@ -87,6 +88,8 @@ def _load():
     lib.mm_fsm_create.restype = C.c_int
     lib.mm_fsm_create.argtypes = [C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, i64, vp, vp, vp,
                                   i32, C.POINTER(vp)]
+    lib.mm_fsm_create_many.restype = C.c_int
+    lib.mm_fsm_create_many.argtypes = [i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]
     lib.mm_fsm_destroy.restype = C.c_int
     lib.mm_fsm_destroy.argtypes = [vp]
     lib.mm_fsm_info.restype = C.c_int

@@ -120,6 +120,7 @@ struct RowVariant {
     std::vector<uint32_t> ptab;  // wave form: [4 waves][2 segments][4 addresses + info][64 lanes] (wave_pdf_table)
     int pdf_nps = 0;             // ... segments per wave it uses (1 or 2)
     void *blob = nullptr;
+    std::shared_ptr<void> arena; // ... or a share of one device allocation for many forms (mm_fsm_create_many): freed with its last user
     RowDev rdev;
 };
 
@@ -132,7 +133,13 @@ struct mm_fsm_s {
     Csr qmat[2];  // the same restricted to the useful states (reachable from an initial state AND
                   // able to reach the final state): the quad kernel computes posteriors, to which
                   // the other states contribute exactly nothing
-    Packed packed[2];
+    Packed packed[2];      // the item forms: packed when first needed (ensure_packed) -- a numerator graph of the wave kernel never needs them
+    std::once_flag packed_once, gen_once;
+    // what the generic path's copies are built from when first asked for (gen_build): the matrix as it was handed over
+    int gen_layout = 0;
+    std::vector<int64_t> raw_ptr;
+    std::vector<int32_t> raw_col;
+    std::vector<double> raw_val;
     bool fast_ok = false;  // the quad kernel's linear path is valid for this FSM
     int depth = 0;         // most arcs from an initial state to any (useful) state
     int64_t nquads[2] = {0, 0};
@@ -246,6 +253,8 @@ struct mm_batch_s {
     // The float64 exact pair kernels (mm_kernel_dpair.hip) take the utterances the float32 pair kernels mark -- and the whole
     // batch, the float32 kernels skipped, while the inputs are "hard": more than a quarter of the last finished call's
     // utterances were beyond the float32 kernels (stat_host, written by the finish kernels; read without synchronising).
+    std::vector<UttDesc> utts_host;     // what d_utts holds
+    bool items_resident = true;         // the FSMs' item forms are on the device (a batch of the wave kernel uploads them on first need)
     bool dpair_ok = false;
     bool quad_built = false;            // the FSMs' quad forms exist (not built for batches whose exact path is the float64 kernels)
     int *stat_dev = nullptr;            // {count, ticket}
@@ -276,8 +285,39 @@ static Geometry pick_geometry(mm_batch_t h) {
 
 // item / tropical kernels: `kernel` keeps the state vectors in LDS; `big` is the same kernel with the vectors in global
 // memory, for FSMs beyond the LDS (the reference has no size limit: src/linalg.jl:170-181)
+static int fsm_to_device(mm_fsm_t f);
+// The item forms of a batch that was created without them (a batch of the wave kernel): upload them and refresh the
+// utterance descriptors, once, when an entry that runs the item / tropical kernels is first called on the batch.
+static int ensure_item_forms(mm_batch_t h, void *stream) {
+    if (h->items_resident) return MM_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return fail(MM_ERR_INVALID, "the item forms of this batch are not on the device yet: run the entry once outside a stream capture");
+    for (int64_t b = 0; b < h->B; ++b) {
+        mm_fsm_t f = h->fsms[size_t(b)];
+        int rc = fsm_to_device(f);
+        if (rc) return rc;
+        UttDesc &u = h->utts_host[size_t(b)];
+        u.g[0] = f->gdev[0];
+        u.g[1] = f->gdev[1];
+        u.init = f->d_init;
+        u.s2p = f->d_s2p;
+        u.pdf_ptr = f->d_pdf_ptr;
+        u.pdf_rows = f->d_pdf_rows;
+        h->max_items = std::max(h->max_items, int(std::max(f->packed[0].items.size(), f->packed[1].items.size())));
+    }
+    // (every other field keeps its value: a kernel still reading the descriptors sees the same bytes)
+    HIP_TRY(hipMemcpy(h->d_utts, h->utts_host.data(), sizeof(UttDesc) * size_t(h->B), hipMemcpyHostToDevice));
+    h->items_resident = true;
+    return MM_OK;
+}
+
 template <typename K>
 static int launch(K kernel, K big, mm_batch_t h, const RunParams &p0, bool with_stage, int NW, void *stream) {
+    {
+        const int rc = ensure_item_forms(h, stream);
+        if (rc) return rc;
+    }
     const int P1p = (h->max_P1 + 3) & ~3;
     RunParams p = p0;
     p.deterministic = h->deterministic ? 1 : 0;
@@ -406,11 +446,23 @@ namespace {
 // one device allocation per FSM: sections appended with 256-byte alignment
 struct Blob {
     std::vector<char> host;
+    // (mm_fsm_create_many) sizes only (dry), or written straight into a staging buffer shared by many forms (ext)
+    bool dry = false;
+    char *ext = nullptr;
+    size_t ext_size = 0;
+    size_t size() const { return (dry || ext) ? ext_size : host.size(); }
     template <class T>
     size_t add(const std::vector<T> &v) {
+        const size_t bytes = v.size() * sizeof(T);
+        if (dry || ext) {
+            const size_t off = align_up(ext_size, 256);
+            ext_size = off + bytes;
+            if (ext && bytes) memcpy(ext + off, v.data(), bytes);
+            return off;
+        }
         const size_t off = align_up(host.size(), 256);
-        host.resize(off + v.size() * sizeof(T));
-        if (!v.empty()) memcpy(host.data() + off, v.data(), v.size() * sizeof(T));
+        host.resize(off + bytes);
+        if (bytes) memcpy(host.data() + off, v.data(), bytes);
         return off;
     }
 };
@@ -435,6 +487,58 @@ extern "C" {
 
 int mm_abi_version(void) { return MM_ABI_VERSION; }
 const char *mm_last_error(void) { return g_err_store.c_str(); }
+
+// the generic path's copies of an FSM (mm_generic.hip): both matrices in double, natural units, rows sorted by column
+static void gen_build(mm_fsm_s *f) {
+    const int64_t S1 = f->S1, nnz = f->nnz;
+    std::vector<int64_t> gptr(f->raw_ptr);
+    std::vector<int32_t> gcol(std::move(f->raw_col));
+    std::vector<double> gval(std::move(f->raw_val));
+    std::vector<std::pair<int32_t, double>> tmp;
+    for (int64_t r = 0; r < S1; ++r) {
+        tmp.clear();
+        for (int64_t k = gptr[r]; k < gptr[r + 1]; ++k) tmp.push_back({gcol[size_t(k)], gval[size_t(k)]});
+        std::stable_sort(tmp.begin(), tmp.end(), [](auto &x, auto &y) { return x.first < y.first; });
+        for (int64_t k = gptr[r]; k < gptr[r + 1]; ++k) {
+            gcol[size_t(k)] = tmp[size_t(k - gptr[r])].first;
+            gval[size_t(k)] = tmp[size_t(k - gptr[r])].second;
+        }
+    }
+    std::vector<int64_t> tptr(size_t(S1) + 1, 0);
+    std::vector<int32_t> tcol(static_cast<size_t>(nnz));
+    std::vector<double> tval(static_cast<size_t>(nnz));
+    for (int64_t k = 0; k < nnz; ++k) tptr[size_t(gcol[size_t(k)]) + 1]++;
+    for (int64_t i = 0; i < S1; ++i) tptr[size_t(i) + 1] += tptr[size_t(i)];
+    std::vector<int64_t> cur(tptr.begin(), tptr.end() - 1);
+    for (int64_t r = 0; r < S1; ++r)
+        for (int64_t k = gptr[r]; k < gptr[r + 1]; ++k) {
+            const int64_t d = cur[size_t(gcol[size_t(k)])]++;
+            tcol[size_t(d)] = int32_t(r);
+            tval[size_t(d)] = gval[size_t(k)];
+        }
+    const int gi = f->gen_layout == MM_CSC ? 0 : 1;  // (the given matrix is the forward one when it came as CSC(T_hat))
+    f->gen_ptr[gi] = std::move(gptr);
+    f->gen_col[gi] = std::move(gcol);
+    f->gen_val[gi] = std::move(gval);
+    f->gen_ptr[1 - gi] = std::move(tptr);
+    f->gen_col[1 - gi] = std::move(tcol);
+    f->gen_val[1 - gi] = std::move(tval);
+    for (int d = 0; d < 2; ++d) {
+        f->gen.ptr[d] = f->gen_ptr[d].data();
+        f->gen.col[d] = f->gen_col[d].data();
+        f->gen.val[d] = f->gen_val[d].data();
+    }
+    f->raw_ptr.clear();
+    f->raw_ptr.shrink_to_fit();
+}
+// the item forms of an FSM (mm_pack.h), packed when first needed
+static void ensure_packed(mm_fsm_s *f) {
+    if (f->semiring == MM_PROB) return;  // (the generic path only)
+    std::call_once(f->packed_once, [&]() {
+        const float NINF = -std::numeric_limits<float>::infinity();
+        for (int d = 0; d < 2; ++d) f->packed[d] = pack_rows(f->S1, f->mat[d].rowptr, f->mat[d].col, f->mat[d].val, f->s2p, NINF);
+    });
+}
 
 static int fsm_create_impl(int semiring, int64_t S1, int64_t nnz, int layout, int index_bytes, int index_base, int val_bytes,
                            const void *ptr, const void *idx, const void *val, int64_t n_init, const void *init_idx,
@@ -503,44 +607,16 @@ static int fsm_create_impl(int semiring, int64_t S1, int64_t nnz, int layout, in
         }
         f->init[s] = rd_val(init_val, val_bytes, k) * scale;
     }
-    {   // the generic path's copy: double, natural units, rows sorted by column like the matrices above
-        const double zero = semiring == MM_PROB ? 0.0 : -std::numeric_limits<double>::infinity();
-        std::vector<int64_t> gptr(given.rowptr);
-        std::vector<int32_t> gcol(static_cast<size_t>(nnz));
-        std::vector<double> gval(static_cast<size_t>(nnz));
+    {   // the generic path's copy (double, natural units) is built when mm_pdfposteriors_ex first asks for it: gen_build()
+        f->gen_layout = layout;
+        f->raw_ptr = given.rowptr;
+        f->raw_col.resize(static_cast<size_t>(nnz));
+        f->raw_val.resize(static_cast<size_t>(nnz));
         for (int64_t k = 0; k < nnz; ++k) {
-            gcol[size_t(k)] = int32_t(rd_index(idx, index_bytes, k) - index_base);
-            gval[size_t(k)] = val_bytes == 4 ? double(static_cast<const float *>(val)[k]) : static_cast<const double *>(val)[k];
+            f->raw_col[size_t(k)] = int32_t(rd_index(idx, index_bytes, k) - index_base);
+            f->raw_val[size_t(k)] = val_bytes == 4 ? double(static_cast<const float *>(val)[k]) : static_cast<const double *>(val)[k];
         }
-        std::vector<std::pair<int32_t, double>> tmp;
-        for (int64_t r = 0; r < S1; ++r) {
-            tmp.clear();
-            for (int64_t k = gptr[r]; k < gptr[r + 1]; ++k) tmp.push_back({gcol[size_t(k)], gval[size_t(k)]});
-            std::stable_sort(tmp.begin(), tmp.end(), [](auto &x, auto &y) { return x.first < y.first; });
-            for (int64_t k = gptr[r]; k < gptr[r + 1]; ++k) {
-                gcol[size_t(k)] = tmp[size_t(k - gptr[r])].first;
-                gval[size_t(k)] = tmp[size_t(k - gptr[r])].second;
-            }
-        }
-        std::vector<int64_t> tptr(size_t(S1) + 1, 0);
-        std::vector<int32_t> tcol(static_cast<size_t>(nnz));
-        std::vector<double> tval(static_cast<size_t>(nnz));
-        for (int64_t k = 0; k < nnz; ++k) tptr[size_t(gcol[size_t(k)]) + 1]++;
-        for (int64_t i = 0; i < S1; ++i) tptr[size_t(i) + 1] += tptr[size_t(i)];
-        std::vector<int64_t> cur(tptr.begin(), tptr.end() - 1);
-        for (int64_t r = 0; r < S1; ++r)
-            for (int64_t k = gptr[r]; k < gptr[r + 1]; ++k) {
-                const int64_t d = cur[size_t(gcol[size_t(k)])]++;
-                tcol[size_t(d)] = int32_t(r);
-                tval[size_t(d)] = gval[size_t(k)];
-            }
-        const int gi = layout == MM_CSC ? 0 : 1;  // (as above: the given matrix is the forward one when it came as CSC(T_hat))
-        f->gen_ptr[gi] = std::move(gptr);
-        f->gen_col[gi] = std::move(gcol);
-        f->gen_val[gi] = std::move(gval);
-        f->gen_ptr[1 - gi] = std::move(tptr);
-        f->gen_col[1 - gi] = std::move(tcol);
-        f->gen_val[1 - gi] = std::move(tval);
+        const double zero = semiring == MM_PROB ? 0.0 : -std::numeric_limits<double>::infinity();
         f->gen_init.assign(size_t(S1), zero);
         for (int64_t k = 0; k < n_init; ++k) {
             const int64_t s = rd_index(init_idx, index_bytes, k) - index_base;
@@ -549,11 +625,6 @@ static int fsm_create_impl(int semiring, int64_t S1, int64_t nnz, int layout, in
         f->gen.semiring = semiring;
         f->gen.S1 = S1;
         f->gen.P1 = P1;
-        for (int d = 0; d < 2; ++d) {
-            f->gen.ptr[d] = f->gen_ptr[d].data();
-            f->gen.col[d] = f->gen_col[d].data();
-            f->gen.val[d] = f->gen_val[d].data();
-        }
         f->gen.init = f->gen_init.data();
         f->gen.s2p = f->s2p.data();
     }
@@ -561,8 +632,6 @@ static int fsm_create_impl(int semiring, int64_t S1, int64_t nnz, int layout, in
         *out = f;
         return MM_OK;
     }
-    f->packed[0] = pack_rows(S1, fwd.rowptr, fwd.col, fwd.val, f->s2p, NINF);
-    f->packed[1] = pack_rows(S1, bwd.rowptr, bwd.col, bwd.val, f->s2p, NINF);
     f->mat[0] = fwd;
     f->mat[1] = bwd;
     if (semiring == MM_LOG) {
@@ -641,6 +710,7 @@ static int fsm_to_device(mm_fsm_t f) {
     HIP_TRY(hipGetDevice(&dev));
     if (f->dev_blob && f->device == dev) return MM_OK;
     if (f->dev_blob) return fail(MM_ERR_INVALID, "FSM already resident on another device");
+    ensure_packed(f);
     Blob bl;
     size_t o_items[2], o_rows[2], o_slots[2];
     for (int d = 0; d < 2; ++d) {
@@ -746,39 +816,51 @@ static int quad_variant(mm_fsm_t f, int dir, int KQ, bool verbose, QuadVariant *
     return MM_OK;
 }
 
-static int upload_row_variant(mm_fsm_t f, RowVariant *v, int dir, float thr, bool pad = true) {
+// the device image of a row-lane form: sections of one blob (offsets in RowBlob) ...
+struct RowBlob {
     Blob bl;
+    size_t o_w, o_a, o_s, o_sc, o_ptr, o_col, o_cw, o_pdf, o_pse, o_init, o_ord, o_pt;
+};
+static void row_variant_blob(RowVariant *v, bool pad, RowBlob &rb) {
     // (zero rows up to MM_ROW_KA_PAD arc slots: the kernels load their whole register window unconditionally)
     if (pad) {
         v->g.w.resize(size_t(MM_ROW_KA_PAD) * 64 * v->g.NWC, 0.f);
         v->g.addr.resize(size_t(MM_ROW_KA_PAD) * 64 * v->g.NWC, 0u);
     }
-    const size_t o_w = bl.add(v->g.w), o_a = bl.add(v->g.addr), o_s = bl.add(v->g.slots), o_sc = bl.add(v->g.sched);
-    const size_t o_ptr = bl.add(v->g.rowptr), o_col = bl.add(v->g.col), o_cw = bl.add(v->g.cw);
-    const size_t o_pdf = bl.add(v->g.rowpdf), o_pse = bl.add(v->g.pdfse), o_init = bl.add(v->init), o_ord = bl.add(v->g.order);
-    const size_t o_pt = bl.add(v->ptab);
-    int rc = upload(bl, &v->blob);
-    if (rc) return rc;
-    char *base = static_cast<char *>(v->blob);
+    Blob &bl = rb.bl;
+    rb.o_w = bl.add(v->g.w), rb.o_a = bl.add(v->g.addr), rb.o_s = bl.add(v->g.slots), rb.o_sc = bl.add(v->g.sched);
+    rb.o_ptr = bl.add(v->g.rowptr), rb.o_col = bl.add(v->g.col), rb.o_cw = bl.add(v->g.cw);
+    rb.o_pdf = bl.add(v->g.rowpdf), rb.o_pse = bl.add(v->g.pdfse), rb.o_init = bl.add(v->init), rb.o_ord = bl.add(v->g.order);
+    rb.o_pt = bl.add(v->ptab);
+}
+// ... and the form's device descriptor once the blob sits at `base`
+static void row_variant_bind(mm_fsm_t f, RowVariant *v, const RowBlob &rb, char *base, float thr) {
     RowDev &d = v->rdev;
-    d.w = reinterpret_cast<const float *>(base + o_w);
-    d.addr = reinterpret_cast<const unsigned *>(base + o_a);
-    d.slots = reinterpret_cast<const unsigned *>(base + o_s);
-    d.sched = reinterpret_cast<const RowSched *>(base + o_sc);
-    d.rowptr = reinterpret_cast<const int *>(base + o_ptr);
-    d.col = reinterpret_cast<const int *>(base + o_col);
-    d.cw = reinterpret_cast<const float *>(base + o_cw);
-    d.rowpdf = reinterpret_cast<const unsigned short *>(base + o_pdf);
-    d.pdfse = reinterpret_cast<const unsigned short *>(base + o_pse);
-    d.init = reinterpret_cast<const float *>(base + o_init);
-    d.order = reinterpret_cast<const int *>(base + o_ord);
-    d.ptab = v->ptab.empty() ? nullptr : reinterpret_cast<const unsigned *>(base + o_pt);
+    d.w = reinterpret_cast<const float *>(base + rb.o_w);
+    d.addr = reinterpret_cast<const unsigned *>(base + rb.o_a);
+    d.slots = reinterpret_cast<const unsigned *>(base + rb.o_s);
+    d.sched = reinterpret_cast<const RowSched *>(base + rb.o_sc);
+    d.rowptr = reinterpret_cast<const int *>(base + rb.o_ptr);
+    d.col = reinterpret_cast<const int *>(base + rb.o_col);
+    d.cw = reinterpret_cast<const float *>(base + rb.o_cw);
+    d.rowpdf = reinterpret_cast<const unsigned short *>(base + rb.o_pdf);
+    d.pdfse = reinterpret_cast<const unsigned short *>(base + rb.o_pse);
+    d.init = reinterpret_cast<const float *>(base + rb.o_init);
+    d.order = reinterpret_cast<const int *>(base + rb.o_ord);
+    d.ptab = v->ptab.empty() ? nullptr : reinterpret_cast<const unsigned *>(base + rb.o_pt);
     d.KA = v->g.KA;
     d.NWC = v->g.NWC;
     d.nslotrows = v->g.nslotrows;
     d.fpos = v->g.pos[f->S1 - 1];
     d.rows = int(f->S1);
     d.thr = thr;
+}
+static int upload_row_variant(mm_fsm_t f, RowVariant *v, int dir, float thr, bool pad = true) {
+    RowBlob rb;
+    row_variant_blob(v, pad, rb);
+    int rc = upload(rb.bl, &v->blob);
+    if (rc) return rc;
+    row_variant_bind(f, v, rb, static_cast<char *>(v->blob), thr);
     (void)dir;
     return MM_OK;
 }
@@ -979,6 +1061,11 @@ static void wave_pack(mm_fsm_t f) {
     opt.spread_pdf = true;
     opt.finish_cost = 4;
     for (float &x : opt.group_speed) x = 1.f;
+    // (greedy placement without the local search: the wave kernel is bound by its waves' latency chains, not by LDS cycles --
+    // 0.434 -> 0.437 ms on the WSJ numerators x 128 -- and the search is half the host time of packing a small graph)
+    opt.place = 1;
+    opt.naive_stats = false;
+    if (const char *e = getenv("MM_WAVE_PLACE")) opt.place = atoi(e);
     // (owned until they are handed to the FSM: the packer may throw -- an allocation that fails)
     std::unique_ptr<RowVariant> rv[2] = {std::make_unique<RowVariant>(), std::make_unique<RowVariant>()};
     const std::vector<int32_t> none;
@@ -1168,6 +1255,7 @@ int mm_fsm_info(mm_fsm_t f, int64_t *S1, int64_t *nnz, int32_t *P1, int64_t pack
     if (nnz) *nnz = f->nnz;
     if (P1) *P1 = f->P1;
     for (int d = 0; d < 2; ++d) {
+        ensure_packed(f);
         if (packed_slots) packed_slots[d] = f->packed[d].n_slot_rows * 64;
         if (packed_items) packed_items[d] = int64_t(f->packed[d].items.size());
     }
@@ -1179,6 +1267,7 @@ int mm_debug_packed_product(mm_fsm_t f, int direction, const float *in, float *o
     std::vector<float> x(f->S1);
     const float s = f->semiring == MM_LOG ? MM_LOG2E : 1.0f;
     for (int64_t i = 0; i < f->S1; ++i) x[i] = in[i] * s;
+    ensure_packed(f);
     eval_packed(f->packed[direction], f->semiring, x.data(), out, argmax, f->S1);
     if (f->semiring == MM_LOG)
         for (int64_t i = 0; i < f->S1; ++i) out[i] *= MM_LN2;
@@ -1388,6 +1477,158 @@ int mm_fsm_create(int semiring, int64_t S1, int64_t nnz, int layout, int index_b
     return no_throw("mm_fsm_create", [&]() {
         return fsm_create_impl(semiring, S1, nnz, layout, index_bytes, index_base, val_bytes, ptr, idx, val, n_init, init_idx, init_val,
                                state2pdf, P1, out);
+    });
+}
+
+// Pinned staging buffer of mm_fsm_create_many (grow only; one upload at a time).
+namespace {
+std::mutex g_stage_lock;
+char *g_stage = nullptr;
+size_t g_stage_bytes = 0;
+}  // namespace
+
+static int fsm_create_many_impl(int64_t n, int semiring, int layout, int index_bytes, int index_base, int val_bytes, const int64_t *S1,
+                                const int64_t *nnz, const void *const *ptr, const void *const *idx, const void *const *val,
+                                const int64_t *n_init, const void *const *init_idx, const void *const *init_val,
+                                const int32_t *const *state2pdf, const int32_t *P1, int threads, mm_fsm_t *out) {
+    if (!out || n < 1) return fail(MM_ERR_INVALID, "mm_fsm_create_many: bad argument");
+    for (int64_t i = 0; i < n; ++i) out[i] = nullptr;
+    if (!S1 || !nnz || !ptr || !idx || !val || !n_init || !init_idx || !init_val || !state2pdf || !P1)
+        return fail(MM_ERR_INVALID, "mm_fsm_create_many: NULL array");
+    const bool verbose = getenv("MM_VERBOSE") != nullptr && getenv("MM_DEBUG") != nullptr;
+    const auto tc0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (verbose) fprintf(stderr, "[mm] create_many: %s at %.2f ms\n", what, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count());
+    };
+    const size_t nthr = size_t(std::max(1, std::min<int>({threads > 0 ? threads : 16, int(std::max(1u, std::thread::hardware_concurrency())), int((n + 3) / 4), 64})));
+    std::vector<int> rcs(static_cast<size_t>(n), MM_OK);
+    std::vector<std::string> msgs{size_t(n), std::string()};
+    std::vector<size_t> bytes(static_cast<size_t>(n), 0);  // device bytes of the FSM's wave forms (0: none)
+    // ---- 1. every graph on a host thread: the FSM (mm_fsm_create), its wave forms, the size of their device image
+    auto run_pool = [&](auto &&body) {
+        std::atomic<int64_t> next{0};
+        auto work = [&]() {
+            for (int64_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) body(i);
+        };
+        if (nthr <= 1) {
+            work();
+            return;
+        }
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < nthr; ++t) pool.emplace_back(work);
+        for (std::thread &t : pool) t.join();
+    };
+    std::atomic<long long> ns_create{0}, ns_pack{0};
+    run_pool([&](int64_t i) {
+        try {
+            const auto ta = std::chrono::steady_clock::now();
+            rcs[size_t(i)] = fsm_create_impl(semiring, S1[i], nnz[i], layout, index_bytes, index_base, val_bytes, ptr[i], idx[i], val[i], n_init[i],
+                                             init_idx[i], init_val[i], state2pdf[i], P1[i], &out[i]);
+            if (rcs[size_t(i)]) {
+                msgs[size_t(i)] = mm_last_error();
+                return;
+            }
+            mm_fsm_t f = out[i];
+            const auto tb = std::chrono::steady_clock::now();
+            ns_create += std::chrono::duration_cast<std::chrono::nanoseconds>(tb - ta).count();
+            if (f->semiring == MM_LOG && f->P1 <= 250 && f->S1 <= 1023 && f->qmat[0].rowptr[size_t(f->S1)] <= 16 * 64 * 4) {
+                wave_pack(f);
+                ns_pack += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tb).count();
+                if (f->wpend[0] && f->wpend[1]) {
+                    size_t tot = 0;
+                    for (int d = 0; d < 2; ++d) {
+                        RowBlob rb;
+                        rb.bl.dry = true;
+                        row_variant_blob(f->wpend[d], false, rb);
+                        tot += align_up(rb.bl.size(), 256);
+                    }
+                    bytes[size_t(i)] = tot;
+                }
+            }
+        } catch (const std::exception &e) {
+            rcs[size_t(i)] = MM_ERR_NOMEM;
+            msgs[size_t(i)] = std::string("mm_fsm_create_many: ") + e.what();
+        }
+    });
+    lap("graphs compiled and packed");
+    if (verbose) fprintf(stderr, "[mm] create_many: per graph %.0f us mm_fsm_create + %.0f us wave forms (%zu threads)\n", 1e-3 * double(ns_create.load()) / double(n), 1e-3 * double(ns_pack.load()) / double(n), nthr);
+    auto undo = [&](int rc, const std::string &msg) {
+        for (int64_t i = 0; i < n; ++i)
+            if (out[i]) {
+                (void)mm_fsm_destroy(out[i]);
+                out[i] = nullptr;
+            }
+        return fail(rc, msg);
+    };
+    for (int64_t i = 0; i < n; ++i)
+        if (rcs[size_t(i)]) return undo(rcs[size_t(i)], "graph " + std::to_string(i) + ": " + msgs[size_t(i)]);
+    // ---- 2. ONE device allocation and ONE copy for the wave forms of all graphs
+    std::vector<size_t> off(size_t(n) + 1, 0);
+    for (int64_t i = 0; i < n; ++i) off[size_t(i) + 1] = off[size_t(i)] + bytes[size_t(i)];
+    const size_t total = off[size_t(n)];
+    if (total == 0) return MM_OK;
+    {   // (without a device the packed forms stay with their FSMs, like after mm_fsm_create: mm_batch_create uploads them)
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+            (void)hipGetLastError();
+            return MM_OK;
+        }
+    }
+    void *dev = nullptr;
+    if (hipMalloc(&dev, total) != hipSuccess) return undo(MM_ERR_HIP, "mm_fsm_create_many: device allocation failed");
+    std::shared_ptr<void> arena(dev, [](void *q) { (void)hipFree(q); });
+    lap("arena allocated");
+    std::lock_guard<std::mutex> guard(g_stage_lock);
+    if (g_stage_bytes < total) {
+        if (g_stage) (void)hipHostFree(g_stage);
+        g_stage = nullptr;
+        g_stage_bytes = 0;
+        void *q = nullptr;
+        const size_t want = std::max(total + total / 2, size_t(1) << 22);
+        if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) return undo(MM_ERR_HIP, "mm_fsm_create_many: staging allocation failed");
+        g_stage = static_cast<char *>(q);
+        g_stage_bytes = want;
+    }
+    std::vector<RowBlob> rbs(size_t(n) * 2);
+    run_pool([&](int64_t i) {
+        if (!bytes[size_t(i)]) return;
+        mm_fsm_t f = out[i];
+        size_t o = off[size_t(i)];
+        for (int d = 0; d < 2; ++d) {
+            RowBlob &rb = rbs[size_t(i) * 2 + d];
+            rb.bl.ext = g_stage + o;
+            row_variant_blob(f->wpend[d], false, rb);
+            o += align_up(rb.bl.size(), 256);
+        }
+    });
+    lap("staged");
+    if (hipMemcpy(dev, g_stage, total, hipMemcpyHostToDevice) != hipSuccess) return undo(MM_ERR_HIP, "mm_fsm_create_many: upload failed");
+    lap("uploaded");
+    for (int64_t i = 0; i < n; ++i) {
+        if (!bytes[size_t(i)]) continue;
+        mm_fsm_t f = out[i];
+        size_t o = off[size_t(i)];
+        for (int d = 0; d < 2; ++d) {
+            RowVariant *rv = f->wpend[d];
+            const RowBlob &rb = rbs[size_t(i) * 2 + d];
+            rv->arena = arena;
+            row_variant_bind(f, rv, rb, static_cast<char *>(dev) + o, 0.f);
+            o += align_up(rb.bl.size(), 256);
+            f->wrows[d] = rv;
+            f->wpend[d] = nullptr;
+        }
+        f->wave_tried = true;
+    }
+    return MM_OK;
+}
+
+int mm_fsm_create_many(int64_t n, int semiring, int layout, int index_bytes, int index_base, int val_bytes, const int64_t *S1,
+                       const int64_t *nnz, const void *const *ptr, const void *const *idx, const void *const *val, const int64_t *n_init,
+                       const void *const *init_idx, const void *const *init_val, const int32_t *const *state2pdf, const int32_t *P1,
+                       int threads, mm_fsm_t *out) {
+    return no_throw("mm_fsm_create_many", [&]() {
+        return fsm_create_many_impl(n, semiring, layout, index_bytes, index_base, val_bytes, S1, nnz, ptr, idx, val, n_init, init_idx, init_val,
+                                    state2pdf, P1, threads, out);
     });
 }
 
@@ -1606,9 +1847,13 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     // has the item kernel behind those: their quad forms are not built)
     const bool want_dpair = h->pairs_ok && !h->dbg.no_dpair;
     h->quad_built = h->fast_ok && !h->wave_ok && !(want_dpair && h->dbg.kernel != DebugOpts::K_QUAD);
+    // (the item forms -- the general fallback, the alpha / beta export, the total-sum family -- of a batch of the wave kernel go to
+    // the device when an entry first needs them, ensure_item_forms(): a batch of new numerator graphs every training step
+    // never does)
+    h->items_resident = !h->wave_ok;
     for (int64_t b = 0; b < B; ++b) {
         mm_fsm_t f = fsms[b];
-        int rc = fsm_to_device(f);
+        int rc = h->items_resident ? fsm_to_device(f) : MM_OK;
         QuadVariant *qv[2] = {nullptr, nullptr};
         for (int d = 0; d < 2 && !rc && h->quad_built; ++d) rc = quad_variant(f, d, h->geo_kq[d], h->dbg.verbose, &qv[d]);
         if (rc) return rc;
@@ -1651,7 +1896,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         h->total_s1p += f->S1p;
         h->max_S1p = std::max(h->max_S1p, f->S1p);
         h->max_P1 = std::max(h->max_P1, int(f->P1));
-        h->max_items = std::max(h->max_items, std::max(f->gdev[0].n_items, f->gdev[1].n_items));
+        if (h->items_resident) h->max_items = std::max(h->max_items, int(std::max(f->packed[0].items.size(), f->packed[1].items.size())));
     }
     {
         int dev = 0, cus = 0;
@@ -1663,6 +1908,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         hipMemcpy(h->d_utts, utts.data(), sizeof(UttDesc) * B, hipMemcpyHostToDevice) != hipSuccess) {
         return fail(MM_ERR_HIP, "mm_batch_create: device allocation failed");
     }
+    h->utts_host = std::move(utts);
     {   // FSMs whose state vectors do not fit the LDS: the item / tropical kernels keep them in global memory
         const int P1p = (h->max_P1 + 3) & ~3;
         if (size_t(lds_plan(h->max_S1p, P1p, true).total) * 4 > 160 * 1024 || h->dbg.bigv) {
@@ -1725,7 +1971,11 @@ int64_t mm_batch_total_states(mm_batch_t h) { return h ? h->total_states : -1; }
 
 }  // extern "C"
 namespace mm {
-FsmGenView *mm_fsm_gen_view(mm_fsm_t f) { return f ? &f->gen : nullptr; }
+FsmGenView *mm_fsm_gen_view(mm_fsm_t f) {
+    if (!f) return nullptr;
+    std::call_once(f->gen_once, [&]() { gen_build(f); });
+    return &f->gen;
+}
 GenScratch *mm_batch_gen_scratch(mm_batch_t h) { return h ? &h->gen : nullptr; }
 int mm_batch_gen_view(mm_batch_t h, int64_t *B, const mm_fsm_t **fsms, int *semiring, int *device) {
     if (!h) return MM_ERR_INVALID;

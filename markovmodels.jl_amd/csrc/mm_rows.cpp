@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -28,57 +29,61 @@ int log2i(int g) {
     return l;
 }
 
-// distinct addresses per bank of one gather instruction of a half-wave, with multiplicities
+// distinct addresses per bank of one gather instruction of a half-wave, with multiplicities.  Allocation free (a pack of a
+// small graph builds thousands of these: with a vector per bank the allocator was most of the time of packing a numerator
+// graph): at most 64 addresses live at a time (32 lanes, and the moves of the local search remove before they add).
 struct Banks {
     struct E {
         uint32_t addr;
-        uint16_t n;
+        uint16_t n, bank;
     };
-    std::vector<E> bank[32];
+    E ent[64];
+    int nent = 0, sqsum = 0;
+    uint8_t cnt[32] = {0};  // distinct addresses per bank
     static int of(uint32_t a) { return int(a >> 2) & 31; }
+    int find(uint32_t a) const {
+        for (int i = 0; i < nent; ++i)
+            if (ent[i].addr == a) return i;
+        return -1;
+    }
     void add(uint32_t a) {
-        auto &v = bank[of(a)];
-        for (auto &e : v)
-            if (e.addr == a) {
-                ++e.n;
-                return;
-            }
-        v.push_back(E{a, 1});
+        const int i = find(a);
+        if (i >= 0) {
+            ++ent[i].n;
+            return;
+        }
+        if (nent >= 64) std::abort();  // (cannot happen: see above)
+        const int bk = of(a);
+        ent[nent++] = E{a, 1, uint16_t(bk)};
+        sqsum += 2 * cnt[bk] + 1;
+        ++cnt[bk];
     }
     void remove(uint32_t a) {
-        auto &v = bank[of(a)];
-        for (size_t i = 0; i < v.size(); ++i)
-            if (v[i].addr == a) {
-                if (--v[i].n == 0) {
-                    v[i] = v.back();
-                    v.pop_back();
-                }
-                return;
-            }
+        const int i = find(a);
+        if (i < 0) return;
+        if (--ent[i].n == 0) {
+            const int bk = ent[i].bank;
+            --cnt[bk];
+            sqsum -= 2 * cnt[bk] + 1;
+            ent[i] = ent[--nent];
+        }
     }
     int cost_of(uint32_t a) const {  // extra cycles this address would add (0: free bank or a broadcast)
-        const auto &v = bank[of(a)];
-        for (auto &e : v)
-            if (e.addr == a) return 0;
-        return int(v.size());
+        return find(a) >= 0 ? 0 : int(cnt[of(a)]);
     }
     int cycles() const {
-        size_t m = 1;
-        for (auto &v : bank) m = std::max(m, v.size());
-        return int(m);
+        int m = 1;
+        for (int c : cnt) m = std::max(m, c);
+        return m;
     }
     // smooth objective of the local search: every resolved conflict lowers it, also where the maximum (cycles())
     // is held by several banks at once and no single move lowers that
-    int sq() const {
-        int q = 0;
-        for (auto &v : bank) q += int(v.size() * v.size());
-        return q;
-    }
-    bool conflicted(uint32_t a) const { return bank[of(a)].size() > 1; }
+    int sq() const { return sqsum; }
+    bool conflicted(uint32_t a) const { return cnt[of(a)] > 1; }
     int least_loaded() const {
         int b = 0;
         for (int i = 1; i < 32; ++i)
-            if (bank[i].size() < bank[b].size()) b = i;
+            if (cnt[i] < cnt[b]) b = i;
         return b;
     }
 };
@@ -419,12 +424,14 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                     for (int64_t a = g.rowptr[i] + sub; a < g.rowptr[i + 1]; a += s.g) la[l].arcs.push_back(a);
                 }
                 // naive placement (CSR order, copy 0) for the statistics
-                for (int l = 0; l < 32; ++l)
+                for (int l = 0; l < 32 && opt.naive_stats; ++l)
                     for (int k = 0; k < s.A; ++k)
                         tabn[k].add(k < int(la[l].arcs.size()) ? uint32_t(4 * g.col[la[l].arcs[k]]) : uint32_t(4 * (l % int(ntot))));  // (model units)
                 // greedy: lane after lane, slot after slot, the remaining arc / copy that is cheapest there
-                std::vector<std::vector<uint32_t>> ad(32, std::vector<uint32_t>(s.A, 0u));
-                std::vector<std::vector<float>> wt(32, std::vector<float>(s.A, 0.f));
+                std::vector<uint32_t> ad_flat(size_t(32) * s.A, 0u);
+                std::vector<float> wt_flat(size_t(32) * s.A, 0.f);
+                auto ad = [&, A = s.A](int l) { return ad_flat.data() + size_t(l) * A; };
+                auto wt = [&, A = s.A](int l) { return wt_flat.data() + size_t(l) * A; };
                 for (int l = 0; l < 32; ++l) {
                     std::vector<char> used(la[l].arcs.size(), 0);
                     for (int k = 0; k < s.A; ++k) {
@@ -432,8 +439,8 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                         uint32_t baddr = 0;
                         for (size_t i = 0; i < la[l].arcs.size() && bcost > 0; ++i) {
                             if (used[i]) continue;
-                            if (opt.keep_order && i != size_t(k)) continue;  // (slot k holds the lane's k-th arc)
-                            for (uint32_t cp = 0; cp < ncopy; ++cp) {
+                            if ((opt.keep_order || opt.place == 0) && i != size_t(k)) continue;  // (slot k holds the lane's k-th arc)
+                            for (uint32_t cp = 0; cp < (opt.place == 0 ? 1u : ncopy); ++cp) {
                                 const uint32_t a = enc(uint32_t(g.col[la[l].arcs[i]]), cp);
                                 const int c = tab[k].cost_of(a);
                                 if (c < bcost) {
@@ -446,33 +453,33 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                         }
                         if (bi >= 0) {
                             used[bi] = 1;
-                            ad[l][k] = baddr;
-                            wt[l][k] = opt.log_weights ? g.cw[la[l].arcs[bi]] : std::exp2(g.cw[la[l].arcs[bi]]);
+                            ad(l)[k] = baddr;
+                            wt(l)[k] = opt.log_weights ? g.cw[la[l].arcs[bi]] : std::exp2(g.cw[la[l].arcs[bi]]);
                             ++real_arcs;
                         } else {  // padding: weight 0, an address that costs nothing
                             const int bnk = tab[k].least_loaded();
-                            ad[l][k] = uint32_t(4 * (bnk < ntot ? bnk : 0));
-                            wt[l][k] = opt.log_weights ? -std::numeric_limits<float>::infinity() : 0.f;
+                            ad(l)[k] = uint32_t(4 * (bnk < ntot ? bnk : 0));
+                            wt(l)[k] = opt.log_weights ? -std::numeric_limits<float>::infinity() : 0.f;
                         }
-                        tab[k].add(ad[l][k]);
+                        tab[k].add(ad(l)[k]);
                     }
                 }
                 auto real = [&](float w) { return opt.log_weights ? w > -std::numeric_limits<float>::infinity() : w != 0.f; };
                 // local search on the sum of squared bank loads: flip the copy of a conflicting slot, or swap it with another
                 // slot of the lane (in either copy)
-                for (int pass = 0; pass < (opt.keep_order ? 0 : 12); ++pass) {
+                for (int pass = 0; pass < (opt.keep_order || opt.place < 2 ? 0 : 12); ++pass) {
                     bool improved = false;
                     for (int l = 0; l < 32; ++l)
                         for (int k = 0; k < s.A; ++k) {
-                            uint32_t a = ad[l][k];
+                            uint32_t a = ad(l)[k];
                             if (!tab[k].conflicted(a)) continue;
-                            if (real(wt[l][k]) && ncopy > 1) {
+                            if (real(wt(l)[k]) && ncopy > 1) {
                                 const uint32_t alt = other(a);
                                 const int before = tab[k].sq();
                                 tab[k].remove(a);
                                 tab[k].add(alt);
                                 if (tab[k].sq() < before) {
-                                    ad[l][k] = a = alt;
+                                    ad(l)[k] = a = alt;
                                     improved = true;
                                     if (!tab[k].conflicted(a)) continue;
                                 } else {
@@ -487,15 +494,15 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                             for (int l2 = l_lo; l2 < l_lo + gl && !moved; ++l2)
                             for (int k2 = 0; k2 < s.A; ++k2) {
                                 if (k2 == k) continue;
-                                const uint32_t b = ad[l2][k2];
+                                const uint32_t b = ad(l2)[k2];
                                 const int before = tab[k].sq() + tab[k2].sq();
                                 tab[k].remove(a);
                                 tab[k2].remove(b);
                                 // the best of the copies of each arc in its new slot
                                 uint32_t na = a, nb = b;
                                 int best = 1 << 30;
-                                for (uint32_t ca = 0; ca < (real(wt[l][k]) ? ncopy : 1u); ++ca)
-                                    for (uint32_t cb = 0; cb < (real(wt[l2][k2]) ? ncopy : 1u); ++cb) {
+                                for (uint32_t ca = 0; ca < (real(wt(l)[k]) ? ncopy : 1u); ++ca)
+                                    for (uint32_t cb = 0; cb < (real(wt(l2)[k2]) ? ncopy : 1u); ++cb) {
                                         const uint32_t xa = ca ? other(a) : a, xb = cb ? other(b) : b;
                                         tab[k].add(xb);
                                         tab[k2].add(xa);
@@ -511,9 +518,9 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                                 if (best < before) {
                                     tab[k].add(nb);
                                     tab[k2].add(na);
-                                    ad[l][k] = nb;
-                                    ad[l2][k2] = na;
-                                    std::swap(wt[l][k], wt[l2][k2]);
+                                    ad(l)[k] = nb;
+                                    ad(l2)[k2] = na;
+                                    std::swap(wt(l)[k], wt(l2)[k2]);
                                     improved = moved = true;
                                     break;
                                 }
@@ -529,8 +536,8 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                     ++n_instr;
                     for (int l = 0; l < 32; ++l) {
                         const size_t e = size_t(k0 + k) * NT + size_t(w) * 64 + half * 32 + l;
-                        g.w[e] = wt[l][k];
-                        g.addr[e] = opt.pair ? 2 * ad[l][k] : ad[l][k];  // (placement worked in 4-byte model units)
+                        g.w[e] = wt(l)[k];
+                        g.addr[e] = opt.pair ? 2 * ad(l)[k] : ad(l)[k];  // (placement worked in 4-byte model units)
                     }
                 }
             }

@@ -131,6 +131,11 @@ struct RowPackOpts {
     // up to 2 arcs per lane take the narrow positions first.  RowSched::nslots = segments | (those in wide positions) << 16;
     // the wave's segments are ordered wide positions first.  mix_n4 < 0: off.
     int mix_n4 = -1, mix_n2 = 0;
+    // Effort of the bank-aware placement: 2 = greedy + local search (the forms of the LDS-bound kernels), 1 = greedy only,
+    // 0 = the arcs stay in CSR order in copy 0 (forms of kernels that are bound by their latency chains, not by LDS cycles:
+    // the wave form -- the placement is most of the host time of packing a small graph).
+    int place = 2;
+    bool naive_stats = true;  // also model the arcs in CSR order (RowGraph::conflict_before: informational)
 };
 
 // rowptr/col/val_log2: 0-based CSR of M (out[r] = (+)_k val[k] (*) in[col[k]]), square, nrows rows.

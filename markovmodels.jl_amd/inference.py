@@ -66,6 +66,19 @@ class CompiledFSM:
                                 aidx.ctypes.data, aval.ctypes.data, s2p.ctypes.data, self.P1, C.byref(h)))
         self._h = h
 
+    @classmethod
+    def _from_handle(cls, fsm: FSM, C_hat: StateMap, h) -> "CompiledFSM":
+        """Around a handle the library has made already (compile_many)."""
+        self = cls.__new__(cls)
+        self.fsm = fsm
+        self.C_hat = C_hat
+        self.semiring = fsm.semiring
+        self.S1 = fsm.S1
+        self.P1 = C_hat.numpdf + 1
+        self.dtype = np.dtype(np.float64) if np.asarray(fsm.nzval).dtype == np.float64 else np.dtype(np.float32)
+        self._h = h
+        return self
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h and lib is not None:  # lib is None while the interpreter shuts down
@@ -141,29 +154,55 @@ def compile(fsm: FSM, C_hat) -> CompiledFSM:  # noqa: A001 - the reference's nam
     return CompiledFSM(fsm, C_hat)
 
 
-def compile_many(fsms, C_hats, threads: int = 8):
+def compile_many(fsms, C_hats, threads: int = 0):
     """`compile.(fsms, C_hats)` (the reference broadcasts compile over a mini-batch of numerator graphs,
-    examples/test_cuda.jl:76-78) on several host threads: mm_fsm_create packs and uploads one graph per call, the calls
-    release the interpreter lock.  C_hats: one state map for all, or one per FSM."""
-    from concurrent.futures import ThreadPoolExecutor
-
+    examples/test_cuda.jl:76-78) in ONE call of the library (mm_fsm_create_many): the graphs are compiled on host threads,
+    small graphs get the forms of their kernel at once, and everything goes to the device as one allocation and one
+    copy.  C_hats: one state map for all, or one per FSM.  The handles are what ``compile`` would have made."""
     fsms = list(fsms)
-    maps = list(C_hats) if isinstance(C_hats, (list, tuple)) else [C_hats] * len(fsms)
-    if len(maps) != len(fsms):
+    n = len(fsms)
+    maps = list(C_hats) if isinstance(C_hats, (list, tuple)) else [C_hats] * n
+    if len(maps) != n:
         raise ValueError("compile_many: one C_hat per FSM (or one for all)")
-    if threads <= 1 or len(fsms) < 4:
-        return [CompiledFSM(f, m) for f, m in zip(fsms, maps)]
-    import torch
+    if n == 0:
+        return []
+    maps = [m if isinstance(m, StateMap) else StateMap.from_matrix(m) for m in maps]
+    sem = fsms[0].semiring
+    f64 = np.asarray(fsms[0].nzval).dtype == np.float64
+    vdt = np.float64 if f64 else np.float32
+    if any(f.semiring != sem or (np.asarray(f.nzval).dtype == np.float64) != f64 for f in fsms):
+        raise TypeError("compile_many: the FSMs of one call share the semiring and the float type (FSM{K})")
+    keep = []  # the arrays the pointers below refer to
 
-    dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+    def arr(a, dt):
+        a = np.asarray(a)
+        if a.dtype != dt or not a.flags.c_contiguous:
+            a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a.__array_interface__["data"][0]
 
-    def one(fm):
-        if dev is not None:
-            torch.cuda.set_device(dev)  # (the current device is per thread: a rank's graphs belong on the rank's GPU)
-        return CompiledFSM(fm[0], fm[1])
-
-    with ThreadPoolExecutor(max_workers=threads) as pool:
-        return list(pool.map(one, zip(fsms, maps)))
+    S1 = np.empty(n, np.int64)
+    nnz = np.empty(n, np.int64)
+    ninit = np.empty(n, np.int64)
+    P1 = np.empty(n, np.int32)
+    ptrs = np.empty((7, n), np.uint64)  # colptr, rowval, nzval, alpha_idx, alpha_val, state2pdf per graph
+    for i, (f, m) in enumerate(zip(fsms, maps)):
+        if m.shape[0] != f.S1:
+            raise _lib.DimensionMismatch(-2, f"C_hat {i} has {m.shape[0]} rows, the FSM {f.S1} states")
+        S1[i], nnz[i], P1[i] = f.S1, f.nnz, m.numpdf + 1
+        ptrs[0, i] = arr(f.colptr, np.int64)
+        ptrs[1, i] = arr(f.rowval, np.int64)
+        ptrs[2, i] = arr(f.nzval, vdt)
+        ai = np.asarray(f.alpha_idx)
+        ninit[i] = ai.shape[0]
+        ptrs[3, i] = arr(ai, np.int64)
+        ptrs[4, i] = arr(f.alpha_val, vdt)
+        ptrs[5, i] = arr(m.state2pdf, np.int32)
+    out = (C.c_void_p * n)()
+    check(lib.mm_fsm_create_many(n, SEMIRING_ID[sem], _lib.MM_CSC, 8, 0, 8 if f64 else 4, S1.ctypes.data, nnz.ctypes.data,
+                                 ptrs[0].ctypes.data, ptrs[1].ctypes.data, ptrs[2].ctypes.data, ninit.ctypes.data, ptrs[3].ctypes.data,
+                                 ptrs[4].ctypes.data, ptrs[5].ctypes.data, P1.ctypes.data, int(threads), out))
+    return [CompiledFSM._from_handle(f, m, C.c_void_p(out[i])) for i, (f, m) in enumerate(zip(fsms, maps))]
 
 
 class BatchedFSM:

@@ -329,3 +329,40 @@ def test_wave_form_products(mm, wl, gname):
         assert np.array_equal(np.isfinite(out), m), (gname, d)
         assert np.allclose(out[m], ref[m], rtol=1e-5, atol=2e-5), (gname, d)
         assert stats[0] <= 16 and stats[1] <= 16  # (at most 4 segments of 4 slots per wave, 4 waves)
+
+
+def test_create_many_equals_single_creates(mm, wl):
+    """mm_fsm_create_many (compile_many: a mini-batch of new numerator graphs in one call, packed on host threads) against
+    mm_fsm_create (compile) graph by graph: 128 different graphs -- the reference's WSJ numerator, lexicon graphs of
+    150..500 states, random sparse graphs, one too large for the wave form -- must give the same handles: sizes, the
+    semiring product through the item form, and through the wave form (positions, weights, schedules), bit for bit."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    gs = [wl.load_npz_graph(os.path.join(here, "num_fsm_wsj.npz"))]
+    for k in range(90):
+        gs.append(wl.lexicon_fsm(150 + 4 * k, 40, seed=k, hubs=1 + k % 3))
+    for k in range(36):
+        gs.append(wl.random_fsm(60 + 7 * k, 40, 2.0 + 0.05 * k, seed=100 + k))
+    gs.append(wl.lfmmi_denominator(1500, 40, seed=1))  # beyond the wave form
+    assert len(gs) == 128
+    P = 40
+    fsms, maps = [], []
+    for g in gs:
+        fsms.append(wl.to_fsm(mm, g))
+        maps.append(mm.statemap(g.state2pdf, max(P, g.P)))
+    many = mm.compile_many(fsms, maps, threads=4)
+    rng = np.random.default_rng(0)
+    for g, f, m, cm in zip(gs, fsms, maps, many):
+        cs = mm.compile(f, m)
+        assert cm.info() == cs.info()
+        x = rng.standard_normal(g.S + 1).astype(np.float32)
+        for d in (0, 1):
+            a, b = cm.packed_product(x, d), cs.packed_product(x, d)
+            assert np.array_equal(a[0], b[0], equal_nan=True)
+            if g.S + 1 <= 1023:
+                wa, wb = cm.wave_product(x, d), cs.wave_product(x, d)
+                assert np.array_equal(wa[0], wb[0], equal_nan=True) and np.array_equal(wa[1], wb[1])
+    with pytest.raises(mm.MarkovModelsAMDError):  # an invalid graph among them: none is created
+        bad = wl.to_fsm(mm, gs[1])
+        bad.rowval = bad.rowval.copy()
+        bad.rowval[0] = 10 ** 6
+        mm.compile_many([fsms[0], bad], [maps[0], maps[1]])

@@ -2090,7 +2090,8 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
 
 // (the pair kernels keep N + 2 vectors per utterance and one workspace slot more than utterances)
 static size_t ws_alpha_bytes(mm_batch_t h, int64_t N) {
-    if (h->pairs_ok) return align_up(size_t(h->B + 1) * size_t(h->pair_H > 1 ? h->split_s1p : h->max_S1p) * size_t(N + 2) * 4, 256);
+    // (+ 16 KB: the service waves copy whole LDS regions of a stored row without clamping, dma_row_b128)
+    if (h->pairs_ok) return align_up(size_t(h->B + 1) * size_t(h->pair_H > 1 ? h->split_s1p : h->max_S1p) * size_t(N + 2) * 4 + 16384, 256);
     return align_up(size_t(h->total_s1p) * size_t(N + 1) * 4, 256);
 }
 static size_t ws_c_bytes(mm_batch_t h, int64_t N) { return align_up(size_t(h->B + 1) * size_t(N + 2) * 8, 256); }

@@ -423,11 +423,8 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             const int n4 = H > 1 ? (int)((xoff / 4u + (unsigned)xcnt + 3u) >> 2) : S1p >> 2;  // float4s of the row
             const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(rowsP + (long long)f * S1p + xal);
             const unsigned dst = L::AL(0) + (unsigned)(tt % 3) * (unsigned)RSH;
-#pragma unroll
-            for (int j = 0; j < NDM; ++j) {
-                const int q = sl + 64 * j;
-                dma_b128(src + (q < n4 ? q : 0), dst + 1024u * j);
-            }
+            (void)n4;
+            dma_row_b128<NDM>(uni(src), (unsigned)sl, dst);  // (no clamping: see pair_agent)
             dma_b32(reinterpret_cast<const unsigned *>(offs + f) + (sl & 1), L::POFF(0, 0) + 512u * (t & 7));
         };
         constexpr int NDMA = NJ + (PHASE ? NDM + 1 : 0);  // DMAs issued per step

@@ -689,11 +689,10 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             if constexpr (small_graph) {  // (one DMA covers the row: the others would copy element 0 again)
                 dma_b128(src + (sl < n4 ? sl : 0), dst);
             } else {
-#pragma unroll
-                for (int j = 0; j < NDM; ++j) {
-                    const int q = sl + 64 * j;
-                    dma_b128(src + (q < n4 ? q : 0), dst + 1024u * j);
-                }
+                // (the whole region in one asm block, no clamping: what lies behind the row -- the next frame's row, or the
+                // workspace's slack behind the last one -- lands in the part of the LDS region no finish reads)
+                (void)n4;
+                dma_row_b128<NDM>(uni(src), (unsigned)sl, dst);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u)

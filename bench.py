@@ -108,6 +108,50 @@ def cpu_baseline(g, N, threads, budget_utts):
     return budget_utts * N / dt, dt
 
 
+def julia_reference(g, N, B):
+    """BASELINE.md plan item 1: the reference ITSELF as the CPU baseline when the box can run it -- `julia` on PATH with
+    MarkovModels.jl (and its Semirings.jl / CUDA.jl dependencies) installed.  Returns (frames/s, seconds, note) or None;
+    this image has no Julia, so the C port below is what normally runs (kind "port")."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("julia")
+    if not exe:
+        return None
+    script = r"""
+using MarkovModels, Semirings, SparseArrays, DelimitedFiles
+K = LogSemiring{Float32}
+d = ARGS[1]
+arcs = readdlm(joinpath(d, "arcs.txt")); init = readdlm(joinpath(d, "init.txt")); fin = readdlm(joinpath(d, "final.txt"))
+s2p = vec(Int.(readdlm(joinpath(d, "s2p.txt")))); S, P, N, B = parse.(Int, ARGS[2:5])
+fsm = FSM([Int(r[1]) => K(r[2]) for r in eachrow(init)], [(Int(r[1]), Int(r[2])) => K(r[3]) for r in eachrow(arcs)],
+          [Int(r[1]) => K(r[2]) for r in eachrow(fin)], collect(1:S))
+C = sparse(1:S+1, vcat(s2p, P + 1), fill(one(K), S + 1), S + 1, P + 1)
+fsms = rawunion([fsm for _ in 1:B]...)
+Vs = [expand(K.(randn(Float32, P, N)), N) for _ in 1:B]
+pdfposteriors(rawunion(fsm), [Vs[1][:, 1:21]], [C])
+t = @elapsed pdfposteriors(fsms, Vs, [C for _ in 1:B])
+println("SECONDS ", t)
+"""
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            np.savetxt(os.path.join(d, "arcs.txt"), np.c_[g.src + 1, g.dst + 1, g.w])
+            np.savetxt(os.path.join(d, "init.txt"), np.c_[g.init_idx + 1, g.init_w])
+            np.savetxt(os.path.join(d, "final.txt"), np.c_[g.final_idx + 1, g.final_w])
+            np.savetxt(os.path.join(d, "s2p.txt"), np.asarray(g.state2pdf) + 1, fmt="%d")
+            open(os.path.join(d, "run.jl"), "w").write(script)
+            r = subprocess.run([exe, os.path.join(d, "run.jl"), d, str(g.S), str(g.P), str(N), str(B)], capture_output=True, text=True,
+                               timeout=600)
+        for ln in r.stdout.splitlines():
+            if ln.startswith("SECONDS "):
+                dt = float(ln.split()[1])
+                return B * N / dt, dt, f"julia {exe}: MarkovModels.pdfposteriors on the host, {B} utterances x {N} frames, Float32"
+    except Exception as e:  # (no MarkovModels.jl in the depot, a different GraphSpec layout, a time-out: the port runs instead)
+        print(f"[bench] julia found but the reference did not run: {e}", file=sys.stderr)
+    return None
+
+
 def host_cores():
     """CPU cores this process can actually use: the affinity mask, capped by the cgroup's CPU quota (a container
     can see 256 hardware threads and be allowed the time of 8: more threads than that only take turns)."""
@@ -332,6 +376,14 @@ def main():
                 "kernel_ms": kernel_ms,
             },
         }
+        if semiring == "tropical":
+            # SURVEY 8(d)'s figure counts int32 back-pointers; the row-lane kernels write ONE byte per state and frame (rows padded to
+            # 256 bytes) and read it back once: what the kernel actually moves, next to what the problem is priced at
+            kbytes = B * ((N + 1) * (4 * (g.P + 1) + 2 * (((g.S + 2) + 255) // 256 * 256)) + 4 * N)
+            out["roofline"]["kernel_bytes_per_launch"] = kbytes
+            out["roofline"]["frac_of_peak_on_kernel_bytes"] = kbytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["note"] = ("frac = SURVEY 8(d)'s algorithmic bytes (int32 back-pointers) / time / peak; frac_of_peak_on_kernel_bytes = "
+                                       "what the byte-back-pointer kernels move (emissions in, one byte per state and frame out and back in, the path)")
         # what actually bounds the kernels: one random 4-byte LDS read per arc and pass (32 lanes per clock
         # and CU without bank conflicts; MI355X_MICROARCH.md: 256 CUs, 128 B/clk/CU LDS, 2.4 GHz)
         lds_bytes = (2 if semiring == "log" else 1) * 4 * g.n_arcs * frames_local
@@ -352,11 +404,15 @@ def main():
             per_thread = max(2, int(round(15.0 * v1 / max(N, 1))))  # ~15 s of work per thread at the one-thread rate
             nb = per_thread * cores
             v, dt = cpu_baseline(g, N, cores, nb)
+            ref = julia_reference(g, N, n1) if semiring == "log" else None
+            if ref is not None:
+                out["cpu_baseline_reference"] = {"value": ref[0], "unit": "frames/s", "cores": 1, "kind": "reference", "sample": ref[2]}
             out["cpu_baseline"] = {
                 "value": v,
                 "unit": "frames/s",
                 "cores": cores,
                 "kind": "port",
+                "julia": "ran: see cpu_baseline_reference" if ref is not None else "not on this box (shutil.which('julia') is None) or MarkovModels.jl missing: the C port",
                 "sample": f"{nb} utterances x {N} frames of the same workload, float32, OpenMP over utterances "
                           f"({per_thread} per thread), {dt:.1f} s",
                 "one_thread": {

@@ -8,6 +8,9 @@
 # of the same ABI is the Python/ctypes one in markovmodels.jl_amd/_lib.py; this file
 # mirrors it call for call.  Device memory comes from AMDGPU.jl (ROCArray).
 #
+# `using MarkovModels` loads CUDA.jl (a hard dependency of the package: src/MarkovModels.jl:7-8); on an AMD box CUDA.jl
+# loads without a device (CUDA.functional() == false) and nothing here calls into it.
+#
 # Seam (see INTEGRATION.md): the reference dispatches on CuArray storage
 # (src/fsm.jl:42-48, src/inference.jl:14-26, src/linalg.jl:163,240,335).  Here the
 # dispatch is on a device handle type, one level up: one ccall per inference call.
@@ -18,6 +21,7 @@ using MarkovModels
 using SparseArrays
 using Semirings
 using AMDGPU
+using Adapt
 using Libdl
 
 # The package's own generic functions are EXTENDED with methods for the device types below (`using MarkovModels`
@@ -26,8 +30,9 @@ using Libdl
 import MarkovModels: compile, batch, pdfposteriors, αrecursion, βrecursion, totalsum, totalcumsum
 
 # what this module adds to the package's API
-export ROCCompiledFSM, ROCBatch, to_device, bestpath, maxstateposteriors, pdfposteriors_generic, last_redo_count,
-       set_deterministic!, set_posterior_floor!, set_rccl, allreduce_logz, allgather_ttl
+export ROCCompiledFSM, ROCBatch, to_device, compile_many, bestpath, maxstateposteriors, pdfposteriors_generic, last_redo_count,
+       last_fallback_count, last_exact_first, reserve_ex!, set_deterministic!, set_posterior_floor!, set_rccl, allreduce_logz,
+       allgather_ttl
 
 const LIB = get(ENV, "MARKOVMODELS_AMD_LIB", "libmarkovmodels_amd.so")
 
@@ -74,6 +79,59 @@ reference, as `compile(fsm, Ĉ)` made it on the host, handed to the engine.  `ba
 `batch(c...) |> gpu`.
 """
 to_device(c::CompiledFSM{K}) where K = _create(K, SparseMatrixCSC(c.T̂), SparseVector(c.α̂), c.Ĉ)
+
+"""
+    Adapt.adapt_structure(ROCArray, cfsm::CompiledFSM) -> ROCCompiledFSM
+
+The reference's own seam (src/inference.jl:14-26: `adapt_structure(::Type{<:CuArray}, cfsm)`, reached through
+`cfsm |> gpu` / `adapt(CuArray, cfsm)`): `adapt(ROCArray, cfsm)` hands the compiled FSM to the engine.  The FSM type
+itself (src/fsm.jl:42-48) has no device form here: the engine takes compiled FSMs (`compile(fsm, Ĉ)` first).
+"""
+Adapt.adapt_structure(::Type{<:ROCArray}, c::CompiledFSM) = to_device(c)
+
+"""
+    compile_many(fsms::Vector{FSM{K}}, Ĉs) -> Vector{ROCCompiledFSM{K}}
+
+`compile.(fsms, Ĉs)` + device adapt for a mini-batch of NEW graphs in one call (mm_fsm_create_many: host threads, one device
+allocation, one copy) -- what examples/test_cuda.jl:74-78 does every training step for the numerator graphs.
+"""
+function compile_many(fsms::Vector{FSM{K}}, Ĉs::Vector{<:AbstractSparseMatrix}; threads::Integer = 0) where K
+    n = length(fsms)
+    n == length(Ĉs) || throw(DimensionMismatch("one Ĉ per FSM"))
+    Ts = [SparseMatrixCSC(f.T̂) for f in fsms]
+    αs = [SparseVector(f.α̂) for f in fsms]
+    vals = [val.(nonzeros(T)) for T in Ts]
+    avals = [val.(nonzeros(a)) for a in αs]
+    ainds = [SparseArrays.nonzeroinds(a) for a in αs]
+    s2ps = map(Ĉs) do Ĉ
+        Ct = SparseMatrixCSC(copy(Ĉ'))
+        all(diff(Ct.colptr) .== 1) || throw(ArgumentError("Ĉ must have exactly one entry per row"))
+        Vector{Int32}(Ct.rowval)
+    end
+    F = eltype(vals[1])
+    S1 = Int64[size(T, 1) for T in Ts]
+    NZ = Int64[nnz(T) for T in Ts]
+    NI = Int64[nnz(a) for a in αs]
+    P1 = Int32[size(Ĉ, 2) for Ĉ in Ĉs]
+    out = fill(Ptr{Cvoid}(C_NULL), n)
+    GC.@preserve Ts αs vals avals ainds s2ps begin
+        p_ptr = Ptr{Cvoid}[pointer(T.colptr) for T in Ts]
+        p_idx = Ptr{Cvoid}[pointer(T.rowval) for T in Ts]
+        p_val = Ptr{Cvoid}[pointer(v) for v in vals]
+        p_ai = Ptr{Cvoid}[pointer(a) for a in ainds]
+        p_av = Ptr{Cvoid}[pointer(a) for a in avals]
+        p_s2p = Ptr{Int32}[pointer(s) for s in s2ps]
+        check(ccall((:mm_fsm_create_many, LIB), Cint,
+            (Int64, Cint, Cint, Cint, Cint, Cint, Ptr{Int64}, Ptr{Int64}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}},
+             Ptr{Int64}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Int32}}, Ptr{Int32}, Cint, Ptr{Ptr{Cvoid}}),
+            n, semiring_id(K), MM_CSC, 8, 1, sizeof(F), S1, NZ, p_ptr, p_idx, p_val, NI, p_ai, p_av, p_s2p, P1, threads, out))
+    end
+    map(1:n) do i
+        obj = ROCCompiledFSM{K}(out[i], S1[i], P1[i])
+        finalizer(o -> ccall((:mm_fsm_destroy, LIB), Cint, (Ptr{Cvoid},), o.handle), obj)
+        obj
+    end
+end
 
 function _create(::Type{K}, T̂::SparseMatrixCSC, α̂::SparseVector, Ĉ::AbstractSparseMatrix) where K
     Ct = SparseMatrixCSC(copy(Ĉ'))                      # column s of Ĉ' = row s of Ĉ
@@ -135,6 +193,58 @@ function pdfposteriors(b::ROCBatch, V::ROCArray{Float32,3}, lens = nothing)
          Ptr{Float32}, Ptr{Cvoid}),
         b.handle, pointer(V), P * N, P, lp, N, pointer(γ), 1, B * P, B, pointer(ttl),
         AMDGPU.stream().stream))
+    γ, ttl
+end
+
+"""
+    pdfposteriors(fsm::FSM{K}, V̂s::Vector{<:ROCMatrix}, Ĉs; expanded = true) -> (γ, ttl)
+
+The reference's own signature (src/inference.jl:145): `fsm` the `rawunion` of the batch's FSMs (src/fsmops.jl:28-36), `V̂s`
+one (P+1) × (N+1) matrix per utterance as `expand` made them, `Ĉs` the state maps -- examples/test_cuda.jl:128 runs
+unchanged but for the array type.  The blocks of the union are cut apart again by the rows of the `Ĉs` (block b has
+size(Ĉs[b], 1) states), compiled (equal blocks once) and batched; `V̂s` are stacked on the device like `vcat(V̂s...)` (:146).
+With Float32 log-semiring FSMs, one-hot `Ĉs` and `expanded = true` the fast kernels run on V̂[1:P, 1:N, b] IN PLACE (strides;
+the lengths are read off the phony row); anything else (`expanded = false`: matrices `expand` did not make; Float64;
+other semirings; general sparse `Ĉs`) goes to `pdfposteriors_generic`.
+"""
+function pdfposteriors(fsm::FSM{K}, V̂s::Vector{<:ROCMatrix{T}}, Ĉs::Vector{<:AbstractSparseMatrix}; expanded::Bool = true) where {K, T}
+    B = length(V̂s)
+    B == length(Ĉs) || throw(DimensionMismatch("one Ĉ per utterance"))
+    P1, N1 = size(V̂s[1])
+    all(size(v) == (P1, N1) for v in V̂s) || throw(DimensionMismatch("all V̂ must share one (P+1) × (N+1) shape"))
+    all(size(Ĉ, 2) == P1 for Ĉ in Ĉs) || throw(DimensionMismatch("V̂ has $P1 rows, a Ĉ has another number of pdfs"))
+    # the blocks of the block-diagonal union
+    T̂, α̂ = SparseMatrixCSC(fsm.T̂), SparseVector(fsm.α̂)
+    sum(size(Ĉ, 1) for Ĉ in Ĉs) == size(T̂, 1) || throw(DimensionMismatch("the Ĉs' rows do not add up to the states of fsm"))
+    onehot = all(all(diff(SparseMatrixCSC(copy(Ĉ')).colptr) .== 1) && all(iszero ∘ val, nonzeros(Ĉ)) for Ĉ in Ĉs)
+    cache = Dict{Any, ROCCompiledFSM{K}}()
+    cfs = ROCCompiledFSM{K}[]
+    lo = 0
+    for Ĉ in Ĉs
+        r = lo+1:lo+size(Ĉ, 1)
+        Tb, ab = T̂[r, r], α̂[r]
+        # (a general sparse Ĉ rides along as an argument of the generic entry: its FSM handle gets a placeholder map)
+        Cb = onehot ? Ĉ : sparse(1:size(Ĉ, 1), [fill(1, size(Ĉ, 1) - 1); size(Ĉ, 2)], fill(one(K), size(Ĉ, 1)), size(Ĉ, 1), size(Ĉ, 2))
+        key = (Tb, ab, Cb)
+        push!(cfs, get!(() -> _create(K, Tb, ab, Cb), cache, key))
+        lo = last(r)
+    end
+    b = batch(cfs...)
+    V̂ = cat(V̂s...; dims = 3)                                    # (P+1) × (N+1) × B on the device
+    fast = expanded && onehot && K <: LogSemiring && T === Float32
+    fast || return pdfposteriors_generic(b, V̂, onehot ? nothing : Ĉs)
+    P, N = P1 - 1, N1 - 1
+    # expand (src/inference.jl:54-60): the phony row is zero(K) up to seqlength, one(K) after
+    lens = ROCArray(Int32.(vec(sum(Array(V̂[P1:P1, 1:N, :]) .== -Inf32, dims = 2))))
+    γ = ROCArray{Float32}(undef, B, P, N)
+    ttl = ROCArray{Float32}(undef, B)
+    # V̂ (b, n, p) -> p + P1*n + P1*N1*b: the kernels read the real pdfs and frames in place
+    check(ccall((:mm_pdfposteriors_f32, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Ptr{Int32}, Int64, Ptr{Float32}, Int64, Int64, Int64,
+         Ptr{Float32}, Ptr{Cvoid}),
+        b.handle, pointer(V̂), P1 * N1, P1, pointer(lens), N, pointer(γ), 1, B * P, B, pointer(ttl),
+        AMDGPU.stream().stream))
+    AMDGPU.synchronize()                                        # (b and V̂ are locals: the call must have run before they go)
     γ, ttl
 end
 
@@ -209,6 +319,18 @@ function last_redo_count(b::ROCBatch)
     Int(n[])
 end
 
+"... and how many of those the float64 exact kernels handed on to the log-domain kernels (normally 0)."
+function last_fallback_count(b::ROCBatch)
+    n = Ref{Int64}(0)
+    check(ccall((:mm_batch_last_fallback_count, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int64}), b.handle, AMDGPU.stream().stream, n))
+    Int(n[])
+end
+"true if the last `pdfposteriors` call skipped the float32 kernels (the inputs of the call before were hard)."
+last_exact_first(b::ROCBatch) = ccall((:mm_batch_last_exact_first, LIB), Cint, (Ptr{Cvoid},), b.handle) != 0
+"Size the generic entry's workspace (before capturing `pdfposteriors_generic` in a hipGraph)."
+reserve_ex!(b::ROCBatch, ::Type{T}, N1::Integer) where T =
+    (check(ccall((:mm_batch_reserve_ex, LIB), Cint, (Ptr{Cvoid}, Cint, Int64), b.handle, sizeof(T), N1)); b)
+
 """
     pdfposteriors_generic(b::ROCBatch{K}, V̂::ROCArray{T,3}, Ĉs = nothing) -> (γ, ttl)
 
@@ -221,6 +343,12 @@ A plain kernel (alpha and beta materialised like the reference does): correctnes
 """
 function pdfposteriors_generic(b::ROCBatch{K}, V̂::ROCArray{T,3}, Ĉs = nothing) where {K, T <: Union{Float32, Float64}}
     P1, N1, B = size(V̂)
+    B == length(b.fsms) || throw(DimensionMismatch("V̂ holds $B matrices, the batch $(length(b.fsms)) FSMs"))
+    # rows of V̂ against the pdfs of the map in force (src/inference.jl:146-150); the C entry checks the same (MM_ERR_DIM)
+    for (i, f) in enumerate(b.fsms)
+        want = Ĉs === nothing ? f.P1 : size(Ĉs[i], 2)
+        P1 == want || throw(DimensionMismatch("V̂ has $P1 rows, the state map of utterance $i has $want pdfs (was expand() applied?)"))
+    end
     γ = ROCArray{T}(undef, B, P1 - 1, N1 - 1)
     ttl = ROCArray{T}(undef, B)
     maps = Ptr{Cvoid}[]
@@ -239,10 +367,11 @@ function pdfposteriors_generic(b::ROCBatch{K}, V̂::ROCArray{T,3}, Ĉs = nothing
     try
         # strides in elements: V̂ (b, n, p) -> p + P1*n + P1*N1*b ; γ (b, n, p) -> b + B*p + B*P*n
         check(ccall((:mm_pdfposteriors_ex, LIB), Cint,
-            (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Cint, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Int64,
+            (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Cint, Int32, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Int64,
              Ptr{Cvoid}, Ptr{Cvoid}),
-            b.handle, isempty(maps) ? C_NULL : pointer(maps), sizeof(T), pointer(V̂), P1 * N1, P1, N1,
+            b.handle, isempty(maps) ? C_NULL : pointer(maps), sizeof(T), Int32(P1), pointer(V̂), P1 * N1, P1, N1,
             pointer(γ), 1, B * (P1 - 1), B, pointer(ttl), AMDGPU.stream().stream))
+        isempty(maps) || AMDGPU.synchronize()           # (the call is asynchronous: the maps must outlive it)
     finally
         foreach(h -> ccall((:mm_statemap_destroy, LIB), Cint, (Ptr{Cvoid},), h), maps)
     end

@@ -154,6 +154,8 @@ struct mm_fsm_s {
     RowVariant *wrows[2] = {nullptr, nullptr};  // wave forms (mm_kernel_wave.hip)
     RowVariant *wpend[2] = {nullptr, nullptr};  // ... packed, not yet uploaded (wave_pack)
     bool wave_tried = false, wave_packed = false;
+    void *lane_blob = nullptr;                  // lane form (mm_kernel_lane.hip: up to 64 states): the device image, the LaneDev at its start
+    bool lane_tried = false;
     RowVariant *vrow = nullptr;                 // Viterbi form (mm_kernel_vit.hip)
     bool vit_tried = false;
     int vit_n4 = 0, vit_n2 = 0;                 // its layout: positions of 4 / of 2 arc slots per wave
@@ -179,7 +181,7 @@ struct mm_fsm_s {
 // MM_KQ / MM_NWAVES / MM_NITEMS force a geometry, MM_NO_XCSR keeps the exact-fallback CSR out of LDS,
 // MM_VERBOSE prints the packing statistics.
 struct DebugOpts {
-    enum { K_AUTO = 0, K_ITEM, K_QUAD, K_ROW, K_PAIR, K_WAVE, K_SPLIT };
+    enum { K_AUTO = 0, K_ITEM, K_QUAD, K_ROW, K_PAIR, K_WAVE, K_SPLIT, K_LANE };
     int kernel = K_AUTO;
     int kq = 0, nwaves = 0, nitems = -1;
     bool no_xcsr = false, verbose = false;
@@ -198,7 +200,7 @@ static DebugOpts read_debug_opts() {
     if (!on || !*on || !strcmp(on, "0")) return d;
     if (const char *e = getenv("MM_KERNEL"))
         d.kernel = !strcmp(e, "item") ? DebugOpts::K_ITEM : !strcmp(e, "quad") ? DebugOpts::K_QUAD
-                 : !strcmp(e, "row") ? DebugOpts::K_ROW : !strcmp(e, "pair") ? DebugOpts::K_PAIR : !strcmp(e, "wave") ? DebugOpts::K_WAVE : !strcmp(e, "split") ? DebugOpts::K_SPLIT : DebugOpts::K_AUTO;
+                 : !strcmp(e, "row") ? DebugOpts::K_ROW : !strcmp(e, "pair") ? DebugOpts::K_PAIR : !strcmp(e, "wave") ? DebugOpts::K_WAVE : !strcmp(e, "split") ? DebugOpts::K_SPLIT : !strcmp(e, "lane") ? DebugOpts::K_LANE : DebugOpts::K_AUTO;
     if (const char *e = getenv("MM_KQ")) d.kq = atoi(e);
     if (const char *e = getenv("MM_NWAVES")) d.nwaves = atoi(e);
     if (const char *e = getenv("MM_NITEMS")) d.nitems = atoi(e);
@@ -235,6 +237,8 @@ struct mm_batch_s {
     int pair_ka = 0, pair_nwc = 1, pair_slotrows = 0;
     bool vit_ok = false;   // every FSM has its Viterbi form: mm_vit_kernel + mm_vit_backtrace_kernel can run
     int vit_n4 = 0, vit_n2 = 0, vit_arcs = 0;
+    bool lane_ok = false;  // every FSM has at most 64 states and 64 pdfs: the lane kernel runs (one wave per utterance and direction)
+    int lane_S = 0;        // ... the most states of one
     bool wave_ok = false;  // every FSM has its wave forms: the wave kernel can run (small graphs that are off the linear paths)
     int wave_nseg = 0;
     int pair_H = 1;        // workgroups per team: 1 = the pair kernels proper, > 1 = the split pair kernels
@@ -362,7 +366,7 @@ static size_t quad_lds_bytes(mm_batch_t h, int dir) {
 }
 
 static bool quad_kernel_usable(mm_batch_t h) {
-    if (h->dbg.kernel == DebugOpts::K_ITEM || h->wave_ok || !h->quad_built) return false;
+    if (h->dbg.kernel == DebugOpts::K_ITEM || h->wave_ok || h->lane_ok || !h->quad_built) return false;
     if (!h->fast_ok || h->geo_kq[0] < 1 || h->geo_kq[1] < 1) return false;
     // small deep graphs (numerators): measured on the reference's WSJ numerator graph (depth 165),
     // item kernel 2.3 ms against 2.7 ms; shallow graphs of the same size are 1.6x faster on the quad kernels
@@ -991,6 +995,64 @@ static int vit_variant(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
 // starts at a multiple of its size; a segment is 64 lanes.  Segment s runs on compute wave 3 - s % 4 as its pdf segment
 // s / 4.  tab[((w * 2 + j) * 5 + k) * 64 + lane]: k < 4 the addresses, k = 4: 4 * pdf of the group's first lane (the lane
 // that stores; others: the trash slot 4 * P1p) | log2(L) << 16.  Returns the segments per wave (1 or 2), 0 if it does not fit.
+// the lane form of an FSM (mm_kernel_lane.hip): up to 64 real states, every one on a real pdf, up to 64 pdfs; built once
+static int lane_variant(mm_fsm_t f, bool *ok) {
+    *ok = f->lane_blob != nullptr;
+    if (*ok || f->lane_tried) return MM_OK;
+    f->lane_tried = true;
+    const int64_t S = f->S1 - 1;
+    const int P = f->P1 - 1;
+    if (f->semiring != MM_LOG || S < 1 || S > 64 || P < 1 || P > 64) return MM_OK;
+    for (int64_t s = 0; s < S; ++s)
+        if (f->s2p[size_t(s)] >= P) return MM_OK;  // (a real state on the phony pdf)
+    std::vector<double> w0(64 * 64, 0.0), w1(64 * 64, 0.0);
+    std::vector<float> init(64, -std::numeric_limits<float>::infinity()), fin(64, -std::numeric_limits<float>::infinity());
+    std::vector<int32_t> s2p(64, 0), pdf_ptr(size_t(P) + 1, 0), pdf_states(64, 0);
+    const Csr &fwd = f->mat[0], &bwd = f->mat[1];
+    for (int64_t j = 0; j < S; ++j)  // forward: row j of T_hat' = the arcs INTO j
+        for (int64_t k = fwd.rowptr[size_t(j)]; k < fwd.rowptr[size_t(j) + 1]; ++k)
+            if (fwd.col[size_t(k)] < S) w0[size_t(fwd.col[size_t(k)]) * 64 + size_t(j)] += std::exp2(double(fwd.val[size_t(k)]));
+    for (int64_t i = 0; i < S; ++i)  // backward: row i of T_hat = the arcs OUT OF i
+        for (int64_t k = bwd.rowptr[size_t(i)]; k < bwd.rowptr[size_t(i) + 1]; ++k) {
+            const int64_t d = bwd.col[size_t(k)];
+            if (d < S) w1[size_t(d) * 64 + size_t(i)] += std::exp2(double(bwd.val[size_t(k)]));
+            else if (bwd.val[size_t(k)] > -std::numeric_limits<float>::infinity())  // the arc to the final state: omega_i
+                fin[size_t(i)] = fin[size_t(i)] > -std::numeric_limits<float>::infinity()
+                                     ? float(std::log2(std::exp2(double(fin[size_t(i)])) + std::exp2(double(bwd.val[size_t(k)]))))
+                                     : bwd.val[size_t(k)];
+        }
+    bool ident = true;
+    for (int64_t s = 0; s < S; ++s) {
+        init[size_t(s)] = f->init[size_t(s)];
+        s2p[size_t(s)] = f->s2p[size_t(s)];
+        ident = ident && f->s2p[size_t(s)] == int32_t(s);
+        ++pdf_ptr[size_t(f->s2p[size_t(s)]) + 1];
+    }
+    for (int q = 0; q < P; ++q) pdf_ptr[size_t(q) + 1] += pdf_ptr[size_t(q)];
+    {
+        std::vector<int32_t> fill(pdf_ptr.begin(), pdf_ptr.end() - 1);
+        for (int64_t s = 0; s < S; ++s) pdf_states[size_t(fill[size_t(f->s2p[size_t(s)])]++)] = int32_t(s);
+    }
+    Blob bl;
+    std::vector<char> head(align_up(mm_lane_dev_bytes(), 256), 0);
+    const size_t o_head = bl.add(head), o_w0 = bl.add(w0), o_w1 = bl.add(w1), o_init = bl.add(init), o_fin = bl.add(fin), o_s2p = bl.add(s2p),
+                 o_pp = bl.add(pdf_ptr), o_ps = bl.add(pdf_states);
+    void *blob = nullptr;
+    HIP_TRY(hipMalloc(&blob, bl.host.size()));
+    char *base = static_cast<char *>(blob);
+    mm_lane_dev_fill(bl.host.data() + o_head, reinterpret_cast<const double *>(base + o_w0), reinterpret_cast<const double *>(base + o_w1),
+                     reinterpret_cast<const float *>(base + o_init), reinterpret_cast<const float *>(base + o_fin),
+                     reinterpret_cast<const int *>(base + o_s2p), reinterpret_cast<const int *>(base + o_pp),
+                     reinterpret_cast<const int *>(base + o_ps), int(S), P, ident ? 1 : 0);
+    if (hipMemcpy(blob, bl.host.data(), bl.host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(blob);
+        return fail(MM_ERR_HIP, "lane form: upload failed");
+    }
+    f->lane_blob = blob;
+    *ok = true;
+    return MM_OK;
+}
+
 static int wave_pdf_table(const RowGraph &g, const std::vector<int32_t> &s2p, int64_t S1, int32_t P1, std::vector<uint32_t> &tab) {
     std::vector<std::vector<uint32_t>> src(static_cast<size_t>(P1));
     std::vector<std::pair<int32_t, int32_t>> bypos;  // (position, pdf): a fixed order of the states of a pdf
@@ -1235,6 +1297,7 @@ int mm_fsm_destroy(mm_fsm_t f) {
             d = nullptr;
         }
     if (f->dev_blob) (void)hipFree(f->dev_blob);
+    if (f->lane_blob) (void)hipFree(f->lane_blob);
     for (auto &kv : f->variants) {
         if (kv.second->blob) (void)hipFree(kv.second->blob);
         delete kv.second;
@@ -1739,8 +1802,21 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     // exception: one shared DENSE graph (more than 16 arcs per state, more than 2 segments per wave) on a batch of more than
     // two utterances per compute unit, where the pair kernels' two utterances per workgroup win (32-state ergodic HMM,
     // B = 1024: 1.90 against 2.33 ms).
+    // The lane kernel FIRST for batches of tiny graphs (every FSM: up to 64 states and 64 pdfs): one wave per utterance and
+    // direction with the graph in its registers, float64, exact -- BASELINE config 2 (dense 64-state HMM, B = 32, T = 500):
+    // 0.60 ms on the pair kernels; config 1 (3-state HMM, one utterance).
+    if (h->semiring == MM_LOG && (h->dbg.kernel == DebugOpts::K_AUTO || h->dbg.kernel == DebugOpts::K_LANE)) {
+        h->lane_ok = true;
+        for (int64_t b = 0; b < B && h->lane_ok; ++b) {
+            bool ok = false;
+            int rc = lane_variant(fsms[b], &ok);
+            if (rc) return rc;
+            h->lane_ok = ok;
+            h->lane_S = std::max(h->lane_S, int(fsms[b]->S1 - 1));
+        }
+    }
     bool wave_first_tried = false;
-    if (h->semiring == MM_LOG && h->dbg.kernel == DebugOpts::K_AUTO) {
+    if (h->semiring == MM_LOG && h->dbg.kernel == DebugOpts::K_AUTO && !h->lane_ok) {
         bool small = h->max_P1 <= 250, same = true;
         for (int64_t b = 0; b < B && small; ++b)
             small = fsms[b]->S1 <= 1023 && fsms[b]->qmat[0].rowptr[fsms[b]->S1] <= 16 * 64 * 4;
@@ -1759,7 +1835,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     // row kernels: every FSM of the batch needs its row-lane forms.  Small deep (left-to-right) graphs keep states
     // alive whose values differ by more than the float range within one frame, so most of their rows would take the
     // exact fallback of the linear-domain kernels: they run on the item kernel (unless a kernel is forced).
-    h->rows_ok = !h->wave_ok && h->fast_ok && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD && h->dbg.kernel != DebugOpts::K_WAVE &&
+    h->rows_ok = !h->wave_ok && !h->lane_ok && h->fast_ok && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD && h->dbg.kernel != DebugOpts::K_WAVE &&
                  !(h->max_depth >= 64 && nq_max[0] <= 3 * 1024 && nq_max[1] <= 3 * 1024 && h->dbg.kernel == DebugOpts::K_AUTO);
     for (int64_t b = 0; b < B && h->rows_ok; ++b) {
         bool ok = false;
@@ -1786,7 +1862,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     }
     // split pair kernels: one shared FSM that is too large for the pair kernels proper (more arcs than the registers of a
     // compute unit hold, more states than half its LDS) -- teams of 2 workgroups per utterance pair and direction
-    if (!h->wave_ok && !h->pairs_ok && h->fast_ok && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD &&
+    if (!h->wave_ok && !h->lane_ok && !h->pairs_ok && h->fast_ok && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD &&
         h->dbg.kernel != DebugOpts::K_ROW && h->dbg.kernel != DebugOpts::K_WAVE &&
         !(h->max_depth >= 64 && nq_max[0] <= 3 * 1024 && nq_max[1] <= 3 * 1024 && h->dbg.kernel == DebugOpts::K_AUTO)) {
         bool same = true;
@@ -1836,7 +1912,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     }
     // wave kernel, the other case: small graphs that none of the linear-domain kernels takes (deep left-to-right graphs:
     // numerators), or the kernel is asked for by name
-    if (h->semiring == MM_LOG && !h->wave_ok && !wave_first_tried && !h->rows_ok && !h->pairs_ok &&
+    if (h->semiring == MM_LOG && !h->wave_ok && !h->lane_ok && !wave_first_tried && !h->rows_ok && !h->pairs_ok &&
         (h->dbg.kernel == DebugOpts::K_WAVE ||
          (h->dbg.kernel == DebugOpts::K_AUTO && (!h->fast_ok || (h->max_depth >= 64 && h->geo_kq[0] <= 3 && h->geo_kq[1] <= 3))))) {
         // (= where the item kernel would run: quad_kernel_usable() says no for these; see there)
@@ -1846,11 +1922,11 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     // (a batch of the wave kernel never runs the quad kernels, and one whose marked utterances go to the float64 pair kernels
     // has the item kernel behind those: their quad forms are not built)
     const bool want_dpair = h->pairs_ok && !h->dbg.no_dpair;
-    h->quad_built = h->fast_ok && !h->wave_ok && !(want_dpair && h->dbg.kernel != DebugOpts::K_QUAD);
+    h->quad_built = h->fast_ok && !h->wave_ok && !h->lane_ok && !(want_dpair && h->dbg.kernel != DebugOpts::K_QUAD);
     // (the item forms -- the general fallback, the alpha / beta export, the total-sum family -- of a batch of the wave kernel go to
     // the device when an entry first needs them, ensure_item_forms(): a batch of new numerator graphs every training step
     // never does)
-    h->items_resident = !h->wave_ok;
+    h->items_resident = !h->wave_ok && !h->lane_ok;
     for (int64_t b = 0; b < B; ++b) {
         mm_fsm_t f = fsms[b];
         int rc = h->items_resident ? fsm_to_device(f) : MM_OK;
@@ -1867,6 +1943,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             u.init_f = qv[0]->d_init_f;
             u.map_bf = qv[1]->d_map_bf;
         }
+        if (h->lane_ok) u.lane = static_cast<const LaneDev *>(f->lane_blob);
         if (h->vit_ok) u.rv = f->vrow->rdev;
         if (h->wave_ok)
             for (int d = 0; d < 2; ++d) u.rw[d] = f->wrows[d]->rdev;
@@ -2048,7 +2125,10 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
         const std::string exact = quad ? "mm_fbq_kernel<" + std::to_string(h->geo_kq[0]) + ",*,0> + mm_fbq_kernel<" +
                                              std::to_string(h->geo_kq[1]) + ",*,1>"
                                        : std::string("mm_log_kernel<MODE_FB> (forward, backward)");
-        if (h->wave_ok) {
+        if (h->lane_ok) {
+            s = "mm_lane_kernel<" + std::to_string(h->lane_S <= 8 ? 8 : h->lane_S <= 16 ? 16 : h->lane_S <= 32 ? 32 : 64) +
+                "> (one wave per utterance and direction, the graph in its registers, float64)";
+        } else if (h->wave_ok) {
             s = "mm_wave_kernel<" + std::to_string(h->wave_nseg <= 2 ? 2 : 4) + "," + std::to_string(h->max_P1 <= 128 ? 2 : 4) +
                 (h->wave_nseg <= 2 && h->B > h->n_cus ? ",two per CU>" : ">");
         } else if (h->pairs_ok && h->pair_H > 1) {
@@ -2215,7 +2295,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     char *const tail0 = static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N);
     int *const order = ordered ? reinterpret_cast<int *>(tail0) : nullptr;  // (first of the tail)
     p.order = order;
-    const bool marks = !h->wave_ok && (h->rows_ok || h->pairs_ok);
+    const bool marks = !h->wave_ok && !h->lane_ok && (h->rows_ok || h->pairs_ok);
     // Which kernels first?  The float32 pair kernels, unless the inputs of the last finished call were beyond them for more
     // than a quarter of its utterances (a sharp acoustic model: every utterance is marked and computed again): then the
     // float64 kernels take the whole batch at once.  They keep reporting (how many utterances have an overlap term below the
@@ -2247,6 +2327,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     }
     p.dbg = g_dbg;
 #endif
+    if (h->lane_ok) return mm_launch_lane(h->B, h->lane_S, p, static_cast<hipStream_t>(stream));
     if (h->wave_ok) {
         char *tail = static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N);
         p.pair_zmin = reinterpret_cast<double *>(tail + 2 * align_up(size_t(h->B + 1) * 4, 256) + align_up(size_t(h->B + 1) * 2 * mm_pair_hand_bytes(), 256));

@@ -90,6 +90,12 @@ struct WaveLaunch {
 };
 int mm_launch_wave(const WaveLaunch &wl, const RunParams &p, hipStream_t stream);
 
+// ---- lane kernel (mm_lane_tu.hip): graphs of up to 64 states and 64 pdfs, one wave per direction
+size_t mm_lane_dev_bytes();
+void mm_lane_dev_fill(void *dst, const double *w0, const double *w1, const float *init, const float *fin, const int *s2p, const int *pdf_ptr,
+                      const int *pdf_states, int S, int P, int ident);
+int mm_launch_lane(int64_t B, int max_S, const RunParams &p, hipStream_t stream);
+
 // ---- Viterbi on the row-lane form (mm_vit_tu.hip)
 struct VitLaunch {
     int64_t B = 0;

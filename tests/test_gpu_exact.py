@@ -188,3 +188,36 @@ def test_sharp_emissions_on_the_float64_team_kernels(mm, wl, oracle, torch, whic
         check_gamma(gam[ok], g_ref[ok], lens[ok])
         assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-3)
         assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()
+
+
+@pytest.mark.parametrize("which", ["config2", "many_to_one", "sharp"])
+def test_lane_kernel(mm, wl, oracle, torch, which):
+    """Graphs of up to 64 states (mm_kernel_lane.hip: one wave per utterance and direction, the graph in its registers,
+    float64, no marks): BASELINE config 2 at full size (dense 64-state HMM, T = 500, B = 32, identity state map); a sparse
+    graph whose states share pdfs (many-to-one map, pdfs without states), lengths 0 and 1 included; and emissions sharp
+    enough (log-softmax of 25 N(0,1), then -300 nats) to overlap the forward and the backward mass at 2^-400."""
+    rng = np.random.default_rng(7)
+    if which == "config2":
+        g, B, N = wl.dense_ergodic(64, seed=0), 32, 500
+        V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+        lens = np.full(B, N, dtype=np.int32)
+        lens[3], lens[17] = 371, 2
+    elif which == "many_to_one":
+        g, B, N = wl.random_fsm(50, 9, 3.0, seed=4), 7, 40
+        V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+        lens = np.array([40, 0, 1, 33, 40, 2, 17], dtype=np.int32)
+    else:
+        g, B, N = wl.dense_ergodic(40, seed=2), 5, 120
+        V = peaky(rng, (B, N, g.P), 25.0) - 300.0
+        lens = np.array([120, 77, 120, 9, 120], dtype=np.int32)
+    bf = make_batch(mm, wl, g, B, {})
+    assert "mm_lane_kernel" in bf.kernels(), bf.kernels()
+    gam, ttl = bf.pdfposteriors(V, lens)
+    assert bf.last_redo_count() == 0
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    ok = np.isfinite(t_ref)
+    check_gamma(gam[ok], g_ref[ok], lens[ok])
+    assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-3)
+    assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()
+    g2, t2 = bf.pdfposteriors(V, lens)  # deterministic: the same bits
+    assert np.array_equal(gam, g2) and np.array_equal(ttl, t2, equal_nan=True)

@@ -332,7 +332,7 @@ def test_odd_batch_beyond_the_compute_units_on_the_pair_kernels(mm, wl, oracle, 
 @pytest.mark.parametrize("kernel", ["pair", "auto"])
 def test_batch_beyond_the_ordered_limit(mm, wl, oracle, torch, kernel):
     """B = 8200 > 8192: the longest-first order is skipped (mm_engine.hip), the utterances run in batch order -- on the pair
-    kernels (forced) and on the engine's own choice for a graph this small, the wave kernel."""
+    kernels (forced) and on the engine's own choice for a graph this small, the lane kernel."""
     g = wl.random_fsm(24, 4, 2.5, seed=3)
     rng = np.random.default_rng(2)
     B, N = 8200, 6
@@ -345,7 +345,7 @@ def test_batch_beyond_the_ordered_limit(mm, wl, oracle, torch, kernel):
         return bf.pdfposteriors(V, lens) + (bf.kernels(),)
 
     gam, ttl, kernels = _with_env({"MM_DEBUG": "1", "MM_KERNEL": kernel}, run)
-    assert ("mm_fbp_kernel" if kernel == "pair" else "mm_wave_kernel") in kernels, kernels
+    assert ("mm_fbp_kernel" if kernel == "pair" else "mm_lane_kernel") in kernels, kernels
     g_ref, t_ref = oracle64(oracle, g, V, lens)
     ok = np.isfinite(t_ref)
     check_gamma(gam[ok], g_ref[ok], lens[ok])

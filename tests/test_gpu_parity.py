@@ -610,16 +610,20 @@ def test_wave_kernel_first_wherever_the_graphs_fit(mm, wl, oracle, torch):
     slots, 250 pdfs) -> the wave kernel, for one shared graph as for different ones and for a single utterance; one shared
     DENSE graph that needs the 4-segment instance on more than two utterances per compute unit -> the pair kernels (more
     utterances than compute units on the 2-segment instance: the build of which two workgroups fit a compute unit); a
-    graph beyond the form -> as before.
+    graph beyond the form -> as before.  Batches of graphs of up to 64 states and pdfs come before all of that: the lane
+    kernel.
     Results against the oracle in every case."""
     o, oc = oracle
     rng = np.random.default_rng(31)
     cases = [("shared lexicon", [wl.lexicon_fsm(300, 20, seed=2, hubs=1)] * 5, "mm_wave_kernel"),
              ("different random graphs", [wl.random_fsm(60 + 40 * b, 12, 3.0, seed=b) for b in range(5)], "mm_wave_kernel"),
-             ("one utterance", [wl.l2r_hmm(3)], "mm_wave_kernel"),
-             ("dense, small batch", [wl.dense_ergodic(20, seed=3)] * 4, "mm_wave_kernel"),
-             ("dense, many utterances, 2 segments per wave", [wl.dense_ergodic(16, seed=3)] * 520, "mm_wave_kernel<2,2,two per CU>"),
-             ("dense, many utterances, 4 segments per wave", [wl.dense_ergodic(32, seed=3)] * 520, "mm_fbp_kernel"),
+             # graphs of up to 64 states: the lane kernel (one wave per utterance and direction), whatever the batch
+             ("one utterance", [wl.l2r_hmm(3)], "mm_lane_kernel<8>"),
+             ("dense, small batch", [wl.dense_ergodic(20, seed=3)] * 4, "mm_lane_kernel<32>"),
+             ("dense, many utterances", [wl.dense_ergodic(16, seed=3)] * 520, "mm_lane_kernel<16>"),
+             ("different tiny graphs", [wl.random_fsm(10 + 9 * b, 12, 3.0, seed=b) for b in range(6)], "mm_lane_kernel<64>"),
+             ("sparse, many utterances, 2 segments per wave", [wl.lexicon_fsm(120, 20, seed=4, hubs=1)] * 520, "mm_wave_kernel<2,2,two per CU>"),
+             ("dense beyond the lane kernel, many utterances, 4 segments per wave", [wl.random_fsm(100, 12, 20.0, seed=5)] * 520, "mm_fbp_kernel"),
              ("more arcs than the form holds", [wl.lfmmi_denominator(400, 20, seed=9)] * 4, "mm_fbp_kernel")]
     for name, gs, want in cases:
         B, N = len(gs), 23

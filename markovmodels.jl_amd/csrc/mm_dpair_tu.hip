@@ -42,6 +42,7 @@ __global__ void __launch_bounds__(1024) mm_fbds_kernel(RunParams p) {
     const int blk = (int)blockIdx.x - (dir ? half : 0);
     const int ui = (blk / (8 * H)) * 8 + (blk & 7), hset = (blk >> 3) % H;  // (the workgroups of a team are 8 apart: mm_split_tu.hip)
     if (ui >= p.B) return;
+    if ((p.x_sleep & 0x400) && hset == 1) return;  // (test aid: a team mate that never shows up)
     dpair_agent<MM_SPLIT_KA, DSplitGeo<H>::RS, PHASE, NJ, H, DSplitGeo<H>::RSH>(p, ui, dir, hset);
 }
 template <int NJ, int PHASE, int H>

@@ -2283,6 +2283,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     p.N = int(N);
     p.B = int(h->B);
     p.x_sleep = h->dbg.x_sleep;
+    p.x_timeout = std::min<unsigned long long>(10000000ull, std::max<unsigned long long>(200000ull, 1000ull * (unsigned long long)N));
     p.lt_floor = h->lt_floor;
     p.ws_alpha = static_cast<float *>(h->ws);
     p.ws_c = reinterpret_cast<double *>(static_cast<char *>(h->ws) + ws_alpha_bytes(h, N));

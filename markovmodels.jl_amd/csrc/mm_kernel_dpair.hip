@@ -302,6 +302,7 @@ template <int KA, int RS, int PHASE, int NJ, int H = 1, int RSH = 2 * RS>
 __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir, int hset = 0) {
     extern __shared__ float lds[];
     const int DIR = __builtin_amdgcn_readfirstlane(rdir);
+    const unsigned long long x_tmo = p.x_timeout;  // (teams) ticks of s_memrealtime a poll waits before it gives the team up
     using L = PairLay<RS, PHASE, RSH>;
     constexpr int D = 3;  // gather pairs in flight ahead of the FMAs
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
@@ -559,7 +560,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                 while (!dead) {
                     other = (unsigned)granule_load(xps_recv[g] + PHASE * 512, 8u * 255u);
                     if (other != 0u) break;
-                    if (__builtin_amdgcn_s_memrealtime() - tstart > MM_SPLIT_TIMEOUT) dead = true;
+                    if (__builtin_amdgcn_s_memrealtime() - tstart > x_tmo) dead = true;
                     __builtin_amdgcn_s_sleep(8);
                 }
                 same = same && other == xcc + 1u;
@@ -578,7 +579,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             for (int g = 0; g < H; ++g) xp[g] = g != hset ? xps_recv[g] + (ts & 3) * 512 : nullptr;
             bool arrived = true;
             const float lt = dpair_finish_frame<NJ, H>(psum, P1, P, lane, p.gamma + (long long)b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp,
-                                                       live && hset == 0, xp, split_tag(ts, t0, 2), dead ? 0ull : MM_SPLIT_TIMEOUT, &arrived);
+                                                       live && hset == 0, xp, split_tag(ts, t0, 2), dead ? 0ull : x_tmo, &arrived);
             if (!arrived) {
                 if (lane == 0) *redo2 = 2;  // (the team is not running together: the log-domain kernels compute the utterance)
                 dead = true;
@@ -753,7 +754,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                             pend = false;
                         }
                         if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
-                        if (__builtin_amdgcn_s_memrealtime() - tstart > MM_SPLIT_TIMEOUT) {
+                        if (__builtin_amdgcn_s_memrealtime() - tstart > x_tmo) {
                             cdead = true;  // the team is not running together: the log-domain kernels compute the utterance
                             if (lane == 0) *redo2 = 2;
                             break;

@@ -84,7 +84,7 @@ inline size_t pair_lds_bytes(int RS, int phase, int nslotrows, int RSH = 0) {
 typedef unsigned long long mm_u64;
 typedef __attribute__((address_space(1))) mm_u64 mm_gu64;
 #ifndef MM_SPLIT_TIMEOUT
-#define MM_SPLIT_TIMEOUT 10000000ull  // ticks of s_memrealtime (100 MHz): 0.1 s
+#define MM_SPLIT_TIMEOUT 10000000ull  // ticks of s_memrealtime (100 MHz): 0.1 s -- the ceiling; a call passes its own (RunParams::x_timeout)
 #endif
 __device__ __forceinline__ void granule_store(float *base, unsigned byte_off, float a, float b) {
     const mm_u64 v = ((mm_u64)__builtin_bit_cast(unsigned, b) << 32) | __builtin_bit_cast(unsigned, a);
@@ -527,6 +527,7 @@ template <int KA, int RS, int PHASE, int DIRT, int NJ, int H = 1, int RSH = 2 * 
 __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hset = 0, int rdir = 0) {
     extern __shared__ float lds[];
     const int DIR = DIRT < 0 ? __builtin_amdgcn_readfirstlane(rdir) : DIRT;
+    const unsigned long long x_tmo = p.x_timeout;  // (teams) ticks of s_memrealtime a poll waits before it gives the team up
     using L = PairLay<RS, PHASE, RSH>;
 #ifndef MM_PAIR_DA
 #define MM_PAIR_DA 3
@@ -768,7 +769,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             if (!pair_finish_frames<NJ, H>(psum, P1, P, sl, p.gamma + (long long)U[0].b * p.gsb + (long long)(f - 1) * p.gsn,
                                            p.gamma + (long long)U[1].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp,
                                            live0 && U[0].valid && writer, live1 && U[1].valid && writer, lt, xp, split_tag(ts, t0, 2),
-                                           xdead ? 0ull : MM_SPLIT_TIMEOUT)) {
+                                           xdead ? 0ull : x_tmo)) {
                 if (sl == 0) {
                     *redo0 = 2;  // (the team is not running together: the exact kernels compute these utterances)
                     *redo1 = 2;
@@ -893,7 +894,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 while (!dead) {
                     other = (unsigned)granule_load(xps_recv[g] + PHASE * 512, 8u * 255u);
                     if (other != 0u) break;
-                    if (__builtin_amdgcn_s_memrealtime() - tstart > MM_SPLIT_TIMEOUT) dead = true;
+                    if (__builtin_amdgcn_s_memrealtime() - tstart > x_tmo) dead = true;
                     __builtin_amdgcn_s_sleep(8);
                 }
                 same = same && other == xcc + 1u;
@@ -920,7 +921,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             if (!pair_finish_frames<NJ, H>(psum, P1, P, lane, p.gamma + (long long)U[0].b * p.gsb + (long long)(f - 1) * p.gsn,
                                            p.gamma + (long long)U[1].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp,
                                            live0 && U[0].valid && writer, live1 && U[1].valid && writer, lt, xp, split_tag(ts, t0, 2),
-                                           dead ? 0ull : MM_SPLIT_TIMEOUT)) {
+                                           dead ? 0ull : x_tmo)) {
                 if (lane == 0) {
                     *redo0 = 2;  // (the team is not running together: the exact kernels compute these utterances)
                     *redo1 = 2;
@@ -1203,7 +1204,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                                 }
                             }
                             if (__builtin_amdgcn_ballot_w64(pnd[0] || pnd[1]) == 0ull) break;
-                            if (__builtin_amdgcn_s_memrealtime() - tstart > MM_SPLIT_TIMEOUT) {
+                            if (__builtin_amdgcn_s_memrealtime() - tstart > x_tmo) {
                                 cdead = true;
                                 if (lane == 0) {
                                     *redo0 = 2;
@@ -1238,7 +1239,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                             pend = false;
                         }
                         if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
-                        if (__builtin_amdgcn_s_memrealtime() - tstart > MM_SPLIT_TIMEOUT) {
+                        if (__builtin_amdgcn_s_memrealtime() - tstart > x_tmo) {
                             cdead = true;  // the team is not running together: the exact kernels compute these utterances
                             if (lane == 0) {
                                 *redo0 = 2;

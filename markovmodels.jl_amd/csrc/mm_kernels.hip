@@ -162,6 +162,11 @@ struct RunParams {
     float *xbuf_d, *xps_d;
     long long x_phase_d;
     int x_sleep;                // the exchange wave sleeps this many x 64 clocks before its first poll of a step
+    // how long a poll of a team waits (ticks of s_memrealtime, 100 MHz) before it gives the team up and marks the utterances: a
+    // workgroup's team mate may be dispatched a whole ROUND later (the compute units are taken by earlier workgroups of the
+    // launch), so the bound follows the length of a launch -- ~4 of them: 10 us per frame, at least 2 ms, at most 0.1 s (it was
+    // 0.1 s flat: a team that really does not run together -- a foreign kernel holds the compute units -- cost every call that)
+    unsigned long long x_timeout;
     float lt_floor;             // mm_pair_finish_kernel: smallest accepted log2 overlap term of a frame (mm_batch_set_posterior_floor)
 };
 

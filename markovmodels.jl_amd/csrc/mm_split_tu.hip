@@ -21,6 +21,7 @@ __global__ void __launch_bounds__(1024) mm_fbs_kernel(RunParams p) {
     const int blk = (int)blockIdx.x - (dir ? half : 0);
     const int pair = (blk / (8 * H)) * 8 + (blk & 7), hset = (blk >> 3) % H;
     if (pair >= (p.B + 1) / 2) return;
+    if ((p.x_sleep & 0x400) && hset == 1) return;  // (test aid, MM_SPLIT_SLEEP bit 0x400: a team mate that never shows up)
     pair_agent<MM_SPLIT_KA, SplitGeo<H>::RS, PHASE, -1, NJ, H, SplitGeo<H>::RSH>(p, pair, hset, dir);
 }
 template <int NJ, int PHASE, int H>

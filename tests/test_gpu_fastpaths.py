@@ -122,6 +122,37 @@ def test_split_kernels_team_that_does_not_run_together(mm, wl, oracle, torch):
     assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)
 
 
+def test_split_kernels_team_mate_that_never_arrives(mm, wl, oracle, torch):
+    """The real thing: the workgroups of set 1 leave at once (MM_SPLIT_SLEEP bit 0x400 -- what a foreign kernel holding the compute
+    units would do to them), the others WAIT for their rows.  Every poll gives up after the call's bound (10 us per frame, at least
+    2 ms; it was 0.1 s flat), the utterances are marked, the float64 team kernels meet the same fate, the item kernel computes:
+    the oracle's results, and the call comes back in tens of milliseconds, not in half a second."""
+    import time
+
+    g = wsj_den(wl)
+    rng = np.random.default_rng(19)
+    B, N = 3, 20
+    V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+    lens = np.array([20, 14, 20], dtype=np.int32)
+
+    def run():
+        cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+        bf = mm.batch(*([cf] * B))
+        bf.pdfposteriors(V, lens)  # (workspace, code objects)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gam, ttl = bf.pdfposteriors(V, lens)
+        torch.cuda.synchronize()
+        return gam, ttl, bf.kernels(), bf.last_redo_count(), bf.last_fallback_count(), time.perf_counter() - t0
+
+    gam, ttl, kernels, redo, fallback, dt = _with_env({"MM_DEBUG": "1", "MM_SPLIT_SLEEP": str(8 | 0x400), "MM_EXACT_FIRST": "0"}, run)
+    assert "mm_fbs_kernel" in kernels and redo == B and fallback == B
+    assert dt < 0.08, dt
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    check_gamma(gam, g_ref, lens)
+    assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)
+
+
 def test_split_kernels_long_utterances_keep_their_range_marks_harmless(mm, wl, oracle, torch):
     """On the WSJ graph the states of the initial contexts fall ~2 log2 per frame behind the rest: after ~55 frames they
     leave the float range of the linear path and the kernels mark the utterance.  The per-frame normalisers agree

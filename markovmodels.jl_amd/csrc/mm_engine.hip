@@ -2365,8 +2365,11 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
                 p.x_phase_d = (long long)(ws_xd_rows_bytes(h) / 8);
                 // (one memset node over what this call can touch: a call that goes to the float64 kernels with the whole batch leaves
                 // the float32 kernels' area alone, one that starts with the float32 kernels zeroes both -- marks are not known here)
+                p.x_H = h->dpair_ok ? h->pair_H : 0;
+                // (one memset node: the float64 kernels' area when they take the whole batch, else the float32 kernels' -- the
+                // finish kernel then zeroes the float64 area of the utterances it leaves marked)
                 if (exact_first) HIP_TRY(hipMemsetAsync(p.xbuf_d, 0, ws_xd_bytes(h), static_cast<hipStream_t>(stream)));
-                else HIP_TRY(hipMemsetAsync(p.xbuf, 0, ws_x_bytes(h) + ws_xd_bytes(h), static_cast<hipStream_t>(stream)));
+                else HIP_TRY(hipMemsetAsync(p.xbuf, 0, ws_x_bytes(h), static_cast<hipStream_t>(stream)));
             }
             h->last_z = p.pair_zmin;
             rc = exact_first ? MM_OK : launch_pairs(h, p, stream);

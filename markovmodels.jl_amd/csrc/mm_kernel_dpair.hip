@@ -349,8 +349,9 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
     bool xplain = false;
     const float *xrecv[H], *xps_recv[H];
     if constexpr (H > 1) {
-        float *xb = p.xbuf_d + (long long)PHASE * p.x_phase_d + ((long long)ui * 2 + DIR) * H * 2 * p.x_slot;
-        float *xq = p.xps_d + ((long long)ui * 2 + DIR) * H * 4 * 512;
+        // (indexed by the utterance: mm_pair_finish_kernel zeroes the areas of the utterances it leaves marked)
+        float *xb = p.xbuf_d + (long long)PHASE * p.x_phase_d + ((long long)b * 2 + DIR) * H * 2 * p.x_slot;
+        float *xq = p.xps_d + ((long long)b * 2 + DIR) * H * 4 * 512;
 #pragma unroll
         for (int g = 0; g < H; ++g) {
             xrecv[g] = g == hset ? nullptr : xb + (long long)g * 2 * p.x_slot;

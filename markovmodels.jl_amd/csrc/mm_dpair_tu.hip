@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(1024) mm_fbd_kernel(RunParams p) {
 }
 template <int NJ, int PHASE>
 static int launch_dpair_phase(const PairLaunch *h, const RunParams &p, hipStream_t st) {
-    const size_t lds = pair_lds_bytes(MM_ROW_RS, PHASE, h->slotrows);
+    const size_t lds = pair_lds_bytes(MM_ROW_RS, PHASE, h->slotrows, 0, pair_pc(NJ));
     if (lds > 160 * 1024) return mm_fail(MM_ERR_UNSUPPORTED, "exact pair kernel: LDS");
     auto kernel = mm_fbd_kernel<NJ, PHASE>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(1024) mm_fbds_kernel(RunParams p) {
 }
 template <int NJ, int PHASE, int H>
 static int launch_dsplit_phase(const PairLaunch *h, const RunParams &p, hipStream_t st) {
-    const size_t lds = pair_lds_bytes(DSplitGeo<H>::RS, PHASE, h->slotrows, DSplitGeo<H>::RSH);
+    const size_t lds = pair_lds_bytes(DSplitGeo<H>::RS, PHASE, h->slotrows, DSplitGeo<H>::RSH, pair_pc(NJ));
     if (lds > 160 * 1024) return mm_fail(MM_ERR_UNSUPPORTED, "exact split kernel: LDS");
     auto kernel = mm_fbds_kernel<NJ, PHASE, H>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
@@ -65,14 +65,16 @@ static int launch_dsplit_nj(const PairLaunch *h, const RunParams &p, hipStream_t
     return MM_OK;
 }
 int mm_launch_dpairs(const PairLaunch &pl, const RunParams &p, hipStream_t s0) {
+    if (pl.max_P1 > MM_PAIR_P1MAX) return MM_ERR_UNSUPPORTED;
+    const int nj = mm_pair_nj(pl.max_P1);
     if (pl.H == 1) {
         if (pl.pair_ka > MM_PAIR_KA) return MM_ERR_UNSUPPORTED;
-        return pl.max_P1 <= 128 ? launch_dpairs_nj<2>(&pl, p, s0) : launch_dpairs_nj<4>(&pl, p, s0);
+        return nj == 2 ? launch_dpairs_nj<2>(&pl, p, s0) : (nj == 4 ? launch_dpairs_nj<4>(&pl, p, s0) : launch_dpairs_nj<8>(&pl, p, s0));
     }
     if (pl.pair_ka > MM_SPLIT_KA) return MM_ERR_UNSUPPORTED;
-    if (pl.H == 4) return pl.max_P1 <= 128 ? launch_dsplit_nj<2, 4>(&pl, p, s0) : launch_dsplit_nj<4, 4>(&pl, p, s0);
+    if (pl.H == 4) return nj == 2 ? launch_dsplit_nj<2, 4>(&pl, p, s0) : (nj == 4 ? launch_dsplit_nj<4, 4>(&pl, p, s0) : launch_dsplit_nj<8, 4>(&pl, p, s0));
     if (pl.H != 2) return mm_fail(MM_ERR_UNSUPPORTED, "exact split kernel: teams of 2 or 4");
-    return pl.max_P1 <= 128 ? launch_dsplit_nj<2, 2>(&pl, p, s0) : launch_dsplit_nj<4, 2>(&pl, p, s0);
+    return nj == 2 ? launch_dsplit_nj<2, 2>(&pl, p, s0) : (nj == 4 ? launch_dsplit_nj<4, 2>(&pl, p, s0) : launch_dsplit_nj<8, 2>(&pl, p, s0));
 }
 
 }  // namespace mm

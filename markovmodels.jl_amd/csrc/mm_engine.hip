@@ -146,6 +146,7 @@ struct mm_fsm_s {
     std::map<int, QuadVariant *> variants;  // by 2 * KQ + direction
     RowVariant *rows[2] = {nullptr, nullptr};  // row-lane forms (built on first use; rows_tried: do not retry)
     bool rows_tried = false;
+    bool pairs_tried = false;
     RowVariant *prows[2] = {nullptr, nullptr};  // ... and their pair variants (mm_kernel_pairs.hip)
     // split pair forms (mm_rows.h make_rows_split): [direction][set], for FSMs beyond the registers / LDS of one compute unit
     RowVariant *srows[2][MM_SPLIT_HMAX] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
@@ -888,7 +889,14 @@ static void split_pack_opts(const DebugOpts &dbg, RowPackOpts &opt, RowPackOpts 
 static int pair_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
     const bool verbose = dbg.verbose;
     *ok = f->prows[0] && f->prows[1];
-    if (*ok || !f->rows[0] || !f->rows[1]) return MM_OK;  // (only FSMs that fit the row forms are tried)
+    if (*ok || f->pairs_tried) return MM_OK;
+    f->pairs_tried = true;
+    // (the row forms' conditions, with the pair kernels' own pdf capacity: 251 .. 506 pdfs run their NJ = 8 instances, which the row
+    // kernels do not have)
+    if (f->semiring != MM_LOG || !f->fast_ok || f->P1 > MM_PAIR_P1MAX || (f->S1 + 1) * 4 > MM_ROW_RS) {
+        if (verbose) fprintf(stderr, "[mm] pair form: not tried (semiring %d, fast_ok %d, P1 %d, S1 %lld)\n", f->semiring, int(f->fast_ok), int(f->P1), (long long)f->S1);
+        return MM_OK;
+    }
     RowPackOpts opt;
     opt.rs = MM_ROW_RS;
     opt.ka_max = MM_PAIR_KA;
@@ -910,7 +918,14 @@ static int pair_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
     }
     bool fits = make_rows(f->S1, f->qmat[0].rowptr, f->qmat[0].col, f->qmat[0].val, f->s2p, f->P1, false, none, opt, rv[0]->g) &&
                 make_rows(f->S1, f->qmat[1].rowptr, f->qmat[1].col, f->qmat[1].val, f->s2p, f->P1, true, rv[0]->g.pos, optb, rv[1]->g);
+    if (verbose && !fits) fprintf(stderr, "[mm] pair form: the graph does not fit the register windows (KA %d)\n", MM_PAIR_KA);
+    // (arc weights below 2^-60 leave too little of the float range to the values: such graphs run on the other kernels)
+    if (fits && std::min(rv[0]->g.wmin_log2, rv[1]->g.wmin_log2) < -60.f) {
+        if (verbose) fprintf(stderr, "[mm] pair form: arc weights down to 2^%.0f\n", std::min(rv[0]->g.wmin_log2, rv[1]->g.wmin_log2));
+        fits = false;
+    }
     if (fits) set_partner(rv[0]->g, rv[1]->g.pos);
+    const float thr = fits ? 125.f + std::min(rv[0]->g.wmin_log2, rv[1]->g.wmin_log2) : 0.f;
     int rc = MM_OK;
     for (int dir = 0; dir < 2 && fits && !rc; ++dir) {
         if (verbose)
@@ -922,7 +937,7 @@ static int pair_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
             rv[0]->init.resize(size_t(f->S1));
             for (int64_t i = 0; i < f->S1; ++i) rv[0]->init[i] = f->init[rv[0]->g.order[i]];
         }
-        rc = upload_row_variant(f, rv[dir], dir, f->rows[0]->rdev.thr);
+        rc = upload_row_variant(f, rv[dir], dir, thr);
     }
     if (!fits || rc) {
         for (RowVariant *x : rv) {
@@ -1179,7 +1194,7 @@ static int split_variants(mm_fsm_t f, const DebugOpts &dbg, int H, bool *ok) {
     *ok = f->split.H == H && f->srows[0][0] != nullptr;
     if (*ok || f->srows[0][0] != nullptr || (f->split_tried >> H) & 1) return MM_OK;  // (one team size per FSM: the first that fits)
     f->split_tried |= 1 << H;
-    if (f->semiring != MM_LOG || !f->fast_ok || f->P1 > 250 || H > MM_SPLIT_HMAX) return MM_OK;
+    if (f->semiring != MM_LOG || !f->fast_ok || f->P1 > MM_PAIR_P1MAX || H > MM_SPLIT_HMAX) return MM_OK;
     RowPackOpts opt, optb;
     split_pack_opts(dbg, opt, optb, H);
     std::vector<RowGraph> gs;
@@ -1724,6 +1739,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         *out = hold.release();
         return MM_OK;
     }
+    for (int64_t b = 0; b < B; ++b) h->max_P1 = std::max(h->max_P1, int(fsms[b]->P1));  // (the choice of kernels below reads it)
     std::vector<UttDesc> utts(B);
     // quad kernels: one geometry (quads per lane, waves) per direction for the whole batch
     int64_t nq_max[2] = {0, 0};
@@ -1835,8 +1851,10 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     // row kernels: every FSM of the batch needs its row-lane forms.  Small deep (left-to-right) graphs keep states
     // alive whose values differ by more than the float range within one frame, so most of their rows would take the
     // exact fallback of the linear-domain kernels: they run on the item kernel (unless a kernel is forced).
-    h->rows_ok = !h->wave_ok && !h->lane_ok && h->fast_ok && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD && h->dbg.kernel != DebugOpts::K_WAVE &&
-                 !(h->max_depth >= 64 && nq_max[0] <= 3 * 1024 && nq_max[1] <= 3 * 1024 && h->dbg.kernel == DebugOpts::K_AUTO);
+    const bool linear_first = !h->wave_ok && !h->lane_ok && h->fast_ok && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD &&
+                              h->dbg.kernel != DebugOpts::K_WAVE &&
+                              !(h->max_depth >= 64 && nq_max[0] <= 3 * 1024 && nq_max[1] <= 3 * 1024 && h->dbg.kernel == DebugOpts::K_AUTO);
+    h->rows_ok = linear_first;
     for (int64_t b = 0; b < B && h->rows_ok; ++b) {
         bool ok = false;
         int rc = row_variants(fsms[b], h->dbg.verbose, &ok);
@@ -1846,7 +1864,8 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     // pair kernels: all utterances on ONE FSM (the graph registers are shared by the two utterances of a workgroup)
     // (a batch of ONE utterance too: its pair runs the utterance twice, the copy writes nothing outside the workspace -- both
     // directions at once instead of the row kernels' two passes: 4.1 -> 2.6 ms on config 3's graph)
-    h->pairs_ok = h->rows_ok && h->dbg.kernel != DebugOpts::K_ROW && h->dbg.kernel != DebugOpts::K_SPLIT;
+    // (the row kernels take up to 250 pdfs, the pair kernels 506: a shared graph of more pdfs has no row forms)
+    h->pairs_ok = linear_first && (h->rows_ok || h->max_P1 > 250) && h->dbg.kernel != DebugOpts::K_ROW && h->dbg.kernel != DebugOpts::K_SPLIT;
     for (int64_t b = 1; b < B && h->pairs_ok; ++b) h->pairs_ok = fsms[b] == fsms[0];
     if (h->pairs_ok) {
         bool ok = false;
@@ -1857,7 +1876,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             h->pair_ka = std::max(fsms[0]->prows[0]->g.KA, fsms[0]->prows[1]->g.KA);
             h->pair_nwc = std::max(fsms[0]->prows[0]->g.NWC, fsms[0]->prows[1]->g.NWC);
             h->pair_slotrows = std::max(fsms[0]->prows[0]->g.nslotrows, fsms[0]->prows[1]->g.nslotrows);
-            h->pairs_ok = h->pair_ka <= MM_PAIR_KA && mm_pair_lds_bytes(1, h->pair_slotrows) <= 160 * 1024;
+            h->pairs_ok = h->pair_ka <= MM_PAIR_KA && mm_pair_lds_bytes(1, h->pair_slotrows, h->max_P1) <= 160 * 1024;
         }
     }
     // split pair kernels: one shared FSM that is too large for the pair kernels proper (more arcs than the registers of a
@@ -1887,7 +1906,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
                     }
                 h->split_s1p = (f0->split.total + 2 + 3) & ~3;
                 h->pairs_ok = h->pair_ka <= MM_SPLIT_KA && h->pair_nwc <= MM_SPLIT_NWC &&
-                              mm_split_lds_bytes(h->pair_H, 1, h->pair_slotrows) <= 160 * 1024;
+                              mm_split_lds_bytes(h->pair_H, 1, h->pair_slotrows, h->max_P1) <= 160 * 1024;
                 if (!h->pairs_ok) h->pair_H = 1;
             }
         }
@@ -2132,7 +2151,7 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
             s = "mm_wave_kernel<" + std::to_string(h->wave_nseg <= 2 ? 2 : 4) + "," + std::to_string(h->max_P1 <= 128 ? 2 : 4) +
                 (h->wave_nseg <= 2 && h->B > h->n_cus ? ",two per CU>" : ">");
         } else if (h->pairs_ok && h->pair_H > 1) {
-            const std::string k = std::to_string(h->max_P1 <= 128 ? 2 : 4), H = std::to_string(h->pair_H);
+            const std::string k = std::to_string(mm_pair_nj(h->max_P1)), H = std::to_string(h->pair_H);
             s = "mm_fbs_kernel<" + k + ",A," + H + ">, then <" + k + ",B," + H + "> (forward and backward agents in one grid, teams of " + H +
                 " workgroups), mm_pair_finish_kernel, then for marked utterances only " +
                 (h->dpair_ok ? "mm_fbds_kernel<" + k + ",A," + H + ">, then <" + k + ",B," + H + "> (float64, one utterance per team; FIRST and "
@@ -2140,7 +2159,7 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
                              : std::string()) +
                 exact;
         } else if (h->pairs_ok) {
-            const std::string k = std::to_string(h->max_P1 <= 128 ? 2 : 4);
+            const std::string k = std::to_string(mm_pair_nj(h->max_P1));
             s = "mm_fbp_kernel<" + k + ",A>, then <" + k + ",B> (forward and backward agents in one grid), mm_pair_finish_kernel, then for marked "
                 "utterances only " +
                 (h->dpair_ok ? "mm_fbd_kernel<" + k + ",A>, then <" + k + ",B> (float64, one utterance per workgroup; FIRST and alone while the "
@@ -2181,14 +2200,14 @@ static size_t ws_x_rows_bytes(mm_batch_t h) {
     return h->pair_H > 1 ? size_t(2) * size_t((h->B + 1) / 2) * 2 * size_t(h->pair_H) * 2 * (2 * size_t(h->split_s1p)) * 4 : 0;
 }
 static size_t ws_x_bytes(mm_batch_t h) {
-    return h->pair_H > 1 ? align_up(ws_x_rows_bytes(h) + size_t((h->B + 1) / 2) * 2 * size_t(h->pair_H) * 4 * 512 * 4, 256) : 0;
+    return h->pair_H > 1 ? align_up(ws_x_rows_bytes(h) + size_t((h->B + 1) / 2) * 2 * size_t(h->pair_H) * 4 * size_t(mm_pair_xps(h->max_P1)) * 4, 256) : 0;
 }
 // ... and for the teams of the float64 kernels (one utterance per team: B "pairs")
 static size_t ws_xd_rows_bytes(mm_batch_t h) {
     return h->pair_H > 1 && h->dpair_ok ? size_t(2) * size_t(h->B) * 2 * size_t(h->pair_H) * 2 * (2 * size_t(h->split_s1p)) * 4 : 0;
 }
 static size_t ws_xd_bytes(mm_batch_t h) {
-    return h->pair_H > 1 && h->dpair_ok ? align_up(ws_xd_rows_bytes(h) + size_t(h->B) * 2 * size_t(h->pair_H) * 4 * 512 * 4, 256) : 0;
+    return h->pair_H > 1 && h->dpair_ok ? align_up(ws_xd_rows_bytes(h) + size_t(h->B) * 2 * size_t(h->pair_H) * 4 * size_t(mm_pair_xps(h->max_P1)) * 4, 256) : 0;
 }
 static size_t ws_tail_bytes(mm_batch_t h) {  // longest-first order, redo marks, pair hand-over, per-direction log Z minima, team buffers
     return 2 * align_up(size_t(h->B + 1) * 4, 256) + align_up(size_t(h->B + 1) * 2 * mm_pair_hand_bytes(), 256) +
@@ -2358,6 +2377,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
                 p.xbuf = reinterpret_cast<float *>(reinterpret_cast<char *>(p.pair_zmin) + align_up(size_t(h->B) * 6 * 8, 256));
                 p.xps = reinterpret_cast<float *>(reinterpret_cast<char *>(p.xbuf) + ws_x_rows_bytes(h));
                 p.x_slot = 2ll * h->split_s1p;
+                p.x_psn = mm_pair_xps(h->max_P1);
                 p.x_phase = (long long)(ws_x_rows_bytes(h) / 8);
                 p.x_sleep = h->dbg.x_sleep;
                 p.xbuf_d = reinterpret_cast<float *>(reinterpret_cast<char *>(p.xbuf) + ws_x_bytes(h));

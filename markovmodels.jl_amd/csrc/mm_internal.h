@@ -27,6 +27,11 @@ int mm_fail(int code, const std::string &msg);
 
 #define MM_ROW_RS 8192  // LDS bytes of one copy of the linear vector (row kernels) / half a pair vector (pair kernels)
 #define MM_PAIR_KA 44   // arc slots per lane of the pair kernels
+// pdfs (+ 1) of the pair / split pair / float64 pair kernels: passes of 64 lanes of their service waves (the NJ of the instances),
+// and the floats of one slot of per-pdf partial sums a team publishes (PairLay::XPS, mm_kernel_pairs.hip)
+#define MM_PAIR_P1MAX 506
+inline int mm_pair_nj(int P1) { return P1 <= 128 ? 2 : (P1 <= 250 ? 4 : 8); }
+inline int mm_pair_xps(int P1) { return P1 <= 250 ? 512 : 1024; }
 // split pair kernels (teams of H workgroups per utterance pair and direction): bytes of half a pair vector, arc slots per
 // lane, compute waves (+ a service wave and an exchange wave)
 #define MM_SPLIT_RS 12288
@@ -72,13 +77,13 @@ struct PairLaunch {
     bool small = false;  // every FSM has at most 127 states: the instance whose service wave copies and scans one row of 64 float4
 };
 int mm_launch_pairs(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
-size_t mm_pair_lds_bytes(int phase, int nslotrows);
+size_t mm_pair_lds_bytes(int phase, int nslotrows, int max_P1);
 size_t mm_pair_hand_bytes();
 // ---- the float64 exact pair kernels (mm_dpair_tu.hip): one utterance per workgroup, for the utterances marked in p.redo
 int mm_launch_dpairs(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
 // ---- split pair kernels (mm_split_tu.hip): teams of pl.H workgroups
 int mm_launch_split(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
-size_t mm_split_lds_bytes(int H, int phase, int nslotrows);
+size_t mm_split_lds_bytes(int H, int phase, int nslotrows, int max_P1);
 
 
 // ---- wave kernel (mm_wave_tu.hip)

@@ -303,7 +303,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
     extern __shared__ float lds[];
     const int DIR = __builtin_amdgcn_readfirstlane(rdir);
     const unsigned long long x_tmo = p.x_timeout;  // (teams) ticks of s_memrealtime a poll waits before it gives the team up
-    using L = PairLay<RS, PHASE, RSH>;
+    using L = PairLay<RS, PHASE, RSH, pair_pc(NJ)>;
     constexpr int D = 3;  // gather pairs in flight ahead of the FMAs
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, NWC = NW - (H > 1 ? 2 : 1);
@@ -351,14 +351,14 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
     if constexpr (H > 1) {
         // (indexed by the utterance: mm_pair_finish_kernel zeroes the areas of the utterances it leaves marked)
         float *xb = p.xbuf_d + (long long)PHASE * p.x_phase_d + ((long long)b * 2 + DIR) * H * 2 * p.x_slot;
-        float *xq = p.xps_d + ((long long)b * 2 + DIR) * H * 4 * 512;
+        float *xq = p.xps_d + ((long long)b * 2 + DIR) * H * 4 * (int)L::XPS;
 #pragma unroll
         for (int g = 0; g < H; ++g) {
             xrecv[g] = g == hset ? nullptr : xb + (long long)g * 2 * p.x_slot;
-            xps_recv[g] = g == hset ? nullptr : xq + (long long)g * 4 * 512;
+            xps_recv[g] = g == hset ? nullptr : xq + (long long)g * 4 * (int)L::XPS;
         }
         xsend = xb + (long long)hset * 2 * p.x_slot;
-        xps_send = xq + (long long)hset * 4 * 512;
+        xps_send = xq + (long long)hset * 4 * (int)L::XPS;
     }
     unsigned long long endmask = 0, lgw0 = 0;
     int nslots = 0;
@@ -415,7 +415,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
         float ltmin = __builtin_inff();  // smallest log2 of a frame's sum of 2^(a~ + b~) (see mm_dpair_finish_kernel)
         auto dma_raw = [&](int t) {  // raw emissions of step t (clamped) -> RAW(t & 3, 0)
             const int tt = t < 1 ? 1 : (t > tEnd ? tEnd : t);
-            row_dma_em<NJ>(L::RAW(0, 0) + 2048u * (t & 3), Vb, p.vsn, frame_of(tt), p.N, P, sl);
+            row_dma_em<NJ>(L::RAW(0, 0) + L::RAWS * (unsigned)(t & 3), Vb, p.vsn, frame_of(tt), p.N, P, sl);
         };
         constexpr int NDM = (RSH / 2 + 16 + 1023) / 1024;  // 1 KB DMAs of a row of floats (teams: + the alignment shift)
         auto dma_partner = [&](int t) {  // the other agent's vector + offset of step t's frame -> AL(t % 3), POFF(t & 7, 0)
@@ -424,7 +424,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             f = f > p.N ? p.N : f;  // (frame N+1 is never combined)
             const int n4 = H > 1 ? (int)((xoff / 4u + (unsigned)xcnt + 3u) >> 2) : S1p >> 2;  // float4s of the row
             const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(rowsP + (long long)f * S1p + xal);
-            const unsigned dst = L::AL(0) + (unsigned)(tt % 3) * (unsigned)RSH;
+            const unsigned dst = L::AL(0) + (unsigned)(tt % L::NR) * (unsigned)RSH;
             (void)n4;
             dma_row_b128<NDM>(uni(src), (unsigned)sl, dst);  // (no clamping: see pair_agent)
             dma_b32(reinterpret_cast<const unsigned *>(offs + f) + (sl & 1), L::POFF(0, 0) + 512u * (t & 7));
@@ -432,7 +432,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
         constexpr int NDMA = NJ + (PHASE ? NDM + 1 : 0);  // DMAs issued per step
         // stage the emissions of step t into EM(t & 1) and account its offset; S = the normaliser the step subtracts
         auto stage = [&](int t, float S) {
-            const float E = pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, 0) + 2048u * (t & 3), 0, frame_of(t), len, P, sl);
+            const float E = pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, 0) + L::RAWS * (unsigned)(t & 3), 0, frame_of(t), len, P, sl);
             cum += (double)S + (double)E;
             if (sl == 0) {
                 ldsw(L::MS(t & 1), S);
@@ -446,7 +446,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
         for (int t = t0; t <= t0 + 3; ++t) dma_raw(t);
         if constexpr (PHASE == 1) {
             dma_partner(t0 + 1);
-            dma_partner(t0 + 2);
+            if constexpr (L::NR == 3) dma_partner(t0 + 2);  // (a ring of 2: pair_agent)
             const PairHand h = hand[0];
             norm.m_prev = h.m_prev;
             norm.s_cur = h.s_cur;
@@ -457,7 +457,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
         }
         MM_ROW_VMCNT(0);
         if (PHASE == 0 || DIR == 1) {  // emissions of the starting step
-            const float E = pair_stage_em<NJ>(L::EM(t0 & 1), L::RAW(0, 0) + 2048u * (t0 & 3), 0, frame_of(t0), len, P, sl);
+            const float E = pair_stage_em<NJ>(L::EM(t0 & 1), L::RAW(0, 0) + L::RAWS * (unsigned)(t0 & 3), 0, frame_of(t0), len, P, sl);
             if (PHASE == 0) {  // step 1 subtracts nothing but E
                 cum = (double)E;
                 if (DIR == 0 && sl == 0 && (H == 1 || hset == 0)) offs[1] = cum;
@@ -484,7 +484,9 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
         auto step = [&](auto RDc, int t) {
             constexpr int RD = decltype(RDc)::value, WR = 1 - RD;  // RD = parity of steps t - 1 and t + 1
             if constexpr (H > 1 || NJ > 2) asm volatile("" : "+v"(sl));
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            constexpr bool ring2 = PHASE == 1 && L::NR == 2;  // (the partner row of step t + 1 requested at the top of step t: pair_agent)
+            if constexpr (ring2) dma_partner(t + 1);
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
             MM_STAMP(2);
             // the normaliser of step t + 1 from the maximum of step t - 1 (complete since the last barrier)
             const float mx = dpair_scan_max<(RS / 8 + 63) / 64>(L::PP(RD), (S1 + 2) >> 1, sl);
@@ -496,12 +498,13 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             MM_STAMP(4);
             dma_raw(t + 4);
             if constexpr (PHASE == 1) {
-                dma_partner(t + 2);
+                if constexpr (!ring2) dma_partner(t + 2);
                 MM_STAMP(5);
                 if constexpr (H == 1)
                     if (t - 2 > t0) frames_of_step(t - 2, L::PSUM(WR));  // gamma of step t - 2: its per-pdf sums were completed in the previous step
                 MM_STAMP(6);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");  // the partner vector of step t + 1 (requested at step t - 1)
+                if constexpr (ring2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");  // the partner vector of step t + 1 (requested at step t - 1)
                 MM_STAMP(7);
             }
             MM_STAMP(0);
@@ -551,7 +554,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             xcc &= 15u;
-            if (lane == 0) granule_store(xps_send + PHASE * 512, 8u * 255u, __builtin_bit_cast(float, xcc + 1u), 0.f);
+            if (lane == 0) granule_store(xps_send + PHASE * (int)L::XPS, 8u * (L::XPS / 2u - 1u), __builtin_bit_cast(float, xcc + 1u), 0.f);
             bool same = true;
             const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
@@ -559,7 +562,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                 if (g == hset) continue;
                 unsigned other = 0u;
                 while (!dead) {
-                    other = (unsigned)granule_load(xps_recv[g] + PHASE * 512, 8u * 255u);
+                    other = (unsigned)granule_load(xps_recv[g] + PHASE * (int)L::XPS, 8u * (L::XPS / 2u - 1u));
                     if (other != 0u) break;
                     if (__builtin_amdgcn_s_memrealtime() - tstart > x_tmo) dead = true;
                     __builtin_amdgcn_s_sleep(8);
@@ -577,7 +580,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             const bool live = f >= 1 && f <= len;
             const float *xp[H];
 #pragma unroll
-            for (int g = 0; g < H; ++g) xp[g] = g != hset ? xps_recv[g] + (ts & 3) * 512 : nullptr;
+            for (int g = 0; g < H; ++g) xp[g] = g != hset ? xps_recv[g] + (ts & 3) * (int)L::XPS : nullptr;
             bool arrived = true;
             const float lt = dpair_finish_frame<NJ, H>(psum, P1, P, lane, p.gamma + (long long)b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp,
                                                        live && hset == 0, xp, split_tag(ts, t0, 2), dead ? 0ull : x_tmo, &arrived);
@@ -669,7 +672,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                 const float S = ldsr(L::MS(WR));  // the step's normaliser, posted by the service wave
                 float e = ldsr((info >> 16) + L::EM(WR));
                 const int f = frame_of(t);
-                const unsigned alb = L::AL(0) + (unsigned)(t % 3) * (unsigned)RSH + xoff;
+                const unsigned alb = L::AL(0) + (unsigned)(t % L::NR) * (unsigned)RSH + xoff;
                 float al = 0.f;
                 if constexpr (PHASE == 1) al = ldsr(((info2 & 0xffffu) >> 1) + alb);
                 float *rowP = rowsP + (long long)(f <= p.N ? f : 0) * S1p;
@@ -724,7 +727,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             }
             if constexpr (PHASE == 1)  // C' * (A .* B) of the previous step (:155)
                 if (t - 1 > t0)
-                    dpair_pdf_sums(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane, H > 1 ? xps_send + ((t - 1) & 3) * 512 : nullptr,
+                    dpair_pdf_sums(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane, H > 1 ? xps_send + ((t - 1) & 3) * (int)L::XPS : nullptr,
                                    H > 1 && split_tag(t - 1, t0, 2) != 0u);
             if constexpr (H > 1) {
                 // The rows of the other sets of this step (pair_agent, MM_SPLIT_CWPOLL): chunk j (128 granules) of the q-th other
@@ -779,7 +782,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
         }
         if constexpr (PHASE == 1) {
             if (t1 > t0)
-                dpair_pdf_sums(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane, H > 1 ? xps_send + (t1 & 3) * 512 : nullptr,
+                dpair_pdf_sums(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane, H > 1 ? xps_send + (t1 & 3) * (int)L::XPS : nullptr,
                                H > 1 && split_tag(t1, t0, 2) != 0u);
             __syncthreads();  // (a)
         }

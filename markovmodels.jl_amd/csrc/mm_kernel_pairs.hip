@@ -43,26 +43,34 @@ __device__ __forceinline__ void ldsw2(unsigned addr, float a, float b) {
 // LDS byte layout of the pair kernels (absolute addresses).  RS2 = bytes of one pair vector; RSH = bytes of the rows ONE
 // workgroup finishes (all of them: RS2; a set of them in the split kernels, H > 1) -- what the partner-row ring and the q
 // vector hold.
-template <int RS, int PHASE, int RSH = 2 * RS>
+// PC = the pdf capacity of the per-pdf arrays: 256, or 512 for the instances of more than 4 passes of 64 lanes over the pdfs
+// (NJ > 4: graphs of 251 .. 506 pdfs).  Those pay for their arrays with the partner-row ring: NR = 2 vectors instead of 3
+// -- a partner row is requested at the top of the step before the one that combines it, not two steps ahead.
+constexpr int pair_pc(int NJ) { return NJ > 4 ? 512 : 256; }
+template <int RS, int PHASE, int RSH = 2 * RS, int PC = 256>
 struct PairLay {
     static constexpr unsigned RS2 = 2 * RS;
+    static constexpr unsigned PC4 = 4u * PC, PC8 = 8u * PC;
+    static constexpr int NR = PC > 256 ? 2 : 3;      // vectors of the partner-row ring
+    static constexpr unsigned RAWS = 2u * PC4;       // bytes of one ring entry of the raw emissions (both utterances)
+    static constexpr unsigned XPS = 2u * PC;         // (teams) floats of one slot of published per-pdf partial sums
     static constexpr unsigned PP(int par) { return unsigned(par) * RS2; }                          // p pairs [pos][2]
-    static constexpr unsigned RAW(int k, int u) { return 2 * RS2 + unsigned(2 * k + u) * 1024u; }  // raw emissions, k < 4
-    static constexpr unsigned EM(int par) { return 2 * RS2 + 8192u + unsigned(par) * 2048u; }      // [pdf][2] pairs
-    static constexpr unsigned MS(int par) { return 2 * RS2 + 12288u + unsigned(par) * 64u; }       // {S_0, S_1} of a step
-    static constexpr unsigned OWN(int k) { return 2 * RS2 + 12288u + 128u + unsigned(k) * 16u; }   // own offsets, k < 4: 2 doubles
-    static constexpr unsigned XFLAG = 2 * RS2 + 12288u + 192u;  // split kernels: != 0 when the whole team runs on one XCD
-    static constexpr unsigned POFF(int k, int u) { return 2 * RS2 + 12288u + 256u + unsigned(2 * k + u) * 256u; }  // partner offsets, k < 8
-    static constexpr unsigned PSUM(int par) { return 2 * RS2 + 12288u + 256u + 4096u + unsigned(par) * 2048u; }   // [pdf][2]
-    static constexpr unsigned PDFSE = 2 * RS2 + 12288u + 256u + 4096u + 4096u;                     // u16 [2 * P1]
-    static constexpr unsigned FIX = PDFSE + 1024u;
-    static constexpr unsigned AL(int k) { return FIX + unsigned(k) * RSH; }                        // partner rows (phase B), k < 3
-    static constexpr unsigned Q(int par) { return FIX + 3u * RSH + unsigned(par) * RSH; }          // q pairs [qpos][2] (phase B)
-    static constexpr unsigned SLOTS = PHASE ? FIX + 5u * RSH : FIX;
+    static constexpr unsigned RAW(int k, int u) { return 2 * RS2 + unsigned(2 * k + u) * PC4; }    // raw emissions, k < 4
+    static constexpr unsigned EM(int par) { return 2 * RS2 + 8u * PC4 + unsigned(par) * PC8; }     // [pdf][2] pairs
+    static constexpr unsigned MS(int par) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + unsigned(par) * 64u; }      // {S_0, S_1} of a step
+    static constexpr unsigned OWN(int k) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + 128u + unsigned(k) * 16u; }  // own offsets, k < 4: 2 doubles
+    static constexpr unsigned XFLAG = 2 * RS2 + 8u * PC4 + 2u * PC8 + 192u;  // split kernels: != 0 when the whole team runs on one XCD
+    static constexpr unsigned POFF(int k, int u) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + 256u + unsigned(2 * k + u) * 256u; }  // partner offsets, k < 8
+    static constexpr unsigned PSUM(int par) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + 256u + 4096u + unsigned(par) * PC8; }   // [pdf][2]
+    static constexpr unsigned PDFSE = 2 * RS2 + 8u * PC4 + 4u * PC8 + 256u + 4096u;                // u16 [2 * P1]
+    static constexpr unsigned FIX = PDFSE + PC4;
+    static constexpr unsigned AL(int k) { return FIX + unsigned(k) * RSH; }                        // partner rows (phase B), k < NR
+    static constexpr unsigned Q(int par) { return FIX + unsigned(NR) * RSH + unsigned(par) * RSH; }  // q pairs [qpos][2] (phase B)
+    static constexpr unsigned SLOTS = PHASE ? FIX + unsigned(NR + 2) * RSH : FIX;
 };
-inline size_t pair_lds_bytes(int RS, int phase, int nslotrows, int RSH = 0) {
-    const size_t fix = size_t(4 * RS) + 12288 + 256 + 4096 + 4096 + 1024;
-    return fix + (phase ? size_t(5) * size_t(RSH ? RSH : 2 * RS) : 0) + size_t(nslotrows) * 64 * 8;
+inline size_t pair_lds_bytes(int RS, int phase, int nslotrows, int RSH = 0, int PC = 256) {
+    const size_t fix = size_t(4 * RS) + size_t(8 * 4 * PC) + size_t(4 * 8 * PC) + 256 + 4096 + size_t(4 * PC);
+    return fix + (phase ? size_t(PC > 256 ? 4 : 5) * size_t(RSH ? RSH : 2 * RS) : 0) + size_t(nslotrows) * 64 * 8;
 }
 
 // ---- split kernels (H > 1): a TEAM of H workgroups computes one direction of an utterance pair; workgroup h finishes the
@@ -528,7 +536,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
     extern __shared__ float lds[];
     const int DIR = DIRT < 0 ? __builtin_amdgcn_readfirstlane(rdir) : DIRT;
     const unsigned long long x_tmo = p.x_timeout;  // (teams) ticks of s_memrealtime a poll waits before it gives the team up
-    using L = PairLay<RS, PHASE, RSH>;
+    using L = PairLay<RS, PHASE, RSH, pair_pc(NJ)>;
 #ifndef MM_PAIR_DA
 #define MM_PAIR_DA 3
 #endif
@@ -601,14 +609,14 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
     const float *xrecv[H], *xps_recv[H];
     if constexpr (H > 1) {
         float *xb = p.xbuf + (long long)PHASE * p.x_phase + ((long long)pair * 2 + DIR) * H * 2 * p.x_slot;
-        float *xq = p.xps + ((long long)pair * 2 + DIR) * H * 4 * 512;
+        float *xq = p.xps + ((long long)pair * 2 + DIR) * H * 4 * (int)L::XPS;
 #pragma unroll
         for (int g = 0; g < H; ++g) {
             xrecv[g] = g == hset ? nullptr : xb + (long long)g * 2 * p.x_slot;
-            xps_recv[g] = g == hset ? nullptr : xq + (long long)g * 4 * 512;
+            xps_recv[g] = g == hset ? nullptr : xq + (long long)g * 4 * (int)L::XPS;
         }
         xsend = xb + (long long)hset * 2 * p.x_slot;
-        xps_send = xq + (long long)hset * 4 * 512;
+        xps_send = xq + (long long)hset * 4 * (int)L::XPS;
     }
     unsigned long long endmask = 0, lgw0 = 0;
     int nslots = 0, start2 = 0;
@@ -675,7 +683,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         auto dma_raw = [&](int t) {  // raw emissions of step t (clamped) -> RAW(t & 3, u)
             const int tt = t < 1 ? 1 : (t > tEnd ? tEnd : t);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) row_dma_em<NJ>(L::RAW(0, u) + 2048u * (t & 3), U[u].Vb, p.vsn, frame_of(tt), p.N, P, sl);
+            for (int u = 0; u < 2; ++u) row_dma_em<NJ>(L::RAW(0, u) + L::RAWS * (unsigned)(t & 3), U[u].Vb, p.vsn, frame_of(tt), p.N, P, sl);
         };
         auto dma_partner = [&](int t) {  // the other agent's vector + offset of step t's frame -> AL(t % 3, u), POFF(t & 3, u)
             const int tt = t < 1 ? 1 : (t > tEnd ? tEnd : t);
@@ -686,7 +694,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             const int n4 = H > 1 ? (xcnt + 1) >> 1 : S1p >> 1;  // float4s of the row of pairs
             constexpr int NDM = RSH / 1024;
             const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(rowsP + (long long)f * 2 * S1p + 2 * xbase);
-            const unsigned dst = L::AL(0) + (unsigned)(tt % 3) * (unsigned)RSH;
+            const unsigned dst = L::AL(0) + (unsigned)(tt % L::NR) * (unsigned)RSH;
             if constexpr (small_graph) {  // (one DMA covers the row: the others would copy element 0 again)
                 dma_b128(src + (sl < n4 ? sl : 0), dst);
             } else {
@@ -706,7 +714,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             float E[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                E[u] = pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, u) + 2048u * (t & 3), u, frame_of(t), U[u].len, P, sl);
+                E[u] = pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, u) + L::RAWS * (unsigned)(t & 3), u, frame_of(t), U[u].len, P, sl);
                 cum[u] += (double)S[u] + (double)E[u];
             }
             if (sl == 0) {
@@ -724,7 +732,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         for (int t = t0; t <= t0 + 3; ++t) dma_raw(t);
         if constexpr (PHASE == 1) {
             dma_partner(t0 + 1);
-            dma_partner(t0 + 2);
+            if constexpr (L::NR == 3) dma_partner(t0 + 2);  // (a ring of 2: step t0 + 1 requests the row of t0 + 2 at its top)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const PairHand h = hand[u];
@@ -740,7 +748,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         if (PHASE == 0 || DIR == 1) {  // emissions of the starting step: the initial alpha needs them, and so does
             float E[2];                // rebuilding the backward agent's linear vector from its stored beta~
 #pragma unroll
-            for (int u = 0; u < 2; ++u) E[u] = pair_stage_em<NJ>(L::EM(t0 & 1), L::RAW(0, u) + 2048u * (t0 & 3), u, frame_of(t0), U[u].len, P, sl);
+            for (int u = 0; u < 2; ++u) E[u] = pair_stage_em<NJ>(L::EM(t0 & 1), L::RAW(0, u) + L::RAWS * (unsigned)(t0 & 3), u, frame_of(t0), U[u].len, P, sl);
             if (PHASE == 0) {  // step 1 subtracts nothing but E
 #pragma unroll
                 for (int u = 0; u < 2; ++u) cum[u] = (double)E[u];
@@ -764,7 +772,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             float lt[2];
             const float *xp[H];
 #pragma unroll
-            for (int g = 0; g < H; ++g) xp[g] = (H > 1 && g != hset) ? xps_recv[g] + (ts & 3) * 512 : nullptr;
+            for (int g = 0; g < H; ++g) xp[g] = (H > 1 && g != hset) ? xps_recv[g] + (ts & 3) * (int)L::XPS : nullptr;
             const bool writer = H == 1 || hset == 0;  // (every workgroup of a team has the sums of all pdfs: the first stores gamma)
             if (!pair_finish_frames<NJ, H>(psum, P1, P, sl, p.gamma + (long long)U[0].b * p.gsb + (long long)(f - 1) * p.gsn,
                                            p.gamma + (long long)U[1].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp,
@@ -796,9 +804,15 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
 #define MM_PAIR_OPAQUE_B 0
 #endif
             if constexpr (H > 1 || NJ > 2 || (MM_PAIR_OPAQUE_B && PHASE == 1)) asm volatile("" : "+v"(sl));
+            // A partner ring of TWO vectors (NJ > 4): the row of step t + 1 is requested here, at the top of step t -- its buffer
+            // was read until the barrier that ended step t - 1 -- and awaited at the bottom with the 2 NJ emission DMAs issued
+            // behind it allowed in flight; those are then all that is in flight at the top of a step, and the emissions of
+            // step t + 1 (requested at step t - 3) have landed.
+            constexpr bool ring2 = PHASE == 1 && L::NR == 2;
+            if constexpr (ring2) dma_partner(t + 1);
             // emissions of step t + 1 (requested at step t - 2: the DMAs of step t - 1 may still be in flight)
             // (a small graph issues ONE partner DMA per step, not RSH / 1024: the bound of what may be in flight shrinks with it)
-            if constexpr (small_graph) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA_SMALL) : "memory");
+            else if constexpr (small_graph) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA_SMALL) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
             MM_STAMP(2);
             // the normaliser of step t + 1 from the maxima of step t - 1 (complete since the last barrier)
@@ -815,7 +829,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             MM_STAMP(4);
             dma_raw(t + 4);
             if constexpr (PHASE == 1) {
-                dma_partner(t + 2);
+                if constexpr (!ring2) dma_partner(t + 2);
                 MM_STAMP(5);
                 // gamma of step t - 2: its per-pdf sums were completed in the previous step
                 // (split kernels: by the exchange wave, which has nothing else to do since the compute waves receive the rows --
@@ -824,7 +838,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                     if (t - 2 > t0) frames_of_step(t - 2, L::PSUM(WR));
                 MM_STAMP(6);
                 // the partner vector of step t + 1 (requested at step t - 1) must be in LDS when the compute waves leave the barrier
-                if constexpr (small_graph) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA_SMALL) : "memory");
+                if constexpr (ring2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
+                else if constexpr (small_graph) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA_SMALL) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
                 MM_STAMP(7);
             }
@@ -884,7 +899,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             xcc &= 15u;
-            if (lane == 0) granule_store(xps_send + PHASE * 512, 8u * 255u, __builtin_bit_cast(float, xcc + 1u), 0.f);
+            if (lane == 0) granule_store(xps_send + PHASE * (int)L::XPS, 8u * (L::XPS / 2u - 1u), __builtin_bit_cast(float, xcc + 1u), 0.f);
             bool same = true;
             const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
@@ -892,7 +907,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 if (g == hset) continue;
                 unsigned other = 0u;
                 while (!dead) {
-                    other = (unsigned)granule_load(xps_recv[g] + PHASE * 512, 8u * 255u);
+                    other = (unsigned)granule_load(xps_recv[g] + PHASE * (int)L::XPS, 8u * (L::XPS / 2u - 1u));
                     if (other != 0u) break;
                     if (__builtin_amdgcn_s_memrealtime() - tstart > x_tmo) dead = true;
                     __builtin_amdgcn_s_sleep(8);
@@ -916,7 +931,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             float lt[2];
             const float *xp[H];
 #pragma unroll
-            for (int g = 0; g < H; ++g) xp[g] = g != hset ? xps_recv[g] + (ts & 3) * 512 : nullptr;
+            for (int g = 0; g < H; ++g) xp[g] = g != hset ? xps_recv[g] + (ts & 3) * (int)L::XPS : nullptr;
             const bool writer = hset == 0;  // (every workgroup of a team has the sums of all pdfs: the first stores gamma)
             if (!pair_finish_frames<NJ, H>(psum, P1, P, lane, p.gamma + (long long)U[0].b * p.gsb + (long long)(f - 1) * p.gsn,
                                            p.gamma + (long long)U[1].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp,
@@ -1089,7 +1104,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 const mm_f32x2 S = ldsr2(L::MS(WR));  // the step's normalisers, posted by the service wave
                 mm_f32x2 e = ldsr2((info >> 16) + L::EM(WR));
                 const int f = frame_of(t);
-                const unsigned alb = L::AL(0) + (unsigned)(t % 3) * (unsigned)RSH;
+                const unsigned alb = L::AL(0) + (unsigned)(t % L::NR) * (unsigned)RSH;
                 mm_f32x2 al = {0.f, 0.f};
                 // (split kernels) where the team reads this step's rows, and the step's tag as a sign
                 float *xw = H > 1 ? xsend + (long long)(t & 1) * p.x_slot - 2 * xbase : nullptr;
@@ -1154,7 +1169,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             }
             if constexpr (PHASE == 1)  // C' * (A .* B) of the previous step (:155)
                 if (t - 1 > t0)
-                    pair_pdf_sums(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane, H > 1 ? xps_send + ((t - 1) & 3) * 512 : nullptr,
+                    pair_pdf_sums(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane, H > 1 ? xps_send + ((t - 1) & 3) * (int)L::XPS : nullptr,
                                   (H > 1 && split_tag(t - 1, t0, 2)) ? -1.f : 1.f);
             if constexpr (H > 1 && MM_SPLIT_CWPOLL) {
                 // The rows of the other sets of this step: chunk j (128 granules) of the q-th other set is item q * NG2 + j, and
@@ -1266,7 +1281,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         }
         if constexpr (PHASE == 1) {
             if (t1 > t0)
-                pair_pdf_sums(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane, H > 1 ? xps_send + (t1 & 3) * 512 : nullptr,
+                pair_pdf_sums(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane, H > 1 ? xps_send + (t1 & 3) * (int)L::XPS : nullptr,
                               (H > 1 && split_tag(t1, t0, 2)) ? -1.f : 1.f);
             __syncthreads();  // (a)
         }
@@ -1331,7 +1346,7 @@ static __global__ void mm_pair_finish_kernel(RunParams p) {
         __syncthreads();
         if (marked) {
             typedef float f4 __attribute__((ext_vector_type(4)));
-            const long long nrow = 2ll * p.x_H * 2 * p.x_slot, nps = 2ll * p.x_H * 4 * 512;  // floats per utterance and phase / of partial sums
+            const long long nrow = 2ll * p.x_H * 2 * p.x_slot, nps = 2ll * p.x_H * 4 * p.x_psn;  // floats per utterance and phase / of partial sums
             for (int ph = 0; ph < 2; ++ph) {
                 f4 *q = reinterpret_cast<f4 *>(p.xbuf_d + ph * p.x_phase_d + (long long)b * nrow);
                 for (long long i = threadIdx.x; i < nrow / 4; i += blockDim.x) q[i] = f4{0.f, 0.f, 0.f, 0.f};

@@ -11,7 +11,8 @@ namespace mm {
 // launched the two directions as two kernels on a pair of library streams, forked from and joined into the caller's stream
 // by events: every fork, join and cross-stream wait cost 10-25 us of idle device -- ~80 us of a 2.9 ms call, rocprofv3
 // timeline --, needed a pool of stream pairs probed for real concurrency, and a special case inside stream captures.)
-// (NJ: 64-lane passes over the pdfs in the service wave, 2 for P + 1 <= 128, else 4)
+// (NJ: 64-lane passes over the pdfs in the service wave, 2 for P + 1 <= 128, 4 up to 250, 8 up to 506 -- the last with per-pdf
+// arrays of twice the size and a partner-row ring of two vectors instead of three: PairLay)
 // (SMALL: graphs of up to 127 states, whose service wave does a sixteenth of the copying and scanning)
 template <int NJ, int PHASE, bool SMALL>
 __global__ void __launch_bounds__(1024) mm_fbp_kernel(RunParams p) {
@@ -20,7 +21,7 @@ __global__ void __launch_bounds__(1024) mm_fbp_kernel(RunParams p) {
 }
 template <int NJ, int PHASE, bool SMALL>
 static int launch_pair_phase(const PairLaunch *h, const RunParams &p, hipStream_t st) {
-    const size_t lds = pair_lds_bytes(MM_ROW_RS, PHASE, h->slotrows);
+    const size_t lds = pair_lds_bytes(MM_ROW_RS, PHASE, h->slotrows, 0, pair_pc(NJ));
     if (lds > 160 * 1024) return mm_fail(MM_ERR_UNSUPPORTED, "pair kernel: LDS");
     auto kernel = mm_fbp_kernel<NJ, PHASE, SMALL>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
@@ -41,9 +42,13 @@ static int launch_pairs_ka(const PairLaunch *h, const RunParams &p, hipStream_t 
 int mm_launch_pairs(const PairLaunch &pl, const RunParams &p, hipStream_t s0) {
     if (pl.pair_ka > MM_PAIR_KA) return MM_ERR_UNSUPPORTED;
     if (pl.max_P1 <= 128) return pl.small ? launch_pairs_ka<2, true>(&pl, p, s0) : launch_pairs_ka<2, false>(&pl, p, s0);
-    return launch_pairs_ka<4, false>(&pl, p, s0);
+    if (pl.max_P1 <= 250) return launch_pairs_ka<4, false>(&pl, p, s0);
+    if (pl.max_P1 > MM_PAIR_P1MAX) return MM_ERR_UNSUPPORTED;
+    return launch_pairs_ka<8, false>(&pl, p, s0);
 }
-size_t mm_pair_lds_bytes(int phase, int nslotrows) { return pair_lds_bytes(MM_ROW_RS, phase, nslotrows); }
+size_t mm_pair_lds_bytes(int phase, int nslotrows, int max_P1) {
+    return pair_lds_bytes(MM_ROW_RS, phase, nslotrows, 0, pair_pc(mm_pair_nj(max_P1)));
+}
 size_t mm_pair_hand_bytes() { return sizeof(PairHand); }
 
 }  // namespace mm

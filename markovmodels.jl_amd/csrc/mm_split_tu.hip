@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(1024) mm_fbs_kernel(RunParams p) {
 }
 template <int NJ, int PHASE, int H>
 static int launch_split_phase(const PairLaunch *h, const RunParams &p, hipStream_t st) {
-    const size_t lds = pair_lds_bytes(SplitGeo<H>::RS, PHASE, h->slotrows, SplitGeo<H>::RSH);
+    const size_t lds = pair_lds_bytes(SplitGeo<H>::RS, PHASE, h->slotrows, SplitGeo<H>::RSH, pair_pc(NJ));
     if (lds > 160 * 1024) return mm_fail(MM_ERR_UNSUPPORTED, "split kernel: LDS");
     auto kernel = mm_fbs_kernel<NJ, PHASE, H>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
@@ -46,12 +46,15 @@ static int launch_split_nj(const PairLaunch *h, const RunParams &p, hipStream_t 
 }
 int mm_launch_split(const PairLaunch &pl, const RunParams &p, hipStream_t s0) {
     if (pl.pair_ka > MM_SPLIT_KA) return MM_ERR_UNSUPPORTED;
-    if (pl.H == 4) return pl.max_P1 <= 128 ? launch_split_nj<2, 4>(&pl, p, s0) : launch_split_nj<4, 4>(&pl, p, s0);
+    if (pl.max_P1 > MM_PAIR_P1MAX) return MM_ERR_UNSUPPORTED;
+    const int nj = mm_pair_nj(pl.max_P1);
+    if (pl.H == 4) return nj == 2 ? launch_split_nj<2, 4>(&pl, p, s0) : (nj == 4 ? launch_split_nj<4, 4>(&pl, p, s0) : launch_split_nj<8, 4>(&pl, p, s0));
     if (pl.H != 2) return mm_fail(MM_ERR_UNSUPPORTED, "split kernel: teams of 2 or 4");
-    return pl.max_P1 <= 128 ? launch_split_nj<2, 2>(&pl, p, s0) : launch_split_nj<4, 2>(&pl, p, s0);
+    return nj == 2 ? launch_split_nj<2, 2>(&pl, p, s0) : (nj == 4 ? launch_split_nj<4, 2>(&pl, p, s0) : launch_split_nj<8, 2>(&pl, p, s0));
 }
-size_t mm_split_lds_bytes(int H, int phase, int nslotrows) {
-    return H == 4 ? pair_lds_bytes(MM_SPLIT4_RS, phase, nslotrows, MM_SPLIT4_RSH) : pair_lds_bytes(MM_SPLIT_RS, phase, nslotrows, MM_SPLIT_RSH);
+size_t mm_split_lds_bytes(int H, int phase, int nslotrows, int max_P1) {
+    const int pc = pair_pc(mm_pair_nj(max_P1));
+    return H == 4 ? pair_lds_bytes(MM_SPLIT4_RS, phase, nslotrows, MM_SPLIT4_RSH, pc) : pair_lds_bytes(MM_SPLIT_RS, phase, nslotrows, MM_SPLIT_RSH, pc);
 }
 
 }  // namespace mm

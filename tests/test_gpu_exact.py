@@ -221,3 +221,21 @@ def test_lane_kernel(mm, wl, oracle, torch, which):
     assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()
     g2, t2 = bf.pdfposteriors(V, lens)  # deterministic: the same bits
     assert np.array_equal(gam, g2) and np.array_equal(ttl, t2, equal_nan=True)
+
+
+def test_float64_kernels_with_400_pdfs(mm, wl, oracle, torch):
+    """mm_fbd_kernel<8, ...>: the float64 pair kernels of graphs with 251 .. 506 pdfs (one utterance per workgroup, per-pdf LDS
+    arrays of twice the size, a partner-row ring of two vectors).  Sharp emissions, nothing behind the float64 kernels."""
+    g = wl.lfmmi_denominator(2000, 400, seed=11)
+    rng = np.random.default_rng(12)
+    B, N = 5, 90
+    lens = np.array([90, 90, 41, 1, 89], dtype=np.int32)
+    V = peaky(rng, (B, N, g.P), 10.0)
+    bf = make_batch(mm, wl, g, B, {"MM_NO_FALLBACK": "1", "MM_EXACT_FIRST": "1"})
+    assert "mm_fbd_kernel<8" in bf.kernels(), bf.kernels()
+    gam, ttl = bf.pdfposteriors(V, lens)
+    assert bf.last_exact_first() and bf.last_fallback_count() == 0
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    ok = np.isfinite(t_ref)
+    check_gamma(gam[ok], g_ref[ok], lens[ok])
+    assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-3)

@@ -317,6 +317,25 @@ def test_pair_kernels_with_many_pdfs(mm, wl, oracle, torch, P):
     assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("S,P", [(1200, 300), (2000, 400), (1500, 505)])
+def test_pair_kernels_with_251_to_506_pdfs(mm, wl, oracle, torch, S, P):
+    """P + 1 in 251..506: eight 64-lane passes over the pdfs (mm_fbp_kernel<8, ...>), per-pdf LDS arrays of twice the size and
+    a partner-row ring of TWO vectors (the row of a step is requested at the top of the step before, PairLay).  These graphs
+    ran on the quad kernels until round 4 (2000 states, 400 pdfs, B = 256, T = 1500: 8.8 ms).  The float32 kernels alone
+    against the float64 oracle; odd batch, lengths down to one frame."""
+    g = wl.lfmmi_denominator(S, P - (P % 2), seed=P)
+    rng = np.random.default_rng(P)
+    B, N = 5, 61
+    V = (1.3 * rng.standard_normal((B, N, g.P))).astype(np.float32)
+    lens = np.array([61, 61, 23, 60, 1], dtype=np.int32)
+    gam, ttl, kernels, redo = run_fast_alone(mm, wl, g, V, lens)
+    assert "mm_fbp_kernel<8" in kernels and "mm_fbd_kernel<8" in kernels and redo == 0, kernels
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    ok = np.isfinite(t_ref)
+    check_gamma(gam[ok], g_ref[ok], lens[ok])
+    assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-4)
+
+
 @pytest.mark.parametrize("S,deg", [(300, 2.0), (900, 12.0), (1500, 16.0), (1900, 16.5)])
 def test_row_kernel_register_windows(mm, wl, oracle, torch, S, deg):
     """Per-utterance graphs of different sizes land on the different register windows of the row kernels

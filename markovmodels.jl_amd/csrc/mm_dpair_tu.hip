@@ -34,8 +34,9 @@ static int launch_dpairs_nj(const PairLaunch *h, const RunParams &p, hipStream_t
 }
 // ---- teams of H workgroups per utterance and direction (the split kernels' graphs: mm_split_tu.hip)
 template <int H> struct DSplitGeo;
-template <> struct DSplitGeo<2> { static constexpr int RS = MM_SPLIT_RS, RSH = MM_SPLIT_RSH; };
-template <> struct DSplitGeo<4> { static constexpr int RS = MM_SPLIT4_RS, RSH = MM_SPLIT4_RSH; };
+template <> struct DSplitGeo<2> { static constexpr int RS = MM_SPLIT_RS, RSH = MM_SPLIT_RSH, KA = 36; };
+template <> struct DSplitGeo<4> { static constexpr int RS = MM_SPLIT4_RS, RSH = MM_SPLIT4_RSH, KA = 36; };
+template <> struct DSplitGeo<8> { static constexpr int RS = MM_SPLIT8_RS, RSH = MM_SPLIT8_RSH, KA = 36; };
 template <int NJ, int PHASE, int H>
 __global__ void __launch_bounds__(1024) mm_fbds_kernel(RunParams p) {
     const int half = (int)gridDim.x / 2, dir = (int)blockIdx.x >= half;
@@ -43,7 +44,7 @@ __global__ void __launch_bounds__(1024) mm_fbds_kernel(RunParams p) {
     const int ui = (blk / (8 * H)) * 8 + (blk & 7), hset = (blk >> 3) % H;  // (the workgroups of a team are 8 apart: mm_split_tu.hip)
     if (ui >= p.B) return;
     if ((p.x_sleep & 0x400) && hset == 1) return;  // (test aid: a team mate that never shows up)
-    dpair_agent<MM_SPLIT_KA, DSplitGeo<H>::RS, PHASE, NJ, H, DSplitGeo<H>::RSH>(p, ui, dir, hset);
+    dpair_agent<DSplitGeo<H>::KA, DSplitGeo<H>::RS, PHASE, NJ, H, DSplitGeo<H>::RSH>(p, ui, dir, hset);
 }
 template <int NJ, int PHASE, int H>
 static int launch_dsplit_phase(const PairLaunch *h, const RunParams &p, hipStream_t st) {
@@ -65,15 +66,16 @@ static int launch_dsplit_nj(const PairLaunch *h, const RunParams &p, hipStream_t
     return MM_OK;
 }
 int mm_launch_dpairs(const PairLaunch &pl, const RunParams &p, hipStream_t s0) {
-    if (pl.max_P1 > MM_PAIR_P1MAX) return MM_ERR_UNSUPPORTED;
-    const int nj = mm_pair_nj(pl.max_P1);
+    const int nj = mm_pair_nj(pl.max_P1, pl.H);
+    if (nj == 0) return MM_ERR_UNSUPPORTED;
     if (pl.H == 1) {
         if (pl.pair_ka > MM_PAIR_KA) return MM_ERR_UNSUPPORTED;
         return nj == 2 ? launch_dpairs_nj<2>(&pl, p, s0) : (nj == 4 ? launch_dpairs_nj<4>(&pl, p, s0) : launch_dpairs_nj<8>(&pl, p, s0));
     }
-    if (pl.pair_ka > MM_SPLIT_KA) return MM_ERR_UNSUPPORTED;
+    if (pl.pair_ka > mm_split_ka(pl.H)) return MM_ERR_UNSUPPORTED;
+    if (pl.H == 8) return nj == 2 ? launch_dsplit_nj<2, 8>(&pl, p, s0) : (nj == 4 ? launch_dsplit_nj<4, 8>(&pl, p, s0) : launch_dsplit_nj<5, 8>(&pl, p, s0));
     if (pl.H == 4) return nj == 2 ? launch_dsplit_nj<2, 4>(&pl, p, s0) : (nj == 4 ? launch_dsplit_nj<4, 4>(&pl, p, s0) : launch_dsplit_nj<8, 4>(&pl, p, s0));
-    if (pl.H != 2) return mm_fail(MM_ERR_UNSUPPORTED, "exact split kernel: teams of 2 or 4");
+    if (pl.H != 2) return mm_fail(MM_ERR_UNSUPPORTED, "exact split kernel: teams of 2, 4 or 8");
     return nj == 2 ? launch_dsplit_nj<2, 2>(&pl, p, s0) : (nj == 4 ? launch_dsplit_nj<4, 2>(&pl, p, s0) : launch_dsplit_nj<8, 2>(&pl, p, s0));
 }
 

@@ -149,7 +149,7 @@ struct mm_fsm_s {
     bool pairs_tried = false;
     RowVariant *prows[2] = {nullptr, nullptr};  // ... and their pair variants (mm_kernel_pairs.hip)
     // split pair forms (mm_rows.h make_rows_split): [direction][set], for FSMs beyond the registers / LDS of one compute unit
-    RowVariant *srows[2][MM_SPLIT_HMAX] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+    RowVariant *srows[2][MM_SPLIT_HMAX] = {};
     SplitInfo split;
     int split_tried = 0;  // bit H: the split forms for teams of H have been tried
     RowVariant *wrows[2] = {nullptr, nullptr};  // wave forms (mm_kernel_wave.hip)
@@ -873,13 +873,13 @@ static int upload_row_variant(mm_fsm_t f, RowVariant *v, int dir, float thr, boo
 // options of the split pair forms (mm_rows.h make_rows_split; the kernels: mm_kernel_pairs.hip with H > 1)
 static void split_pack_opts(const DebugOpts &dbg, RowPackOpts &opt, RowPackOpts &optb, int H = 2) {
     opt = RowPackOpts();
-    opt.rs = H == 4 ? MM_SPLIT4_RS : MM_SPLIT_RS;
-    opt.ka_max = MM_SPLIT_KA;
+    opt.rs = mm_split_rs(H);
+    opt.ka_max = mm_split_ka(H);
     opt.nwc_max = MM_SPLIT_NWC;
     opt.pair = true;
     for (float &x : opt.group_speed) x = 1.f;
     if (dbg.finish_cost > 0) opt.finish_cost = dbg.finish_cost;
-    opt.ka_choices[0] = MM_SPLIT_KA;
+    opt.ka_choices[0] = mm_split_ka(H);
     optb = opt;
     if (dbg.finish_cost <= 0) optb.finish_cost = 24;
 }
@@ -1194,19 +1194,24 @@ static int split_variants(mm_fsm_t f, const DebugOpts &dbg, int H, bool *ok) {
     *ok = f->split.H == H && f->srows[0][0] != nullptr;
     if (*ok || f->srows[0][0] != nullptr || (f->split_tried >> H) & 1) return MM_OK;  // (one team size per FSM: the first that fits)
     f->split_tried |= 1 << H;
-    if (f->semiring != MM_LOG || !f->fast_ok || f->P1 > MM_PAIR_P1MAX || H > MM_SPLIT_HMAX) return MM_OK;
+    if (f->semiring != MM_LOG || !f->fast_ok || mm_pair_nj(f->P1, H) == 0 || H > MM_SPLIT_HMAX) return MM_OK;
     RowPackOpts opt, optb;
     split_pack_opts(dbg, opt, optb, H);
     std::vector<RowGraph> gs;
     SplitInfo info;
     if (!make_rows_split(H, f->S1, f->qmat[0].rowptr, f->qmat[0].col, f->qmat[0].val, f->qmat[1].rowptr, f->qmat[1].col,
-                         f->qmat[1].val, f->s2p, f->P1, opt, optb, gs, info))
+                         f->qmat[1].val, f->s2p, f->P1, opt, optb, gs, info)) {
+        if (dbg.verbose) fprintf(stderr, "[mm] split forms for teams of %d: the graph does not fit them\n", H);
         return MM_OK;
+    }
     float wmin = 0.f;
     for (const RowGraph &g : gs) wmin = std::min(wmin, g.wmin_log2);
     if (wmin < -60.f) return MM_OK;  // (as for the row forms: too little of the float range would be left to the values)
     for (int h = 0; h < H; ++h)
-        if (size_t(info.count[h] + 1) * 8 > size_t(H == 4 ? MM_SPLIT4_RSH : MM_SPLIT_RSH)) return MM_OK;
+        if (size_t(info.count[h] + 1) * 8 > size_t(mm_split_rsh(H))) {
+            if (dbg.verbose) fprintf(stderr, "[mm] split forms for teams of %d: set %d has %d rows\n", H, h, info.count[h]);
+            return MM_OK;
+        }
     const float NINF = -std::numeric_limits<float>::infinity();
     int rc = MM_OK;
     for (int d = 0; d < 2 && !rc; ++d) {
@@ -1889,8 +1894,10 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         if (same) {
             bool ok = false;
             int rc = split_variants(fsms[0], h->dbg, 2, &ok);
-            // (a graph beyond the teams of 2 -- more than 3070 states or 2 x 14 x 64 x 36 arcs: teams of 4)
+            // (a graph beyond the teams of 2 -- more than 3070 states or 2 x 14 x 64 x 36 arcs: teams of 4; beyond those -- more
+            // than 4094 states: teams of 8, up to 6014 states and 314 pdfs)
             if (!rc && !ok) rc = split_variants(fsms[0], h->dbg, 4, &ok);
+            if (!rc && !ok) rc = split_variants(fsms[0], h->dbg, 8, &ok);
             if (rc) return rc;
             if (ok) {
                 const mm_fsm_t f0 = fsms[0];
@@ -1905,8 +1912,9 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
                         h->pair_slotrows = std::max(h->pair_slotrows, f0->srows[d][s]->g.nslotrows);
                     }
                 h->split_s1p = (f0->split.total + 2 + 3) & ~3;
-                h->pairs_ok = h->pair_ka <= MM_SPLIT_KA && h->pair_nwc <= MM_SPLIT_NWC &&
-                              mm_split_lds_bytes(h->pair_H, 1, h->pair_slotrows, h->max_P1) <= 160 * 1024;
+                const size_t lds = mm_split_lds_bytes(h->pair_H, 1, h->pair_slotrows, h->max_P1);
+                h->pairs_ok = h->pair_ka <= mm_split_ka(h->pair_H) && h->pair_nwc <= MM_SPLIT_NWC && lds > 0 && lds <= 160 * 1024;
+                if (h->dbg.verbose) fprintf(stderr, "[mm] teams of %d: LDS %zu bytes in phase B\n", h->pair_H, lds);
                 if (!h->pairs_ok) h->pair_H = 1;
             }
         }
@@ -2151,7 +2159,7 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
             s = "mm_wave_kernel<" + std::to_string(h->wave_nseg <= 2 ? 2 : 4) + "," + std::to_string(h->max_P1 <= 128 ? 2 : 4) +
                 (h->wave_nseg <= 2 && h->B > h->n_cus ? ",two per CU>" : ">");
         } else if (h->pairs_ok && h->pair_H > 1) {
-            const std::string k = std::to_string(mm_pair_nj(h->max_P1)), H = std::to_string(h->pair_H);
+            const std::string k = std::to_string(mm_pair_nj(h->max_P1, h->pair_H)), H = std::to_string(h->pair_H);
             s = "mm_fbs_kernel<" + k + ",A," + H + ">, then <" + k + ",B," + H + "> (forward and backward agents in one grid, teams of " + H +
                 " workgroups), mm_pair_finish_kernel, then for marked utterances only " +
                 (h->dpair_ok ? "mm_fbds_kernel<" + k + ",A," + H + ">, then <" + k + ",B," + H + "> (float64, one utterance per team; FIRST and "
@@ -2200,14 +2208,14 @@ static size_t ws_x_rows_bytes(mm_batch_t h) {
     return h->pair_H > 1 ? size_t(2) * size_t((h->B + 1) / 2) * 2 * size_t(h->pair_H) * 2 * (2 * size_t(h->split_s1p)) * 4 : 0;
 }
 static size_t ws_x_bytes(mm_batch_t h) {
-    return h->pair_H > 1 ? align_up(ws_x_rows_bytes(h) + size_t((h->B + 1) / 2) * 2 * size_t(h->pair_H) * 4 * size_t(mm_pair_xps(h->max_P1)) * 4, 256) : 0;
+    return h->pair_H > 1 ? align_up(ws_x_rows_bytes(h) + size_t((h->B + 1) / 2) * 2 * size_t(h->pair_H) * 4 * size_t(mm_pair_xps(h->max_P1, h->pair_H)) * 4, 256) : 0;
 }
 // ... and for the teams of the float64 kernels (one utterance per team: B "pairs")
 static size_t ws_xd_rows_bytes(mm_batch_t h) {
     return h->pair_H > 1 && h->dpair_ok ? size_t(2) * size_t(h->B) * 2 * size_t(h->pair_H) * 2 * (2 * size_t(h->split_s1p)) * 4 : 0;
 }
 static size_t ws_xd_bytes(mm_batch_t h) {
-    return h->pair_H > 1 && h->dpair_ok ? align_up(ws_xd_rows_bytes(h) + size_t(h->B) * 2 * size_t(h->pair_H) * 4 * size_t(mm_pair_xps(h->max_P1)) * 4, 256) : 0;
+    return h->pair_H > 1 && h->dpair_ok ? align_up(ws_xd_rows_bytes(h) + size_t(h->B) * 2 * size_t(h->pair_H) * 4 * size_t(mm_pair_xps(h->max_P1, h->pair_H)) * 4, 256) : 0;
 }
 static size_t ws_tail_bytes(mm_batch_t h) {  // longest-first order, redo marks, pair hand-over, per-direction log Z minima, team buffers
     return 2 * align_up(size_t(h->B + 1) * 4, 256) + align_up(size_t(h->B + 1) * 2 * mm_pair_hand_bytes(), 256) +
@@ -2377,7 +2385,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
                 p.xbuf = reinterpret_cast<float *>(reinterpret_cast<char *>(p.pair_zmin) + align_up(size_t(h->B) * 6 * 8, 256));
                 p.xps = reinterpret_cast<float *>(reinterpret_cast<char *>(p.xbuf) + ws_x_rows_bytes(h));
                 p.x_slot = 2ll * h->split_s1p;
-                p.x_psn = mm_pair_xps(h->max_P1);
+                p.x_psn = mm_pair_xps(h->max_P1, h->pair_H);
                 p.x_phase = (long long)(ws_x_rows_bytes(h) / 8);
                 p.x_sleep = h->dbg.x_sleep;
                 p.xbuf_d = reinterpret_cast<float *>(reinterpret_cast<char *>(p.xbuf) + ws_x_bytes(h));

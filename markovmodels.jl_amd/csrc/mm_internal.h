@@ -30,8 +30,9 @@ int mm_fail(int code, const std::string &msg);
 // pdfs (+ 1) of the pair / split pair / float64 pair kernels: passes of 64 lanes of their service waves (the NJ of the instances),
 // and the floats of one slot of per-pdf partial sums a team publishes (PairLay::XPS, mm_kernel_pairs.hip)
 #define MM_PAIR_P1MAX 506
-inline int mm_pair_nj(int P1) { return P1 <= 128 ? 2 : (P1 <= 250 ? 4 : 8); }
-inline int mm_pair_xps(int P1) { return P1 <= 250 ? 512 : 1024; }
+// (teams of 8 have no LDS for the arrays of 512 pdfs: 5 passes, 314 pdfs)
+inline int mm_pair_nj(int P1, int H = 1) { return P1 <= 128 ? 2 : (P1 <= 250 ? 4 : (H == 8 ? (P1 <= 314 ? 5 : 0) : (P1 <= MM_PAIR_P1MAX ? 8 : 0))); }
+inline int mm_pair_xps(int P1, int H = 1) { const int nj = mm_pair_nj(P1, H); return nj <= 4 ? 512 : 128 * nj; }
 // split pair kernels (teams of H workgroups per utterance pair and direction): bytes of half a pair vector, arc slots per
 // lane, compute waves (+ a service wave and an exchange wave)
 #define MM_SPLIT_RS 12288
@@ -40,6 +41,13 @@ inline int mm_pair_xps(int P1) { return P1 <= 250 ? 512 : 1024; }
 // teams of 4: the team's vector of pairs is 32 KB (up to 4094 states), a workgroup finishes a quarter of the rows
 #define MM_SPLIT4_RS 16384
 #define MM_SPLIT4_RSH 9216
+// teams of 8: 47.5 KB (up to ~6050 states), an eighth of the rows each (a multiple of 1 KB: the partner rows come in 1 KB DMAs);
+// what the LDS of a compute unit holds next to two such vectors
+#define MM_SPLIT8_RS 24320
+#define MM_SPLIT8_RSH 6144
+inline int mm_split_rs(int H) { return H == 8 ? MM_SPLIT8_RS : (H == 4 ? MM_SPLIT4_RS : MM_SPLIT_RS); }
+inline int mm_split_ka(int H) { return H == 8 ? 36 : 36; }  // arc slots per lane (teams of 8: fewer arcs per workgroup, and more registers to the exchange)
+inline int mm_split_rsh(int H) { return H == 8 ? MM_SPLIT8_RSH : (H == 4 ? MM_SPLIT4_RSH : MM_SPLIT_RSH); }
 #define MM_SPLIT_KA 36
 #define MM_SPLIT_NWC 14
 
@@ -83,7 +91,7 @@ size_t mm_pair_hand_bytes();
 int mm_launch_dpairs(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
 // ---- split pair kernels (mm_split_tu.hip): teams of pl.H workgroups
 int mm_launch_split(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
-size_t mm_split_lds_bytes(int H, int phase, int nslotrows, int max_P1);
+size_t mm_split_lds_bytes(int H, int phase, int nslotrows, int max_P1);  // (0: no instance for that many pdfs)
 
 
 // ---- wave kernel (mm_wave_tu.hip)

@@ -147,35 +147,49 @@ __device__ __forceinline__ float dpair_finish_frame(unsigned psum, int P1, int P
         s[j] = ldsr_d(psum + 8u * (q < P1 ? q : 0));
     }
     if constexpr (H > 1) {
+        // (the other sets' parts requested together, four sets at a time, before the first is looked at: pair_finish_frames)
+        constexpr int GB = H < 4 ? H : 4;
         double tot[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) tot[j] = 0.0;
-        for (int g = 0; g < H; ++g) {
-            if (xp[g] == nullptr) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) tot[j] += s[j];
-                continue;
-            }
-            mm_u64 v[NJ];
+        for (int g0 = 0; g0 < H; g0 += GB) {
+            mm_u64 v[GB][NJ];
             const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
             for (;;) {
                 bool ok = true;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int q = lane + 64 * j;
-                    v[j] = granule_load(xp[g], 8u * (unsigned)(q < P1 ? q : 0));
+                for (int g = 0; g < GB; ++g) {
+                    if (xp[g0 + g] == nullptr) continue;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int q = lane + 64 * j;
+                        v[g][j] = granule_load(xp[g0 + g], 8u * (unsigned)(q < P1 ? q : 0));
+                    }
                 }
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) ok = ok && ((unsigned)(v[j] >> 63) == tag);
+                for (int g = 0; g < GB; ++g) {
+                    if (xp[g0 + g] == nullptr) continue;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) ok = ok && ((unsigned)(v[g][j] >> 63) == tag);
+                }
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                if (__builtin_amdgcn_s_memrealtime() - tstart >= tmo) {
+                if (!*arrived || __builtin_amdgcn_s_memrealtime() - tstart >= tmo) {
                     *arrived = false;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) tot[j] += __builtin_bit_cast(double, v[j] & 0x7fffffffffffffffull);
+            for (int g = 0; g < GB; ++g) {
+                if (xp[g0 + g] == nullptr) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) tot[j] += s[j];
+                    continue;
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) tot[j] += __builtin_bit_cast(double, v[g][j] & 0x7fffffffffffffffull);
+            }
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) s[j] = tot[j];
@@ -427,7 +441,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             const unsigned dst = L::AL(0) + (unsigned)(tt % L::NR) * (unsigned)RSH;
             (void)n4;
             dma_row_b128<NDM>(uni(src), (unsigned)sl, dst);  // (no clamping: see pair_agent)
-            dma_b32(reinterpret_cast<const unsigned *>(offs + f) + (sl & 1), L::POFF(0, 0) + 512u * (t & 7));
+            dma_b32(reinterpret_cast<const unsigned *>(offs + f) + (sl & 1), L::POFF(0, 0) + 512u * (unsigned)(t & (L::POFFN - 1)));
         };
         constexpr int NDMA = NJ + (PHASE ? NDM + 1 : 0);  // DMAs issued per step
         // stage the emissions of step t into EM(t & 1) and account its offset; S = the normaliser the step subtracts
@@ -474,7 +488,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             const float lt = dpair_finish_frame<NJ>(psum, P1, P, sl, p.gamma + (long long)b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp, live);
             if (live) {
                 const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN(ts & 3));
-                const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, 0) + 512u * (ts & 7));
+                const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, 0) + 512u * (unsigned)(ts & (L::POFFN - 1)));
                 const double z = (double)lt + own + oth;
                 zmin = z < zmin ? z : zmin;
                 zmax = z > zmax ? z : zmax;  // (NaN: neither comparison holds; the finish kernel tests zmin <= zmax)
@@ -590,7 +604,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             }
             if (live) {
                 const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN(ts & 3));
-                const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, 0) + 512u * (ts & 7));
+                const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, 0) + 512u * (unsigned)(ts & (L::POFFN - 1)));
                 const double z = (double)lt + own + oth;
                 xzmin = z < xzmin ? z : xzmin;
                 xzmax = z > xzmax ? z : xzmax;
@@ -737,7 +751,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                 const unsigned tg = split_tag(t, t0, 1);
                 for (int i = wave; i < I; i += NWC) {
                     const int q = i / NG2, j = i % NG2, g = q < hset ? q : q + 1;
-                    const float *src = xrecv[g] + (long long)(t & 1) * p.x_slot;
+                    const float *src = uni(xrecv[g] + (long long)(t & 1) * p.x_slot);
                     const int ng = p.sp_cnt[g];
                     const unsigned dsta = L::PP(WR) + 8u * (unsigned)p.sp_base[g] + 16u * (unsigned)(lane + 64 * j);
                     const bool have = 2 * (lane + 64 * j) < ng, second = 2 * (lane + 64 * j) + 1 < ng;

@@ -46,12 +46,14 @@ __device__ __forceinline__ void ldsw2(unsigned addr, float a, float b) {
 // PC = the pdf capacity of the per-pdf arrays: 256, or 512 for the instances of more than 4 passes of 64 lanes over the pdfs
 // (NJ > 4: graphs of 251 .. 506 pdfs).  Those pay for their arrays with the partner-row ring: NR = 2 vectors instead of 3
 // -- a partner row is requested at the top of the step before the one that combines it, not two steps ahead.
-constexpr int pair_pc(int NJ) { return NJ > 4 ? 512 : 256; }
+constexpr int pair_pc(int NJ) { return NJ > 4 ? 64 * NJ : 256; }
+// (teams of 8: the team's vector of pairs is 48 KB, twice: a ring of two partner vectors there as well)
+constexpr int pair_nr(int RS, int PC) { return (PC > 256 || RS > 16384) ? 2 : 3; }
 template <int RS, int PHASE, int RSH = 2 * RS, int PC = 256>
 struct PairLay {
     static constexpr unsigned RS2 = 2 * RS;
     static constexpr unsigned PC4 = 4u * PC, PC8 = 8u * PC;
-    static constexpr int NR = PC > 256 ? 2 : 3;      // vectors of the partner-row ring
+    static constexpr int NR = pair_nr(RS, PC);       // vectors of the partner-row ring
     static constexpr unsigned RAWS = 2u * PC4;       // bytes of one ring entry of the raw emissions (both utterances)
     static constexpr unsigned XPS = 2u * PC;         // (teams) floats of one slot of published per-pdf partial sums
     static constexpr unsigned PP(int par) { return unsigned(par) * RS2; }                          // p pairs [pos][2]
@@ -60,17 +62,21 @@ struct PairLay {
     static constexpr unsigned MS(int par) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + unsigned(par) * 64u; }      // {S_0, S_1} of a step
     static constexpr unsigned OWN(int k) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + 128u + unsigned(k) * 16u; }  // own offsets, k < 4: 2 doubles
     static constexpr unsigned XFLAG = 2 * RS2 + 8u * PC4 + 2u * PC8 + 192u;  // split kernels: != 0 when the whole team runs on one XCD
-    static constexpr unsigned POFF(int k, int u) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + 256u + unsigned(2 * k + u) * 256u; }  // partner offsets, k < 8
-    static constexpr unsigned PSUM(int par) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + 256u + 4096u + unsigned(par) * PC8; }   // [pdf][2]
-    static constexpr unsigned PDFSE = 2 * RS2 + 8u * PC4 + 4u * PC8 + 256u + 4096u;                // u16 [2 * P1]
+    // partner offsets, k < POFFN: requested with the partner row (two steps ahead, one with a ring of two rows), read when the
+    // posteriors of the step are put out, two steps behind
+    static constexpr int POFFN = NR == 2 ? 4 : 8;
+    static constexpr unsigned POFFB = 512u * POFFN;
+    static constexpr unsigned POFF(int k, int u) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + 256u + unsigned(2 * k + u) * 256u; }
+    static constexpr unsigned PSUM(int par) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + 256u + POFFB + unsigned(par) * PC8; }   // [pdf][2]
+    static constexpr unsigned PDFSE = 2 * RS2 + 8u * PC4 + 4u * PC8 + 256u + POFFB;                // u16 [2 * P1]
     static constexpr unsigned FIX = PDFSE + PC4;
     static constexpr unsigned AL(int k) { return FIX + unsigned(k) * RSH; }                        // partner rows (phase B), k < NR
     static constexpr unsigned Q(int par) { return FIX + unsigned(NR) * RSH + unsigned(par) * RSH; }  // q pairs [qpos][2] (phase B)
     static constexpr unsigned SLOTS = PHASE ? FIX + unsigned(NR + 2) * RSH : FIX;
 };
 inline size_t pair_lds_bytes(int RS, int phase, int nslotrows, int RSH = 0, int PC = 256) {
-    const size_t fix = size_t(4 * RS) + size_t(8 * 4 * PC) + size_t(4 * 8 * PC) + 256 + 4096 + size_t(4 * PC);
-    return fix + (phase ? size_t(PC > 256 ? 4 : 5) * size_t(RSH ? RSH : 2 * RS) : 0) + size_t(nslotrows) * 64 * 8;
+    const size_t fix = size_t(4 * RS) + size_t(8 * 4 * PC) + size_t(4 * 8 * PC) + 256 + (pair_nr(RS, PC) == 2 ? 2048 : 4096) + size_t(4 * PC);
+    return fix + (phase ? size_t(pair_nr(RS, PC) + 2) * size_t(RSH ? RSH : 2 * RS) : 0) + size_t(nslotrows) * 64 * 8;
 }
 
 // ---- split kernels (H > 1): a TEAM of H workgroups computes one direction of an utterance pair; workgroup h finishes the
@@ -317,37 +323,53 @@ __device__ __forceinline__ bool pair_finish_frames(unsigned psum, int P1, int P,
         s[j] = ldsr2(psum + 8u * (q < P1 ? q : 0));
     }
     if constexpr (H > 1) {
+        // the other sets' partial sums: requested together, four sets at a time, before the first is looked at (one memory round
+        // trip per frame for teams of up to 4, two for teams of 8 -- not one per set; all seven sets of a team of 8 at once do
+        // not fit the registers), summed in the order of the sets -- the same bits in every workgroup
+        constexpr int GB = H < 4 ? H : 4;
         mm_f32x2 tot[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) tot[j] = mm_f32x2{0.f, 0.f};
-        for (int g = 0; g < H; ++g) {
-            if (xp[g] == nullptr) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) tot[j] += s[j];
-                continue;
-            }
-            mm_u64 v[NJ];
+        for (int g0 = 0; g0 < H; g0 += GB) {
+            mm_u64 v[GB][NJ];
             const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
             for (;;) {
                 bool ok = true;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int q = lane + 64 * j;
-                    v[j] = granule_load(xp[g], 8u * (unsigned)(q < P1 ? q : 0));
+                for (int g = 0; g < GB; ++g) {
+                    if (xp[g0 + g] == nullptr) continue;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int q = lane + 64 * j;
+                        v[g][j] = granule_load(xp[g0 + g], 8u * (unsigned)(q < P1 ? q : 0));
+                    }
                 }
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) ok = ok && ((unsigned)(v[j] >> 31) % 2u == tag);
+                for (int g = 0; g < GB; ++g) {
+                    if (xp[g0 + g] == nullptr) continue;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) ok = ok && ((unsigned)(v[g][j] >> 31) % 2u == tag);
+                }
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                if (__builtin_amdgcn_s_memrealtime() - tstart >= tmo) {
+                if (!arrived || __builtin_amdgcn_s_memrealtime() - tstart >= tmo) {
                     arrived = false;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                tot[j].x += __builtin_bit_cast(float, (unsigned)v[j] & 0x7fffffffu);
-                tot[j].y += __builtin_bit_cast(float, (unsigned)(v[j] >> 32) & 0x7fffffffu);
+            for (int g = 0; g < GB; ++g) {
+                if (xp[g0 + g] == nullptr) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) tot[j] += s[j];
+                    continue;
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    tot[j].x += __builtin_bit_cast(float, (unsigned)v[g][j] & 0x7fffffffu);
+                    tot[j].y += __builtin_bit_cast(float, (unsigned)(v[g][j] >> 32) & 0x7fffffffu);
+                }
             }
         }
 #pragma unroll
@@ -705,7 +727,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u)
-                dma_b32(reinterpret_cast<const unsigned *>(U[u].offs + f) + (sl & 1), L::POFF(0, u) + 512u * (t & 7));
+                dma_b32(reinterpret_cast<const unsigned *>(U[u].offs + f) + (sl & 1), L::POFF(0, u) + 512u * (unsigned)(t & (L::POFFN - 1)));
         };
         constexpr int NDMA = 2 * NJ + (PHASE ? RSH / 1024 + 2 : 0);  // DMAs issued per step (a lower bound of the VMEM operations)
         constexpr int NDMA_SMALL = 2 * NJ + (PHASE ? 1 + 2 : 0);     // ... of a small graph (see dma_partner)
@@ -788,7 +810,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             for (int u = 0; u < 2; ++u)
                 if (u ? live1 : live0) {
                     const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN(ts & 3) + 8u * u);
-                    const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 512u * (ts & 7));
+                    const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 512u * (unsigned)(ts & (L::POFFN - 1)));
                     const double z = (double)lt[u] + own + oth;
                     zmin[u] = z < zmin[u] ? z : zmin[u];
                     zmax[u] = z > zmax[u] ? z : zmax[u];  // (NaN: neither comparison holds; the finish kernel tests zmin <= zmax)
@@ -947,7 +969,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             for (int u = 0; u < 2; ++u)
                 if (u ? live1 : live0) {
                     const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN(ts & 3) + 8u * u);
-                    const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 512u * (ts & 7));
+                    const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 512u * (unsigned)(ts & (L::POFFN - 1)));
                     const double z = (double)lt[u] + own + oth;
                     xzmin[u] = z < xzmin[u] ? z : xzmin[u];
                     xzmax[u] = z > xzmax[u] ? z : xzmax[u];
@@ -959,7 +981,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
 #define MM_SPLIT_CWPOLL 1
 #endif
         for (int t = t0 + 1; t <= t1; ++t) {
-            if (!dead && !MM_SPLIT_CWPOLL) {
+            if constexpr (!MM_SPLIT_CWPOLL) if (!dead) {
                 // (teams of 2 as well: the chunks of the other set checked and written as they return instead of all loaded, all
                 // awaited, all written -- 2.73 -> 2.30 ms on the reference's WSJ denominator.  Loads in flight, measured on that
                 // graph / on a 4000-state graph with teams of 4: 2: 2.52 / 7.03 ms, 3: 2.29 / 6.00, 4: 2.29 / 5.77, 5: 2.30 / 5.48,
@@ -1181,44 +1203,63 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 const unsigned tg = split_tag(t, t0, 1);
                 if constexpr (H > 2) {
                     // (teams of 4: 27 chunks on 14 waves -- a wave's two chunks are polled together, both loads in flight: one
-                    // after the other, the second cost another round trip behind the first)
-                    static_assert(2 * 14 >= I, "two items per wave");
-                    const float *srcs[2];
-                    unsigned offs2[2], dst2[2];
-                    bool pnd[2], sec[2];
+                    // after the other, the second cost another round trip behind the first; teams of 8: 49 chunks, four per wave)
+                    constexpr int NI = (I + 13) / 14;
+                    static_assert(NI >= 2 && NI <= 4, "items per wave");
+                    const float *srcs[NI];
+                    unsigned offs2[NI], dst2[NI];
+                    bool pnd[NI], sec[NI], any = false;
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
+                    for (int e = 0; e < NI; ++e) {
                         const int i = wave + e * NWC, ic = i < I ? i : 0;
                         const int q = ic / NG2, j = ic % NG2, g = q < hset ? q : q + 1;
-                        srcs[e] = xrecv[g] + (long long)(t & 1) * p.x_slot;
+                        srcs[e] = uni(xrecv[g] + (long long)(t & 1) * p.x_slot);
                         const int ng = p.sp_cnt[g];
                         dst2[e] = L::PP(WR) + 8u * (unsigned)p.sp_base[g] + 16u * (unsigned)(lane + 64 * j);
                         pnd[e] = i < I && 2 * (lane + 64 * j) < ng;
                         sec[e] = 2 * (lane + 64 * j) + 1 < ng;
                         offs2[e] = pnd[e] ? 16u * (unsigned)(lane + 64 * j) : 0u;
+                        any = any || pnd[e];
                     }
-                    if (!cdead && __builtin_amdgcn_ballot_w64(pnd[0] || pnd[1]) != 0ull) {
+                    if (!cdead && __builtin_amdgcn_ballot_w64(any) != 0ull) {
                         const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
                         for (;;) {
-                            mm_u32x4 v0, v1;
-                            asm volatile("global_load_dwordx4 %0, %2, %3 sc1\n\tglobal_load_dwordx4 %1, %4, %5 sc1\n\ts_waitcnt vmcnt(0)"
-                                         : "=&v"(v0), "=&v"(v1)
-                                         : "v"(offs2[0]), "s"(srcs[0]), "v"(offs2[1]), "s"(srcs[1])
-                                         : "memory");
+                            // (the loads of a poll and their wait in ONE asm block: the compiler may copy a register an
+                            // asynchronous load has not filled yet)
+                            mm_u32x4 v[NI];
+                            if constexpr (NI == 2)
+                                asm volatile("global_load_dwordx4 %0, %2, %3 sc1\n\tglobal_load_dwordx4 %1, %4, %5 sc1\n\ts_waitcnt vmcnt(0)"
+                                             : "=&v"(v[0]), "=&v"(v[1])
+                                             : "v"(offs2[0]), "s"(srcs[0]), "v"(offs2[1]), "s"(srcs[1])
+                                             : "memory");
+                            else if constexpr (NI == 3)
+                                asm volatile("global_load_dwordx4 %0, %3, %4 sc1\n\tglobal_load_dwordx4 %1, %5, %6 sc1\n\t"
+                                             "global_load_dwordx4 %2, %7, %8 sc1\n\ts_waitcnt vmcnt(0)"
+                                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
+                                             : "v"(offs2[0]), "s"(srcs[0]), "v"(offs2[1]), "s"(srcs[1]), "v"(offs2[2]), "s"(srcs[2])
+                                             : "memory");
+                            else
+                                asm volatile("global_load_dwordx4 %0, %4, %5 sc1\n\tglobal_load_dwordx4 %1, %6, %7 sc1\n\t"
+                                             "global_load_dwordx4 %2, %8, %9 sc1\n\tglobal_load_dwordx4 %3, %10, %11 sc1\n\ts_waitcnt vmcnt(0)"
+                                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                                             : "v"(offs2[0]), "s"(srcs[0]), "v"(offs2[1]), "s"(srcs[1]), "v"(offs2[2]), "s"(srcs[2]), "v"(offs2[3]),
+                                               "s"(srcs[3])
+                                             : "memory");
+                            any = false;
 #pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                const mm_u32x4 v = e ? v1 : v0;
-                                if (pnd[e] && (v.x >> 31) == tg && (!sec[e] || (v.z >> 31) == tg)) {
+                            for (int e = 0; e < NI; ++e) {
+                                if (pnd[e] && (v[e].x >> 31) == tg && (!sec[e] || (v[e].z >> 31) == tg)) {
                                     mm_f32x4 w;
-                                    w.x = __builtin_bit_cast(float, v.x & 0x7fffffffu);
-                                    w.y = __builtin_bit_cast(float, v.y & 0x7fffffffu);
-                                    w.z = sec[e] ? __builtin_bit_cast(float, v.z & 0x7fffffffu) : 0.f;
-                                    w.w = sec[e] ? __builtin_bit_cast(float, v.w & 0x7fffffffu) : 0.f;
+                                    w.x = __builtin_bit_cast(float, v[e].x & 0x7fffffffu);
+                                    w.y = __builtin_bit_cast(float, v[e].y & 0x7fffffffu);
+                                    w.z = sec[e] ? __builtin_bit_cast(float, v[e].z & 0x7fffffffu) : 0.f;
+                                    w.w = sec[e] ? __builtin_bit_cast(float, v[e].w & 0x7fffffffu) : 0.f;
                                     *(__attribute__((address_space(3))) mm_f32x4 *)(__UINTPTR_TYPE__)dst2[e] = w;
                                     pnd[e] = false;
                                 }
+                                any = any || pnd[e];
                             }
-                            if (__builtin_amdgcn_ballot_w64(pnd[0] || pnd[1]) == 0ull) break;
+                            if (__builtin_amdgcn_ballot_w64(any) == 0ull) break;
                             if (__builtin_amdgcn_s_memrealtime() - tstart > x_tmo) {
                                 cdead = true;
                                 if (lane == 0) {

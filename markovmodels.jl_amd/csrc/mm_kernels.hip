@@ -33,7 +33,7 @@ namespace mm {
 #define MM_LOG2E 1.4426950408889634f
 #define MM_LN2 0.6931471805599453f
 #define MM_MAX_WAVES 16
-#define MM_SPLIT_HMAX 4  // workgroups of a team (split pair kernels)
+#define MM_SPLIT_HMAX 8  // workgroups of a team (split pair kernels)
 
 enum { MODE_FB = 0, MODE_ALPHA = 1, MODE_BETA = 2 };
 

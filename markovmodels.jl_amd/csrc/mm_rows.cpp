@@ -1,5 +1,7 @@
 // mm_rows.cpp -- see mm_rows.h
 #include "mm_rows.h"
+#include <cstdio>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cmath>
@@ -221,6 +223,9 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     for (int acap : {4, 12, 16, 24, 32, 48, 64}) {
         if (opt.acap_force ? acap != opt.acap_force : (acap == 4 || acap > opt.ka_max)) continue;
         Plan p = plan_for(myrows, rowptr, acap, opt, &row2pdf);
+        if (!p.ok && getenv("MM_VERBOSE_PLAN"))
+            fprintf(stderr, "[mm] plan with at most %d arcs per lane and row: %zu segments on %zu waves, KA %d (limit %d)\n", acap, p.segs.size(),
+                    p.wave_segs.size(), p.KA, opt.ka_max);
         if (!p.ok) continue;
         if (!best.ok || p.maxcost < best.maxcost || (p.maxcost == best.maxcost && p.KA < best.KA)) best = std::move(p);
     }
@@ -585,7 +590,9 @@ bool make_rows_split(int H, int64_t nrows, const std::vector<int64_t> &fwd_ptr, 
     });
     std::vector<double> load[2] = {std::vector<double>(H, 0.0), std::vector<double>(H, 0.0)};
     std::vector<int> cnt(H, 0);
-    const int cap = int((nrows + H - 1) / H) + int(nrows / (8 * H)) + 1;  // (the sets' regions are sized alike: keep the counts close)
+    // (the sets' regions are sized alike: keep the counts close -- within an eighth for teams of up to 4, within a 64th for the
+    // larger teams, whose workgroups have no LDS to spare for rows they do not have)
+    const int cap = int((nrows + H - 1) / H) + int(nrows / ((H > 4 ? 64 : 8) * H)) + 1;
     info.part.assign(size_t(nrows), 0);
     for (int32_t r : idx) {
         int best = -1;
@@ -626,7 +633,10 @@ bool make_rows_split(int H, int64_t nrows, const std::vector<int64_t> &fwd_ptr, 
             o.gtrash = info.total;
             o.plan_only = true;
             RowGraph tmp;
-            if (!make_rows(nrows, *ptr[d], d ? bwd_col : fwd_col, d ? bwd_val : fwd_val, row2pdf, P1, d == 1, none, o, tmp)) return false;
+            if (!make_rows(nrows, *ptr[d], d ? bwd_col : fwd_col, d ? bwd_val : fwd_val, row2pdf, P1, d == 1, none, o, tmp)) {
+                if (getenv("MM_VERBOSE")) fprintf(stderr, "[mm] make_rows_split(%d): plan of direction %d, set %d (%zu rows) failed\n", H, d, h, sets[h].size());
+                return false;
+            }
             for (int32_t r : sets[h]) {
                 lpos[d][size_t(r)] = tmp.pos[size_t(r)];
                 info.gpos[d][size_t(r)] = info.base[h] + tmp.pos[size_t(r)];
@@ -641,8 +651,10 @@ bool make_rows_split(int H, int64_t nrows, const std::vector<int64_t> &fwd_ptr, 
             o.pos_base = info.base[h];
             o.gtrash = info.total;
             if (!make_rows(nrows, *ptr[d], d ? bwd_col : fwd_col, d ? bwd_val : fwd_val, row2pdf, P1, d == 1, lpos[1 - d], o,
-                           out[size_t(d * H + h)]))
+                           out[size_t(d * H + h)])) {
+                if (getenv("MM_VERBOSE")) fprintf(stderr, "[mm] make_rows_split(%d): form of direction %d, set %d failed\n", H, d, h);
                 return false;
+            }
         }
     return true;
 }

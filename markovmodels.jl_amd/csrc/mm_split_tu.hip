@@ -11,8 +11,9 @@ namespace mm {
 // 8 apart, so their exchange stays inside one L2 where that holds (speed only; any placement is correct).
 // (teams of 2: a vector of 24 KB, up to 3070 states; teams of 4: 32 KB, up to 4094 states, a quarter of the rows each)
 template <int H> struct SplitGeo;
-template <> struct SplitGeo<2> { static constexpr int RS = MM_SPLIT_RS, RSH = MM_SPLIT_RSH; };
-template <> struct SplitGeo<4> { static constexpr int RS = MM_SPLIT4_RS, RSH = MM_SPLIT4_RSH; };
+template <> struct SplitGeo<2> { static constexpr int RS = MM_SPLIT_RS, RSH = MM_SPLIT_RSH, KA = 36; };
+template <> struct SplitGeo<4> { static constexpr int RS = MM_SPLIT4_RS, RSH = MM_SPLIT4_RSH, KA = 36; };
+template <> struct SplitGeo<8> { static constexpr int RS = MM_SPLIT8_RS, RSH = MM_SPLIT8_RSH, KA = 36; };
 // One launch per phase: the teams of the forward agents are the first half of the grid, those of the backward agents the
 // second (mm_pairs_tu.hip; a half is a multiple of 8 H workgroups: the block -> XCD pattern is the same in both).
 template <int NJ, int PHASE, int H>
@@ -22,7 +23,7 @@ __global__ void __launch_bounds__(1024) mm_fbs_kernel(RunParams p) {
     const int pair = (blk / (8 * H)) * 8 + (blk & 7), hset = (blk >> 3) % H;
     if (pair >= (p.B + 1) / 2) return;
     if ((p.x_sleep & 0x400) && hset == 1) return;  // (test aid, MM_SPLIT_SLEEP bit 0x400: a team mate that never shows up)
-    pair_agent<MM_SPLIT_KA, SplitGeo<H>::RS, PHASE, -1, NJ, H, SplitGeo<H>::RSH>(p, pair, hset, dir);
+    pair_agent<SplitGeo<H>::KA, SplitGeo<H>::RS, PHASE, -1, NJ, H, SplitGeo<H>::RSH>(p, pair, hset, dir);
 }
 template <int NJ, int PHASE, int H>
 static int launch_split_phase(const PairLaunch *h, const RunParams &p, hipStream_t st) {
@@ -45,16 +46,17 @@ static int launch_split_nj(const PairLaunch *h, const RunParams &p, hipStream_t 
     return MM_OK;
 }
 int mm_launch_split(const PairLaunch &pl, const RunParams &p, hipStream_t s0) {
-    if (pl.pair_ka > MM_SPLIT_KA) return MM_ERR_UNSUPPORTED;
-    if (pl.max_P1 > MM_PAIR_P1MAX) return MM_ERR_UNSUPPORTED;
-    const int nj = mm_pair_nj(pl.max_P1);
+    if (pl.pair_ka > mm_split_ka(pl.H)) return MM_ERR_UNSUPPORTED;
+    const int nj = mm_pair_nj(pl.max_P1, pl.H);
+    if (nj == 0) return MM_ERR_UNSUPPORTED;
+    if (pl.H == 8) return nj == 2 ? launch_split_nj<2, 8>(&pl, p, s0) : (nj == 4 ? launch_split_nj<4, 8>(&pl, p, s0) : launch_split_nj<5, 8>(&pl, p, s0));
     if (pl.H == 4) return nj == 2 ? launch_split_nj<2, 4>(&pl, p, s0) : (nj == 4 ? launch_split_nj<4, 4>(&pl, p, s0) : launch_split_nj<8, 4>(&pl, p, s0));
-    if (pl.H != 2) return mm_fail(MM_ERR_UNSUPPORTED, "split kernel: teams of 2 or 4");
+    if (pl.H != 2) return mm_fail(MM_ERR_UNSUPPORTED, "split kernel: teams of 2, 4 or 8");
     return nj == 2 ? launch_split_nj<2, 2>(&pl, p, s0) : (nj == 4 ? launch_split_nj<4, 2>(&pl, p, s0) : launch_split_nj<8, 2>(&pl, p, s0));
 }
 size_t mm_split_lds_bytes(int H, int phase, int nslotrows, int max_P1) {
-    const int pc = pair_pc(mm_pair_nj(max_P1));
-    return H == 4 ? pair_lds_bytes(MM_SPLIT4_RS, phase, nslotrows, MM_SPLIT4_RSH, pc) : pair_lds_bytes(MM_SPLIT_RS, phase, nslotrows, MM_SPLIT_RSH, pc);
+    const int nj = mm_pair_nj(max_P1, H);
+    return nj ? pair_lds_bytes(mm_split_rs(H), phase, nslotrows, mm_split_rsh(H), pair_pc(nj)) : 0;
 }
 
 }  // namespace mm

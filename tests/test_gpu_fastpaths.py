@@ -256,11 +256,12 @@ def test_posterior_floor_keeps_sharp_emissions_on_the_fast_kernels(mm, wl, oracl
     assert bf.last_redo_count() == strict_redone
 
 
-@pytest.mark.parametrize("S,P", [(6000, 300), (2900, 120), (1000, 640)])
+@pytest.mark.parametrize("S,P", [(6000, 300), (5000, 100), (2900, 120), (1000, 640), (6100, 60)])
 def test_graph_beyond_the_fast_paths(mm, wl, oracle, torch, S, P):
-    """The reference's products have no size limit (src/linalg.jl:170-181).  6000 states x 300 pdfs and 1000 states x
-    640 pdfs are beyond the pair kernels (2047 states, 250 pdfs) and the teams (4094 states, 128 pdfs): they run on the
-    quad / item kernels; a 2900-state graph of config 3's family takes the teams of two.  Same results either way."""
+    """The reference's products have no size limit (src/linalg.jl:170-181).  1000 states x 640 pdfs and 6100 states are beyond
+    the pair kernels (2047 states, 506 pdfs) and the teams (6014 states; 314 pdfs for teams of 8): they run on the quad / item
+    kernels; a 2900-state graph of config 3's family takes the teams of two, 5000 and 6000 states (the latter with 300 pdfs:
+    mm_fbs_kernel<5, ., 8>) teams of EIGHT workgroups per utterance pair and direction.  Same results either way."""
     g = wl.lfmmi_denominator(S, P, seed=S)
     rng = np.random.default_rng(S + P)
     B, N = 5, 36
@@ -270,7 +271,9 @@ def test_graph_beyond_the_fast_paths(mm, wl, oracle, torch, S, P):
     bf = mm.batch(*([cf] * B))
     gam, ttl = bf.pdfposteriors(V, lens)
     kernels = bf.kernels()
-    assert ("mm_fbs_kernel" in kernels) == (S == 2900), kernels
+    assert ("mm_fbs_kernel" in kernels) == (S in (2900, 5000, 6000)), kernels
+    if S in (5000, 6000):
+        assert ("mm_fbs_kernel<5,A,8>" if P == 300 else "mm_fbs_kernel<2,A,8>") in kernels, kernels
     assert bf.last_redo_count() == 0 or "mm_fbs_kernel" not in kernels
     g_ref, t_ref = oracle64(oracle, g, V, lens)
     check_gamma(gam, g_ref, lens)

@@ -148,7 +148,7 @@ __device__ __forceinline__ float dpair_finish_frame(unsigned psum, int P1, int P
     }
     if constexpr (H > 1) {
         // (the other sets' parts requested together, four sets at a time, before the first is looked at: pair_finish_frames)
-        constexpr int GB = H < 4 ? H : 4;
+        constexpr int GB = H < MM_XPS_GB ? H : MM_XPS_GB;
         double tot[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) tot[j] = 0.0;
@@ -614,7 +614,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
         MM_STAMP_RESET;
         for (int t = t0 + 1; t <= t1; ++t) {
             if constexpr (PHASE == 1)
-                if (t - 2 > t0) xframes(t - 2, L::PSUM(t & 1));
+                if (t - 2 > t0 && hset == 0) xframes(t - 2, L::PSUM(t & 1));  // (the first workgroup's business: pair_agent)
             MM_STAMP(0);
             MM_STEP_SYNC();
             MM_STAMP(1);
@@ -623,7 +623,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             for (int k = 1; k >= 0; --k) {
                 const int t = t1 - k;
                 if (k == 0) __syncthreads();  // (a)
-                if (t > t0) xframes(t, L::PSUM(t & 1));
+                if (t > t0 && hset == 0) xframes(t, L::PSUM(t & 1));
             }
             if (lane == 0 && hset == 0) {
                 p.pair_zmin[(long long)b * 6 + DIR] = xzmin;

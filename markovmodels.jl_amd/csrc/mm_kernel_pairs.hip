@@ -326,7 +326,10 @@ __device__ __forceinline__ bool pair_finish_frames(unsigned psum, int P1, int P,
         // the other sets' partial sums: requested together, four sets at a time, before the first is looked at (one memory round
         // trip per frame for teams of up to 4, two for teams of 8 -- not one per set; all seven sets of a team of 8 at once do
         // not fit the registers), summed in the order of the sets -- the same bits in every workgroup
-        constexpr int GB = H < 4 ? H : 4;
+#ifndef MM_XPS_GB
+#define MM_XPS_GB 4
+#endif
+        constexpr int GB = H < MM_XPS_GB ? H : MM_XPS_GB;
         mm_f32x2 tot[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) tot[j] = mm_f32x2{0.f, 0.f};
@@ -1038,8 +1041,10 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                     }
                 }
             }
+            // (the posteriors and the per-frame statistics are the FIRST workgroup's business: the others publish their partial
+            // sums and read nobody's -- eight workgroups polling seven sets each was eight times the traffic for the same result)
             if constexpr (PHASE == 1)
-                if (t - 2 > t0) xframes(t - 2, L::PSUM(t & 1));
+                if (t - 2 > t0 && hset == 0) xframes(t - 2, L::PSUM(t & 1));
             MM_STAMP(0);
             MM_STEP_SYNC();
             MM_STAMP(1);
@@ -1049,9 +1054,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             for (int k = 1; k >= 0; --k) {
                 const int t = t1 - k;
                 if (k == 0) __syncthreads();  // (a)
-                if (t > t0) xframes(t, L::PSUM(t & 1));
+                if (t > t0 && hset == 0) xframes(t, L::PSUM(t & 1));
             }
-            if (lane == 0) {
+            if (lane == 0 && hset == 0) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     if (U[u].valid) {

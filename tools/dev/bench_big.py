@@ -7,7 +7,10 @@ import __graft_entry__ as ge
 import torch
 mm = ge.load_package()
 wl = importlib.import_module(mm.__name__ + ".workloads")
-for S, P, B, N in ((6000, 300, 128, 700), (4000, 84, 128, 700), (2000, 400, 256, 1500), (10000, 1000, 64, 700)):
+CASES = ((6000, 300, 128, 700), (4000, 84, 128, 700), (2000, 400, 256, 1500), (10000, 1000, 64, 700))
+if len(sys.argv) > 1:  # S P B N
+    CASES = (tuple(int(x) for x in sys.argv[1:5]),)
+for S, P, B, N in CASES:
     g = wl.lfmmi_denominator(S, P, seed=1)
     cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
     bf = mm.batch(*([cf] * B))

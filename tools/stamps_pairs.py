@@ -22,6 +22,8 @@ if os.environ.get("WL") == "wsj_den":
     g, B = wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "den_fsm_wsj.npz")), 128
 if os.environ.get("WL") == "lfmmi_den4000":
     g, B = wl.lfmmi_denominator(4000, 84, seed=1), 32
+if os.environ.get("WL") == "big6000":  # teams of 8
+    g, B = wl.lfmmi_denominator(6000, int(os.environ.get("P", 300)), seed=1), 32
 if os.environ.get("WL") == "ergodic64":
     g, B = wl.dense_ergodic(64, seed=0), 32
 N = int(os.environ.get("N", 300))

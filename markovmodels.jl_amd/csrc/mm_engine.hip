@@ -1142,6 +1142,7 @@ static void wave_pack(mm_fsm_t f) {
     // 0.434 -> 0.437 ms on the WSJ numerators x 128 -- and the search is half the host time of packing a small graph)
     opt.place = 1;
     opt.naive_stats = false;
+    opt.q_positions = false;  // (the wave kernel sums the posteriors per pdf through its own tables: wave_pdf_table)
     if (const char *e = getenv("MM_WAVE_PLACE")) opt.place = atoi(e);
     // (owned until they are handed to the FSM: the packer may throw -- an allocation that fails)
     std::unique_ptr<RowVariant> rv[2] = {std::make_unique<RowVariant>(), std::make_unique<RowVariant>()};
@@ -1570,6 +1571,7 @@ char *g_stage = nullptr;
 size_t g_stage_bytes = 0;
 }  // namespace
 
+extern "C" std::atomic<long long> mm_rows_prof_ns[8];  // (mm_rows.cpp: where the time of make_rows goes, MM_VERBOSE)
 static int fsm_create_many_impl(int64_t n, int semiring, int layout, int index_bytes, int index_base, int val_bytes, const int64_t *S1,
                                 const int64_t *nnz, const void *const *ptr, const void *const *idx, const void *const *val,
                                 const int64_t *n_init, const void *const *init_idx, const void *const *init_val,
@@ -1634,6 +1636,10 @@ static int fsm_create_many_impl(int64_t n, int semiring, int layout, int index_b
         }
     });
     lap("graphs compiled and packed");
+    if (verbose) {
+        fprintf(stderr, "[mm] make_rows sections (us per graph): plan %.0f, numbering %.0f, csr %.0f, slots+placement %.0f\n", 1e-3 * double(mm_rows_prof_ns[0].exchange(0)) / double(n),
+                1e-3 * double(mm_rows_prof_ns[1].exchange(0)) / double(n), 1e-3 * double(mm_rows_prof_ns[2].exchange(0)) / double(n), 1e-3 * double(mm_rows_prof_ns[3].exchange(0)) / double(n));
+    }
     if (verbose) fprintf(stderr, "[mm] create_many: per graph %.0f us mm_fsm_create + %.0f us wave forms (%zu threads)\n", 1e-3 * double(ns_create.load()) / double(n), 1e-3 * double(ns_pack.load()) / double(n), nthr);
     auto undo = [&](int rc, const std::string &msg) {
         for (int64_t i = 0; i < n; ++i)

@@ -1,6 +1,8 @@
 // mm_rows.cpp -- see mm_rows.h
 #include "mm_rows.h"
 #include <cstdio>
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
 
 #include <algorithm>
@@ -200,9 +202,21 @@ Plan plan_for(const std::vector<int32_t> &rows, const std::vector<int64_t> &rowp
 
 }  // namespace
 
+}  // namespace mm
+extern "C" {
+std::atomic<long long> mm_rows_prof_ns[8];
+}
+namespace mm {
+#define PROF_LAP(i)                                                                                                              \
+    do {                                                                                                                         \
+        const auto now_ = std::chrono::steady_clock::now();                                                                      \
+        mm_rows_prof_ns[i] += std::chrono::duration_cast<std::chrono::nanoseconds>(now_ - prof_t_).count();                          \
+        prof_t_ = now_;                                                                                                          \
+    } while (0)
 bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &col,
                const std::vector<float> &val, const std::vector<int32_t> &row2pdf, int32_t P1, bool backward,
                const std::vector<int32_t> &fwd_pos, const RowPackOpts &opt, RowGraph &g) {
+    auto prof_t_ = std::chrono::steady_clock::now();
     g = RowGraph();
     // the rows this form computes (all, or a subset: split forms) and the positions of the vector its arcs read
     std::vector<int32_t> myrows;
@@ -230,6 +244,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
         if (!best.ok || p.maxcost < best.maxcost || (p.maxcost == best.maxcost && p.KA < best.KA)) best = std::move(p);
     }
     if (!best.ok) return false;
+    PROF_LAP(0);
     const int NWC = int(best.wave_segs.size());
     int KA = std::max(2, (best.KA + 1) & ~1);
     if (opt.mix_n4 >= 0) {
@@ -267,7 +282,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
     g.scale = opt.pair ? 8 : 4;
     g.ncopy = opt.copies ? opt.copies : (opt.pair ? 1 : 2);
     const uint32_t SC = uint32_t(g.scale);
-    const bool want_q = backward || opt.pair || opt.want_partner;  // pdf-major positions
+    const bool want_q = (backward || opt.pair || opt.want_partner) && opt.q_positions;  // pdf-major positions
     g.maxcost = best.maxcost;
     g.mincost = best.mincost;
     // ---- numbering: the order in which the rows are finished
@@ -339,6 +354,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                 }
             }
     }
+    PROF_LAP(1);
     // ---- CSR in internal numbering (exact fallback)
     g.rowptr.assign(size_t(nsub) + 1, 0);
     g.col.clear();
@@ -355,6 +371,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
         }
         g.rowptr[nsub] = int32_t(a_out);
     }
+    PROF_LAP(2);
     // ---- schedules, slot table
     const int zero_pdf = (P1 + 3) & ~3;  // emission slot that always holds zero(K)
     g.sched.assign(NWC, RowSched{0, 0, 0, 0});
@@ -417,28 +434,53 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
             // arcs of the segment: every lane of a row's group takes every g-th arc; inside its A slots the
             // lane's arcs are ordered (and their copy chosen) by the bank model, one half-wave at a time
             for (int half = 0; half < 2; ++half) {
-                std::vector<Banks> tabn(s.A), tab(s.A);
+                // (scratch of the thread, reused: a pack of a small graph runs this block dozens of times, and its allocations
+                // were half the time of packing a numerator graph)
+                static thread_local std::vector<Banks> tabn_s, tab_s;
+                static thread_local std::vector<int64_t> la_s;
+                static thread_local std::vector<uint32_t> ad_s;
+                static thread_local std::vector<float> wt_s;
+                static thread_local std::vector<char> used_s;
+                if (tab_s.size() < size_t(s.A)) tab_s.resize(size_t(s.A));
+                if (opt.naive_stats && tabn_s.size() < size_t(s.A)) tabn_s.resize(size_t(s.A));
+                for (int k = 0; k < s.A; ++k) {
+                    tab_s[size_t(k)] = Banks();
+                    if (opt.naive_stats) tabn_s[size_t(k)] = Banks();
+                }
+                Banks *const tab = tab_s.data(), *const tabn = tabn_s.data();
+                // the lane's arcs (indices into the internal CSR): at most A each
                 struct LaneArcs {
-                    std::vector<int64_t> arcs;  // indices into the internal CSR
+                    const int64_t *p;
+                    size_t n;
+                    size_t size() const { return n; }
+                    int64_t operator[](size_t i) const { return p[i]; }
                 };
-                LaneArcs la[32];
+                struct {
+                    LaneArcs arcs;
+                } la[32];
+                la_s.resize(size_t(32) * size_t(s.A));
                 for (int l = 0; l < 32; ++l) {
+                    int64_t *dst = la_s.data() + size_t(l) * size_t(s.A);
+                    size_t cnt = 0;
                     const int lane = half * 32 + l, grp = lane / s.g, sub = lane % s.g;
-                    if (grp >= int(s.rows.size())) continue;
-                    const int64_t i = g.pos[s.rows[grp]];
-                    for (int64_t a = g.rowptr[i] + sub; a < g.rowptr[i + 1]; a += s.g) la[l].arcs.push_back(a);
+                    if (grp < int(s.rows.size())) {
+                        const int64_t i = g.pos[s.rows[grp]];
+                        for (int64_t a = g.rowptr[i] + sub; a < g.rowptr[i + 1] && cnt < size_t(s.A); a += s.g) dst[cnt++] = a;
+                    }
+                    la[l].arcs = LaneArcs{dst, cnt};
                 }
                 // naive placement (CSR order, copy 0) for the statistics
                 for (int l = 0; l < 32 && opt.naive_stats; ++l)
                     for (int k = 0; k < s.A; ++k)
                         tabn[k].add(k < int(la[l].arcs.size()) ? uint32_t(4 * g.col[la[l].arcs[k]]) : uint32_t(4 * (l % int(ntot))));  // (model units)
                 // greedy: lane after lane, slot after slot, the remaining arc / copy that is cheapest there
-                std::vector<uint32_t> ad_flat(size_t(32) * s.A, 0u);
-                std::vector<float> wt_flat(size_t(32) * s.A, 0.f);
-                auto ad = [&, A = s.A](int l) { return ad_flat.data() + size_t(l) * A; };
-                auto wt = [&, A = s.A](int l) { return wt_flat.data() + size_t(l) * A; };
+                ad_s.assign(size_t(32) * s.A, 0u);
+                wt_s.assign(size_t(32) * s.A, 0.f);
+                auto ad = [&, A = s.A](int l) { return ad_s.data() + size_t(l) * A; };
+                auto wt = [&, A = s.A](int l) { return wt_s.data() + size_t(l) * A; };
                 for (int l = 0; l < 32; ++l) {
-                    std::vector<char> used(la[l].arcs.size(), 0);
+                    used_s.assign(la[l].arcs.size(), 0);
+                    char *const used = used_s.data();
                     for (int k = 0; k < s.A; ++k) {
                         int bi = -1, bcost = 1 << 30;
                         uint32_t baddr = 0;
@@ -536,7 +578,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                     if (!improved) break;
                 }
                 for (int k = 0; k < s.A; ++k) {
-                    cyc_naive += tabn[k].cycles();
+                    cyc_naive += opt.naive_stats ? tabn[k].cycles() : 1;
                     cyc_sched += tab[k].cycles();
                     ++n_instr;
                     for (int l = 0; l < 32; ++l) {
@@ -551,6 +593,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
             ++slotrow;
         }
     }
+    PROF_LAP(3);
     // the padding rows of the slot table
     for (int pr = 0; pr < 2; ++pr)
         for (int l = 0; l < 64; ++l) {

@@ -136,6 +136,8 @@ struct RowPackOpts {
     // the wave form -- the placement is most of the host time of packing a small graph).
     int place = 2;
     bool naive_stats = true;  // also model the arcs in CSR order (RowGraph::conflict_before: informational)
+    bool q_positions = true;  // pdf-major positions of the rows (the kernels that sum the posteriors per pdf over contiguous ranges);
+                              // false: the slot table's q field stays 0 (the wave kernel has its own pdf tables)
 };
 
 // rowptr/col/val_log2: 0-based CSR of M (out[r] = (+)_k val[k] (*) in[col[k]]), square, nrows rows.

@@ -192,6 +192,7 @@ struct DebugOpts {
     int exact_first = -1;           // MM_EXACT_FIRST=0/1: never / always skip the float32 pair kernels (default: by the last call's marks)
     bool bigv = false;              // MM_BIGV: item / tropical kernels with the state vectors in global memory whatever the size
     int finish_cost = 0;            // MM_FINISH_COST: cost model of the pair forms (0: default)
+    int split_q10 = 0;              // MM_SPLIT_Q10: where the pair kernels cut the frames between the agents (1024ths; 0: the engine's choice)
     int x_sleep = 8;                // MM_SPLIT_SLEEP: split kernels, 64-clock units the exchange wave sleeps before a step's first poll
     float group_speed[4] = {0, 0, 0, 0};  // MM_GROUP_SPEED=a,b,c,d
 };
@@ -214,6 +215,7 @@ static DebugOpts read_debug_opts() {
     if (const char *e = getenv("MM_EXACT_FIRST")) d.exact_first = atoi(e) != 0;
     if (const char *e = getenv("MM_FINISH_COST")) d.finish_cost = atoi(e);
     if (const char *e = getenv("MM_SPLIT_SLEEP")) d.x_sleep = atoi(e);
+    if (const char *e = getenv("MM_SPLIT_Q10")) d.split_q10 = atoi(e);
     if (const char *e = getenv("MM_GROUP_SPEED")) sscanf(e, "%f,%f,%f,%f", &d.group_speed[0], &d.group_speed[1], &d.group_speed[2], &d.group_speed[3]);
     return d;
 }
@@ -2316,6 +2318,10 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     p.N = int(N);
     p.B = int(h->B);
     p.x_sleep = h->dbg.x_sleep;
+    // (the backward agent's phase-B steps are ~10 % dearer than the forward agent's on the pair kernels -- cycle stamps, config 3:
+    // 4990 against 4520 --, the phase-A steps alike: the cut that levels both launches lies at 0.48 of the frames; the steps of
+    // the team kernels are bound by the exchange, the same in both directions)
+    p.split_q10 = h->dbg.split_q10 > 0 ? h->dbg.split_q10 : (h->pair_H == 1 ? MM_PAIR_SPLIT_Q10 : 512);
     p.x_timeout = std::min<unsigned long long>(10000000ull, std::max<unsigned long long>(200000ull, 1000ull * (unsigned long long)N));
     p.lt_floor = h->lt_floor;
     p.ws_alpha = static_cast<float *>(h->ws);
@@ -2330,16 +2336,22 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     int *const order = ordered ? reinterpret_cast<int *>(tail0) : nullptr;  // (first of the tail)
     p.order = order;
     const bool marks = !h->wave_ok && !h->lane_ok && (h->rows_ok || h->pairs_ok);
-    // Which kernels first?  The float32 pair kernels, unless the inputs of the last finished call were beyond them for more
-    // than a quarter of its utterances (a sharp acoustic model: every utterance is marked and computed again): then the
-    // float64 kernels take the whole batch at once.  They keep reporting (how many utterances have an overlap term below the
-    // float32 kernels' floor), so the choice follows the data back as well.  Read without synchronising: the count of
-    // whatever call finished last.
+    // Which kernels first?  The float32 pair kernels, unless the inputs of the last finished call were beyond them for some of
+    // its utterances (a sharp acoustic model marks every utterance) AND starting with the float64 kernels costs no more rounds
+    // of workgroups than the float32 kernels followed by the float64 kernels for that many utterances would -- a launch lasts as
+    // long as its rounds (one workgroup per compute unit), whatever the number of workgroups in the last of them: config 3
+    // (B = 256: one round of pairs, two of single utterances) with 38 utterances marked is 6.0 ms float32-first, 5.5 ms
+    // float64-first; B = 512 with the same 38 stays float32-first.  (Until round 4: "more than a quarter of the utterances".)
+    // The float64 kernels keep reporting (how many utterances have an overlap term below the float32 kernels' floor), so the
+    // choice follows the data back as well.  Read without synchronising: the count of whatever call finished last.
     bool exact_first = false;
     if (marks) {
         p.redo = reinterpret_cast<int *>(tail0 + align_up(size_t(h->B + 1) * 4, 256));
         if (h->dpair_ok) {
-            exact_first = h->exact_first >= 0 ? h->exact_first != 0 : 4 * int64_t(h->stat_host[0]) > h->B;
+            const int64_t M = h->stat_host[0], H = h->pair_H, cus = std::max(1, h->n_cus);
+            auto rounds = [&](int64_t wgs) { return (wgs + cus - 1) / cus; };
+            const bool by_rounds = M > 0 && rounds(2 * h->B * H) <= rounds(2 * ((h->B + 1) / 2) * H) + rounds(2 * std::min<int64_t>(M, h->B) * H);
+            exact_first = h->exact_first >= 0 ? h->exact_first != 0 : by_rounds;
             p.redo2 = reinterpret_cast<int *>(tail0 + ws_tail_bytes(h) - align_up(size_t(h->B + 1) * 4, 256));
             p.stat_dev = h->stat_dev;
             p.stat_host = h->stat_host;

@@ -30,6 +30,7 @@ int mm_fail(int code, const std::string &msg);
 // pdfs (+ 1) of the pair / split pair / float64 pair kernels: passes of 64 lanes of their service waves (the NJ of the instances),
 // and the floats of one slot of per-pdf partial sums a team publishes (PairLay::XPS, mm_kernel_pairs.hip)
 #define MM_PAIR_P1MAX 506
+#define MM_PAIR_SPLIT_Q10 512  // (mm_engine.hip: RunParams::split_q10 of the pair kernels)
 // (teams of 8 have no LDS for the arrays of 512 pdfs: 5 passes, 314 pdfs)
 inline int mm_pair_nj(int P1, int H = 1) { return P1 <= 128 ? 2 : (P1 <= 250 ? 4 : (H == 8 ? (P1 <= 314 ? 5 : 0) : (P1 <= MM_PAIR_P1MAX ? 8 : 0))); }
 inline int mm_pair_xps(int P1, int H = 1) { const int nj = mm_pair_nj(P1, H); return nj <= 4 ? 512 : 128 * nj; }

@@ -338,8 +338,8 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
     // state vectors of the utterance's frames (alpha~ up to the split, beta~ beyond): float32 log2 values [N + 2][S1p]
     float *rowsP = p.ws_alpha + (long long)b * (long long)(p.N + 2) * S1p;
     const float thr = r.thr + MM_DPAIR_THR_EXTRA;
-    int m = NFp / 2;
-    m = m < 1 ? 1 : m;
+    int m = (int)(((long long)NFp * (p.split_q10 > 0 ? p.split_q10 : 512)) >> 10);
+    m = m < 1 ? 1 : (m > NFp - 1 && NFp > 1 ? NFp - 1 : m);
     const int tA = DIR ? NFp - m : m, tEnd = NFp;
     auto frame_of = [&](int t) { return DIR ? NFp + 1 - t : t; };
     PairHand *hand = reinterpret_cast<PairHand *>(p.pair_hand) + ((long long)b * 2 + DIR);

@@ -605,8 +605,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
     // ~1e-5, and the sharp emissions it was meant for -- log-softmax of 10 N(0,1) -- need 160 log2 in the COMBINE, which no
     // level gives: those inputs go to the exact kernels, mm_pair_finish_kernel.)
     // split: forward steps 1..m are phase A, backward steps 1..NFp-m
-    int m = NFp / 2;
-    m = m < 1 ? 1 : m;
+    int m = (int)(((long long)NFp * (p.split_q10 > 0 ? p.split_q10 : 512)) >> 10);
+    m = m < 1 ? 1 : (m > NFp - 1 && NFp > 1 ? NFp - 1 : m);
     const int tA = DIR ? NFp - m : m, tEnd = NFp;
     auto frame_of = [&](int t) { return DIR ? NFp + 1 - t : t; };
     PairHand *hand = reinterpret_cast<PairHand *>(p.pair_hand) + ((long long)pair * 2 + DIR) * 2;

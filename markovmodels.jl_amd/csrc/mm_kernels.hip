@@ -162,6 +162,9 @@ struct RunParams {
     float *xbuf_d, *xps_d;
     long long x_phase_d;
     int x_H;  // workgroups of a team (0: no teams)
+    // where the frames of a pair are cut between its two agents, in 1024ths of the frames (512: in the middle).  The backward
+    // agent's steps of phase B are the dearest (its finishes: mm_engine.hip pair_variants), so it gets a little less than half
+    int split_q10;
     int x_psn;  // floats of one slot of per-pdf partial sums (512; 1024 for the instances of more than 250 pdfs)
     int x_sleep;                // the exchange wave sleeps this many x 64 clocks before its first poll of a step
     // how long a poll of a team waits (ticks of s_memrealtime, 100 MHz) before it gives the team up and marks the utterances: a

@@ -75,8 +75,9 @@ def test_sharp_emissions_on_the_float64_kernels_alone(mm, wl, oracle, torch, sig
 
 
 def test_the_choice_follows_the_data(mm, wl, oracle, torch):
-    """randn -> sharp -> sharp -> randn -> randn: the float32 kernels run first until a call leaves more than a quarter of its
-    utterances marked, the float64 kernels take whole batches while their overlap statistics say the float32 kernels
+    """randn -> sharp -> sharp -> randn -> randn: the float32 kernels run first until a call leaves utterances marked (and starting with the
+    float64 kernels costs no more rounds of workgroups than redoing that many behind the float32 kernels: mm_engine.hip), the
+    float64 kernels take whole batches while their overlap statistics say the float32 kernels
     would fail, and the engine goes back when the data does.  Results are the oracle's on every call."""
     g = wl.lfmmi_denominator(1500, 84, seed=2)
     rng = np.random.default_rng(3)

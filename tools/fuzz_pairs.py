@@ -36,7 +36,9 @@ def main(seed=0):
     bad = n = 0
     graphs = [lambda: wl.random_fsm(13, 3, 2.0, seed=1), lambda: wl.random_fsm(300, 9, 2.5, seed=2),
               lambda: wl.lfmmi_denominator(600, 40, seed=5), lambda: wl.lfmmi_denominator(2000, 84, seed=0),
-              lambda: wl.lexicon_fsm(1500, 30, seed=3), lambda: wl.dense_ergodic(64, seed=0), lambda: wl.wide_row_fsm()]
+              lambda: wl.lexicon_fsm(1500, 30, seed=3), lambda: wl.dense_ergodic(64, seed=0), lambda: wl.wide_row_fsm(),
+              # (251 .. 506 pdfs: the NJ = 8 instances of the pair kernels; no row forms there -- "row" falls to the engine's choice)
+              lambda: wl.lfmmi_denominator(1700, 2 * int(rng.integers(126, 253)), seed=int(rng.integers(1 << 30)))]
     for gi, mk in enumerate(graphs):
         g = mk()
         cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))

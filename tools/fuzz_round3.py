@@ -61,12 +61,16 @@ def fuzz_split(rng):
     here = os.path.join(ROOT, "tests", "golden", "den_fsm_wsj.npz")
     graphs = [lambda: wl.load_npz_graph(here), lambda: wl.lfmmi_denominator(2900, 120, seed=int(rng.integers(1 << 30))),
               lambda: wl.lfmmi_denominator(2400, 200, seed=int(rng.integers(1 << 30))),
-              lambda: wl.lfmmi_denominator(int(rng.integers(1600, 2040)) * 2, 100, seed=int(rng.integers(1 << 30)))]  # (teams of 4)
+              lambda: wl.lfmmi_denominator(int(rng.integers(1600, 2040)) * 2, 100, seed=int(rng.integers(1 << 30))),  # (teams of 4)
+              lambda: wl.lfmmi_denominator(int(rng.integers(2100, 3000)) * 2, 2 * int(rng.integers(20, 157)), seed=int(rng.integers(1 << 30))),  # (teams of 8)
+              lambda: wl.lfmmi_denominator(2600, 2 * int(rng.integers(126, 253)), seed=int(rng.integers(1 << 30)))]  # (teams of 2, 251 .. 506 pdfs)
     for gi, mk in enumerate(graphs):
         g = mk()
         cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
         for B, N in ((1, 1), (1, 6), (1, 61), (2, 1), (2, 2), (3, 3), (3, 4), (5, 7), (8, 40), (9, 101), (300, 12), (515, 9)):
             V = torch.from_numpy((1.5 * rng.standard_normal((B, N, g.P))).astype(np.float32)).cuda()
+            if rng.integers(0, 3) == 0:  # (sharp: the float64 team kernels behind the float32 ones)
+                V = torch.log_softmax(8.0 * V, dim=-1)
             lens = lens_pattern(rng, B, N)
             lt = torch.from_numpy(lens).cuda()
             ref_g, ref_t, _, _ = posteriors([cf] * B, V, lt, "item")

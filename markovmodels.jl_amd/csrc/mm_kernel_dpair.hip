@@ -222,24 +222,30 @@ __device__ __forceinline__ double dsigned(double v, bool neg) {  // v with the t
 
 // pdf sums (q doubles in pdf-major order): 8 pdfs per wave and pass, 8 lanes per pdf (pair_pdf_sums for doubles)
 // (teams: xs = the slot the partial sums are published in, tagged by `neg`)
+// (LG: log2 of the lanes per pdf, 3 or -- the instances of more than 256 pdfs -- 1: pair_pdf_sums)
+template <int LG = 3>
 __device__ __forceinline__ void dpair_pdf_sums(unsigned qbase, unsigned pdfse_base, unsigned psum_base, int P1, int wave, int NWC, int lane,
                                                float *xs = nullptr, bool neg = false) {
-    for (int p0 = wave * 8; p0 < P1; p0 += NWC * 8) {
-        const int pdf = p0 + (lane >> 3);
+    constexpr int LP = 1 << LG, PPW = 64 >> LG;
+    constexpr unsigned STR = 8u * LP;
+    for (int p0 = wave * PPW; p0 < P1; p0 += NWC * PPW) {
+        const int pdf = p0 + (lane >> LG);
         double s0 = 0.0;
         if (pdf < P1) {
             const unsigned se = ldsru(pdfse_base + 4u * pdf);  // first | end << 16
-            const unsigned a0 = 8u * ((se & 0xffffu) + (lane & 7)), a1 = 8u * (se >> 16);
+            const unsigned a0 = 8u * ((se & 0xffffu) + (lane & (LP - 1))), a1 = 8u * (se >> 16);
             double v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = ldsr_d(qbase + (a0 + 64u * k < a1 ? a0 + 64u * k : 0u));
+            for (int k = 0; k < 4; ++k) v[k] = ldsr_d(qbase + (a0 + STR * k < a1 ? a0 + STR * k : 0u));
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (a0 + 64u * k < a1) s0 += v[k];
-            for (unsigned a = a0 + 256u; a < a1; a += 64u) s0 += ldsr_d(qbase + a);
+                if (a0 + STR * k < a1) s0 += v[k];
+            for (unsigned a = a0 + 4u * STR; a < a1; a += STR) s0 += ldsr_d(qbase + a);
         }
-        s0 = dgrp_sum8(s0);
-        if (pdf < P1 && (lane & 7) == 0) {
+        if constexpr (LG == 3) s0 = dgrp_sum8(s0);
+        else s0 = dpp_add_d<MM_DPP_XOR1, 0xF>(s0);
+        static_assert(LG == 3 || LG == 1, "lanes per pdf: 8 or 2");
+        if (pdf < P1 && (lane & (LP - 1)) == 0) {
             ldsw_d(psum_base + 8u * pdf, s0);
             if (xs) dgranule_store(xs, 8u * (unsigned)pdf, dsigned(s0, neg));
         }
@@ -741,7 +747,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             }
             if constexpr (PHASE == 1)  // C' * (A .* B) of the previous step (:155)
                 if (t - 1 > t0)
-                    dpair_pdf_sums(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane, H > 1 ? xps_send + ((t - 1) & 3) * (int)L::XPS : nullptr,
+                    dpair_pdf_sums<(NJ > 4 ? 1 : 3)>(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane, H > 1 ? xps_send + ((t - 1) & 3) * (int)L::XPS : nullptr,
                                    H > 1 && split_tag(t - 1, t0, 2) != 0u);
             if constexpr (H > 1) {
                 // The rows of the other sets of this step (pair_agent, MM_SPLIT_CWPOLL): chunk j (128 granules) of the q-th other
@@ -796,7 +802,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
         }
         if constexpr (PHASE == 1) {
             if (t1 > t0)
-                dpair_pdf_sums(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane, H > 1 ? xps_send + (t1 & 3) * (int)L::XPS : nullptr,
+                dpair_pdf_sums<(NJ > 4 ? 1 : 3)>(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane, H > 1 ? xps_send + (t1 & 3) * (int)L::XPS : nullptr,
                                H > 1 && split_tag(t1, t0, 2) != 0u);
             __syncthreads();  // (a)
         }

@@ -267,6 +267,50 @@ __device__ __forceinline__ float pair_stage_em(unsigned dst, unsigned rawsrc, in
     return E;
 }
 
+// The same for BOTH utterances at once with 16-byte reads: a lane takes 4 consecutive pdfs per pass (the instances of more
+// than 4 passes of 64 pdfs, whose service wave is the longest actor of every step: 2000 states / 400 pdfs spent 3100 of a
+// 4800-cycle phase-A step here with 32 four-byte LDS accesses; now 4 reads of 16 bytes and 8 writes of 8).
+template <int NJ>
+__device__ __forceinline__ void pair_stage_em_wide(unsigned dst, unsigned raw0, unsigned raw1, int n, int len0, int len1, int P, int lane,
+                                                   float (&E)[2]) {
+    constexpr int NP = (NJ + 3) / 4;
+    mm_f32x4 v0[NP], v1[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const unsigned o = 4u * (unsigned)(256 * j + 4 * lane);
+        v0[j] = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(raw0 + o);
+        v1[j] = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(raw1 + o);
+    }
+    float e0 = MM_NINF, e1 = MM_NINF;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = 256 * j + 4 * lane + i;
+            v0[j][i] = em_value(v0[j][i], n, len0, P, q);
+            v1[j][i] = em_value(v1[j][i], n, len1, P, q);
+            if (q < P) {
+                e0 = max_nc(e0, v0[j][i]);
+                e1 = max_nc(e1, v1[j][i]);
+            }
+        }
+    }
+    e0 = wave_max_rl(e0);
+    e1 = wave_max_rl(e1);
+    if (!(e0 > MM_NINF)) e0 = 0.f;
+    if (!(e1 > MM_NINF)) e1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = 256 * j + 4 * lane + i;
+            if (q <= P) ldsw2(dst + 8u * (unsigned)q, v0[j][i] - e0, v1[j][i] - e1);
+        }
+    }
+    E[0] = e0;
+    E[1] = e1;
+}
+
 // service wave: log2 of the maxima of both linear vectors (pairs [pos][2]; n2 float4s = 2 states each, n2 <= 64 * NB).
 // All loads are issued before the first maximum (clamped indices: a duplicate changes no maximum) -- a loop with one
 // load per trip costs the wave one LDS round trip per trip, and the service wave is the one wave whose own latency
@@ -402,34 +446,84 @@ __device__ __forceinline__ bool pair_finish_frames(unsigned psum, int P1, int P,
     return arrived;
 }
 
+// The same with 16-byte reads (a lane takes 2 consecutive pdfs of both utterances per pass) and, where the rows of gamma
+// allow it (pdfs contiguous, rows 8-byte aligned: `wide`), 8-byte stores: the instances of more than 4 passes, H = 1.
+template <int NJ>
+__device__ __forceinline__ void pair_finish_frames_wide(unsigned psum, int P1, int P, int lane, float *gp0, float *gp1, long long gsp, bool store0,
+                                                        bool store1, bool wide, float (&lt)[2]) {
+    constexpr int NP = (NJ + 1) / 2;
+    mm_f32x4 s[NP];
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int q = 128 * j + 2 * lane;
+        s[j] = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(psum + 8u * (unsigned)(q < P1 ? q : 0));
+        if (q < P1) {
+            t0 += s[j].x;
+            t1 += s[j].y;
+        }
+        if (q + 1 < P1) {
+            t0 += s[j].z;
+            t1 += s[j].w;
+        }
+    }
+    t0 = wave_sum_rl(t0);
+    t1 = wave_sum_rl(t1);
+    const float i0 = t0 > 0.f ? 1.f / t0 : 0.f, i1 = t1 > 0.f ? 1.f / t1 : 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int q = 128 * j + 2 * lane;
+        if (wide && q + 1 < P) {
+            if (store0) *reinterpret_cast<mm_f32x2 *>(gp0 + q) = mm_f32x2{s[j].x * i0, s[j].z * i0};
+            if (store1) *reinterpret_cast<mm_f32x2 *>(gp1 + q) = mm_f32x2{s[j].y * i1, s[j].w * i1};
+        } else {
+            if (q < P) {
+                if (store0) gp0[q * gsp] = s[j].x * i0;
+                if (store1) gp1[q * gsp] = s[j].y * i1;
+            }
+            if (q + 1 < P) {
+                if (store0) gp0[(q + 1) * gsp] = s[j].z * i0;
+                if (store1) gp1[(q + 1) * gsp] = s[j].w * i1;
+            }
+        }
+    }
+    lt[0] = fast_log2(t0);
+    lt[1] = fast_log2(t1);
+}
+
 // pdf sums of both utterances (q pairs in pdf-major order): 8 pdfs per wave and pass, 8 lanes per pdf
 // (split kernels: xs = the slot the partial sums are published in for the team, sg = +-1 carrying the tag)
+// (LG: log2 of the lanes per pdf -- 8 lanes, 8 pdfs per wave and pass; the instances of more than 256 pdfs, whose pdfs have a
+// handful of states each: 2 lanes, 32 pdfs per wave and pass -- 400 pdfs in one pass of the 15 compute waves instead of four)
+template <int LG = 3>
 __device__ __forceinline__ void pair_pdf_sums(unsigned qbase, unsigned pdfse_base, unsigned psum_base, int P1, int wave, int NWC, int lane,
                                               float *xs = nullptr, float sg = 1.f) {
-    for (int p0 = wave * 8; p0 < P1; p0 += NWC * 8) {
-        const int pdf = p0 + (lane >> 3);
+    constexpr int LP = 1 << LG, PPW = 64 >> LG;
+    constexpr unsigned STR = 8u * LP;
+    for (int p0 = wave * PPW; p0 < P1; p0 += NWC * PPW) {
+        const int pdf = p0 + (lane >> LG);
         float s0 = 0.f, s1 = 0.f;
         if (pdf < P1) {
             const unsigned se = ldsru(pdfse_base + 4u * pdf);  // first | end << 16
-            const unsigned a0 = 8u * ((se & 0xffffu) + (lane & 7)), a1 = 8u * (se >> 16);
+            const unsigned a0 = 8u * ((se & 0xffffu) + (lane & (LP - 1))), a1 = 8u * (se >> 16);
             mm_f32x2 v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = ldsr2(qbase + (a0 + 64u * k < a1 ? a0 + 64u * k : 0u));
+            for (int k = 0; k < 4; ++k) v[k] = ldsr2(qbase + (a0 + STR * k < a1 ? a0 + STR * k : 0u));
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (a0 + 64u * k < a1) {
+                if (a0 + STR * k < a1) {
                     s0 += v[k].x;
                     s1 += v[k].y;
                 }
-            for (unsigned a = a0 + 256u; a < a1; a += 64u) {
+            for (unsigned a = a0 + 4u * STR; a < a1; a += STR) {
                 const mm_f32x2 w = ldsr2(qbase + a);
                 s0 += w.x;
                 s1 += w.y;
             }
         }
-        s0 = grp_sum(s0, 3);
-        s1 = grp_sum(s1, 3);
-        if (pdf < P1 && (lane & 7) == 0) {
+        s0 = grp_sum(s0, LG);
+        s1 = grp_sum(s1, LG);
+        if (pdf < P1 && (lane & (LP - 1)) == 0) {
             ldsw2(psum_base + 8u * pdf, s0, s1);
             if (xs) granule_store(xs, 8u * (unsigned)pdf, s0 * sg, s1 * sg);
         }
@@ -737,11 +831,18 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         // stage the emissions of step t into EM(t & 1) and account its offsets; S = the normaliser the step subtracts
         auto stage = [&](int t, const float (&S)[2]) {
             float E[2];
+#ifndef MM_PAIR_WIDE_SERVICE
+#define MM_PAIR_WIDE_SERVICE 1
+#endif
+            if constexpr (NJ > 4 && MM_PAIR_WIDE_SERVICE) {
+                pair_stage_em_wide<NJ>(L::EM(t & 1), L::RAW(0, 0) + L::RAWS * (unsigned)(t & 3), L::RAW(0, 1) + L::RAWS * (unsigned)(t & 3), frame_of(t),
+                                       U[0].len, U[1].len, P, sl, E);
+            } else {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                E[u] = pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, u) + L::RAWS * (unsigned)(t & 3), u, frame_of(t), U[u].len, P, sl);
-                cum[u] += (double)S[u] + (double)E[u];
+                for (int u = 0; u < 2; ++u) E[u] = pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, u) + L::RAWS * (unsigned)(t & 3), u, frame_of(t), U[u].len, P, sl);
             }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) cum[u] += (double)S[u] + (double)E[u];
             if (sl == 0) {
                 ldsw2(L::MS(t & 1), S[0], S[1]);
                 // the offset that turns the step's stored vector into log2 values: forward alpha~ includes the emission
@@ -791,6 +892,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         dma_raw(t0 + 4);
         __syncthreads();  // (2) starting vector in LDS, step t0 + 1 prepared
         // posteriors and per-frame log Z of step ts (its per-pdf sums are complete)
+        // (8-byte stores of the posteriors where every row of gamma allows them: pdfs contiguous, rows and batch strides even, the
+        // base 8-byte aligned)
+        const bool gwide = p.gsp == 1 && ((p.gsn | p.gsb) & 1) == 0 && ((__UINTPTR_TYPE__)p.gamma & 7) == 0;
         auto frames_of_step = [&](int ts, unsigned psum) {
             const int f = frame_of(ts);
             const bool live0 = f >= 1 && f <= U[0].len, live1 = f >= 1 && f <= U[1].len;
@@ -799,7 +903,11 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
 #pragma unroll
             for (int g = 0; g < H; ++g) xp[g] = (H > 1 && g != hset) ? xps_recv[g] + (ts & 3) * (int)L::XPS : nullptr;
             const bool writer = H == 1 || hset == 0;  // (every workgroup of a team has the sums of all pdfs: the first stores gamma)
-            if (!pair_finish_frames<NJ, H>(psum, P1, P, sl, p.gamma + (long long)U[0].b * p.gsb + (long long)(f - 1) * p.gsn,
+            if constexpr (H == 1 && NJ > 4 && MM_PAIR_WIDE_SERVICE) {
+                pair_finish_frames_wide<NJ>(psum, P1, P, sl, p.gamma + (long long)U[0].b * p.gsb + (long long)(f - 1) * p.gsn,
+                                            p.gamma + (long long)U[1].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp, live0 && U[0].valid,
+                                            live1 && U[1].valid, gwide, lt);
+            } else if (!pair_finish_frames<NJ, H>(psum, P1, P, sl, p.gamma + (long long)U[0].b * p.gsb + (long long)(f - 1) * p.gsn,
                                            p.gamma + (long long)U[1].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp,
                                            live0 && U[0].valid && writer, live1 && U[1].valid && writer, lt, xp, split_tag(ts, t0, 2),
                                            xdead ? 0ull : x_tmo)) {
@@ -1196,7 +1304,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             }
             if constexpr (PHASE == 1)  // C' * (A .* B) of the previous step (:155)
                 if (t - 1 > t0)
-                    pair_pdf_sums(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane, H > 1 ? xps_send + ((t - 1) & 3) * (int)L::XPS : nullptr,
+                    pair_pdf_sums<(NJ > 4 ? 1 : 3)>(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane, H > 1 ? xps_send + ((t - 1) & 3) * (int)L::XPS : nullptr,
                                   (H > 1 && split_tag(t - 1, t0, 2)) ? -1.f : 1.f);
             if constexpr (H > 1 && MM_SPLIT_CWPOLL) {
                 // The rows of the other sets of this step: chunk j (128 granules) of the q-th other set is item q * NG2 + j, and
@@ -1327,7 +1435,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         }
         if constexpr (PHASE == 1) {
             if (t1 > t0)
-                pair_pdf_sums(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane, H > 1 ? xps_send + (t1 & 3) * (int)L::XPS : nullptr,
+                pair_pdf_sums<(NJ > 4 ? 1 : 3)>(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane, H > 1 ? xps_send + (t1 & 3) * (int)L::XPS : nullptr,
                               (H > 1 && split_tag(t1, t0, 2)) ? -1.f : 1.f);
             __syncthreads();  // (a)
         }

@@ -242,9 +242,10 @@ __device__ __forceinline__ void dpair_pdf_sums(unsigned qbase, unsigned pdfse_ba
                 if (a0 + STR * k < a1) s0 += v[k];
             for (unsigned a = a0 + 4u * STR; a < a1; a += STR) s0 += ldsr_d(qbase + a);
         }
-        if constexpr (LG == 3) s0 = dgrp_sum8(s0);
-        else s0 = dpp_add_d<MM_DPP_XOR1, 0xF>(s0);
-        static_assert(LG == 3 || LG == 1, "lanes per pdf: 8 or 2");
+        static_assert(LG >= 1 && LG <= 3, "lanes per pdf: 2, 4 or 8");
+        s0 = dpp_add_d<MM_DPP_XOR1, 0xF>(s0);
+        if constexpr (LG >= 2) s0 = dpp_add_d<MM_DPP_XOR2, 0xF>(s0);
+        if constexpr (LG >= 3) s0 = dpp_add_d<MM_DPP_HALF_MIRROR, 0xF>(s0);
         if (pdf < P1 && (lane & (LP - 1)) == 0) {
             ldsw_d(psum_base + 8u * pdf, s0);
             if (xs) dgranule_store(xs, 8u * (unsigned)pdf, dsigned(s0, neg));
@@ -747,7 +748,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             }
             if constexpr (PHASE == 1)  // C' * (A .* B) of the previous step (:155)
                 if (t - 1 > t0)
-                    dpair_pdf_sums<(NJ > 4 ? 1 : 3)>(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane, H > 1 ? xps_send + ((t - 1) & 3) * (int)L::XPS : nullptr,
+                    dpair_pdf_sums<(NJ > 4 ? 1 : (NJ > 2 ? 2 : 3))>(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane, H > 1 ? xps_send + ((t - 1) & 3) * (int)L::XPS : nullptr,
                                    H > 1 && split_tag(t - 1, t0, 2) != 0u);
             if constexpr (H > 1) {
                 // The rows of the other sets of this step (pair_agent, MM_SPLIT_CWPOLL): chunk j (128 granules) of the q-th other
@@ -802,7 +803,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
         }
         if constexpr (PHASE == 1) {
             if (t1 > t0)
-                dpair_pdf_sums<(NJ > 4 ? 1 : 3)>(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane, H > 1 ? xps_send + (t1 & 3) * (int)L::XPS : nullptr,
+                dpair_pdf_sums<(NJ > 4 ? 1 : (NJ > 2 ? 2 : 3))>(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane, H > 1 ? xps_send + (t1 & 3) * (int)L::XPS : nullptr,
                                H > 1 && split_tag(t1, t0, 2) != 0u);
             __syncthreads();  // (a)
         }

@@ -494,7 +494,8 @@ __device__ __forceinline__ void pair_finish_frames_wide(unsigned psum, int P1, i
 // pdf sums of both utterances (q pairs in pdf-major order): 8 pdfs per wave and pass, 8 lanes per pdf
 // (split kernels: xs = the slot the partial sums are published in for the team, sg = +-1 carrying the tag)
 // (LG: log2 of the lanes per pdf -- 8 lanes, 8 pdfs per wave and pass; the instances of more than 256 pdfs, whose pdfs have a
-// handful of states each: 2 lanes, 32 pdfs per wave and pass -- 400 pdfs in one pass of the 15 compute waves instead of four)
+// handful of states each: 2 lanes, 32 pdfs per wave and pass -- 400 pdfs in one pass of the 15 compute waves instead of four;
+// 129 .. 250 pdfs: 4 lanes)
 template <int LG = 3>
 __device__ __forceinline__ void pair_pdf_sums(unsigned qbase, unsigned pdfse_base, unsigned psum_base, int P1, int wave, int NWC, int lane,
                                               float *xs = nullptr, float sg = 1.f) {
@@ -1304,7 +1305,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             }
             if constexpr (PHASE == 1)  // C' * (A .* B) of the previous step (:155)
                 if (t - 1 > t0)
-                    pair_pdf_sums<(NJ > 4 ? 1 : 3)>(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane, H > 1 ? xps_send + ((t - 1) & 3) * (int)L::XPS : nullptr,
+                    pair_pdf_sums<(NJ > 4 ? 1 : (NJ > 2 ? 2 : 3))>(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane, H > 1 ? xps_send + ((t - 1) & 3) * (int)L::XPS : nullptr,
                                   (H > 1 && split_tag(t - 1, t0, 2)) ? -1.f : 1.f);
             if constexpr (H > 1 && MM_SPLIT_CWPOLL) {
                 // The rows of the other sets of this step: chunk j (128 granules) of the q-th other set is item q * NG2 + j, and
@@ -1435,7 +1436,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         }
         if constexpr (PHASE == 1) {
             if (t1 > t0)
-                pair_pdf_sums<(NJ > 4 ? 1 : 3)>(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane, H > 1 ? xps_send + (t1 & 3) * (int)L::XPS : nullptr,
+                pair_pdf_sums<(NJ > 4 ? 1 : (NJ > 2 ? 2 : 3))>(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane, H > 1 ? xps_send + (t1 & 3) * (int)L::XPS : nullptr,
                               (H > 1 && split_tag(t1, t0, 2)) ? -1.f : 1.f);
             __syncthreads();  // (a)
         }

@@ -62,6 +62,9 @@ struct PairLay {
     static constexpr unsigned MS(int par) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + unsigned(par) * 64u; }      // {S_0, S_1} of a step
     static constexpr unsigned OWN(int k) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + 128u + unsigned(k) * 16u; }  // own offsets, k < 4: 2 doubles
     static constexpr unsigned XFLAG = 2 * RS2 + 8u * PC4 + 2u * PC8 + 192u;  // split kernels: != 0 when the whole team runs on one XCD
+    // split kernels: the maxima of the vector a step writes, {utterance 0, 1} as unsigned (linear values are >= 0), gathered by
+    // the waves that write it (LDS atomic max) and read -- then zeroed -- by the service wave a step later
+    static constexpr unsigned MX(int par) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + 200u + unsigned(par) * 8u; }
     // partner offsets, k < POFFN: requested with the partner row (two steps ahead, one with a ring of two rows), read when the
     // posteriors of the step are put out, two steps behind
     static constexpr int POFFN = NR == 2 ? 4 : 8;
@@ -373,7 +376,10 @@ __device__ __forceinline__ bool pair_finish_frames(unsigned psum, int P1, int P,
 #ifndef MM_XPS_GB
 #define MM_XPS_GB 4
 #endif
-        constexpr int GB = H < MM_XPS_GB ? H : MM_XPS_GB;
+#ifndef MM_XPS_GB2
+#define MM_XPS_GB2 1
+#endif
+        constexpr int GB = (NJ <= 2 && MM_XPS_GB2) ? H : (H < MM_XPS_GB ? H : MM_XPS_GB);  // (up to 128 pdfs: the registers hold all seven sets)
         mm_f32x2 tot[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) tot[j] = mm_f32x2{0.f, 0.f};
@@ -653,6 +659,13 @@ struct PairHand {  // what an agent hands from phase A to phase B, per utterance
 // What depends on the direction at run time is scalar arithmetic (frame_of, indices) and one select per finished row.
 template <int KA, int RS, int PHASE, int DIRT, int NJ, int H = 1, int RSH = 2 * RS, bool SMALL = false>
 __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hset = 0, int rdir = 0) {
+// (teams, tried in round 4 and left OFF: the waves that write a step's vector -- finishes and received rows -- gather its maxima
+// with LDS atomics instead of the service wave scanning the team's whole vector (3300 .. 4200 cycles of its step for teams of
+// 8).  The ~40 instructions per compute wave and step cost more than the scan they replace, which is not on the critical
+// path: 5000 states / 100 pdfs 7.7 -> 8.7 ms, the 4000-state graph 3.45 -> 3.63, 6000 / 300 9.7 -> 9.6, WSJ 1.79 -> 1.78.)
+#ifndef MM_SPLIT_MAXTRACK
+#define MM_SPLIT_MAXTRACK 0
+#endif
     extern __shared__ float lds[];
     const int DIR = DIRT < 0 ? __builtin_amdgcn_readfirstlane(rdir) : DIRT;
     const unsigned long long x_tmo = p.x_timeout;  // (teams) ticks of s_memrealtime a poll waits before it gives the team up
@@ -713,6 +726,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
     if constexpr (PHASE == 1)
         for (unsigned q = tid * 4u; q < 2u * RSH; q += NT * 4u) ldsw(L::Q(0) + q, 0.f);
     if (tid < 32) ldsw(L::MS(0) + 4u * tid, 0.f);
+    if (tid < 4) ldswu(L::MX(0) + 4u * tid, 0u);
     if (tid < 4) ldsw(L::EM(tid >> 1) + 8u * P1p + 4u * (tid & 1), MM_NINF);  // the emission slot of lanes without a row
     const int nslotwords = r.nslotrows * 128;
     for (int q = tid; q < nslotwords; q += NT) ldswu(L::SLOTS + 4u * q, as_global(r.slots)[q]);
@@ -953,7 +967,22 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             float mx[2];
             // (a graph of up to 511 states: 4 loads per lane instead of the region's 16 -- the service wave is the longest
             // actor of a small graph's step, BASELINE config 2)
-            if constexpr (small_graph) pair_scan_max<4>(L::PP(RD), (S1 + 2) >> 1, sl, mx[0], mx[1]);
+            // (teams: the waves that wrote the vector left its maxima in MX -- a scan of a team's whole vector, 48 KB for teams of 8,
+            // was the longest thing this wave did: 3300 .. 4200 of the 6500 cycles that bounded a step of theirs; the starting
+            // vector of a launch is scanned)
+            if constexpr (H > 1 && MM_SPLIT_MAXTRACK) {
+                if (t == t0 + 1) {
+                    pair_scan_max<(RS / 8 + 63) / 64>(L::PP(RD), (S1 + 2) >> 1, sl, mx[0], mx[1]);
+                } else {
+                    const mm_u32x2 w = ldsr2u(L::MX(RD));
+                    mx[0] = fast_log2(__builtin_bit_cast(float, (unsigned)__builtin_amdgcn_readfirstlane((int)w.x)));
+                    mx[1] = fast_log2(__builtin_bit_cast(float, (unsigned)__builtin_amdgcn_readfirstlane((int)w.y)));
+                }
+                if (sl == 0) {
+                    ldswu(L::MX(RD), 0u);
+                    ldswu(L::MX(RD) + 4u, 0u);
+                }
+            } else if constexpr (small_graph) pair_scan_max<4>(L::PP(RD), (S1 + 2) >> 1, sl, mx[0], mx[1]);
             else pair_scan_max<(RS / 8 + 63) / 64>(L::PP(RD), (S1 + 2) >> 1, sl, mx[0], mx[1]);
             MM_STAMP(3);
             if (t + 1 <= tEnd) {
@@ -1215,6 +1244,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         bool cdead = H > 1 && (p.x_sleep & 0x200) != 0;  // (split kernels) a poll of this wave timed out: it waits no more
         auto step = [&](auto RDc, int t) {
             constexpr int RD = decltype(RDc)::value, WR = 1 - RD;
+            float vmx0 = 0.f, vmx1 = 0.f;  // (teams) maxima of what this wave writes into the step's vector
             if (nslots > 0) {
                 constexpr unsigned rdoff = L::PP(RD);
                 mm_f32x2 x[2 * D];
@@ -1268,6 +1298,10 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                                                                    __builtin_fmaf(__builtin_fabsf(y1), 0.f, __builtin_fabsf(y1))));
                     const float p0 = fast_exp2(y0), p1 = fast_exp2(y1);
                     ldsw2(pos8 + L::PP(WR), p0, p1);
+                    if constexpr (H > 1 && MM_SPLIT_MAXTRACK) {
+                        vmx0 = max_nc(vmx0, p0);
+                        vmx1 = max_nc(vmx1, p1);
+                    }
                     if constexpr (H > 1) {
                         if (xplain) *reinterpret_cast<mm_f32x2 *>(reinterpret_cast<char *>(xw) + pos8) = mm_f32x2{p0 * xsg, p1 * xsg};
                         else granule_store(xw, pos8, p0 * xsg, p1 * xsg);
@@ -1369,6 +1403,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                                     w.z = sec[e] ? __builtin_bit_cast(float, v[e].z & 0x7fffffffu) : 0.f;
                                     w.w = sec[e] ? __builtin_bit_cast(float, v[e].w & 0x7fffffffu) : 0.f;
                                     *(__attribute__((address_space(3))) mm_f32x4 *)(__UINTPTR_TYPE__)dst2[e] = w;
+                                    vmx0 = max_nc(vmx0, max_nc(w.x, w.z));
+                                    vmx1 = max_nc(vmx1, max_nc(w.y, w.w));
                                     pnd[e] = false;
                                 }
                                 any = any || pnd[e];
@@ -1406,6 +1442,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                             w.z = second ? __builtin_bit_cast(float, v.z & 0x7fffffffu) : 0.f;
                             w.w = second ? __builtin_bit_cast(float, v.w & 0x7fffffffu) : 0.f;
                             *(__attribute__((address_space(3))) mm_f32x4 *)(__UINTPTR_TYPE__)dsta = w;
+                            vmx0 = max_nc(vmx0, max_nc(w.x, w.z));
+                            vmx1 = max_nc(vmx1, max_nc(w.y, w.w));
                             pend = false;
                         }
                         if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
@@ -1419,6 +1457,17 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                         }
                         __builtin_amdgcn_s_sleep(1);
                     }
+                }
+            }
+            if constexpr (H > 1 && MM_SPLIT_MAXTRACK) {
+                // (a finished or received value that is a NaN is dropped by v_max: the range marks catch what produced it)
+                const float m0 = wave_max_rl(vmx0), m1 = wave_max_rl(vmx1);
+                if (lane == 0) {
+                    typedef __attribute__((address_space(3))) unsigned lds_u32;
+                    (void)__hip_atomic_fetch_max((lds_u32 *)(__UINTPTR_TYPE__)L::MX(WR), __builtin_bit_cast(unsigned, m0), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+                    (void)__hip_atomic_fetch_max((lds_u32 *)(__UINTPTR_TYPE__)(L::MX(WR) + 4u), __builtin_bit_cast(unsigned, m1), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
             MM_STAMP(0);

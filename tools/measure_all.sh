@@ -13,6 +13,8 @@ python3 bench.py --workload lfmmi_den4000 --emissions peaky --no-cpu-baseline --
 python3 tools/sharpness.py > $P/$1_sharpness.txt 2>/dev/null
 # the N > 1 path of bench.py on this box's one GPU (two ranks over gloo)
 MM_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $P/$1_bench_lfmmi_den_2ranks_one_gpu_gloo.json
+# graphs beyond config 3's size: more pdfs, more states (teams of 4 / 8), beyond every fast path
+python3 tools/bench_big.py $P/$1_bench_big.json > /dev/null 2>&1
 # host cost of a batch of new numerator graphs
 python3 tools/host_cost.py $P/$1_host_cost.json > /dev/null 2>&1
 # per-step cycle stamps (diagnostic build, if it was made: make -C markovmodels.jl_amd/csrc stamps)

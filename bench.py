@@ -41,7 +41,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 
 def make_workload(wl, name):
     """(graph, frames, utterances per GPU, semiring).  lfmmi_den = BASELINE.json configs[2] (the metric's
     configuration); lexicon5000 = configs[4] (Viterbi); ergodic64 = configs[1]; l2r3 = configs[0]; wsj_den / wsj_num = the reference's
-    own benchmark graphs (misc/benchmark/README.md: T = 700, B = 128); lfmmi_den4000 = a 4000-state graph of config 3's family."""
+    own benchmark graphs (misc/benchmark/README.md: T = 700, B = 128); lfmmi_den4000 / lfmmi_den6000 / lfmmi_den_p400 = graphs of
+    config 3's family beyond config 3's size (teams of 4, teams of 8, 400 pdfs)."""
     if name == "lfmmi_den":
         return wl.lfmmi_denominator(2000, 84, seed=0), 1500, 256, "log"
     if name == "ergodic64":
@@ -56,6 +57,10 @@ def make_workload(wl, name):
         return wl.lexicon_fsm(5000, 84, seed=0), 1000, 128, "tropical"
     if name == "lfmmi_den4000":  # (config 3's graph family beyond the teams of two: teams of four workgroups)
         return wl.lfmmi_denominator(4000, 84, seed=1), 700, 128, "log"
+    if name == "lfmmi_den6000":  # (6000 states, 97 k arcs, 300 pdfs: teams of eight workgroups, five pdf passes)
+        return wl.lfmmi_denominator(6000, 300, seed=1), 700, 128, "log"
+    if name == "lfmmi_den_p400":  # (config 3's size with 400 pdfs: the pair kernels' instances of eight pdf passes)
+        return wl.lfmmi_denominator(2000, 400, seed=1), 1500, 256, "log"
     raise SystemExit(f"unknown workload {name}")
 
 

@@ -12,7 +12,9 @@ rows = [("lfmmi_den", "config 3 `lfmmi_den` (pair kernels; S = 2000, T = 1500, B
         ("lexicon5000", "config 5 `lexicon5000` (Viterbi, T = 1000, B = 128; row-lane kernels)"),
         ("ergodic64", "config 2 `ergodic64` (dense 64-state HMM, T = 500, B = 32; pair kernels)"),
         ("l2r3", "config 1 `l2r3` (3-state left-to-right HMM, T = 100, B = 1: the reference's CPU-runnable plumbing case; wave kernel, one workgroup -- a latency)"),
-        ("lfmmi_den4000", "`lfmmi_den4000`: config 3's family, 4000 states, 65 k arcs, B = 128, T = 700 (teams of 4: 1024 workgroups per phase in 4 rounds)")]
+        ("lfmmi_den4000", "`lfmmi_den4000`: config 3's family, 4000 states, 65 k arcs, B = 128, T = 700 (teams of 4)"),
+        ("lfmmi_den6000", "`lfmmi_den6000`: 6000 states, 97 k arcs, 300 pdfs, B = 128, T = 700 (teams of 8, 5 pdf passes)"),
+        ("lfmmi_den_p400", "`lfmmi_den_p400`: 2000 states, 33 k arcs, 400 pdfs, B = 256, T = 1500 (pair kernels, 8 pdf passes)")]
 print("| workload | ms / call | frames/s | `roofline.frac` | HBM traffic (TCC counters) vs algorithmic | CPU port, all host cores / 1 thread | source hash |")
 print("|---|---|---|---|---|---|---|")
 for w, name in rows:

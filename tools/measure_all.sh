@@ -1,6 +1,6 @@
 #!/bin/bash
 # all tracked workloads of one round: bash tools/measure_all.sh <tag>   (on the GPU box, from the repo root)
-for w in lfmmi_den wsj_den wsj_num lexicon5000 ergodic64 l2r3 lfmmi_den4000; do
+for w in lfmmi_den wsj_den wsj_num lexicon5000 ergodic64 l2r3 lfmmi_den4000 lfmmi_den6000 lfmmi_den_p400; do
   bash tools/measure.sh "$1" $w > gpurun_out/measure_$w.log 2>&1
   tail -2 gpurun_out/measure_$w.log
 done

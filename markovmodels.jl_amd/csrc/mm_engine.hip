@@ -2128,13 +2128,18 @@ int mm_batch_last_redo_count(mm_batch_t h, void *stream, int64_t *n) {
         std::vector<double> z(size_t(h->B) * 6);
         HIP_TRY(hipMemcpy(z.data(), h->last_z, z.size() * 8, hipMemcpyDeviceToHost));
         double sp = 0, lm = 0;
-        int worst_b = -1;
+        int worst_b = -1, below[5] = {0, 0, 0, 0, 0};
+        const double thr[5] = {-8, -11, -14, -17, -20};
         for (int64_t b = 0; b < h->B; ++b) {
             const double zmin = std::min(z[6 * b], z[6 * b + 1]), zmax = std::max(z[6 * b + 2], z[6 * b + 3]);
             if (zmax - zmin > sp) sp = zmax - zmin, worst_b = int(b);
-            lm = std::min(lm, std::min(z[6 * b + 4], z[6 * b + 5]));
+            const double l = std::min(z[6 * b + 4], z[6 * b + 5]);
+            lm = std::min(lm, l);
+            for (int k = 0; k < 5; ++k) below[k] += l < thr[k];
         }
-        fprintf(stderr, "[mm] per-frame log2 normalisers: largest spread %.3g (utterance %d), smallest overlap term %.3g\n", sp, worst_b, lm);
+        fprintf(stderr, "[mm] per-frame log2 normalisers: largest spread %.3g (utterance %d), smallest overlap term %.3g; utterances with an overlap term "
+                        "below -8 / -11 / -14 / -17 / -20: %d / %d / %d / %d / %d of %lld\n", sp, worst_b, lm, below[0], below[1], below[2], below[3], below[4],
+                (long long)h->B);
     }
     return MM_OK;
 }

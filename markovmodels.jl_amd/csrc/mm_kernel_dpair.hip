@@ -448,7 +448,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             const unsigned dst = L::AL(0) + (unsigned)(tt % L::NR) * (unsigned)RSH;
             (void)n4;
             dma_row_b128<NDM>(uni(src), (unsigned)sl, dst);  // (no clamping: see pair_agent)
-            dma_b32(reinterpret_cast<const unsigned *>(offs + f) + (sl & 1), L::POFF(0, 0) + 512u * (unsigned)(t & (L::POFFN - 1)));
+            if (sl < 2) dma_b32(reinterpret_cast<const unsigned *>(offs + f) + sl, L::POFF(0, 0) + 16u * (unsigned)(t & (L::POFFN - 1)));
         };
         constexpr int NDMA = NJ + (PHASE ? NDM + 1 : 0);  // DMAs issued per step
         // stage the emissions of step t into EM(t & 1) and account its offset; S = the normaliser the step subtracts
@@ -495,7 +495,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             const float lt = dpair_finish_frame<NJ>(psum, P1, P, sl, p.gamma + (long long)b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp, live);
             if (live) {
                 const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN(ts & 3));
-                const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, 0) + 512u * (unsigned)(ts & (L::POFFN - 1)));
+                const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, 0) + 16u * (unsigned)(ts & (L::POFFN - 1)));
                 const double z = (double)lt + own + oth;
                 zmin = z < zmin ? z : zmin;
                 zmax = z > zmax ? z : zmax;  // (NaN: neither comparison holds; the finish kernel tests zmin <= zmax)
@@ -611,7 +611,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             }
             if (live) {
                 const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN(ts & 3));
-                const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, 0) + 512u * (unsigned)(ts & (L::POFFN - 1)));
+                const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, 0) + 16u * (unsigned)(ts & (L::POFFN - 1)));
                 const double z = (double)lt + own + oth;
                 xzmin = z < xzmin ? z : xzmin;
                 xzmax = z > xzmax ? z : xzmax;

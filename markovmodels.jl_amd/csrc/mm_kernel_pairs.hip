@@ -67,9 +67,11 @@ struct PairLay {
     static constexpr unsigned MX(int par) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + 200u + unsigned(par) * 8u; }
     // partner offsets, k < POFFN: requested with the partner row (two steps ahead, one with a ring of two rows), read when the
     // posteriors of the step are put out, two steps behind
+    // (an entry is the double itself: its LDS-DMA runs with two lanes active -- with all 64 it wrote 256 bytes per entry, 2 to 4 KB
+    // of LDS for a ring of numbers)
     static constexpr int POFFN = NR == 2 ? 4 : 8;
-    static constexpr unsigned POFFB = 512u * POFFN;
-    static constexpr unsigned POFF(int k, int u) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + 256u + unsigned(2 * k + u) * 256u; }
+    static constexpr unsigned POFFB = 16u * POFFN;
+    static constexpr unsigned POFF(int k, int u) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + 256u + unsigned(2 * k + u) * 8u; }
     static constexpr unsigned PSUM(int par) { return 2 * RS2 + 8u * PC4 + 2u * PC8 + 256u + POFFB + unsigned(par) * PC8; }   // [pdf][2]
     static constexpr unsigned PDFSE = 2 * RS2 + 8u * PC4 + 4u * PC8 + 256u + POFFB;                // u16 [2 * P1]
     static constexpr unsigned FIX = PDFSE + PC4;
@@ -78,7 +80,7 @@ struct PairLay {
     static constexpr unsigned SLOTS = PHASE ? FIX + unsigned(NR + 2) * RSH : FIX;
 };
 inline size_t pair_lds_bytes(int RS, int phase, int nslotrows, int RSH = 0, int PC = 256) {
-    const size_t fix = size_t(4 * RS) + size_t(8 * 4 * PC) + size_t(4 * 8 * PC) + 256 + (pair_nr(RS, PC) == 2 ? 2048 : 4096) + size_t(4 * PC);
+    const size_t fix = size_t(4 * RS) + size_t(8 * 4 * PC) + size_t(4 * 8 * PC) + 256 + (pair_nr(RS, PC) == 2 ? 64 : 128) + size_t(4 * PC);
     return fix + (phase ? size_t(pair_nr(RS, PC) + 2) * size_t(RSH ? RSH : 2 * RS) : 0) + size_t(nslotrows) * 64 * 8;
 }
 
@@ -839,7 +841,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u)
-                dma_b32(reinterpret_cast<const unsigned *>(U[u].offs + f) + (sl & 1), L::POFF(0, u) + 512u * (unsigned)(t & (L::POFFN - 1)));
+                if (sl < 2) dma_b32(reinterpret_cast<const unsigned *>(U[u].offs + f) + sl, L::POFF(0, u) + 16u * (unsigned)(t & (L::POFFN - 1)));
         };
         constexpr int NDMA = 2 * NJ + (PHASE ? RSH / 1024 + 2 : 0);  // DMAs issued per step (a lower bound of the VMEM operations)
         constexpr int NDMA_SMALL = 2 * NJ + (PHASE ? 1 + 2 : 0);     // ... of a small graph (see dma_partner)
@@ -936,7 +938,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             for (int u = 0; u < 2; ++u)
                 if (u ? live1 : live0) {
                     const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN(ts & 3) + 8u * u);
-                    const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 512u * (unsigned)(ts & (L::POFFN - 1)));
+                    const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 16u * (unsigned)(ts & (L::POFFN - 1)));
                     const double z = (double)lt[u] + own + oth;
                     zmin[u] = z < zmin[u] ? z : zmin[u];
                     zmax[u] = z > zmax[u] ? z : zmax[u];  // (NaN: neither comparison holds; the finish kernel tests zmin <= zmax)
@@ -1110,7 +1112,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             for (int u = 0; u < 2; ++u)
                 if (u ? live1 : live0) {
                     const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN(ts & 3) + 8u * u);
-                    const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 512u * (unsigned)(ts & (L::POFFN - 1)));
+                    const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 16u * (unsigned)(ts & (L::POFFN - 1)));
                     const double z = (double)lt[u] + own + oth;
                     xzmin[u] = z < xzmin[u] ? z : xzmin[u];
                     xzmax[u] = z > xzmax[u] ? z : xzmax[u];

@@ -108,7 +108,9 @@ int mm_batch_destroy(mm_batch_t batch);
 /* Sum over the batch of S1 (rows of the block-diagonal system). */
 int64_t mm_batch_total_states(mm_batch_t batch);
 /* Names of the kernels a run entry launches for this batch (the engine picks them from the graphs' sizes and
- * shapes): entry 0 = mm_pdfposteriors_f32, 1 = mm_viterbi_f32.  Informational (bench.py quotes it). */
+ * shapes): entry 0 = mm_pdfposteriors_f32, 1 = mm_viterbi_f32, 2 = what the last mm_pdfposteriors_ex call on the batch launched
+ * (the recursion kernel; for ProbSemiring FSMs in float32 with general state maps, the emission GEMM C_hat * V_hat on the matrix
+ * cores before it).  Informational (bench.py quotes it). */
 int mm_batch_kernels(mm_batch_t batch, int entry, char *buf, size_t n);
 /* Allocate the internal workspace for runs of up to N frames now (synchronises if it has to grow). */
 int mm_batch_reserve(mm_batch_t batch, int64_t N);

@@ -2201,6 +2201,8 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
     } else if (entry == 1) {  // mm_viterbi_f32
         s = h->vit_ok ? "mm_vit_kernel + mm_vit_backtrace_kernel (mm_tropical_kernel + mm_backtrace_kernel when the int32 back-pointers are asked for)"
                       : "mm_tropical_kernel + mm_backtrace_kernel";
+    } else if (entry == 2) {  // mm_pdfposteriors_ex: what its last call on this batch launched
+        s = h->gen.last_kernels.empty() ? std::string("mm_generic_kernel (not called yet)") : h->gen.last_kernels;
     } else {
         return fail(MM_ERR_INVALID, "mm_batch_kernels: unknown entry");
     }

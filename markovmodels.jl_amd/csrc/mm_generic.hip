@@ -28,6 +28,10 @@ struct mm_statemap_view {  // device CSR of C_hat (S1 x P1) and of its transpose
     const void *cval;
     const int *tptr, *tcol;    // C_hat' rows: pdf -> (state, weight)
     const void *tval;
+    // ProbSemiring, float32, a general map: C_hat as a DENSE matrix [S1 rounded up to 32][dense_ld] (zero padded, dense_ld even)
+    // -- the B operand of the emission GEMM on the matrix cores (mm_prob_emission_mfma_kernel); NULL otherwise
+    const float *dense;
+    int dense_ld, pad_;
 };
 
 template <typename T>
@@ -44,6 +48,10 @@ struct GenUtt {
     GenFsmDev<T> f;
     mm_statemap_view c;
     long long ws_off;  // offset of the utterance's alpha / beta arrays in the workspace (elements)
+    // (ProbSemiring, float32, a general map) the state-level emissions C_hat * V_hat of every frame, computed ahead by the
+    // emission GEMM: [N1][E_ld] (E_ld = S1 rounded up to 32); NULL: the recursion gathers them itself
+    const T *E;
+    long long E_ld;
 };
 
 template <typename T, int SR>
@@ -80,6 +88,7 @@ __global__ void __launch_bounds__(256) mm_generic_kernel(const GenUtt<T> *utts, 
     T *zp = reinterpret_cast<T *>(smem);  // [P1] per-pdf sums of a frame, then [1] the frame's sum
     // state-level emission (C_hat * V_hat)[s, n]   (src/inference.jl:150)
     auto em = [&](int s, int n) {
+        if (u.E) return u.E[(long long)n * u.E_ld + s];
         const T *cv = static_cast<const T *>(u.c.cval);
         T acc = K::zero();
         for (int k = u.c.cptr[s]; k < u.c.cptr[s + 1]; ++k) acc = K::add(acc, K::mul(cv[k], Vb[(long long)n * vsn + u.c.ccol[k]]));
@@ -143,6 +152,42 @@ __global__ void __launch_bounds__(256) mm_generic_kernel(const GenUtt<T> *utts, 
     if (tid == 0) ttl[blockIdx.x] = tmin;
 }
 
+// The one place of the path where the matrix cores apply (BASELINE north star: "MFMA only for the dense emission GEMM in the
+// probability semiring"): lhs = C_hat * V_hat (src/inference.jl:150) is a plain GEMM when K is the ProbSemiring -- multiply and
+// add of real numbers -- and C_hat is a general (mixture) map; in the Log / Tropical semirings the same product is a
+// log-sum-exp / a maximum per entry and stays in the recursion kernel.  Per utterance E[N1 x S1] = V_hat'[N1 x P1] * C_hat'[P1 x S1]
+// in float32 on v_mfma_f32_32x32x2f32: a wave owns a 32 x 32 tile of E (32 frames x 32 states), K runs over the pdfs two at a
+// time; operands straight from global memory (both matrices are small and cache resident: this is the correctness-first
+// path's GEMM, not a tuned one).  Lane l supplies A[row l % 32][k l / 32] and B[k l / 32][column l % 32]; accumulator v of lane l
+// is D[8 (v / 4) + 4 (l / 32) + v % 4][l % 32].
+typedef float mm_acc16 __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256) mm_prob_emission_mfma_kernel(const GenUtt<float> *utts, const float *V, long long vsb, long long vsn,
+                                                                    int N1) {
+    const GenUtt<float> &u = utts[blockIdx.z];
+    if (!u.E || !u.c.dense) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, kk = lane >> 5;
+    const int n0 = (int)blockIdx.x * 32, s0 = ((int)blockIdx.y * 4 + wave) * 32;
+    if (s0 >= (int)u.E_ld) return;
+    const int P1 = u.c.P1, ld = u.c.dense_ld;
+    const int n = n0 + r < N1 ? n0 + r : N1 - 1;
+    const float *arow = V + (long long)blockIdx.z * vsb + (long long)n * vsn;  // V_hat[:, n]
+    const float *brow = u.c.dense + (long long)(s0 + r) * ld;                  // C_hat[s, :]
+    mm_acc16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    for (int k0 = 0; k0 < ld; k0 += 2) {
+        const int q = k0 + kk;
+        const float a = q < P1 ? arow[q] : 0.f, b = brow[q];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    float *E = const_cast<float *>(u.E);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int nr = n0 + 8 * (v / 4) + 4 * kk + (v % 4);
+        if (nr < N1) E[(long long)nr * u.E_ld + s0 + r] = acc[v];
+    }
+}
+
 // ---- host side
 namespace {
 
@@ -150,6 +195,8 @@ struct DevFsm {  // owns the device copy of one FSM in one precision
     void *blob = nullptr;
     int S1 = 0, P1 = 0;
     size_t off_ptr[2], off_col[2], off_val[2], off_init, off_cptr, off_ccol, off_cval, off_tptr, off_tcol, off_tval;
+    size_t off_dense = 0;
+    int dense_ld = 0;  // > 0: the blob holds C_hat as a dense float matrix (ProbSemiring maps in float32)
 };
 
 template <typename T>
@@ -241,6 +288,9 @@ mm_statemap_view view_of(const DevFsm *d, int val_bytes) {
     v.tptr = reinterpret_cast<const int *>(b + d->off_tptr);
     v.tcol = reinterpret_cast<const int *>(b + d->off_tcol);
     v.tval = b + d->off_tval;
+    v.dense = d->dense_ld > 0 ? reinterpret_cast<const float *>(b + d->off_dense) : nullptr;
+    v.dense_ld = d->dense_ld;
+    v.pad_ = 0;
     return v;
 }
 
@@ -288,6 +338,16 @@ static int statemap_to_device(mm_statemap_s *m, DevFsm **out) {
     push(h, d->off_tptr, tptr);
     push(h, d->off_tcol, tcol);
     push(h, d->off_tval, tval);
+    if (m->semiring == MM_PROB && sizeof(T) == 4) {  // the B operand of the emission GEMM (at most 64 MB: else the recursion gathers)
+        const size_t S1r = (size_t(m->S1) + 31) / 32 * 32, ld = (size_t(m->P1) + 1) / 2 * 2;
+        if (S1r * ld * 4 <= (size_t(64) << 20)) {
+            std::vector<float> dense(S1r * ld, 0.f);
+            for (int64_t s = 0; s < m->S1; ++s)
+                for (int64_t k = m->ptr[size_t(s)]; k < m->ptr[size_t(s) + 1]; ++k) dense[size_t(s) * ld + size_t(m->col[size_t(k)])] += float(m->val[size_t(k)]);
+            push(h, d->off_dense, dense);
+            d->dense_ld = int(ld);
+        }
+    }
     if (hipMalloc(&d->blob, h.size() ? h.size() : 256) != hipSuccess ||
         hipMemcpy(d->blob, h.data(), h.size(), hipMemcpyHostToDevice) != hipSuccess) {
         if (d->blob) (void)hipFree(d->blob);
@@ -300,10 +360,19 @@ static int statemap_to_device(mm_statemap_s *m, DevFsm **out) {
 }
 
 // workspace elements (of T) of one call: alpha and beta of every utterance, [N1][S1] each
-static size_t generic_ws_elems(int64_t B, const mm_fsm_t *fsms, int64_t N1) {
+// (ProbSemiring: + the state-level emissions of every frame, [N1][S1 rounded up to 32], which the emission GEMM writes)
+static size_t generic_ws_elems(int64_t B, const mm_fsm_t *fsms, int64_t N1, int semiring) {
     size_t n = 0;
-    for (int64_t b = 0; b < B; ++b) n += size_t(2) * size_t(N1) * size_t(mm_fsm_gen_view(fsms[b])->S1);
+    for (int64_t b = 0; b < B; ++b) {
+        const size_t S1 = size_t(mm_fsm_gen_view(fsms[b])->S1);
+        n += size_t(2) * size_t(N1) * S1 + (semiring == MM_PROB ? size_t(N1) * ((S1 + 31) / 32 * 32) : 0);
+    }
     return n;
+}
+// (MM_GENERIC_NO_MFMA, read once: the recursion kernel gathers the emissions itself -- what the emission GEMM is measured against)
+static bool generic_no_mfma() {
+    static const bool off = getenv("MM_GENERIC_NO_MFMA") != nullptr;
+    return off;
 }
 // grow a device buffer of the batch (never while the stream is capturing: the old pointer may be baked into a graph)
 static int grow(void **buf, size_t *have, size_t want, hipStream_t stream) {
@@ -325,8 +394,9 @@ template <typename T, int SR>
 static int run_generic(mm_batch_t batch, int64_t B, const mm_fsm_t *fsms, const mm_statemap_t *maps, int32_t P1, const T *V, int64_t vsb,
                        int64_t vsn, int64_t N1, T *gamma, int64_t gsb, int64_t gsn, int64_t gsp, T *ttl, hipStream_t stream) {
     std::vector<GenUtt<T>> utts(static_cast<size_t>(B));
-    long long ws_elems = 0;
-    int maxP1 = 0;
+    std::vector<long long> e_off(static_cast<size_t>(B), -1);
+    long long ws_elems = 0, max_S1r = 0;
+    int maxP1 = 0, n_mfma = 0;
     for (int64_t b = 0; b < B; ++b) {
         FsmGenView *g = mm_fsm_gen_view(fsms[b]);
         DevFsm *d = nullptr;
@@ -361,11 +431,20 @@ static int run_generic(mm_batch_t batch, int64_t B, const mm_fsm_t *fsms, const 
         maxP1 = std::max(maxP1, int(u.c.P1));
         u.ws_off = ws_elems;
         ws_elems += 2ll * N1 * d->S1;
+        if (SR == MM_PROB && sizeof(T) == 4 && u.c.dense && !generic_no_mfma()) {  // (its address is filled in below: the workspace may move)
+            u.E_ld = (long long)(d->S1 + 31) / 32 * 32;
+            e_off[size_t(b)] = ws_elems;
+            ws_elems += N1 * u.E_ld;
+            n_mfma++;
+            max_S1r = std::max<long long>(max_S1r, u.E_ld);
+        }
     }
     // workspace and descriptors live with the batch: no allocation, no synchronisation in the steady state
     GenScratch *sc = mm_batch_gen_scratch(batch);
     int rc = grow(&sc->ws, &sc->ws_bytes, sizeof(T) * size_t(ws_elems), stream);
     if (rc) return rc;
+    for (int64_t b = 0; b < B; ++b)
+        if (e_off[size_t(b)] >= 0) utts[size_t(b)].E = static_cast<const T *>(sc->ws) + e_off[size_t(b)];
     const size_t ub = sizeof(GenUtt<T>) * size_t(B);
     if (sc->utts_bytes < ub) sc->host.clear();
     rc = grow(&sc->d_utts, &sc->utts_bytes, ub, stream);
@@ -374,6 +453,17 @@ static int run_generic(mm_batch_t batch, int64_t B, const mm_fsm_t *fsms, const 
         // (stream-ordered behind the last call's kernel; the source is the batch's own image, alive as long as the batch)
         sc->host.assign(reinterpret_cast<const char *>(utts.data()), reinterpret_cast<const char *>(utts.data()) + ub);
         HIP_TRY(hipMemcpyAsync(sc->d_utts, sc->host.data(), ub, hipMemcpyHostToDevice, stream));
+    }
+    sc->last_kernels = std::string("mm_generic_kernel<") + (sizeof(T) == 4 ? "float" : "double") + "," + (SR == MM_LOG ? "log" : SR == MM_TROPICAL ? "tropical" : "prob") + ">";
+    if constexpr (SR == MM_PROB && sizeof(T) == 4) {
+        if (n_mfma > 0) {  // C_hat * V_hat of every frame on the matrix cores, for the utterances whose map is a general one
+            hipLaunchKernelGGL(mm_prob_emission_mfma_kernel, dim3(unsigned((N1 + 31) / 32), unsigned((max_S1r / 32 + 3) / 4), unsigned(B)), dim3(256), 0,
+                               stream, static_cast<const GenUtt<float> *>(sc->d_utts), reinterpret_cast<const float *>(V), (long long)vsb, (long long)vsn,
+                               int(N1));
+            HIP_TRY(hipGetLastError());
+            sc->last_kernels = "mm_prob_emission_mfma_kernel (v_mfma_f32_32x32x2f32: C_hat * V_hat of " + std::to_string(n_mfma) + " utterances), then " +
+                               sc->last_kernels;
+        }
     }
     hipLaunchKernelGGL((mm_generic_kernel<T, SR>), dim3(unsigned(B)), dim3(256), size_t(maxP1 + 1) * sizeof(T), stream,
                        static_cast<const GenUtt<T> *>(sc->d_utts), V, (long long)vsb, (long long)vsn, int(N1), static_cast<T *>(sc->ws), gamma,
@@ -437,7 +527,7 @@ int mm_batch_reserve_ex(mm_batch_t batch, int val_bytes, int64_t N1) {
     HIP_TRY(hipGetDevice(&dev));
     if (dev != device) return mm_fail(MM_ERR_INVALID, "mm_batch_reserve_ex: batch lives on another device");
     GenScratch *sc = mm_batch_gen_scratch(batch);
-    int rc = grow(&sc->ws, &sc->ws_bytes, size_t(val_bytes) * generic_ws_elems(B, fsms, N1), nullptr);
+    int rc = grow(&sc->ws, &sc->ws_bytes, size_t(val_bytes) * generic_ws_elems(B, fsms, N1, semiring), nullptr);
     if (rc) return rc;
     if (sc->utts_bytes < sizeof(GenUtt<double>) * size_t(B)) sc->host.clear();
     return grow(&sc->d_utts, &sc->utts_bytes, sizeof(GenUtt<double>) * size_t(B), nullptr);

@@ -74,6 +74,7 @@ struct GenScratch {
     void *d_utts = nullptr;
     size_t utts_bytes = 0;
     std::vector<char> host;  // what d_utts holds
+    std::string last_kernels;  // what the last call of the generic entry launched (mm_batch_kernels, entry 2)
 };
 GenScratch *mm_batch_gen_scratch(mm_batch_t h);
 int mm_batch_gen_view(mm_batch_t h, int64_t *B, const mm_fsm_t **fsms, int *semiring, int *device);

@@ -418,6 +418,14 @@ class BatchedFSM:
         check(lib.mm_batch_kernels(self._h, 0 if semiring == "log" else 1, buf, 512))
         return buf.value.decode()
 
+    def kernels_generic(self) -> str:
+        """What the last call of the generic entry (mm_pdfposteriors_ex) launched for this batch (informational)."""
+        import ctypes
+
+        buf = ctypes.create_string_buffer(512)
+        check(lib.mm_batch_kernels(self._h, 2, buf, 512))
+        return buf.value.decode()
+
     def viterbi(self, V, lens=None, return_backpointers=False):
         """Best paths: (path[B, N] 0-based states, -1 beyond len; score[B][, bp[N+1, sum S1]])."""
         torch, Vt, lt, as_numpy = self._prep(V, lens)

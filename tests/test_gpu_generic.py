@@ -190,3 +190,45 @@ def test_generic_entry_is_asynchronous_and_capturable(mm, wl, oracle, torch):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(gam, gam0) and torch.equal(ttl, ttl0)
+
+
+@pytest.mark.parametrize("S,P", [(25, 5), (130, 70)])
+def test_prob_semiring_emission_gemm_on_the_matrix_cores(mm, wl, oracle, torch, S, P):
+    """ProbSemiring FSMs with a general (mixture) state map in float32: lhs = C_hat * V_hat (src/inference.jl:150) is a plain
+    GEMM there, and the generic entry computes it on the matrix cores (mm_prob_emission_mfma_kernel, v_mfma_f32_32x32x2f32)
+    before the recursion kernel -- the one MFMA site BASELINE's north star names.  A DENSE C_hat (every state a mixture of all
+    pdfs), matrices V_hat that expand() did not make, two utterances with different maps (one of them the FSM's own one-hot
+    map: no GEMM for it); against the float64 oracle, and against the same call with the GEMM switched off."""
+    import scipy.sparse as sp
+
+    o, _ = oracle
+    K = o.PROB
+    g = wl.random_fsm(S, P, 3.0, seed=7)
+    S1, P1, N1 = g.S + 1, g.P + 1, 45
+    rng = np.random.default_rng(S)
+    Cd = rng.random((S1, P1)) * (rng.random((S1, P1)) < 0.6)  # a dense mixture map, 60 % filled
+    Cd[:g.S, g.P] = 0.0  # real states do not read the phony pdf,
+    Cd[g.S, :] = 0.0     # the final state reads nothing else
+    Cd[g.S, g.P] = 1.0
+    Cd[np.arange(g.S), g.state2pdf] += 0.5  # (no empty row)
+    Cd /= Cd.sum(1, keepdims=True)           # (mixture weights: unnormalised, 44 frames of 130 states overflow float32 -- in the reference too)
+    rows, cols = np.nonzero(Cd)
+    vals = Cd[rows, cols]
+    Vh = [np.exp(0.5 * rng.standard_normal((P1, N1))) for _ in range(2)]
+    f = graphs.to_oracle(o, lin(g), "prob", np.float64)
+    C_or = o.csc_from_coo(list(rows), list(cols), vals, (S1, P1), K)
+    own = o.csc_from_coo(list(range(S1)), list(g.state2pdf) + [g.P], np.ones(S1), (S1, P1), K)
+    g_ref, t_ref = o.pdfposteriors(o.rawunion([f, f]), Vh, [C_or, own])
+    Cm = mm.GeneralStateMap(sp.csr_matrix((vals, (rows, cols)), shape=(S1, P1)), "prob")
+    fsm = wl.to_fsm(mm, lin(g), "prob", np.float32)
+    cf = mm.compile(fsm, mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(cf, cf)
+    gam, ttl = bf.pdfposteriors_generic(Vh, [Cm, None])
+    assert "mm_prob_emission_mfma_kernel" in bf.kernels_generic() and "1 utterances" in bf.kernels_generic(), bf.kernels_generic()
+    assert gam.dtype == np.float32
+    assert np.allclose(gam, g_ref, rtol=3e-5, atol=3e-6) and np.allclose(ttl, t_ref, rtol=3e-5)
+    # float64 FSMs: no float64 GEMM (the recursion kernel gathers), same answer
+    bf64 = mm.batch(*([mm.compile(wl.to_fsm(mm, lin(g), "prob", np.float64), mm.statemap(g.state2pdf, g.P))] * 2))
+    g64, t64 = bf64.pdfposteriors_generic(Vh, [Cm, None])
+    assert "mfma" not in bf64.kernels_generic()
+    assert np.allclose(g64, g_ref, rtol=1e-10, atol=1e-12) and np.allclose(t64, t_ref, rtol=1e-10)

@@ -28,7 +28,7 @@ struct mm_statemap_view {  // device CSR of C_hat (S1 x P1) and of its transpose
     const void *cval;
     const int *tptr, *tcol;    // C_hat' rows: pdf -> (state, weight)
     const void *tval;
-    // ProbSemiring, float32, a general map: C_hat as a DENSE matrix [S1 rounded up to 32][dense_ld] (zero padded, dense_ld even)
+    // ProbSemiring, float32, a general map: C_hat as a DENSE matrix [S1 rounded up to 32][dense_ld] (zero padded, dense_ld a multiple of 16)
     // -- the B operand of the emission GEMM on the matrix cores (mm_prob_emission_mfma_kernel); NULL otherwise
     const float *dense;
     int dense_ld, pad_;
@@ -158,8 +158,8 @@ __global__ void __launch_bounds__(256) mm_generic_kernel(const GenUtt<T> *utts, 
 // log-sum-exp / a maximum per entry and stays in the recursion kernel.  Per utterance E[N1 x S1] = V_hat'[N1 x P1] * C_hat'[P1 x S1]
 // in float32 on v_mfma_f32_32x32x2f32: a wave owns a 32 x 32 tile of E (32 frames x 32 states), K runs over the pdfs two at a
 // time; operands straight from global memory (both matrices are small and cache resident: this is the correctness-first
-// path's GEMM, not a tuned one).  Lane l supplies A[row l % 32][k l / 32] and B[k l / 32][column l % 32]; accumulator v of lane l
-// is D[8 (v / 4) + 4 (l / 32) + v % 4][l % 32].
+// path's GEMM, not a tuned one).  Lane l supplies A[row l % 32][a pdf of half l / 32] and B[the same pdf][column l % 32];
+// accumulator v of lane l is D[8 (v / 4) + 4 (l / 32) + v % 4][l % 32].
 typedef float mm_acc16 __attribute__((ext_vector_type(16)));
 __global__ void __launch_bounds__(256) mm_prob_emission_mfma_kernel(const GenUtt<float> *utts, const float *V, long long vsb, long long vsn,
                                                                     int N1) {
@@ -175,10 +175,27 @@ __global__ void __launch_bounds__(256) mm_prob_emission_mfma_kernel(const GenUtt
     mm_acc16 acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-    for (int k0 = 0; k0 < ld; k0 += 2) {
-        const int q = k0 + kk;
-        const float a = q < P1 ? arow[q] : 0.f, b = brow[q];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    // 16 pdfs per trip.  Which pdf a (lane half, instruction) pair takes is free as long as A and B agree: half kk takes the 8
+    // CONSECUTIVE pdfs k0 + 8 kk .. + 7, so a lane reads its 8 values of either operand with two 16-byte loads from its own row
+    // (one load, one wait, one instruction at a time, a pdf per load, the kernel ran at 15 TFLOP/s; with the 16 scalar loads of
+    // a trip issued ahead of its 8 instructions at 17: every load instruction touched 64 cache lines for 4 bytes of each).
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // (a row of V_hat starts at any multiple of 4 bytes)
+    for (int k0 = 0; k0 < ld; k0 += 16) {
+        const int q0 = k0 + 8 * kk;
+        float a[8], b[8];
+        const f4u b0 = *reinterpret_cast<const f4u *>(brow + q0), b1 = *reinterpret_cast<const f4u *>(brow + q0 + 4);
+        if (q0 + 8 <= P1) {
+            const f4u a0 = *reinterpret_cast<const f4u *>(arow + q0), a1 = *reinterpret_cast<const f4u *>(arow + q0 + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = a0[i], a[4 + i] = a1[i];
+        } else {  // (the last pdfs of a row: nothing is read beyond them)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = q0 + i < P1 ? arow[q0 + i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = b0[i], b[4 + i] = b1[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
     }
     float *E = const_cast<float *>(u.E);
 #pragma unroll
@@ -339,7 +356,7 @@ static int statemap_to_device(mm_statemap_s *m, DevFsm **out) {
     push(h, d->off_tcol, tcol);
     push(h, d->off_tval, tval);
     if (m->semiring == MM_PROB && sizeof(T) == 4) {  // the B operand of the emission GEMM (at most 64 MB: else the recursion gathers)
-        const size_t S1r = (size_t(m->S1) + 31) / 32 * 32, ld = (size_t(m->P1) + 1) / 2 * 2;
+        const size_t S1r = (size_t(m->S1) + 31) / 32 * 32, ld = (size_t(m->P1) + 15) / 16 * 16;
         if (S1r * ld * 4 <= (size_t(64) << 20)) {
             std::vector<float> dense(S1r * ld, 0.f);
             for (int64_t s = 0; s < m->S1; ++s)

@@ -19,6 +19,9 @@ Prints ONE JSON line on rank 0 (see the task contract), including
   "cpu_baseline": the C oracle (a port of the reference's CPU operation order;
                   the Julia reference cannot run here) timed on the host cores
                   on a bounded sample of the same workload.
+  "sharp":        the same workload on the inputs of a trained acoustic model (log-softmax of 10 x N(0,1)), measured in the
+                  same process after the timed region: ms_per_step, frac, redo_utterances, which kernels ran
+  "per_rank":     (N > 1) every rank's kernel time per call and the time of its log Z all-reduce
 """
 from __future__ import annotations
 
@@ -237,6 +240,61 @@ def self_launch(args):
     sys.exit(rc)
 
 
+def reduce_over_ranks(dist, torch, rdev, elapsed, frames_local, kernel_ms, allreduce_ms):
+    """What rank 0 reports for a run of `world` ranks: the step time is the MAX over ranks of the barrier-bracketed elapsed time,
+    the work the SUM of the ranks' frames (value = sum frames x steps / max elapsed), plus every rank's own kernel time per
+    call and the time of its log Z all-reduce so that a bad scaling curve can be attributed (a slow rank, a slow collective)."""
+    world = dist.get_world_size()
+    mine = torch.tensor([elapsed, float(frames_local), kernel_ms, allreduce_ms], device=rdev, dtype=torch.float64)
+    rows = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(rows, mine)
+    tab = torch.stack(rows).cpu().numpy()
+    return {
+        "elapsed": float(tab[:, 0].max()),
+        "frames_total": int(round(tab[:, 1].sum())),
+        "kernel_ms": [float(x) for x in tab[:, 2]],
+        "allreduce_ms": [float(x) for x in tab[:, 3]],
+        "elapsed_per_rank": [float(x) for x in tab[:, 0]],
+    }
+
+
+def sharp_record(torch, bf, g, B, N, gamma, lens, abytes, rank):
+    """The same workload on the inputs a TRAINED acoustic model produces -- log-softmax of 10 x N(0,1): the forward and the
+    backward mass of a frame overlap ~160 log2 below their maxima, beyond float32's exponent range, so the float64 kernels do
+    the work (examples/test_cuda.jl:124-143 feeds network outputs).  Measured in this process AFTER the timed headline, with
+    the engine's own policy (mm_batch_set_exact_policy auto: the second call on such inputs skips the float32 kernels)."""
+    gen = torch.Generator(device="cuda").manual_seed(5000 + rank)
+    Vs = torch.log_softmax(10.0 * torch.randn(B, N, g.P, device="cuda", generator=gen), dim=-1)
+    for _ in range(4):
+        bf.pdfposteriors(Vs, lens, out=gamma)
+        torch.cuda.synchronize()  # (the policy reads the last FINISHED call's marks)
+    K = 10
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        ttl = bf.pdfposteriors(Vs, lens, out=gamma)[1]
+        b.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / K
+    kms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    return {
+        "emissions": "log-softmax(10 x N(0,1))",
+        "steps": K,
+        "ms_per_step": 1e3 * wall,
+        "kernel_ms": kms,
+        "value": float(lens.sum().item()) / wall,
+        "unit": "frames/s",
+        "frac": abytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "redo_utterances": bf.last_redo_count(),
+        "fallback_utterances": bf.last_fallback_count(),
+        "exact_first": bool(bf.last_exact_first()),
+        "kernels": bf.kernels("log"),
+        "finite": bool(torch.isfinite(ttl).all().item()),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,6 +305,7 @@ def main():
     ap.add_argument("--frames", type=int, default=0)
     ap.add_argument("--varlen", action="store_true", help="lengths U[N/2, N] instead of all N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sharp", action="store_true", help="skip the `sharp` sub-record (the same workload on sharp emissions, after the timed region)")
     ap.add_argument("--emissions", default="randn", choices=["randn", "peaky", "peaky_offset"],
                     help="randn: N(0,1) log-likelihoods (default); peaky: log-softmax of 10 x N(0,1) (a sharp acoustic model); "
                          "peaky_offset: the same shifted by -300 nats (GMM-like scores)")
@@ -313,7 +372,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -324,24 +383,26 @@ def main():
         ev[i][1].record()
         if use_dist:
             mm.dist.allreduce_logz(ttl)
+            ev[i][2].record()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kernel_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    # (over gloo the reduction is a host round trip inside allreduce_logz: the events then bracket the device's idle time)
+    allreduce_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if use_dist else 0.0
     frames_total = frames_local
+    per_rank = None
     if use_dist:
-        rdev = "cpu" if backend == "gloo" else "cuda"
-        t = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        f = torch.tensor([frames_local], device=rdev, dtype=torch.float64)
-        dist.all_reduce(f, op=dist.ReduceOp.SUM)
-        frames_total = int(f.item())
+        per_rank = reduce_over_ranks(dist, torch, "cpu" if backend == "gloo" else "cuda", elapsed, frames_local, kernel_ms, allreduce_ms)
+        elapsed, frames_total = per_rank["elapsed"], per_rank["frames_total"]
     assert os.environ.get("MM_BENCH_NOCHECK") or torch.isfinite(ttl).all(), "non-finite log-likelihoods"
     # utterances of the last call that the fast kernels handed to the exact ones (flag and redo): they were computed twice
     redo = bf.last_redo_count() if semiring == "log" else 0
 
+    sharp = None
+    if semiring == "log" and args.emissions == "randn" and not args.no_sharp and args.posterior_floor <= 0:
+        sharp = sharp_record(torch, bf, g, B, N, gamma, lens, algorithmic_bytes(g, B, N, frames_local, semiring), rank)
     if rank == 0:
         abytes = algorithmic_bytes(g, B, N, frames_local, semiring)
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
@@ -382,6 +443,15 @@ def main():
                 "kernel_ms": kernel_ms,
             },
         }
+        if sharp is not None:
+            out["sharp"] = sharp
+        if per_rank is not None:
+            # every rank's own numbers: kernel time per call (HIP events), the log Z all-reduce behind it, the barrier-bracketed wall
+            out["per_rank"] = {
+                "kernel_ms": per_rank["kernel_ms"], "kernel_ms_min": min(per_rank["kernel_ms"]), "kernel_ms_max": max(per_rank["kernel_ms"]),
+                "allreduce_ms": per_rank["allreduce_ms"], "allreduce_ms_max": max(per_rank["allreduce_ms"]),
+                "elapsed_s": per_rank["elapsed_per_rank"], "backend": backend,
+            }
         if semiring == "tropical":
             # SURVEY 8(d)'s figure counts int32 back-pointers; the row-lane kernels write ONE byte per state and frame (rows padded to
             # 256 bytes) and read it back once: what the kernel actually moves, next to what the problem is priced at

@@ -26,7 +26,10 @@
  *     instead of invalidating the pointers earlier captures baked in.
  *   - weights/likelihoods are natural-log values of the Log/Tropical
  *     semirings (zero(K) = -inf, one(K) = 0), bit-compatible with the
- *     reference's Array{K} storage.  The engine computes in float32.
+ *     reference's Array{K} storage.  The fast entries (mm_*_f32) take and return float32 like the reference's
+ *     Float32 FSMs; inside, the linear-domain kernels carry float32 or -- for inputs beyond float32's exponent range --
+ *     float64 values (mm_batch_set_exact_policy); the generic entry (mm_pdfposteriors_ex) and the linear algebra
+ *     (mm_spmv / mm_spmm / mm_svdv) compute in the caller's float type.
  *   - the FSM is the reference's *extended* system (src/fsm.jl:19-28): S1 =
  *     S + 1 states, the last one being the phony final state (self loop of
  *     weight one); P1 = P + 1 pdfs, the last one being the phony pdf that
@@ -43,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 2 /* 2: mm_pdfposteriors_ex takes the rows of V_hat (P1); mm_batch_reserve_ex */
+#define MM_ABI_VERSION 3 /* 2: mm_pdfposteriors_ex takes the rows of V_hat (P1); mm_batch_reserve_ex.  3: mm_spmv / mm_spmm / mm_svdv, mm_batch_set_exact_policy */
 
 enum mm_status {
     MM_OK = 0,
@@ -132,10 +135,10 @@ size_t mm_batch_workspace_bytes(mm_batch_t batch, int64_t N);
  * An utterance with no accepting path (Z = 0) yields gamma = 0, ttl = -inf
  * (the reference yields NaN: src/inference.jl:158; guarded only in the dead
  * code at :198-200). */
-/* Streams: the call is asynchronous on `stream`.  Some batches run two kernels side by side (the forward and the backward
- * agents of the pair kernels): they fork from `stream` into a pair of library-owned streams and join back into it.  Every
- * batch that is alive has a pair of its own (probed once for really running side by side, reused after mm_batch_destroy):
- * two batches driven from two caller streams do not wait for each other. */
+/* Streams: the call is a chain of kernel launches on `stream` and nothing else -- no library-owned streams, no events, no
+ * host synchronisation (the forward and the backward agents of an utterance are workgroups of ONE grid per phase); it can be
+ * captured in a hipGraph once the workspace is sized (mm_batch_reserve).  Two batches driven from two caller streams do
+ * not wait for each other. */
 int mm_pdfposteriors_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t v_stride_n,
                          const int32_t *lens, int64_t N, float *gamma, int64_t g_stride_b, int64_t g_stride_n,
                          int64_t g_stride_p, float *ttl, void *stream);
@@ -232,7 +235,12 @@ int mm_batch_set_deterministic(mm_batch_t batch, int on);
  * below, say, 1e-12 are zero (LF-MMI gradients) says so here: results then differ from the reference's by less than the
  * floor in any posterior (those below it may come out as 0), log Z is unaffected beyond 1e-4 relative as before, and
  * inputs up to ~6 sigma of logit spread stay on the fast kernels.  floor in [1e-30, 1e-6]; the log-domain kernels (wave,
- * item, generic) are exact and ignore it.  The reference has no such switch (one algorithm, log domain throughout). */
+ * item, generic) are exact and ignore it.  The reference has no such switch (one algorithm, log domain throughout).
+ * Caveat of the DEFAULT floor: the acceptance test bounds every dropped TERM, i.e. an absolute error
+ * of K * 7.9e-31 for a pdf of K states -- the 1e-4 relative bar on log gamma holds by construction for posteriors above
+ * ~1e-26; between 1e-30 and 1e-26 a posterior of an ACCEPTED utterance can be low by about a per cent (seen once in ~1000
+ * fuzzer comparisons: 1.436e-30 computed as 1.423e-30).  mm_batch_set_exact_policy(batch, MM_EXACT_F64_FIRST) removes the
+ * float32 kernels from the path altogether. */
 int mm_batch_set_posterior_floor(mm_batch_t batch, float floor);
 
 /* How many utterances of the LAST mm_pdfposteriors_f32 call on this batch the fast (linear-domain) kernels handed to
@@ -250,6 +258,46 @@ int mm_batch_last_fallback_count(mm_batch_t batch, void *stream, int64_t *n);
  * beyond the float32 kernels -- a sharp acoustic model; mm_batch_last_redo_count then reports the whole batch), else 0.
  * No synchronisation.  Observability only: results are the same either way. */
 int mm_batch_last_exact_first(mm_batch_t batch);
+
+/* Which linear-domain kernels a shared-graph batch starts with (the batches of the pair / split pair kernels; others ignore it).
+ *   MM_EXACT_AUTO (default)  float32 first; float64 first while the last FINISHED call left utterances marked and that costs
+ *                            no more rounds of workgroups.  The engine reads that call's count from pinned host memory without
+ *                            synchronising, so WHICH kernels a pipelined caller's next call launches depends on host / device
+ *                            timing (results are within the parity bar either way; the last bits of gamma and the time are not
+ *                            reproducible from run to run), and a hipGraph capture freezes the choice current at capture time.
+ *   MM_EXACT_F32_FIRST       always float32 first, marked utterances redone by the float64 kernels: the launches of a call
+ *                            are a function of the call alone
+ *   MM_EXACT_F64_FIRST       always the float64 kernels on the whole batch (a trained acoustic model's sharp outputs)
+ * With a fixed policy two identical call sequences give bit-identical results.  During stream capture MM_EXACT_AUTO behaves
+ * as MM_EXACT_F32_FIRST (a captured graph must not bake in the state of an unrelated earlier call).  The reference has no
+ * such switch (src/inference.jl:145-161: one algorithm for every input). */
+enum mm_exact_policy { MM_EXACT_AUTO = 0, MM_EXACT_F32_FIRST = 1, MM_EXACT_F64_FIRST = 2 };
+int mm_batch_set_exact_policy(mm_batch_t batch, int policy);
+
+/* ---- the reference's semiring linear algebra on caller-owned device arrays (src/linalg.jl) ------------------------------
+ * Generic in K like the reference: semiring in {MM_LOG, MM_TROPICAL, MM_PROB}, val_bytes 4 (Float32) / 8 (Float64) for
+ * every value array of a call.  A is a CuSparseMatrixCSR{K} (src/linalg.jl:80: Cint indices): rowptr[rows + 1],
+ * colval[nnz], nzval[nnz], index_base 1 as Julia stores them (0 accepted).  All pointers are DEVICE pointers; the calls
+ * are asynchronous on `stream`; sizes are checked like the reference's @boundscheck (MM_ERR_DIM = DimensionMismatch).
+ * Values are in the semiring's own domain (natural log for Log / Tropical, zero(K) = -inf). */
+
+/* LinearAlgebra.mul!(c, A, b) (src/linalg.jl:163-184; kernel _cukernel_mul_smdv! :213-233, warp_reduce :204-211):
+ * c[r] = (+)_k nzval[k] (*) b[colval[k]] over row r.  b_len / c_len: the lengths of b and c (checked against cols / rows).
+ * An A without stored entries leaves c untouched (`if length(A.nzVal) > 0`, :169). */
+int mm_spmv(int semiring, int val_bytes, int64_t rows, int64_t cols, int64_t nnz, const int32_t *rowptr, const int32_t *colval,
+            int index_base, const void *nzval, const void *b, int64_t b_len, void *c, int64_t c_len, void *stream);
+/* LinearAlgebra.mul!(C, A, B, alpha, beta) (src/linalg.jl:240-262; kernel _cukernel_mul_smdm! :268-280):
+ * C = (beta (*) C) (+) A (*) B with B (b_rows x b_cols) and C (c_rows x c_cols) column-major with leading dimensions ldb /
+ * ldc.  beta = 0: C is overwritten (fill!(C, zero(K)), :247 -- what the 3-argument mul! passes); beta = 1: accumulated into;
+ * any other beta: rmul!(C, beta) first (:247), beta a value of K's domain.  alpha is ignored like in the reference. */
+int mm_spmm(int semiring, int val_bytes, int64_t rows, int64_t cols, int64_t nnz, const int32_t *rowptr, const int32_t *colval,
+            int index_base, const void *nzval, const void *B, int64_t b_rows, int64_t b_cols, int64_t ldb, void *C, int64_t c_rows,
+            int64_t c_cols, int64_t ldc, double beta, void *stream);
+/* Sparse vector (.) dense vector broadcast, _copyto!(f, dest, x::CuSparseVector, y) (src/linalg.jl:294-315; kernel :320-328):
+ * dest = zero(K) everywhere, then dest[nzind[i]] = f(nzval[i], y[nzind[i]]), f = (*) for op 0 (elmul!, :290), (/) for op 1
+ * (eldiv!, :292).  n = length of x, y (y_len) and dest (dest_len). */
+int mm_svdv(int semiring, int val_bytes, int op, int64_t n, int64_t nnz, const int32_t *nzind, int index_base, const void *nzval,
+            const void *y, int64_t y_len, void *dest, int64_t dest_len, void *stream);
 
 /* ---- multi-GPU boundary (one process per GPU, RCCL over xGMI) -------------------------------------------------
  * The batch is block diagonal (src/fsmops.jl:28-36, src/inference.jl:28-36): utterances shard over the ranks with no

@@ -26,5 +26,6 @@ from .inference import (  # noqa: F401
     αrecursion,
     βrecursion,
 )
-from . import dist  # noqa: F401
+from . import dist, linalg  # noqa: F401
+from .linalg import SparseCSR, SparseVector, eldiv_, elmul_, mul_  # noqa: F401
 from .lfmmi import lfmmi_loss  # noqa: F401

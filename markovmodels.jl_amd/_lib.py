@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("MM_AMD_LIB", os.path.join(_HERE, "libmarkovmodels_amd
 MM_OK = 0
 MM_LOG, MM_TROPICAL, MM_PROB = 0, 1, 2
 MM_CSC, MM_CSR = 0, 1
+MM_EXACT_AUTO, MM_EXACT_F32_FIRST, MM_EXACT_F64_FIRST = 0, 1, 2
 SEMIRING_ID = {"log": MM_LOG, "tropical": MM_TROPICAL, "prob": MM_PROB}
 
 #: every symbol include/markovmodels_amd.h declares
@@ -37,6 +38,10 @@ SYMBOLS = [
     "mm_batch_last_redo_count",
     "mm_batch_last_fallback_count",
     "mm_batch_last_exact_first",
+    "mm_batch_set_exact_policy",
+    "mm_spmv",
+    "mm_spmm",
+    "mm_svdv",
     "mm_pdfposteriors_f32",
     "mm_pdfposteriors_ex",
     "mm_statemap_create",
@@ -114,6 +119,14 @@ def _load():
     lib.mm_batch_last_fallback_count.argtypes = [vp, vp, C.POINTER(i64)]
     lib.mm_batch_last_exact_first.restype = C.c_int
     lib.mm_batch_last_exact_first.argtypes = [vp]
+    lib.mm_batch_set_exact_policy.restype = C.c_int
+    lib.mm_batch_set_exact_policy.argtypes = [vp, C.c_int]
+    lib.mm_spmv.restype = C.c_int
+    lib.mm_spmv.argtypes = [C.c_int, C.c_int, i64, i64, i64, vp, vp, C.c_int, vp, vp, i64, vp, i64, vp]
+    lib.mm_spmm.restype = C.c_int
+    lib.mm_spmm.argtypes = [C.c_int, C.c_int, i64, i64, i64, vp, vp, C.c_int, vp, vp, i64, i64, i64, vp, i64, i64, i64, C.c_double, vp]
+    lib.mm_svdv.restype = C.c_int
+    lib.mm_svdv.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64, vp, C.c_int, vp, vp, i64, vp, i64, vp]
     lib.mm_batch_kernels.restype = C.c_int
     lib.mm_batch_kernels.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
     lib.mm_statemap_create.restype = C.c_int

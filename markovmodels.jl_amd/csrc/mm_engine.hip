@@ -1325,12 +1325,14 @@ int mm_fsm_destroy(mm_fsm_t f) {
         if (kv.second->blob) (void)hipFree(kv.second->blob);
         delete kv.second;
     }
-    for (RowVariant *rv : {f->rows[0], f->rows[1], f->prows[0], f->prows[1], f->wrows[0], f->wrows[1], f->wpend[0], f->wpend[1], f->vrow, f->srows[0][0], f->srows[0][1], f->srows[0][2], f->srows[0][3],
-                           f->srows[1][0], f->srows[1][1], f->srows[1][2], f->srows[1][3]})
-        if (rv) {
-            if (rv->blob) (void)hipFree(rv->blob);
-            delete rv;
-        }
+    auto drop = [](RowVariant *rv) {
+        if (!rv) return;
+        if (rv->blob) (void)hipFree(rv->blob);
+        delete rv;
+    };
+    for (RowVariant *rv : {f->rows[0], f->rows[1], f->prows[0], f->prows[1], f->wrows[0], f->wrows[1], f->wpend[0], f->wpend[1], f->vrow}) drop(rv);
+    for (int d = 0; d < 2; ++d)
+        for (int hh = 0; hh < MM_SPLIT_HMAX; ++hh) drop(f->srows[d][hh]);  // (teams of up to MM_SPLIT_HMAX sets)
     delete f;
     return MM_OK;
 }
@@ -2110,6 +2112,14 @@ int mm_batch_set_posterior_floor(mm_batch_t h, float floor) {
     return MM_OK;
 }
 
+int mm_batch_set_exact_policy(mm_batch_t h, int policy) {
+    if (!h) return fail(MM_ERR_INVALID, "mm_batch_set_exact_policy: NULL batch");
+    if (policy != MM_EXACT_AUTO && policy != MM_EXACT_F32_FIRST && policy != MM_EXACT_F64_FIRST)
+        return fail(MM_ERR_INVALID, "mm_batch_set_exact_policy: unknown policy");
+    h->exact_first = policy == MM_EXACT_AUTO ? -1 : (policy == MM_EXACT_F64_FIRST ? 1 : 0);
+    return MM_OK;
+}
+
 int mm_batch_set_deterministic(mm_batch_t h, int on) {
     if (!h) return fail(MM_ERR_INVALID, "mm_batch_set_deterministic: NULL batch");
     h->deterministic = on != 0;
@@ -2358,7 +2368,10 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
             const int64_t M = h->stat_host[0], H = h->pair_H, cus = std::max(1, h->n_cus);
             auto rounds = [&](int64_t wgs) { return (wgs + cus - 1) / cus; };
             const bool by_rounds = M > 0 && rounds(2 * h->B * H) <= rounds(2 * ((h->B + 1) / 2) * H) + rounds(2 * std::min<int64_t>(M, h->B) * H);
-            exact_first = h->exact_first >= 0 ? h->exact_first != 0 : by_rounds;
+            // (a capture must not bake in the marks of whatever call finished last: the automatic choice is float32-first there)
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+            exact_first = h->exact_first >= 0 ? h->exact_first != 0 : (by_rounds && !capturing);
             p.redo2 = reinterpret_cast<int *>(tail0 + ws_tail_bytes(h) - align_up(size_t(h->B + 1) * 4, 256));
             p.stat_dev = h->stat_dev;
             p.stat_host = h->stat_host;
@@ -2380,7 +2393,16 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     }
     p.dbg = g_dbg;
 #endif
-    if (h->lane_ok) return mm_launch_lane(h->B, h->lane_S, p, static_cast<hipStream_t>(stream));
+    if (h->lane_ok) {
+        // the lane kernel decides per utterance whether its float64 range was enough (every workgroup writes its own mark: no
+        // zeroing pass); what it marks -- the one path of a left-to-right graph through values 1000 log2 below their frames'
+        // maxima -- goes to the item kernel, both passes in ONE launch whose workgroups leave at once otherwise
+        p.redo = reinterpret_cast<int *>(tail0 + align_up(size_t(h->B + 1) * 4, 256));
+        h->last_redo = p.redo;
+        rc = mm_launch_lane(h->B, h->lane_S, p, static_cast<hipStream_t>(stream));
+        if (rc || h->dbg.no_redo) return rc;
+        return launch(mm_log_kernel<MODE_FB, 0, 0, false, false>, mm_log_kernel<MODE_FB, 0, 0, false, true>, h, p, true, pick_geometry(h).NW, stream);
+    }
     if (h->wave_ok) {
         char *tail = static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N);
         p.pair_zmin = reinterpret_cast<double *>(tail + 2 * align_up(size_t(h->B + 1) * 4, 256) + align_up(size_t(h->B + 1) * 2 * mm_pair_hand_bytes(), 256));

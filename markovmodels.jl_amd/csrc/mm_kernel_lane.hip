@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) mm_lane_kernel(RunParams p) {
     __shared__ float pr_ring[2][D][64];   // the partner's stored row of a frame (phase B)
     __shared__ double pr_off[2][D][32];   // ... and its offset (a DMA writes 4 bytes for every lane: a slot is 256 bytes, the double its first 8)
     __shared__ double qbuf[2][64];        // a .* b per state, for the sums over the states of a pdf
-    __shared__ double zstat[2][2];        // per agent: min, max over its frames of the per-frame log2 normaliser
+    __shared__ double zstat[2][3];        // per agent: min, max over its frames of the per-frame log2 normaliser; min of log2 sum_s 2^(a~ + b~)
     __shared__ int pdfp[66], pdfs[64];    // pdf -> states (CSR), for maps that are not the identity
     __shared__ mm_f64x2 pvec[2][2][32];   // the agent's vector of a step (by the step's parity): what its next product reads
     __shared__ double bvec[2][64];        // backward agent: beta~ of a step without the frame's emission (what is stored / combined)
@@ -100,7 +100,10 @@ __global__ void __launch_bounds__(256) mm_lane_kernel(RunParams p) {
     // beyond the sequence: exact zeros (src/inference.jl:54-60: expand() leaves the real pdfs zero(K) there)
     for (long long q = threadIdx.x; q < (long long)(p.N - len) * P; q += 256) p.gamma[gbase + (len + q / P) * p.gsn + (q % P) * p.gsp] = 0.f;
     if (len == 0) {  // no frame: no path of length 0
-        if (threadIdx.x == 0) p.ttl[b] = MM_NINF;
+        if (threadIdx.x == 0) {
+            p.ttl[b] = MM_NINF;
+            if (p.redo) p.redo[b] = 0;
+        }
         return;
     }
     const long long s1p_prefix = ((long long)uni((int)(u.s1p_prefix >> 32)) << 32) | (unsigned)uni((int)u.s1p_prefix);
@@ -147,7 +150,10 @@ __global__ void __launch_bounds__(256) mm_lane_kernel(RunParams p) {
             float E = wave_max_rl(e2);
             if (!(E > MM_NINF)) E = 0.f;
             *Eout = E;
-            return (double)fast_exp2(e2 - E);  // (<= 1; 0 beyond S and for zero(K))
+            // (dexp2: the fraction through v_exp_f32, the integer part through v_ldexp_f64 -- a float 2^(e - E) is 0 below 2^-149 of the
+            // frame's best pdf, and a left-to-right graph's only path may go through such a state: the double's 1022 log2 are the
+            // kernel's contract)
+            return dexp2(e2 - E);  // (<= 1; 0 beyond S and for zero(K))
         };
         for (int t = 1; t <= D; ++t) dma_em(t);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the counted wait below holds from then on)
@@ -235,6 +241,7 @@ __global__ void __launch_bounds__(256) mm_lane_kernel(RunParams p) {
             dma_b32(reinterpret_cast<const unsigned *>(offs + f) + (lane & 1), po_base + 256u * (unsigned)(t & (D - 1)));
         };
         double zmin = __builtin_inf(), zmax = -__builtin_inf();
+        float ltmin = __builtin_inff();  // smallest log2 of a frame's sum of 2^(a~ + b~): how far below their maxima the two masses overlap
         // posteriors of frame f from the agent's vector v and the partner's stored row (slot of step t)
         auto combine = [&](int t, int f, double v, double own_off) {
             const float pr = pr_ring[DIR][t & (D - 1)][lane];
@@ -253,7 +260,9 @@ __global__ void __launch_bounds__(256) mm_lane_kernel(RunParams p) {
             const float tf = (float)__builtin_amdgcn_ldexp(tot, -e);
             const float inv = tf > 0.f ? 1.f / tf : 0.f;
             if (lane < P) p.gamma[gbase + (long long)(f - 1) * p.gsn + (long long)lane * p.gsp] = (float)__builtin_amdgcn_ldexp(g, -e) * inv;  // (:158, :160)
-            const double z = (double)dlog2(tot) + own_off + pr_off[DIR][t & (D - 1)][0];
+            const float lt = dlog2(tot);
+            ltmin = lt < ltmin ? lt : ltmin;
+            const double z = (double)lt + own_off + pr_off[DIR][t & (D - 1)][0];
             zmin = z < zmin ? z : zmin;
             zmax = z > zmax ? z : zmax;
         };
@@ -297,6 +306,7 @@ __global__ void __launch_bounds__(256) mm_lane_kernel(RunParams p) {
         if (lane == 0) {
             zstat[DIR][0] = zmin;
             zstat[DIR][1] = zmax;
+            zstat[DIR][2] = (double)ltmin;
         }
 #ifdef MM_STAMPS
         if (p.dbg && lane == 0)
@@ -307,6 +317,17 @@ __global__ void __launch_bounds__(256) mm_lane_kernel(RunParams p) {
     if (threadIdx.x == 0) {  // ttl = min over the frames of the per-frame log-normaliser (src/inference.jl:159)
         const double z = zstat[0][0] < zstat[1][0] ? zstat[0][0] : zstat[1][0];
         p.ttl[b] = (z < __builtin_inf()) ? (float)(z * (double)MM_LN2) : MM_NINF;
+        // The double's range is wide, not unbounded: a value more than ~1000 log2 below its frame's maximum is flushed, and on a
+        // left-to-right graph with very sharp emissions the ONE path may run through such values (64 states in 64 frames,
+        // emissions 250 nats apart).  The same two tests as mm_dpair_finish_kernel decide whether anything that matters can have
+        // been lost -- the frames' normalisers agree, and the forward and the backward mass overlap within the double's range less
+        // the posterior floor --; otherwise redo[b] hands the utterance to the log-domain kernel behind this launch.
+        if (p.redo) {
+            const double zM = zstat[0][1] > zstat[1][1] ? zstat[0][1] : zstat[1][1];
+            const double lm = zstat[0][2] < zstat[1][2] ? zstat[0][2] : zstat[1][2];
+            const bool agree = z > -__builtin_inf() && zM < __builtin_inf() && zM - z <= MM_Z_SPREAD_TOL;
+            p.redo[b] = (len >= 1 && !(agree && lm >= (double)p.lt_floor - (double)MM_DPAIR_THR_EXTRA)) ? 1 : 0;
+        }
     }
 }
 

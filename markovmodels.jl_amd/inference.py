@@ -405,6 +405,15 @@ class BatchedFSM:
         check(lib.mm_batch_last_fallback_count(self._h, self._stream(_torch()), ctypes.byref(n)))
         return int(n.value)
 
+    def set_exact_policy(self, policy: str = "auto"):
+        """mm_batch_set_exact_policy: which linear-domain kernels a shared-graph batch starts with -- "auto" (float32 first,
+        float64 first while the last finished call left utterances marked: depends on host / device timing for pipelined
+        callers), "f32_first" or "f64_first" (both: the launches of a call are a function of the call alone, identical call
+        sequences give identical bits)."""
+        pol = {"auto": _lib.MM_EXACT_AUTO, "f32_first": _lib.MM_EXACT_F32_FIRST, "f64_first": _lib.MM_EXACT_F64_FIRST}[policy]
+        check(lib.mm_batch_set_exact_policy(self._h, pol))
+        return self
+
     def last_exact_first(self) -> bool:
         """True if the last pdfposteriors call skipped the float32 kernels (the inputs of the call before were hard: the
         float64 exact kernels then run the whole batch at once)."""

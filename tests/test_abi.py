@@ -21,7 +21,7 @@ def test_header_symbols_are_exported(mm):
         assert hasattr(lib, s), f"{s} declared in the header but not exported"
     assert sorted(mm.SYMBOLS) == syms, "the ctypes binding must bind exactly the header's entry points"
     lib.mm_abi_version.restype = C.c_int
-    assert lib.mm_abi_version() == 2
+    assert lib.mm_abi_version() == 3
 
 
 def test_no_torch_types_in_the_abi():

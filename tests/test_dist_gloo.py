@@ -50,6 +50,44 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _agg_worker(rank, world, port, q):
+    """one rank of a `bench.py --gpus 4` run as far as its end-of-run reductions go (the engine needs a GPU; the numbers a
+    rank brings to them do not)"""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, N, steps = 256, 1500, 20
+    elapsed = 0.060 + 0.004 * rank  # rank 3 is the slowest
+    r = bench.reduce_over_ranks(dist, torch, "cpu", elapsed, B * N, 2.9 + 0.1 * rank, 0.05 * (rank + 1))
+    q.put((rank, r, B * world, r["frames_total"] * steps / r["elapsed"]))
+    dist.destroy_process_group()
+
+
+def test_four_rank_bench_reductions():
+    """What rank 0 of `bench.py --gpus 4` prints: global_batch = 4 B, value = (sum of the ranks' frames) x steps / (MAX of the
+    ranks' elapsed times), and every rank's own kernel / all-reduce time next to it -- the reductions themselves, on four
+    gloo ranks (the kernels need a GPU: tests/test_dist_gloo.py::test_bench_launches_its_own_ranks runs the whole program)."""
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_agg_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, r, gb, value in got:
+        assert gb == 4 * 256
+        assert r["frames_total"] == 4 * 256 * 1500
+        assert abs(r["elapsed"] - 0.072) < 1e-12 and len(r["kernel_ms"]) == 4
+        assert np.allclose(r["kernel_ms"], [2.9, 3.0, 3.1, 3.2]) and np.allclose(r["allreduce_ms"], [0.05, 0.1, 0.15, 0.2])
+        assert np.allclose(r["elapsed_per_rank"], [0.060, 0.064, 0.068, 0.072])
+        assert abs(value - 4 * 256 * 1500 * 20 / 0.072) < 1e-3
+
+
 def test_shard_helpers():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as ge

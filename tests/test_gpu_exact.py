@@ -214,9 +214,11 @@ def test_lane_kernel(mm, wl, oracle, torch, which):
     bf = make_batch(mm, wl, g, B, {})
     assert "mm_lane_kernel" in bf.kernels(), bf.kernels()
     gam, ttl = bf.pdfposteriors(V, lens)
-    assert bf.last_redo_count() == 0
     g_ref, t_ref = oracle64(oracle, g, V, lens)
     ok = np.isfinite(t_ref)
+    # (marks: only utterances without any path -- too short to reach a final state -- are looked at again by the log-domain
+    # kernel behind the lane kernel: Z = 0 is what an underflow would look like too)
+    assert bf.last_redo_count() == int((~ok & (lens >= 1)).sum())
     check_gamma(gam[ok], g_ref[ok], lens[ok])
     assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-3)
     assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()
@@ -240,3 +242,64 @@ def test_float64_kernels_with_400_pdfs(mm, wl, oracle, torch):
     ok = np.isfinite(t_ref)
     check_gamma(gam[ok], g_ref[ok], lens[ok])
     assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("S", [3, 24, 64])
+def test_lane_kernel_left_to_right_with_sharp_emissions(mm, wl, oracle, torch, S):
+    """A left-to-right HMM (the reference's 3-state demo graph, test/test_algorithms.jl:13-26, and longer chains) has ONE way
+    through: when a frame's emission for the state the path must be in lies hundreds of nats below the frame's best pdf, that
+    state's linear emission 2^(e - E) must still be a positive number -- a float32 v_exp_f32 gave 0 there (alpha = 0, ttl =
+    -inf, gamma = 0 where the reference is finite).  log-softmax of 40 N(0,1): emissions down to ~-250 nats below the best."""
+    g = wl.l2r_hmm(S)
+    rng = np.random.default_rng(S)
+    B, N = 5, max(2 * S, 12)
+    V = peaky(rng, (B, N, g.P), 40.0)
+    V[0] -= 300.0
+    lens = np.array([N, N - 1, N, max(S, 2), N], dtype=np.int32)
+    bf = make_batch(mm, wl, g, B, {})
+    assert "mm_lane_kernel" in bf.kernels(), bf.kernels()
+    gam, ttl = bf.pdfposteriors(V, lens)
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    assert np.isfinite(t_ref).all()
+    assert (V.max(-1) - V.min(-1)).max() > 150.0  # (beyond what a float32 exponent can hold below the frame's best)
+    assert np.isfinite(ttl).all(), ttl
+    check_gamma(gam, g_ref, lens)
+    assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("policy", ["f32_first", "f64_first"])
+def test_fixed_exact_policy_is_reproducible(mm, wl, oracle, torch, policy):
+    """mm_batch_set_exact_policy: under a FIXED policy the launches of a call are a function of the call alone, so two identical
+    PIPELINED call sequences (no synchronisation between the calls: what a training loop does) give identical bits -- under
+    "auto" the second call's kernels depend on whether the host saw the first call's marks in time.  randn, sharp, sharp, randn
+    on one stream, twice; results also against the float64 oracle."""
+    g = wl.lfmmi_denominator(1500, 84, seed=2)
+    rng = np.random.default_rng(21)
+    B, N = 9, 80
+    lens = torch.from_numpy(rng.integers(30, N + 1, B).astype(np.int32)).cuda()
+    Vr = torch.from_numpy(rng.standard_normal((B, N, g.P)).astype(np.float32)).cuda()
+    Vs = torch.from_numpy(peaky(rng, (B, N, g.P), 10.0)).cuda()
+    seq = [Vr, Vs, Vs, Vr]
+
+    def run():
+        bf = make_batch(mm, wl, g, B, {}).set_exact_policy(policy)
+        outs = [torch.empty(B, N, g.P, device="cuda") for _ in seq]
+        ttls, firsts = [], []
+        for V, o in zip(seq, outs):  # (no synchronisation in here)
+            ttls.append(bf.pdfposteriors(V, lens, out=o)[1].clone())
+            firsts.append(bf.last_exact_first())
+        torch.cuda.synchronize()
+        return [o.cpu().numpy() for o in outs], [t.cpu().numpy() for t in ttls], firsts
+
+    g1, t1, f1 = run()
+    g2, t2, f2 = run()
+    assert f1 == f2 == [policy == "f64_first"] * 4
+    for a, b in zip(g1 + t1, g2 + t2):
+        assert np.array_equal(a, b, equal_nan=True)
+    ln = lens.cpu().numpy()
+    for V, gam, ttl in zip(seq, g1, t1):
+        g_ref, t_ref = oracle64(oracle, g, V.cpu().numpy(), ln)
+        check_gamma(gam, g_ref, ln)
+        assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-3)
+    with pytest.raises(mm.MarkovModelsAMDError):
+        mm._lib.check(mm._lib.lib.mm_batch_set_exact_policy(make_batch(mm, wl, g, 2, {})._h, 7))

@@ -188,6 +188,7 @@ struct DebugOpts {
     bool no_xcsr = false, verbose = false;
     bool no_redo = false;           // MM_NO_REDO: the exact kernels do not run after the fast ones (what the fast path alone computes)
     bool no_dpair = false;          // MM_NO_DPAIR: no float64 pair kernels (marked utterances go straight to the quad / item kernels)
+    bool no_wpair = false;          // MM_NO_WPAIR: a whole batch on the exact kernels runs the one-utterance float64 kernels, not the wide pair kernels
     bool no_fallback = false;       // MM_NO_FALLBACK: the float64 pair kernels run, the log-domain kernels behind them do not
     int exact_first = -1;           // MM_EXACT_FIRST=0/1: never / always skip the float32 pair kernels (default: by the last call's marks)
     bool bigv = false;              // MM_BIGV: item / tropical kernels with the state vectors in global memory whatever the size
@@ -211,6 +212,7 @@ static DebugOpts read_debug_opts() {
     d.bigv = getenv("MM_BIGV") != nullptr;
     d.no_redo = getenv("MM_NO_REDO") != nullptr;
     d.no_dpair = getenv("MM_NO_DPAIR") != nullptr;
+    d.no_wpair = getenv("MM_NO_WPAIR") != nullptr;
     d.no_fallback = getenv("MM_NO_FALLBACK") != nullptr;
     if (const char *e = getenv("MM_EXACT_FIRST")) d.exact_first = atoi(e) != 0;
     if (const char *e = getenv("MM_FINISH_COST")) d.finish_cost = atoi(e);
@@ -263,6 +265,7 @@ struct mm_batch_s {
     std::vector<UttDesc> utts_host;     // what d_utts holds
     bool items_resident = true;         // the FSMs' item forms are on the device (a batch of the wave kernel uploads them on first need)
     bool dpair_ok = false;
+    bool wpair_ok = false;              // a whole batch on the exact kernels fits the wide pair kernels (mm_kernel_wpair.hip: two utterances per workgroup)
     bool quad_built = false;            // the FSMs' quad forms exist (not built for batches whose exact path is the float64 kernels)
     int *stat_dev = nullptr;            // {count, ticket}
     volatile int *stat_host = nullptr;  // pinned: {count of hard utterances, sequence number of the call that counted}
@@ -2041,6 +2044,16 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             h->stat_host[1] = 0;
             h->dpair_ok = true;
             h->exact_first = h->dbg.exact_first;
+            {
+                PairLaunch pl;
+                pl.B = h->B;
+                pl.nwc = h->pair_nwc;
+                pl.slotrows = h->pair_slotrows;
+                pl.max_P1 = h->max_P1;
+                pl.pair_ka = h->pair_ka;
+                pl.H = h->pair_H;
+                h->wpair_ok = !h->dbg.no_wpair && mm_wpair_fits(pl);
+            }
         }
     }
     if (h->fast_ok && h->geo_kq[0] <= 3 && h->geo_kq[1] <= 3 && !h->dbg.no_xcsr) {
@@ -2193,8 +2206,11 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
             const std::string k = std::to_string(mm_pair_nj(h->max_P1));
             s = "mm_fbp_kernel<" + k + ",A>, then <" + k + ",B> (forward and backward agents in one grid), mm_pair_finish_kernel, then for marked "
                 "utterances only " +
-                (h->dpair_ok ? "mm_fbd_kernel<" + k + ",A>, then <" + k + ",B> (float64, one utterance per workgroup; FIRST and alone while the "
-                               "inputs are hard), mm_dpair_finish_kernel, then for what those mark "
+                (h->dpair_ok ? "mm_fbd_kernel<" + k + ",A>, then <" + k + ",B> (float64, one utterance per workgroup" +
+                                   (h->wpair_ok ? std::string("); FIRST and alone while the inputs are hard: mm_fbw_kernel<") + k + ",A>, then <" + k +
+                                                      ",B> (wide-exponent pairs, two utterances per workgroup)"
+                                                : std::string("; FIRST and alone while the inputs are hard)")) +
+                                   ", mm_dpair_finish_kernel, then for what those mark "
                              : std::string()) +
                 exact;
         } else if (h->rows_ok) {
@@ -2367,7 +2383,9 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
         if (h->dpair_ok) {
             const int64_t M = h->stat_host[0], H = h->pair_H, cus = std::max(1, h->n_cus);
             auto rounds = [&](int64_t wgs) { return (wgs + cus - 1) / cus; };
-            const bool by_rounds = M > 0 && rounds(2 * h->B * H) <= rounds(2 * ((h->B + 1) / 2) * H) + rounds(2 * std::min<int64_t>(M, h->B) * H);
+            // (the wide pair kernels take a whole batch in the float32 kernels' one grid per phase, a third slower: cheaper than the
+            // float32 kernels followed by a round of the float64 ones for ANY number of marked utterances)
+            const bool by_rounds = M > 0 && (h->wpair_ok || rounds(2 * h->B * H) <= rounds(2 * ((h->B + 1) / 2) * H) + rounds(2 * std::min<int64_t>(M, h->B) * H));
             // (a capture must not bake in the marks of whatever call finished last: the automatic choice is float32-first there)
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             const bool capturing = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
@@ -2463,7 +2481,8 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
             pl.max_P1 = h->max_P1;
             pl.pair_ka = h->pair_ka;
             pl.H = h->pair_H;
-            rc = mm_launch_dpairs(pl, p, static_cast<hipStream_t>(stream));
+            // a whole batch (exact_first: every utterance is marked): two utterances per workgroup on the wide pair kernels
+            rc = exact_first && h->wpair_ok ? mm_launch_wpairs(pl, p, static_cast<hipStream_t>(stream)) : mm_launch_dpairs(pl, p, static_cast<hipStream_t>(stream));
             if (rc) return rc;
             h->last_redo2 = p.redo2;
             p.redo = p.redo2;

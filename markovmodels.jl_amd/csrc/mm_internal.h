@@ -91,6 +91,10 @@ size_t mm_pair_lds_bytes(int phase, int nslotrows, int max_P1);
 size_t mm_pair_hand_bytes();
 // ---- the float64 exact pair kernels (mm_dpair_tu.hip): one utterance per workgroup, for the utterances marked in p.redo
 int mm_launch_dpairs(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
+// ---- the wide-exponent pair kernels (mm_wpair_tu.hip): two utterances per workgroup with a float64's range, whole batches only
+// (every utterance marked in p.redo): what a call that goes to the exact kernels FIRST runs when the batch fits
+bool mm_wpair_fits(const PairLaunch &pl);
+int mm_launch_wpairs(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
 // ---- split pair kernels (mm_split_tu.hip): teams of pl.H workgroups
 int mm_launch_split(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
 size_t mm_split_lds_bytes(int H, int phase, int nslotrows, int max_P1);  // (0: no instance for that many pdfs)

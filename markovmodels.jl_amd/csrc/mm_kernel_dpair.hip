@@ -253,8 +253,44 @@ __device__ __forceinline__ void dpair_pdf_sums(unsigned qbase, unsigned pdfse_ba
     }
 }
 
-// One arc: acc += (double)w * x.  The conversion sits in the same asm block as the FMA: the weights are loop invariant, and
-// a conversion the compiler can see is hoisted out of the time loop -- KA more register pairs than a wave has.
+// ---- the arcs.  MM_DPAIR_W32 (an experiment of round 5, OFF; its pieces are what mm_kernel_wpair.hip is built from): "wide-exponent 32-bit" operands -- the HIGH dword of a double (sign, 11 exponent bits, 20
+// mantissa bits) is all an arc reads or keeps:
+//   * the linear vector is gathered with ds_read_b32 of the high dwords (the finish still stores whole doubles: the scans, the
+//     teams' exchange and the per-pdf sums read them); the low dword of the FMA's operand pair is whatever its register holds
+//     -- up to 2^-20 relative on a term, unbiased enough: the frames are renormalised by their own sums, and the bar is 1e-4 on
+//     log gamma;
+//   * a weight is the high dword of its double (rounded to nearest on the 20 bits: 2.4e-7 relative, the graph's weights
+//     perturbed by less than float32 rounds them in the reference), kept in the odd register of an aligned pair whose even
+//     register is the arc's LDS address (its bits sit 2^-32 below the last mantissa bit that counts): the pair IS the v_fma_f64
+//     operand.  No conversion, no extra register: an arc is ds_read_b32 + v_fma_f64 where it was ds_read_b64 + v_cvt_f64_f32 +
+//     v_fma_f64.
+// Measured (config 3, sharp emissions, the whole batch on these kernels): 7.7 ms against 5.5 -- SLOWER.  The vector of doubles
+// keeps its 8-byte stride, a 4-byte read of the high dwords touches only the odd banks, and two lanes of a 32-lane pass whose
+// positions differ by 16 collide (bank = address / 4 mod 32 for ds_read_b32: tools/dev/lds_test.hip "b32 stride 8 B" 2.0 against
+// 1.45 cycles); the saved conversion buys nothing because the step is bound by the LDS, not the vector ALU.  What the format IS
+// good for: two utterances in the 8 bytes of a state again -- mm_kernel_wpair.hip.
+#ifndef MM_DPAIR_W32
+#define MM_DPAIR_W32 0
+#endif
+typedef unsigned mm_du32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double d_wpair(float w, unsigned addr) {  // {address, high dword of (double)w rounded to 20 mantissa bits}
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, (double)w) + 0x80000000ull;
+    mm_du32x2 t;
+    t.x = addr;
+    t.y = (unsigned)(bits >> 32);
+    return __builtin_bit_cast(double, t);
+}
+__device__ __forceinline__ unsigned d_waddr(const double &wa) { return __builtin_bit_cast(mm_du32x2, wa).x; }
+// the gathered operand: the high dword from LDS into the odd register of the pair `x` lives in; the low dword keeps what it
+// held (the ring of operands is declared OUTSIDE the time loop for that: a fresh low word per gather is a v_mov per arc)
+__device__ __forceinline__ void d_gather_hi(double &x, unsigned addr) {
+    mm_du32x2 t = __builtin_bit_cast(mm_du32x2, x);
+    t.y = ldsru(addr + 4u);
+    x = __builtin_bit_cast(double, t);
+}
+
+// One arc: acc += (double)w * x.  (MM_DPAIR_W32 = 0) The conversion sits in the same asm block as the FMA: the weights are loop
+// invariant, and a conversion the compiler can see is hoisted out of the time loop -- KA more register pairs than a wave has.
 __device__ __forceinline__ void d_fma_w(double &acc, float w, const double &x) {
     double t;
     asm("v_cvt_f64_f32 %1, %2\n\tv_fma_f64 %0, %1, %3, %0" : "+v"(acc), "=&v"(t) : "v"(w), "v"(x));
@@ -263,7 +299,53 @@ __device__ __forceinline__ void d_mul_w(double &acc, float w, const double &x) {
     double t;
     asm("v_cvt_f64_f32 %1, %2\n\tv_mul_f64 %0, %1, %3" : "=v"(acc), "=&v"(t) : "v"(w), "v"(x));
 }
+__device__ __forceinline__ void d_fma_ww(double &acc, const double &wa, const double &x) {
+    asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(wa), "v"(x));
+}
+__device__ __forceinline__ void d_mul_ww(double &acc, const double &wa, const double &x) {
+    asm("v_mul_f64 %0, %1, %2" : "=v"(acc) : "v"(wa), "v"(x));
+}
 
+// what a compute wave keeps across the steps: MM_DPAIR_W32 the {address, weight} pairs, else PairRegs (mm_kernel_pairs.hip)
+template <int KA>
+struct DPairRegs {
+#if MM_DPAIR_W32
+    double wa[KA];
+#else
+    mm_f32x2 w2[KA / 2];
+    unsigned a[KA];
+#endif
+};
+
+#if MM_DPAIR_W32
+template <int K2, int KA, int D>
+__device__ __forceinline__ void dpair_one(const DPairRegs<KA> &rg, double (&x)[2 * D], double &accA, unsigned rdoff) {
+    constexpr int s0 = (2 * K2) % (2 * D);
+    d_fma_ww(accA, rg.wa[2 * K2], x[s0]);
+    d_fma_ww(accA, rg.wa[2 * K2 + 1], x[s0 + 1]);
+    if constexpr (2 * (K2 + D) < KA) {
+        d_gather_hi(x[s0], d_waddr(rg.wa[2 * (K2 + D)]) + rdoff);
+        d_gather_hi(x[s0 + 1], d_waddr(rg.wa[2 * (K2 + D) + 1]) + rdoff);
+    }
+}
+template <int K2, int KA, int D>
+__device__ __forceinline__ void dpair_two(const DPairRegs<KA> &rg, double (&x)[2 * D], double &accA, double &accN, unsigned rdoff) {
+    constexpr int s0 = (2 * K2) % (2 * D), s1 = (2 * K2 + 2) % (2 * D);
+    d_fma_ww(accA, rg.wa[2 * K2], x[s0]);
+    d_mul_ww(accN, rg.wa[2 * K2 + 2], x[s1]);
+    d_fma_ww(accA, rg.wa[2 * K2 + 1], x[s0 + 1]);
+    d_fma_ww(accN, rg.wa[2 * K2 + 3], x[s1 + 1]);
+    if constexpr (2 * (K2 + D) < KA) {
+        d_gather_hi(x[s0], d_waddr(rg.wa[2 * (K2 + D)]) + rdoff);
+        d_gather_hi(x[s0 + 1], d_waddr(rg.wa[2 * (K2 + D) + 1]) + rdoff);
+    }
+    if constexpr (2 * (K2 + 1 + D) < KA) {
+        d_gather_hi(x[s1], d_waddr(rg.wa[2 * (K2 + 1 + D)]) + rdoff);
+        d_gather_hi(x[s1 + 1], d_waddr(rg.wa[2 * (K2 + 1 + D) + 1]) + rdoff);
+    }
+}
+#define MM_DPAIR_ARGS rg
+#else
 template <int K2, int KA, int D>
 __device__ __forceinline__ void dpair_one(const mm_f32x2 (&wr)[KA / 2], const unsigned (&ar)[KA], double (&x)[2 * D], double &accA, unsigned rdoff) {
     constexpr int s0 = (2 * K2) % (2 * D);
@@ -292,14 +374,16 @@ __device__ __forceinline__ void dpair_two(const mm_f32x2 (&wr)[KA / 2], const un
         x[s1 + 1] = ldsr_d(ar[2 * (K2 + 1 + D) + 1] + rdoff);
     }
 }
+#define MM_DPAIR_ARGS rg.w2, rg.a
+#endif
 #define MM_DPAIR_ONE(k)                                                                   \
     if constexpr (2 * (k) < KA) {                                                         \
-        dpair_one<(2 * (k) < KA ? (k) : 0), KA, D>(rg.w2, rg.a, x, accA, rdoff);          \
+        dpair_one<(2 * (k) < KA ? (k) : 0), KA, D>(MM_DPAIR_ARGS, x, accA, rdoff);          \
         if (MM_PAIR_END(k)) finish();                                                     \
     }
 #define MM_DPAIR_TWO(k)                                                                   \
     if constexpr (2 * (k) + 2 < KA) {                                                     \
-        dpair_two<(2 * (k) + 2 < KA ? (k) : 0), KA, D>(rg.w2, rg.a, x, accA, accN, rdoff); \
+        dpair_two<(2 * (k) + 2 < KA ? (k) : 0), KA, D>(MM_DPAIR_ARGS, x, accA, accN, rdoff); \
         if (__builtin_expect(((((k) < 32 ? em_lo : em_hi) >> ((k) & 31)) & 3u) != 0u, 0)) { \
             if (MM_PAIR_END(k)) finish();                                                 \
             accA += accN;                                                                 \
@@ -397,7 +481,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
     lgw0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(lgw0 >> 32)) << 32) |
            (unsigned)__builtin_amdgcn_readfirstlane((unsigned)lgw0);
     nslots = __builtin_amdgcn_readfirstlane(nslots);
-    PairRegs<KA> rg;
+    DPairRegs<KA> rg;
     auto load_graph = [&]() {
         static_assert(KA <= MM_ROW_KA_PAD, "register window larger than the padding of the device arrays");
         const int nt = 64 * r.NWC;
@@ -405,6 +489,10 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
         const auto wp = as_global(r.w);
         const auto ap = as_global(r.addr);
         const int t0 = mine ? tid : 0;
+#if MM_DPAIR_W32
+#pragma unroll
+        for (int k = 0; k < KA; ++k) rg.wa[k] = d_wpair(mine ? wp[k * nt + t0] : 0.f, mine ? ap[k * nt + t0] : 0u);
+#else
 #pragma unroll
         for (int k = 0; k < KA; ++k) {
             if (k & 1) rg.w2[k / 2].y = wp[k * nt + t0];
@@ -419,6 +507,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                 rg.a[k] = 0u;
             }
         }
+#endif
     };
     // steps of this launch: (t0, t1]; the vector of step t0 is the starting point
     const int t0 = PHASE ? tA : 1, t1 = PHASE ? tEnd : tA;
@@ -667,15 +756,30 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
         __syncthreads();  // (2)
         if constexpr (H > 1) xplain = __builtin_amdgcn_readfirstlane(ldsru(L::XFLAG)) != 0u;
         bool cdead = H > 1 && (p.x_sleep & 0x200) != 0;  // (teams) a poll of this wave timed out: it waits no more
+#if MM_DPAIR_W32
+        double x[2 * D];  // the ring of gathered operands: register pairs whose low words nothing writes after this (d_gather_hi)
+#pragma unroll
+        for (int j = 0; j < 2 * D; ++j) {
+            x[j] = 0.0;
+            asm volatile("" : "+v"(x[j]));
+        }
+#endif
         auto step = [&](auto RDc, int t) {
             constexpr int RD = decltype(RDc)::value, WR = 1 - RD;
             if (nslots > 0) {
                 constexpr unsigned rdoff = L::PP(RD);
+#if !MM_DPAIR_W32
                 double x[2 * D];
+#endif
 #pragma unroll
                 for (int j = 0; j < D; ++j) {  // the first gathers leave before anything else
+#if MM_DPAIR_W32
+                    d_gather_hi(x[2 * j], d_waddr(rg.wa[(2 * j < KA) ? 2 * j : 0]) + rdoff);
+                    d_gather_hi(x[2 * j + 1], d_waddr(rg.wa[(2 * j + 1 < KA) ? 2 * j + 1 : 0]) + rdoff);
+#else
                     x[2 * j] = ldsr_d(rg.a[(2 * j < KA) ? 2 * j : 0] + rdoff);
                     x[2 * j + 1] = ldsr_d(rg.a[(2 * j + 1 < KA) ? 2 * j + 1 : 0] + rdoff);
+#endif
                 }
                 // the slot table runs one segment ahead (infoN / info2N): see pair_agent
                 unsigned sa = slot_base;

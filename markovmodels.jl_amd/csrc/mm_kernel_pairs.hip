@@ -592,6 +592,18 @@ __device__ __forceinline__ void pair_two(const mm_f32x2 (&wr)[KA / 2], const uns
     pk_mul_wlo(accN, wr[K2 + 1], x[s1]);
     pk_fma_whi(accA, wr[K2], x[s0 + 1]);
     pk_fma_whi(accN, wr[K2 + 1], x[s1 + 1]);
+#ifdef MM_PAIR_DUMMY
+    {   // timing experiment (never shipped): the instruction mix of a two-utterance float64 form -- per arc one more 64-bit FMA and
+        // a move next to the (here: packed) FMA that exists; results go nowhere
+        double da;
+        unsigned dt;
+        asm volatile("" : "=v"(da), "=v"(dt));
+        asm volatile("v_mov_b32 %1, %6\n\tv_fma_f64 %0, %2, %3, %0\n\tv_mov_b32 %1, %7\n\tv_fma_f64 %0, %2, %4, %0\n\t"
+                     "v_mov_b32 %1, %6\n\tv_fma_f64 %0, %5, %3, %0\n\tv_mov_b32 %1, %7\n\tv_fma_f64 %0, %5, %4, %0"
+                     : "+v"(da), "+v"(dt)
+                     : "v"(wr[K2]), "v"(x[s0]), "v"(x[s0 + 1]), "v"(wr[K2 + 1]), "v"(x[s1].x), "v"(x[s1 + 1].x));
+    }
+#endif
     if constexpr (2 * (K2 + D) < KA) {
         x[s0] = ldsr2(ar[2 * (K2 + D)] + rdoff);
         x[s0 + 1] = ldsr2(ar[2 * (K2 + D) + 1] + rdoff);

@@ -63,7 +63,10 @@ def test_sharp_emissions_on_the_float64_kernels_alone(mm, wl, oracle, torch, sig
     assert np.allclose(t1[ok], t_ref[ok], rtol=1e-5, atol=1e-3)
     assert (g1[~ok] == 0).all() and np.isneginf(t1[~ok]).all()
     g2, t2 = bf.pdfposteriors(V, lens)
-    assert bf.last_exact_first() and bf.last_redo_count() == B and bf.last_fallback_count() == 0
+    # (the whole batch on the wide pair kernels, two utterances per workgroup: an utterance WITHOUT any path whose partner raised
+    # a range mark stays marked -- Z = 0 is what a total underflow would look like -- and would go to the log-domain kernels)
+    assert bf.last_exact_first() and bf.last_redo_count() == B and bf.last_fallback_count() <= int((~ok & (lens >= 1)).sum())
+    assert "mm_fbw_kernel" in bf.kernels()
     check_gamma(g2[ok], g_ref[ok], lens[ok])
     assert np.allclose(t2[ok], t_ref[ok], rtol=1e-5, atol=1e-3)
     m = lens >= 2  # (the utterances both calls computed on the float64 kernels: the same bits)
@@ -101,16 +104,19 @@ def test_the_choice_follows_the_data(mm, wl, oracle, torch):
         assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-3)
 
 
-def test_float64_kernels_first_on_ordinary_inputs(mm, wl, oracle, torch):
-    """MM_EXACT_FIRST=1: the float64 kernels alone on N(0,1) log-likelihoods, B beyond the compute units' pairs, P + 1 > 128
-    (the 4-pass service wave), against the oracle and against the float32 kernels' result."""
+@pytest.mark.parametrize("wide", [True, False])
+def test_float64_kernels_first_on_ordinary_inputs(mm, wl, oracle, torch, wide):
+    """MM_EXACT_FIRST=1: the exact linear-domain kernels alone on N(0,1) log-likelihoods, B beyond the compute units' pairs (and
+    odd), P + 1 > 128 (the 4-pass service wave), against the oracle and against the float32 kernels' result.  wide: the whole
+    batch on the wide-exponent pair kernels (mm_kernel_wpair.hip: two utterances per workgroup, what the engine runs); else
+    (MM_NO_WPAIR) on the one-utterance float64 kernels."""
     g = wl.lfmmi_denominator(1200, 150, seed=5)
     rng = np.random.default_rng(8)
     B, N = 11, 70
     lens = rng.integers(1, N + 1, B).astype(np.int32)
     V = rng.standard_normal((B, N, g.P)).astype(np.float32)
-    bf = make_batch(mm, wl, g, B, {"MM_EXACT_FIRST": "1", "MM_NO_FALLBACK": "1"})
-    assert "mm_fbd_kernel<4" in bf.kernels(), bf.kernels()
+    bf = make_batch(mm, wl, g, B, dict({"MM_EXACT_FIRST": "1", "MM_NO_FALLBACK": "1"}, **({} if wide else {"MM_NO_WPAIR": "1"})))
+    assert "mm_fbd_kernel<4" in bf.kernels() and ("mm_fbw_kernel<4" in bf.kernels()) == wide, bf.kernels()
     gam, ttl = bf.pdfposteriors(V, lens)
     assert bf.last_exact_first() and bf.last_fallback_count() == 0
     g_ref, t_ref = oracle64(oracle, g, V, lens)
@@ -122,7 +128,8 @@ def test_float64_kernels_first_on_ordinary_inputs(mm, wl, oracle, torch):
     assert np.allclose(g32, gam, rtol=2e-4, atol=1e-6) and np.allclose(t32, ttl, rtol=1e-6, atol=1e-4)
 
 
-def test_emission_offsets_and_masked_pdfs(mm, wl, oracle, torch):
+@pytest.mark.parametrize("wide", [True, False])
+def test_emission_offsets_and_masked_pdfs(mm, wl, oracle, torch, wide):
     """GMM-like scores (-300 nats), and pdfs masked with -1e4 in some frames (states on them underflow even a double: the marks
     the float64 kernels raise carry no mass and are cleared by mm_dpair_finish_kernel)."""
     g = wl.lfmmi_denominator(800, 60, seed=7)
@@ -131,7 +138,7 @@ def test_emission_offsets_and_masked_pdfs(mm, wl, oracle, torch):
     lens = np.array([80, 64, 80, 33, 80], dtype=np.int32)
     V = peaky(rng, (B, N, g.P), 8.0) - 300.0
     V[:, ::3, :7] = -1e4
-    bf = make_batch(mm, wl, g, B, {"MM_EXACT_FIRST": "1", "MM_NO_FALLBACK": "1"})
+    bf = make_batch(mm, wl, g, B, dict({"MM_EXACT_FIRST": "1", "MM_NO_FALLBACK": "1"}, **({} if wide else {"MM_NO_WPAIR": "1"})))
     gam, ttl = bf.pdfposteriors(V, lens)
     assert bf.last_fallback_count() == 0
     g_ref, t_ref = oracle64(oracle, g, V, lens)
@@ -303,3 +310,25 @@ def test_fixed_exact_policy_is_reproducible(mm, wl, oracle, torch, policy):
         assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-3)
     with pytest.raises(mm.MarkovModelsAMDError):
         mm._lib.check(mm._lib.lib.mm_batch_set_exact_policy(make_batch(mm, wl, g, 2, {})._h, 7))
+
+
+def test_wide_pair_kernels_at_full_length(mm, wl, oracle, torch):
+    """Config 3's graph, T = 1500, sharp emissions, the whole batch on the wide-exponent pair kernels: the 20 mantissa bits of
+    their operands must not add up over 1500 frames -- four utterances against the float64 oracle (posteriors AND the spread of
+    the per-frame log Z, which mm_dpair_finish_kernel reads as "no mass lost": nothing may be handed on), and every utterance's
+    posteriors summing to 1 in every frame."""
+    g = wl.lfmmi_denominator(2000, 84, seed=0)
+    rng = np.random.default_rng(31)
+    B, N = 6, 1500
+    lens = np.array([1500, 1500, 1211, 1500, 977, 1500], dtype=np.int32)
+    V = peaky(rng, (B, N, g.P), 10.0)
+    bf = make_batch(mm, wl, g, B, {"MM_EXACT_FIRST": "1", "MM_NO_FALLBACK": "1"})
+    assert "mm_fbw_kernel<2" in bf.kernels()
+    gam, ttl = bf.pdfposteriors(V, lens)
+    assert bf.last_exact_first() and bf.last_redo_count() == B and bf.last_fallback_count() == 0
+    sel = [0, 1, 2, 4]
+    g_ref, t_ref = oracle64(oracle, g, V[sel], lens[sel])
+    check_gamma(gam[sel], g_ref, lens[sel])
+    assert np.allclose(ttl[sel], t_ref, rtol=1e-6, atol=1e-3)
+    for b in range(B):
+        assert np.allclose(gam[b, : lens[b]].sum(-1), 1.0, atol=2e-5) and (gam[b, lens[b]:] == 0).all()

@@ -23,6 +23,7 @@ using Semirings
 using AMDGPU
 using Adapt
 using Libdl
+using LinearAlgebra
 
 # The package's own generic functions are EXTENDED with methods for the device types below (`using MarkovModels`
 # already exports compile, batch, pdfposteriors, ...: src/MarkovModels.jl:14-45 -- defining functions of the same
@@ -31,8 +32,8 @@ import MarkovModels: compile, batch, pdfposteriors, αrecursion, βrecursion, to
 
 # what this module adds to the package's API
 export ROCCompiledFSM, ROCBatch, to_device, compile_many, bestpath, maxstateposteriors, pdfposteriors_generic, last_redo_count,
-       last_fallback_count, last_exact_first, reserve_ex!, set_deterministic!, set_posterior_floor!, set_rccl, allreduce_logz,
-       allgather_ttl
+       last_fallback_count, last_exact_first, reserve_ex!, set_deterministic!, set_posterior_floor!, set_exact_policy!, set_rccl,
+       allreduce_logz, allgather_ttl, ROCSparseCSR, ROCSparseVec, elmul!, eldiv!, compiled_cache_clear!
 
 const LIB = get(ENV, "MARKOVMODELS_AMD_LIB", "libmarkovmodels_amd.so")
 
@@ -95,7 +96,7 @@ Adapt.adapt_structure(::Type{<:ROCArray}, c::CompiledFSM) = to_device(c)
 `compile.(fsms, Ĉs)` + device adapt for a mini-batch of NEW graphs in one call (mm_fsm_create_many: host threads, one device
 allocation, one copy) -- what examples/test_cuda.jl:74-78 does every training step for the numerator graphs.
 """
-function compile_many(fsms::Vector{FSM{K}}, Ĉs::Vector{<:AbstractSparseMatrix}; threads::Integer = 0) where K
+function compile_many(fsms::Vector{<:FSM{K}}, Ĉs::Vector{<:AbstractSparseMatrix}; threads::Integer = 0) where K
     n = length(fsms)
     n == length(Ĉs) || throw(DimensionMismatch("one Ĉ per FSM"))
     Ts = [SparseMatrixCSC(f.T̂) for f in fsms]
@@ -160,6 +161,7 @@ mutable struct ROCBatch{K}
     handle::Ptr{Cvoid}
     fsms::Vector{ROCCompiledFSM{K}}      # keeps the FSM handles alive
     P::Int
+    keep::Any                            # device arrays an asynchronous call on this batch still reads (replaced by the next call)
 end
 
 function batch(f1::ROCCompiledFSM{K}, fs::ROCCompiledFSM{K}...) where K
@@ -167,7 +169,7 @@ function batch(f1::ROCCompiledFSM{K}, fs::ROCCompiledFSM{K}...) where K
     hs = Ptr{Cvoid}[f.handle for f in all_]
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:mm_batch_create, LIB), Cint, (Ptr{Ptr{Cvoid}}, Int64, Ref{Ptr{Cvoid}}), hs, length(hs), h))
-    obj = ROCBatch{K}(h[], all_, f1.P1 - 1)
+    obj = ROCBatch{K}(h[], all_, f1.P1 - 1, nothing)
     finalizer(o -> ccall((:mm_batch_destroy, LIB), Cint, (Ptr{Cvoid},), o.handle), obj)
     obj
 end
@@ -197,45 +199,51 @@ function pdfposteriors(b::ROCBatch, V::ROCArray{Float32,3}, lens = nothing)
 end
 
 """
-    pdfposteriors(fsm::FSM{K}, V̂s::Vector{<:ROCMatrix}, Ĉs; expanded = true) -> (γ, ttl)
+    pdfposteriors(fsm::FSM{K}, V̂s::Vector{<:ROCMatrix}, Ĉs; expanded = true, seqlengths = nothing) -> (γ, ttl)
 
 The reference's own signature (src/inference.jl:145): `fsm` the `rawunion` of the batch's FSMs (src/fsmops.jl:28-36), `V̂s`
 one (P+1) × (N+1) matrix per utterance as `expand` made them, `Ĉs` the state maps -- examples/test_cuda.jl:128 runs
 unchanged but for the array type.  The blocks of the union are cut apart again by the rows of the `Ĉs` (block b has
-size(Ĉs[b], 1) states), compiled (equal blocks once) and batched; `V̂s` are stacked on the device like `vcat(V̂s...)` (:146).
-With Float32 log-semiring FSMs, one-hot `Ĉs` and `expanded = true` the fast kernels run on V̂[1:P, 1:N, b] IN PLACE (strides;
-the lengths are read off the phony row); anything else (`expanded = false`: matrices `expand` did not make; Float64;
-other semirings; general sparse `Ĉs`) goes to `pdfposteriors_generic`.
+size(Ĉs[b], 1) states) and looked up in a PROCESS-WIDE cache of compiled graphs keyed by their content (`hash` of the
+block's T̂, α̂ and Ĉ): a graph is packed and uploaded the first time it is seen -- the misses of one call together, by
+`compile_many` -- and found again on every later call (the denominator graph; an utterance's numerator across epochs).
+The whole batch is remembered per `(fsm, Ĉs)` object pair as well, so a loop that passes the same objects pays one
+dictionary look-up.  `V̂s` are stacked on the device like `vcat(V̂s...)` (:146).
+With Float32 log-semiring FSMs, one-hot `Ĉs` and `expanded = true` the fast kernels run on V̂[1:P, 1:N, b] IN PLACE (strides).
+The lengths: `seqlengths` (what `expand` was given: a Vector or ROCVector of integers) keeps the call asynchronous; without it
+they are read off the phony row on the host, and the form `expand` gives a matrix (phony row zero(K) up to the length and
+one(K) after, real rows zero(K) beyond it) is CHECKED -- a matrix of another form goes to the generic entry like
+`expanded = false`.  Anything else (Float64; other semirings; general sparse `Ĉs`) goes to `pdfposteriors_generic`.
+Nothing synchronises the device: the batch lives in the cache, and the stacked V̂ and the lengths stay referenced by the batch
+(`b.keep`) until the next call on it replaces them -- stream order then guarantees the earlier call has read them.
 """
-function pdfposteriors(fsm::FSM{K}, V̂s::Vector{<:ROCMatrix{T}}, Ĉs::Vector{<:AbstractSparseMatrix}; expanded::Bool = true) where {K, T}
+function pdfposteriors(fsm::FSM{K}, V̂s::Vector{<:ROCMatrix{T}}, Ĉs::Vector{<:AbstractSparseMatrix}; expanded::Bool = true,
+                       seqlengths = nothing) where {K, T}
     B = length(V̂s)
     B == length(Ĉs) || throw(DimensionMismatch("one Ĉ per utterance"))
     P1, N1 = size(V̂s[1])
     all(size(v) == (P1, N1) for v in V̂s) || throw(DimensionMismatch("all V̂ must share one (P+1) × (N+1) shape"))
     all(size(Ĉ, 2) == P1 for Ĉ in Ĉs) || throw(DimensionMismatch("V̂ has $P1 rows, a Ĉ has another number of pdfs"))
-    # the blocks of the block-diagonal union
-    T̂, α̂ = SparseMatrixCSC(fsm.T̂), SparseVector(fsm.α̂)
-    sum(size(Ĉ, 1) for Ĉ in Ĉs) == size(T̂, 1) || throw(DimensionMismatch("the Ĉs' rows do not add up to the states of fsm"))
-    onehot = all(all(diff(SparseMatrixCSC(copy(Ĉ')).colptr) .== 1) && all(iszero ∘ val, nonzeros(Ĉ)) for Ĉ in Ĉs)
-    cache = Dict{Any, ROCCompiledFSM{K}}()
-    cfs = ROCCompiledFSM{K}[]
-    lo = 0
-    for Ĉ in Ĉs
-        r = lo+1:lo+size(Ĉ, 1)
-        Tb, ab = T̂[r, r], α̂[r]
-        # (a general sparse Ĉ rides along as an argument of the generic entry: its FSM handle gets a placeholder map)
-        Cb = onehot ? Ĉ : sparse(1:size(Ĉ, 1), [fill(1, size(Ĉ, 1) - 1); size(Ĉ, 2)], fill(one(K), size(Ĉ, 1)), size(Ĉ, 1), size(Ĉ, 2))
-        key = (Tb, ab, Cb)
-        push!(cfs, get!(() -> _create(K, Tb, ab, Cb), cache, key))
-        lo = last(r)
-    end
-    b = batch(cfs...)
+    b, onehot = _cached_batch(fsm, Ĉs)
     V̂ = cat(V̂s...; dims = 3)                                    # (P+1) × (N+1) × B on the device
     fast = expanded && onehot && K <: LogSemiring && T === Float32
-    fast || return pdfposteriors_generic(b, V̂, onehot ? nothing : Ĉs)
     P, N = P1 - 1, N1 - 1
-    # expand (src/inference.jl:54-60): the phony row is zero(K) up to seqlength, one(K) after
-    lens = ROCArray(Int32.(vec(sum(Array(V̂[P1:P1, 1:N, :]) .== -Inf32, dims = 2))))
+    lens = nothing
+    if fast
+        if seqlengths !== nothing
+            lens = seqlengths isa ROCArray ? ROCArray{Int32}(seqlengths) : ROCArray(Int32.(collect(seqlengths)))
+        else
+            # expand (src/inference.jl:54-60): the phony row is zero(K) up to seqlength and one(K) after, the real rows are
+            # zero(K) beyond it -- read and verified on the host (one round trip; pass `seqlengths` to avoid it)
+            ph = Array(V̂[P1, :, :])                             # (N+1) × B
+            L = vec(sum(ph .== -Inf32, dims = 1))
+            step_ok = all(all(ph[1:L[j], j] .== -Inf32) && all(ph[L[j]+1:end, j] .== 0f0) && L[j] <= N for j in 1:B)
+            tail_ok = step_ok && all(Array(mapreduce(x -> x == -Inf32, &, V̂[1:P, L[j]+1:N1, j]; init = true)) for j in 1:B if L[j] < N1)
+            fast = step_ok && tail_ok
+            lens = ROCArray(Int32.(L))
+        end
+    end
+    fast || return pdfposteriors_generic(b, V̂, onehot ? nothing : Ĉs)
     γ = ROCArray{Float32}(undef, B, P, N)
     ttl = ROCArray{Float32}(undef, B)
     # V̂ (b, n, p) -> p + P1*n + P1*N1*b: the kernels read the real pdfs and frames in place
@@ -244,8 +252,56 @@ function pdfposteriors(fsm::FSM{K}, V̂s::Vector{<:ROCMatrix{T}}, Ĉs::Vector{<:
          Ptr{Float32}, Ptr{Cvoid}),
         b.handle, pointer(V̂), P1 * N1, P1, pointer(lens), N, pointer(γ), 1, B * P, B, pointer(ttl),
         AMDGPU.stream().stream))
-    AMDGPU.synchronize()                                        # (b and V̂ are locals: the call must have run before they go)
+    # (asynchronous: the batch lives in the cache; the stacked V̂ and the lengths are kept until the NEXT call on this batch
+    # replaces them -- stream order then guarantees this call has read them)
+    b.keep = (V̂, lens)
     γ, ttl
+end
+
+# ---- the compiled-graph cache behind the method above
+const _COMPILED = Dict{UInt64, Any}()          # content hash of (T̂ block, α̂ block, Ĉ) -> ROCCompiledFSM
+const _BATCHES = IdDict{Any, Any}()             # fsm object -> (Ĉs object, ROCBatch, onehot)
+"Forget every compiled graph and batch the reference-shaped `pdfposteriors` has cached."
+compiled_cache_clear!() = (empty!(_COMPILED); empty!(_BATCHES); nothing)
+
+_isonehot(Ĉ::AbstractSparseMatrix{K}) where K =
+    all(diff(SparseMatrixCSC(copy(Ĉ')).colptr) .== 1) && all(x -> x == one(K), nonzeros(Ĉ))   # (one(ProbSemiring) = 1: not iszero ∘ val)
+
+function _cached_batch(fsm::FSM{K}, Ĉs) where K
+    hit = get(_BATCHES, fsm, nothing)
+    hit !== nothing && hit[1] === Ĉs && return hit[2], hit[3]
+    T̂, α̂ = SparseMatrixCSC(fsm.T̂), SparseVector(fsm.α̂)
+    sum(size(Ĉ, 1) for Ĉ in Ĉs) == size(T̂, 1) || throw(DimensionMismatch("the Ĉs' rows do not add up to the states of fsm"))
+    onehot = all(_isonehot, Ĉs)
+    keys = UInt64[]
+    blocks = Dict{UInt64, Any}()
+    lo = 0
+    for Ĉ in Ĉs
+        r = lo+1:lo+size(Ĉ, 1)
+        Tb, ab = T̂[r, r], α̂[r]
+        # (a general sparse Ĉ rides along as an argument of the generic entry: its FSM handle gets a placeholder map)
+        Cb = onehot ? Ĉ : sparse(1:size(Ĉ, 1), [fill(1, size(Ĉ, 1) - 1); size(Ĉ, 2)], fill(one(K), size(Ĉ, 1)), size(Ĉ, 1), size(Ĉ, 2))
+        k = hash((K, Tb.colptr, Tb.rowval, val.(nonzeros(Tb)), SparseArrays.nonzeroinds(ab), val.(nonzeros(ab)), Cb.colptr, Cb.rowval, size(Cb)))
+        push!(keys, k)
+        haskey(_COMPILED, k) || haskey(blocks, k) || (blocks[k] = (Tb, ab, Cb))
+        lo = last(r)
+    end
+    if !isempty(blocks)                      # the misses of this call, compiled together
+        ks = collect(Base.keys(blocks))
+        if length(ks) == 1
+            Tb, ab, Cb = blocks[ks[1]]
+            _COMPILED[ks[1]] = _create(K, Tb, ab, Cb)
+        else
+            fs = [FSM(blocks[k][2], blocks[k][1], eltype(fsm.λ)[]) for k in ks]   # (the struct's own constructor, src/fsm.jl:7-17, 44: labels play no part in inference)
+            made = compile_many(fs, [blocks[k][3] for k in ks])
+            for (k, c) in zip(ks, made)
+                _COMPILED[k] = c
+            end
+        end
+    end
+    b = batch((_COMPILED[k]::ROCCompiledFSM{K} for k in keys)...)
+    _BATCHES[fsm] = (Ĉs, b, onehot)
+    b, onehot
 end
 
 function _recursion(sym::Symbol, b::ROCBatch, V::ROCArray{Float32,3}, lens)
@@ -377,6 +433,75 @@ function pdfposteriors_generic(b::ROCBatch{K}, V̂::ROCArray{T,3}, Ĉs = nothing
     end
     γ, ttl
 end
+
+"""
+    set_exact_policy!(b::ROCBatch, policy::Symbol = :auto)
+
+Which linear-domain kernels a shared-graph batch starts with (mm_batch_set_exact_policy): `:auto` (float32 first; the
+wide-exponent kernels first while the last FINISHED call left utterances marked -- read without synchronising, so a pipelined
+caller's kernel choice depends on host / device timing), `:f32_first`, `:f64_first` (both: the launches of a call are a
+function of the call alone, identical call sequences give identical bits).
+"""
+set_exact_policy!(b::ROCBatch, policy::Symbol = :auto) =
+    (check(ccall((:mm_batch_set_exact_policy, LIB), Cint, (Ptr{Cvoid}, Cint), b.handle,
+                 policy === :auto ? 0 : policy === :f32_first ? 1 : policy === :f64_first ? 2 : throw(ArgumentError("policy")))); b)
+
+# ---- the reference's semiring linear algebra on the device (src/linalg.jl): mul! and the sparse-vector broadcast --------------
+"""
+    ROCSparseCSR{K}(A::SparseMatrixCSC{K})  /  ROCSparseVec{K}(x::SparseVector{K})
+
+What `CuSparseMatrixCSR(adapt(CuArray, A))` / `adapt(CuArray, x)` are on the CUDA path (src/linalg.jl:80-131, test/test_linalg.jl:96):
+rowPtr / colVal (`Cint`, 1-based) / nzVal of A on the device.  `LinearAlgebra.mul!(c, A, b)` and `mul!(C, A, B, α, β)` on them are
+single calls of the HIP library (mm_spmv / mm_spmm), generic in `K` ∈ {Log, Tropical, Prob}Semiring{Float32 | Float64} like the
+reference's methods (src/linalg.jl:163-184, 240-262); dense operands are `ROCArray{K}` (a one-field immutable wrapper around a
+float: bit-identical to an array of floats).
+"""
+struct ROCSparseCSR{K}
+    rowPtr::ROCVector{Cint}
+    colVal::ROCVector{Cint}
+    nzVal::ROCVector{K}
+    dims::NTuple{2, Int}
+end
+function ROCSparseCSR(A::SparseMatrixCSC{K}) where K
+    At = SparseMatrixCSC(copy(A'))                     # CSC of A' = CSR of A
+    ROCSparseCSR{K}(ROCArray(Cint.(At.colptr)), ROCArray(Cint.(At.rowval)), ROCArray(nonzeros(At)), size(A))
+end
+Base.size(A::ROCSparseCSR) = A.dims
+Base.size(A::ROCSparseCSR, i::Integer) = A.dims[i]
+struct ROCSparseVec{K}
+    nzInd::ROCVector{Cint}
+    nzVal::ROCVector{K}
+    n::Int
+end
+ROCSparseVec(x::SparseVector{K}) where K = ROCSparseVec{K}(ROCArray(Cint.(SparseArrays.nonzeroinds(x))), ROCArray(nonzeros(x)), length(x))
+_floatbytes(::Type{K}) where K = sizeof(K)              # K wraps one float
+
+function LinearAlgebra.mul!(c::ROCVector{K}, A::ROCSparseCSR{K}, b::ROCVector{K}) where K
+    check(ccall((:mm_spmv, LIB), Cint,
+        (Cint, Cint, Int64, Int64, Int64, Ptr{Cint}, Ptr{Cint}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+        semiring_id(K), _floatbytes(K), size(A, 1), size(A, 2), length(A.nzVal), pointer(A.rowPtr), pointer(A.colVal), 1,
+        pointer(A.nzVal), pointer(b), length(b), pointer(c), length(c), AMDGPU.stream().stream))
+    c
+end
+function LinearAlgebra.mul!(C::ROCMatrix{K}, A::ROCSparseCSR{K}, B::ROCMatrix{K}, α::Number = true, β::Number = false) where K
+    check(ccall((:mm_spmm, LIB), Cint,
+        (Cint, Cint, Int64, Int64, Int64, Ptr{Cint}, Ptr{Cint}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Int64,
+         Int64, Cdouble, Ptr{Cvoid}),
+        semiring_id(K), _floatbytes(K), size(A, 1), size(A, 2), length(A.nzVal), pointer(A.rowPtr), pointer(A.colVal), 1,
+        pointer(A.nzVal), pointer(B), size(B, 1), size(B, 2), stride(B, 2), pointer(C), size(C, 1), size(C, 2), stride(C, 2),
+        Float64(β), AMDGPU.stream().stream))
+    C
+end
+"elmul!(out, y, x::ROCSparseVec) / eldiv!(out, x::ROCSparseVec, y) (src/linalg.jl:287-328): out = zero(K), out[i] = x[i] ⊗ y[i] (⊘) at x's stored entries."
+function _svdv!(op::Integer, out::ROCVector{K}, x::ROCSparseVec{K}, y::ROCVector{K}) where K
+    check(ccall((:mm_svdv, LIB), Cint,
+        (Cint, Cint, Cint, Int64, Int64, Ptr{Cint}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+        semiring_id(K), _floatbytes(K), op, x.n, length(x.nzVal), pointer(x.nzInd), 1, pointer(x.nzVal), pointer(y), length(y),
+        pointer(out), length(out), AMDGPU.stream().stream))
+    out
+end
+elmul!(out::ROCVector{K}, y::ROCVector{K}, x::ROCSparseVec{K}) where K = _svdv!(0, out, x, y)
+eldiv!(out::ROCVector{K}, x::ROCSparseVec{K}, y::ROCVector{K}) where K = _svdv!(1, out, x, y)
 
 """
     set_rccl(lib)

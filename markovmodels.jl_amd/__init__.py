@@ -17,6 +17,8 @@ from .inference import (  # noqa: F401
     betarecursion,
     compile,
     compile_many,
+    compiled_cache_clear,
+    compiled_cache_stats,
     expand,
     maxstateposteriors,
     pdfposteriors,

@@ -16,6 +16,7 @@ Two ways in:
 from __future__ import annotations
 
 import ctypes as C
+from collections import OrderedDict  # noqa: F401
 from typing import List, Optional, Sequence, Union
 
 import numpy as np
@@ -508,6 +509,83 @@ def _need_expanded(Vhats):
     return un
 
 
+# ---- compiled graphs of the reference-shaped entries: a process-wide LRU keyed by CONTENT.  `pdfposteriors(fsm::FSM, V_hats,
+# C_hats)` (src/inference.jl:145-161) takes plain FSMs and transposes / re-batches them on every call (:148-151); here a graph
+# is compiled (packed into the kernels' forms, uploaded) the first time its content is seen and found again by a 128-bit hash of
+# its fields afterwards -- the denominator graph of every call, the numerator graphs of an utterance across epochs.  Misses of
+# one call are compiled together (compile_many: host threads, one allocation, one copy).
+_COMPILED_LRU: "OrderedDict[bytes, CompiledFSM]" = None  # type: ignore[assignment]
+_COMPILED_LRU_MAX = 8192
+_CACHE_STATS = {"hits": 0, "misses": 0, "memo_hits": 0}
+
+
+def compiled_cache_stats(reset: bool = False) -> dict:
+    """{"hits", "misses", "memo_hits", "entries"} of the compiled-graph cache behind the reference-shaped entries."""
+    out = dict(_CACHE_STATS, entries=0 if _COMPILED_LRU is None else len(_COMPILED_LRU))
+    if reset:
+        for k in _CACHE_STATS:
+            _CACHE_STATS[k] = 0
+    return out
+
+
+def compiled_cache_clear():
+    global _COMPILED_LRU
+    _COMPILED_LRU = None
+
+
+def _content_key(part: FSM, c: StateMap) -> bytes:
+    try:
+        import xxhash
+
+        h = xxhash.xxh3_128()
+    except ImportError:  # pragma: no cover
+        import hashlib
+
+        h = hashlib.blake2b(digest_size=16)
+    nz = np.ascontiguousarray(part.nzval)
+    h.update(f"{part.semiring}|{part.S1}|{part.nnz}|{nz.dtype.str}|{c.numpdf}|".encode())
+    for a in (part.colptr, part.rowval, nz, part.alpha_idx, part.alpha_val, c.state2pdf):
+        a = np.ascontiguousarray(a)
+        h.update(memoryview(a).cast("B"))
+        h.update(b"|")
+    return h.digest()
+
+
+def _compiled_for(parts, Cs) -> List[CompiledFSM]:
+    global _COMPILED_LRU
+    from collections import OrderedDict
+
+    if _COMPILED_LRU is None:
+        _COMPILED_LRU = OrderedDict()
+    lru = _COMPILED_LRU
+    local, keys = {}, []
+    for part, c in zip(parts, Cs):  # (the same objects repeated -- one denominator graph B times -- are hashed once)
+        ik = (id(part), id(c))
+        if ik not in local:
+            local[ik] = _content_key(part, c)
+        keys.append(local[ik])
+    miss = {}
+    for k, part, c in zip(keys, parts, Cs):
+        if k in lru:
+            lru.move_to_end(k)
+        elif k not in miss:
+            miss[k] = (part, c)
+    _CACHE_STATS["hits"] += len(keys) - len(miss)
+    _CACHE_STATS["misses"] += len(miss)
+    if miss:
+        # one call per (semiring, float type) group: compile_many's graphs share both
+        groups = {}
+        for k, (part, c) in miss.items():
+            groups.setdefault((part.semiring, np.asarray(part.nzval).dtype == np.float64), []).append((k, part, c))
+        for grp in groups.values():
+            made = compile_many([g[1] for g in grp], [g[2] for g in grp]) if len(grp) > 1 else [CompiledFSM(grp[0][1], grp[0][2])]
+            for (k, _, _), cf in zip(grp, made):
+                lru[k] = cf
+        while len(lru) > _COMPILED_LRU_MAX:
+            lru.popitem(last=False)
+    return [lru[k] for k in keys]
+
+
 def _as_batch(fsm, Chats) -> BatchedFSM:
     if isinstance(fsm, BatchedFSM):
         return fsm
@@ -515,33 +593,85 @@ def _as_batch(fsm, Chats) -> BatchedFSM:
         return BatchedFSM([fsm])
     if Chats is None:
         raise TypeError("pdfposteriors(fsm::FSM, V_hats, C_hats) needs the state maps")
+    # the same FSM object with the same map objects as last time (a training loop's denominator): the batch as it was
+    memo = fsm.__dict__.get("_mm_batch_memo")
+    if memo is not None and len(memo[0]) == len(Chats) and all(a is b for a, b in zip(memo[0], Chats)):
+        _CACHE_STATS["memo_hits"] += 1
+        return memo[1]
     # (a general sparse C_hat rides along as an argument of the generic entry; its FSM handle gets a placeholder map)
     Cs = [c if isinstance(c, StateMap) else
           (StateMap(np.zeros(c.shape[0] - 1, dtype=np.int64), c.numpdf) if isinstance(c, GeneralStateMap) else StateMap.from_matrix(c))
           for c in Chats]
     parts = split_blocks(fsm, [c.shape[0] for c in Cs])
-    cache, cf = {}, []
-    for part, c in zip(parts, Cs):
-        key = (id(part), id(c))
-        if key not in cache:
-            cache[key] = CompiledFSM(part, c)
-        cf.append(cache[key])
-    return BatchedFSM(cf)
+    bf = BatchedFSM(_compiled_for(parts, Cs))
+    fsm.__dict__["_mm_batch_memo"] = (list(Chats), bf)
+    return bf
 
 
-def pdfposteriors(fsm, Vhats, Chats=None):
+def _device_vhats(Vhats):
+    """The V_hats as ONE device tensor [B, P+1, N+1] if they are float32 tensors on the HIP device (a list of (P+1) x (N+1)
+    matrices, or the stacked tensor itself), else None."""
+    try:
+        import torch
+    except ImportError:  # pragma: no cover
+        return None
+    if isinstance(Vhats, torch.Tensor):
+        return Vhats if (Vhats.is_cuda and Vhats.dim() == 3 and Vhats.dtype == torch.float32) else None
+    Vh = list(Vhats)
+    if not Vh or not all(isinstance(v, torch.Tensor) and v.is_cuda and v.dim() == 2 and v.dtype == torch.float32 for v in Vh):
+        return None
+    if any(v.shape != Vh[0].shape for v in Vh):
+        raise _lib.DimensionMismatch(-2, "all V_hat must share one (P+1) x (N+1) shape")
+    return torch.stack(Vh)
+
+
+def _pdfposteriors_device(bf: BatchedFSM, Vd, seqlengths):
+    """The reference call shape on device-resident V_hats, nothing crossing to the host unless asked to: the (P+1) x (N+1)
+    matrices of expand() (src/inference.jl:54-60) become the engine's [B, N, P] log-likelihoods + lengths by one transposing
+    copy; the lengths come from ``seqlengths`` (trusted, asynchronous) or -- one small reduction and a host read -- from the phony
+    row, whose form is then checked like _unexpand checks it.  Returns device tensors (gamma[B, P, N] as a view, ttl[B])."""
+    torch = _torch()
+    B, P1, N1 = Vd.shape
+    if B != bf.B:
+        raise _lib.DimensionMismatch(-2, f"{B} matrices V_hat for a batch of {bf.B} FSMs")
+    if seqlengths is None:
+        ph = Vd[:, P1 - 1, :]
+        lens = torch.isinf(ph).sum(dim=1).to(torch.int32)
+        step = torch.arange(N1, device=Vd.device)[None, :] < lens[:, None]
+        ok = bool((torch.where(step, torch.isneginf(ph), ph == 0).all() & (lens <= N1 - 1).all()).item())
+        if ok:  # real pdfs beyond the length are zero(K)
+            ok = bool(torch.isneginf(Vd[:, : P1 - 1, :]).masked_fill(step[:, None, :], True).all().item())
+        if not ok:
+            return None
+    else:
+        lens = torch.as_tensor(seqlengths, dtype=torch.int32, device=Vd.device)
+    V = Vd[:, : P1 - 1, : N1 - 1].transpose(1, 2).contiguous()
+    g, ttl = bf.pdfposteriors(V, lens)
+    return g.transpose(1, 2), ttl
+
+
+def pdfposteriors(fsm, Vhats, Chats=None, seqlengths=None):
     """pdfposteriors(fsm, V_hats, C_hats) (src/inference.jl:145-161) -- ``fsm`` the
     rawunion of the batch -- or pdfposteriors2(cfsm, V_hats) (:164-180) when
     given a BatchedFSM/CompiledFSM.  Returns (gamma[B, P, N] probabilities,
-    ttl[B]) as NumPy arrays, like the reference returns fresh arrays."""
-    Vh = [np.asarray(v.cpu() if hasattr(v, "cpu") else v) for v in Vhats]
+    ttl[B]): NumPy arrays for host inputs, like the reference returns fresh arrays; DEVICE tensors for float32 V_hats
+    that live on the HIP device (a list of (P+1) x (N+1) tensors or one [B, P+1, N+1] tensor), with nothing but the
+    compiled-graph cache between the call and the kernels (``seqlengths``: the lengths expand() was given, so that they
+    need not be read back from the phony row)."""
+    Vd = _device_vhats(Vhats)
     if Chats is not None:  # general sparse maps that are one-hot after all take the fast kernels
         Chats = [(c.one_hot() or c) if isinstance(c, GeneralStateMap) else c for c in Chats]
     bf = _as_batch(fsm, Chats)
     general_c = Chats is not None and any(isinstance(c, GeneralStateMap) for c in Chats)
+    fast = not (general_c or bf.semiring == "prob" or bf.dtype == np.float64)
+    if Vd is not None and fast:
+        out = _pdfposteriors_device(bf, Vd, seqlengths)
+        if out is not None:
+            return out
+    Vh = [np.asarray(v.cpu() if hasattr(v, "cpu") else v) for v in Vhats]
     # the precision follows the FSM's K like the reference (src/inference.jl:147 converts V_hat to K): a Float32 FSM computes
     # in float32 whatever the dtype of V_hat (NumPy's default float64 included), a Float64 FSM in float64
-    un = None if (general_c or bf.semiring == "prob" or bf.dtype == np.float64) else _unexpand(Vh)
+    un = _unexpand(Vh) if fast else None
     if un is None:
         # a Float64 FSM, ProbSemiring, a general C_hat, or V_hat that expand() did not make: the generic entry
         return bf.pdfposteriors_generic(Vh, Chats if general_c else None)

@@ -498,3 +498,65 @@ def test_two_batches_alive_on_two_streams(mm, wl, oracle, torch):
     bf3 = mm.batch(*([cf] * B))
     g3, t3 = bf3.pdfposteriors(V[0])
     assert torch.equal(g3, ref[0][0])
+
+
+@pytest.mark.parametrize("case", ["wsj_numerators", "config3_x64"])
+def test_reference_shaped_entry_at_engine_speed(mm, wl, oracle, torch, case):
+    """`pdfposteriors(rawunion(fsms...), V_hats, C_hats)` (src/inference.jl:145, the call of examples/test_cuda.jl:128) on DEVICE
+    tensors: the second call -- the graphs found in the compiled-graph cache, nothing crossing to the host -- within 1.3x of
+    BatchedFSM.pdfposteriors on the same batch, with its results; 128 WSJ numerator graphs (one per utterance, each a separate
+    FSM object with the same content here) and config 3's graph x 64."""
+    import time
+
+    if case == "wsj_numerators":
+        g0 = wl.load_npz_graph(os.path.join(HERE, "golden", "num_fsm_wsj.npz"))
+        B, N = 128, 700
+        fsms = [wl.to_fsm(mm, g0) for _ in range(B)]
+    else:
+        g0 = wl.lfmmi_denominator(2000, 84, seed=0)
+        B, N = 64, 1500
+        f0 = wl.to_fsm(mm, g0)
+        fsms = [f0] * B
+    Cs = [mm.statemap(g0.state2pdf, g0.P)] * B
+    rng = np.random.default_rng(0)
+    lens = rng.integers(N // 2, N + 1, B).astype(np.int32)
+    V = torch.randn(B, N, g0.P, device="cuda")
+    ninf = torch.full((), -float("inf"), device="cuda")
+    Vhat = torch.full((B, g0.P + 1, N + 1), -float("inf"), device="cuda")  # expand() (src/inference.jl:54-60) on the device
+    t = torch.arange(N + 1, device="cuda")[None, :] < torch.from_numpy(lens).cuda()[:, None]
+    Vhat[:, : g0.P, :N] = torch.where(t[:, None, :N], V.transpose(1, 2), ninf)
+    Vhat[:, g0.P, :] = torch.where(t, ninf, torch.zeros((), device="cuda"))
+    Vhats = [Vhat[b] for b in range(B)]
+    u = mm.rawunion(*fsms)
+    mm.compiled_cache_clear()
+    mm.compiled_cache_stats(reset=True)
+    g1, t1 = mm.pdfposteriors(u, Vhats, Cs)  # first call: compiles (one graph by content, found B - 1 times)
+    st = mm.compiled_cache_stats(reset=True)
+    assert st["misses"] == 1 and st["hits"] == B - 1
+    assert isinstance(g1, torch.Tensor) and g1.is_cuda and tuple(g1.shape) == (B, g0.P, N)
+    bf = mm.batch(*mm.compile_many(fsms, Cs)) if case == "wsj_numerators" else mm.batch(*([mm.compile(fsms[0], Cs[0])] * B))
+    ld = torch.from_numpy(lens).cuda()
+    g_ref, t_ref = bf.pdfposteriors(V, ld)
+    assert torch.allclose(g1.transpose(1, 2), g_ref, rtol=1e-4, atol=1e-6) and torch.allclose(t1, t_ref, rtol=1e-5, atol=1e-4)
+
+    def timed(fn, reps=10):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    t_engine = timed(lambda: bf.pdfposteriors(V, ld))
+    t_ref_shape = timed(lambda: mm.pdfposteriors(u, Vhats, Cs, seqlengths=ld))  # lengths given: nothing is read back
+    t_checked = timed(lambda: mm.pdfposteriors(u, Vhats, Cs))                    # lengths from the phony row (a host read)
+    st = mm.compiled_cache_stats()
+    assert st["misses"] == 0 and st["memo_hits"] >= 20
+    print(f"{case}: engine {1e3 * t_engine:.3f} ms, reference-shaped {1e3 * t_ref_shape:.3f} ms ({t_ref_shape / t_engine:.2f}x), "
+          f"with the lengths read from the phony row {1e3 * t_checked:.3f} ms")
+    assert t_ref_shape <= 1.3 * t_engine + 5e-5, (t_ref_shape, t_engine)
+    # a fresh rawunion of the same graphs (what a training step builds): the graphs are found by content, no compile
+    u2 = mm.rawunion(*fsms)
+    g2, t2 = mm.pdfposteriors(u2, Vhats, Cs, seqlengths=ld)
+    assert mm.compiled_cache_stats()["misses"] == 0 and torch.equal(t2, mm.pdfposteriors(u, Vhats, Cs, seqlengths=ld)[1])

@@ -366,3 +366,37 @@ def test_create_many_equals_single_creates(mm, wl):
         bad.rowval = bad.rowval.copy()
         bad.rowval[0] = 10 ** 6
         mm.compile_many([fsms[0], bad], [maps[0], maps[1]])
+
+
+def test_compiled_graph_cache_is_keyed_by_content(mm, wl):
+    """The reference-shaped entries (pdfposteriors(fsm::FSM, V_hats, C_hats), src/inference.jl:145) find a graph they have compiled
+    before by the CONTENT of its fields: equal graphs built twice share one CompiledFSM, a changed weight or state map does not,
+    the misses of one call are compiled together, and a repeated object is hashed once."""
+    import importlib
+
+    inf = importlib.import_module(mm.__name__ + ".inference")
+    inf.compiled_cache_clear()
+    inf.compiled_cache_stats(reset=True)
+    gs = [wl.random_fsm(20 + i, 5, 3.0, seed=i) for i in range(4)]
+    fsms = [wl.to_fsm(mm, g) for g in gs]
+    maps = [mm.statemap(g.state2pdf, g.P) for g in gs]
+    a = inf._compiled_for(fsms + [fsms[0]], maps + [maps[0]])
+    st = inf.compiled_cache_stats(reset=True)
+    assert st["misses"] == 4 and st["hits"] == 1 and a[0] is a[4] and len({id(x) for x in a}) == 4
+    # the same graphs built again from scratch: every one found
+    fsms2 = [wl.to_fsm(mm, wl.random_fsm(20 + i, 5, 3.0, seed=i)) for i in range(4)]
+    maps2 = [mm.statemap(g.state2pdf, g.P) for g in gs]
+    b = inf._compiled_for(fsms2, maps2)
+    st = inf.compiled_cache_stats(reset=True)
+    assert st["misses"] == 0 and st["hits"] == 4 and all(x is y for x, y in zip(a, b))
+    # one weight changed / another state map: new entries
+    f3 = wl.to_fsm(mm, gs[1])
+    f3.nzval = f3.nzval.copy()
+    f3.nzval[0] += 0.25
+    s2p = gs[2].state2pdf.copy()
+    s2p[0] = (s2p[0] + 1) % gs[2].P
+    c = inf._compiled_for([f3, fsms[2]], [maps[1], mm.statemap(s2p, gs[2].P)])
+    st = inf.compiled_cache_stats()
+    assert st["misses"] == 2 and c[0] is not a[1] and c[1] is not a[2] and st["entries"] == 6
+    assert inf._content_key(fsms[0], maps[0]) == inf._content_key(fsms2[0], maps2[0]) != inf._content_key(fsms[1], maps[1])
+    inf.compiled_cache_clear()

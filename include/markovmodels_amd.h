@@ -359,6 +359,13 @@ int mm_debug_split_product(mm_fsm_t fsm, int H, int direction, const float *in, 
  * MM_ERR_UNSUPPORTED if the FSM does not fit the form (more than 16 segments). */
 int mm_debug_wave_product(mm_fsm_t fsm, int direction, const float *in, float *out, double stats[4]);
 
+/* Test aid (host only, no GPU): the product evaluated THROUGH THE STREAM FORM of the stream kernels (mm_stream.hip: rows sorted
+ * by length and cut into segments of 64, one lane per row, rows of more than 128 arcs on a whole wave; 8-byte arc records
+ * {LDS address of the source, high dword of the weight's double}; float64 accumulation) exactly as a workgroup walks it.
+ * MM_LOG FSMs of up to 16 383 states and 1024 pdfs (MM_ERR_UNSUPPORTED otherwise).  stats (may be NULL) receives {arc slots per
+ * lane summed over the 15 waves, segments, real arcs / arc slots, arc slots of the most loaded wave}. */
+int mm_debug_stream_product(mm_fsm_t fsm, int direction, const float *in, float *out, double stats[4]);
+
 /* Test aid (host only, no GPU): the static bound the fast kernels use to recognise dead rows without a walk --
  * the fewest arcs from an initial state to every state (direction 0) or from every state to the phony final
  * state (direction 1), on the pruned graph; -1 = unreachable (such states are dropped).  out: host int32[S1].

@@ -157,6 +157,8 @@ struct mm_fsm_s {
     bool wave_tried = false, wave_packed = false;
     void *lane_blob = nullptr;                  // lane form (mm_kernel_lane.hip: up to 64 states): the device image, the LaneDev at its start
     bool lane_tried = false;
+    StreamForm *stream = nullptr;               // stream form (mm_stream.hip: graphs beyond the register-resident forms)
+    bool stream_tried = false;
     RowVariant *vrow = nullptr;                 // Viterbi form (mm_kernel_vit.hip)
     bool vit_tried = false;
     int vit_n4 = 0, vit_n2 = 0;                 // its layout: positions of 4 / of 2 arc slots per wave
@@ -182,7 +184,7 @@ struct mm_fsm_s {
 // MM_KQ / MM_NWAVES / MM_NITEMS force a geometry, MM_NO_XCSR keeps the exact-fallback CSR out of LDS,
 // MM_VERBOSE prints the packing statistics.
 struct DebugOpts {
-    enum { K_AUTO = 0, K_ITEM, K_QUAD, K_ROW, K_PAIR, K_WAVE, K_SPLIT, K_LANE };
+    enum { K_AUTO = 0, K_ITEM, K_QUAD, K_ROW, K_PAIR, K_WAVE, K_SPLIT, K_LANE, K_STREAM };
     int kernel = K_AUTO;
     int kq = 0, nwaves = 0, nitems = -1;
     bool no_xcsr = false, verbose = false;
@@ -203,7 +205,7 @@ static DebugOpts read_debug_opts() {
     if (!on || !*on || !strcmp(on, "0")) return d;
     if (const char *e = getenv("MM_KERNEL"))
         d.kernel = !strcmp(e, "item") ? DebugOpts::K_ITEM : !strcmp(e, "quad") ? DebugOpts::K_QUAD
-                 : !strcmp(e, "row") ? DebugOpts::K_ROW : !strcmp(e, "pair") ? DebugOpts::K_PAIR : !strcmp(e, "wave") ? DebugOpts::K_WAVE : !strcmp(e, "split") ? DebugOpts::K_SPLIT : !strcmp(e, "lane") ? DebugOpts::K_LANE : DebugOpts::K_AUTO;
+                 : !strcmp(e, "row") ? DebugOpts::K_ROW : !strcmp(e, "pair") ? DebugOpts::K_PAIR : !strcmp(e, "wave") ? DebugOpts::K_WAVE : !strcmp(e, "split") ? DebugOpts::K_SPLIT : !strcmp(e, "lane") ? DebugOpts::K_LANE : !strcmp(e, "stream") ? DebugOpts::K_STREAM : DebugOpts::K_AUTO;
     if (const char *e = getenv("MM_KQ")) d.kq = atoi(e);
     if (const char *e = getenv("MM_NWAVES")) d.nwaves = atoi(e);
     if (const char *e = getenv("MM_NITEMS")) d.nitems = atoi(e);
@@ -265,6 +267,8 @@ struct mm_batch_s {
     std::vector<UttDesc> utts_host;     // what d_utts holds
     bool items_resident = true;         // the FSMs' item forms are on the device (a batch of the wave kernel uploads them on first need)
     bool dpair_ok = false;
+    int stream_S1 = 0;
+    bool stream_ok = false;             // every FSM has a stream form and nothing faster takes the batch (mm_stream.hip)
     bool wpair_ok = false;              // a whole batch on the exact kernels fits the wide pair kernels (mm_kernel_wpair.hip: two utterances per workgroup)
     bool quad_built = false;            // the FSMs' quad forms exist (not built for batches whose exact path is the float64 kernels)
     int *stat_dev = nullptr;            // {count, ticket}
@@ -1073,6 +1077,23 @@ static int lane_variant(mm_fsm_t f, bool *ok) {
     return MM_OK;
 }
 
+// the stream form of an FSM (mm_stream.hip): built once; *ok = false if the graph does not fit it
+static int stream_variant(mm_fsm_t f, bool *ok) {
+    *ok = f->stream != nullptr;
+    if (f->stream || f->stream_tried) return MM_OK;
+    f->stream_tried = true;
+    if (f->semiring != MM_LOG) return MM_OK;
+    const int64_t *rp[2] = {f->mat[0].rowptr.data(), f->mat[1].rowptr.data()};
+    const int32_t *cl[2] = {f->mat[0].col.data(), f->mat[1].col.data()};
+    const float *vl[2] = {f->mat[0].val.data(), f->mat[1].val.data()};
+    int dev = -1;
+    const bool have_dev = hipGetDevice(&dev) == hipSuccess;
+    int rc = mm_stream_build(f->S1, f->P1, rp, cl, vl, f->init.data(), f->s2p.data(), have_dev, &f->stream);
+    if (rc) return rc;
+    *ok = f->stream != nullptr;
+    return MM_OK;
+}
+
 static int wave_pdf_table(const RowGraph &g, const std::vector<int32_t> &s2p, int64_t S1, int32_t P1, std::vector<uint32_t> &tab) {
     std::vector<std::vector<uint32_t>> src(static_cast<size_t>(P1));
     std::vector<std::pair<int32_t, int32_t>> bypos;  // (position, pdf): a fixed order of the states of a pdf
@@ -1324,6 +1345,7 @@ int mm_fsm_destroy(mm_fsm_t f) {
         }
     if (f->dev_blob) (void)hipFree(f->dev_blob);
     if (f->lane_blob) (void)hipFree(f->lane_blob);
+    mm_stream_free(f->stream);
     for (auto &kv : f->variants) {
         if (kv.second->blob) (void)hipFree(kv.second->blob);
         delete kv.second;
@@ -1482,6 +1504,18 @@ int mm_debug_row_product_ex(mm_fsm_t f, int direction, int flags, const float *i
         stats[7] = g.conflict_after;
     }
     return MM_OK;
+}
+
+int mm_debug_stream_product(mm_fsm_t f, int direction, const float *in, float *out, double stats[4]) {
+    if (!f || !in || !out || (direction != 0 && direction != 1)) return fail(MM_ERR_INVALID, "mm_debug_stream_product: bad argument");
+    return no_throw("mm_debug_stream_product", [&]() {
+        bool ok = false;
+        int rc = stream_variant(f, &ok);
+        if (rc) return rc;
+        if (!ok) return fail(MM_ERR_UNSUPPORTED, "mm_debug_stream_product: the FSM does not fit the stream form");
+        mm_stream_eval(f->stream, direction, in, out, stats);
+        return int(MM_OK);
+    });
 }
 
 int mm_debug_wave_product(mm_fsm_t f, int direction, const float *in, float *out, double stats[4]) {
@@ -1961,8 +1995,27 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     }
     // (a batch of the wave kernel never runs the quad kernels, and one whose marked utterances go to the float64 pair kernels
     // has the item kernel behind those: their quad forms are not built)
+    // stream kernels (mm_stream.hip): graphs beyond every register-resident form and beyond the quad kernels' LDS (more than ~3000
+    // states, more than 250 pdfs on different graphs / 506 on a shared one, weights outside the float range) -- what the item
+    // kernel ran until round 5
+    {
+        int64_t s1_max = 0;
+        for (int64_t b = 0; b < B; ++b) s1_max = std::max(s1_max, fsms[b]->S1);
+        const bool beyond = s1_max > 3000 || h->max_P1 > 250 || !h->fast_ok;
+        if (h->semiring == MM_LOG && !h->lane_ok && !h->wave_ok && !h->pairs_ok && !h->rows_ok &&
+            (h->dbg.kernel == DebugOpts::K_STREAM || (h->dbg.kernel == DebugOpts::K_AUTO && beyond))) {
+            h->stream_ok = true;
+            for (int64_t b = 0; b < B && h->stream_ok; ++b) {
+                bool ok = false;
+                int rc = stream_variant(fsms[b], &ok);
+                if (rc) return rc;
+                h->stream_ok = ok && mm_stream_dev(fsms[b]->stream) != nullptr;
+            }
+            h->stream_S1 = int(s1_max);
+        }
+    }
     const bool want_dpair = h->pairs_ok && !h->dbg.no_dpair;
-    h->quad_built = h->fast_ok && !h->wave_ok && !h->lane_ok && !(want_dpair && h->dbg.kernel != DebugOpts::K_QUAD);
+    h->quad_built = h->fast_ok && !h->wave_ok && !h->lane_ok && !h->stream_ok && !(want_dpair && h->dbg.kernel != DebugOpts::K_QUAD);
     // (the item forms -- the general fallback, the alpha / beta export, the total-sum family -- of a batch of the wave kernel go to
     // the device when an entry first needs them, ensure_item_forms(): a batch of new numerator graphs every training step
     // never does)
@@ -1984,6 +2037,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             u.map_bf = qv[1]->d_map_bf;
         }
         if (h->lane_ok) u.lane = static_cast<const LaneDev *>(f->lane_blob);
+        if (h->stream_ok) u.stream = mm_stream_dev(f->stream);
         if (h->vit_ok) u.rv = f->vrow->rdev;
         if (h->wave_ok)
             for (int d = 0; d < 2; ++d) u.rw[d] = f->wrows[d]->rdev;
@@ -2194,6 +2248,9 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
         } else if (h->wave_ok) {
             s = "mm_wave_kernel<" + std::to_string(h->wave_nseg <= 2 ? 2 : 4) + "," + std::to_string(h->max_P1 <= 128 ? 2 : 4) +
                 (h->wave_nseg <= 2 && h->B > h->n_cus ? ",two per CU>" : ">");
+        } else if (h->stream_ok) {
+            s = "mm_stream_kernel<forward>, then <backward> (arcs streamed from L2, the vector in LDS as wide-exponent 32-bit values, one utterance per "
+                "workgroup), mm_stream_finish_kernel, then for marked utterances only " + exact;
         } else if (h->pairs_ok && h->pair_H > 1) {
             const std::string k = std::to_string(mm_pair_nj(h->max_P1, h->pair_H)), H = std::to_string(h->pair_H);
             s = "mm_fbs_kernel<" + k + ",A," + H + ">, then <" + k + ",B," + H + "> (forward and backward agents in one grid, teams of " + H +
@@ -2368,7 +2425,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     char *const tail0 = static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N);
     int *const order = ordered ? reinterpret_cast<int *>(tail0) : nullptr;  // (first of the tail)
     p.order = order;
-    const bool marks = !h->wave_ok && !h->lane_ok && (h->rows_ok || h->pairs_ok);
+    const bool marks = !h->wave_ok && !h->lane_ok && (h->rows_ok || h->pairs_ok || h->stream_ok);
     // Which kernels first?  The float32 pair kernels, unless the inputs of the last finished call were beyond them for some of
     // its utterances (a sharp acoustic model marks every utterance) AND starting with the float64 kernels costs no more rounds
     // of workgroups than the float32 kernels followed by the float64 kernels for that many utterances would -- a launch lasts as
@@ -2418,6 +2475,16 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
         p.redo = reinterpret_cast<int *>(tail0 + align_up(size_t(h->B + 1) * 4, 256));
         h->last_redo = p.redo;
         rc = mm_launch_lane(h->B, h->lane_S, p, static_cast<hipStream_t>(stream));
+        if (rc || h->dbg.no_redo) return rc;
+        return launch(mm_log_kernel<MODE_FB, 0, 0, false, false>, mm_log_kernel<MODE_FB, 0, 0, false, true>, h, p, true, pick_geometry(h).NW, stream);
+    }
+    if (h->stream_ok) {
+        // the stream kernels (forward launch, backward launch, finish), then -- for the utterances whose range marks stay: values
+        // beyond the double's range that carry mass, normally none -- the item kernel, both passes in one launch
+        p.pair_zmin = reinterpret_cast<double *>(tail0 + 2 * align_up(size_t(h->B + 1) * 4, 256) + align_up(size_t(h->B + 1) * 2 * mm_pair_hand_bytes(), 256));
+        h->last_redo = p.redo;
+        h->last_z = p.pair_zmin;
+        rc = mm_launch_stream(h->B, h->stream_S1, h->max_P1, p, static_cast<hipStream_t>(stream));
         if (rc || h->dbg.no_redo) return rc;
         return launch(mm_log_kernel<MODE_FB, 0, 0, false, false>, mm_log_kernel<MODE_FB, 0, 0, false, true>, h, p, true, pick_geometry(h).NW, stream);
     }

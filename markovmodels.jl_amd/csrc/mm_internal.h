@@ -115,6 +115,17 @@ void mm_lane_dev_fill(void *dst, const double *w0, const double *w1, const float
                       const int *pdf_states, int S, int P, int ident);
 int mm_launch_lane(int64_t B, int max_S, const RunParams &p, hipStream_t stream);
 
+// ---- stream kernels (mm_stream.hip): graphs beyond every register-resident form -- the arcs streamed from L2 as 8-byte records,
+// the vector in LDS as wide-exponent 32-bit values, one utterance per workgroup, forward launch then backward launch
+struct StreamForm;
+size_t mm_stream_lds_bytes(int S1, int P1);
+int mm_stream_build(int64_t S1, int32_t P1, const int64_t *const rowptr[2], const int32_t *const col[2], const float *const val[2],
+                    const float *init, const int32_t *s2p, bool upload, StreamForm **out);  // *out NULL: does not fit
+void mm_stream_free(StreamForm *f);
+const void *mm_stream_dev(const StreamForm *f);
+void mm_stream_eval(const StreamForm *f, int d, const float *in, float *out, double stats[4]);
+int mm_launch_stream(int64_t B, int max_S1, int max_P1, const RunParams &p, hipStream_t st);
+
 // ---- Viterbi on the row-lane form (mm_vit_tu.hip)
 struct VitLaunch {
     int64_t B = 0;

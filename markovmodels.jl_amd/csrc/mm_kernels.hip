@@ -92,6 +92,7 @@ struct UttDesc {
     const int *s2p;     // state -> pdf [S1]
     const int *pdf_ptr, *pdf_rows;  // pdf -> states, CSR [P1 + 1], [S1]
     const struct LaneDev *lane;     // the lane form (mm_kernel_lane.hip: graphs of up to 64 states), else NULL
+    const void *stream;             // the stream form (mm_stream.hip: graphs beyond the register-resident forms; StreamPairDev), else NULL
     int S1, S1p, P1, pad;
     long long state_off;   // offset of this FSM in the block-diagonal state space
     long long s1p_prefix;  // sum of S1p of the utterances before this one

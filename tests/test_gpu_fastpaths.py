@@ -259,8 +259,8 @@ def test_posterior_floor_keeps_sharp_emissions_on_the_fast_kernels(mm, wl, oracl
 @pytest.mark.parametrize("S,P", [(6000, 300), (5000, 100), (2900, 120), (1000, 640), (6100, 60)])
 def test_graph_beyond_the_fast_paths(mm, wl, oracle, torch, S, P):
     """The reference's products have no size limit (src/linalg.jl:170-181).  1000 states x 640 pdfs and 6100 states are beyond
-    the pair kernels (2047 states, 506 pdfs) and the teams (6014 states; 314 pdfs for teams of 8): they run on the quad / item
-    kernels; a 2900-state graph of config 3's family takes the teams of two, 5000 and 6000 states (the latter with 300 pdfs:
+    the pair kernels (2047 states, 506 pdfs) and the teams (6014 states; 314 pdfs for teams of 8): they run on the stream kernels
+    (mm_stream.hip; the quad / item kernels until round 5); a 2900-state graph of config 3's family takes the teams of two, 5000 and 6000 states (the latter with 300 pdfs:
     mm_fbs_kernel<5, ., 8>) teams of EIGHT workgroups per utterance pair and direction.  Same results either way."""
     g = wl.lfmmi_denominator(S, P, seed=S)
     rng = np.random.default_rng(S + P)
@@ -272,6 +272,7 @@ def test_graph_beyond_the_fast_paths(mm, wl, oracle, torch, S, P):
     gam, ttl = bf.pdfposteriors(V, lens)
     kernels = bf.kernels()
     assert ("mm_fbs_kernel" in kernels) == (S in (2900, 5000, 6000)), kernels
+    assert ("mm_stream_kernel" in kernels) == (S in (1000, 6100)), kernels  # (beyond every register-resident form: the stream kernels)
     if S in (5000, 6000):
         assert ("mm_fbs_kernel<5,A,8>" if P == 300 else "mm_fbs_kernel<2,A,8>") in kernels, kernels
     assert bf.last_redo_count() == 0 or "mm_fbs_kernel" not in kernels
@@ -560,3 +561,61 @@ def test_reference_shaped_entry_at_engine_speed(mm, wl, oracle, torch, case):
     u2 = mm.rawunion(*fsms)
     g2, t2 = mm.pdfposteriors(u2, Vhats, Cs, seqlengths=ld)
     assert mm.compiled_cache_stats()["misses"] == 0 and torch.equal(t2, mm.pdfposteriors(u, Vhats, Cs, seqlengths=ld)[1])
+
+
+@pytest.mark.parametrize("case", ["forced_small", "different_graphs", "wsj_den", "sharp", "big"])
+def test_stream_kernels(mm, wl, oracle, torch, case):
+    """The stream kernels (mm_stream.hip: the arcs streamed from L2 as 8-byte records, the vector in LDS as wide-exponent 32-bit
+    values, float64 accumulation, one utterance per workgroup, forward launch then backward launch) against the float64 oracle:
+    forced onto graphs the faster kernels would take (different graphs in one batch; the reference's WSJ denominator with its
+    whole-wave final row; sharp emissions at -300 nats: no float32 anywhere on the path), and a 9000-state / 1000-pdf graph of
+    config 3's family -- beyond every register-resident form -- against the item kernel, which ran such graphs until round 5."""
+    rng = np.random.default_rng(3)
+    env = {"MM_KERNEL": "stream"}
+    if case == "forced_small":
+        gs = [wl.random_fsm(300, 11, 4.0, seed=9)] * 4
+        N, lens = 40, np.array([40, 1, 17, 0], dtype=np.int32)
+    elif case == "different_graphs":
+        gs = [wl.random_fsm(200 + 37 * i, 7, 3.0 + 0.3 * i, seed=i) for i in range(5)]
+        N, lens = 33, np.array([33, 33, 12, 30, 2], dtype=np.int32)
+    elif case == "wsj_den":
+        gs = [wsj_den(wl)] * 3
+        N, lens = 120, np.array([120, 77, 119], dtype=np.int32)
+    elif case == "sharp":
+        gs = [wl.lfmmi_denominator(1500, 84, seed=2)] * 5
+        N, lens = 90, np.array([90, 41, 90, 3, 88], dtype=np.int32)
+    else:
+        gs = [wl.lfmmi_denominator(9000, 1000, seed=5)] * 3
+        N, lens = 30, np.array([30, 19, 30], dtype=np.int32)
+        env = {}
+    B, P = len(gs), gs[0].P
+    V = (1.3 * rng.standard_normal((B, N, P))).astype(np.float32)
+    if case == "sharp":
+        x = 10.0 * rng.standard_normal((B, N, P))
+        V = (x - np.log(np.exp(x - x.max(-1, keepdims=True)).sum(-1, keepdims=True)) - x.max(-1, keepdims=True) - 300.0).astype(np.float32)
+    cfs = {}
+    for g in gs:
+        if id(g) not in cfs:
+            cfs[id(g)] = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = _with_env(dict(env, MM_DEBUG="1"), lambda: mm.batch(*[cfs[id(g)] for g in gs]))
+    assert "mm_stream_kernel" in bf.kernels(), bf.kernels()
+    gam, ttl = bf.pdfposteriors(V, lens)
+    assert bf.last_redo_count() == 0
+    if case == "big":  # (the oracle would take minutes: the item kernel is the independent implementation here)
+        bi = _with_env({"MM_DEBUG": "1", "MM_KERNEL": "item"}, lambda: mm.batch(*[cfs[id(g)] for g in gs]))
+        assert "mm_stream_kernel" not in bi.kernels()
+        g_ref, t_ref = bi.pdfposteriors(V, lens)
+        g_ref = g_ref.astype(np.float64)
+    else:
+        o, oc = oracle
+        g_ref = np.zeros((B, N, P))
+        t_ref = np.zeros(B)
+        for b, g in enumerate(gs):
+            gr, tr = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, V[b : b + 1], lens[b : b + 1], dtype=np.float64)
+            g_ref[b], t_ref[b] = gr[0], tr[0]
+    ok = np.isfinite(t_ref)
+    check_gamma(gam[ok], g_ref[ok], lens[ok])
+    assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-3)
+    assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()
+    g2, t2 = bf.pdfposteriors(V, lens)  # (float64 atomics in the per-pdf sums: the last bits may differ between runs, not more)
+    assert np.allclose(g2, gam, rtol=1e-5, atol=1e-7) and np.allclose(t2[ok], ttl[ok], rtol=1e-6)

@@ -400,3 +400,25 @@ def test_compiled_graph_cache_is_keyed_by_content(mm, wl):
     assert st["misses"] == 2 and c[0] is not a[1] and c[1] is not a[2] and st["entries"] == 6
     assert inf._content_key(fsms[0], maps[0]) == inf._content_key(fsms2[0], maps2[0]) != inf._content_key(fsms[1], maps[1])
     inf.compiled_cache_clear()
+
+
+@pytest.mark.parametrize("gname", ["rand300", "wide", "den_wsj", "big"])
+def test_stream_form_product(mm, wl, gname):
+    """The stream form (mm_stream.hip: arcs as 8-byte records streamed per frame, rows in segments of 64 sorted by length, rows of
+    more than 128 arcs on a whole wave) evaluates the same semiring products as the packed item form, in both directions: the
+    reference's WSJ denominator (its final state has ~1000 incoming arcs: a whole-wave row), a graph with wide rows, and a
+    7000-state / 900-pdf graph of config 3's family that no register-resident form takes."""
+    g = {"rand300": lambda: wl.random_fsm(300, 11, 4.0, seed=9), "wide": lambda: wl.wide_row_fsm(700, 11),
+         "den_wsj": lambda: wl.load_npz_graph(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "den_fsm_wsj.npz")),
+         "big": lambda: wl.lfmmi_denominator(7000, 900, seed=3)}[gname]()
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(cf.S1).astype(np.float32)
+    x[rng.integers(0, cf.S1, 5)] = -np.inf
+    for d in (0, 1):
+        ref, _ = cf.packed_product(x, d)
+        got, stats = cf.stream_product(x, d)
+        fin = np.isfinite(ref)
+        assert (got[~fin] == ref[~fin]).all()
+        assert np.allclose(got[fin], ref[fin], rtol=0, atol=5e-6 * np.maximum(1, np.abs(ref[fin])).max() + 2e-6 * 44), (gname, d)
+        assert (0.6 if cf.S1 > 2000 else 0.1) < stats[2] <= 1.0 and stats[1] >= cf.S1 / 64

@@ -1904,7 +1904,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     // alive whose values differ by more than the float range within one frame, so most of their rows would take the
     // exact fallback of the linear-domain kernels: they run on the item kernel (unless a kernel is forced).
     const bool linear_first = !h->wave_ok && !h->lane_ok && h->fast_ok && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD &&
-                              h->dbg.kernel != DebugOpts::K_WAVE &&
+                              h->dbg.kernel != DebugOpts::K_WAVE && h->dbg.kernel != DebugOpts::K_STREAM &&
                               !(h->max_depth >= 64 && nq_max[0] <= 3 * 1024 && nq_max[1] <= 3 * 1024 && h->dbg.kernel == DebugOpts::K_AUTO);
     h->rows_ok = linear_first;
     for (int64_t b = 0; b < B && h->rows_ok; ++b) {
@@ -1934,7 +1934,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     // split pair kernels: one shared FSM that is too large for the pair kernels proper (more arcs than the registers of a
     // compute unit hold, more states than half its LDS) -- teams of 2 workgroups per utterance pair and direction
     if (!h->wave_ok && !h->lane_ok && !h->pairs_ok && h->fast_ok && h->dbg.kernel != DebugOpts::K_ITEM && h->dbg.kernel != DebugOpts::K_QUAD &&
-        h->dbg.kernel != DebugOpts::K_ROW && h->dbg.kernel != DebugOpts::K_WAVE &&
+        h->dbg.kernel != DebugOpts::K_ROW && h->dbg.kernel != DebugOpts::K_WAVE && h->dbg.kernel != DebugOpts::K_STREAM &&
         !(h->max_depth >= 64 && nq_max[0] <= 3 * 1024 && nq_max[1] <= 3 * 1024 && h->dbg.kernel == DebugOpts::K_AUTO)) {
         bool same = true;
         for (int64_t b = 1; b < B && same; ++b) same = fsms[b] == fsms[0];
@@ -2249,8 +2249,8 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
             s = "mm_wave_kernel<" + std::to_string(h->wave_nseg <= 2 ? 2 : 4) + "," + std::to_string(h->max_P1 <= 128 ? 2 : 4) +
                 (h->wave_nseg <= 2 && h->B > h->n_cus ? ",two per CU>" : ">");
         } else if (h->stream_ok) {
-            s = "mm_stream_kernel<forward>, then <backward> (arcs streamed from L2, the vector in LDS as wide-exponent 32-bit values, one utterance per "
-                "workgroup), mm_stream_finish_kernel, then for marked utterances only " + exact;
+            s = "mm_stream_kernel (forward and backward recursions as workgroups of one grid; arcs streamed from L2, the vector in LDS as wide-exponent "
+                "32-bit values), mm_stream_combine_kernel, mm_stream_finish_kernel, then for marked utterances only " + exact;
         } else if (h->pairs_ok && h->pair_H > 1) {
             const std::string k = std::to_string(mm_pair_nj(h->max_P1, h->pair_H)), H = std::to_string(h->pair_H);
             s = "mm_fbs_kernel<" + k + ",A," + H + ">, then <" + k + ",B," + H + "> (forward and backward agents in one grid, teams of " + H +
@@ -2322,6 +2322,10 @@ static size_t ws_tail_bytes(mm_batch_t h) {  // longest-first order, redo marks,
 
 // (quad kernels) the emissions shifted by their per-frame maxima [B][N][P], and the maxima [B][N]
 static size_t ws_shift_bytes(mm_batch_t h, int64_t N) {
+    if (h->stream_ok) {  // (stream kernels: the backward direction's vectors and offsets, the frames' log Z)
+        size_t off[3];
+        return mm_stream_extra_bytes(h->B, h->total_s1p, N, off);
+    }
     if (!h->fast_ok || !h->quad_built) return 0;
     return align_up(size_t(h->B) * size_t(N) * size_t(h->max_P1 - 1) * 4, 256) + align_up(size_t(h->B) * size_t(N) * 4, 256);
 }
@@ -2484,7 +2488,15 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
         p.pair_zmin = reinterpret_cast<double *>(tail0 + 2 * align_up(size_t(h->B + 1) * 4, 256) + align_up(size_t(h->B + 1) * 2 * mm_pair_hand_bytes(), 256));
         h->last_redo = p.redo;
         h->last_z = p.pair_zmin;
-        rc = mm_launch_stream(h->B, h->stream_S1, h->max_P1, p, static_cast<hipStream_t>(stream));
+        {
+            size_t off[3];
+            (void)mm_stream_extra_bytes(h->B, h->total_s1p, N, off);
+            char *base = tail0 + ws_tail_bytes(h);
+            p.xbuf = reinterpret_cast<float *>(base + off[0]);    // the backward direction's vectors
+            p.xbuf_d = reinterpret_cast<float *>(base + off[1]);  // ... and offsets (doubles)
+            p.xps = reinterpret_cast<float *>(base + off[2]);     // the frames' {log2 Z, overlap term} (doubles)
+        }
+        rc = mm_launch_stream(h->B, h->n_cus, h->stream_S1, h->max_P1, p, static_cast<hipStream_t>(stream));
         if (rc || h->dbg.no_redo) return rc;
         return launch(mm_log_kernel<MODE_FB, 0, 0, false, false>, mm_log_kernel<MODE_FB, 0, 0, false, true>, h, p, true, pick_geometry(h).NW, stream);
     }

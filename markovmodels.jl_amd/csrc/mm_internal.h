@@ -124,7 +124,8 @@ int mm_stream_build(int64_t S1, int32_t P1, const int64_t *const rowptr[2], cons
 void mm_stream_free(StreamForm *f);
 const void *mm_stream_dev(const StreamForm *f);
 void mm_stream_eval(const StreamForm *f, int d, const float *in, float *out, double stats[4]);
-int mm_launch_stream(int64_t B, int max_S1, int max_P1, const RunParams &p, hipStream_t st);
+size_t mm_stream_extra_bytes(int64_t B, int64_t total_s1p, int64_t N, size_t off[3]);
+int mm_launch_stream(int64_t B, int n_cus, int max_S1, int max_P1, const RunParams &p, hipStream_t st);
 
 // ---- Viterbi on the row-lane form (mm_vit_tu.hip)
 struct VitLaunch {

@@ -19,10 +19,19 @@
 //   * emissions per ROW: a finish reads its pdf's staged emission from LDS (1000 pdfs: 4 KB per frame, staged by the service
 //     wave a step ahead); the state -> pdf sums of the combine are LDS float64 atomics (ds_add_f64) into per-pdf sums the service
 //     wave normalises a step later -- any number of pdfs up to 1024, no per-pdf ranges;
-//   * forward launch (alpha~ stored once per frame, in the BACKWARD numbering: the scattered stores cost nothing, the backward
-//     launch then reads its rows' alpha~ coalesced and a segment ahead), then backward launch (beta never materialised).
-// Per frame a workgroup streams its whole graph: ~1.4 MB at the ~130 GB/s a compute unit gets from its L2 is ~10 us; 700 + 700
-// frames = 15 ms at B = 64 (64 workgroups; the bidirectional split of the pair kernels would halve it and is not built).
+//   * BOTH recursions at once: the forward and the backward workgroup of an utterance are workgroups of ONE grid (2 B workgroups:
+//     B = 64 uses 128 compute units; two grids one after the other when 2 B exceeds the chip); each stores its normalised log2
+//     vector of every frame -- alpha~ with, beta~ without the frame's emission -- in a numbering both share (states sorted by
+//     pdf: the scattered 4-byte stores of a finish cost nothing), and mm_stream_combine_kernel then reads both rows of a frame
+//     coalesced, sums 2^(alpha~ + beta~) over each pdf's contiguous range in float64 -- no atomics, a fixed order: deterministic
+//     --, normalises the frame like the reference (src/inference.jl:154-160) and leaves the frame's log Z for the finish kernel.
+//     (The first version ran a forward launch, then a backward launch that combined on the fly with LDS float64 atomics: 41 ms for
+//     10 000 states / 1000 pdfs at B = 64 on 64 compute units; this one: see DESIGN.md.)
+// What bounds a frame (10 000 states, 162 k arcs: 1.3 MB of records): the vector memory path of the compute unit -- the records
+// alone cost ~14 us per frame (2500 wave loads of 512 bytes; the same kernel with the ring loaded once per frame takes half the
+// time) -- next to ~14 us of gathers, FMAs, finishes and barriers that a wave's serial chain (wait for records, gather, wait, FMA)
+// overlaps only partly; the gathers' bank conflicts (no bank-aware placement here) do not show: without the gathers the time is
+// the same (-DMM_STREAM_NOGATHER / -DMM_STREAM_NOLOAD, timing experiments).
 #define MM_SECONDARY_TU
 #include "mm_internal.h"
 #include "mm_kernel_wpair.hip"
@@ -38,7 +47,7 @@ namespace mm {
 struct StreamDev {  // one direction, device pointers
     const unsigned long long *arcs;  // [slots of all waves][64]: {4 * position of the source, high dword of the weight}
     const unsigned *seg;             // [segments][4]: arc slots, log2 lanes per row (0 or 6), first position, rows
-    const unsigned *rinfo;           // [rows] by position: pdf | position in the OTHER direction's numbering << 12
+    const unsigned *rinfo;           // [rows] by position: pdf | position in the pdf-major numbering both directions store in << 12
     const float *init;               // [rows] by position: alpha_hat, log2 (forward)
     int wave_seg0[16], wave_slot0[16];  // per compute wave: first segment / first arc slot (entry 15: the totals)
     int rows, fpos, vb, pad;         // vb: bytes of one LDS vector
@@ -47,6 +56,8 @@ struct StreamDev {  // one direction, device pointers
 };
 struct StreamPairDev {
     StreamDev d[2];
+    const int *pdf_ptr;  // [P1 + 1]: the states of pdf q are the pdf-major positions pdf_ptr[q] .. pdf_ptr[q + 1] - 1
+    int P1, pad;
 };
 
 struct StreamForm {
@@ -58,11 +69,12 @@ struct StreamForm {
     std::vector<unsigned long long> h_arcs[2];
     std::vector<unsigned> h_seg[2], h_rinfo[2];
     std::vector<float> h_init;
-    std::vector<int32_t> pos[2];
+    std::vector<int32_t> pos[2], qpos, h_pdf_ptr;
 };
 
 constexpr int kStreamWaves = 15;
 constexpr int kStreamWide = 128;  // rows of more arcs get a whole wave
+constexpr int kStreamChunk = 4;   // records per chunk: a segment is a whole number of chunks, its info record the last of them
 
 static unsigned w_hi_of(double v) {  // high dword, 20 mantissa bits rounded to nearest
     unsigned long long b;
@@ -74,7 +86,7 @@ static int stream_nj(int P1) { return P1 <= 128 ? 2 : (P1 <= 256 ? 4 : (P1 <= 51
 size_t mm_stream_lds_bytes(int S1, int P1) {
     const size_t vb = (size_t(4) * (size_t(S1) + 1) + 255) & ~size_t(255);
     const size_t pc = size_t(64) * size_t(stream_nj(P1));
-    return 2 * vb + 24 * pc /* EM 2 x 4, PSUM 2 x 8 per pdf */ + 256;
+    return 2 * vb + 8 * pc /* EM: 2 x 4 bytes per pdf */ + 256;
 }
 
 static bool stream_pack(int d, int64_t S1, const int64_t *rowptr, const int32_t *col, const float *val, std::vector<int32_t> &pos,
@@ -123,7 +135,7 @@ static bool stream_pack(int d, int64_t S1, const int64_t *rowptr, const int32_t 
             seg.push_back(unsigned(sg.n));
             for (int k = 0; k < sg.n; ++k) pos[size_t(rows[size_t(sg.first + k)])] = p0 + k;
             p0 += sg.n;
-            nslot += sg.nsl;
+            nslot += kStreamChunk * ((sg.nsl + 1 + kStreamChunk - 1) / kStreamChunk);  // (its arcs + the info record, in whole chunks)
             ++nseg;
         }
     }
@@ -139,15 +151,16 @@ static bool stream_pack(int d, int64_t S1, const int64_t *rowptr, const int32_t 
 }
 
 static void stream_fill(int64_t S1, const int64_t *rowptr, const int32_t *col, const float *val, const std::vector<int32_t> &pos,
-                        const std::vector<unsigned> &seg, const int (&wave_slot0)[16], const int (&wave_seg0)[16],
-                        std::vector<unsigned long long> &arcs) {
+                        const std::vector<int32_t> &qpos, const int32_t *s2p, const std::vector<unsigned> &seg,
+                        const int (&wave_slot0)[16], const int (&wave_seg0)[16], std::vector<unsigned long long> &arcs) {
     std::vector<int32_t> order(static_cast<size_t>(S1));
     for (int64_t r = 0; r < S1; ++r) order[size_t(pos[size_t(r)])] = int32_t(r);
-    arcs.assign(size_t(wave_slot0[kStreamWaves]) * 64, 0ull);
+    arcs.assign((size_t(wave_slot0[kStreamWaves]) + 32) * 64, 0ull);  // (+ padding: the kernels' ring reads 24 records ahead)
     for (int w = 0; w < kStreamWaves; ++w) {
         size_t slot = size_t(wave_slot0[w]);
         for (int s = wave_seg0[w]; s < wave_seg0[w + 1]; ++s) {
             const unsigned nsl = seg[size_t(4 * s)], lg = seg[size_t(4 * s + 1)], p0 = seg[size_t(4 * s + 2)], n = seg[size_t(4 * s + 3)];
+            const unsigned nrec = unsigned(kStreamChunk) * ((nsl + 1 + kStreamChunk - 1) / kStreamChunk);
             for (unsigned l = 0; l < 64; ++l) {
                 const int32_t r = lg ? order[p0] : (l < n ? order[p0 + l] : -1);
                 if (r < 0) continue;
@@ -158,8 +171,10 @@ static void stream_fill(int64_t S1, const int64_t *rowptr, const int32_t *col, c
                     const double wl = std::exp2(double(val[a]));
                     arcs[(slot + k) * 64 + l] = (static_cast<unsigned long long>(w_hi_of(wl)) << 32) | (4u * unsigned(pos[size_t(col[a])]));
                 }
+                // the info record of the segment: {0, pdf | pdf-major position << 12} of the lane's row
+                arcs[(slot + nrec - 1) * 64 + l] = static_cast<unsigned long long>(unsigned(s2p[r]) | (unsigned(qpos[size_t(r)]) << 12)) << 32;
             }
-            slot += nsl;
+            slot += nrec;
         }
     }
 }
@@ -177,13 +192,29 @@ int mm_stream_build(int64_t S1, int32_t P1, const int64_t *const rowptr[2], cons
     for (int d = 0; d < 2; ++d) {
         if (!stream_pack(d, S1, rowptr[d], col[d], val[d], f->pos[d], f->h_seg[d], f->host.d[d].wave_seg0, f->host.d[d].wave_slot0, &wmin[d]))
             return MM_OK;
-        stream_fill(S1, rowptr[d], col[d], val[d], f->pos[d], f->h_seg[d], f->host.d[d].wave_slot0, f->host.d[d].wave_seg0, f->h_arcs[d]);
     }
+    // the numbering both directions STORE in: states sorted by pdf (the combine kernel sums a pdf's contiguous range)
+    {
+        std::vector<int32_t> by(static_cast<size_t>(S1));
+        std::iota(by.begin(), by.end(), 0);
+        std::stable_sort(by.begin(), by.end(), [&](int32_t a, int32_t b) { return s2p[a] < s2p[b]; });
+        f->qpos.assign(size_t(S1), 0);
+        f->h_pdf_ptr.assign(size_t(P1) + 1, 0);
+        for (int64_t i = 0; i < S1; ++i) {
+            f->qpos[size_t(by[size_t(i)])] = int32_t(i);
+            if (s2p[by[size_t(i)]] < 0 || s2p[by[size_t(i)]] >= P1) return MM_OK;
+            ++f->h_pdf_ptr[size_t(s2p[by[size_t(i)]]) + 1];
+        }
+        for (int q = 0; q < P1; ++q) f->h_pdf_ptr[size_t(q) + 1] += f->h_pdf_ptr[size_t(q)];
+    }
+    for (int d = 0; d < 2; ++d)
+        stream_fill(S1, rowptr[d], col[d], val[d], f->pos[d], f->qpos, s2p, f->h_seg[d], f->host.d[d].wave_slot0, f->host.d[d].wave_seg0,
+                    f->h_arcs[d]);
     f->h_init.assign(size_t(S1), -INFINITY);
     for (int d = 0; d < 2; ++d) {
         f->h_rinfo[d].assign(size_t(S1), 0u);
         for (int64_t r = 0; r < S1; ++r)
-            f->h_rinfo[d][size_t(f->pos[d][size_t(r)])] = unsigned(s2p[r]) | (unsigned(f->pos[1 - d][size_t(r)]) << 12);
+            f->h_rinfo[d][size_t(f->pos[d][size_t(r)])] = unsigned(s2p[r]) | (unsigned(f->qpos[size_t(r)]) << 12);
         StreamDev &sd = f->host.d[d];
         sd.rows = int(S1);
         sd.fpos = f->pos[d][size_t(S1 - 1)];
@@ -194,7 +225,7 @@ int mm_stream_build(int64_t S1, int32_t P1, const int64_t *const rowptr[2], cons
     for (int64_t r = 0; r < S1; ++r) f->h_init[size_t(f->pos[0][size_t(r)])] = init[r];
     if (upload) {
         size_t off = (sizeof(StreamPairDev) + 255) & ~size_t(255);
-        size_t o_arcs[2], o_seg[2], o_rinfo[2], o_init;
+        size_t o_arcs[2], o_seg[2], o_rinfo[2], o_init, o_pp;
         auto place = [&](size_t bytes) {
             const size_t o = off;
             off = (off + bytes + 255) & ~size_t(255);
@@ -206,6 +237,7 @@ int mm_stream_build(int64_t S1, int32_t P1, const int64_t *const rowptr[2], cons
             o_rinfo[d] = place(f->h_rinfo[d].size() * 4);
         }
         o_init = place(f->h_init.size() * 4);
+        o_pp = place(f->h_pdf_ptr.size() * 4);
         std::vector<char> img(off, 0);
         HIP_TRY(hipMalloc(&f->blob, off));
         char *base = static_cast<char *>(f->blob);
@@ -220,6 +252,10 @@ int mm_stream_build(int64_t S1, int32_t P1, const int64_t *const rowptr[2], cons
             dv.d[d].init = reinterpret_cast<const float *>(base + o_init);
         }
         memcpy(img.data() + o_init, f->h_init.data(), f->h_init.size() * 4);
+        memcpy(img.data() + o_pp, f->h_pdf_ptr.data(), f->h_pdf_ptr.size() * 4);
+        dv.pdf_ptr = reinterpret_cast<const int *>(base + o_pp);
+        dv.P1 = P1;
+        dv.pad = 0;
         memcpy(img.data(), &dv, sizeof(dv));
         if (hipMemcpy(f->blob, img.data(), off, hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipFree(f->blob);
@@ -268,7 +304,7 @@ void mm_stream_eval(const StreamForm *f, int d, const float *in, float *out, dou
             } else {
                 for (unsigned l = 0; l < n; ++l) res[p0 + l] = acc[l];
             }
-            slot += nsl;
+            slot += size_t(kStreamChunk) * ((nsl + 1 + kStreamChunk - 1) / kStreamChunk);  // (whole chunks: arcs, padding, the info record)
         }
     }
     for (int r = 0; r < S1; ++r) {
@@ -289,35 +325,40 @@ void mm_stream_eval(const StreamForm *f, int d, const float *in, float *out, dou
 template <int NJ>
 struct StreamLay {  // LDS bytes behind the two vectors (vb each)
     static constexpr unsigned PC = 64u * NJ;
-    static constexpr unsigned EM(int par) { return unsigned(par) * 4u * PC; }              // staged emissions [pdf] (+ the phony pdf)
-    static constexpr unsigned PSUM(int par) { return 8u * PC + unsigned(par) * 8u * PC; }  // doubles [pdf]
-    static constexpr unsigned MS(int par) { return 24u * PC + 8u * unsigned(par); }        // the step's normaliser
-    static constexpr unsigned MX(int par) { return 24u * PC + 16u + 8u * unsigned(par); }  // maximum (high dword) of the vector a step writes
-    static constexpr unsigned OWN(int k) { return 24u * PC + 32u + 8u * unsigned(k); }     // own offsets of the last 4 steps (doubles)
-    static constexpr unsigned TOTAL = 24u * PC + 64u;
+    static constexpr unsigned EM(int par) { return unsigned(par) * 4u * PC; }               // staged emissions [pdf] (+ the phony pdf)
+    static constexpr unsigned MS(int par) { return 8u * PC + 8u * unsigned(par); }          // the step's normaliser
+    static constexpr unsigned MX(int par) { return 8u * PC + 16u + 8u * unsigned(par); }    // maximum (high dword) of the vector a step writes
+    static constexpr unsigned TOTAL = 8u * PC + 64u;
 };
 
-__device__ __forceinline__ void lds_atomic_add_f64(unsigned addr, double v) {
-    typedef __attribute__((address_space(3))) double lds_f64;
-    (void)__hip_atomic_fetch_add((lds_f64 *)(__UINTPTR_TYPE__)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 __device__ __forceinline__ void lds_atomic_max_u32(unsigned addr, unsigned v) {
     typedef __attribute__((address_space(3))) unsigned lds_u32;
     (void)__hip_atomic_fetch_max((lds_u32 *)(__UINTPTR_TYPE__)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// PASS 0: forward (alpha~ of every frame stored in the backward numbering), 1: backward (+ combine, per-pdf sums, gamma)
-template <int PASS, int NJ>
-__global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p) {
+// where the two recursions leave their vectors and offsets (p.ws_alpha / p.ws_c hold the forward direction's; the backward
+// direction's follow in the stream batch's extra workspace: RunParams::xbuf / xbuf_d reused as plain pointers)
+__device__ __forceinline__ float *stream_rows(const RunParams &p, int dir) { return dir ? p.xbuf : p.ws_alpha; }
+__device__ __forceinline__ double *stream_offs(const RunParams &p, int dir) { return dir ? reinterpret_cast<double *>(p.xbuf_d) : p.ws_c; }
+
+// One workgroup = one direction (dir: 0 forward / alpha, 1 backward / beta; a run-time value, uniform) of one utterance.
+// The record stream of a wave: per segment its arc records, then ONE info record {0, pdf | pdf-major position << 12} of the rows
+// the lanes finish -- everything a finish needs arrives in the ring, nothing is loaded inside it: a load issued in the middle of
+// the stream can only be waited for by draining the ring (the counter is in order), 10 drains per wave and frame.
+template <int NJ>
+__global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_base) {
     extern __shared__ float lds[];
     using L = StreamLay<NJ>;
-    constexpr int C = 8;  // arc records per chunk (two chunks in flight per wave)
+    constexpr int C = kStreamChunk, K = 6;  // records per chunk, chunks in flight per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool service = wave == kStreamWaves;
-    const int b = uni(p.order ? p.order[blockIdx.x] : (int)blockIdx.x);
+    // (one grid holds both directions -- the first B workgroups forward, the second B backward -- or dir_base says which)
+    const int DIR = uni(dir_base >= 0 ? dir_base : ((int)blockIdx.x >= p.B ? 1 : 0));
+    const int ui = (int)blockIdx.x - (dir_base < 0 && DIR ? p.B : 0);
+    const int b = uni(p.order ? p.order[ui] : ui);
     const UttDesc &ud = p.utts[b];
     const StreamPairDev *spd = uni(reinterpret_cast<const StreamPairDev *>(ud.stream));
-    const StreamDev &sd = spd->d[PASS];
+    const StreamDev &sd = spd->d[DIR];
     const int S1 = uni(sd.rows), P1 = uni(ud.P1), P = P1 - 1, S1p = uni(ud.S1p);
     const unsigned VB = (unsigned)uni(sd.vb), FIX = 2u * VB;
     int len = uni(p.lens ? p.lens[b] : p.N);
@@ -325,35 +366,29 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p) {
     const int NF = len + 1;
     const float *Vb = p.V + (long long)b * p.vsb;
     const long long s1p_prefix = ((long long)uni((int)(ud.s1p_prefix >> 32)) << 32) | (unsigned)uni((int)ud.s1p_prefix);
-    float *rows = p.ws_alpha + s1p_prefix * (long long)(p.N + 1);  // [frame - 1][S1p]: alpha~ by BACKWARD position
-    double *offs = p.ws_c + (long long)b * (p.N + 2);               // [frame]: the offset of the stored alpha~
+    float *rows = stream_rows(p, DIR) + s1p_prefix * (long long)(p.N + 1);  // [frame - 1][S1p]: the direction's log2 vectors, pdf-major
+    double *offs = stream_offs(p, DIR) + (long long)b * (p.N + 2);           // [frame]: their offsets
     const float thr = sd.thr;
-    auto frame_of = [&](int t) { return PASS ? NF + 1 - t : t; };
+    auto frame_of = [&](int t) { return DIR ? NF + 1 - t : t; };
     if (lds_addr_of(lds) != 0u) __builtin_trap();
-    if (len == 0) {  // no frame: no path of length 0 (the finish kernel writes ttl = -inf and the zeros)
-        if (PASS == 1 && tid == 0) {
-            p.pair_zmin[(long long)b * 6 + 0] = p.pair_zmin[(long long)b * 6 + 1] = __builtin_inf();
-            p.pair_zmin[(long long)b * 6 + 2] = p.pair_zmin[(long long)b * 6 + 3] = -__builtin_inf();
-            p.pair_zmin[(long long)b * 6 + 4] = p.pair_zmin[(long long)b * 6 + 5] = __builtin_inf();
-        }
-        return;
-    }
+    if (len == 0) return;  // no frame: no path of length 0 (the combine / finish kernels write ttl = -inf and the zeros)
     for (unsigned q = tid * 4u; q < FIX + L::TOTAL; q += 4096u) ldsw(q, 0.f);
     __syncthreads();
 
     if (service) {
-        // ================= service wave: emissions, normalisers, offsets; backward: the posteriors =================
+        // ================= service wave: emissions, normalisers, offsets =================
         RowNorm norm;
-        double cum = 0.0, zmin = __builtin_inf(), zmax = -__builtin_inf();
-        float ltmin = __builtin_inff();
+        double cum = 0.0;
         // stage the emissions of step t (frame f) into EM(t & 1): log2 values relative to the frame's maximum E
         auto stage = [&](int t, float S) {
             const int f = frame_of(t);
             float v[NJ], E = MM_NINF;
 #pragma unroll
+            for (int j = 0; j < NJ; ++j) v[j] = em_load_raw(Vb, p.vsn, f, p.N, P, lane + 64 * j);  // (all loads first: one round trip, not NJ)
+#pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int q = lane + 64 * j;
-                v[j] = em_value(em_load_raw(Vb, p.vsn, f, p.N, P, q), f, len, P, q);
+                v[j] = em_value(v[j], f, len, P, q);
                 if (q < P) E = max_nc(E, v[j]);
             }
             E = wave_max_rl(E);
@@ -366,49 +401,11 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p) {
             cum += (double)S + (double)E;
             if (lane == 0) {
                 ldsw(FIX + L::MS(t & 1), S);
-                // the offset that turns the step's stored / combined vector into log2 values: alpha~ includes the frame's emission
-                const double off = PASS ? cum - (double)E : cum;
-                *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(FIX + L::OWN(t & 3)) = off;
-                if (PASS == 0) offs[f] = off;
+                // the offset that turns the step's stored vector into log2 values: alpha~ includes the frame's emission, beta~ not
+                offs[f] = DIR ? cum - (double)E : cum;
             }
         };
-        // posteriors and per-frame log Z of step ts (its per-pdf sums are complete); then the sums are zeroed for step ts + 2
-        auto frames_of_step = [&](int ts) {
-            const int f = frame_of(ts);
-            const unsigned psum = FIX + L::PSUM(ts & 1);
-            double t = 0.0;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {  // (the sums are read twice: 16 passes of doubles kept in registers spilled)
-                const int q = lane + 64 * j;
-                const double v = ldsr_d(psum + 8u * (unsigned)(q < P1 ? q : 0));
-                if (q < P1) t += v;
-            }
-            t = dwave_sum_rl(t);
-            const int e = __builtin_amdgcn_frexp_exp(t);
-            const float tf = (float)__builtin_amdgcn_ldexp(t, -e);
-            const float inv = tf > 0.f ? 1.f / tf : 0.f;
-            float *gp = p.gamma + (long long)b * p.gsb + (long long)(f - 1) * p.gsn;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int q = lane + 64 * j;
-                if (q < P1) {
-                    const double v = ldsr_d(psum + 8u * (unsigned)q);
-                    if (q < P && f >= 1 && f <= len) gp[q * p.gsp] = (float)__builtin_amdgcn_ldexp(v, -e) * inv;
-                    ldsw_d(psum + 8u * (unsigned)q, 0.0);
-                }
-            }
-            if (f >= 1 && f <= len) {
-                const float lt = dlog2(t);
-                const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(FIX + L::OWN(ts & 3));
-                const double z = (double)lt + own + offs[f];
-                zmin = z < zmin ? z : zmin;
-                zmax = z > zmax ? z : zmax;
-                ltmin = lt < ltmin ? lt : ltmin;
-            }
-        };
-        if (PASS == 0) {  // step 1: alpha_hat (*) lhs[:, 1] needs the emissions of frame 1 (nothing but E is subtracted)
-            stage(1, 0.f);
-        }
+        if (DIR == 0) stage(1, 0.f);  // step 1: alpha_hat (*) lhs[:, 1] needs the emissions of frame 1 (nothing but E is subtracted)
         __syncthreads();  // (1)
         if (2 <= NF) stage(2, 0.f);
         __syncthreads();  // (2) the starting vector is in LDS
@@ -418,33 +415,26 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p) {
             const float mx = w_log2_hi(ldsru(mxa));
             if (lane == 0) ldswu(mxa, 0u);
             if (t + 1 <= NF) stage(t + 1, norm.next(mx));
-            if (PASS == 1 && t - 1 >= 2) frames_of_step(t - 1);
             __syncthreads();
-        }
-        if (PASS == 1) {
-            if (NF >= 2) frames_of_step(NF);
-            if (lane == 0) {
-                p.pair_zmin[(long long)b * 6 + 0] = p.pair_zmin[(long long)b * 6 + 1] = zmin;
-                p.pair_zmin[(long long)b * 6 + 2] = p.pair_zmin[(long long)b * 6 + 3] = zmax;
-                p.pair_zmin[(long long)b * 6 + 4] = p.pair_zmin[(long long)b * 6 + 5] = (double)ltmin;
-            }
         }
     } else {
         // ================= compute waves =================
         __syncthreads();  // (1)
         unsigned vmax = 0u;
         float worst = 0.f;
-        if (PASS == 0) {  // alpha_hat (*) lhs[:, 1]   (src/inference.jl:68)
-            const unsigned *ri = uni(sd.rinfo);
-            const float *ini = uni(sd.init);
+        typedef __attribute__((address_space(1))) float *gfptr;
+        if (DIR == 0) {  // alpha_hat (*) lhs[:, 1]   (src/inference.jl:68)
+            const auto rinfo = as_global(uni(sd.rinfo));
+            const auto ini = as_global(uni(sd.init));
+            const gfptr rows_g = (gfptr)(__UINTPTR_TYPE__)rows;
             for (int i = tid; i < S1; i += 64 * kStreamWaves) {
-                const unsigned info = ri[i];
+                const unsigned info = rinfo[i];
                 const float v0 = ini[i] + ldsr(FIX + L::EM(1) + 4u * (info & 0xfffu));
                 worst = __builtin_fmaxf(worst, __builtin_fmaf(__builtin_fabsf(v0), 0.f, __builtin_fabsf(v0)));
                 const unsigned hi = w_exp2_hi(v0);
                 vmax = vmax > hi ? vmax : hi;
                 ldswu(VB * 1u + 4u * (unsigned)i, hi);
-                rows[(long long)0 * S1p + (info >> 12)] = v0;
+                rows_g[(long long)0 * S1p + (info >> 12)] = v0;
             }
         } else {  // B[:, N+1] = one at the final state   (src/inference.jl:104)
             if (tid == 0) {
@@ -460,14 +450,17 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p) {
         __syncthreads();  // (2)
         const int seg0 = uni(sd.wave_seg0[wave]), seg1 = uni(sd.wave_seg0[wave + 1]);
         const int slot0 = uni(sd.wave_slot0[wave]), nslots = uni(sd.wave_slot0[wave + 1]) - slot0;
-        const unsigned long long *ap = uni(sd.arcs) + (long long)slot0 * 64 + lane;
-        const unsigned *segt = uni(sd.seg);
-        const unsigned *rinfo = uni(sd.rinfo);
-        const int nchunks = (nslots + C - 1) / C;
-        // the operand pair of the gathered value: only its high register is written in the loops below
-        double xop[C];
+        // (a scalar base in the GLOBAL address space: global_load, counted by vmcnt alone -- a flat load also counts as an LDS
+        // operation, and every wait became a wait for everything)
+        const auto apw = as_global(uni(sd.arcs) + (long long)slot0 * 64);
+        // (the segment table through the scalar cache: constant address space, s_load)
+        typedef const __attribute__((address_space(4))) unsigned *seg_cptr;
+        const seg_cptr segt = (seg_cptr)(__UINTPTR_TYPE__)uni(sd.seg);
+        const int nchunks = nslots / C;  // (whole chunks by construction)
+        // the operand pairs of the gathered values: only their high registers are written in the loops below
+        double xop[2 * C];
 #pragma unroll
-        for (int j = 0; j < C; ++j) {
+        for (int j = 0; j < 2 * C; ++j) {
             xop[j] = 0.0;
             asm volatile("" : "+v"(xop[j]));
         }
@@ -475,27 +468,22 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p) {
             const unsigned rd = VB * (unsigned)((t - 1) & 1), wr = VB * (unsigned)(t & 1);
             const int f = frame_of(t);
             const float S = ldsr(FIX + L::MS(t & 1));
-            const unsigned emb = FIX + L::EM(t & 1), psb = FIX + L::PSUM(t & 1);
-            float *rowf = rows + (long long)(f - 1) * S1p;
-            // the segment the wave is in, and what its finish needs (a segment ahead: the loads are long done when it ends)
+            const unsigned emb = FIX + L::EM(t & 1);
+            const gfptr rowf = (gfptr)(__UINTPTR_TYPE__)(rows + (long long)(f - 1) * S1p);
+            // the segment the wave is in
             int sg = seg0;
-            unsigned s_nsl = 0, s_lg = 0, s_p0 = 0, s_n = 0, info = 0;
-            float al = 0.f;
+            unsigned s_lg = 0, s_p0 = 0, s_n = 0;
             int remaining = 0;
-            auto load_seg = [&](int s) {  // (wave-uniform table entries; the per-row words of the lanes)
+            auto load_seg = [&](int s) {
                 if (s < seg1) {
-                    s_nsl = (unsigned)uni((int)segt[4 * s]);
-                    s_lg = (unsigned)uni((int)segt[4 * s + 1]);
-                    s_p0 = (unsigned)uni((int)segt[4 * s + 2]);
-                    s_n = (unsigned)uni((int)segt[4 * s + 3]);
-                    const unsigned i = s_p0 + (s_lg ? 0u : ((unsigned)lane < s_n ? (unsigned)lane : 0u));
-                    info = rinfo[i];
-                    if (PASS == 1) al = rowf[i];
-                    remaining = (int)s_nsl;
+                    remaining = ((int)segt[4 * s] + C) / C;  // chunks: its arcs + the info record, rounded up
+                    s_lg = segt[4 * s + 1];
+                    s_p0 = segt[4 * s + 2];
+                    s_n = segt[4 * s + 3];
                 }
             };
             double acc = 0.0;
-            auto finish = [&]() {
+            auto finish = [&](unsigned info) {
                 double s0 = acc;
                 if (s_lg) s0 = dwave_sum_rl(s0);
                 const bool mine = s_lg ? lane == 0 : (unsigned)lane < s_n;
@@ -509,43 +497,64 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p) {
                     const unsigned hi = w_exp2_hi(y);
                     vmax = vmax > hi ? vmax : hi;
                     ldswu(wr + 4u * posi, hi);
-                    if (PASS == 0) {
-                        rowf[info >> 12] = y;  // alpha~ in the backward numbering
-                    } else if (f <= len) {
-                        lds_atomic_add_f64(psb + 8u * (info & 0xfffu), dexp2(bb + al));  // C' * (A .* B)   (:154-155)
-                    }
+                    rowf[info >> 12] = DIR ? bb : y;  // the vector that is combined, in the pdf-major numbering
                 }
                 acc = 0.0;
                 ++sg;
                 load_seg(sg);
             };
             load_seg(sg);
-            while (sg < seg1 && remaining == 0) finish();  // (rows without arcs)
-            unsigned long long cur[C], nxt[C];
+            // K chunks of C records in flight per wave (the ring's slots are static registers: the chunk loop is unrolled K times;
+            // the loads are unconditional -- the array ends in K * C records of padding -- so that their number in flight is a
+            // constant of the code).  A segment is a whole number of chunks and its info record the LAST record of its last chunk:
+            // ONE scalar test per chunk -- with a test per record (is it in the stream? is it an arc?) the frame was bound by the
+            // scalar unit.  Chunks are taken in pairs: the gathers of both leave before the first FMA (half the LDS round trips on
+            // a wave's chain).
+            unsigned long long buf[K][C];
 #pragma unroll
-            for (int j = 0; j < C; ++j) cur[j] = j < nslots ? ap[(long long)j * 64] : 0ull;
-            for (int c = 0; c < nchunks; ++c) {
-                const int base = c * C;
+            for (int kk = 0; kk < K; ++kk)
 #pragma unroll
-                for (int j = 0; j < C; ++j) nxt[j] = base + C + j < nslots ? ap[(long long)(base + C + j) * 64] : 0ull;
+                for (int j = 0; j < C; ++j) buf[kk][j] = apw[(kk * C + j) * 64 + lane];
+            for (int c = 0; c < nchunks; c += K) {
 #pragma unroll
-                for (int j = 0; j < C; ++j) {  // the gathers of the chunk leave together
-                    mm_u32x2 o = __builtin_bit_cast(mm_u32x2, xop[j]);
-                    o.y = ldsru(rd + (unsigned)cur[j]);
-                    xop[j] = __builtin_bit_cast(double, o);
-                }
+                for (int k2 = 0; k2 < K; k2 += 2) {
+                    if (c + k2 < nchunks) {
+                        const bool two = c + k2 + 1 < nchunks;
 #pragma unroll
-                for (int j = 0; j < C; ++j) {
-                    if (base + j < nslots) {
-                        asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(__builtin_bit_cast(double, cur[j])), "v"(xop[j]));
-                        if (--remaining == 0) {
-                            finish();
-                            while (sg < seg1 && remaining == 0) finish();
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int j = 0; j < C; ++j) {  // (padding and info records gather address 0)
+                                mm_u32x2 o = __builtin_bit_cast(mm_u32x2, xop[h * C + j]);
+#ifdef MM_STREAM_NOGATHER  // (timing experiment: no LDS gathers)
+                                o.y = (unsigned)buf[k2 + h][j] | 0x3ff00000u;
+#else
+                                o.y = ldsru(rd + (unsigned)buf[k2 + h][j]);
+#endif
+                                xop[h * C + j] = __builtin_bit_cast(double, o);
+                            }
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            if (h == 0 || two) {
+#pragma unroll
+                                for (int j = 0; j < C - 1; ++j)
+                                    asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(__builtin_bit_cast(double, buf[k2 + h][j])), "v"(xop[h * C + j]));
+                                if (--remaining == 0) {
+                                    finish((unsigned)(buf[k2 + h][C - 1] >> 32));
+                                } else {
+                                    asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(__builtin_bit_cast(double, buf[k2 + h][C - 1])), "v"(xop[h * C + C - 1]));
+                                }
+                            }
                         }
+#ifndef MM_STREAM_NOLOAD  // (timing experiment: the ring is loaded once per frame)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {  // the slots' next chunks
+                            const auto sp = apw + (long long)(c + k2 + h + K) * (C * 64);
+#pragma unroll
+                            for (int j = 0; j < C; ++j) buf[k2 + h][j] = sp[j * 64 + lane];
+                        }
+#endif
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < C; ++j) cur[j] = nxt[j];
             }
             {
                 const unsigned m = wave_max_u32(vmax);
@@ -558,47 +567,133 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p) {
     }
 }
 
+// C' * (A .* B), the per-frame sums, the division and exp (src/inference.jl:154-160) from the two directions' stored vectors:
+// one workgroup per utterance and group of frames, a thread per pdf (its states are a contiguous range of the pdf-major
+// numbering both directions stored in).  float64 sums in a fixed order: deterministic.  Leaves log2 Z of every frame (and the
+// log2 of the frame's sum of 2^(a~ + b~): the overlap term of mm_pair_finish_kernel's second criterion) for the finish kernel.
+constexpr int kStreamCombineFrames = 8;
+static __global__ void __launch_bounds__(1024) mm_stream_combine_kernel(RunParams p) {
+    __shared__ double part[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const UttDesc &ud = p.utts[b];
+    const StreamPairDev *spd = reinterpret_cast<const StreamPairDev *>(ud.stream);
+    const int P1 = ud.P1, P = P1 - 1, S1p = ud.S1p;
+    int len = p.lens ? p.lens[b] : p.N;
+    len = len < 0 ? 0 : (len > p.N ? p.N : len);
+    const long long rbase = ud.s1p_prefix * (long long)(p.N + 1);
+    const float *ra = p.ws_alpha + rbase, *rb = p.xbuf + rbase;
+    const double *oa = p.ws_c + (long long)b * (p.N + 2), *ob = reinterpret_cast<const double *>(p.xbuf_d) + (long long)b * (p.N + 2);
+    double *zf = reinterpret_cast<double *>(p.xps) + (long long)b * 2 * (p.N + 2);  // [frame][2]: log2 Z, overlap term
+    const int q0 = tid < P1 ? spd->pdf_ptr[tid] : 0, q1 = tid < P1 ? spd->pdf_ptr[tid + 1] : 0;
+    const int f0 = 1 + (int)blockIdx.y * kStreamCombineFrames;
+    for (int f = f0; f < f0 + kStreamCombineFrames && f <= len; ++f) {
+        const float *a = ra + (long long)(f - 1) * S1p, *bt = rb + (long long)(f - 1) * S1p;
+        double s = 0.0;
+        for (int q = q0; q < q1; ++q) s += dexp2(a[q] + bt[q]);
+        double t = dwave_sum_rl(s);
+        __syncthreads();
+        if (lane == 0) part[wave] = t;
+        __syncthreads();
+        t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += part[w];
+        const int e = __builtin_amdgcn_frexp_exp(t);
+        const float tf = (float)__builtin_amdgcn_ldexp(t, -e);
+        const float inv = tf > 0.f ? 1.f / tf : 0.f;
+        if (tid < P) p.gamma[(long long)b * p.gsb + (long long)(f - 1) * p.gsn + (long long)tid * p.gsp] = (float)__builtin_amdgcn_ldexp(s, -e) * inv;
+        if (tid == 0) {
+            const float lt = dlog2(t);
+            zf[2 * f] = (double)lt + oa[f] + ob[f];
+            zf[2 * f + 1] = (double)lt;
+        }
+    }
+}
+
 // ttl = min over the frames of the per-frame log-normaliser (src/inference.jl:159); zeros beyond the sequence lengths; and what
-// a range mark means (mm_dpair_finish_kernel's two criteria on the double's range): cleared, or the item kernel computes the
-// utterance again
-static __global__ void mm_stream_finish_kernel(RunParams p) {
-    const int b = blockIdx.x;
+// a range mark means (mm_dpair_finish_kernel's two criteria on the double's range: the frames' log Z agree, the forward and the
+// backward mass overlap within the range less the posterior floor): cleared, or the item kernel computes the utterance again
+static __global__ void __launch_bounds__(256) mm_stream_finish_kernel(RunParams p) {
+    __shared__ double red[3][4];
+    const int b = blockIdx.x, tid = threadIdx.x;
     int len = p.lens ? p.lens[b] : p.N;
     len = len < 0 ? 0 : (len > p.N ? p.N : len);
     const int P = p.utts[b].P1 - 1;
-    if (threadIdx.x == 0) {
-        const double z = p.pair_zmin[6 * b], zM = p.pair_zmin[6 * b + 2], lm = p.pair_zmin[6 * b + 4];
-        p.ttl[b] = (z < __builtin_inf()) ? (float)(z * (double)MM_LN2) : MM_NINF;
-        const bool agree = z > -__builtin_inf() && zM < __builtin_inf() && zM - z <= MM_Z_SPREAD_TOL;
-        if (p.redo[b] == 1 && agree && lm >= (double)p.lt_floor - (double)MM_DPAIR_THR_EXTRA) p.redo[b] = 0;
+    const double *zf = reinterpret_cast<const double *>(p.xps) + (long long)b * 2 * (p.N + 2);
+    double zmin = __builtin_inf(), zmax = -__builtin_inf(), lmin = __builtin_inf();
+    for (int f = 1 + tid; f <= len; f += 256) {
+        const double z = zf[2 * f], l = zf[2 * f + 1];
+        zmin = z < zmin ? z : zmin;
+        zmax = z > zmax ? z : zmax;
+        lmin = l < lmin ? l : lmin;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double a = __shfl_xor(zmin, off), c = __shfl_xor(zmax, off), d = __shfl_xor(lmin, off);
+        zmin = a < zmin ? a : zmin;
+        zmax = c > zmax ? c : zmax;
+        lmin = d < lmin ? d : lmin;
+    }
+    if ((tid & 63) == 0) {
+        red[0][tid >> 6] = zmin;
+        red[1][tid >> 6] = zmax;
+        red[2][tid >> 6] = lmin;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) {
+            zmin = red[0][w] < zmin ? red[0][w] : zmin;
+            zmax = red[1][w] > zmax ? red[1][w] : zmax;
+            lmin = red[2][w] < lmin ? red[2][w] : lmin;
+        }
+        p.ttl[b] = (zmin < __builtin_inf()) ? (float)(zmin * (double)MM_LN2) : MM_NINF;  // (no frame: no path of length 0)
+        p.pair_zmin[6 * b] = p.pair_zmin[6 * b + 1] = zmin;
+        p.pair_zmin[6 * b + 2] = p.pair_zmin[6 * b + 3] = zmax;
+        p.pair_zmin[6 * b + 4] = p.pair_zmin[6 * b + 5] = lmin;
+        const bool agree = zmin > -__builtin_inf() && zmax < __builtin_inf() && zmax - zmin <= MM_Z_SPREAD_TOL;
+        if (p.redo[b] == 1 && agree && lmin >= (double)p.lt_floor - (double)MM_DPAIR_THR_EXTRA) p.redo[b] = 0;
     }
     const long long gbase = (long long)b * p.gsb;
-    for (long long q = threadIdx.x; q < (long long)(p.N - len) * P; q += blockDim.x)
+    for (long long q = tid; q < (long long)(p.N - len) * P; q += 256)
         p.gamma[gbase + (len + q / P) * p.gsn + (q % P) * p.gsp] = 0.f;
 }
 
+// both recursions in ONE grid when the chip holds them (2 B workgroups of one per compute unit), else one grid per direction
 template <int NJ>
-static int launch_stream_nj(int64_t B, size_t lds, const RunParams &p, hipStream_t st) {
-    auto k0 = mm_stream_kernel<0, NJ>;
-    auto k1 = mm_stream_kernel<1, NJ>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-    hipLaunchKernelGGL(k0, dim3(unsigned(B)), dim3(1024), lds, st, p);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k1, dim3(unsigned(B)), dim3(1024), lds, st, p);
+static int launch_stream_nj(int64_t B, int n_cus, size_t lds, const RunParams &p, hipStream_t st) {
+    auto k = mm_stream_kernel<NJ>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    if (2 * B <= int64_t(n_cus)) {
+        hipLaunchKernelGGL(k, dim3(unsigned(2 * B)), dim3(1024), lds, st, p, -1);
+        HIP_TRY(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k, dim3(unsigned(B)), dim3(1024), lds, st, p, 0);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k, dim3(unsigned(B)), dim3(1024), lds, st, p, 1);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(mm_stream_combine_kernel, dim3(unsigned(B), unsigned((p.N + kStreamCombineFrames - 1) / kStreamCombineFrames)), dim3(1024), 0, st, p);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(mm_stream_finish_kernel, dim3(unsigned(B)), dim3(256), 0, st, p);
     HIP_TRY(hipGetLastError());
     return MM_OK;
 }
-int mm_launch_stream(int64_t B, int max_S1, int max_P1, const RunParams &p, hipStream_t st) {
+// extra workspace of a stream batch behind the common one: the backward direction's vectors [sum S1p][N + 1] floats and offsets
+// [B][N + 2] doubles, the frames' {log2 Z, overlap term} [B][N + 2][2] doubles
+size_t mm_stream_extra_bytes(int64_t B, int64_t total_s1p, int64_t N, size_t off[3]) {
+    auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+    off[0] = 0;
+    off[1] = up(size_t(total_s1p) * size_t(N + 1) * 4);
+    off[2] = off[1] + up(size_t(B) * size_t(N + 2) * 8);
+    return off[2] + up(size_t(B) * size_t(N + 2) * 16);
+}
+int mm_launch_stream(int64_t B, int n_cus, int max_S1, int max_P1, const RunParams &p, hipStream_t st) {
     const size_t lds = mm_stream_lds_bytes(max_S1, max_P1);
     if (lds > 160 * 1024 || max_P1 > 1024) return mm_fail(MM_ERR_UNSUPPORTED, "stream kernel: LDS");
+    if ((p.N + kStreamCombineFrames - 1) / kStreamCombineFrames > 65535) return mm_fail(MM_ERR_UNSUPPORTED, "stream kernel: more than 524 280 frames");
     switch (stream_nj(max_P1)) {
-        case 2: return launch_stream_nj<2>(B, lds, p, st);
-        case 4: return launch_stream_nj<4>(B, lds, p, st);
-        case 8: return launch_stream_nj<8>(B, lds, p, st);
-        default: return launch_stream_nj<16>(B, lds, p, st);
+        case 2: return launch_stream_nj<2>(B, n_cus, lds, p, st);
+        case 4: return launch_stream_nj<4>(B, n_cus, lds, p, st);
+        case 8: return launch_stream_nj<8>(B, n_cus, lds, p, st);
+        default: return launch_stream_nj<16>(B, n_cus, lds, p, st);
     }
 }
 

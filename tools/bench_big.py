@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Graphs of config 3's family beyond config 3's size -- more pdfs (251 .. 506: the NJ = 8 instances of the pair kernels), more
-states (teams of 4 and of 8 workgroups), and beyond every fast path (the item kernel): ms per pdfposteriors call.
+states (teams of 4 and of 8 workgroups), and beyond every register-resident form (the stream kernels; the item kernel until round 5): ms per
+pdfposteriors call.
 
     python tools/bench_big.py [S P B N] [--json out.json]      # on the GPU box (tools/measure_all.sh -> profiles/<tag>_bench_big.json)
 """
@@ -12,7 +13,8 @@ import torch
 mm = ge.load_package()
 wl = importlib.import_module(mm.__name__ + ".workloads")
 import json
-CASES = ((2000, 400, 256, 1500), (2000, 200, 256, 1500), (4000, 84, 128, 700), (5000, 100, 128, 700), (6000, 300, 128, 700), (10000, 1000, 64, 700))
+CASES = ((2000, 400, 256, 1500), (2000, 200, 256, 1500), (4000, 84, 128, 700), (5000, 100, 128, 700), (6000, 300, 128, 700), (7000, 300, 64, 700),
+         (10000, 1000, 64, 700), (10000, 1000, 256, 700), (14000, 1000, 64, 300))
 args = [a for a in sys.argv[1:] if a != "--json" and not a.endswith(".json")]
 out_json = next((a for a in sys.argv[1:] if a.endswith(".json")), None)
 if len(args) >= 4:  # S P B N

@@ -2255,8 +2255,11 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
             const std::string k = std::to_string(mm_pair_nj(h->max_P1, h->pair_H)), H = std::to_string(h->pair_H);
             s = "mm_fbs_kernel<" + k + ",A," + H + ">, then <" + k + ",B," + H + "> (forward and backward agents in one grid, teams of " + H +
                 " workgroups), mm_pair_finish_kernel, then for marked utterances only " +
-                (h->dpair_ok ? "mm_fbds_kernel<" + k + ",A," + H + ">, then <" + k + ",B," + H + "> (float64, one utterance per team; FIRST and "
-                               "alone while the inputs are hard), mm_dpair_finish_kernel, then for what those mark "
+                (h->dpair_ok ? "mm_fbds_kernel<" + k + ",A," + H + ">, then <" + k + ",B," + H + "> (float64, one utterance per team" +
+                                   (h->wpair_ok ? std::string("); FIRST and alone while the inputs are hard: mm_fbws_kernel<") + k + ",A," + H + ">, then <" + k +
+                                                      ",B," + H + "> (wide-exponent pairs, two utterances per team)"
+                                                : std::string("; FIRST and alone while the inputs are hard)")) +
+                                   ", mm_dpair_finish_kernel, then for what those mark "
                              : std::string()) +
                 exact;
         } else if (h->pairs_ok) {
@@ -2313,7 +2316,9 @@ static size_t ws_xd_rows_bytes(mm_batch_t h) {
     return h->pair_H > 1 && h->dpair_ok ? size_t(2) * size_t(h->B) * 2 * size_t(h->pair_H) * 2 * (2 * size_t(h->split_s1p)) * 4 : 0;
 }
 static size_t ws_xd_bytes(mm_batch_t h) {
-    return h->pair_H > 1 && h->dpair_ok ? align_up(ws_xd_rows_bytes(h) + size_t(h->B) * 2 * size_t(h->pair_H) * 4 * size_t(mm_pair_xps(h->max_P1, h->pair_H)) * 4, 256) : 0;
+    // (+ 64 KB: the wide pair teams lay their slots of per-pdf sums -- two doubles per pdf, 16 bytes more per slot for 128 pdfs -- over
+    // the same area, (B + 1) / 2 teams instead of B)
+    return h->pair_H > 1 && h->dpair_ok ? align_up(ws_xd_rows_bytes(h) + size_t(h->B) * 2 * size_t(h->pair_H) * 4 * size_t(mm_pair_xps(h->max_P1, h->pair_H)) * 4 + 65536, 256) : 0;
 }
 static size_t ws_tail_bytes(mm_batch_t h) {  // longest-first order, redo marks, pair hand-over, per-direction log Z minima, team buffers
     return 2 * align_up(size_t(h->B + 1) * 4, 256) + align_up(size_t(h->B + 1) * 2 * mm_pair_hand_bytes(), 256) +

@@ -30,12 +30,16 @@
 
 namespace mm {
 
-// LDS layout: PairLay with per-pdf sums of two doubles
-template <int RS, int PHASE, int PC = 256>
+// LDS layout: PairLay with per-pdf sums of two doubles (RSH: bytes of the rows ONE workgroup finishes -- all of them, or a team's set)
+template <int RS, int PHASE, int PC = 256, int RSH_ = 2 * RS>
 struct WPairLay {
-    using B = PairLay<RS, PHASE, 2 * RS, PC>;
-    static constexpr unsigned RS2 = B::RS2, RSH = 2 * RS, PC4 = B::PC4, PC8 = B::PC8, RAWS = B::RAWS;
+    using B = PairLay<RS, PHASE, RSH_, PC>;
+    static constexpr unsigned RS2 = B::RS2, RSH = RSH_, PC4 = B::PC4, PC8 = B::PC8, RAWS = B::RAWS;
     static constexpr int NR = B::NR, POFFN = B::POFFN;
+    // (teams) floats of one slot of published per-pdf partial sums: two doubles per pdf, the XCD handshake in the slot's last 8 bytes
+    // (128 pdfs fill an array of 128: 16 bytes more)
+    static constexpr unsigned XPS = 4u * PC + (PC == 128 ? 4u : 0u);
+    static constexpr unsigned XFLAG = B::XFLAG;
     static constexpr unsigned PP(int par) { return B::PP(par); }
     static constexpr unsigned RAW(int k, int u) { return B::RAW(k, u); }
     static constexpr unsigned EM(int par) { return B::EM(par); }
@@ -49,7 +53,11 @@ struct WPairLay {
     static constexpr unsigned Q(int par) { return FIX + unsigned(NR) * RSH + unsigned(par) * RSH; }
     static constexpr unsigned SLOTS = PHASE ? FIX + unsigned(NR + 2) * RSH : FIX;
 };
-inline size_t wpair_lds_bytes(int RS, int phase, int nslotrows, int PC = 256) { return pair_lds_bytes(RS, phase, nslotrows, 0, PC) + size_t(16) * PC; }
+inline size_t wpair_lds_bytes(int RS, int phase, int nslotrows, int PC = 256, int RSH = 0) {
+    return pair_lds_bytes(RS, phase, nslotrows, RSH, PC) + size_t(16) * PC;
+}
+// pdf capacity of the per-pdf arrays: the teams' instances of up to 128 pdfs take arrays of half the size (their LDS is the tightest)
+constexpr int wpair_pc(int NJ, int H) { return (H > 1 && NJ <= 2) ? 128 : pair_pc(NJ); }
 
 __device__ __forceinline__ void ldsw2u(unsigned addr, unsigned a, unsigned b) {
     mm_u32x2 v = {a, b};
@@ -188,17 +196,74 @@ __device__ __forceinline__ void wpair_scan_max(unsigned pbase, int n2, int lane,
     m1 = w_log2_hi(wave_max_u32(b));
 }
 
+// a granule of two tagged doubles (teams: the per-pdf partial sums of a set; the sign bits carry the step's tag)
+__device__ __forceinline__ void wgranule_store2(float *base, unsigned byte_off, double a, double b, bool neg) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(1))) u64x2 gu64x2;
+    const unsigned long long sg = neg ? 0x8000000000000000ull : 0ull;
+    u64x2 v = {__builtin_bit_cast(unsigned long long, a) | sg, __builtin_bit_cast(unsigned long long, b) | sg};
+    // (one 16-byte write-through store: both doubles of a pdf arrive together or not at all -- the tag of the first tells)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"((gu64x2 *)(__UINTPTR_TYPE__)(reinterpret_cast<char *>(base) + byte_off)), "v"(v) : "memory");
+}
 // one wave, both utterances: per-frame sums over the pdfs (psum: two doubles per pdf), divide, store gamma
 // (src/inference.jl:156-160); lt[u] = log2 of the sum (-inf, and gamma = 0, if nothing is alive)
-template <int NJ>
-__device__ __forceinline__ void wpair_finish_frames(unsigned psum, int P1, int P, int lane, float *gp0, float *gp1, long long gsp, bool store0,
-                                                    bool store1, float (&lt)[2]) {
+// (teams: xp[g] = the slot of the step in which set g published its partial sums, NULL for the own set; the sum of a pdf is the
+// sum of the sets' parts in the order of the sets -- the same bits in every workgroup; returns false if a poll timed out)
+template <int NJ, int H = 1>
+__device__ __forceinline__ bool wpair_finish_frames(unsigned psum, int P1, int P, int lane, float *gp0, float *gp1, long long gsp, bool store0,
+                                                    bool store1, float (&lt)[2], const float *const *xp = nullptr, unsigned tag = 0u,
+                                                    unsigned long long tmo = MM_SPLIT_TIMEOUT) {
     mm_f64x2 s[NJ];
     double t0 = 0.0, t1 = 0.0;
+    bool arrived = true;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int q = lane + 64 * j;
         s[j] = *(__attribute__((address_space(3))) const mm_f64x2 *)(__UINTPTR_TYPE__)(psum + 16u * (unsigned)(q < P1 ? q : 0));
+    }
+    if constexpr (H > 1) {
+        typedef unsigned mm_u32x4 __attribute__((ext_vector_type(4)));
+        mm_f64x2 tot[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) tot[j] = mm_f64x2{0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < H; ++g) {  // (one set at a time: 2 NJ registers pairs per set in flight)
+            if (xp[g] == nullptr) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) tot[j] += s[j];
+                continue;
+            }
+            mm_u32x4 v[NJ];
+            const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int q = lane + 64 * j;
+                    asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(v[j]) : "v"(16u * (unsigned)(q < P1 ? q : 0)), "s"(xp[g]) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    asm volatile("" : "+v"(v[j]));
+                    ok = ok && ((v[j].y >> 31) == tag) && ((v[j].w >> 31) == tag);
+                }
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                if (!arrived || __builtin_amdgcn_s_memrealtime() - tstart >= tmo) {
+                    arrived = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const unsigned long long a = ((unsigned long long)(v[j].y & 0x7fffffffu) << 32) | v[j].x, b = ((unsigned long long)(v[j].w & 0x7fffffffu) << 32) | v[j].z;
+                tot[j].x += __builtin_bit_cast(double, a);
+                tot[j].y += __builtin_bit_cast(double, b);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) s[j] = tot[j];
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -222,11 +287,13 @@ __device__ __forceinline__ void wpair_finish_frames(unsigned psum, int P1, int P
     }
     lt[0] = dlog2(t0);
     lt[1] = dlog2(t1);
+    return arrived;
 }
 
 // pdf sums of both utterances (q: pairs of high dwords in pdf-major order), 1 << LG lanes per pdf (pair_pdf_sums)
 template <int LG = 3>
-__device__ __forceinline__ void wpair_pdf_sums(unsigned qbase, unsigned pdfse_base, unsigned psum_base, int P1, int wave, int NWC, int lane) {
+__device__ __forceinline__ void wpair_pdf_sums(unsigned qbase, unsigned pdfse_base, unsigned psum_base, int P1, int wave, int NWC, int lane,
+                                               float *xs = nullptr, bool neg = false) {
     constexpr int LP = 1 << LG, PPW = 64 >> LG;
     constexpr unsigned STR = 8u * LP;
     for (int p0 = wave * PPW; p0 < P1; p0 += NWC * PPW) {
@@ -264,23 +331,29 @@ __device__ __forceinline__ void wpair_pdf_sums(unsigned qbase, unsigned pdfse_ba
         if (pdf < P1 && (lane & (LP - 1)) == 0) {
             mm_f64x2 w = {s0, s1};
             *(__attribute__((address_space(3))) mm_f64x2 *)(__UINTPTR_TYPE__)(psum_base + 16u * (unsigned)pdf) = w;
+            if (xs) wgranule_store2(xs, 16u * (unsigned)pdf, s0, s1, neg);
         }
     }
 }
 
 // One agent: direction rdir (0: forward / alpha, 1: backward / beta) of pair `pair`, phase PHASE (0: A, 1: B).  pair_agent
-// for H = 1 with the arithmetic above.
-template <int KA, int RS, int PHASE, int NJ>
-__device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rdir) {
+// with the arithmetic above.  H > 1: the agent is a TEAM of H workgroups, this one finishes the rows of set `hset` (the split
+// kernels, mm_kernel_pairs.hip 4.1b: graphs beyond the registers / LDS of one compute unit); the exchange is pair_agent's bit for
+// bit -- a granule is the pair of high dwords of a row, the step's tag in their sign bits (the values are >= 0) -- in the float64
+// team kernels' exchange areas (p.xbuf_d / p.xps_d: B slots, (B + 1) / 2 pairs use them), the per-pdf partial sums two tagged
+// doubles per pdf.
+template <int KA, int RS, int PHASE, int NJ, int H = 1, int RSH = 2 * RS>
+__device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rdir, int hset = 0) {
     extern __shared__ float lds[];
     const int DIR = __builtin_amdgcn_readfirstlane(rdir);
-    using L = WPairLay<RS, PHASE, pair_pc(NJ)>;
-    constexpr int RSH = 2 * RS;
+    const unsigned long long x_tmo = p.x_timeout;  // (teams) ticks of s_memrealtime a poll waits before it gives the team up
+    using L = WPairLay<RS, PHASE, wpair_pc(NJ, H), RSH>;
     constexpr int D = PHASE ? 2 : 3;  // gather pairs in flight ahead of the FMAs (phase B: the registers of two)
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, NWC = NW - 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, NWC = NW - (H > 1 ? 2 : 1);
     const bool service = wave == NWC;
-    if (service) __builtin_amdgcn_s_setprio(3);
+    const bool xwave = H > 1 && wave == NWC + 1;  // the exchange wave of a team's workgroup
+    if (service || xwave) __builtin_amdgcn_s_setprio(3);
     // ---- the two utterances
     PairUtt U[2];
     int NFp = 1;
@@ -302,7 +375,7 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
     }
     float *rowsP = p.ws_alpha + (long long)pair * (long long)(p.N + 2) * 2 * p.pair_s1p;  // [N + 2][S1p][2] float32 log2 values
     const UttDesc &ud = p.utts[U[0].b];
-    const RowU r = uni(ud.rp[DIR]);
+    const RowU r = uni(H > 1 ? ud.rps[DIR][hset] : ud.rp[DIR]);
     const int S1 = r.rows, S1p = p.pair_s1p, P1 = uni(ud.P1), P = P1 - 1, P1p = (P1 + 3) & ~3;
     const float thr = r.thr + MM_DPAIR_THR_EXTRA;
     int m = (int)(((long long)NFp * (p.split_q10 > 0 ? p.split_q10 : 512)) >> 10);
@@ -325,6 +398,23 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
         for (int q = tid; q < P1; q += NT) ldswu(L::PDFSE + 4u * q, as_global(reinterpret_cast<const unsigned *>(r.pdfse))[q]);
     // (marks: values beyond the DOUBLE's range -- redo2, decided by mm_dpair_finish_kernel)
     int *redo0 = p.redo2 + U[0].b, *redo1 = p.redo2 + (U[1].valid ? U[1].b : p.B);
+    // ---- the team: own set's region, own / others' slots of this launch (the float64 team kernels' exchange areas)
+    const int xbase = H > 1 ? p.sp_base[hset] : 0, xcnt = H > 1 ? p.sp_cnt[hset] : 0;
+    (void)xcnt;
+    float *xsend = nullptr, *xps_send = nullptr;
+    bool xplain = false;
+    const float *xrecv[H], *xps_recv[H];
+    if constexpr (H > 1) {
+        float *xb = p.xbuf_d + (long long)PHASE * p.x_phase_d + ((long long)pair * 2 + DIR) * H * 2 * p.x_slot;
+        float *xq = p.xps_d + ((long long)pair * 2 + DIR) * H * 4 * (int)L::XPS;
+#pragma unroll
+        for (int g = 0; g < H; ++g) {
+            xrecv[g] = g == hset ? nullptr : xb + (long long)g * 2 * p.x_slot;
+            xps_recv[g] = g == hset ? nullptr : xq + (long long)g * 4 * (int)L::XPS;
+        }
+        xsend = xb + (long long)hset * 2 * p.x_slot;
+        xps_send = xq + (long long)hset * 4 * (int)L::XPS;
+    }
     unsigned long long endmask = 0, lgw0 = 0;
     int nslots = 0;
     unsigned slot_base = 0;
@@ -373,7 +463,8 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
             int f = frame_of(tt);
             f = f > p.N ? p.N : f;  // (frame N+1 is never combined)
             constexpr int NDM = RSH / 1024;
-            const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(rowsP + (long long)f * 2 * S1p);
+            // (teams: the rows of the own set only -- the other direction's workgroup of the same set stored them, contiguously, at the set's base)
+            const mm_f32x4 *src = reinterpret_cast<const mm_f32x4 *>(rowsP + (long long)f * 2 * S1p + 2 * xbase);
             const unsigned dst = L::AL(0) + (unsigned)(tt % L::NR) * (unsigned)RSH;
             dma_row_b128<NDM>(uni(src), (unsigned)sl, dst);  // (no clamping: pair_agent)
 #pragma unroll
@@ -438,7 +529,7 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
             const int f = frame_of(ts);
             const bool live0 = f >= 1 && f <= U[0].len, live1 = f >= 1 && f <= U[1].len;
             float lt[2];
-            wpair_finish_frames<NJ>(psum, P1, P, sl, p.gamma + (long long)U[0].b * p.gsb + (long long)(f - 1) * p.gsn,
+            (void)wpair_finish_frames<NJ>(psum, P1, P, sl, p.gamma + (long long)U[0].b * p.gsb + (long long)(f - 1) * p.gsn,
                                     p.gamma + (long long)U[1].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp, live0 && U[0].valid, live1 && U[1].valid, lt);
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -456,7 +547,7 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
             // (the lane index opaque at the top of every step: nothing derived from it -- the addresses of the emission DMAs, of the
             // posteriors' stores, of the scan -- is hoisted out of the step loop into registers this kernel does not have; every
             // reload of a spilled one is a scratch load whose wait also waits for the LDS-DMAs in flight)
-            if constexpr (NJ > 2 || PHASE == 1) asm volatile("" : "+v"(sl));
+            if constexpr (H > 1 || NJ > 2 || PHASE == 1) asm volatile("" : "+v"(sl));
             constexpr bool ring2 = PHASE == 1 && L::NR == 2;
             if constexpr (ring2) dma_partner(t + 1);
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
@@ -473,7 +564,9 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
             if constexpr (PHASE == 1) {
                 if constexpr (!ring2) dma_partner(t + 2);
                 MM_STAMP(5);
-                if (t - 2 > t0) frames_of_step(t - 2, L::PSUM(WR));  // gamma of step t - 2: its per-pdf sums were completed in the previous step
+                // gamma of step t - 2: its per-pdf sums were completed in the previous step (teams: the exchange wave's business)
+                if constexpr (H == 1)
+                    if (t - 2 > t0) frames_of_step(t - 2, L::PSUM(WR));
                 MM_STAMP(6);
                 if constexpr (ring2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
@@ -512,9 +605,9 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
             for (int k = 1; k >= 0; --k) {
                 const int t = t1 - k;
                 if (k == 0) __syncthreads();  // (a)
-                if (t > t0) frames_of_step(t, L::PSUM(t & 1));
+                if (H == 1 && t > t0) frames_of_step(t, L::PSUM(t & 1));
             }
-            if (sl == 0) {
+            if (H == 1 && sl == 0) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     if (U[u].valid) {
@@ -524,13 +617,94 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
                     }
             }
         }
+    } else if (xwave) {
+        // ================= exchange wave (teams): the XCD handshake; phase B: the posteriors of the FIRST workgroup =================
+        __syncthreads();  // (1)
+        bool dead = (p.x_sleep & 0x200) != 0;
+        {   // which XCD is the team on?  (pair_agent: a granule in the unused tail of psum slot PHASE of the own set)
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 15u;
+            if (lane == 0) granule_store(xps_send + PHASE * (int)L::XPS, 4u * (L::XPS - 2u), __builtin_bit_cast(float, xcc + 1u), 0.f);
+            bool same = true;
+            const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+            for (int g = 0; g < H; ++g) {
+                if (g == hset) continue;
+                unsigned other = 0u;
+                while (!dead) {
+                    other = (unsigned)granule_load(xps_recv[g] + PHASE * (int)L::XPS, 4u * (L::XPS - 2u));
+                    if (other != 0u) break;
+                    if (__builtin_amdgcn_s_memrealtime() - tstart > x_tmo) dead = true;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                same = same && other == xcc + 1u;
+            }
+            if (dead && lane == 0) {
+                *redo0 = 2;
+                *redo1 = 2;
+            }
+            if (lane == 0) ldswu(L::XFLAG, (same && !dead && !(p.x_sleep & 0x800)) ? 1u : 0u);
+        }
+        __syncthreads();  // (2)
+        double xzmin[2] = {__builtin_inf(), __builtin_inf()}, xzmax[2] = {-__builtin_inf(), -__builtin_inf()};
+        float xltmin[2] = {__builtin_inff(), __builtin_inff()};
+        auto xframes = [&](int ts, unsigned psum) {
+            const int f = frame_of(ts);
+            const bool live0 = f >= 1 && f <= U[0].len, live1 = f >= 1 && f <= U[1].len;
+            float lt[2];
+            const float *xp[H];
+#pragma unroll
+            for (int g = 0; g < H; ++g) xp[g] = g != hset ? xps_recv[g] + (ts & 3) * (int)L::XPS : nullptr;
+            if (!wpair_finish_frames<NJ, H>(psum, P1, P, lane, p.gamma + (long long)U[0].b * p.gsb + (long long)(f - 1) * p.gsn,
+                                            p.gamma + (long long)U[1].b * p.gsb + (long long)(f - 1) * p.gsn, p.gsp, live0 && U[0].valid,
+                                            live1 && U[1].valid, lt, xp, split_tag(ts, t0, 2), dead ? 0ull : x_tmo)) {
+                if (lane == 0) {
+                    *redo0 = 2;  // (the team is not running together: the log-domain kernels compute these utterances)
+                    *redo1 = 2;
+                }
+                dead = true;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (u ? live1 : live0) {
+                    const double own = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::OWN(ts & 3) + 8u * u);
+                    const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 16u * (unsigned)(ts & (L::POFFN - 1)));
+                    const double z = (double)lt[u] + own + oth;
+                    xzmin[u] = z < xzmin[u] ? z : xzmin[u];
+                    xzmax[u] = z > xzmax[u] ? z : xzmax[u];
+                    xltmin[u] = lt[u] < xltmin[u] ? lt[u] : xltmin[u];
+                }
+        };
+        for (int t = t0 + 1; t <= t1; ++t) {
+            if constexpr (PHASE == 1)
+                if (t - 2 > t0 && hset == 0) xframes(t - 2, L::PSUM(t & 1));  // (the first workgroup's business: pair_agent)
+            MM_STEP_SYNC();
+        }
+        if constexpr (PHASE == 1) {
+            for (int k = 1; k >= 0; --k) {
+                const int t = t1 - k;
+                if (k == 0) __syncthreads();  // (a)
+                if (t > t0 && hset == 0) xframes(t, L::PSUM(t & 1));
+            }
+            if (lane == 0 && hset == 0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (U[u].valid) {
+                        p.pair_zmin[(long long)U[u].b * 6 + DIR] = xzmin[u];
+                        p.pair_zmin[(long long)U[u].b * 6 + 2 + DIR] = xzmax[u];
+                        p.pair_zmin[(long long)U[u].b * 6 + 4 + DIR] = (double)xltmin[u];
+                    }
+            }
+        }
     } else {
         // ================= compute waves =================
         __syncthreads();  // (1)
         // the starting vector (step t0)
         if (PHASE == 0 && DIR == 0) {  // alpha_hat (*) lhs[:,1]   (src/inference.jl:68)
             for (int i = tid; i < S1; i += 64 * NWC) {
-                const unsigned pdfi = as_global(r.rowpdf)[i];
+                unsigned pdfi = as_global(r.rowpdf)[i];
+                if (H > 1 && pdfi == 0xffffu) pdfi = (unsigned)P1p;  // (alignment padding between the sets' regions: init = -inf)
                 const mm_f32x2 e = ldsr2(L::EM(1) + 8u * pdfi);
                 const float a0 = as_global(r.init)[i];
                 const float v0 = a0 + e.x, v1 = a0 + e.y;
@@ -548,15 +722,18 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
                 float v0 = vv.x, v1 = vv.y;
                 const unsigned pdfi = as_global(r.rowpdf)[i];
                 if (DIR == 1) {  // beta~ is stored without the frame's emission
-                    const mm_f32x2 e = ldsr2(L::EM(t0 & 1) + 8u * pdfi);
+                    const mm_f32x2 e = ldsr2(L::EM(t0 & 1) + 8u * (H > 1 && pdfi == 0xffffu ? (unsigned)P1p : pdfi));
                     v0 += e.x;
                     v1 += e.y;
                 }
+                if (H > 1 && pdfi == 0xffffu) v0 = v1 = MM_NINF;  // (padding: never stored)
                 ldsw2u(L::PP(t0 & 1) + 8u * i, w_exp2_hi(v0), w_exp2_hi(v1));
             }
         }
         load_graph();
         __syncthreads();  // (2)
+        if constexpr (H > 1) xplain = __builtin_amdgcn_readfirstlane(ldsru(L::XFLAG)) != 0u;
+        bool cdead = H > 1 && (p.x_sleep & 0x200) != 0;  // (teams) a poll of this wave timed out: it waits no more
         // the operand pairs of the two utterances: only their high registers are written in the loop
         double tmp[2] = {0.0, 0.0};
         asm volatile("" : "+v"(tmp[0]), "+v"(tmp[1]));
@@ -589,6 +766,11 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
                 mm_f32x2 al = {0.f, 0.f};
                 if constexpr (PHASE == 1) al = ldsr2((info2 & 0xffffu) + alb);
                 float *rowP = rowsP + (long long)(f <= p.N ? f : 0) * 2 * S1p;
+                // (teams) where the team reads this step's rows, and the step's tag as a sign bit
+                float *xw = H > 1 ? xsend + (long long)(t & 1) * p.x_slot - 2 * xbase : nullptr;
+                const unsigned xtag = (H > 1 && split_tag(t, t0, 1)) ? 0x80000000u : 0u;
+                (void)xw;
+                (void)xtag;
                 float worst = 0.f;
                 double accA0 = 0.0, accA1 = 0.0, accN0 = 0.0, accN1 = 0.0;
                 unsigned long long lgw = lgw0;
@@ -608,7 +790,13 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
                     const float y0 = b0 + e.x, y1 = b1 + e.y;
                     worst = __builtin_fmaxf(worst, __builtin_fmaxf(__builtin_fmaf(__builtin_fabsf(y0), 0.f, __builtin_fabsf(y0)),
                                                                    __builtin_fmaf(__builtin_fabsf(y1), 0.f, __builtin_fabsf(y1))));
-                    ldsw2u(pos8 + L::PP(WR), w_exp2_hi(y0), w_exp2_hi(y1));
+                    const unsigned h0 = w_exp2_hi(y0), h1 = w_exp2_hi(y1);
+                    ldsw2u(pos8 + L::PP(WR), h0, h1);
+                    if constexpr (H > 1) {  // the row for the team: its pair of high dwords, the step's tag in their sign bits
+                        const mm_u32x2 gv = {h0 | xtag, h1 | xtag};
+                        if (xplain) *reinterpret_cast<mm_u32x2 *>(reinterpret_cast<char *>(xw) + pos8) = gv;
+                        else granule_store(xw, pos8, __builtin_bit_cast(float, gv.x), __builtin_bit_cast(float, gv.y));
+                    }
                     const float st0 = DIR ? b0 : y0, st1 = DIR ? b1 : y1;  // the vector that is stored / combined
                     if constexpr (PHASE == 0) {
                         *reinterpret_cast<mm_f32x2 *>(reinterpret_cast<char *>(rowP) + pos8) = mm_f32x2{st0, st1};
@@ -638,7 +826,50 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
                 }
             }
             if constexpr (PHASE == 1)  // C' * (A .* B) of the previous step (:155)
-                if (t - 1 > t0) wpair_pdf_sums<(NJ > 2 ? 2 : 3)>(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane);
+                if (t - 1 > t0)
+                    wpair_pdf_sums<(NJ > 2 ? 2 : 3)>(L::Q(RD), L::PDFSE, L::PSUM(RD), P1, wave, NWC, lane, H > 1 ? xps_send + ((t - 1) & 3) * (int)L::XPS : nullptr,
+                                                      H > 1 && split_tag(t - 1, t0, 2) != 0u);
+            if constexpr (H > 1) {
+                // The rows of the other sets of this step (pair_agent, MM_SPLIT_CWPOLL): chunk j (128 granules) of the q-th other set
+                // is item q * NG2 + j, compute wave w receives the items w, w + NWC, ...; a granule is a pair of tagged high dwords.
+                constexpr int NG2 = (RSH / 16 + 63) / 64, I = (H - 1) * NG2;
+                typedef unsigned mm_u32x4 __attribute__((ext_vector_type(4)));
+                const unsigned tg = split_tag(t, t0, 1);
+                for (int i = wave; i < I; i += NWC) {
+                    const int q = i / NG2, j = i % NG2, g = q < hset ? q : q + 1;
+                    const float *src = uni(xrecv[g] + (long long)(t & 1) * p.x_slot);
+                    const int ng = p.sp_cnt[g];
+                    const unsigned dsta = L::PP(WR) + 8u * (unsigned)p.sp_base[g] + 16u * (unsigned)(lane + 64 * j);
+                    const bool have = 2 * (lane + 64 * j) < ng, second = 2 * (lane + 64 * j) + 1 < ng;
+                    const unsigned off = have ? 16u * (unsigned)(lane + 64 * j) : 0u;
+                    bool pend = have;
+                    if (__builtin_amdgcn_ballot_w64(pend) == 0ull || cdead) continue;
+                    const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
+                    for (;;) {
+                        mm_u32x4 v;
+                        asm volatile("global_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(off), "s"(src) : "memory");
+                        if (pend && (v.x >> 31) == tg && (!second || (v.z >> 31) == tg)) {
+                            mm_u32x4 w;
+                            w.x = v.x & 0x7fffffffu;
+                            w.y = v.y & 0x7fffffffu;
+                            w.z = second ? v.z & 0x7fffffffu : 0u;
+                            w.w = second ? v.w & 0x7fffffffu : 0u;
+                            *(__attribute__((address_space(3))) mm_u32x4 *)(__UINTPTR_TYPE__)dsta = w;
+                            pend = false;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
+                        if (__builtin_amdgcn_s_memrealtime() - tstart > x_tmo) {
+                            cdead = true;  // the team is not running together: the log-domain kernels compute these utterances
+                            if (lane == 0) {
+                                *redo0 = 2;
+                                *redo1 = 2;
+                            }
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+            }
             MM_STAMP(0);
             MM_STEP_SYNC();
             MM_STAMP(1);
@@ -653,7 +884,9 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
             }
         }
         if constexpr (PHASE == 1) {
-            if (t1 > t0) wpair_pdf_sums<(NJ > 2 ? 2 : 3)>(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane);
+            if (t1 > t0)
+                wpair_pdf_sums<(NJ > 2 ? 2 : 3)>(L::Q(t1 & 1), L::PDFSE, L::PSUM(t1 & 1), P1, wave, NWC, lane, H > 1 ? xps_send + (t1 & 3) * (int)L::XPS : nullptr,
+                                                  H > 1 && split_tag(t1, t0, 2) != 0u);
             __syncthreads();  // (a)
         }
     }

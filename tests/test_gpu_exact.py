@@ -187,12 +187,16 @@ def test_sharp_emissions_on_the_float64_team_kernels(mm, wl, oracle, torch, whic
     bf = make_batch(mm, wl, g, B, {"MM_NO_FALLBACK": "1"})
     assert "mm_fbs_kernel" in bf.kernels() and "mm_fbds_kernel" in bf.kernels(), bf.kernels()
     assert ("teams of 2" if which == "wsj_den" else "teams of 4") in bf.kernels()
+    # (teams of 2: a whole batch goes to the WIDE pair teams, mm_fbws_kernel -- two utterances per team; teams of 4 stay on mm_fbds)
+    assert ("mm_fbws_kernel" in bf.kernels()) == (which == "wsj_den"), bf.kernels()
     g_ref, t_ref = oracle64(oracle, g, V, lens)
     ok = np.isfinite(t_ref)  # (one frame is too short for a path through these graphs: Z = 0, the reference's 0 / 0)
     for call in range(2):
         gam, ttl = bf.pdfposteriors(V, lens)
         assert bf.last_exact_first() == (call == 1)
-        assert bf.last_redo_count() >= 3 and bf.last_fallback_count() == 0
+        # (an utterance without any path that shares a wide pair with a marked partner stays marked: Z = 0 is what a total underflow
+        # would look like)
+        assert bf.last_redo_count() >= 3 and bf.last_fallback_count() <= (int((~ok & (lens >= 1)).sum()) if call == 1 else 0)
         check_gamma(gam[ok], g_ref[ok], lens[ok])
         assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-3)
         assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()

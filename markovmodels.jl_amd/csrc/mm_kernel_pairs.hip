@@ -103,6 +103,10 @@ inline size_t pair_lds_bytes(int RS, int phase, int nslotrows, int RSH = 0, int 
 typedef unsigned long long mm_u64;
 typedef __attribute__((address_space(1))) mm_u64 mm_gu64;
 #ifndef MM_SPLIT_TIMEOUT
+#ifndef MM_PAIR_LINFIN
+#define MM_PAIR_LINFIN 1
+#endif
+#define MM_LINF_EMIN (-40.f)  // log2 of the smallest emission factor of a step that raises no mark (pair_stage_em)
 #define MM_SPLIT_TIMEOUT 10000000ull  // ticks of s_memrealtime (100 MHz): 0.1 s -- the ceiling; a call passes its own (RunParams::x_timeout)
 #endif
 __device__ __forceinline__ void granule_store(float *base, unsigned byte_off, float a, float b) {
@@ -253,8 +257,10 @@ struct PairUtt {  // one utterance of the pair (scalar registers)
 
 // emissions of one frame for utterance u of the pair: raw values from LDS (DMA), log2 domain relative to the frame's
 // maximum E (row_stage_em for interleaved pairs).  Returns E.
-template <int NJ>  // NJ * 64 >= P + 1
-__device__ __forceinline__ float pair_stage_em(unsigned dst, unsigned rawsrc, int u, int n, int len, int P, int lane) {
+// LIN: the LINEAR factor of the step's finishes instead, 2^(v - E - S) with the step's normaliser S folded in -- a finish is then
+// one multiplication (no v_log_f32 / v_exp_f32 in the compute waves: quarter-rate instructions, 4 to 6 per finish until round 5).
+template <int NJ, bool LIN = false>  // NJ * 64 >= P + 1
+__device__ __forceinline__ float pair_stage_em(unsigned dst, unsigned rawsrc, int u, int n, int len, int P, int lane, float S = 0.f, int *mark = nullptr) {
     float v[NJ], E = MM_NINF;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -267,7 +273,10 @@ __device__ __forceinline__ float pair_stage_em(unsigned dst, unsigned rawsrc, in
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int q = lane + 64 * j;
-        if (q <= P) ldsw(dst + 8u * q + 4u * u, v[j] - E);
+        if (q <= P) ldsw(dst + 8u * q + 4u * u, LIN ? fast_exp2(v[j] - E - S) : v[j] - E);
+        // (a finite emission whose factor is about to leave the float range: if a whole vector dies of it the utterance looks like
+        // one without a path -- the mark tells mm_pair_finish_kernel not to believe that)
+        if (LIN && q <= P && v[j] - E - S < MM_LINF_EMIN && v[j] > MM_NINF) *mark = 1;
     }
     return E;
 }
@@ -275,9 +284,9 @@ __device__ __forceinline__ float pair_stage_em(unsigned dst, unsigned rawsrc, in
 // The same for BOTH utterances at once with 16-byte reads: a lane takes 4 consecutive pdfs per pass (the instances of more
 // than 4 passes of 64 pdfs, whose service wave is the longest actor of every step: 2000 states / 400 pdfs spent 3100 of a
 // 4800-cycle phase-A step here with 32 four-byte LDS accesses; now 4 reads of 16 bytes and 8 writes of 8).
-template <int NJ>
+template <int NJ, bool LIN = false>
 __device__ __forceinline__ void pair_stage_em_wide(unsigned dst, unsigned raw0, unsigned raw1, int n, int len0, int len1, int P, int lane,
-                                                   float (&E)[2]) {
+                                                   float (&E)[2], float S0 = 0.f, float S1 = 0.f, int *mark0 = nullptr, int *mark1 = nullptr) {
     constexpr int NP = (NJ + 3) / 4;
     mm_f32x4 v0[NP], v1[NP];
 #pragma unroll
@@ -309,7 +318,13 @@ __device__ __forceinline__ void pair_stage_em_wide(unsigned dst, unsigned raw0, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int q = 256 * j + 4 * lane + i;
-            if (q <= P) ldsw2(dst + 8u * (unsigned)q, v0[j][i] - e0, v1[j][i] - e1);
+            if (q <= P) {
+                if constexpr (LIN) {
+                    ldsw2(dst + 8u * (unsigned)q, fast_exp2(v0[j][i] - e0 - S0), fast_exp2(v1[j][i] - e1 - S1));
+                    if (v0[j][i] - e0 - S0 < MM_LINF_EMIN && v0[j][i] > MM_NINF) *mark0 = 1;
+                    if (v1[j][i] - e1 - S1 < MM_LINF_EMIN && v1[j][i] > MM_NINF) *mark1 = 1;
+                } else ldsw2(dst + 8u * (unsigned)q, v0[j][i] - e0, v1[j][i] - e1);
+            }
         }
     }
     E[0] = e0;
@@ -547,6 +562,11 @@ __device__ __forceinline__ void pair_pdf_sums(unsigned qbase, unsigned pdfse_bas
 // acc += w (broadcast) * x for the two utterances in ONE packed FMA (v_pk_fma_f32 issues at the rate of v_fma_f32 on
 // gfx950): the weights of an arc pair share an aligned register pair, op_sel picks the half that both lanes of the
 // packed operation use.
+__device__ __forceinline__ unsigned min3_u32(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ void pk_fma_wlo(mm_f32x2 &acc, const mm_f32x2 &w2, const mm_f32x2 &x) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w2), "v"(x));
 }
@@ -688,6 +708,13 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
 #define MM_PAIR_DA 3
 #endif
     constexpr bool MM_PAIR_DOUBLE = true;
+    // LINF: the finishes stay in the linear domain (round 5): the service wave stages the step's emissions as factors 2^(v - E - S),
+    // a finish is p = s * factor (and, in phase B, q = s * partner), BOTH directions store p -- the vector with the frame's emission --
+    // and combine with their own s (the vector without it): alpha_n beta_n = (T' alpha_{n-1}) (beta_n (*) lhs_n) either way.
+    // Until then a finish went through log2: v_log_f32 of the sum, the normaliser and the emission added, v_exp_f32 back, and a
+    // second v_exp_f32 for the combine -- 4 (phase A) / 6 (phase B) quarter-rate instructions per finish for the two utterances,
+    // ~1100 of a SIMD's ~3000 busy cycles per phase-B step (SQ_INSTS_VALU, profiles/r05_pmc_lfmmi_den.json).
+    constexpr bool LINF = MM_PAIR_LINFIN != 0;
     constexpr int D = PHASE ? 3 : MM_PAIR_DA;  // gather pairs in flight ahead of the FMAs
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, NWC = NW - (H > 1 ? 2 : 1);
@@ -721,6 +748,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
     const RowU r = uni(H > 1 ? ud.rps[DIR][hset] : ud.rp[DIR]);
     const int S1 = r.rows, S1p = p.pair_s1p, P1 = uni(ud.P1), P = P1 - 1, P1p = (P1 + 3) & ~3;
     const float thr = r.thr;
+    // (LINF) bits - 1 of the smallest sum a finish accepts: 2^-(thr + MM_LINF_EMIN), see the finishes
+    const unsigned sthr = ((unsigned)(127 - (int)(thr + MM_LINF_EMIN < 1.f ? 1.f : thr + MM_LINF_EMIN)) << 23) - 1u;
     // (Steering the frame maxima to 2^(thr - 20) instead of 2^0 -- to use the upper half of the float exponent range and keep
     // states up to ~190 log2 below the maximum on the linear path -- was tried and dropped: v_log_f32 returns log2 of sums
     // near 2^87 as floats 7.6e-6 apart, the per-frame normalisers of one utterance then scatter by 2e-4..7e-4 log2 instead of
@@ -741,7 +770,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         for (unsigned q = tid * 4u; q < 2u * RSH; q += NT * 4u) ldsw(L::Q(0) + q, 0.f);
     if (tid < 32) ldsw(L::MS(0) + 4u * tid, 0.f);
     if (tid < 4) ldswu(L::MX(0) + 4u * tid, 0u);
-    if (tid < 4) ldsw(L::EM(tid >> 1) + 8u * P1p + 4u * (tid & 1), MM_NINF);  // the emission slot of lanes without a row
+    if (tid < 4) ldsw(L::EM(tid >> 1) + 8u * P1p + 4u * (tid & 1), LINF ? 0.f : MM_NINF);  // the emission slot of lanes without a row
     const int nslotwords = r.nslotrows * 128;
     for (int q = tid; q < nslotwords; q += NT) ldswu(L::SLOTS + 4u * q, as_global(r.slots)[q]);
     if constexpr (PHASE == 1)
@@ -864,21 +893,28 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
 #define MM_PAIR_WIDE_SERVICE 1
 #endif
             if constexpr (NJ > 4 && MM_PAIR_WIDE_SERVICE) {
-                pair_stage_em_wide<NJ>(L::EM(t & 1), L::RAW(0, 0) + L::RAWS * (unsigned)(t & 3), L::RAW(0, 1) + L::RAWS * (unsigned)(t & 3), frame_of(t),
-                                       U[0].len, U[1].len, P, sl, E);
+                pair_stage_em_wide<NJ, LINF>(L::EM(t & 1), L::RAW(0, 0) + L::RAWS * (unsigned)(t & 3), L::RAW(0, 1) + L::RAWS * (unsigned)(t & 3), frame_of(t),
+                                             U[0].len, U[1].len, P, sl, E, S[0], S[1], redo0, redo1);
             } else {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) E[u] = pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, u) + L::RAWS * (unsigned)(t & 3), u, frame_of(t), U[u].len, P, sl);
+                for (int u = 0; u < 2; ++u)
+                    E[u] = pair_stage_em<NJ, LINF>(L::EM(t & 1), L::RAW(0, u) + L::RAWS * (unsigned)(t & 3), u, frame_of(t), U[u].len, P, sl, S[u], u ? redo1 : redo0);
             }
+            double before[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) cum[u] += (double)S[u] + (double)E[u];
+            for (int u = 0; u < 2; ++u) {
+                before[u] = cum[u];
+                cum[u] += (double)S[u] + (double)E[u];
+            }
             if (sl == 0) {
-                ldsw2(L::MS(t & 1), S[0], S[1]);
-                // the offset that turns the step's stored vector into log2 values: forward alpha~ includes the emission
+                if constexpr (!LINF) ldsw2(L::MS(t & 1), S[0], S[1]);
+                // the offsets that turn the step's vectors into log2 values.  LINF: the stored vector p includes the step's
+                // normaliser and emission (both directions); what is combined with the partner's is s, the sum before either
+                // (OWN).  Else: forward alpha~ includes the emission, backward beta~ does not, and both are what is combined.
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const double off = DIR ? cum[u] - (double)E[u] : cum[u];
-                    *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(L::OWN(t & 3) + 8u * u) = off;
+                    const double off = LINF ? cum[u] : (DIR ? cum[u] - (double)E[u] : cum[u]);
+                    *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(L::OWN(t & 3) + 8u * u) = LINF ? before[u] : off;
                     if (PHASE == 0) U[u].offs[frame_of(t)] = off;
                 }
             }
@@ -900,8 +936,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             }
         }
         MM_ROW_VMCNT(0);
-        if (PHASE == 0 || DIR == 1) {  // emissions of the starting step: the initial alpha needs them, and so does
-            float E[2];                // rebuilding the backward agent's linear vector from its stored beta~
+        if (PHASE == 0 || (DIR == 1 && !LINF)) {  // emissions of the starting step: the initial alpha needs them, and so does
+            float E[2];                           // rebuilding the backward agent's linear vector from its stored beta~ (!LINF)
 #pragma unroll
             for (int u = 0; u < 2; ++u) E[u] = pair_stage_em<NJ>(L::EM(t0 & 1), L::RAW(0, u) + L::RAWS * (unsigned)(t0 & 3), u, frame_of(t0), U[u].len, P, sl);
             if (PHASE == 0) {  // step 1 subtracts nothing but E
@@ -953,7 +989,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                     const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, u) + 16u * (unsigned)(ts & (L::POFFN - 1)));
                     const double z = (double)lt[u] + own + oth;
                     zmin[u] = z < zmin[u] ? z : zmin[u];
-                    zmax[u] = z > zmax[u] ? z : zmax[u];  // (NaN: neither comparison holds; the finish kernel tests zmin <= zmax)
+                    zmax[u] = z > zmax[u] ? z : zmax[u];
+                    if (!(z == z)) zmax[u] = __builtin_inf();  // (an overflow somewhere: inf * 0; the finish kernel sends the utterance to the exact kernels)
                     ltmin[u] = lt[u] < ltmin[u] ? lt[u] : ltmin[u];
                 }
         };
@@ -1128,6 +1165,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                     const double z = (double)lt[u] + own + oth;
                     xzmin[u] = z < xzmin[u] ? z : xzmin[u];
                     xzmax[u] = z > xzmax[u] ? z : xzmax[u];
+                    if (!(z == z)) xzmax[u] = __builtin_inf();
                     xltmin[u] = lt[u] < xltmin[u] ? lt[u] : xltmin[u];
                 }
         };
@@ -1229,11 +1267,13 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 const unsigned e8 = 8u * pdfi;
                 const mm_f32x2 e = ldsr2(L::EM(1) + e8);
                 const float a = as_global(r.init)[i];
-                const float v0 = a + e.x, v1 = a + e.y;
+                float v0 = a + e.x, v1 = a + e.y;
+                if (LINF && H > 1 && pdfi == (unsigned)P1p) v0 = v1 = MM_NINF;  // (LINF: the slot of lanes without a row holds the linear 0)
                 if (row_out_of_range(v0, thr)) *redo0 = 1;
                 if (row_out_of_range(v1, thr)) *redo1 = 1;
                 ldsw2(L::PP(1) + 8u * i, fast_exp2(v0), fast_exp2(v1));
-                *reinterpret_cast<mm_f32x2 *>(rowsP + ((long long)1 * S1p + i) * 2) = mm_f32x2{v0, v1};
+                if constexpr (LINF) *reinterpret_cast<mm_f32x2 *>(rowsP + ((long long)1 * S1p + i) * 2) = mm_f32x2{fast_exp2(v0), fast_exp2(v1)};
+                else *reinterpret_cast<mm_f32x2 *>(rowsP + ((long long)1 * S1p + i) * 2) = mm_f32x2{v0, v1};
             }
         } else if (DIR == 1 && t0 == 1) {  // B[:, N+1] = one at the final state   (src/inference.jl:104)
             if (tid == 0) ldsw2(L::PP(1) + 8u * r.fpos, 1.f, 1.f);
@@ -1243,6 +1283,11 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 const mm_f32x2 vv = *reinterpret_cast<const mm_f32x2 *>(rowsP + ((long long)f * S1p + i) * 2);
                 float v0 = vv.x, v1 = vv.y;
                 const unsigned pdfi = as_global(r.rowpdf)[i];
+                if constexpr (LINF) {  // the stored vector IS the linear vector of the step
+                    if (H > 1 && pdfi == 0xffffu) v0 = v1 = 0.f;  // (padding: never stored)
+                    ldsw2(L::PP(t0 & 1) + 8u * i, v0, v1);
+                    continue;
+                }
                 if (DIR == 1) {  // beta~ is stored without the frame's emission
                     const mm_f32x2 e = ldsr2(L::EM(t0 & 1) + 8u * (H > 1 && pdfi == 0xffffu ? (unsigned)P1p : pdfi));
                     v0 += e.x;
@@ -1281,7 +1326,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                     info = ldsru(sa);
                     infoN = ldsru(sa + 512u);
                 }
-                const mm_f32x2 S = ldsr2(L::MS(WR));  // the step's normalisers, posted by the service wave
+                mm_f32x2 S = {0.f, 0.f};
+                if constexpr (!LINF) S = ldsr2(L::MS(WR));  // the step's normalisers, posted by the service wave
                 mm_f32x2 e = ldsr2((info >> 16) + L::EM(WR));
                 const int f = frame_of(t);
                 const unsigned alb = L::AL(0) + (unsigned)(t % L::NR) * (unsigned)RSH;
@@ -1293,6 +1339,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 float *rowP = rowsP + (long long)(f <= p.N ? f : 0) * 2 * S1p;
                 // even / odd arcs (phase B has no registers to spare: one chain there)
                 float worst = 0.f;
+                unsigned smin = 0xffffffffu;
                 mm_f32x2 accA = {0.f, 0.f}, accN = {0.f, 0.f};
                 mm_f32x2 &accB = accA;
                 unsigned long long lgw = lgw0;
@@ -1302,6 +1349,29 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                     float s0 = accA.x, s1 = accA.y;
                     if (lg) grp_sum_last2(s0, s1, lg);
                     const unsigned pos8 = info & 0xffffu;
+                    if constexpr (LINF) {
+                        // p = s * 2^(emission - E - S): the step's vector, forward (T' alpha) (*) lhs (src/inference.jl:70-71),
+                        // backward B (*) lhs, the operand of the next product (:106-107).
+                        // Range check, deferred to the end of the step: the smallest non-zero sum of the lane, as integers (a
+                        // non-negative float orders like its bits; bits - 1 sends the semiring's zero to the top).  With every
+                        // non-zero s >= 2^-(thr - 40) and every non-zero factor >= 2^-40 (the service wave marks smaller ones:
+                        // pair_stage_em) every non-zero p is >= 2^-thr, and no product of the next step's sums leaves the float
+                        // range.  An overflow ends as a NaN frame sum (mm_pair_finish_kernel).
+                        smin = min3_u32(smin, __builtin_bit_cast(unsigned, s0) - 1u, __builtin_bit_cast(unsigned, s1) - 1u);
+                        mm_f32x2 sv = {s0, s1}, pv, qv;
+                        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(pv) : "v"(sv), "v"(e));
+                        ldsw2(pos8 + L::PP(WR), pv.x, pv.y);
+                        if constexpr (H > 1) {
+                            if (xplain) *reinterpret_cast<mm_f32x2 *>(reinterpret_cast<char *>(xw) + pos8) = mm_f32x2{pv.x * xsg, pv.y * xsg};
+                            else granule_store(xw, pos8, pv.x * xsg, pv.y * xsg);
+                        }
+                        if constexpr (PHASE == 0) {
+                            *reinterpret_cast<mm_f32x2 *>(reinterpret_cast<char *>(rowP) + pos8) = pv;
+                        } else {
+                            asm("v_pk_mul_f32 %0, %1, %2" : "=v"(qv) : "v"(sv), "v"(al));  // A .* B   (:154)
+                            ldsw2((info2 >> 16) + L::Q(WR), qv.x, qv.y);
+                        }
+                    } else {
                     // forward: (T' alpha) (*) lhs (src/inference.jl:70-71); backward: T (B (*) lhs) (:106-107), the emission is
                     // added for the next step's product only
                     const float b0 = fast_log2(s0) - S.x, b1 = fast_log2(s1) - S.y;
@@ -1326,6 +1396,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                     } else {
                         ldsw2((info2 >> 16) + L::Q(WR), fast_exp2(st0 + al.x), fast_exp2(st1 + al.y));  // A .* B   (:154)
                     }
+                    }
                     accA = mm_f32x2{0.f, 0.f};
                     sa += 512u;
                     // (a plain copy is coalesced away and paid for with register moves on the no-finish path of EVERY pair)
@@ -1346,7 +1417,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 MM_PAIR_CASES(MM_PAIR_TWO)
                 // out of the linear range somewhere: both utterances go to the exact kernels (the check does not tell
                 // them apart; it only costs time)
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(worst > thr) != 0ull, 0)) {
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(LINF ? smin < sthr : worst > thr) != 0ull, 0)) {
                     *redo0 = 1;
                     *redo1 = 1;
                 }
@@ -1549,7 +1620,10 @@ static __global__ void mm_pair_finish_kernel(RunParams p) {
         const double lm = l0 < l1 ? l0 : l1;
         p.ttl[b] = (z < __builtin_inf()) ? (float)(z * (double)MM_LN2) : MM_NINF;  // (no frame: no path of length 0)
         int mark = p.redo[b];
-        if (mark == 1 && z > -__builtin_inf() && zM < __builtin_inf() && zM - z <= MM_Z_SPREAD_TOL && lm >= (double)p.lt_floor) p.redo[b] = mark = 0;
+        const bool sound = z > -__builtin_inf() && zM < __builtin_inf() && zM - z <= MM_Z_SPREAD_TOL && lm >= (double)p.lt_floor;
+        if (mark == 1 && sound) p.redo[b] = mark = 0;
+        // MM_PAIR_LINFIN: an overflow raises no mark in the kernels; it ends as a frame sum that is not a number (zM = inf)
+        if (MM_PAIR_LINFIN && mark == 0 && len >= 1 && !(zM < __builtin_inf())) p.redo[b] = mark = 1;
         if (p.stat_mode == 0) report_hard(p, mark != 0);
     }
     const long long gbase = (long long)b * p.gsb;

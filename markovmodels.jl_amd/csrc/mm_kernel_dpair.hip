@@ -946,6 +946,8 @@ static __global__ void mm_dpair_finish_kernel(RunParams p) {
         // log-domain kernels compute the utterance
         // (a mark of value 2 -- a team that did not run together -- stays)
         if (p.redo2[b] == 1 && agree && lm >= (double)p.lt_floor - (double)MM_DPAIR_THR_EXTRA) p.redo2[b] = 0;
+        // (the wide kernels' linear finishes raise no mark on an overflow: it ends as a frame sum that is not a number, zM = inf)
+        if (p.redo2[b] == 0 && len >= 1 && !(zM < __builtin_inf())) p.redo2[b] = 1;
         // (a call that skipped the float32 kernels: would they have coped?  Not with an overlap term below their floor)
         if (p.stat_mode == 1) report_hard(p, !(lm >= (double)p.lt_floor));
     }

@@ -749,7 +749,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
     const int S1 = r.rows, S1p = p.pair_s1p, P1 = uni(ud.P1), P = P1 - 1, P1p = (P1 + 3) & ~3;
     const float thr = r.thr;
     // (LINF) bits - 1 of the smallest sum a finish accepts: 2^-(thr + MM_LINF_EMIN), see the finishes
-    const unsigned sthr = ((unsigned)(127 - (int)(thr + MM_LINF_EMIN < 1.f ? 1.f : thr + MM_LINF_EMIN)) << 23) - 1u;
+    unsigned sthr;  // (a scalar register by force: as a vector register it was spilled in the phase-B instance of the wide kernels)
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(sthr) : "v"(((unsigned)(127 - (int)(thr + MM_LINF_EMIN < 1.f ? 1.f : thr + MM_LINF_EMIN)) << 23) - 1u));
     // (Steering the frame maxima to 2^(thr - 20) instead of 2^0 -- to use the upper half of the float exponent range and keep
     // states up to ~190 log2 below the maximum on the linear path -- was tried and dropped: v_log_f32 returns log2 of sums
     // near 2^87 as floats 7.6e-6 apart, the per-frame normalisers of one utterance then scatter by 2e-4..7e-4 log2 instead of

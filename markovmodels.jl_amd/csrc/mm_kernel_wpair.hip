@@ -94,6 +94,33 @@ __device__ __forceinline__ float w_log2_acc(const double &s) {
     return ex != 0u ? l : MM_NINF;
 }
 
+#ifndef MM_WPAIR_LINFIN
+#define MM_WPAIR_LINFIN 1
+#endif
+#define MM_WLINF_EMIN (-500.f)  // log2 of the smallest emission factor of a step that raises no mark (wpair_stage_em)
+// pair_stage_em<NJ, LIN> for the wide kernels: the step's emission factors 2^(v - E - S) as wide values (high dwords)
+template <int NJ>
+__device__ __forceinline__ float wpair_stage_em(unsigned dst, unsigned rawsrc, int u, int n, int len, int P, int lane, float S, int *mark) {
+    float v[NJ], E = MM_NINF;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = lane + 64 * j;
+        v[j] = em_value(ldsr(rawsrc + 256u * j + 4u * lane), n, len, P, q);
+        if (q < P) E = max_nc(E, v[j]);
+    }
+    E = wave_max_rl(E);
+    if (!(E > MM_NINF)) E = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = lane + 64 * j;
+        if (q <= P) {
+            ldswu(dst + 8u * q + 4u * u, w_exp2_hi(v[j] - E - S));
+            if (v[j] - E - S < MM_WLINF_EMIN && v[j] > MM_NINF) *mark = 1;
+        }
+    }
+    return E;
+}
+
 // One arc for the two utterances: acc0 += w * x_0, acc1 += w * x_1 with xx = {high dword of x_0, high dword of x_1} as gathered.
 // `tmp`: two register pairs that live across the steps; only their high registers are written here, their low registers stay 0.
 // (The pair as it landed would do as utterance 1's operand without a move -- its low dword is then utterance 0's high dword: up to
@@ -117,6 +144,16 @@ __device__ __forceinline__ void w_mul2(double &acc0, double &acc1, const double 
     tmp[1] = __builtin_bit_cast(double, t1);
     asm("v_mul_f64 %0, %1, %2" : "=v"(acc0) : "v"(wa), "v"(tmp[0]));
     asm("v_mul_f64 %0, %1, %2" : "=v"(acc1) : "v"(wa), "v"(tmp[1]));
+}
+// the two utterances' products with two different left factors: a0 = s0 * x_0, a1 = s1 * x_1 (the finishes)
+__device__ __forceinline__ void w_mul2s(double &a0, double &a1, const double &s0, const double &s1, const mm_u32x2 &xx, double (&tmp)[2]) {
+    mm_u32x2 t0 = __builtin_bit_cast(mm_u32x2, tmp[0]), t1 = __builtin_bit_cast(mm_u32x2, tmp[1]);
+    t0.y = xx.x;
+    t1.y = xx.y;
+    tmp[0] = __builtin_bit_cast(double, t0);
+    tmp[1] = __builtin_bit_cast(double, t1);
+    asm("v_mul_f64 %0, %1, %2" : "=v"(a0) : "v"(s0), "v"(tmp[0]));
+    asm("v_mul_f64 %0, %1, %2" : "=v"(a1) : "v"(s1), "v"(tmp[1]));
 }
 // (Tried and dropped, round 5: an arc as TWO ds_read_b32, each straight into the high register of a persistent operand pair whose low
 // register stays 0 -- no moves, 2 LDS + 2 vector instructions per arc instead of 1 + 4.  Slower: 5.8 against 5.2 ms on the
@@ -378,6 +415,12 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
     const RowU r = uni(H > 1 ? ud.rps[DIR][hset] : ud.rp[DIR]);
     const int S1 = r.rows, S1p = p.pair_s1p, P1 = uni(ud.P1), P = P1 - 1, P1p = (P1 + 3) & ~3;
     const float thr = r.thr + MM_DPAIR_THR_EXTRA;
+    // LINF (pair_agent): the finishes stay in the linear domain -- p = s * factor, q = s * partner as v_mul_f64 on wide values,
+    // no logarithms or exponentials in the compute waves (a finish was ~55 vector instructions, 4 to 6 of them quarter-rate)
+    constexpr bool LINF = MM_WPAIR_LINFIN != 0;
+    // bits - 1 of the high dword of the smallest sum a finish accepts: 2^-(thr + MM_WLINF_EMIN)
+    unsigned sthr;  // (a scalar register by force: as a vector register it was spilled in the phase-B instance of the wide kernels)
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(sthr) : "v"(((unsigned)(1023 - (int)(thr + MM_WLINF_EMIN < 1.f ? 1.f : thr + MM_WLINF_EMIN)) << 20) - 1u));
     int m = (int)(((long long)NFp * (p.split_q10 > 0 ? p.split_q10 : 512)) >> 10);
     m = m < 1 ? 1 : (m > NFp - 1 && NFp > 1 ? NFp - 1 : m);
     const int tA = DIR ? NFp - m : m, tEnd = NFp;
@@ -391,7 +434,7 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
     if constexpr (PHASE == 1)
         for (unsigned q = tid * 4u; q < 2u * RSH; q += NT * 4u) ldsw(L::Q(0) + q, 0.f);
     if (tid < 32) ldsw(L::MS(0) + 4u * tid, 0.f);
-    if (tid < 4) ldsw(L::EM(tid >> 1) + 8u * P1p + 4u * (tid & 1), MM_NINF);  // the emission slot of lanes without a row
+    if (tid < 4) ldsw(L::EM(tid >> 1) + 8u * P1p + 4u * (tid & 1), LINF ? 0.f : MM_NINF);  // the emission slot of lanes without a row
     const int nslotwords = r.nslotrows * 128;
     for (int q = tid; q < nslotwords; q += NT) ldswu(L::SLOTS + 4u * q, as_global(r.slots)[q]);
     if constexpr (PHASE == 1)
@@ -475,15 +518,24 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
         auto stage = [&](int t, const float (&S)[2]) {
             float E[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) E[u] = pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, u) + L::RAWS * (unsigned)(t & 3), u, frame_of(t), U[u].len, P, sl);
+            for (int u = 0; u < 2; ++u) {
+                if constexpr (LINF) E[u] = wpair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, u) + L::RAWS * (unsigned)(t & 3), u, frame_of(t), U[u].len, P, sl, S[u], u ? redo1 : redo0);
+                else E[u] = pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, u) + L::RAWS * (unsigned)(t & 3), u, frame_of(t), U[u].len, P, sl);
+            }
+            double before[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) cum[u] += (double)S[u] + (double)E[u];
+            for (int u = 0; u < 2; ++u) {
+                before[u] = cum[u];
+                cum[u] += (double)S[u] + (double)E[u];
+            }
             if (sl == 0) {
-                ldsw2(L::MS(t & 1), S[0], S[1]);
+                if constexpr (!LINF) ldsw2(L::MS(t & 1), S[0], S[1]);
+                // (LINF: the stored vector p carries the step's normaliser and emission in both directions; what is combined with
+                // the partner's is s, the sum before either -- pair_agent)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const double off = DIR ? cum[u] - (double)E[u] : cum[u];
-                    *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(L::OWN(t & 3) + 8u * u) = off;
+                    const double off = LINF ? cum[u] : (DIR ? cum[u] - (double)E[u] : cum[u]);
+                    *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(L::OWN(t & 3) + 8u * u) = LINF ? before[u] : off;
                     if (PHASE == 0) U[u].offs[frame_of(t)] = off;
                 }
             }
@@ -505,7 +557,7 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
             }
         }
         MM_ROW_VMCNT(0);
-        if (PHASE == 0 || DIR == 1) {  // emissions of the starting step
+        if (PHASE == 0 || (DIR == 1 && !LINF)) {  // emissions of the starting step
             float E[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) E[u] = pair_stage_em<NJ>(L::EM(t0 & 1), L::RAW(0, u) + L::RAWS * (unsigned)(t0 & 3), u, frame_of(t0), U[u].len, P, sl);
@@ -539,6 +591,7 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
                     const double z = (double)lt[u] + own + oth;
                     zmin[u] = z < zmin[u] ? z : zmin[u];
                     zmax[u] = z > zmax[u] ? z : zmax[u];
+                    if (!(z == z)) zmax[u] = __builtin_inf();  // (an overflow somewhere: inf * 0; mm_dpair_finish_kernel keeps the utterance marked)
                     ltmin[u] = lt[u] < ltmin[u] ? lt[u] : ltmin[u];
                 }
         };
@@ -673,6 +726,7 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
                     const double z = (double)lt[u] + own + oth;
                     xzmin[u] = z < xzmin[u] ? z : xzmin[u];
                     xzmax[u] = z > xzmax[u] ? z : xzmax[u];
+                    if (!(z == z)) xzmax[u] = __builtin_inf();
                     xltmin[u] = lt[u] < xltmin[u] ? lt[u] : xltmin[u];
                 }
         };
@@ -707,11 +761,13 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
                 if (H > 1 && pdfi == 0xffffu) pdfi = (unsigned)P1p;  // (alignment padding between the sets' regions: init = -inf)
                 const mm_f32x2 e = ldsr2(L::EM(1) + 8u * pdfi);
                 const float a0 = as_global(r.init)[i];
-                const float v0 = a0 + e.x, v1 = a0 + e.y;
+                float v0 = a0 + e.x, v1 = a0 + e.y;
+                if (LINF && H > 1 && pdfi == (unsigned)P1p) v0 = v1 = MM_NINF;  // (LINF: the slot of lanes without a row holds the linear 0)
                 if (row_out_of_range(v0, thr)) *redo0 = 1;
                 if (row_out_of_range(v1, thr)) *redo1 = 1;
                 ldsw2u(L::PP(1) + 8u * i, w_exp2_hi(v0), w_exp2_hi(v1));
-                *reinterpret_cast<mm_f32x2 *>(rowsP + ((long long)1 * S1p + i) * 2) = mm_f32x2{v0, v1};
+                if constexpr (LINF) *reinterpret_cast<mm_u32x2 *>(rowsP + ((long long)1 * S1p + i) * 2) = mm_u32x2{w_exp2_hi(v0), w_exp2_hi(v1)};
+                else *reinterpret_cast<mm_f32x2 *>(rowsP + ((long long)1 * S1p + i) * 2) = mm_f32x2{v0, v1};
             }
         } else if (DIR == 1 && t0 == 1) {  // B[:, N+1] = one at the final state   (src/inference.jl:104)
             if (tid == 0) ldsw2u(L::PP(1) + 8u * r.fpos, 0x3ff00000u, 0x3ff00000u);
@@ -721,6 +777,11 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
                 const mm_f32x2 vv = *reinterpret_cast<const mm_f32x2 *>(rowsP + ((long long)f * S1p + i) * 2);
                 float v0 = vv.x, v1 = vv.y;
                 const unsigned pdfi = as_global(r.rowpdf)[i];
+                if constexpr (LINF) {  // the stored vector IS the step's vector of wide values
+                    const bool pad = H > 1 && pdfi == 0xffffu;  // (padding: never stored)
+                    ldsw2u(L::PP(t0 & 1) + 8u * i, pad ? 0u : __builtin_bit_cast(unsigned, v0), pad ? 0u : __builtin_bit_cast(unsigned, v1));
+                    continue;
+                }
                 if (DIR == 1) {  // beta~ is stored without the frame's emission
                     const mm_f32x2 e = ldsr2(L::EM(t0 & 1) + 8u * (H > 1 && pdfi == 0xffffu ? (unsigned)P1p : pdfi));
                     v0 += e.x;
@@ -759,8 +820,8 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
                 }
                 // (the step's normalisers, posted by the service wave, are read in every finish: phase B has no two registers to keep them in)
                 mm_f32x2 S0 = {0.f, 0.f};
-                if constexpr (PHASE == 0) S0 = ldsr2(L::MS(WR));
-                mm_f32x2 e = ldsr2((info >> 16) + L::EM(WR));
+                if constexpr (PHASE == 0 && !LINF) S0 = ldsr2(L::MS(WR));
+                mm_f32x2 e = ldsr2((info >> 16) + L::EM(WR));  // (LINF: the bits of two wide values)
                 const int f = frame_of(t);
                 const unsigned alb = L::AL(0) + (unsigned)(t % L::NR) * (unsigned)RSH;
                 mm_f32x2 al = {0.f, 0.f};
@@ -772,6 +833,7 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
                 (void)xw;
                 (void)xtag;
                 float worst = 0.f;
+                unsigned smin = 0xffffffffu;
                 double accA0 = 0.0, accA1 = 0.0, accN0 = 0.0, accN1 = 0.0;
                 unsigned long long lgw = lgw0;
                 auto finish = [&]() {
@@ -783,6 +845,27 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
                         s1 = dgrp_sum_last(s1, lg);
                     }
                     const unsigned pos8 = info & 0xffffu;
+                    if constexpr (LINF) {
+                        // range check, deferred to the end of the step: the smallest non-zero sum of the lane by its high dword
+                        // (pair_agent); p = s * factor, q = s * partner with the operand pairs of the arcs
+                        smin = min3_u32(smin, __builtin_bit_cast(mm_u32x2, s0).y - 1u, __builtin_bit_cast(mm_u32x2, s1).y - 1u);
+                        double p0, p1;
+                        w_mul2s(p0, p1, s0, s1, __builtin_bit_cast(mm_u32x2, e), tmp);
+                        const unsigned h0 = __builtin_bit_cast(mm_u32x2, p0).y, h1 = __builtin_bit_cast(mm_u32x2, p1).y;
+                        ldsw2u(pos8 + L::PP(WR), h0, h1);
+                        if constexpr (H > 1) {  // the row for the team: its pair of high dwords, the step's tag in their sign bits
+                            const mm_u32x2 gv = {h0 | xtag, h1 | xtag};
+                            if (xplain) *reinterpret_cast<mm_u32x2 *>(reinterpret_cast<char *>(xw) + pos8) = gv;
+                            else granule_store(xw, pos8, __builtin_bit_cast(float, gv.x), __builtin_bit_cast(float, gv.y));
+                        }
+                        if constexpr (PHASE == 0) {
+                            *reinterpret_cast<mm_u32x2 *>(reinterpret_cast<char *>(rowP) + pos8) = mm_u32x2{h0, h1};
+                        } else {
+                            double q0, q1;
+                            w_mul2s(q0, q1, s0, s1, __builtin_bit_cast(mm_u32x2, al), tmp);  // A .* B   (:154)
+                            ldsw2u((info2 >> 16) + L::Q(WR), __builtin_bit_cast(mm_u32x2, q0).y, __builtin_bit_cast(mm_u32x2, q1).y);
+                        }
+                    } else {
                     const mm_f32x2 S = PHASE == 0 ? S0 : ldsr2(L::MS(WR));
                     // forward: (T' alpha) (*) lhs (src/inference.jl:70-71); backward: T (B (*) lhs) (:106-107), the emission is
                     // added for the next step's product only
@@ -803,6 +886,7 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
                     } else {
                         ldsw2u((info2 >> 16) + L::Q(WR), w_exp2_hi(st0 + al.x), w_exp2_hi(st1 + al.y));  // A .* B   (:154)
                     }
+                    }
                     accA0 = accA1 = 0.0;
                     sa += 512u;
                     asm volatile("v_mov_b32 %0, %1" : "=v"(info) : "v"(infoN));
@@ -820,7 +904,7 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
                 asm volatile("" : "+s"(em_lo), "+s"(em_hi));
                 __builtin_amdgcn_s_setprio(2);
                 MM_PAIR_CASES(MM_WPAIR_TWO)
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(worst > thr) != 0ull, 0)) {
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(LINF ? smin < sthr : worst > thr) != 0ull, 0)) {
                     *redo0 = 1;
                     *redo1 = 1;
                 }

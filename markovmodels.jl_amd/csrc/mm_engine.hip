@@ -190,6 +190,7 @@ struct DebugOpts {
     bool no_xcsr = false, verbose = false;
     bool no_redo = false;           // MM_NO_REDO: the exact kernels do not run after the fast ones (what the fast path alone computes)
     bool no_dpair = false;          // MM_NO_DPAIR: no float64 pair kernels (marked utterances go straight to the quad / item kernels)
+    bool bankopt = false;           // MM_BANKOPT: the pair forms choose the banks of their rows (RowPackOpts::bank_opt; an experiment, off by default)
     bool no_wpair = false;          // MM_NO_WPAIR: a whole batch on the exact kernels runs the one-utterance float64 kernels, not the wide pair kernels
     bool no_fallback = false;       // MM_NO_FALLBACK: the float64 pair kernels run, the log-domain kernels behind them do not
     int exact_first = -1;           // MM_EXACT_FIRST=0/1: never / always skip the float32 pair kernels (default: by the last call's marks)
@@ -215,6 +216,7 @@ static DebugOpts read_debug_opts() {
     d.no_redo = getenv("MM_NO_REDO") != nullptr;
     d.no_dpair = getenv("MM_NO_DPAIR") != nullptr;
     d.no_wpair = getenv("MM_NO_WPAIR") != nullptr;
+    d.bankopt = getenv("MM_BANKOPT") != nullptr;
     d.no_fallback = getenv("MM_NO_FALLBACK") != nullptr;
     if (const char *e = getenv("MM_EXACT_FIRST")) d.exact_first = atoi(e) != 0;
     if (const char *e = getenv("MM_FINISH_COST")) d.finish_cost = atoi(e);
@@ -915,6 +917,7 @@ static int pair_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
     if (dbg.group_speed[0] > 0)
         for (int i = 0; i < 4; ++i) opt.group_speed[i] = dbg.group_speed[i];
     opt.ka_choices[0] = MM_PAIR_KA;
+    opt.bank_opt = dbg.bankopt ? 1 : 0;
     RowVariant *rv[2] = {new RowVariant(), new RowVariant()};
     const std::vector<int32_t> none;
     // (cost of a finish in arcs: measured with cycle stamps on config 3 -- the backward agent's finishes are the dearer
@@ -1458,7 +1461,7 @@ int mm_debug_row_product(mm_fsm_t f, int direction, const float *in, float *out,
 }
 
 int mm_debug_row_product_ex(mm_fsm_t f, int direction, int flags, const float *in, float *out, double stats[8]) {
-    if (!f || !in || !out || direction < 0 || direction > 1 || flags < 0 || flags > 15)
+    if (!f || !in || !out || direction < 0 || direction > 1 || flags < 0 || flags > 31)
         return fail(MM_ERR_INVALID, "mm_debug_row_product: bad argument");
     if (f->semiring != MM_LOG) return fail(MM_ERR_INVALID, "mm_debug_row_product: log-semiring FSMs only");
     RowPackOpts opt;
@@ -1473,6 +1476,7 @@ int mm_debug_row_product_ex(mm_fsm_t f, int direction, int flags, const float *i
     }
     opt.copies = (flags >> 1) & 3;
     opt.copy_perm = (flags & 8) != 0;
+    opt.bank_opt = (flags & 16) ? 1 : 0;
     if (opt.copies > 2) return fail(MM_ERR_INVALID, "mm_debug_row_product: at most two copies");
     RowGraph gf, g;
     const std::vector<int32_t> none;

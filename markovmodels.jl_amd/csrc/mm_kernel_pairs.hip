@@ -106,6 +106,9 @@ typedef __attribute__((address_space(1))) mm_u64 mm_gu64;
 #ifndef MM_PAIR_LINFIN
 #define MM_PAIR_LINFIN 1
 #endif
+#ifndef MM_PAIR_SCAN_BATCH
+#define MM_PAIR_SCAN_BATCH 8  // 16-byte LDS reads the service wave's scan keeps in flight
+#endif
 #define MM_LINF_EMIN (-40.f)  // log2 of the smallest emission factor of a step that raises no mark (pair_stage_em)
 #define MM_SPLIT_TIMEOUT 10000000ull  // ticks of s_memrealtime (100 MHz): 0.1 s -- the ceiling; a call passes its own (RunParams::x_timeout)
 #endif
@@ -281,6 +284,68 @@ __device__ __forceinline__ float pair_stage_em(unsigned dst, unsigned rawsrc, in
     return E;
 }
 
+// two wave-wide maxima at once: the DPP steps of the two chains alternate (each fills the other's wait states), then the 4 row
+// results of each through readlane
+__device__ __forceinline__ void wave_max_rl2(float &a, float &b) {
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+        : "+v"(a), "+v"(b));
+    const int ia = __builtin_bit_cast(int, a), ib = __builtin_bit_cast(int, b);
+    const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ia, 0)), b0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ib, 0));
+    const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ia, 16)), b1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ib, 16));
+    const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ia, 32)), b2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ib, 32));
+    const float a3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ia, 48)), b3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ib, 48));
+    a = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+    b = fmaxf(fmaxf(b0, b1), fmaxf(b2, b3));
+}
+
+// pair_stage_em<NJ, true> for BOTH utterances in one pass (up to 4 passes of 64 pdfs): all raw values are read before anything is
+// written -- called once per utterance, the second call's LDS reads wait behind the first call's LDS writes (the compiler cannot
+// tell them apart), and the service wave's own chain of round trips is what bounds a step since the finishes went linear --, the
+// two maxima share one DPP ladder, and a pdf's two factors leave in ONE 8-byte write.
+template <int NJ>
+__device__ __forceinline__ void pair_stage_em2(unsigned dst, unsigned raw0, unsigned raw1, int n, int len0, int len1, int P, int lane, float S0,
+                                               float S1, int *mark0, int *mark1, float (&E)[2]) {
+    float v0[NJ], v1[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        v0[j] = ldsr(raw0 + 256u * j + 4u * lane);
+        v1[j] = ldsr(raw1 + 256u * j + 4u * lane);
+    }
+    float e0 = MM_NINF, e1 = MM_NINF;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = lane + 64 * j;
+        v0[j] = em_value(v0[j], n, len0, P, q);
+        v1[j] = em_value(v1[j], n, len1, P, q);
+        if (q < P) {
+            e0 = max_nc(e0, v0[j]);
+            e1 = max_nc(e1, v1[j]);
+        }
+    }
+    wave_max_rl2(e0, e1);
+    if (!(e0 > MM_NINF)) e0 = 0.f;
+    if (!(e1 > MM_NINF)) e1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = lane + 64 * j;
+        if (q <= P) {
+            const float x0 = v0[j] - e0 - S0, x1 = v1[j] - e1 - S1;
+            ldsw2(dst + 8u * (unsigned)q, fast_exp2(x0), fast_exp2(x1));
+            if (x0 < MM_LINF_EMIN && v0[j] > MM_NINF) *mark0 = 1;
+            if (x1 < MM_LINF_EMIN && v1[j] > MM_NINF) *mark1 = 1;
+        }
+    }
+    E[0] = e0;
+    E[1] = e1;
+}
+
 // The same for BOTH utterances at once with 16-byte reads: a lane takes 4 consecutive pdfs per pass (the instances of more
 // than 4 passes of 64 pdfs, whose service wave is the longest actor of every step: 2000 states / 400 pdfs spent 3100 of a
 // 4800-cycle phase-A step here with 32 four-byte LDS accesses; now 4 reads of 16 bytes and 8 writes of 8).
@@ -335,25 +400,28 @@ __device__ __forceinline__ void pair_stage_em_wide(unsigned dst, unsigned raw0, 
 // All loads are issued before the first maximum (clamped indices: a duplicate changes no maximum) -- a loop with one
 // load per trip costs the wave one LDS round trip per trip, and the service wave is the one wave whose own latency
 // chain every step waits for.
-template <int NB>
+template <int NB, int BATCH = 4>
 __device__ __forceinline__ void pair_scan_max(unsigned pbase, int n2, int lane, float &m0, float &m1) {
     float a = 0.f, b = 0.f;
 #pragma unroll
-    for (int j0 = 0; j0 < NB; j0 += 4) {  // (batches of 4 loads: 16 registers; more spill in the phase B kernels)
-        mm_f32x4 v[4];
+    for (int j0 = 0; j0 < NB; j0 += BATCH) {  // (batches of 4 loads: 16 registers; more spill in the phase B kernels)
+        mm_f32x4 v[BATCH];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < BATCH; ++j) {
             const int q = lane + 64 * (j0 + j);
-            v[j] = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(pbase + 16u * (q < n2 ? q : n2 - 1));
+            if (j0 + j < NB) v[j] = *(__attribute__((address_space(3))) const mm_f32x4 *)(__UINTPTR_TYPE__)(pbase + 16u * (q < n2 ? q : n2 - 1));
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a = max_nc(a, max_nc(v[j].x, v[j].z));
-            b = max_nc(b, max_nc(v[j].y, v[j].w));
+        for (int j = 0; j < BATCH; ++j) {
+            if (j0 + j < NB) {
+                a = max_nc(a, max_nc(v[j].x, v[j].z));
+                b = max_nc(b, max_nc(v[j].y, v[j].w));
+            }
         }
     }
-    m0 = fast_log2(wave_max_rl(a));
-    m1 = fast_log2(wave_max_rl(b));
+    wave_max_rl2(a, b);
+    m0 = fast_log2(a);
+    m1 = fast_log2(b);
 }
 
 // wave-wide sum without the LDS crossbar: 16-lane rows by DPP, then the 4 row results through readlane
@@ -707,6 +775,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
 #ifndef MM_PAIR_DA
 #define MM_PAIR_DA 3
 #endif
+#ifndef MM_PAIR_DB
+#define MM_PAIR_DB 3
+#endif
     constexpr bool MM_PAIR_DOUBLE = true;
     // LINF: the finishes stay in the linear domain (round 5): the service wave stages the step's emissions as factors 2^(v - E - S),
     // a finish is p = s * factor (and, in phase B, q = s * partner), BOTH directions store p -- the vector with the frame's emission --
@@ -715,7 +786,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
     // second v_exp_f32 for the combine -- 4 (phase A) / 6 (phase B) quarter-rate instructions per finish for the two utterances,
     // ~1100 of a SIMD's ~3000 busy cycles per phase-B step (SQ_INSTS_VALU, profiles/r05_pmc_lfmmi_den.json).
     constexpr bool LINF = MM_PAIR_LINFIN != 0;
-    constexpr int D = PHASE ? 3 : MM_PAIR_DA;  // gather pairs in flight ahead of the FMAs
+    constexpr int D = PHASE ? MM_PAIR_DB : MM_PAIR_DA;  // gather pairs in flight ahead of the FMAs
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, NWC = NW - (H > 1 ? 2 : 1);
     const bool service = wave == NWC;
@@ -896,6 +967,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             if constexpr (NJ > 4 && MM_PAIR_WIDE_SERVICE) {
                 pair_stage_em_wide<NJ, LINF>(L::EM(t & 1), L::RAW(0, 0) + L::RAWS * (unsigned)(t & 3), L::RAW(0, 1) + L::RAWS * (unsigned)(t & 3), frame_of(t),
                                              U[0].len, U[1].len, P, sl, E, S[0], S[1], redo0, redo1);
+            } else if constexpr (LINF) {
+                pair_stage_em2<NJ>(L::EM(t & 1), L::RAW(0, 0) + L::RAWS * (unsigned)(t & 3), L::RAW(0, 1) + L::RAWS * (unsigned)(t & 3), frame_of(t), U[0].len,
+                                   U[1].len, P, sl, S[0], S[1], redo0, redo1, E);
             } else {
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
@@ -1035,7 +1109,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                     ldswu(L::MX(RD) + 4u, 0u);
                 }
             } else if constexpr (small_graph) pair_scan_max<4>(L::PP(RD), (S1 + 2) >> 1, sl, mx[0], mx[1]);
-            else pair_scan_max<(RS / 8 + 63) / 64>(L::PP(RD), (S1 + 2) >> 1, sl, mx[0], mx[1]);
+            else pair_scan_max<(RS / 8 + 63) / 64, MM_PAIR_SCAN_BATCH>(L::PP(RD), (S1 + 2) >> 1, sl, mx[0], mx[1]);
             MM_STAMP(3);
             if (t + 1 <= tEnd) {
                 const float S[2] = {norm[0].next(mx[0]), norm[1].next(mx[1])};

@@ -213,6 +213,213 @@ namespace mm {
         mm_rows_prof_ns[i] += std::chrono::duration_cast<std::chrono::nanoseconds>(now_ - prof_t_).count();                          \
         prof_t_ = now_;                                                                                                          \
     } while (0)
+
+// ---- bank_opt (RowPackOpts): the banks of the rows of a whole-graph pair form.
+// A half-wave gather of segment h (32 lanes, A_h arc slots each) is free of bank conflicts iff the lanes' arcs can be dealt to the
+// slots with no bank twice in a slot; by Koenig's edge-colouring theorem that is possible iff no bank holds more than A_h of the
+// half-segment's sources (the lanes hold at most A_h arcs by construction).  The bank of a row is its position mod 32, and the
+// position is free inside the row's segment (a finish writes wherever the slot table says): rows of one segment trade positions
+// while that lowers the excess sum_h sum_b max(0, D[h][b] - A_h) (+ a small term that levels D, + a small price on finishes whose
+// 16-lane store groups hit a bank pair twice).
+static void optimise_banks(const Plan &plan, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &col, std::vector<int32_t> &pos,
+                           std::vector<int32_t> &order) {
+    const int nseg = int(plan.segs.size());
+    const int NH = 2 * nseg;
+    std::vector<int> cap(size_t(NH), 0);
+    std::vector<std::vector<std::pair<int, int>>> mem(pos.size());  // row (as a source) -> (half-segment, arcs that read it)
+    std::vector<int> D(size_t(NH) * 32, 0);
+    {
+        std::vector<int> cnt(pos.size(), 0);
+        std::vector<int32_t> touched;
+        for (int si = 0; si < nseg; ++si) {
+            const Segment &s = plan.segs[size_t(si)];
+            for (int half = 0; half < 2; ++half) {
+                const int h = 2 * si + half;
+                cap[size_t(h)] = s.A;
+                touched.clear();
+                for (int l = 0; l < 32; ++l) {
+                    const int lane = half * 32 + l, grp = lane / s.g, sub = lane % s.g;
+                    if (grp >= int(s.rows.size())) continue;
+                    const int32_t r = s.rows[size_t(grp)];
+                    int n = 0;
+                    for (int64_t a = rowptr[r] + sub; a < rowptr[r + 1] && n < s.A; a += s.g, ++n) {
+                        if (cnt[size_t(col[a])]++ == 0) touched.push_back(col[a]);
+                    }
+                }
+                for (int32_t c : touched) {
+                    mem[size_t(c)].push_back({h, cnt[size_t(c)]});
+                    D[size_t(h) * 32 + size_t(pos[size_t(c)] & 31)] += cnt[size_t(c)];
+                    cnt[size_t(c)] = 0;
+                }
+            }
+        }
+    }
+    // finishing lane of a row inside its segment, and the store groups' (position mod 16) counts
+    std::vector<int> seg_of(pos.size(), -1), lane_of(pos.size(), 0);
+    std::vector<int> W(size_t(nseg) * 4 * 16, 0);
+    for (int si = 0; si < nseg; ++si) {
+        const Segment &s = plan.segs[size_t(si)];
+        for (size_t j = 0; j < s.rows.size(); ++j) {
+            const int32_t r = s.rows[j];
+            seg_of[size_t(r)] = si;
+            lane_of[size_t(r)] = int(j) * s.g + s.g - 1;
+            ++W[(size_t(si) * 4 + size_t(lane_of[size_t(r)] / 16)) * 16 + size_t(pos[size_t(r)] & 15)];
+        }
+    }
+    constexpr long long WX = 4096, WW = 256;
+    auto phi = [&](int h, int d) -> long long {
+        const int x = d - cap[size_t(h)];
+        return (x > 0 ? WX * x : 0) + (long long)d * d;
+    };
+    auto wcost = [&](int c) -> long long { return c > 1 ? WW * (c - 1) : 0; };
+    long long excess = 0;
+    for (int h = 0; h < NH; ++h)
+        for (int b = 0; b < 32; ++b) excess += std::max(0, D[size_t(h) * 32 + b] - cap[size_t(h)]);
+    if (getenv("MM_VERBOSE_PLAN")) fprintf(stderr, "[mm] bank_opt: excess before %lld\n", excess);
+    std::vector<int> dd(size_t(NH), 0);
+    std::vector<int> th;
+    // all rows in a fixed order; a pass tries every pair (first the pairs of one segment -- the cheap moves --, then, while an
+    // excess remains, every pair of rows)
+    std::vector<int32_t> all;
+    for (int si = 0; si < nseg; ++si)
+        for (int32_t r : plan.segs[size_t(si)].rows) all.push_back(r);
+    const int nall = int(all.size());
+    for (int pass = 0; pass < 40 && excess > 0; ++pass) {
+        bool improved = false;
+        const bool wide = pass >= 6 && getenv("MM_BANKOPT_WIDE") != nullptr;  // (rows that leave their segment's block scatter the finishes' global stores)
+        if (pass >= 6 && !wide) break;
+        {
+            for (int i = 0; i < nall; ++i)
+                for (int j = i + 1; j < nall; ++j) {
+                    const int32_t r = all[size_t(i)], t = all[size_t(j)];
+                    if (!wide && seg_of[size_t(r)] != seg_of[size_t(t)]) break;  // (rows of a segment are adjacent in `all`)
+                    const int b = pos[size_t(r)] & 31, b2 = pos[size_t(t)] & 31;
+                    if (b == b2) continue;
+                    if (wide) {  // only rows that sit in an overloaded (half-segment, bank) are worth the full search
+                        bool hot = false;
+                        for (auto &m : mem[size_t(r)]) hot = hot || D[size_t(m.first) * 32 + b] > cap[size_t(m.first)];
+                        if (!hot) break;
+                    }
+                    // net change of bank b in every touched half-segment: + the arcs that read t, - those that read r
+                    th.clear();
+                    for (auto &m : mem[size_t(r)]) {
+                        if (dd[size_t(m.first)] == 0) th.push_back(m.first);
+                        dd[size_t(m.first)] -= m.second;
+                    }
+                    for (auto &m : mem[size_t(t)]) {
+                        if (dd[size_t(m.first)] == 0) th.push_back(m.first);
+                        dd[size_t(m.first)] += m.second;
+                    }
+                    long long delta = 0;
+                    for (int h : th) {
+                        const int d = dd[size_t(h)];
+                        if (d == 0) continue;
+                        const int o1 = D[size_t(h) * 32 + b], o2 = D[size_t(h) * 32 + b2];
+                        delta += phi(h, o1 + d) - phi(h, o1) + phi(h, o2 - d) - phi(h, o2);
+                    }
+                    const int g1 = lane_of[size_t(r)] / 16, g2 = lane_of[size_t(t)] / 16;
+                    const int c1 = pos[size_t(r)] & 15, c2 = pos[size_t(t)] & 15;
+                    const int sr = seg_of[size_t(r)], st = seg_of[size_t(t)];
+                    if ((g1 != g2 || sr != st) && c1 != c2) {
+                        int *w1 = &W[(size_t(sr) * 4 + size_t(g1)) * 16], *w2 = &W[(size_t(st) * 4 + size_t(g2)) * 16];
+                        delta += wcost(w1[c1] - 1) - wcost(w1[c1]) + wcost(w1[c2] + 1) - wcost(w1[c2]);
+                        delta += wcost(w2[c2] - 1) - wcost(w2[c2]) + wcost(w2[c1] + 1) - wcost(w2[c1]);
+                    }
+                    if (delta < 0) {
+                        for (int h : th) {
+                            const int d = dd[size_t(h)];
+                            if (d == 0) continue;
+                            int &o1 = D[size_t(h) * 32 + b], &o2 = D[size_t(h) * 32 + b2];
+                            excess -= std::max(0, o1 - cap[size_t(h)]) + std::max(0, o2 - cap[size_t(h)]);
+                            o1 += d;
+                            o2 -= d;
+                            excess += std::max(0, o1 - cap[size_t(h)]) + std::max(0, o2 - cap[size_t(h)]);
+                        }
+                        if ((g1 != g2 || sr != st) && c1 != c2) {
+                            int *w1 = &W[(size_t(sr) * 4 + size_t(g1)) * 16], *w2 = &W[(size_t(st) * 4 + size_t(g2)) * 16];
+                            --w1[c1], ++w1[c2], --w2[c2], ++w2[c1];
+                        }
+                        std::swap(pos[size_t(r)], pos[size_t(t)]);
+                        improved = true;
+                    }
+                    for (int h : th) dd[size_t(h)] = 0;
+                }
+        }
+        if (!improved) break;
+    }
+    if (getenv("MM_VERBOSE_PLAN")) {
+        long long tot = 0, slots = 0, mx = 0;
+        for (int h = 0; h < NH; ++h) {
+            int m = 0;
+            for (int b = 0; b < 32; ++b) {
+                tot += D[size_t(h) * 32 + b];
+                m = std::max(m, D[size_t(h) * 32 + b] - cap[size_t(h)]);
+            }
+            mx += std::max(0, m);
+            slots += 32ll * cap[size_t(h)];
+        }
+        fprintf(stderr, "[mm] bank_opt: %d half-segments, %lld arcs in %lld slots, excess %lld (sum over banks), %lld (sum of the half-segments' worst bank)\n", NH, tot, slots, excess, mx);
+    }
+    for (size_t r = 0; r < pos.size(); ++r)
+        if (pos[r] >= 0) order[size_t(pos[r])] = int32_t(r);
+}
+
+// Exact dealing of a half-wave segment's arcs to its A slots: an edge colouring of the bipartite multigraph (lane, bank) with A
+// colours.  A bank that holds more than A of the arcs is split into virtual banks of at most A (the arcs beyond A meet another arc
+// of their bank in some slot: the conflicts that cannot be avoided).  lane_arcs[l] = {bank, id} of the lane's arcs (at most A);
+// slot_of[l][i] receives the slot of the lane's i-th arc.
+static void colour_half_segment(int A, const std::vector<std::pair<int, int>> (&lane_arcs)[32], std::vector<int> (&slot_of)[32]) {
+    struct Edge {
+        int l, v, colour;
+    };
+    std::vector<Edge> ed;
+    int bank_n[32] = {0};
+    std::vector<std::pair<int, int>> where;  // edge -> (lane, index in the lane)
+    for (int l = 0; l < 32; ++l) {
+        slot_of[l].assign(lane_arcs[l].size(), -1);
+        for (size_t i = 0; i < lane_arcs[l].size(); ++i) {
+            const int b = lane_arcs[l][i].first;
+            ed.push_back(Edge{l, b + 32 * (bank_n[b]++ / A), -1});
+            where.push_back({l, int(i)});
+        }
+    }
+    int nv = 32;
+    for (auto &e : ed) nv = std::max(nv, e.v + 1);
+    std::vector<int> lc(size_t(32) * A, -1), vc(size_t(nv) * A, -1);
+    for (int e = 0; e < int(ed.size()); ++e) {
+        const int l = ed[size_t(e)].l, v = ed[size_t(e)].v;
+        int a = 0, b = 0;
+        while (lc[size_t(l) * A + a] >= 0) ++a;
+        while (vc[size_t(v) * A + b] >= 0) ++b;
+        if (vc[size_t(v) * A + a] >= 0) {
+            // the a / b alternating path from v: flip it (it cannot reach lane l: it enters lanes by edges of colour a, and l has none)
+            std::vector<int> path;
+            int cur = vc[size_t(v) * A + a];
+            bool want_b = true;  // the next edge leaves a lane, by colour b
+            while (cur >= 0) {
+                path.push_back(cur);
+                cur = want_b ? lc[size_t(ed[size_t(cur)].l) * A + b] : vc[size_t(ed[size_t(cur)].v) * A + a];
+                want_b = !want_b;
+            }
+            for (int pe : path) {
+                const Edge &x = ed[size_t(pe)];
+                lc[size_t(x.l) * A + x.colour] = -1;
+                vc[size_t(x.v) * A + x.colour] = -1;
+            }
+            for (int pe : path) {
+                Edge &x = ed[size_t(pe)];
+                x.colour = x.colour == a ? b : a;
+                lc[size_t(x.l) * A + x.colour] = pe;
+                vc[size_t(x.v) * A + x.colour] = pe;
+            }
+        }
+        ed[size_t(e)].colour = a;
+        lc[size_t(l) * A + a] = e;
+        vc[size_t(v) * A + a] = e;
+    }
+    for (int e = 0; e < int(ed.size()); ++e) slot_of[where[size_t(e)].first][size_t(where[size_t(e)].second)] = ed[size_t(e)].colour;
+}
+
 bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vector<int32_t> &col,
                const std::vector<float> &val, const std::vector<int32_t> &row2pdf, int32_t P1, bool backward,
                const std::vector<int32_t> &fwd_pos, const RowPackOpts &opt, RowGraph &g) {
@@ -299,6 +506,9 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                 }
         if (next != nsub) return false;
     }
+    const bool bank_opt = opt.bank_opt && opt.pair && !opt.subset && !opt.gpos && !opt.keep_order && opt.place >= 2 &&
+                          (opt.copies ? opt.copies : 1) == 1 && !opt.log_weights && opt.mix_n4 < 0 && !opt.seg_stride;
+    if (bank_opt) optimise_banks(best, rowptr, col, g.pos, g.order);
     if (opt.plan_only) return true;
     // position of a source state in the vector the arcs read
     auto gp = [&](int32_t r) { return opt.gpos ? (*opt.gpos)[size_t(r)] : g.pos[size_t(r)]; };
@@ -478,7 +688,33 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                 wt_s.assign(size_t(32) * s.A, 0.f);
                 auto ad = [&, A = s.A](int l) { return ad_s.data() + size_t(l) * A; };
                 auto wt = [&, A = s.A](int l) { return wt_s.data() + size_t(l) * A; };
-                for (int l = 0; l < 32; ++l) {
+                if (bank_opt) {  // exact: an edge colouring of (lane, bank) with A colours; the padding slots last
+                    std::vector<std::pair<int, int>> lane_arcs[32];
+                    std::vector<int> slot_of[32];
+                    for (int l = 0; l < 32; ++l)
+                        for (size_t i = 0; i < la[l].arcs.size(); ++i)
+                            lane_arcs[l].push_back({Banks::of(enc(uint32_t(g.col[la[l].arcs[i]]), 0)), int(i)});
+                    colour_half_segment(s.A, lane_arcs, slot_of);
+                    std::vector<char> filled(size_t(32) * s.A, 0);
+                    for (int l = 0; l < 32; ++l)
+                        for (size_t i = 0; i < la[l].arcs.size(); ++i) {
+                            const int k = slot_of[l][i];
+                            ad(l)[k] = enc(uint32_t(g.col[la[l].arcs[i]]), 0);
+                            wt(l)[k] = std::exp2(g.cw[la[l].arcs[i]]);
+                            filled[size_t(l) * s.A + k] = 1;
+                            tab[k].add(ad(l)[k]);
+                            ++real_arcs;
+                        }
+                    for (int l = 0; l < 32; ++l)
+                        for (int k = 0; k < s.A; ++k)
+                            if (!filled[size_t(l) * s.A + k]) {  // padding: weight 0, an address that costs nothing
+                                const int bnk = tab[k].least_loaded();
+                                ad(l)[k] = uint32_t(4 * (bnk < ntot ? bnk : 0));
+                                wt(l)[k] = 0.f;
+                                tab[k].add(ad(l)[k]);
+                            }
+                }
+                for (int l = 0; l < 32 && !bank_opt; ++l) {
                     used_s.assign(la[l].arcs.size(), 0);
                     char *const used = used_s.data();
                     for (int k = 0; k < s.A; ++k) {
@@ -514,7 +750,7 @@ bool make_rows(int64_t nrows, const std::vector<int64_t> &rowptr, const std::vec
                 auto real = [&](float w) { return opt.log_weights ? w > -std::numeric_limits<float>::infinity() : w != 0.f; };
                 // local search on the sum of squared bank loads: flip the copy of a conflicting slot, or swap it with another
                 // slot of the lane (in either copy)
-                for (int pass = 0; pass < (opt.keep_order || opt.place < 2 ? 0 : 12); ++pass) {
+                for (int pass = 0; pass < (opt.keep_order || opt.place < 2 || bank_opt ? 0 : 12); ++pass) {
                     bool improved = false;
                     for (int l = 0; l < 32; ++l)
                         for (int k = 0; k < s.A; ++k) {

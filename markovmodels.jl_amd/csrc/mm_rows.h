@@ -135,6 +135,11 @@ struct RowPackOpts {
     // 0 = the arcs stay in CSR order in copy 0 (forms of kernels that are bound by their latency chains, not by LDS cycles:
     // the wave form -- the placement is most of the host time of packing a small graph).
     int place = 2;
+    // Pair form of a whole graph (no subset): 1 = the BANKS of the rows are chosen too -- rows of a segment trade their positions
+    // (the segment keeps its block of positions) until no bank holds more sources of a half-wave segment than the segment has arc
+    // slots, as far as that goes; the arcs of a half-wave segment then go to their slots by an exact edge colouring of the
+    // (lane, bank) multigraph (Koenig: as many colours as the largest degree) instead of the greedy pass + local search.
+    int bank_opt = 0;
     bool naive_stats = true;  // also model the arcs in CSR order (RowGraph::conflict_before: informational)
     bool q_positions = true;  // pdf-major positions of the rows (the kernels that sum the posteriors per pdf over contiguous ranges);
                               // false: the slot table's q field stays 0 (the wave kernel has its own pdf tables)

@@ -127,7 +127,7 @@ class CompiledFSM:
         return out, stats
 
 
-    def row_product(self, x: np.ndarray, direction: int = 0, pair: bool = False, copies: int = 0, scrambled: bool = False):
+    def row_product(self, x: np.ndarray, direction: int = 0, pair: bool = False, copies: int = 0, scrambled: bool = False, bank_opt: bool = False):
         """Host evaluation of the same product through the row-lane form of the row kernels, or its pair variant
         (test aid); copies / scrambled: the copies of the linear vector the placement may use.
         Returns (out, stats = [KA, compute waves, segments, arcs / arc slots, max wave cost, min wave cost,
@@ -135,7 +135,7 @@ class CompiledFSM:
         x = np.ascontiguousarray(x, dtype=np.float32)
         out = np.empty(self.S1, dtype=np.float32)
         stats = np.zeros(8, dtype=np.float64)
-        flags = (1 if pair else 0) | (int(copies) << 1) | (8 if scrambled else 0)
+        flags = (1 if pair else 0) | (int(copies) << 1) | (8 if scrambled else 0) | (16 if bank_opt else 0)
         check(lib.mm_debug_row_product_ex(self._h, direction, flags, x.ctypes.data, out.ctypes.data, stats.ctypes.data))
         return out, stats
 

@@ -47,6 +47,36 @@ __device__ __forceinline__ float dlog2(double s) {
     return (float)ex + fast_log2(mf);
 }
 
+#ifndef MM_DPAIR_LINFIN
+#define MM_DPAIR_LINFIN 1
+#endif
+#define MM_DLINF_EMIN (-500.f)  // log2 of the smallest emission factor of a step that raises no mark (dpair_stage_em)
+// pair_stage_em<NJ, LIN> for the float64 kernels: the step's emission factors 2^(v - E - S) as doubles (the pair layout's 8 bytes
+// per pdf); returns E
+template <int NJ>
+__device__ __forceinline__ float dpair_stage_em(unsigned dst, unsigned rawsrc, int n, int len, int P, int lane, float S, int *mark) {
+    float v[NJ], E = MM_NINF;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = lane + 64 * j;
+        v[j] = em_value(ldsr(rawsrc + 256u * j + 4u * lane), n, len, P, q);
+        if (q < P) E = max_nc(E, v[j]);
+    }
+    E = wave_max_rl(E);
+    if (!(E > MM_NINF)) E = 0.f;
+    bool tiny = false;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = lane + 64 * j;
+        if (q <= P) {
+            ldsw_d(dst + 8u * q, dexp2(v[j] - E - S));
+            tiny = tiny || (v[j] - E - S < MM_DLINF_EMIN && v[j] > MM_NINF);
+        }
+    }
+    if (tiny) *mark = 1;
+    return E;
+}
+
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dpp_add_d(double v) {
     const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
@@ -429,6 +459,11 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
     // state vectors of the utterance's frames (alpha~ up to the split, beta~ beyond): float32 log2 values [N + 2][S1p]
     float *rowsP = p.ws_alpha + (long long)b * (long long)(p.N + 2) * S1p;
     const float thr = r.thr + MM_DPAIR_THR_EXTRA;
+    // LINF (pair_agent): linear-domain finishes -- p = s * factor (the factor a double in LDS), q = s * partner (the partner's stored
+    // value: the high dword of its double, 20 mantissa bits -- the 4 bytes per state of the stored rows as before)
+    constexpr bool LINF = MM_DPAIR_LINFIN != 0;
+    unsigned sthr;  // bits - 1 of the high dword of the smallest sum a finish accepts: 2^-(thr + MM_DLINF_EMIN)
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(sthr) : "v"(((unsigned)(1023 - (int)(thr + MM_DLINF_EMIN < 1.f ? 1.f : thr + MM_DLINF_EMIN)) << 20) - 1u));
     int m = (int)(((long long)NFp * (p.split_q10 > 0 ? p.split_q10 : 512)) >> 10);
     m = m < 1 ? 1 : (m > NFp - 1 && NFp > 1 ? NFp - 1 : m);
     const int tA = DIR ? NFp - m : m, tEnd = NFp;
@@ -442,7 +477,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
     if constexpr (PHASE == 1)
         for (unsigned q = tid * 4u; q < 2u * RSH; q += NT * 4u) ldsw(L::Q(0) + q, 0.f);
     if (tid < 32) ldsw(L::MS(0) + 4u * tid, 0.f);
-    if (tid < 4) ldsw(L::EM(tid >> 1) + 8u * P1p + 4u * (tid & 1), MM_NINF);  // the emission slot of lanes without a row
+    if (tid < 4) ldsw(L::EM(tid >> 1) + 8u * P1p + 4u * (tid & 1), LINF ? 0.f : MM_NINF);  // the emission slot of lanes without a row
     const int nslotwords = r.nslotrows * 128;
     for (int q = tid; q < nslotwords; q += NT) ldswu(L::SLOTS + 4u * q, as_global(r.slots)[q]);
     if constexpr (PHASE == 1)
@@ -542,13 +577,17 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
         constexpr int NDMA = NJ + (PHASE ? NDM + 1 : 0);  // DMAs issued per step
         // stage the emissions of step t into EM(t & 1) and account its offset; S = the normaliser the step subtracts
         auto stage = [&](int t, float S) {
-            const float E = pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, 0) + L::RAWS * (unsigned)(t & 3), 0, frame_of(t), len, P, sl);
+            const float E = LINF ? dpair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, 0) + L::RAWS * (unsigned)(t & 3), frame_of(t), len, P, sl, S, redo2)
+                                 : pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, 0) + L::RAWS * (unsigned)(t & 3), 0, frame_of(t), len, P, sl);
+            const double before = cum;
             cum += (double)S + (double)E;
             if (sl == 0) {
-                ldsw(L::MS(t & 1), S);
+                if constexpr (!LINF) ldsw(L::MS(t & 1), S);
                 // the offset that turns the step's stored vector into log2 values: forward alpha~ includes the emission
-                const double off = DIR ? cum - (double)E : cum;
-                *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(L::OWN(t & 3)) = off;
+                // (LINF: the stored vector carries the step's normaliser and emission in both directions; what is combined with the
+                // partner's is s, the sum before either -- pair_agent)
+                const double off = LINF ? cum : (DIR ? cum - (double)E : cum);
+                *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(L::OWN(t & 3)) = LINF ? before : off;
                 if (PHASE == 0 && (H == 1 || hset == 0)) offs[frame_of(t)] = off;
             }
         };
@@ -566,7 +605,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             cum = h.cum;
         }
         MM_ROW_VMCNT(0);
-        if (PHASE == 0 || DIR == 1) {  // emissions of the starting step
+        if (PHASE == 0 || (DIR == 1 && !LINF)) {  // emissions of the starting step
             const float E = pair_stage_em<NJ>(L::EM(t0 & 1), L::RAW(0, 0) + L::RAWS * (unsigned)(t0 & 3), 0, frame_of(t0), len, P, sl);
             if (PHASE == 0) {  // step 1 subtracts nothing but E
                 cum = (double)E;
@@ -587,7 +626,8 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                 const double oth = *(__attribute__((address_space(3))) const double *)(__UINTPTR_TYPE__)(L::POFF(0, 0) + 16u * (unsigned)(ts & (L::POFFN - 1)));
                 const double z = (double)lt + own + oth;
                 zmin = z < zmin ? z : zmin;
-                zmax = z > zmax ? z : zmax;  // (NaN: neither comparison holds; the finish kernel tests zmin <= zmax)
+                zmax = z > zmax ? z : zmax;
+                if (!(z == z)) zmax = __builtin_inf();  // (an overflow somewhere: inf * 0; mm_dpair_finish_kernel keeps the utterance marked)
                 ltmin = lt < ltmin ? lt : ltmin;
             }
         };
@@ -704,6 +744,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                 const double z = (double)lt + own + oth;
                 xzmin = z < xzmin ? z : xzmin;
                 xzmax = z > xzmax ? z : xzmax;
+                if (!(z == z)) xzmax = __builtin_inf();
                 xltmin = lt < xltmin ? lt : xltmin;
             }
         };
@@ -735,10 +776,13 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             for (int i = tid; i < S1; i += 64 * NWC) {
                 unsigned pdfi = as_global(r.rowpdf)[i];
                 if (H > 1 && pdfi == 0xffffu) pdfi = (unsigned)P1p;  // (alignment padding between the sets' regions: init = -inf)
-                const float v0 = as_global(r.init)[i] + ldsr(L::EM(1) + 8u * pdfi);
+                float v0 = as_global(r.init)[i] + ldsr(L::EM(1) + 8u * pdfi);
+                if (LINF && H > 1 && pdfi == (unsigned)P1p) v0 = MM_NINF;  // (LINF: the slot of lanes without a row holds the linear 0)
                 if (row_out_of_range(v0, thr)) *redo2 = 1;
-                ldsw_d(L::PP(1) + 8u * i, dexp2(v0));
-                rowsP[(long long)1 * S1p + i] = v0;
+                const double p0 = dexp2(v0);
+                ldsw_d(L::PP(1) + 8u * i, p0);
+                if constexpr (LINF) reinterpret_cast<unsigned *>(rowsP)[(long long)1 * S1p + i] = __builtin_bit_cast(mm_u32x2, p0).y;
+                else rowsP[(long long)1 * S1p + i] = v0;
             }
         } else if (DIR == 1 && t0 == 1) {  // B[:, N+1] = one at the final state   (src/inference.jl:104)
             if (tid == 0) ldsw_d(L::PP(1) + 8u * r.fpos, 1.0);
@@ -747,6 +791,11 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
             for (int i = tid; i < S1; i += 64 * NWC) {
                 float v0 = rowsP[(long long)f * S1p + i];
                 const unsigned pdfi = as_global(r.rowpdf)[i];
+                if constexpr (LINF) {  // the stored value IS the step's (the high dword of its double)
+                    const bool pad = H > 1 && pdfi == 0xffffu;  // (padding: never stored)
+                    ldsw_d(L::PP(t0 & 1) + 8u * i, pad ? 0.0 : __builtin_bit_cast(double, mm_u32x2{0u, __builtin_bit_cast(unsigned, v0)}));
+                    continue;
+                }
                 if (DIR == 1) v0 += ldsr(L::EM(t0 & 1) + 8u * (H > 1 && pdfi == 0xffffu ? (unsigned)P1p : pdfi));  // beta~ is stored without the frame's emission
                 if (H > 1 && pdfi == 0xffffu) v0 = MM_NINF;  // (padding: never stored)
                 ldsw_d(L::PP(t0 & 1) + 8u * i, dexp2(v0));
@@ -794,8 +843,12 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                     info = ldsru(sa);
                     infoN = ldsru(sa + 512u);
                 }
-                const float S = ldsr(L::MS(WR));  // the step's normaliser, posted by the service wave
-                float e = ldsr((info >> 16) + L::EM(WR));
+                float S = 0.f;
+                if constexpr (!LINF) S = ldsr(L::MS(WR));  // the step's normaliser, posted by the service wave
+                float e = 0.f;
+                double ed = 0.0;  // (LINF) the emission factor of the segment's rows
+                if constexpr (LINF) ed = ldsr_d((info >> 16) + L::EM(WR));
+                else e = ldsr((info >> 16) + L::EM(WR));
                 const int f = frame_of(t);
                 const unsigned alb = L::AL(0) + (unsigned)(t % L::NR) * (unsigned)RSH + xoff;
                 float al = 0.f;
@@ -805,6 +858,9 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                 float *xw = H > 1 ? xsend + (long long)(t & 1) * p.x_slot - 2 * xbase : nullptr;
                 const bool xneg = H > 1 && split_tag(t, t0, 1) != 0u;
                 float worst = 0.f;
+                unsigned smin = 0xffffffffu;
+                double alz = 0.0;  // (LINF) the operand pair of the partner's value: only its high register is written
+                asm volatile("" : "+v"(alz));
                 double accA = 0.0, accN = 0.0;
                 unsigned long long lgw = lgw0;
                 auto finish = [&]() {
@@ -813,6 +869,27 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                     double s0 = accA;
                     if (lg) s0 = dgrp_sum_last(s0, lg);
                     const unsigned pos8 = info & 0xffffu;
+                    if constexpr (LINF) {
+                        // range check, deferred to the end of the step: the smallest non-zero sum of the lane by its high dword (pair_agent)
+                        const unsigned sh = __builtin_bit_cast(mm_u32x2, s0).y - 1u;
+                        smin = sh < smin ? sh : smin;
+                        const double p0 = s0 * ed;
+                        ldsw_d(pos8 + L::PP(WR), p0);
+                        if constexpr (H > 1) {
+                            if (xplain) *reinterpret_cast<double *>(reinterpret_cast<char *>(xw) + pos8) = dsigned(p0, xneg);
+                            else dgranule_store(xw, pos8, dsigned(p0, xneg));
+                        }
+                        if constexpr (PHASE == 0) {
+                            *reinterpret_cast<unsigned *>(reinterpret_cast<char *>(rowP) + (pos8 >> 1)) = __builtin_bit_cast(mm_u32x2, p0).y;
+                        } else {
+                            mm_u32x2 t = __builtin_bit_cast(mm_u32x2, alz);
+                            t.y = __builtin_bit_cast(unsigned, al);
+                            alz = __builtin_bit_cast(double, t);
+                            double q0;
+                            asm("v_mul_f64 %0, %1, %2" : "=v"(q0) : "v"(s0), "v"(alz));
+                            ldsw_d((info2 >> 16) + L::Q(WR), q0);  // A .* B   (:154)
+                        }
+                    } else {
                     // forward: (T' alpha) (*) lhs (src/inference.jl:70-71); backward: T (B (*) lhs) (:106-107), the emission is
                     // added for the next step's product only
                     const float b0 = dlog2(s0) - S;
@@ -831,10 +908,12 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                     } else {
                         ldsw_d((info2 >> 16) + L::Q(WR), dexp2(st0 + al));  // A .* B   (:154)
                     }
+                    }
                     accA = 0.0;
                     sa += 512u;
                     asm volatile("v_mov_b32 %0, %1" : "=v"(info) : "v"(infoN));
-                    e = ldsr((info >> 16) + L::EM(WR));
+                    if constexpr (LINF) ed = ldsr_d((info >> 16) + L::EM(WR));
+                    else e = ldsr((info >> 16) + L::EM(WR));
                     if constexpr (PHASE == 1) {
                         asm volatile("v_mov_b32 %0, %1" : "=v"(info2) : "v"(info2N));
                         al = ldsr(((info2 & 0xffffu) >> 1) + alb);
@@ -848,7 +927,7 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
                 asm volatile("" : "+s"(em_lo), "+s"(em_hi));
                 __builtin_amdgcn_s_setprio(2);
                 MM_PAIR_CASES(MM_DPAIR_TWO)
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(worst > thr) != 0ull, 0)) *redo2 = 1;
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(LINF ? smin < sthr : worst > thr) != 0ull, 0)) *redo2 = 1;
             }
             if constexpr (PHASE == 1)  // C' * (A .* B) of the previous step (:155)
                 if (t - 1 > t0)

@@ -273,14 +273,16 @@ __device__ __forceinline__ float pair_stage_em(unsigned dst, unsigned rawsrc, in
     }
     E = wave_max_rl(E);
     if (!(E > MM_NINF)) E = 0.f;
+    bool tiny = false;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int q = lane + 64 * j;
         if (q <= P) ldsw(dst + 8u * q + 4u * u, LIN ? fast_exp2(v[j] - E - S) : v[j] - E);
         // (a finite emission whose factor is about to leave the float range: if a whole vector dies of it the utterance looks like
         // one without a path -- the mark tells mm_pair_finish_kernel not to believe that)
-        if (LIN && q <= P && v[j] - E - S < MM_LINF_EMIN && v[j] > MM_NINF) *mark = 1;
+        if (LIN) tiny = tiny || (q <= P && v[j] - E - S < MM_LINF_EMIN && v[j] > MM_NINF);
     }
+    if (LIN && tiny) *mark = 1;
     return E;
 }
 
@@ -332,16 +334,19 @@ __device__ __forceinline__ void pair_stage_em2(unsigned dst, unsigned raw0, unsi
     wave_max_rl2(e0, e1);
     if (!(e0 > MM_NINF)) e0 = 0.f;
     if (!(e1 > MM_NINF)) e1 = 0.f;
+    bool tiny0 = false, tiny1 = false;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int q = lane + 64 * j;
         if (q <= P) {
             const float x0 = v0[j] - e0 - S0, x1 = v1[j] - e1 - S1;
             ldsw2(dst + 8u * (unsigned)q, fast_exp2(x0), fast_exp2(x1));
-            if (x0 < MM_LINF_EMIN && v0[j] > MM_NINF) *mark0 = 1;
-            if (x1 < MM_LINF_EMIN && v1[j] > MM_NINF) *mark1 = 1;
+            tiny0 = tiny0 || (x0 < MM_LINF_EMIN && v0[j] > MM_NINF);
+            tiny1 = tiny1 || (x1 < MM_LINF_EMIN && v1[j] > MM_NINF);
         }
     }
+    if (tiny0) *mark0 = 1;
+    if (tiny1) *mark1 = 1;
     E[0] = e0;
     E[1] = e1;
 }
@@ -374,10 +379,10 @@ __device__ __forceinline__ void pair_stage_em_wide(unsigned dst, unsigned raw0, 
             }
         }
     }
-    e0 = wave_max_rl(e0);
-    e1 = wave_max_rl(e1);
+    wave_max_rl2(e0, e1);
     if (!(e0 > MM_NINF)) e0 = 0.f;
     if (!(e1 > MM_NINF)) e1 = 0.f;
+    bool tiny0 = false, tiny1 = false;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
 #pragma unroll
@@ -386,12 +391,14 @@ __device__ __forceinline__ void pair_stage_em_wide(unsigned dst, unsigned raw0, 
             if (q <= P) {
                 if constexpr (LIN) {
                     ldsw2(dst + 8u * (unsigned)q, fast_exp2(v0[j][i] - e0 - S0), fast_exp2(v1[j][i] - e1 - S1));
-                    if (v0[j][i] - e0 - S0 < MM_LINF_EMIN && v0[j][i] > MM_NINF) *mark0 = 1;
-                    if (v1[j][i] - e1 - S1 < MM_LINF_EMIN && v1[j][i] > MM_NINF) *mark1 = 1;
+                    tiny0 = tiny0 || (v0[j][i] - e0 - S0 < MM_LINF_EMIN && v0[j][i] > MM_NINF);
+                    tiny1 = tiny1 || (v1[j][i] - e1 - S1 < MM_LINF_EMIN && v1[j][i] > MM_NINF);
                 } else ldsw2(dst + 8u * (unsigned)q, v0[j][i] - e0, v1[j][i] - e1);
             }
         }
     }
+    if (LIN && tiny0) *mark0 = 1;
+    if (LIN && tiny1) *mark1 = 1;
     E[0] = e0;
     E[1] = e1;
 }
@@ -785,7 +792,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
     // Until then a finish went through log2: v_log_f32 of the sum, the normaliser and the emission added, v_exp_f32 back, and a
     // second v_exp_f32 for the combine -- 4 (phase A) / 6 (phase B) quarter-rate instructions per finish for the two utterances,
     // ~1100 of a SIMD's ~3000 busy cycles per phase-B step (SQ_INSTS_VALU, profiles/r05_pmc_lfmmi_den.json).
-    constexpr bool LINF = MM_PAIR_LINFIN != 0;
+    // (not the instances of more than 4 passes over the pdfs, 251 .. 506 pdfs: their service wave bounds the step, and 16 more
+    // exponentials per lane and step in it cost more than the compute waves save -- 2000 states / 400 pdfs: 4.65 against 3.62 ms)
+    constexpr bool LINF = MM_PAIR_LINFIN != 0 && NJ <= 4;
     constexpr int D = PHASE ? MM_PAIR_DB : MM_PAIR_DA;  // gather pairs in flight ahead of the FMAs
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, NWC = NW - (H > 1 ? 2 : 1);

@@ -110,14 +110,16 @@ __device__ __forceinline__ float wpair_stage_em(unsigned dst, unsigned rawsrc, i
     }
     E = wave_max_rl(E);
     if (!(E > MM_NINF)) E = 0.f;
+    bool tiny = false;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int q = lane + 64 * j;
         if (q <= P) {
             ldswu(dst + 8u * q + 4u * u, w_exp2_hi(v[j] - E - S));
-            if (v[j] - E - S < MM_WLINF_EMIN && v[j] > MM_NINF) *mark = 1;
+            tiny = tiny || (v[j] - E - S < MM_WLINF_EMIN && v[j] > MM_NINF);
         }
     }
+    if (tiny) *mark = 1;
     return E;
 }
 

@@ -785,6 +785,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
 #ifndef MM_PAIR_DB
 #define MM_PAIR_DB 3
 #endif
+#ifndef MM_PAIR_EXITS_B
+#define MM_PAIR_EXITS_B 1  // phase B leaves the arc window after the wave's last segment like phase A (until the finishes went linear: 8 spilled registers)
+#endif
     constexpr bool MM_PAIR_DOUBLE = true;
     // LINF: the finishes stay in the linear domain (round 5): the service wave stages the step's emissions as factors 2^(v - E - S),
     // a finish is p = s * factor (and, in phase B, q = s * partner), BOTH directions store p -- the vector with the frame's emission --
@@ -890,7 +893,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
     unsigned em_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)endmask);
     unsigned em_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(endmask >> 32));
     // the wave's last pair of arcs (phase B runs the whole window: the exits cost it 8 spilled VGPRs)
-    const int lastp = PHASE ? 63 : (em_hi ? 63 - __builtin_clz(em_hi) : (em_lo ? 31 - __builtin_clz(em_lo) : -1));
+    const int lastp = (PHASE && !(MM_PAIR_EXITS_B && NJ <= 4)) ? 63 : (em_hi ? 63 - __builtin_clz(em_hi) : (em_lo ? 31 - __builtin_clz(em_lo) : -1));
     lgw0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(lgw0 >> 32)) << 32) |
            (unsigned)__builtin_amdgcn_readfirstlane((unsigned)lgw0);
     nslots = __builtin_amdgcn_readfirstlane(nslots);

@@ -307,13 +307,28 @@ __device__ __forceinline__ void wave_max_rl2(float &a, float &b) {
     b = fmaxf(fmaxf(b0, b1), fmaxf(b2, b3));
 }
 
+// the wave-wide maximum of max(a, b) with ONE scalar result (lane 63 after two row broadcasts; wave_max_rl2 takes eight scalar
+// registers for its readlanes, which the instances of the large teams do not have)
+__device__ __forceinline__ float wave_max_of2(float a, float b) {
+    float v = max_nc(a, b);
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+        : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // pair_stage_em<NJ, true> for BOTH utterances in one pass (up to 4 passes of 64 pdfs): all raw values are read before anything is
 // written -- called once per utterance, the second call's LDS reads wait behind the first call's LDS writes (the compiler cannot
 // tell them apart), and the service wave's own chain of round trips is what bounds a step since the finishes went linear --, the
 // two maxima share one DPP ladder, and a pdf's two factors leave in ONE 8-byte write.
-template <int NJ>
+// (ADAPT: X = minus the smallest finite log2 factor of the step; else a fixed bound, MM_LINF_EMIN, and marks for what is below it)
+template <int NJ, bool ADAPT>
 __device__ __forceinline__ void pair_stage_em2(unsigned dst, unsigned raw0, unsigned raw1, int n, int len0, int len1, int P, int lane, float S0,
-                                               float S1, int *mark0, int *mark1, float (&E)[2]) {
+                                               float S1, float (&E)[2], float &X, int *mark0, int *mark1) {
     float v0[NJ], v1[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -334,19 +349,24 @@ __device__ __forceinline__ void pair_stage_em2(unsigned dst, unsigned raw0, unsi
     wave_max_rl2(e0, e1);
     if (!(e0 > MM_NINF)) e0 = 0.f;
     if (!(e1 > MM_NINF)) e1 = 0.f;
-    bool tiny0 = false, tiny1 = false;
+    // X: minus the smallest finite log2 factor of the step (0 if there is none) -- how much of the float range the emissions take
+    float n0 = 0.f, n1 = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int q = lane + 64 * j;
         if (q <= P) {
             const float x0 = v0[j] - e0 - S0, x1 = v1[j] - e1 - S1;
             ldsw2(dst + 8u * (unsigned)q, fast_exp2(x0), fast_exp2(x1));
-            tiny0 = tiny0 || (x0 < MM_LINF_EMIN && v0[j] > MM_NINF);
-            tiny1 = tiny1 || (x1 < MM_LINF_EMIN && v1[j] > MM_NINF);
+            n0 = max_nc(n0, v0[j] > MM_NINF ? -x0 : 0.f);
+            n1 = max_nc(n1, v1[j] > MM_NINF ? -x1 : 0.f);
         }
     }
-    if (tiny0) *mark0 = 1;
-    if (tiny1) *mark1 = 1;
+    if constexpr (ADAPT) {
+        X = wave_max_of2(n0, n1);
+    } else {
+        if (n0 > -MM_LINF_EMIN) *mark0 = 1;
+        if (n1 > -MM_LINF_EMIN) *mark1 = 1;
+    }
     E[0] = e0;
     E[1] = e1;
 }
@@ -798,6 +818,10 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
     // (not the instances of more than 4 passes over the pdfs, 251 .. 506 pdfs: their service wave bounds the step, and 16 more
     // exponentials per lane and step in it cost more than the compute waves save -- 2000 states / 400 pdfs: 4.65 against 3.62 ms)
     constexpr bool LINF = MM_PAIR_LINFIN != 0 && NJ <= 4;
+    // The range check of the linear finishes: the smallest non-zero sum a step accepts.  ADAPT: from the step's emissions (the service
+    // wave posts it: stage()); the teams' instances, which have no register for anything more: a fixed split of the range, sums down to
+    // 2^-(thr + MM_LINF_EMIN), factors down to 2^MM_LINF_EMIN (smaller ones are marked by the service wave).
+    constexpr bool ADAPT = LINF && H == 1;
     constexpr int D = PHASE ? MM_PAIR_DB : MM_PAIR_DA;  // gather pairs in flight ahead of the FMAs
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, NWC = NW - (H > 1 ? 2 : 1);
@@ -831,9 +855,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
     const RowU r = uni(H > 1 ? ud.rps[DIR][hset] : ud.rp[DIR]);
     const int S1 = r.rows, S1p = p.pair_s1p, P1 = uni(ud.P1), P = P1 - 1, P1p = (P1 + 3) & ~3;
     const float thr = r.thr;
-    // (LINF) bits - 1 of the smallest sum a finish accepts: 2^-(thr + MM_LINF_EMIN), see the finishes
-    unsigned sthr;  // (a scalar register by force: as a vector register it was spilled in the phase-B instance of the wide kernels)
-    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(sthr) : "v"(((unsigned)(127 - (int)(thr + MM_LINF_EMIN < 1.f ? 1.f : thr + MM_LINF_EMIN)) << 23) - 1u));
+    unsigned sthr = 0u;  // (a scalar register by force)
+    if constexpr (LINF && !ADAPT)
+        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(sthr) : "v"(((unsigned)(127 - (int)(thr + MM_LINF_EMIN < 1.f ? 1.f : thr + MM_LINF_EMIN)) << 23) - 1u));
     // (Steering the frame maxima to 2^(thr - 20) instead of 2^0 -- to use the upper half of the float exponent range and keep
     // states up to ~190 log2 below the maximum on the linear path -- was tried and dropped: v_log_f32 returns log2 of sums
     // near 2^87 as floats 7.6e-6 apart, the per-frame normalisers of one utterance then scatter by 2e-4..7e-4 log2 instead of
@@ -931,6 +955,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         // hoisted out of the step loop -- with the 24 KB vectors of those kernels the hoisted LDS addresses did not fit the
         // registers, and every reload of a spilled one is a scratch load whose wait also waits for the LDS-DMAs in flight)
         int sl = lane;
+        float thr_v = thr;  // (a vector register: the instances of the large teams have no scalar register to keep it in across the steps)
+        asm volatile("" : "+v"(thr_v));
         RowNorm norm[2];
         double cum[2] = {0.0, 0.0};
         double zmin[2] = {__builtin_inf(), __builtin_inf()}, zmax[2] = {-__builtin_inf(), -__builtin_inf()};
@@ -972,7 +998,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         constexpr int NDMA_SMALL = 2 * NJ + (PHASE ? 1 + 2 : 0);     // ... of a small graph (see dma_partner)
         // stage the emissions of step t into EM(t & 1) and account its offsets; S = the normaliser the step subtracts
         auto stage = [&](int t, const float (&S)[2]) {
-            float E[2];
+            float E[2], X = 0.f;
 #ifndef MM_PAIR_WIDE_SERVICE
 #define MM_PAIR_WIDE_SERVICE 1
 #endif
@@ -980,8 +1006,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 pair_stage_em_wide<NJ, LINF>(L::EM(t & 1), L::RAW(0, 0) + L::RAWS * (unsigned)(t & 3), L::RAW(0, 1) + L::RAWS * (unsigned)(t & 3), frame_of(t),
                                              U[0].len, U[1].len, P, sl, E, S[0], S[1], redo0, redo1);
             } else if constexpr (LINF) {
-                pair_stage_em2<NJ>(L::EM(t & 1), L::RAW(0, 0) + L::RAWS * (unsigned)(t & 3), L::RAW(0, 1) + L::RAWS * (unsigned)(t & 3), frame_of(t), U[0].len,
-                                   U[1].len, P, sl, S[0], S[1], redo0, redo1, E);
+                pair_stage_em2<NJ, ADAPT>(L::EM(t & 1), L::RAW(0, 0) + L::RAWS * (unsigned)(t & 3), L::RAW(0, 1) + L::RAWS * (unsigned)(t & 3), frame_of(t),
+                                          U[0].len, U[1].len, P, sl, S[0], S[1], E, X, redo0, redo1);
             } else {
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
@@ -992,6 +1018,21 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
             for (int u = 0; u < 2; ++u) {
                 before[u] = cum[u];
                 cum[u] += (double)S[u] + (double)E[u];
+            }
+            if constexpr (ADAPT) {
+                // the smallest sum the step's finishes accept: with every non-zero s >= 2^-(thr - X) and every non-zero factor >=
+                // 2^-X, every non-zero p is >= 2^-thr and no product of the next step's sums leaves the float range.  Posted as
+                // the bits of that float - 1 (the finishes compare integers); emissions that leave the sums less than 2^-16 of
+                // room: marked here.
+                float room = thr_v - X;
+                if (room < 16.f) {
+                    room = 16.f;
+                    if (sl == 0) {
+                        *redo0 = 1;
+                        *redo1 = 1;
+                    }
+                }
+                if (sl == 0) ldswu(L::MS(t & 1), ((unsigned)(127 - (int)room) << 23) - 1u);
             }
             if (sl == 0) {
                 if constexpr (!LINF) ldsw2(L::MS(t & 1), S[0], S[1]);
@@ -1440,10 +1481,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                         // p = s * 2^(emission - E - S): the step's vector, forward (T' alpha) (*) lhs (src/inference.jl:70-71),
                         // backward B (*) lhs, the operand of the next product (:106-107).
                         // Range check, deferred to the end of the step: the smallest non-zero sum of the lane, as integers (a
-                        // non-negative float orders like its bits; bits - 1 sends the semiring's zero to the top).  With every
-                        // non-zero s >= 2^-(thr - 40) and every non-zero factor >= 2^-40 (the service wave marks smaller ones:
-                        // pair_stage_em) every non-zero p is >= 2^-thr, and no product of the next step's sums leaves the float
-                        // range.  An overflow ends as a NaN frame sum (mm_pair_finish_kernel).
+                        // non-negative float orders like its bits; bits - 1 sends the semiring's zero to the top), against the
+                        // step's threshold (the service wave's stage()).  An overflow ends as a NaN frame sum
+                        // (mm_pair_finish_kernel).
                         smin = min3_u32(smin, __builtin_bit_cast(unsigned, s0) - 1u, __builtin_bit_cast(unsigned, s1) - 1u);
                         mm_f32x2 sv = {s0, s1}, pv, qv;
                         asm("v_pk_mul_f32 %0, %1, %2" : "=v"(pv) : "v"(sv), "v"(e));
@@ -1504,7 +1544,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 MM_PAIR_CASES(MM_PAIR_TWO)
                 // out of the linear range somewhere: both utterances go to the exact kernels (the check does not tell
                 // them apart; it only costs time)
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(LINF ? smin < sthr : worst > thr) != 0ull, 0)) {
+                // (LINF: bits - 1 of the smallest sum the step's finishes accept, posted by the service wave -- read here, at the end:
+                // a register that lives across the arcs is one the instances of the large teams do not have)
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(LINF ? smin < (ADAPT ? ldsru(L::MS(WR)) : sthr) : worst > thr) != 0ull, 0)) {
                     *redo0 = 1;
                     *redo1 = 1;
                 }

@@ -97,6 +97,9 @@ __device__ __forceinline__ float w_log2_acc(const double &s) {
 #ifndef MM_WPAIR_LINFIN
 #define MM_WPAIR_LINFIN 1
 #endif
+#ifndef MM_WPAIR_EXITS_B
+#define MM_WPAIR_EXITS_B 0  // 1: phase B leaves the arc window after the last segment like pair_agent -- this compiler (ROCm 7.2) then fails ("illegal VGPR to SGPR copy")
+#endif
 #define MM_WLINF_EMIN (-500.f)  // log2 of the smallest emission factor of a step that raises no mark (wpair_stage_em)
 // pair_stage_em<NJ, LIN> for the wide kernels: the step's emission factors 2^(v - E - S) as wide values (high dwords)
 template <int NJ>
@@ -472,7 +475,7 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
     }
     unsigned em_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)endmask);
     unsigned em_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(endmask >> 32));
-    const int lastp = PHASE ? 63 : (em_hi ? 63 - __builtin_clz(em_hi) : (em_lo ? 31 - __builtin_clz(em_lo) : -1));
+    const int lastp = (PHASE && !MM_WPAIR_EXITS_B) ? 63 : (em_hi ? 63 - __builtin_clz(em_hi) : (em_lo ? 31 - __builtin_clz(em_lo) : -1));
     lgw0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(lgw0 >> 32)) << 32) |
            (unsigned)__builtin_amdgcn_readfirstlane((unsigned)lgw0);
     nslots = __builtin_amdgcn_readfirstlane(nslots);

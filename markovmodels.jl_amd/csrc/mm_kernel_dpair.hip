@@ -461,7 +461,9 @@ __device__ __forceinline__ void dpair_agent(const RunParams &p, int ui, int rdir
     const float thr = r.thr + MM_DPAIR_THR_EXTRA;
     // LINF (pair_agent): linear-domain finishes -- p = s * factor (the factor a double in LDS), q = s * partner (the partner's stored
     // value: the high dword of its double, 20 mantissa bits -- the 4 bytes per state of the stored rows as before)
-    constexpr bool LINF = MM_DPAIR_LINFIN != 0;
+    // (not the one-workgroup instances of more than 250 pdfs: their service wave bounds the step, 8 double exponentials more per lane
+    // in it cost more than the compute waves save -- 2000 states / 400 pdfs on sharp emissions: 6.96 against 6.41 ms)
+    constexpr bool LINF = MM_DPAIR_LINFIN != 0 && (NJ <= 4 || H > 1);
     unsigned sthr;  // bits - 1 of the high dword of the smallest sum a finish accepts: 2^-(thr + MM_DLINF_EMIN)
     asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(sthr) : "v"(((unsigned)(1023 - (int)(thr + MM_DLINF_EMIN < 1.f ? 1.f : thr + MM_DLINF_EMIN)) << 20) - 1u));
     int m = (int)(((long long)NFp * (p.split_q10 > 0 ? p.split_q10 : 512)) >> 10);

@@ -379,8 +379,10 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_ba
         // ================= service wave: emissions, normalisers, offsets =================
         RowNorm norm;
         double cum = 0.0;
-        // stage the emissions of step t (frame f) into EM(t & 1): log2 values relative to the frame's maximum E
-        auto stage = [&](int t, float S) {
+        // stage the emissions of step t (frame f) into EM(t & 1): log2 values relative to the frame's maximum E for the initial
+        // vector (lin = false); for the steps their linear factors 2^(v - E - S) as wide values -- a finish is then p = s * factor,
+        // one v_mul_f64, where it went through a logarithm and an exponential until round 5 (pair_agent, LINF)
+        auto stage = [&](int t, float S, bool lin) {
             const int f = frame_of(t);
             float v[NJ], E = MM_NINF;
 #pragma unroll
@@ -393,28 +395,36 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_ba
             }
             E = wave_max_rl(E);
             if (!(E > MM_NINF)) E = 0.f;
+            bool tiny = false;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int q = lane + 64 * j;
-                if (q <= P) ldsw(FIX + L::EM(t & 1) + 4u * q, v[j] - E);
+                if (q <= P) {
+                    if (lin) {
+                        ldswu(FIX + L::EM(t & 1) + 4u * q, w_exp2_hi(v[j] - E - S));
+                        tiny = tiny || (v[j] - E - S < MM_WLINF_EMIN && v[j] > MM_NINF);
+                    } else {
+                        ldsw(FIX + L::EM(t & 1) + 4u * q, v[j] - E);
+                    }
+                }
             }
+            if (tiny) p.redo[b] = 1;
+            const double before = cum;
             cum += (double)S + (double)E;
-            if (lane == 0) {
-                ldsw(FIX + L::MS(t & 1), S);
-                // the offset that turns the step's stored vector into log2 values: alpha~ includes the frame's emission, beta~ not
-                offs[f] = DIR ? cum - (double)E : cum;
-            }
+            // the offset that turns the step's stored vector into log2 values: forward, p = s * factor, normaliser and emission
+            // included; backward, the sum s itself -- beta~ without the frame's emission -- before either
+            if (lane == 0) offs[f] = DIR ? before : cum;
         };
-        if (DIR == 0) stage(1, 0.f);  // step 1: alpha_hat (*) lhs[:, 1] needs the emissions of frame 1 (nothing but E is subtracted)
+        if (DIR == 0) stage(1, 0.f, false);  // step 1: alpha_hat (*) lhs[:, 1] needs the emissions of frame 1 (nothing but E is subtracted)
         __syncthreads();  // (1)
-        if (2 <= NF) stage(2, 0.f);
+        if (2 <= NF) stage(2, 0.f, true);
         __syncthreads();  // (2) the starting vector is in LDS
         for (int t = 2; t <= NF; ++t) {
             // the normaliser of step t + 1 from the maximum of the vector of step t - 1 (complete since the last barrier)
             const unsigned mxa = FIX + L::MX((t - 1) & 1);
             const float mx = w_log2_hi(ldsru(mxa));
             if (lane == 0) ldswu(mxa, 0u);
-            if (t + 1 <= NF) stage(t + 1, norm.next(mx));
+            if (t + 1 <= NF) stage(t + 1, norm.next(mx), true);
             __syncthreads();
         }
     } else {
@@ -434,7 +444,7 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_ba
                 const unsigned hi = w_exp2_hi(v0);
                 vmax = vmax > hi ? vmax : hi;
                 ldswu(VB * 1u + 4u * (unsigned)i, hi);
-                rows_g[(long long)0 * S1p + (info >> 12)] = v0;
+                rows_g[(long long)0 * S1p + (info >> 12)] = __builtin_bit_cast(float, hi);  // (the stored vectors: wide values)
             }
         } else {  // B[:, N+1] = one at the final state   (src/inference.jl:104)
             if (tid == 0) {
@@ -464,10 +474,12 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_ba
             xop[j] = 0.0;
             asm volatile("" : "+v"(xop[j]));
         }
+        double eop = 0.0;  // ... and of a finish's emission factor
+        asm volatile("" : "+v"(eop));
+        unsigned smin = 0xffffffffu;
         for (int t = 2; t <= NF; ++t) {
             const unsigned rd = VB * (unsigned)((t - 1) & 1), wr = VB * (unsigned)(t & 1);
             const int f = frame_of(t);
-            const float S = ldsr(FIX + L::MS(t & 1));
             const unsigned emb = FIX + L::EM(t & 1);
             const gfptr rowf = (gfptr)(__UINTPTR_TYPE__)(rows + (long long)(f - 1) * S1p);
             // the segment the wave is in
@@ -489,15 +501,20 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_ba
                 const bool mine = s_lg ? lane == 0 : (unsigned)lane < s_n;
                 const unsigned posi = s_p0 + (s_lg ? 0u : (unsigned)lane);
                 // forward: (T' alpha) (*) lhs (src/inference.jl:70-71); backward: T (B (*) lhs) (:106-107), the emission is
-                // added for the next step's product only
-                const float bb = w_log2_acc(s0) - S;
-                const float y = bb + ldsr(emb + 4u * (info & 0xfffu));
+                // multiplied in for the next step's product only
+                mm_u32x2 eo = __builtin_bit_cast(mm_u32x2, eop);
+                eo.y = ldsru(emb + 4u * (info & 0xfffu));
+                eop = __builtin_bit_cast(double, eo);
+                double p0;
+                asm("v_mul_f64 %0, %1, %2" : "=v"(p0) : "v"(s0), "v"(eop));
                 if (mine) {
-                    worst = __builtin_fmaxf(worst, __builtin_fmaf(__builtin_fabsf(y), 0.f, __builtin_fabsf(y)));
-                    const unsigned hi = w_exp2_hi(y);
+                    // (range check, at the end of the launch: the smallest non-zero sum of the lane by its high dword -- pair_agent)
+                    const unsigned sh = __builtin_bit_cast(mm_u32x2, s0).y;
+                    smin = sh - 1u < smin ? sh - 1u : smin;
+                    const unsigned hi = __builtin_bit_cast(mm_u32x2, p0).y;
                     vmax = vmax > hi ? vmax : hi;
                     ldswu(wr + 4u * posi, hi);
-                    rowf[info >> 12] = DIR ? bb : y;  // the vector that is combined, in the pdf-major numbering
+                    rowf[info >> 12] = __builtin_bit_cast(float, DIR ? sh : hi);  // the vector that is combined, in the pdf-major numbering
                 }
                 acc = 0.0;
                 ++sg;
@@ -563,7 +580,9 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_ba
             }
             __syncthreads();
         }
-        if (__builtin_amdgcn_ballot_w64(worst > thr) != 0ull && lane == 0) p.redo[b] = 1;
+        // (sums down to 2^-(thr + MM_WLINF_EMIN), factors down to 2^MM_WLINF_EMIN: every non-zero value of a vector >= 2^-thr)
+        const unsigned sthr = ((unsigned)(1023 - (int)(thr + MM_WLINF_EMIN < 1.f ? 1.f : thr + MM_WLINF_EMIN)) << 20) - 1u;
+        if (__builtin_amdgcn_ballot_w64(worst > thr || smin < sthr) != 0ull && lane == 0) p.redo[b] = 1;
     }
 }
 
@@ -589,7 +608,7 @@ static __global__ void __launch_bounds__(1024) mm_stream_combine_kernel(RunParam
     for (int f = f0; f < f0 + kStreamCombineFrames && f <= len; ++f) {
         const float *a = ra + (long long)(f - 1) * S1p, *bt = rb + (long long)(f - 1) * S1p;
         double s = 0.0;
-        for (int q = q0; q < q1; ++q) s += dexp2(a[q] + bt[q]);
+        for (int q = q0; q < q1; ++q) s += w_from_hi(__builtin_bit_cast(unsigned, a[q])) * w_from_hi(__builtin_bit_cast(unsigned, bt[q]));
         double t = dwave_sum_rl(s);
         __syncthreads();
         if (lane == 0) part[wave] = t;
@@ -624,6 +643,7 @@ static __global__ void __launch_bounds__(256) mm_stream_finish_kernel(RunParams 
         const double z = zf[2 * f], l = zf[2 * f + 1];
         zmin = z < zmin ? z : zmin;
         zmax = z > zmax ? z : zmax;
+        if (!(z == z)) zmax = __builtin_inf();  // (an overflow somewhere: inf * 0)
         lmin = l < lmin ? l : lmin;
     }
     for (int off = 32; off >= 1; off >>= 1) {
@@ -650,6 +670,7 @@ static __global__ void __launch_bounds__(256) mm_stream_finish_kernel(RunParams 
         p.pair_zmin[6 * b + 4] = p.pair_zmin[6 * b + 5] = lmin;
         const bool agree = zmin > -__builtin_inf() && zmax < __builtin_inf() && zmax - zmin <= MM_Z_SPREAD_TOL;
         if (p.redo[b] == 1 && agree && lmin >= (double)p.lt_floor - (double)MM_DPAIR_THR_EXTRA) p.redo[b] = 0;
+        if (p.redo[b] == 0 && len >= 1 && !(zmax < __builtin_inf())) p.redo[b] = 1;  // (the linear finishes raise no mark on an overflow)
     }
     const long long gbase = (long long)b * p.gsb;
     for (long long q = tid; q < (long long)(p.N - len) * P; q += 256)

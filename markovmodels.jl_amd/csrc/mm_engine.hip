@@ -888,6 +888,7 @@ static void split_pack_opts(const DebugOpts &dbg, RowPackOpts &opt, RowPackOpts 
     opt.ka_max = mm_split_ka(H);
     opt.nwc_max = MM_SPLIT_NWC;
     opt.pair = true;
+    opt.pdf_halves = getenv("MM_NO_PDF_HALVES") == nullptr;
     for (float &x : opt.group_speed) x = 1.f;
     if (dbg.finish_cost > 0) opt.finish_cost = dbg.finish_cost;
     opt.ka_choices[0] = mm_split_ka(H);
@@ -912,6 +913,7 @@ static int pair_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
     opt.rs = MM_ROW_RS;
     opt.ka_max = MM_PAIR_KA;
     opt.pair = true;
+    opt.pdf_halves = getenv("MM_NO_PDF_HALVES") == nullptr;
     for (float &x : opt.group_speed) x = 1.f;  // (the waves of a SIMD progress together: mm_rows.h)
     if (dbg.finish_cost > 0) opt.finish_cost = dbg.finish_cost;
     if (dbg.group_speed[0] > 0)
@@ -1469,6 +1471,7 @@ int mm_debug_row_product_ex(mm_fsm_t f, int direction, int flags, const float *i
     opt.ka_max = kRowKA[sizeof(kRowKA) / sizeof(kRowKA[0]) - 1];
     if (flags & 1) {  // the pair form as pair_variants() builds it
         opt.pair = true;
+    opt.pdf_halves = getenv("MM_NO_PDF_HALVES") == nullptr;
         opt.ka_max = MM_PAIR_KA;
         opt.ka_choices[0] = MM_PAIR_KA;
         for (float &x : opt.group_speed) x = 1.f;

@@ -153,6 +153,68 @@ Plan plan_for(const std::vector<int32_t> &rows, const std::vector<int64_t> &rowp
             p.segs.push_back(std::move(s));
         }
     }
+    // Pair forms: a finish reads the emission factor of its row, 8 bytes at 8 * pdf -- bank pair pdf mod 32, served per half-wave; two
+    // rows of one half with different pdfs in one bank pair cost an LDS cycle more.  The rows of a segment are interchangeable
+    // (same lane group, same slots): the pdfs of a bank pair are dealt to the two halves in turn (rows of ONE pdf stay together:
+    // a broadcast), as far as the halves' capacities go.
+    if (opt.pdf_halves && row2pdf) {
+        long long before = 0, after = 0;
+        auto half_cost = [&](const Segment &sg) {
+            long long c = 0;
+            const int per_half = 32 / std::min(sg.g, 32);
+            for (int h = 0; h < 2 && sg.g <= 32; ++h) {
+                int distinct[32] = {0};
+                std::vector<int32_t> seen;
+                for (int j = h * per_half; j < std::min<int>((h + 1) * per_half, int(sg.rows.size())); ++j) {
+                    const int32_t pd = (*row2pdf)[size_t(sg.rows[size_t(j)])];
+                    if (std::find(seen.begin(), seen.end(), pd) == seen.end()) {
+                        seen.push_back(pd);
+                        ++distinct[pd & 31];
+                    }
+                }
+                int m = 1;
+                for (int d : distinct) m = std::max(m, d);
+                c += m - 1;
+            }
+            return c;
+        };
+        for (auto &sg : p.segs) {
+            if (sg.g > 16 || sg.rows.size() < 3) continue;
+            before += half_cost(sg);
+            const int per_half = 32 / sg.g, n = int(sg.rows.size());
+            const int cap0 = std::min(per_half, n), cap1 = n - cap0;
+            if (cap1 <= 0) continue;
+            // groups of rows by pdf, the pdfs ordered by bank pair
+            std::vector<int32_t> rows = sg.rows;
+            std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) {
+                const int32_t pa = (*row2pdf)[size_t(a)], pb = (*row2pdf)[size_t(b)];
+                return (pa & 31) != (pb & 31) ? (pa & 31) < (pb & 31) : pa < pb;
+            });
+            std::vector<int32_t> half[2];
+            int nb[2][32] = {{0}, {0}};
+            for (size_t i0 = 0; i0 < rows.size();) {
+                size_t i1 = i0;
+                const int32_t pd = (*row2pdf)[size_t(rows[i0])];
+                while (i1 < rows.size() && (*row2pdf)[size_t(rows[i1])] == pd) ++i1;
+                const int bk = pd & 31, free0 = cap0 - int(half[0].size()), free1 = cap1 - int(half[1].size());
+                int h = nb[0][bk] < nb[1][bk] ? 0 : (nb[1][bk] < nb[0][bk] ? 1 : (free0 >= free1 ? 0 : 1));
+                if ((h ? free1 : free0) <= 0) h = 1 - h;
+                for (size_t i = i0; i < i1; ++i) {
+                    if (int(half[h].size()) >= (h ? cap1 : cap0)) h = 1 - h;  // (the group is cut: both halves read the pdf)
+                    if (half[h].empty() || (*row2pdf)[size_t(half[h].back())] != pd) ++nb[h][bk];
+                    half[h].push_back(rows[i]);
+                }
+                i0 = i1;
+            }
+            std::vector<int32_t> out = half[0];
+            out.insert(out.end(), half[1].begin(), half[1].end());
+            Segment trial = sg;
+            trial.rows = out;
+            if (half_cost(trial) <= half_cost(sg)) sg.rows = std::move(out);
+            after += half_cost(sg);
+        }
+        if (getenv("MM_VERBOSE_PLAN")) fprintf(stderr, "[mm] pdf_halves: extra LDS cycles of the emission reads %lld -> %lld (%zu segments)\n", before, after, p.segs.size());
+    }
     const int nwc = std::max(1, std::min<int>(opt.nwc_max, int(p.segs.size())));
     auto cost = [&](const Segment &s) { return s.A + opt.finish_cost + opt.group_cost * log2i(s.g); };
     std::vector<int> idx(p.segs.size());

@@ -140,6 +140,9 @@ struct RowPackOpts {
     // slots, as far as that goes; the arcs of a half-wave segment then go to their slots by an exact edge colouring of the
     // (lane, bank) multigraph (Koenig: as many colours as the largest degree) instead of the greedy pass + local search.
     int bank_opt = 0;
+    // Pair forms: the rows of a segment are dealt to its two half-waves so that the emission factors a finish reads (8 bytes at
+    // 8 * pdf) meet in as few bank pairs as possible (plan_for)
+    bool pdf_halves = false;
     bool naive_stats = true;  // also model the arcs in CSR order (RowGraph::conflict_before: informational)
     bool q_positions = true;  // pdf-major positions of the rows (the kernels that sum the posteriors per pdf over contiguous ranges);
                               // false: the slot table's q field stays 0 (the wave kernel has its own pdf tables)

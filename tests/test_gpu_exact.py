@@ -336,3 +336,28 @@ def test_wide_pair_kernels_at_full_length(mm, wl, oracle, torch):
     assert np.allclose(ttl[sel], t_ref, rtol=1e-6, atol=1e-3)
     for b in range(B):
         assert np.allclose(gam[b, : lens[b]].sum(-1), 1.0, atol=2e-5) and (gam[b, lens[b]:] == 0).all()
+
+
+@pytest.mark.parametrize("which", ["config3", "wsj_den"])
+def test_medium_sharp_emissions_under_every_policy(mm, wl, oracle, torch, which):
+    """log-softmax of 2 .. 6 N(0,1): between the benchmark's inputs and a sharp acoustic model, where the float32 kernels' range check
+    (round 5: the smallest non-zero SUM of a step against a threshold the service wave derives from the step's emission factors --
+    the finishes are linear, src/inference.jl:70-71 as one multiplication) decides utterance by utterance.  Whatever it decides, and
+    whichever kernels run first, the result is the float64 oracle's; the float32-first call of the mildest input keeps every
+    utterance on the float32 kernels."""
+    g = wl.lfmmi_denominator(2000, 84, seed=0) if which == "config3" else wl.load_npz_graph(os.path.join(HERE, "golden", "den_fsm_wsj.npz"))
+    rng = np.random.default_rng(41)
+    B, N = 6, 160
+    lens = np.array([N, N, 97, N, 31, N], dtype=np.int32)
+    for sigma in (2.0, 3.0, 4.0, 6.0):
+        V = peaky(rng, (B, N, g.P), sigma)
+        g_ref, t_ref = oracle64(oracle, g, V, lens)
+        for policy in ("f32_first", "f64_first"):
+            bf = make_batch(mm, wl, g, B, {})
+            bf.set_exact_policy(policy)
+            gam, ttl = bf.pdfposteriors(V, lens)
+            assert bf.last_fallback_count() == 0
+            if policy == "f32_first" and sigma == 2.0 and which == "config3":
+                assert bf.last_redo_count() == 0 and "mm_fbp_kernel" in bf.kernels()
+            check_gamma(gam, g_ref, lens)
+            assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-3)

@@ -399,6 +399,8 @@ def main():
     assert os.environ.get("MM_BENCH_NOCHECK") or torch.isfinite(ttl).all(), "non-finite log-likelihoods"
     # utterances of the last call that the fast kernels handed to the exact ones (flag and redo): they were computed twice
     redo = bf.last_redo_count() if semiring == "log" else 0
+    # team kernels: how many of the launches' workgroups found their whole team on one XCD (warm-up + timed steps)
+    teams_xcd = bf.team_xcd_stats() if semiring == "log" else (0, 0)
 
     sharp = None
     if semiring == "log" and args.emissions == "randn" and not args.no_sharp and args.posterior_floor <= 0:
@@ -422,6 +424,7 @@ def main():
             "data": ("synthetic" if args.emissions == "randn" else f"synthetic ({args.emissions} emissions)")
                     + (f", posterior floor {args.posterior_floor:g}" if args.posterior_floor > 0 else ""),
             "redo_utterances": redo,
+            **({"teams_on_one_xcd": {"workgroups": teams_xcd[0], "of": teams_xcd[1], "share": teams_xcd[0] / teams_xcd[1]}} if teams_xcd[1] else {}),
             "config": {
                 "workload": f"{g.name}: S={g.S} states, {g.n_arcs} arcs, P={g.P} pdfs, T={N} frames, "
                             f"B={B} utterances/GPU, {semiring} semiring, shared graph"

@@ -258,6 +258,10 @@ int mm_batch_last_fallback_count(mm_batch_t batch, void *stream, int64_t *n);
  * beyond the float32 kernels -- a sharp acoustic model; mm_batch_last_redo_count then reports the whole batch), else 0.
  * No synchronisation.  Observability only: results are the same either way. */
 int mm_batch_last_exact_first(mm_batch_t batch);
+/* Team kernels (graphs beyond one compute unit): out[0] = workgroups of the float32 team kernels' phase-A launches, since the last
+ * call of this function, that found their whole team on ONE XCD (they exchange rows by plain stores through that XCD's L2; the
+ * others by write-through stores), out[1] = all such workgroups.  Synchronises the device; a measurement aid (bench.py). */
+int mm_batch_team_xcd_stats(mm_batch_t batch, int out[2]);
 
 /* Which linear-domain kernels a shared-graph batch starts with (the batches of the pair / split pair kernels; others ignore it).
  *   MM_EXACT_AUTO (default)  float32 first; float64 first while the last FINISHED call left utterances marked and that costs

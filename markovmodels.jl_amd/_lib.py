@@ -38,6 +38,7 @@ SYMBOLS = [
     "mm_batch_last_redo_count",
     "mm_batch_last_fallback_count",
     "mm_batch_last_exact_first",
+    "mm_batch_team_xcd_stats",
     "mm_batch_set_exact_policy",
     "mm_spmv",
     "mm_spmm",
@@ -120,6 +121,8 @@ def _load():
     lib.mm_batch_last_fallback_count.argtypes = [vp, vp, C.POINTER(i64)]
     lib.mm_batch_last_exact_first.restype = C.c_int
     lib.mm_batch_last_exact_first.argtypes = [vp]
+    lib.mm_batch_team_xcd_stats.restype = C.c_int
+    lib.mm_batch_team_xcd_stats.argtypes = [vp, vp]
     lib.mm_batch_set_exact_policy.restype = C.c_int
     lib.mm_batch_set_exact_policy.argtypes = [vp, C.c_int]
     lib.mm_spmv.restype = C.c_int

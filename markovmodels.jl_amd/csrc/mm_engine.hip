@@ -273,7 +273,7 @@ struct mm_batch_s {
     bool stream_ok = false;             // every FSM has a stream form and nothing faster takes the batch (mm_stream.hip)
     bool wpair_ok = false;              // a whole batch on the exact kernels fits the wide pair kernels (mm_kernel_wpair.hip: two utterances per workgroup)
     bool quad_built = false;            // the FSMs' quad forms exist (not built for batches whose exact path is the float64 kernels)
-    int *stat_dev = nullptr;            // {count, ticket}
+    int *stat_dev = nullptr;            // {count, ticket, team workgroups whose team sits on ONE XCD, team workgroups} (the last two: mm_batch_team_xcd_stats)
     volatile int *stat_host = nullptr;  // pinned: {count of hard utterances, sequence number of the call that counted}
     int stat_seq = 0;
     int exact_first = -1;               // MM_EXACT_FIRST (under MM_DEBUG): 0 / 1 force the choice, -1: by the statistics
@@ -2098,7 +2098,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     }
     if (want_dpair) {
         void *hp = nullptr;
-        if (hipMalloc(&h->stat_dev, 2 * sizeof(int)) == hipSuccess && hipMemset(h->stat_dev, 0, 2 * sizeof(int)) == hipSuccess &&
+        if (hipMalloc(&h->stat_dev, 4 * sizeof(int)) == hipSuccess && hipMemset(h->stat_dev, 0, 4 * sizeof(int)) == hipSuccess &&
             hipHostMalloc(&hp, 2 * sizeof(int), hipHostMallocMapped) == hipSuccess) {
             h->stat_host = static_cast<volatile int *>(hp);
             h->stat_host[0] = 0;
@@ -2240,6 +2240,19 @@ int mm_batch_last_fallback_count(mm_batch_t h, void *stream, int64_t *n) {
 }
 
 int mm_batch_last_exact_first(mm_batch_t h) { return h && h->last_exact_first ? 1 : 0; }
+
+int mm_batch_team_xcd_stats(mm_batch_t h, int out[2]) {
+    if (!h || !out) return fail(MM_ERR_INVALID, "mm_batch_team_xcd_stats: bad argument");
+    out[0] = out[1] = 0;
+    if (!h->stat_dev) return MM_OK;
+    return no_throw("mm_batch_team_xcd_stats", [&]() {
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out, h->stat_dev + 2, 2 * sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(h->stat_dev + 2, 0, 2 * sizeof(int)));
+        return int(MM_OK);
+    });
+}
 
 int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
     if (!h || !buf || n < 2) return fail(MM_ERR_INVALID, "mm_batch_kernels: bad argument");

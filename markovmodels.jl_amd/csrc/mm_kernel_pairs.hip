@@ -1261,6 +1261,12 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 *redo1 = 2;
             }
             if (lane == 0) ldswu(L::XFLAG, (same && !dead && !(p.x_sleep & 0x800)) ? 1u : 0u);
+            // (how often the hardware's placement puts a whole team on one XCD: counted per workgroup of the phase-A launch,
+            // read and cleared by mm_batch_team_xcd_stats -- bench.py prints it for the team workloads)
+            if (PHASE == 0 && lane == 0 && p.stat_dev) {
+                atomicAdd(&p.stat_dev[3], 1);
+                if (same && !dead) atomicAdd(&p.stat_dev[2], 1);
+            }
         }
         __syncthreads();  // (2)
         constexpr int NG2 = (RSH / 16 + 63) / 64;

@@ -429,6 +429,13 @@ class BatchedFSM:
         float64 exact kernels then run the whole batch at once)."""
         return bool(lib.mm_batch_last_exact_first(self._h))
 
+    def team_xcd_stats(self):
+        """(workgroups of the team kernels' launches since the last call of this method whose whole team sat on ONE XCD, all
+        such workgroups): how the hardware placed the teams (a measurement aid; synchronises the device)."""
+        out = np.zeros(2, dtype=np.int32)
+        check(lib.mm_batch_team_xcd_stats(self._h, out.ctypes.data))
+        return int(out[0]), int(out[1])
+
     def kernels(self, semiring: str = "log") -> str:
         """The kernels the engine launches for this batch (informational)."""
         import ctypes

@@ -619,3 +619,24 @@ def test_stream_kernels(mm, wl, oracle, torch, case):
     assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()
     g2, t2 = bf.pdfposteriors(V, lens)  # (float64 atomics in the per-pdf sums: the last bits may differ between runs, not more)
     assert np.allclose(g2, gam, rtol=1e-5, atol=1e-7) and np.allclose(t2[ok], ttl[ok], rtol=1e-6)
+
+
+def test_team_xcd_counter(mm, wl, torch):
+    """mm_batch_team_xcd_stats: every workgroup of the team kernels' phase-A launch reports whether its whole team sits on one XCD
+    (the plain-store exchange) -- counted since the last read, cleared by the read; no teams, no counts."""
+    g = wsj_den(wl)
+    B, N = 6, 40
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(*([cf] * B))
+    V = torch.randn(B, N, g.P, device="cuda")
+    assert bf.team_xcd_stats() == (0, 0)
+    for _ in range(3):
+        bf.pdfposteriors(V, None)
+    assert "mm_fbs_kernel" in bf.kernels()
+    same, total = bf.team_xcd_stats()
+    assert total == 3 * 2 * 2 * ((B + 1) // 2) and 0 <= same <= total  # calls x directions x workgroups of a team x pairs
+    assert bf.team_xcd_stats() == (0, 0)
+    g3 = wl.lfmmi_denominator(2000, 84, seed=0)
+    b3 = mm.batch(*([mm.compile(wl.to_fsm(mm, g3), mm.statemap(g3.state2pdf, g3.P))] * 4))
+    b3.pdfposteriors(torch.randn(4, 30, g3.P, device="cuda"), None)
+    assert b3.team_xcd_stats() == (0, 0)

@@ -2443,6 +2443,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     p.split_q10 = h->dbg.split_q10 > 0 ? h->dbg.split_q10 : (h->pair_H == 1 ? MM_PAIR_SPLIT_Q10 : 512);
     p.x_timeout = std::min<unsigned long long>(10000000ull, std::max<unsigned long long>(200000ull, 1000ull * (unsigned long long)N));
     p.lt_floor = h->lt_floor;
+    p.clear_marks = getenv("MM_NEVER_CLEAR") ? 0 : 1;
     p.ws_alpha = static_cast<float *>(h->ws);
     p.ws_c = reinterpret_cast<double *>(static_cast<char *>(h->ws) + ws_alpha_bytes(h, N));
     p.gamma = gamma;

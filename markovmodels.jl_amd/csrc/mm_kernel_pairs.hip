@@ -1756,9 +1756,15 @@ static __global__ void mm_pair_finish_kernel(RunParams p) {
         p.ttl[b] = (z < __builtin_inf()) ? (float)(z * (double)MM_LN2) : MM_NINF;  // (no frame: no path of length 0)
         int mark = p.redo[b];
         const bool sound = z > -__builtin_inf() && zM < __builtin_inf() && zM - z <= MM_Z_SPREAD_TOL && lm >= (double)p.lt_floor;
-        if (mark == 1 && sound) p.redo[b] = mark = 0;
+        if (mark == 1 && sound && p.clear_marks) p.redo[b] = mark = 0;
         // MM_PAIR_LINFIN: an overflow raises no mark in the kernels; it ends as a frame sum that is not a number (zM = inf)
         if (MM_PAIR_LINFIN && mark == 0 && len >= 1 && !(zM < __builtin_inf())) p.redo[b] = mark = 1;
+        // The second condition holds for UNMARKED utterances too (round 5): a range mark says that a value of a VECTOR may have been
+        // flushed; the product of the combine, 2^(a~ + b~), is flushed below 2^-126 whatever the vectors' ranges -- no mark -- and what
+        // it was worth is bounded by the same overlap term.  (Until then an unmarked utterance whose forward and backward mass
+        // overlapped at 2^-50 could lose a posterior of 1e-28: found by tools/fuzz_round3.py, SEED=1.)  All frames without mass: an
+        // utterance without a path, Z = 0 like the reference's.
+        if (mark == 0 && len >= 1 && !(z == -__builtin_inf() && zM == -__builtin_inf()) && !(lm >= (double)p.lt_floor)) p.redo[b] = mark = 1;
         if (p.stat_mode == 0) report_hard(p, mark != 0);
     }
     const long long gbase = (long long)b * p.gsb;

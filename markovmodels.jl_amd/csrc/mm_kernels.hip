@@ -142,6 +142,7 @@ struct RunParams {
     // stat_mode 0: mm_pair_finish_kernel (utterances still marked after its decision), 1: mm_dpair_finish_kernel on a call
     // that skipped the float32 kernels (utterances whose smallest overlap term is below the float32 kernels' floor).
     int *stat_dev;
+    int clear_marks;  // mm_pair_finish_kernel: 1 = a range mark is cleared when the two criteria hold; 0 = it stays (see there)
     volatile int *stat_host;
     int stat_seq, stat_mode;
     // Pair kernels (mm_kernel_pairs.hip): ws_alpha holds [B + 1][N + 2][pair_s1p] state vectors, ws_c [B + 1][N + 2]

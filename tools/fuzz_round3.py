@@ -88,6 +88,39 @@ def fuzz_split(rng):
             if not ok:
                 bad += 1
                 print(f"MISMATCH split graph {gi} B {B} N {N} lens {lens.tolist()[:12]} ({names[:50]}): ttl {et:.2e} gamma {eg:.2e}")
+                if os.environ.get("FUZZ_VERBOSE"):  # where, and how large the reference's value is there
+                    m = ref_g > float(os.environ.get("FUZZ_ABOVE", 1e-30))
+                    rel = np.zeros_like(ref_g)
+                    rel[m] = np.abs(np.log(np.maximum(a_g[m], 1e-300)) - np.log(ref_g[m])) / np.maximum(np.abs(np.log(ref_g[m])), 1)
+                    idx = np.unravel_index(np.argmax(rel), rel.shape)
+                    print(f"   worst relative log error {rel[idx]:.3e} at {idx}: reference {ref_g[idx]:.6e}, computed {a_g[idx]:.6e}; redo {bf.last_redo_count()}, "
+                          f"fallback {bf.last_fallback_count()}, abs max {np.abs(a_g - ref_g).max():.3e}")
+                    b0, n0, p0 = (int(x) for x in idx)
+                    print(f"   utterance {b0}: length {int(lens[b0])}, frame {n0}, pdf {p0}; the reference's frame sums to {ref_g[b0, n0].sum():.9f}")
+                    # the states of the pdf: log2 alpha / beta (item kernel, log domain) relative to the frame's maxima, and their products
+                    set_kernel("item")
+                    b1 = mm.batch(cf)
+                    Vs, ls = V[[b0]].contiguous(), lt[[b0]].contiguous()
+                    A = b1.alpharecursion(Vs, ls).cpu().numpy().astype(np.float64) / np.log(2.0)
+                    Bt = b1.betarecursion(Vs, ls).cpu().numpy().astype(np.float64) / np.log(2.0)
+                    fr = n0  # column of frame n0 + 1 in the (S+1) x (N+1) matrices
+                    a, bb = A[:g.S, fr], Bt[:g.S, fr]
+                    st = np.nonzero(np.asarray(g.state2pdf) == p0)[0]
+                    fin = np.isfinite(a + bb)
+                    print(f"   frame maxima: log2 alpha {a[np.isfinite(a)].max():.1f}, log2 beta {bb[np.isfinite(bb)].max():.1f}, log2 sum alpha*beta "
+                          f"{np.log2(np.exp2((a + bb)[fin] - (a + bb)[fin].max()).sum()) + (a + bb)[fin].max():.1f}")
+                    for sidx in st:
+                        print(f"   state {sidx}: log2 alpha - max {a[sidx] - a[np.isfinite(a)].max():.1f}, log2 beta - max {bb[sidx] - bb[np.isfinite(bb)].max():.1f}")
+                    for pol in ("f32_first", "f64_first"):  # the utterance alone, and with its neighbour
+                        for sel in ([b0], [b0, (b0 + 1) % B]):
+                            set_kernel(None)
+                            os.environ["MM_VERBOSE"] = "1"
+                            b2 = mm.batch(*([cf] * len(sel)))
+                            os.environ.pop("MM_VERBOSE")
+                            b2.set_exact_policy(pol)
+                            g2, t2 = b2.pdfposteriors(V[sel].contiguous(), lt[sel].contiguous())
+                            g2 = g2.cpu().numpy()
+                            print(f"   {pol} batch {sel}: computed {g2[0, n0, p0]:.6e}, redo {b2.last_redo_count()}, fallback {b2.last_fallback_count()}, {b2.kernels()[:40]}")
     return n, bad
 
 

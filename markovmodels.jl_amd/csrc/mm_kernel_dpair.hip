@@ -1029,6 +1029,9 @@ static __global__ void mm_dpair_finish_kernel(RunParams p) {
         if (p.redo2[b] == 1 && agree && lm >= (double)p.lt_floor - (double)MM_DPAIR_THR_EXTRA) p.redo2[b] = 0;
         // (the wide kernels' linear finishes raise no mark on an overflow: it ends as a frame sum that is not a number, zM = inf)
         if (p.redo2[b] == 0 && len >= 1 && !(zM < __builtin_inf())) p.redo2[b] = 1;
+        // (... and the overlap condition holds for unmarked utterances too: a product of the combine below 2^-1022 is flushed without
+        // a mark -- mm_pair_finish_kernel; all frames without mass: an utterance without a path)
+        if (p.redo2[b] == 0 && len >= 1 && !(z == -__builtin_inf() && zM == -__builtin_inf()) && !(lm >= (double)p.lt_floor - (double)MM_DPAIR_THR_EXTRA)) p.redo2[b] = 1;
         // (a call that skipped the float32 kernels: would they have coped?  Not with an overlap term below their floor)
         if (p.stat_mode == 1) report_hard(p, !(lm >= (double)p.lt_floor));
     }

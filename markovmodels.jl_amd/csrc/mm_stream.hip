@@ -671,6 +671,8 @@ static __global__ void __launch_bounds__(256) mm_stream_finish_kernel(RunParams 
         const bool agree = zmin > -__builtin_inf() && zmax < __builtin_inf() && zmax - zmin <= MM_Z_SPREAD_TOL;
         if (p.redo[b] == 1 && agree && lmin >= (double)p.lt_floor - (double)MM_DPAIR_THR_EXTRA) p.redo[b] = 0;
         if (p.redo[b] == 0 && len >= 1 && !(zmax < __builtin_inf())) p.redo[b] = 1;  // (the linear finishes raise no mark on an overflow)
+        // (the overlap condition for unmarked utterances too: mm_pair_finish_kernel; all frames without mass: no path)
+        if (p.redo[b] == 0 && len >= 1 && !(zmin == -__builtin_inf() && zmax == -__builtin_inf()) && !(lmin >= (double)p.lt_floor - (double)MM_DPAIR_THR_EXTRA)) p.redo[b] = 1;
     }
     const long long gbase = (long long)b * p.gsb;
     for (long long q = tid; q < (long long)(p.N - len) * P; q += 256)

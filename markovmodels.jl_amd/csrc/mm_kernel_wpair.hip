@@ -126,6 +126,49 @@ __device__ __forceinline__ float wpair_stage_em(unsigned dst, unsigned rawsrc, i
     return E;
 }
 
+// ... for BOTH utterances in one pass (pair_stage_em2): all raw values are read before anything is written, the two maxima share one
+// DPP ladder, a pdf's two factors leave in ONE 8-byte write -- the service wave is what a step of phase B waits for in these kernels
+// (profiles/r05_stamps_wide.txt)
+template <int NJ>
+__device__ __forceinline__ void wpair_stage_em2(unsigned dst, unsigned raw0, unsigned raw1, int n, int len0, int len1, int P, int lane, float S0,
+                                                float S1, int *mark0, int *mark1, float (&E)[2]) {
+    float v0[NJ], v1[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        v0[j] = ldsr(raw0 + 256u * j + 4u * lane);
+        v1[j] = ldsr(raw1 + 256u * j + 4u * lane);
+    }
+    float e0 = MM_NINF, e1 = MM_NINF;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = lane + 64 * j;
+        v0[j] = em_value(v0[j], n, len0, P, q);
+        v1[j] = em_value(v1[j], n, len1, P, q);
+        if (q < P) {
+            e0 = max_nc(e0, v0[j]);
+            e1 = max_nc(e1, v1[j]);
+        }
+    }
+    wave_max_rl2(e0, e1);
+    if (!(e0 > MM_NINF)) e0 = 0.f;
+    if (!(e1 > MM_NINF)) e1 = 0.f;
+    bool tiny0 = false, tiny1 = false;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = lane + 64 * j;
+        if (q <= P) {
+            const float x0 = v0[j] - e0 - S0, x1 = v1[j] - e1 - S1;
+            ldsw2u(dst + 8u * (unsigned)q, w_exp2_hi(x0), w_exp2_hi(x1));
+            tiny0 = tiny0 || (x0 < MM_WLINF_EMIN && v0[j] > MM_NINF);
+            tiny1 = tiny1 || (x1 < MM_WLINF_EMIN && v1[j] > MM_NINF);
+        }
+    }
+    if (tiny0) *mark0 = 1;
+    if (tiny1) *mark1 = 1;
+    E[0] = e0;
+    E[1] = e1;
+}
+
 // One arc for the two utterances: acc0 += w * x_0, acc1 += w * x_1 with xx = {high dword of x_0, high dword of x_1} as gathered.
 // `tmp`: two register pairs that live across the steps; only their high registers are written here, their low registers stay 0.
 // (The pair as it landed would do as utterance 1's operand without a move -- its low dword is then utterance 0's high dword: up to
@@ -215,20 +258,21 @@ __device__ __forceinline__ void wpair_two(const double (&wa)[KA], mm_u32x2 (&x)[
 
 // service wave: log2 of the maxima of both linear vectors (pairs of high dwords [pos][2]; n2 16-byte reads = 2 states each).
 // Non-negative doubles order like their high dwords.
-template <int NB>
+template <int NB, int BATCH = 4>
 __device__ __forceinline__ void wpair_scan_max(unsigned pbase, int n2, int lane, float &m0, float &m1) {
     typedef unsigned mm_u32x4 __attribute__((ext_vector_type(4)));
+    static_assert(NB % BATCH == 0, "batches of the scan");
     unsigned a = 0u, b = 0u;
 #pragma unroll
-    for (int j0 = 0; j0 < NB; j0 += 4) {
-        mm_u32x4 v[4];
+    for (int j0 = 0; j0 < NB; j0 += BATCH) {
+        mm_u32x4 v[BATCH];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < BATCH; ++j) {
             const int q = lane + 64 * (j0 + j);
             v[j] = *(__attribute__((address_space(3))) const mm_u32x4 *)(__UINTPTR_TYPE__)(pbase + 16u * (q < n2 ? q : n2 - 1));
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < BATCH; ++j) {
             const unsigned ma = v[j].x > v[j].z ? v[j].x : v[j].z, mb = v[j].y > v[j].w ? v[j].y : v[j].w;
             a = a > ma ? a : ma;
             b = b > mb ? b : mb;
@@ -522,10 +566,12 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
         constexpr int NDMA = 2 * NJ + (PHASE ? RSH / 1024 + 2 : 0);  // DMAs issued per step
         auto stage = [&](int t, const float (&S)[2]) {
             float E[2];
+            if constexpr (LINF) {
+                wpair_stage_em2<NJ>(L::EM(t & 1), L::RAW(0, 0) + L::RAWS * (unsigned)(t & 3), L::RAW(0, 1) + L::RAWS * (unsigned)(t & 3), frame_of(t), U[0].len,
+                                    U[1].len, P, sl, S[0], S[1], redo0, redo1, E);
+            } else {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if constexpr (LINF) E[u] = wpair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, u) + L::RAWS * (unsigned)(t & 3), u, frame_of(t), U[u].len, P, sl, S[u], u ? redo1 : redo0);
-                else E[u] = pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, u) + L::RAWS * (unsigned)(t & 3), u, frame_of(t), U[u].len, P, sl);
+                for (int u = 0; u < 2; ++u) E[u] = pair_stage_em<NJ>(L::EM(t & 1), L::RAW(0, u) + L::RAWS * (unsigned)(t & 3), u, frame_of(t), U[u].len, P, sl);
             }
             double before[2];
 #pragma unroll
@@ -611,7 +657,7 @@ __device__ __forceinline__ void wpair_agent(const RunParams &p, int pair, int rd
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
             MM_STAMP(2);
             float mx[2];
-            wpair_scan_max<(RS / 8 + 63) / 64>(L::PP(RD), (S1 + 2) >> 1, sl, mx[0], mx[1]);
+            wpair_scan_max<(RS / 8 + 63) / 64, ((RS / 8 + 63) / 64) % 8 == 0 ? 8 : 4>(L::PP(RD), (S1 + 2) >> 1, sl, mx[0], mx[1]);  // (8 reads in flight: pair_agent)
             MM_STAMP(3);
             if (t + 1 <= tEnd) {
                 const float S[2] = {norm[0].next(mx[0]), norm[1].next(mx[1])};

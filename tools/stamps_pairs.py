@@ -30,6 +30,9 @@ N = int(os.environ.get("N", 300))
 cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
 bf = mm.batch(*([cf] * B))
 V = torch.randn(B, N, g.P, device="cuda")
+if os.environ.get("SHARP"):  # log-softmax(10 N(0,1)) and the exact kernels first: the stamps of the wide pair kernels
+    V = torch.log_softmax(10.0 * V, dim=-1)
+    bf.set_exact_policy("f64_first")
 print(bf.kernels())
 bf.pdfposteriors(V)
 bf.pdfposteriors(V)

@@ -642,3 +642,28 @@ def test_team_xcd_counter(mm, wl, torch):
     b3 = mm.batch(*([mm.compile(wl.to_fsm(mm, g3), mm.statemap(g3.state2pdf, g3.P))] * 4))
     b3.pdfposteriors(torch.randn(4, 30, g3.P, device="cuda"), None)
     assert b3.team_xcd_stats() == (0, 0)
+
+
+def test_never_clear_keeps_every_range_mark(mm, wl, oracle, torch):
+    """MM_NEVER_CLEAR=1: a mark raised by a range check stays whatever the two criteria say -- the reference's WSJ denominator, whose
+    initial-context states decay out of the float range in every utterance (marked and cleared by default: redo 0), is then computed
+    by the exact kernels; the results are the float64 oracle's either way."""
+    g = wsj_den(wl)
+    rng = np.random.default_rng(29)
+    B, N = 6, 90
+    V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+    lens = np.array([90, 90, 71, 90, 84, 90], dtype=np.int32)
+
+    def run():
+        cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+        bf = mm.batch(*([cf] * B))
+        bf.set_exact_policy("f32_first")
+        gam, ttl = bf.pdfposteriors(V, lens)
+        return gam, ttl, bf.last_redo_count(), bf.last_fallback_count()
+
+    g_ref, t_ref = oracle64(oracle, g, V, lens)
+    for env, want in (({}, 0), ({"MM_NEVER_CLEAR": "1"}, B)):
+        gam, ttl, redo, fallback = _with_env(env, run)
+        assert redo == want and fallback == 0
+        check_gamma(gam, g_ref, lens)
+        assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)

@@ -32,7 +32,7 @@ import MarkovModels: compile, batch, pdfposteriors, αrecursion, βrecursion, to
 
 # what this module adds to the package's API
 export ROCCompiledFSM, ROCBatch, to_device, compile_many, bestpath, maxstateposteriors, pdfposteriors_generic, last_redo_count,
-       last_fallback_count, last_exact_first, reserve_ex!, set_deterministic!, set_posterior_floor!, set_exact_policy!, set_rccl,
+       last_fallback_count, last_exact_first, team_xcd_stats, reserve_ex!, set_deterministic!, set_posterior_floor!, set_exact_policy!, set_rccl,
        allreduce_logz, allgather_ttl, ROCSparseCSR, ROCSparseVec, elmul!, eldiv!, compiled_cache_clear!
 
 const LIB = get(ENV, "MARKOVMODELS_AMD_LIB", "libmarkovmodels_amd.so")
@@ -238,7 +238,7 @@ function pdfposteriors(fsm::FSM{K}, V̂s::Vector{<:ROCMatrix{T}}, Ĉs::Vector{<:
             ph = Array(V̂[P1, :, :])                             # (N+1) × B
             L = vec(sum(ph .== -Inf32, dims = 1))
             step_ok = all(all(ph[1:L[j], j] .== -Inf32) && all(ph[L[j]+1:end, j] .== 0f0) && L[j] <= N for j in 1:B)
-            tail_ok = step_ok && all(Array(mapreduce(x -> x == -Inf32, &, V̂[1:P, L[j]+1:N1, j]; init = true)) for j in 1:B if L[j] < N1)
+            tail_ok = step_ok && all(mapreduce(x -> x == -Inf32, &, V̂[1:P, L[j]+1:N1, j]; init = true) for j in 1:B if L[j] < N1)   # (a GPU reduction returns a host scalar)
             fast = step_ok && tail_ok
             lens = ROCArray(Int32.(L))
         end
@@ -383,6 +383,12 @@ function last_fallback_count(b::ROCBatch)
 end
 "true if the last `pdfposteriors` call skipped the float32 kernels (the inputs of the call before were hard)."
 last_exact_first(b::ROCBatch) = ccall((:mm_batch_last_exact_first, LIB), Cint, (Ptr{Cvoid},), b.handle) != 0
+"(workgroups of the team kernels' launches since the last call whose whole team sat on one XCD, all such workgroups): a measurement aid; synchronises the device."
+function team_xcd_stats(b::ROCBatch)
+    out = zeros(Cint, 2)
+    check(ccall((:mm_batch_team_xcd_stats, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}), b.handle, out))
+    Int(out[1]), Int(out[2])
+end
 "Size the generic entry's workspace (before capturing `pdfposteriors_generic` in a hipGraph)."
 reserve_ex!(b::ROCBatch, ::Type{T}, N1::Integer) where T =
     (check(ccall((:mm_batch_reserve_ex, LIB), Cint, (Ptr{Cvoid}, Cint, Int64), b.handle, sizeof(T), N1)); b)
@@ -521,8 +527,8 @@ set_deterministic!(b::ROCBatch, on::Bool = true) =
     set_posterior_floor!(b::ROCBatch, floor = 1f-30)
 
 Posteriors below `floor` may come out as 0 from the fast (linear-domain) kernels; the default keeps every posterior
-above 1e-30 and sends utterances with sharp emissions to the exact kernels (3-6x the time).  `1f-12` keeps them on the
-fast path (LF-MMI gradients do not see the difference).
+above 1e-30 and sends utterances with sharp emissions to the exact kernels (~1.4x the time since round 5; 3-6x before).
+`1f-12` keeps them on the fast path (LF-MMI gradients do not see the difference).
 """
 set_posterior_floor!(b::ROCBatch, floor::Real = 1f-30) =
     (check(ccall((:mm_batch_set_posterior_floor, LIB), Cint, (Ptr{Cvoid}, Cfloat), b.handle, Float32(floor))); b)

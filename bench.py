@@ -258,13 +258,18 @@ def reduce_over_ranks(dist, torch, rdev, elapsed, frames_local, kernel_ms, allre
     }
 
 
-def sharp_record(torch, bf, g, B, N, gamma, lens, abytes, rank):
-    """The same workload on the inputs a TRAINED acoustic model produces -- log-softmax of 10 x N(0,1): the forward and the
-    backward mass of a frame overlap ~160 log2 below their maxima, beyond float32's exponent range, so the float64 kernels do
-    the work (examples/test_cuda.jl:124-143 feeds network outputs).  Measured in this process AFTER the timed headline, with
-    the engine's own policy (mm_batch_set_exact_policy auto: the second call on such inputs skips the float32 kernels)."""
-    gen = torch.Generator(device="cuda").manual_seed(5000 + rank)
-    Vs = torch.log_softmax(10.0 * torch.randn(B, N, g.P, device="cuda", generator=gen), dim=-1)
+def sharp_record(torch, bf, g, B, N, gamma, lens, abytes, rank, Vs=None, label="log-softmax(10 x N(0,1))", workload=None, suffix="_peaky"):
+    """The same workload on the inputs a TRAINED acoustic model produces, measured in this process AFTER the timed headline with
+    the engine's own policy (mm_batch_set_exact_policy auto: the second call on hard inputs skips the float32 kernels).  Two
+    flavours (examples/test_cuda.jl:124-143 feeds network outputs):
+      "sharp"             log-softmax of 10 x N(0,1): sharp and INCONSISTENT with the graph (a random arg-max sequence is not a
+                          path) -- the forward and the backward mass of a frame overlap ~160 log2 below their maxima, beyond
+                          float32's exponent range: the wide-exponent kernels do the work;
+      "sharp_consistent"  log-softmax(10 x (onehot(pdf of a path sampled from the graph) + 0.3 N(0,1))): sharp ALONG a path, as a
+                          trained model's outputs are -- the two masses meet on the path."""
+    if Vs is None:
+        gen = torch.Generator(device="cuda").manual_seed(5000 + rank)
+        Vs = torch.log_softmax(10.0 * torch.randn(B, N, g.P, device="cuda", generator=gen), dim=-1)
     for _ in range(4):
         bf.pdfposteriors(Vs, lens, out=gamma)
         torch.cuda.synchronize()  # (the policy reads the last FINISHED call's marks)
@@ -279,20 +284,127 @@ def sharp_record(torch, bf, g, B, N, gamma, lens, abytes, rank):
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / K
     kms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    traffic, traffic_src = measured_traffic(workload + suffix, B, N) if workload else (None, None)
     return {
-        "emissions": "log-softmax(10 x N(0,1))",
+        "emissions": label,
         "steps": K,
         "ms_per_step": 1e3 * wall,
         "kernel_ms": kms,
         "value": float(lens.sum().item()) / wall,
         "unit": "frames/s",
         "frac": abytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "traffic_source": traffic_src,
         "redo_utterances": bf.last_redo_count(),
         "fallback_utterances": bf.last_fallback_count(),
         "exact_first": bool(bf.last_exact_first()),
         "kernels": bf.kernels("log"),
         "finite": bool(torch.isfinite(ttl).all().item()),
     }
+
+
+def lfmmi_step_main(args):
+    """`--workload lfmmi_step`: the caller's step (examples/test_cuda.jl:128-152) -- the reference's WSJ denominator x B + B WSJ
+    numerators (one compiled graph per utterance, as a training step brings them), `lfmmi_loss` forward + backward on device-resident
+    log-likelihoods -- next to its parts: the denominator call alone, the numerator call alone, the three assemblies of
+    gamma_den - gamma_num (lfmmi.py: fused / serial / concurrent) and the fused step replayed from ONE hipGraph."""
+    import torch
+
+    torch.cuda.set_device(0)
+    mm = ge.load_package()
+    wl = importlib.import_module(mm.__name__ + ".workloads")
+    lf = importlib.import_module(mm.__name__ + ".lfmmi")
+    den = wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "den_fsm_wsj.npz"))
+    num = wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "num_fsm_wsj.npz"))
+    N = args.frames or 700
+    B = args.batch or 128
+    P = den.P
+    cden = mm.compile(wl.to_fsm(mm, den), mm.statemap(den.state2pdf, P))
+    bden = mm.batch(*([cden] * B))
+    nf = wl.to_fsm(mm, num)
+    t0 = time.perf_counter()
+    cnums = mm.compile_many([nf] * B, mm.statemap(num.state2pdf, P))  # B handles: one graph per utterance
+    bnum = mm.batch(*cnums)
+    host_ms = 1e3 * (time.perf_counter() - t0)
+    if args.posterior_floor > 0:
+        bden.set_posterior_floor(args.posterior_floor)
+    bden.reserve(N)
+    bnum.reserve(N)
+    gen = torch.Generator(device="cuda").manual_seed(1000)
+    V = torch.randn(B, N, P, device="cuda", generator=gen)
+    if args.emissions != "randn":
+        V = torch.log_softmax(10.0 * V, dim=-1)
+    lens = torch.full((B,), N, device="cuda", dtype=torch.int32)
+    buf = torch.empty(B, N, P, device="cuda")
+    frames = B * N
+
+    def timed(fn, K=args.steps, W=args.warmup):
+        for _ in range(W):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        wall = 1e3 * (time.perf_counter() - t0) / K
+        return wall, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    Vg = V.clone().requires_grad_(True)
+
+    def full_step():
+        Vg.grad = None
+        loss, _, _ = mm.lfmmi_loss(Vg, bnum, bden, lens)
+        loss.backward()
+
+    den_ms = timed(lambda: bden.pdfposteriors(V, lens, out=buf))
+    num_ms = timed(lambda: bnum.pdfposteriors(V, lens, out=buf))
+    parts = {m: timed(lambda m=m: lf.posteriors_difference(V, bnum, bden, lens, m, out=buf)) for m in ("fused", "serial", "concurrent")}
+    step_ms = timed(full_step)
+    # the fused step from one hipGraph
+    bden.set_exact_policy("f32_first")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        lf.posteriors_difference(V, bnum, bden, lens, "fused", out=buf)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        lf.posteriors_difference(V, bnum, bden, lens, "fused", out=buf)
+    graph_ms = timed(graph.replay)
+    f32_ms = timed(lambda: lf.posteriors_difference(V, bnum, bden, lens, "fused", out=buf))  # (the same launches, eager)
+    bden.set_exact_policy("auto")
+    out = {
+        "metric": "lfmmi_step_frames_per_sec",
+        "value": frames / (step_ms[0] * 1e-3),
+        "unit": "frames/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": step_ms[0],
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic" if args.emissions == "randn" else f"synthetic ({args.emissions} emissions)",
+        "config": {"workload": f"lfmmi_step: WSJ denominator (S={den.S}, {den.n_arcs} arcs) x {B} + {B} WSJ numerators (S={num.S}, one compiled graph per "
+                               f"utterance), P={P}, T={N}, lfmmi_loss forward + backward (examples/test_cuda.jl:128-152)",
+                   "global_batch": B, "seq_len": N, "parallelism": "one GPU"},
+        # wall = host clock per call (launch-bound steps show here), kernel = HIP events around the call on its stream
+        "step": {"wall_ms": step_ms[0], "kernel_ms": step_ms[1], "what": "lfmmi_loss(mode='auto') forward + loss.backward()"},
+        "den_ms": {"wall_ms": den_ms[0], "kernel_ms": den_ms[1], "kernels": bden.kernels()},
+        "num_ms": {"wall_ms": num_ms[0], "kernel_ms": num_ms[1], "kernels": bnum.kernels()},
+        "difference_ms": {m: {"wall_ms": v[0], "kernel_ms": v[1]} for m, v in parts.items()},
+        "grad_ms": {"kernel_ms": step_ms[1] - parts["fused"][1], "what": "forward + backward minus the fused difference: the loss scalar and grad * grad_output"},
+        "hipgraph": {"replay_wall_ms": graph_ms[0], "replay_kernel_ms": graph_ms[1], "eager_wall_ms": f32_ms[0], "eager_kernel_ms": f32_ms[1],
+                     "what": "posteriors_difference(mode='fused'), exact policy f32_first, captured once and replayed"},
+        "ratio_step_to_den": step_ms[1] / den_ms[1],
+        "ratio_fused_difference_to_den": parts["fused"][1] / den_ms[1],
+        "redo_utterances": bden.last_redo_count(),
+        "host_ms_compile_and_batch_numerators": host_ms,
+    }
+    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -306,12 +418,16 @@ def main():
     ap.add_argument("--varlen", action="store_true", help="lengths U[N/2, N] instead of all N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sharp", action="store_true", help="skip the `sharp` sub-record (the same workload on sharp emissions, after the timed region)")
-    ap.add_argument("--emissions", default="randn", choices=["randn", "peaky", "peaky_offset"],
-                    help="randn: N(0,1) log-likelihoods (default); peaky: log-softmax of 10 x N(0,1) (a sharp acoustic model); "
-                         "peaky_offset: the same shifted by -300 nats (GMM-like scores)")
+    ap.add_argument("--emissions", default="randn", choices=["randn", "peaky", "peaky_offset", "consistent"],
+                    help="randn: N(0,1) log-likelihoods (default); peaky: log-softmax of sigma x N(0,1) (sharp, inconsistent with the graph); "
+                         "peaky_offset: the same shifted by -300 nats (GMM-like scores); consistent: log-softmax(sigma x (onehot(pdf of a "
+                         "path sampled from the graph) + 0.3 N(0,1))) (sharp along a path: a trained acoustic model)")
+    ap.add_argument("--sigma", type=float, default=10.0, help="sharpness of the peaky / consistent emissions")
     ap.add_argument("--posterior-floor", type=float, default=0.0,
                     help="mm_batch_set_posterior_floor (default: the library's 1e-30); 1e-12 keeps sharp emissions on the fast kernels")
     args = ap.parse_args()
+    if args.workload == "lfmmi_step":
+        return lfmmi_step_main(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)  # (does not return)
 
@@ -351,8 +467,10 @@ def main():
         bf.set_posterior_floor(args.posterior_floor)
     gen = torch.Generator(device="cuda").manual_seed(1000 + rank)
     V = torch.randn(B, N, g.P, device="cuda", generator=gen)
-    if args.emissions != "randn":
-        V = torch.log_softmax(10.0 * V, dim=-1) - (300.0 if args.emissions == "peaky_offset" else 0.0)
+    if args.emissions == "consistent":
+        V = torch.from_numpy(wl.path_consistent_emissions(g, B, N, args.sigma, seed=1000 + rank)).cuda()
+    elif args.emissions != "randn":
+        V = torch.log_softmax(args.sigma * V, dim=-1) - (300.0 if args.emissions == "peaky_offset" else 0.0)
     if args.varlen:
         lens = torch.randint(N // 2, N + 1, (B,), device="cuda", generator=gen, dtype=torch.int32)
     else:
@@ -402,9 +520,18 @@ def main():
     # team kernels: how many of the launches' workgroups found their whole team on one XCD (warm-up + timed steps)
     teams_xcd = bf.team_xcd_stats() if semiring == "log" else (0, 0)
 
-    sharp = None
+    sharp = sharp_consistent = None
     if semiring == "log" and args.emissions == "randn" and not args.no_sharp and args.posterior_floor <= 0:
-        sharp = sharp_record(torch, bf, g, B, N, gamma, lens, algorithmic_bytes(g, B, N, frames_local, semiring), rank)
+        ab = algorithmic_bytes(g, B, N, frames_local, semiring)
+        wname = None if (args.varlen or args.batch or args.frames) else args.workload
+        sharp = sharp_record(torch, bf, g, B, N, gamma, lens, ab, rank, workload=wname)
+        try:  # (left-to-right graphs have no accepting path of an arbitrary length to sample: no record for them)
+            Vc = torch.from_numpy(wl.path_consistent_emissions(g, B, N, 10.0, seed=7000 + rank)).cuda()
+        except ValueError:
+            Vc = None
+        if Vc is not None and not args.varlen:
+            sharp_consistent = sharp_record(torch, bf, g, B, N, gamma, lens, ab, rank, Vs=Vc, workload=wname, suffix="_consistent",
+                                            label="log-softmax(10 x (onehot(pdf of a sampled path) + 0.3 N(0,1)))")
     if rank == 0:
         abytes = algorithmic_bytes(g, B, N, frames_local, semiring)
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
@@ -421,7 +548,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": ("synthetic" if args.emissions == "randn" else f"synthetic ({args.emissions} emissions)")
+            "data": ("synthetic" if args.emissions == "randn" else f"synthetic ({args.emissions} emissions, sigma {args.sigma:g})")
                     + (f", posterior floor {args.posterior_floor:g}" if args.posterior_floor > 0 else ""),
             "redo_utterances": redo,
             **({"teams_on_one_xcd": {"workgroups": teams_xcd[0], "of": teams_xcd[1], "share": teams_xcd[0] / teams_xcd[1]}} if teams_xcd[1] else {}),
@@ -448,6 +575,8 @@ def main():
         }
         if sharp is not None:
             out["sharp"] = sharp
+        if sharp_consistent is not None:
+            out["sharp_consistent"] = sharp_consistent
         if per_rank is not None:
             # every rank's own numbers: kernel time per call (HIP events), the log Z all-reduce behind it, the barrier-bracketed wall
             out["per_rank"] = {

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 3 /* 2: mm_pdfposteriors_ex takes the rows of V_hat (P1); mm_batch_reserve_ex.  3: mm_spmv / mm_spmm / mm_svdv, mm_batch_set_exact_policy */
+#define MM_ABI_VERSION 4 /* 2: mm_pdfposteriors_ex takes the rows of V_hat (P1); mm_batch_reserve_ex.  3: mm_spmv / mm_spmm / mm_svdv, mm_batch_set_exact_policy.  4: mm_batch_set_mark_policy, mm_batch_set_gamma_mode */
 
 enum mm_status {
     MM_OK = 0,
@@ -277,6 +277,40 @@ int mm_batch_team_xcd_stats(mm_batch_t batch, int out[2]);
  * such switch (src/inference.jl:145-161: one algorithm for every input). */
 enum mm_exact_policy { MM_EXACT_AUTO = 0, MM_EXACT_F32_FIRST = 1, MM_EXACT_F64_FIRST = 2 };
 int mm_batch_set_exact_policy(mm_batch_t batch, int policy);
+
+/* What a RANGE MARK of the float32 linear-domain kernels means (the batches of the pair / split pair kernels; others ignore it).
+ * Those kernels mark an utterance when a value of a state vector left the range in which float32 products keep every term.
+ *   MM_MARKS_DECIDE (default)  the finish kernel clears the mark when two criteria say that nothing that matters was lost (the
+ *                              frames' log Z agree within 2e-4 log2; every term that can have been dropped is below the posterior
+ *                              floor): the reference's own benchmark graph marks every utterance after ~55 frames -- its
+ *                              initial-context states decay out of the float range -- and none of those marks carries mass.
+ *                              Contract: log gamma within 1e-4 relative for posteriors above ~1e-24, an ABSOLUTE error below
+ *                              ~1e-27 for smaller ones (a flushed value of a recursion takes its descendants along: a posterior
+ *                              of 8.5e-29 has been seen computed as 0 on a 5-frame utterance; DESIGN.md section 3,
+ *                              tests/test_gpu_exact.py::test_fuzzer_findings_pin_the_parity_contract).
+ *   MM_MARKS_KEEP              a range mark always stays: the exact kernels (float64 / wide-exponent values, 1022 log2 of range)
+ *                              compute every utterance whose float32 vectors left the range, whatever the criteria say.  The
+ *                              1e-4 relative bar on log gamma then holds down to 1e-30 like SURVEY section 8(d) states it; costs a
+ *                              second pass on inputs that raise marks (the reference's WSJ denominator: 2.03 instead of 1.76 ms;
+ *                              config 3 on the benchmark's inputs raises none: unchanged).
+ * Per batch, takes effect at the next call; the reference has no such switch (src/inference.jl:145-161: one algorithm, log
+ * domain, every input). */
+enum mm_mark_policy { MM_MARKS_DECIDE = 0, MM_MARKS_KEEP = 1 };
+int mm_batch_set_mark_policy(mm_batch_t batch, int policy);
+
+/* What mm_pdfposteriors_f32 does with the posteriors, for the caller's step right behind the path (examples/test_cuda.jl:140-152:
+ * the LF-MMI gradient gamma_den - gamma_num, formed by the reference in a separate broadcast over two B x P x N arrays):
+ *   accumulate = 0, scale = 1 (default)   gamma_out  = gamma, frames n >= len_b zeroed
+ *   accumulate = 0, scale = s             gamma_out  = s * gamma
+ *   accumulate = 1, scale = s             gamma_out += s * gamma (frames n >= len_b left as they are): the numerator call with
+ *                                         s = -1 on the buffer the denominator call has just written leaves the gradient there,
+ *                                         no third pass.  Every element receives exactly one float add per call (a no-return
+ *                                         atomic): the result does not depend on any order.
+ * Supported by batches of the wave kernel (every graph <= 1023 states and <= 4096 arc slots per direction, any batch: LF-MMI
+ * numerators; mm_batch_kernels says which kernel a batch runs); MM_ERR_UNSUPPORTED for the others (their float32 kernels may hand
+ * an utterance to the exact kernels, whose result must REPLACE the first: the caller subtracts in a pass of its own).  Per batch,
+ * takes effect at the next call. */
+int mm_batch_set_gamma_mode(mm_batch_t batch, int accumulate, float scale);
 
 /* ---- the reference's semiring linear algebra on caller-owned device arrays (src/linalg.jl) ------------------------------
  * Generic in K like the reference: semiring in {MM_LOG, MM_TROPICAL, MM_PROB}, val_bytes 4 (Float32) / 8 (Float64) for

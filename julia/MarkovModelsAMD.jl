@@ -32,13 +32,22 @@ import MarkovModels: compile, batch, pdfposteriors, αrecursion, βrecursion, to
 
 # what this module adds to the package's API
 export ROCCompiledFSM, ROCBatch, to_device, compile_many, bestpath, maxstateposteriors, pdfposteriors_generic, last_redo_count,
-       last_fallback_count, last_exact_first, team_xcd_stats, reserve_ex!, set_deterministic!, set_posterior_floor!, set_exact_policy!, set_rccl,
-       allreduce_logz, allgather_ttl, ROCSparseCSR, ROCSparseVec, elmul!, eldiv!, compiled_cache_clear!
+       last_fallback_count, last_exact_first, team_xcd_stats, reserve_ex!, set_deterministic!, set_posterior_floor!, set_exact_policy!,
+       set_mark_policy!, set_gamma_mode!, set_rccl, allreduce_logz, allgather_ttl, ROCSparseCSR, ROCSparseVec, elmul!, eldiv!,
+       compiled_cache_clear!, compiled_cache_limits!
 
 const LIB = get(ENV, "MARKOVMODELS_AMD_LIB", "libmarkovmodels_amd.so")
 
 const MM_LOG, MM_TROPICAL, MM_PROB = Cint(0), Cint(1), Cint(2)
 const MM_CSC = Cint(0)
+const MM_ABI_VERSION = 4      # include/markovmodels_amd.h: the version every ccall tuple of this file was written against
+
+# A library of another ABI version would be called with the wrong argument lists: refuse it when the module is loaded.
+function __init__()
+    v = ccall((:mm_abi_version, LIB), Cint, ())
+    v == MM_ABI_VERSION || error("$(LIB) has ABI version $(v), MarkovModelsAMD.jl was written against $(MM_ABI_VERSION)")
+    nothing
+end
 
 struct MMError <: Exception
     code::Cint
@@ -183,10 +192,11 @@ layout of `vcat(V̂s...)` without the phony row/frame: expand() happens inside);
 `lens` a ROCVector{Int32} or nothing.  Returns (γ::ROCArray{Float32,3} of size
 B × P × N like the reference, ttl::ROCVector{Float32}).
 """
-function pdfposteriors(b::ROCBatch, V::ROCArray{Float32,3}, lens = nothing)
+function pdfposteriors(b::ROCBatch, V::ROCArray{Float32,3}, lens = nothing; out::Union{Nothing, ROCArray{Float32,3}} = nothing)
     P, N, B = size(V)
     P == b.P || throw(DimensionMismatch("V has $P pdfs, the FSMs $(b.P)"))
-    γ = ROCArray{Float32}(undef, B, P, N)
+    out === nothing || size(out) == (B, P, N) || throw(DimensionMismatch("out must be B × P × N"))
+    γ = out === nothing ? ROCArray{Float32}(undef, B, P, N) : out      # (`out`: the array set_gamma_mode!(accumulate = true) adds into)
     ttl = ROCArray{Float32}(undef, B)
     lp = lens === nothing ? Ptr{Int32}(C_NULL) : Ptr{Int32}(pointer(lens))
     # strides in elements: V (b, n, p) -> p + P*n + P*N*b ; γ (b, n, p) -> b + B*p + B*P*n
@@ -258,49 +268,104 @@ function pdfposteriors(fsm::FSM{K}, V̂s::Vector{<:ROCMatrix{T}}, Ĉs::Vector{<:
     γ, ttl
 end
 
-# ---- the compiled-graph cache behind the method above
-const _COMPILED = Dict{UInt64, Any}()          # content hash of (T̂ block, α̂ block, Ĉ) -> ROCCompiledFSM
-const _BATCHES = IdDict{Any, Any}()             # fsm object -> (Ĉs object, ROCBatch, onehot)
+# ---- the compiled-graph cache behind the method above: two BOUNDED least-recently-used tables
+# _COMPILED: 128-bit content key of (T̂ block, α̂ block, Ĉ) -> ROCCompiledFSM (two independent 64-bit hashes of the same fields: a
+#            collision of both is not a practical event; the Python mirror uses a 128-bit digest likewise)
+# _BATCHES:  identity of the caller's fsm object -> (Ĉs object, ROCBatch, onehot): a loop that passes the same objects pays one look-up.
+# Both hold strong references, so both are bounded: a training loop that builds a new numerator union every step would otherwise
+# keep every ROCBatch (its device workspace, its descriptors, its last stacked V̂ through `keep`) until the device is full.  A batch
+# that falls out of _BATCHES is destroyed at once (mm_batch_destroy frees with hipFree, which waits for the device: a call still in
+# flight on it finishes first); compiled graphs that fall out of _COMPILED are freed by their finalizers when no batch uses them.
+mutable struct _LRU{Kt, Vt}
+    d::Dict{Kt, Tuple{Vt, Int}}       # key -> (value, stamp of its last use)
+    clock::Int
+    limit::Int
+end
+_LRU{Kt, Vt}(limit::Integer) where {Kt, Vt} = _LRU{Kt, Vt}(Dict{Kt, Tuple{Vt, Int}}(), 0, Int(limit))
+function _lru_get(c::_LRU, k)
+    e = get(c.d, k, nothing)
+    e === nothing && return nothing
+    c.clock += 1
+    c.d[k] = (e[1], c.clock)
+    e[1]
+end
+"Insert; returns the values that fell out (oldest first) so that the caller can release what they own."
+function _lru_put!(c::_LRU{Kt, Vt}, k, v) where {Kt, Vt}
+    c.clock += 1
+    c.d[k] = (v, c.clock)
+    out = Vt[]
+    while length(c.d) > c.limit
+        oldest = first(c.d)
+        for kv in c.d
+            kv.second[2] < oldest.second[2] && (oldest = kv)
+        end
+        push!(out, oldest.second[1])
+        delete!(c.d, oldest.first)
+    end
+    out
+end
+const _COMPILED = _LRU{NTuple{2, UInt64}, Any}(8192)
+const _BATCHES = _LRU{UInt, Any}(16)
 "Forget every compiled graph and batch the reference-shaped `pdfposteriors` has cached."
-compiled_cache_clear!() = (empty!(_COMPILED); empty!(_BATCHES); nothing)
+function compiled_cache_clear!()
+    for e in values(_BATCHES.d)
+        finalize(e[1][2])
+    end
+    empty!(_BATCHES.d); empty!(_COMPILED.d); nothing
+end
+"Bounds of the two tables: compiled graphs (default 8192) and whole batches (default 16)."
+compiled_cache_limits!(; graphs::Integer = 8192, batches::Integer = 16) = (_COMPILED.limit = graphs; _BATCHES.limit = batches; nothing)
 
 _isonehot(Ĉ::AbstractSparseMatrix{K}) where K =
     all(diff(SparseMatrixCSC(copy(Ĉ')).colptr) .== 1) && all(x -> x == one(K), nonzeros(Ĉ))   # (one(ProbSemiring) = 1: not iszero ∘ val)
 
 function _cached_batch(fsm::FSM{K}, Ĉs) where K
-    hit = get(_BATCHES, fsm, nothing)
-    hit !== nothing && hit[1] === Ĉs && return hit[2], hit[3]
+    id = objectid(fsm)
+    hit = _lru_get(_BATCHES, id)
+    # (objectid of an immutable FSM is the identity of its fields: the same T̂ / α̂ / λ arrays; the entry keeps `fsm` itself, so the id
+    # cannot be reused by another object while the entry lives)
+    hit !== nothing && hit[4] === fsm && hit[1] === Ĉs && return hit[2], hit[3]
     T̂, α̂ = SparseMatrixCSC(fsm.T̂), SparseVector(fsm.α̂)
     sum(size(Ĉ, 1) for Ĉ in Ĉs) == size(T̂, 1) || throw(DimensionMismatch("the Ĉs' rows do not add up to the states of fsm"))
     onehot = all(_isonehot, Ĉs)
-    keys = UInt64[]
-    blocks = Dict{UInt64, Any}()
+    keys = NTuple{2, UInt64}[]
+    blocks = Dict{NTuple{2, UInt64}, Any}()
     lo = 0
     for Ĉ in Ĉs
         r = lo+1:lo+size(Ĉ, 1)
         Tb, ab = T̂[r, r], α̂[r]
         # (a general sparse Ĉ rides along as an argument of the generic entry: its FSM handle gets a placeholder map)
         Cb = onehot ? Ĉ : sparse(1:size(Ĉ, 1), [fill(1, size(Ĉ, 1) - 1); size(Ĉ, 2)], fill(one(K), size(Ĉ, 1)), size(Ĉ, 1), size(Ĉ, 2))
-        k = hash((K, Tb.colptr, Tb.rowval, val.(nonzeros(Tb)), SparseArrays.nonzeroinds(ab), val.(nonzeros(ab)), Cb.colptr, Cb.rowval, size(Cb)))
+        content = (K, Tb.colptr, Tb.rowval, val.(nonzeros(Tb)), SparseArrays.nonzeroinds(ab), val.(nonzeros(ab)), Cb.colptr, Cb.rowval, size(Cb))
+        k = (hash(content, UInt(0x243f6a8885a308d3)), hash(content, UInt(0x13198a2e03707344)))
         push!(keys, k)
-        haskey(_COMPILED, k) || haskey(blocks, k) || (blocks[k] = (Tb, ab, Cb))
+        haskey(_COMPILED.d, k) || haskey(blocks, k) || (blocks[k] = (Tb, ab, Cb))
         lo = last(r)
     end
     if !isempty(blocks)                      # the misses of this call, compiled together
         ks = collect(Base.keys(blocks))
         if length(ks) == 1
             Tb, ab, Cb = blocks[ks[1]]
-            _COMPILED[ks[1]] = _create(K, Tb, ab, Cb)
+            _lru_put!(_COMPILED, ks[1], _create(K, Tb, ab, Cb))
         else
             fs = [FSM(blocks[k][2], blocks[k][1], eltype(fsm.λ)[]) for k in ks]   # (the struct's own constructor, src/fsm.jl:7-17, 44: labels play no part in inference)
             made = compile_many(fs, [blocks[k][3] for k in ks])
             for (k, c) in zip(ks, made)
-                _COMPILED[k] = c
+                _lru_put!(_COMPILED, k, c)
             end
         end
     end
-    b = batch((_COMPILED[k]::ROCCompiledFSM{K} for k in keys)...)
-    _BATCHES[fsm] = (Ĉs, b, onehot)
+    # (the graphs of THIS call are fetched before anything else is inserted: a batch larger than the table's bound still finds them)
+    cfs = ROCCompiledFSM{K}[]
+    for k in keys
+        c = _lru_get(_COMPILED, k)
+        c === nothing && error("compiled-graph cache: the bound ($(_COMPILED.limit)) is smaller than one batch's distinct graphs")
+        push!(cfs, c::ROCCompiledFSM{K})
+    end
+    b = batch(cfs...)
+    for old in _lru_put!(_BATCHES, id, (Ĉs, b, onehot, fsm))
+        finalize(old[2])                      # mm_batch_destroy now: workspace, descriptors, and the V̂ it kept
+    end
     b, onehot
 end
 
@@ -451,6 +516,29 @@ function of the call alone, identical call sequences give identical bits).
 set_exact_policy!(b::ROCBatch, policy::Symbol = :auto) =
     (check(ccall((:mm_batch_set_exact_policy, LIB), Cint, (Ptr{Cvoid}, Cint), b.handle,
                  policy === :auto ? 0 : policy === :f32_first ? 1 : policy === :f64_first ? 2 : throw(ArgumentError("policy")))); b)
+
+"""
+    set_mark_policy!(b::ROCBatch, policy::Symbol = :decide)
+
+What a range mark of the float32 linear-domain kernels means (mm_batch_set_mark_policy): `:decide` -- the finish kernel clears it
+when its two criteria say nothing that matters was lost (log γ within 1e-4 relative above ~1e-24, an absolute error below ~1e-27
+for smaller posteriors) --, `:keep` -- it always stays and the exact kernels compute the utterance: the relative bar down to 1e-30,
+at the price of a second pass on inputs that raise marks.
+"""
+set_mark_policy!(b::ROCBatch, policy::Symbol = :decide) =
+    (check(ccall((:mm_batch_set_mark_policy, LIB), Cint, (Ptr{Cvoid}, Cint), b.handle,
+                 policy === :decide ? 0 : policy === :keep ? 1 : throw(ArgumentError("policy")))); b)
+
+"""
+    set_gamma_mode!(b::ROCBatch; accumulate = false, scale = 1f0)
+
+What `pdfposteriors(b, V, lens)` does with the posteriors (mm_batch_set_gamma_mode): `γ = scale * γ`, or with `accumulate = true`
+`γ_out += scale * γ` into the array passed as `out` -- the numerator call with `scale = -1` on the array the denominator call has just
+written leaves the LF-MMI gradient `γ_den - γ_num` (examples/test_cuda.jl:140-152) there without a third pass.  Batches of the wave
+kernel only (numerator graphs); others throw `MMError(-4, …)`.
+"""
+set_gamma_mode!(b::ROCBatch; accumulate::Bool = false, scale::Real = 1f0) =
+    (check(ccall((:mm_batch_set_gamma_mode, LIB), Cint, (Ptr{Cvoid}, Cint, Cfloat), b.handle, accumulate ? 1 : 0, Float32(scale))); b)
 
 # ---- the reference's semiring linear algebra on the device (src/linalg.jl): mul! and the sparse-vector broadcast --------------
 """

@@ -16,6 +16,8 @@ MM_OK = 0
 MM_LOG, MM_TROPICAL, MM_PROB = 0, 1, 2
 MM_CSC, MM_CSR = 0, 1
 MM_EXACT_AUTO, MM_EXACT_F32_FIRST, MM_EXACT_F64_FIRST = 0, 1, 2
+MM_MARKS_DECIDE, MM_MARKS_KEEP = 0, 1
+MM_ABI_VERSION = 4  # include/markovmodels_amd.h: what the argtypes below were written against
 SEMIRING_ID = {"log": MM_LOG, "tropical": MM_TROPICAL, "prob": MM_PROB}
 
 #: every symbol include/markovmodels_amd.h declares
@@ -40,6 +42,8 @@ SYMBOLS = [
     "mm_batch_last_exact_first",
     "mm_batch_team_xcd_stats",
     "mm_batch_set_exact_policy",
+    "mm_batch_set_mark_policy",
+    "mm_batch_set_gamma_mode",
     "mm_spmv",
     "mm_spmm",
     "mm_svdv",
@@ -91,6 +95,8 @@ def _load():
     lib = C.CDLL(LIB_PATH)
     i64, i32, vp, fp = C.c_int64, C.c_int32, C.c_void_p, C.c_void_p
     lib.mm_abi_version.restype = C.c_int
+    if lib.mm_abi_version() != MM_ABI_VERSION:  # (a stale build: every call below would pass the wrong argument lists)
+        raise ImportError(f"{LIB_PATH} has ABI version {lib.mm_abi_version()}, this binding was written against {MM_ABI_VERSION}: rebuild it")
     lib.mm_last_error.restype = C.c_char_p
     lib.mm_fsm_create.restype = C.c_int
     lib.mm_fsm_create.argtypes = [C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, i64, vp, vp, vp,
@@ -125,6 +131,10 @@ def _load():
     lib.mm_batch_team_xcd_stats.argtypes = [vp, vp]
     lib.mm_batch_set_exact_policy.restype = C.c_int
     lib.mm_batch_set_exact_policy.argtypes = [vp, C.c_int]
+    lib.mm_batch_set_mark_policy.restype = C.c_int
+    lib.mm_batch_set_mark_policy.argtypes = [vp, C.c_int]
+    lib.mm_batch_set_gamma_mode.restype = C.c_int
+    lib.mm_batch_set_gamma_mode.argtypes = [vp, C.c_int, C.c_float]
     lib.mm_spmv.restype = C.c_int
     lib.mm_spmv.argtypes = [C.c_int, C.c_int, i64, i64, i64, vp, vp, C.c_int, vp, vp, i64, vp, i64, vp]
     lib.mm_spmm.restype = C.c_int

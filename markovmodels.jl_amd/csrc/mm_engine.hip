@@ -179,8 +179,9 @@ struct mm_fsm_s {
     const int *d_pdf_ptr = nullptr, *d_pdf_rows = nullptr;  // pdf -> states (CSR)
 };
 
-// Test/diagnostic switches.  Read from the environment ONCE, at mm_batch_create, and only when MM_DEBUG is
-// set: the run entry points never call getenv.  MM_KERNEL = item | quad | row | pair forces a pdfposteriors kernel,
+// Test/diagnostic switches.  Read from the environment at mm_batch_create (and once per process for the entries that have no
+// batch: process_debug_opts), and only when MM_DEBUG is set: the run entry points never call getenv, and no environment variable
+// changes what a production process computes or packs.  MM_KERNEL = item | quad | row | pair forces a pdfposteriors kernel,
 // MM_KQ / MM_NWAVES / MM_NITEMS force a geometry, MM_NO_XCSR keeps the exact-fallback CSR out of LDS,
 // MM_VERBOSE prints the packing statistics.
 struct DebugOpts {
@@ -193,6 +194,8 @@ struct DebugOpts {
     bool bankopt = false;           // MM_BANKOPT: the pair forms choose the banks of their rows (RowPackOpts::bank_opt; an experiment, off by default)
     bool no_wpair = false;          // MM_NO_WPAIR: a whole batch on the exact kernels runs the one-utterance float64 kernels, not the wide pair kernels
     bool no_fallback = false;       // MM_NO_FALLBACK: the float64 pair kernels run, the log-domain kernels behind them do not
+    bool no_pdf_halves = false;     // MM_NO_PDF_HALVES: the packer does not deal a segment's rows to its half-waves by the bank pair of their pdf
+    int wave_place = -1;            // MM_WAVE_PLACE: placement mode of the wave forms (-1: the packer's default)
     int exact_first = -1;           // MM_EXACT_FIRST=0/1: never / always skip the float32 pair kernels (default: by the last call's marks)
     bool bigv = false;              // MM_BIGV: item / tropical kernels with the state vectors in global memory whatever the size
     int finish_cost = 0;            // MM_FINISH_COST: cost model of the pair forms (0: default)
@@ -218,11 +221,19 @@ static DebugOpts read_debug_opts() {
     d.no_wpair = getenv("MM_NO_WPAIR") != nullptr;
     d.bankopt = getenv("MM_BANKOPT") != nullptr;
     d.no_fallback = getenv("MM_NO_FALLBACK") != nullptr;
+    d.no_pdf_halves = getenv("MM_NO_PDF_HALVES") != nullptr;
+    if (const char *e = getenv("MM_WAVE_PLACE")) d.wave_place = atoi(e);
     if (const char *e = getenv("MM_EXACT_FIRST")) d.exact_first = atoi(e) != 0;
     if (const char *e = getenv("MM_FINISH_COST")) d.finish_cost = atoi(e);
     if (const char *e = getenv("MM_SPLIT_SLEEP")) d.x_sleep = atoi(e);
     if (const char *e = getenv("MM_SPLIT_Q10")) d.split_q10 = atoi(e);
     if (const char *e = getenv("MM_GROUP_SPEED")) sscanf(e, "%f,%f,%f,%f", &d.group_speed[0], &d.group_speed[1], &d.group_speed[2], &d.group_speed[3]);
+    return d;
+}
+
+// (entries without a batch -- mm_fsm_create_many's packing, the host-only test aids: the switches as the process started with them)
+static const DebugOpts &process_debug_opts() {
+    static const DebugOpts d = read_debug_opts();
     return d;
 }
 
@@ -248,12 +259,16 @@ struct mm_batch_s {
     int vit_n4 = 0, vit_n2 = 0, vit_arcs = 0;
     bool lane_ok = false;  // every FSM has at most 64 states and 64 pdfs: the lane kernel runs (one wave per utterance and direction)
     int lane_S = 0;        // ... the most states of one
+    bool lane_redo_wave = false;  // ... and every FSM has its wave forms too: what the lane kernel marks goes to the wave kernel (else: the item kernel)
     bool wave_ok = false;  // every FSM has its wave forms: the wave kernel can run (small graphs that are off the linear paths)
     int wave_nseg = 0;
     int pair_H = 1;        // workgroups per team: 1 = the pair kernels proper, > 1 = the split pair kernels
     int split_s1p = 0;     // floats / 2 of a stored vector of the split kernels (positions of the team's vector, padded)
     bool deterministic = false;  // mm_batch_set_deterministic(): no float atomics in the item kernel
     float lt_floor = -20.f;      // mm_batch_set_posterior_floor(): smallest accepted log2 overlap of a frame (mm_pair_finish_kernel)
+    float g_scale = 1.f;         // mm_batch_set_gamma_mode(): gamma_out = g_scale * gamma, or (g_acc) gamma_out += g_scale * gamma
+    bool g_acc = false;
+    bool keep_marks = false;     // mm_batch_set_mark_policy(MM_MARKS_KEEP): a range mark is never cleared by the finish kernels' two criteria
     float *ws_big = nullptr;  // [B][4 * max_S1p]: state vectors of FSMs beyond the LDS (launch())
     int device = -1;
     int n_cus = 256;  // compute units of the device
@@ -888,7 +903,7 @@ static void split_pack_opts(const DebugOpts &dbg, RowPackOpts &opt, RowPackOpts 
     opt.ka_max = mm_split_ka(H);
     opt.nwc_max = MM_SPLIT_NWC;
     opt.pair = true;
-    opt.pdf_halves = getenv("MM_NO_PDF_HALVES") == nullptr;
+    opt.pdf_halves = !dbg.no_pdf_halves;
     for (float &x : opt.group_speed) x = 1.f;
     if (dbg.finish_cost > 0) opt.finish_cost = dbg.finish_cost;
     opt.ka_choices[0] = mm_split_ka(H);
@@ -913,7 +928,7 @@ static int pair_variants(mm_fsm_t f, const DebugOpts &dbg, bool *ok) {
     opt.rs = MM_ROW_RS;
     opt.ka_max = MM_PAIR_KA;
     opt.pair = true;
-    opt.pdf_halves = getenv("MM_NO_PDF_HALVES") == nullptr;
+    opt.pdf_halves = !dbg.no_pdf_halves;
     for (float &x : opt.group_speed) x = 1.f;  // (the waves of a SIMD progress together: mm_rows.h)
     if (dbg.finish_cost > 0) opt.finish_cost = dbg.finish_cost;
     if (dbg.group_speed[0] > 0)
@@ -1174,7 +1189,7 @@ static void wave_pack(mm_fsm_t f) {
     opt.place = 1;
     opt.naive_stats = false;
     opt.q_positions = false;  // (the wave kernel sums the posteriors per pdf through its own tables: wave_pdf_table)
-    if (const char *e = getenv("MM_WAVE_PLACE")) opt.place = atoi(e);
+    if (process_debug_opts().wave_place >= 0) opt.place = process_debug_opts().wave_place;
     // (owned until they are handed to the FSM: the packer may throw -- an allocation that fails)
     std::unique_ptr<RowVariant> rv[2] = {std::make_unique<RowVariant>(), std::make_unique<RowVariant>()};
     const std::vector<int32_t> none;
@@ -1471,7 +1486,7 @@ int mm_debug_row_product_ex(mm_fsm_t f, int direction, int flags, const float *i
     opt.ka_max = kRowKA[sizeof(kRowKA) / sizeof(kRowKA[0]) - 1];
     if (flags & 1) {  // the pair form as pair_variants() builds it
         opt.pair = true;
-    opt.pdf_halves = getenv("MM_NO_PDF_HALVES") == nullptr;
+        opt.pdf_halves = !process_debug_opts().no_pdf_halves;
         opt.ka_max = MM_PAIR_KA;
         opt.ka_choices[0] = MM_PAIR_KA;
         for (float &x : opt.group_speed) x = 1.f;
@@ -1628,7 +1643,7 @@ static int fsm_create_many_impl(int64_t n, int semiring, int layout, int index_b
     for (int64_t i = 0; i < n; ++i) out[i] = nullptr;
     if (!S1 || !nnz || !ptr || !idx || !val || !n_init || !init_idx || !init_val || !state2pdf || !P1)
         return fail(MM_ERR_INVALID, "mm_fsm_create_many: NULL array");
-    const bool verbose = getenv("MM_VERBOSE") != nullptr && getenv("MM_DEBUG") != nullptr;
+    const bool verbose = process_debug_opts().verbose;
     const auto tc0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (verbose) fprintf(stderr, "[mm] create_many: %s at %.2f ms\n", what, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count());
@@ -1890,6 +1905,17 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             h->lane_S = std::max(h->lane_S, int(fsms[b]->S1 - 1));
         }
     }
+    // What the lane kernel marks (mass beyond the double's range: the one path of a sharp left-to-right graph) is computed again in the
+    // log domain: by the WAVE kernel when every graph has its wave forms (up to 4096 arc slots per direction; packed with the graph by
+    // mm_fsm_create_many, nothing to upload at the first call, capturable from the first call on), else -- a dense 64-state HMM has
+    // 4161 arcs -- by the item kernel, whose forms then go to the device here.
+    if (h->lane_ok) {
+        int rc = try_wave();
+        if (rc) return rc;
+        h->lane_redo_wave = h->wave_ok;
+        h->wave_ok = false;
+        if (!h->lane_redo_wave) h->wave_nseg = 0;
+    }
     bool wave_first_tried = false;
     if (h->semiring == MM_LOG && h->dbg.kernel == DebugOpts::K_AUTO && !h->lane_ok) {
         bool small = h->max_P1 <= 250, same = true;
@@ -2026,7 +2052,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     // (the item forms -- the general fallback, the alpha / beta export, the total-sum family -- of a batch of the wave kernel go to
     // the device when an entry first needs them, ensure_item_forms(): a batch of new numerator graphs every training step
     // never does)
-    h->items_resident = !h->wave_ok && !h->lane_ok;
+    h->items_resident = !h->wave_ok && !(h->lane_ok && h->lane_redo_wave);
     for (int64_t b = 0; b < B; ++b) {
         mm_fsm_t f = fsms[b];
         int rc = h->items_resident ? fsm_to_device(f) : MM_OK;
@@ -2046,7 +2072,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         if (h->lane_ok) u.lane = static_cast<const LaneDev *>(f->lane_blob);
         if (h->stream_ok) u.stream = mm_stream_dev(f->stream);
         if (h->vit_ok) u.rv = f->vrow->rdev;
-        if (h->wave_ok)
+        if (h->wave_ok || h->lane_redo_wave)
             for (int d = 0; d < 2; ++d) u.rw[d] = f->wrows[d]->rdev;
         if (h->pairs_ok && h->pair_H == 1)
             for (int d = 0; d < 2; ++d) u.rp[d] = f->prows[d]->rdev;
@@ -2191,6 +2217,28 @@ int mm_batch_set_exact_policy(mm_batch_t h, int policy) {
     if (policy != MM_EXACT_AUTO && policy != MM_EXACT_F32_FIRST && policy != MM_EXACT_F64_FIRST)
         return fail(MM_ERR_INVALID, "mm_batch_set_exact_policy: unknown policy");
     h->exact_first = policy == MM_EXACT_AUTO ? -1 : (policy == MM_EXACT_F64_FIRST ? 1 : 0);
+    return MM_OK;
+}
+
+int mm_batch_set_gamma_mode(mm_batch_t h, int accumulate, float scale) {
+    if (!h) return fail(MM_ERR_INVALID, "mm_batch_set_gamma_mode: NULL batch");
+    if (!(scale == scale) || std::isinf(scale)) return fail(MM_ERR_INVALID, "mm_batch_set_gamma_mode: scale is not finite");
+    const bool plain = !accumulate && scale == 1.f;
+    // (every other kernel family may compute an utterance TWICE -- the linear-domain kernels first, the exact ones for what they
+    // mark -- and the second result must replace the first, not add to it)
+    if (!plain && !h->wave_ok)
+        return fail(MM_ERR_UNSUPPORTED, "mm_batch_set_gamma_mode: only batches of the wave kernel (every graph <= 1023 states, <= 4096 arc slots per direction: "
+                                        "LF-MMI numerators) scale or accumulate their posteriors");
+    h->g_acc = accumulate != 0;
+    h->g_scale = scale;
+    return MM_OK;
+}
+
+int mm_batch_set_mark_policy(mm_batch_t h, int policy) {
+    if (!h) return fail(MM_ERR_INVALID, "mm_batch_set_mark_policy: NULL batch");
+    if (policy != MM_MARKS_DECIDE && policy != MM_MARKS_KEEP) return fail(MM_ERR_INVALID, "mm_batch_set_mark_policy: unknown policy");
+    h->keep_marks = policy == MM_MARKS_KEEP;
+    if (h->stat_host) h->stat_host[0] = 0;  // (what the last call counted was counted under the other policy: float32 kernels first)
     return MM_OK;
 }
 
@@ -2443,7 +2491,9 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     p.split_q10 = h->dbg.split_q10 > 0 ? h->dbg.split_q10 : (h->pair_H == 1 ? MM_PAIR_SPLIT_Q10 : 512);
     p.x_timeout = std::min<unsigned long long>(10000000ull, std::max<unsigned long long>(200000ull, 1000ull * (unsigned long long)N));
     p.lt_floor = h->lt_floor;
-    p.clear_marks = getenv("MM_NEVER_CLEAR") ? 0 : 1;
+    p.clear_marks = h->keep_marks ? 0 : 1;
+    p.g_scale = h->g_scale;
+    p.g_acc = h->g_acc ? 1 : 0;
     p.ws_alpha = static_cast<float *>(h->ws);
     p.ws_c = reinterpret_cast<double *>(static_cast<char *>(h->ws) + ws_alpha_bytes(h, N));
     p.gamma = gamma;
@@ -2506,6 +2556,15 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
         h->last_redo = p.redo;
         rc = mm_launch_lane(h->B, h->lane_S, p, static_cast<hipStream_t>(stream));
         if (rc || h->dbg.no_redo) return rc;
+        if (h->lane_redo_wave) {  // (the wave kernel's workgroups of unmarked utterances leave at once; same workspace layout)
+            p.pair_zmin = reinterpret_cast<double *>(tail0 + 2 * align_up(size_t(h->B + 1) * 4, 256) + align_up(size_t(h->B + 1) * 2 * mm_pair_hand_bytes(), 256));
+            WaveLaunch wlc;
+            wlc.B = h->B;
+            wlc.nseg = h->wave_nseg;
+            wlc.max_P1 = h->max_P1;
+            wlc.n_cus = h->n_cus;
+            return mm_launch_wave(wlc, p, static_cast<hipStream_t>(stream));
+        }
         return launch(mm_log_kernel<MODE_FB, 0, 0, false, false>, mm_log_kernel<MODE_FB, 0, 0, false, true>, h, p, true, pick_geometry(h).NW, stream);
     }
     if (h->stream_ok) {

@@ -104,7 +104,8 @@ mm_wave_kernel(RunParams p) {
     MM_STAMP_DECL;
     const unsigned base = (unsigned)DIR * MM_WAVE_SLICE;
     if (len == 0) {  // no frame: gamma = 0, no path of length 0
-        for (long long q = threadIdx.x; q < (long long)p.N * P; q += NT) p.gamma[gbase + (q / P) * p.gsn + (q % P) * p.gsp] = 0.f;
+        if (!p.g_acc)
+            for (long long q = threadIdx.x; q < (long long)p.N * P; q += NT) p.gamma[gbase + (q / P) * p.gsn + (q % P) * p.gsp] = 0.f;
         if (threadIdx.x == 0) p.ttl[b] = MM_NINF;
         return;
     }
@@ -296,12 +297,20 @@ mm_wave_kernel(RunParams p) {
             tot += pl[j];
         }
         tot = wave_sum_fixed(tot);
-        const float inv = tot > 0.f ? 1.f / tot : 0.f;
+        const float inv = (tot > 0.f ? 1.f / tot : 0.f) * p.g_scale;  // (mm_batch_set_gamma_mode: 1 by default)
         float *gp = p.gamma + gbase + (long long)(f - 1) * p.gsn;
+        if (p.g_acc) {  // gamma_out += scale * gamma: fire-and-forget float atomics (nothing for this wave to wait for)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int q = lane + 64 * j;
-            if (q < P) gp[q * p.gsp] = pl[j] * inv;
+            for (int j = 0; j < NJ; ++j) {
+                const int q = lane + 64 * j;
+                if (q < P) (void)__hip_atomic_fetch_add(gp + q * p.gsp, pl[j] * inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int q = lane + 64 * j;
+                if (q < P) gp[q * p.gsp] = pl[j] * inv;
+            }
         }
         const double z = alive ? (double)fast_log2(tot) + (double)M + own_off + partner_off : -__builtin_inf();
         zmin = z < zmin ? z : zmin;
@@ -597,8 +606,9 @@ mm_wave_kernel(RunParams p) {
         }
         p.ttl[b] = (z < __builtin_inf() && z > -__builtin_inf()) ? (float)(z * (double)MM_LN2) : MM_NINF;
     }
-    for (long long q = threadIdx.x; q < (long long)(p.N - len) * P; q += NT)
-        p.gamma[gbase + (len + q / P) * p.gsn + (q % P) * p.gsp] = 0.f;
+    if (!p.g_acc)
+        for (long long q = threadIdx.x; q < (long long)(p.N - len) * P; q += NT)
+            p.gamma[gbase + (len + q / P) * p.gsn + (q % P) * p.gsp] = 0.f;
 }
 
 }  // namespace mm

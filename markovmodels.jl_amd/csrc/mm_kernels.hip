@@ -175,6 +175,11 @@ struct RunParams {
     // 0.1 s flat: a team that really does not run together -- a foreign kernel holds the compute units -- cost every call that)
     unsigned long long x_timeout;
     float lt_floor;             // mm_pair_finish_kernel: smallest accepted log2 overlap term of a frame (mm_batch_set_posterior_floor)
+    // mm_batch_set_gamma_mode (wave kernel): gamma_out = g_scale * gamma (g_acc = 0) or gamma_out += g_scale * gamma (g_acc = 1: one
+    // no-return float atomic per element -- every element is touched once per call, so the sum does not depend on any order; the
+    // frames beyond len_b are left alone instead of zeroed)
+    float g_scale;
+    int g_acc;
 };
 
 // one thread per workgroup of a finish kernel: add `hard` to the call's count; the last workgroup publishes it to the host

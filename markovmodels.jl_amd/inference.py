@@ -424,6 +424,20 @@ class BatchedFSM:
         check(lib.mm_batch_set_exact_policy(self._h, pol))
         return self
 
+    def set_mark_policy(self, policy: str = "decide"):
+        """mm_batch_set_mark_policy: "decide" (default: the finish kernel clears a range mark of the float32 kernels when its two
+        criteria hold -- log gamma within 1e-4 relative above ~1e-24, an absolute error below ~1e-27 for smaller posteriors) or "keep"
+        (a range mark always stays: the exact kernels compute the utterance -- the relative bar down to 1e-30)."""
+        check(lib.mm_batch_set_mark_policy(self._h, {"decide": _lib.MM_MARKS_DECIDE, "keep": _lib.MM_MARKS_KEEP}[policy]))
+        return self
+
+    def set_gamma_mode(self, accumulate: bool = False, scale: float = 1.0):
+        """mm_batch_set_gamma_mode: what pdfposteriors writes -- gamma_out = scale * gamma, or (accumulate) gamma_out += scale * gamma
+        into the ``out`` tensor of the call (frames beyond the lengths left alone).  Batches of the wave kernel (numerator graphs)
+        only: MarkovModelsAMDError(-4) otherwise.  The LF-MMI gradient gamma_den - gamma_num without a third pass (lfmmi.py)."""
+        check(lib.mm_batch_set_gamma_mode(self._h, 1 if accumulate else 0, float(scale)))
+        return self
+
     def last_exact_first(self) -> bool:
         """True if the last pdfposteriors call skipped the float32 kernels (the inputs of the call before were hard: the
         float64 exact kernels then run the whole batch at once)."""

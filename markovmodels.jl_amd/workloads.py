@@ -172,3 +172,62 @@ def load_npz_graph(path: str) -> GraphSpec:
     z = np.load(path)
     return GraphSpec(os.path.basename(path).split(".")[0], int(z["S"]), z["init_idx"], z["init_w"], z["src"], z["dst"],
                      z["w"], z["final_idx"], z["final_w"], z["state2pdf"].astype(np.int32), int(z["P"]))
+
+
+def sample_paths(g: GraphSpec, B: int, N: int, seed: int = 0, tail: int = 96) -> np.ndarray:
+    """B accepting state paths of exactly N frames drawn from the graph's own distribution (initial weights, then the arcs'
+    probabilities; the last `tail` frames restricted to the arcs from which a final state is still reachable in exactly the
+    frames that are left, and the last state drawn by its final weight).  Returns states[B, N] (0-based).  What a TRAINED acoustic
+    model's outputs are consistent with (examples/test_cuda.jl:124-143 feeds network outputs): `path_consistent_emissions`."""
+    rng = np.random.default_rng(seed)
+    S = g.S
+    order = np.argsort(g.src, kind="stable")
+    src, dst, p = g.src[order], g.dst[order], np.exp(g.w[order])
+    deg = np.bincount(src, minlength=S)
+    ptr = np.concatenate([[0], np.cumsum(deg)])
+    D = int(deg.max())
+    col = np.arange(src.size) - ptr[src]
+    DST = np.zeros((S, D), dtype=np.int64)
+    PRB = np.zeros((S, D))
+    DST[src, col], PRB[src, col] = dst, p
+    fin = np.zeros(S)
+    fin[g.final_idx] = np.exp(g.final_w)
+    # can[r][s]: from s, a final state can be reached in exactly r more arcs (r = 0: s is final)
+    tail = int(min(tail, N - 1)) if N > 1 else 0
+    can = [fin > 0]
+    for _ in range(tail):
+        can.append(((PRB > 0) & can[-1][DST]).any(axis=1))
+    if N - 1 > tail and not can[tail][np.unique(dst)].all():
+        raise ValueError("sample_paths: some state cannot reach a final state in `tail` arcs: raise `tail`")
+
+    def draw(W):  # one column per row of W by its (unnormalised) weights
+        c = np.cumsum(W, axis=1)
+        if not (c[:, -1] > 0).all():
+            raise ValueError("sample_paths: a path ran into a state from which no accepting path of the right length leaves")
+        u = rng.random(W.shape[0]) * c[:, -1]
+        return np.minimum((c < u[:, None]).sum(axis=1), W.shape[1] - 1)
+
+    out = np.empty((B, N), dtype=np.int64)
+    iw = np.exp(g.init_w) * (can[min(tail, N - 1)][g.init_idx] if N - 1 <= tail else 1.0)
+    out[:, 0] = g.init_idx[draw(np.broadcast_to(iw, (B, iw.size)))]
+    for n in range(1, N):
+        left = N - 1 - n  # arcs still to come after this one
+        s = out[:, n - 1]
+        W = PRB[s]
+        if left <= tail:
+            W = W * (can[left][DST[s]] * (fin[DST[s]] if left == 0 else 1.0))
+        out[:, n] = DST[s, draw(W)]
+    return out
+
+
+def path_consistent_emissions(g: GraphSpec, B: int, N: int, sigma: float, seed: int = 0, noise: float = 0.3) -> np.ndarray:
+    """V[B, N, P] float32 = log-softmax(sigma * (onehot(pdf of the state of a sampled accepting path) + noise * N(0,1))): sharp AND
+    consistent with the graph -- the forward and the backward mass of every frame meet on the path, as under a trained model
+    (log-softmax of sigma * N(0,1) alone is sharp and inconsistent: a random arg-max sequence is not a path)."""
+    rng = np.random.default_rng(seed + 7919)
+    pdf = np.asarray(g.state2pdf)[sample_paths(g, B, N, seed)]
+    x = noise * rng.standard_normal((B, N, g.P))
+    np.put_along_axis(x, pdf[:, :, None], np.take_along_axis(x, pdf[:, :, None], 2) + 1.0, 2)
+    x *= sigma
+    x -= x.max(-1, keepdims=True)
+    return (x - np.log(np.exp(x).sum(-1, keepdims=True))).astype(np.float32)

@@ -31,10 +31,8 @@ def set_kernel(kernel):
         os.environ.pop("MM_KERNEL", None)
 
 
-def lens_pattern(rng, B, N):
-    pat = rng.integers(0, 3)
-    lens = np.full(B, N) if pat == 0 else rng.integers(0, N + 1, B) if pat == 1 else rng.integers(max(0, N - 2), N + 1, B)
-    return lens.astype(np.int32)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fuzz_cases import lens_pattern, split_cases  # noqa: E402  (the team fuzzer's inputs, replayable case by case: tests/fuzz_cases.py)
 
 
 def posterior_error(a_g, a_t, ref_g, ref_t):
@@ -63,22 +61,18 @@ def posteriors(cfs, V, lt, kernel):
     return gam.cpu().numpy().astype(np.float64), ttl.cpu().numpy().astype(np.float64), bf.kernels("log"), bf
 
 
-def fuzz_split(rng):
+def fuzz_split(seed):
     bad = n = 0
-    here = os.path.join(ROOT, "tests", "golden", "den_fsm_wsj.npz")
-    graphs = [lambda: wl.load_npz_graph(here), lambda: wl.lfmmi_denominator(2900, 120, seed=int(rng.integers(1 << 30))),
-              lambda: wl.lfmmi_denominator(2400, 200, seed=int(rng.integers(1 << 30))),
-              lambda: wl.lfmmi_denominator(int(rng.integers(1600, 2040)) * 2, 100, seed=int(rng.integers(1 << 30))),  # (teams of 4)
-              lambda: wl.lfmmi_denominator(int(rng.integers(2100, 3000)) * 2, 2 * int(rng.integers(20, 157)), seed=int(rng.integers(1 << 30))),  # (teams of 8)
-              lambda: wl.lfmmi_denominator(2600, 2 * int(rng.integers(126, 253)), seed=int(rng.integers(1 << 30)))]  # (teams of 2, 251 .. 506 pdfs)
-    for gi, mk in enumerate(graphs):
-        g = mk()
-        cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
-        for B, N in ((1, 1), (1, 6), (1, 61), (2, 1), (2, 2), (3, 3), (3, 4), (5, 7), (8, 40), (9, 101), (300, 12), (515, 9)):
-            V = torch.from_numpy((1.5 * rng.standard_normal((B, N, g.P))).astype(np.float32)).cuda()
-            if rng.integers(0, 3) == 0:  # (sharp: the float64 team kernels behind the float32 ones)
+    cfs = {}
+    if True:
+        for gi, g, B, N, V0, sharp, lens in split_cases(wl, seed):
+            if gi not in cfs:
+                cfs.clear()
+                cfs[gi] = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+            cf = cfs[gi]
+            V = torch.from_numpy(V0).cuda()
+            if sharp:  # (sharp: the float64 team kernels behind the float32 ones)
                 V = torch.log_softmax(8.0 * V, dim=-1)
-            lens = lens_pattern(rng, B, N)
             lt = torch.from_numpy(lens).cuda()
             ref_g, ref_t, _, _ = posteriors([cf] * B, V, lt, "item")
             a_g, a_t, names, bf = posteriors([cf] * B, V, lt, None)
@@ -190,7 +184,7 @@ def main(seed=0, which=("split", "wave", "viterbi")):
     saved = {k: os.environ.get(k) for k in ("MM_DEBUG", "MM_KERNEL")}
     total = bad = 0
     for name in which:
-        n, b = {"split": fuzz_split, "wave": fuzz_wave, "viterbi": fuzz_viterbi}[name](rng)
+        n, b = fuzz_split(seed) if name == "split" else {"wave": fuzz_wave, "viterbi": fuzz_viterbi}[name](rng)
         print(f"{name}: {n} comparisons, {b} mismatches", flush=True)
         total += n
         bad += b

@@ -47,9 +47,14 @@ def counters(sub):
     return {k: {c: v / len(disp[k]) for c, v in cs.items()} for k, cs in acc.items()}, {k: len(v) for k, v in disp.items()}
 
 
-bench = json.loads(open(os.path.join(src, "bench.json")).read())
-bench["source_hash"] = sha
-json.dump(bench, open(os.path.join(dst, f"{tag}_bench_{workload}.json"), "w"), indent=1)
+# (tools/measure_cmd.sh profiles a tool that is not bench.py: no bench line, the counters and the kernel statistics only)
+bench = None
+try:
+    bench = json.loads(open(os.path.join(src, "bench.json")).read())
+    bench["source_hash"] = sha
+    json.dump(bench, open(os.path.join(dst, f"{tag}_bench_{workload}.json"), "w"), indent=1)
+except (OSError, ValueError):
+    pass
 
 stats = {}
 for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
@@ -69,15 +74,15 @@ for k in sorted(set(fetch) | set(write)):
     rd = 2.0 * fetch.get(k, {}).get("FETCH_SIZE", 0.0) * 1024
     wr = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
     per_kernel[k] = {"read_bytes_corrected": rd, "write_bytes": wr, "dispatches_measured": [nf.get(k, 0), nw.get(k, 0)]}
-cfg = bench["config"]
+cfg = bench["config"] if bench else {}
 traffic = {
     "workload": workload,
     "source_hash": sha,
-    "B": cfg["global_batch"],
-    "N": cfg["seq_len"],
+    "B": cfg.get("global_batch"),
+    "N": cfg.get("seq_len"),
     "per_kernel": per_kernel,
     "hbm_bytes_per_launch": sum(v["read_bytes_corrected"] + v["write_bytes"] for v in per_kernel.values()),
-    "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+    "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"] if bench and "roofline" in bench else None,
     "correction": "gfx950: FETCH_SIZE x2 for wide coalesced reads (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; one "
                   "pdfposteriors call = one dispatch of each kernel",
 }
@@ -101,5 +106,5 @@ for k in sorted(set(pa) | set(pb)):
 json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_{workload}.json"), "w"), indent=1)
 
 print(json.dumps({"source_hash": sha, "kernel_avg_ns": {k: v["avg_ns"] for k, v in stats.items()},
-                  "hbm_bytes_per_launch": traffic["hbm_bytes_per_launch"], "bench_ms": bench["ms_per_step"],
-                  "frac": bench["roofline"]["frac"]}))
+                  "hbm_bytes_per_launch": traffic["hbm_bytes_per_launch"], "bench_ms": bench["ms_per_step"] if bench else None,
+                  "frac": bench["roofline"]["frac"] if bench and "roofline" in bench else None}))

@@ -2625,8 +2625,17 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
                 p.x_H = h->dpair_ok ? h->pair_H : 0;
                 // (one memset node: the float64 kernels' area when they take the whole batch, else the float32 kernels' -- the
                 // finish kernel then zeroes the float64 area of the utterances it leaves marked)
-                if (exact_first) HIP_TRY(hipMemsetAsync(p.xbuf_d, 0, ws_xd_bytes(h), static_cast<hipStream_t>(stream)));
-                else HIP_TRY(hipMemsetAsync(p.xbuf, 0, ws_x_bytes(h), static_cast<hipStream_t>(stream)));
+                // (a kernel of the library's own, not hipMemsetAsync: inside a captured hipGraph the runtime's memset node has been seen
+                // to overlap the team kernel behind it on replay -- the handshake granules of a launch wiped after they were
+                // published, every team timing out and every utterance recomputed by the exact kernels: round 6,
+                // tests/test_gpu_lfmmi.py::test_lfmmi_step_in_one_hip_graph; and the runtime's memset is two fill kernels, this is one)
+                {
+                    char *zp = reinterpret_cast<char *>(exact_first ? p.xbuf_d : p.xbuf);
+                    const size_t zn = (exact_first ? ws_xd_bytes(h) : ws_x_bytes(h)) / 16;  // (both sizes are multiples of 256)
+                    const unsigned zb = unsigned(std::min<size_t>(2048, (zn + 255) / 256));
+                    hipLaunchKernelGGL(mm_zero_kernel, dim3(zb), dim3(256), 0, static_cast<hipStream_t>(stream), zp, (unsigned long long)zn);
+                    HIP_TRY(hipGetLastError());
+                }
             }
             h->last_z = p.pair_zmin;
             rc = exact_first ? MM_OK : launch_pairs(h, p, stream);

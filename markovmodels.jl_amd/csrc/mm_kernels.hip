@@ -1201,6 +1201,13 @@ __global__ void __launch_bounds__(256) mm_prologue_kernel(const int *lens, int B
     if (i < B) order[rank] = i;
 }
 
+// zero n16 x 16 bytes at dst (16-byte aligned): the team kernels' exchange areas, before every call
+__global__ void __launch_bounds__(256) mm_zero_kernel(char *dst, unsigned long long n16) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 *q = reinterpret_cast<f4 *>(dst);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * 256ull) q[i] = f4{0.f, 0.f, 0.f, 0.f};
+}
+
 // Emission shift for the quad kernels (they normalise by a lagged state maximum only: log-likelihoods far from 0 -- GMM
 // scores around -300 nats -- push every row off their linear path and onto the exact per-row fallback, 30x slower).
 // Posteriors do not change when a frame's log-likelihoods are shifted by a constant, and log Z changes by the sum of the

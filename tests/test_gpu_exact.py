@@ -361,3 +361,83 @@ def test_medium_sharp_emissions_under_every_policy(mm, wl, oracle, torch, which)
                 assert bf.last_redo_count() <= B // 2 and "mm_fbp_kernel" in bf.kernels()  # (most utterances stay on the float32 kernels)
             check_gamma(gam, g_ref, lens)
             assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-3)
+
+
+RTOL = 1e-4  # |d log gamma| <= 1e-4 max(|log gamma|, 1) wherever gamma_ref > 1e-30
+
+
+# ---- the parity contract, pinned on what the team fuzzer found (tools/fuzz_round3.py `split`, inputs replayed from the seed) ----
+def _documented_bound_ok(a, ref):
+    """The DEFAULT mark policy's contract (include/markovmodels_amd.h, mm_batch_set_mark_policy): |d log gamma| <= 1e-4 max(|log gamma|, 1)
+    for posteriors above 1e-24, an absolute error below 1e-27 for smaller ones, 2e-5 absolute overall."""
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    if not (np.isfinite(a).all() and np.abs(a - ref).max() <= 2e-5):
+        return False, "absolute"
+    hi = ref >= 1e-24
+    if hi.any():
+        lr = np.log(ref[hi])
+        err = np.abs(np.log(np.maximum(a[hi], 1e-300)) - lr) / np.maximum(np.abs(lr), 1.0)
+        if err.max() > 1e-4:
+            return False, f"relative {err.max():.3e}"
+    lo = ~hi
+    if lo.any() and np.abs(a[lo] - ref[lo]).max() > 1e-27:
+        return False, f"absolute below 1e-24: {np.abs(a[lo] - ref[lo]).max():.3e}"
+    return True, ""
+
+
+def _strict_miss(a, ref):
+    """largest |d log gamma| / max(|log gamma|, 1) over gamma_ref > 1e-30: SURVEY 8(d)'s bar is 1e-4"""
+    m = ref > 1e-30
+    if not m.any():
+        return 0.0
+    lr = np.log(ref[m])
+    return float((np.abs(np.log(np.maximum(a[m], 1e-300)) - lr) / np.maximum(np.abs(lr), 1.0)).max())
+
+
+@pytest.mark.parametrize("seed", [1, 3])
+def test_fuzzer_findings_pin_the_parity_contract(mm, wl, oracle, torch, seed):
+    """Round 4 / 5's fuzzer findings as tests: SEED=1 of `tools/fuzz_round3.py split` holds a 5-frame utterance
+    on a 2600-state / 472-pdf graph, sharp emissions, whose float32 range marks are raised and CLEARED and one posterior of 8.49e-29
+    comes out as 0 (its only state sits 105 log2 below its frame's maximum, behind flushed predecessors); SEED=3 held a posterior
+    of 1.436e-30 computed 1 % low in round 4 (the kernels have changed since: its stream is replayed whole).  Every case of both
+    streams, regenerated from the seed (tests/fuzz_cases.py), against the item kernel (log domain):
+      * default policy: the DOCUMENTED bound -- relative above 1e-24, absolute 1e-27 below -- an explicit assertion;
+      * every case that misses SURVEY 8(d)'s bar (relative down to 1e-30) on the default path, and the pinned case of seed 1 in
+        any event: under mm_batch_set_mark_policy(MM_MARKS_KEEP) check_gamma passes UNCHANGED, the pinned case against the float64
+        oracle as well."""
+    from fuzz_cases import split_cases
+
+    pinned = {(5, 300, 12)} if seed == 1 else set()
+    misses, n = [], 0
+    cf, last = None, None
+    for gi, g, B, N, V0, sharp, lens in split_cases(wl, seed):
+        if gi != last:
+            cf, last = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P)), gi
+        V = torch.from_numpy(V0).cuda()
+        if sharp:
+            V = torch.log_softmax(8.0 * V, dim=-1)
+        lt = torch.from_numpy(lens).cuda()
+        ref = _with_env({"MM_DEBUG": "1", "MM_KERNEL": "item"}, lambda: mm.batch(*([cf] * B))).pdfposteriors(V, lt)[0].cpu().numpy().astype(np.float64)
+        bf = mm.batch(*([cf] * B))
+        assert "mm_fbs_kernel" in bf.kernels(), bf.kernels()
+        a = bf.pdfposteriors(V, lt)[0].cpu().numpy().astype(np.float64)
+        ok, why = _documented_bound_ok(a, ref)
+        assert ok, (seed, gi, B, N, why)
+        n += 1
+        miss = _strict_miss(a, ref)
+        if miss > RTOL or (gi, B, N) in pinned:
+            misses.append((gi, B, N, miss))
+            bk = mm.batch(*([cf] * B)).set_mark_policy("keep")
+            ak, tk = bk.pdfposteriors(V, lt)
+            ak, tk = ak.cpu().numpy(), tk.cpu().numpy()
+            if (gi, B, N) in pinned:  # the float64 oracle itself
+                ref, t_ref = oracle64(oracle, g, V.cpu().numpy(), lens)
+                okp = np.isfinite(t_ref)
+                assert np.allclose(tk[okp], t_ref[okp], rtol=1e-5, atol=1e-4)
+                assert _strict_miss(a, ref) > 1.0, "the pinned finding no longer misses on the default path: the contract in the header can be tightened"
+            path = ak.reshape(B, -1).sum(1) > 0  # (utterances without a path: gamma = 0, nothing to compare)
+            check_gamma(ak[path], ref[path], lens[path])
+            assert (ak[~path] == 0).all() and _strict_miss(ak, ref) <= RTOL
+    assert n == 72 and all(m[:3] in pinned or m[3] > RTOL for m in misses)
+    if seed == 1:
+        assert any(m[:3] == (5, 300, 12) and m[3] > 1.0 for m in misses), misses  # 8.49e-29 computed as 0: |d log| / |log| > 1

@@ -644,26 +644,31 @@ def test_team_xcd_counter(mm, wl, torch):
     assert b3.team_xcd_stats() == (0, 0)
 
 
-def test_never_clear_keeps_every_range_mark(mm, wl, oracle, torch):
-    """MM_NEVER_CLEAR=1: a mark raised by a range check stays whatever the two criteria say -- the reference's WSJ denominator, whose
-    initial-context states decay out of the float range in every utterance (marked and cleared by default: redo 0), is then computed
-    by the exact kernels; the results are the float64 oracle's either way."""
+def test_mark_policy_keep_keeps_every_range_mark(mm, wl, oracle, torch):
+    """mm_batch_set_mark_policy(MM_MARKS_KEEP): a mark raised by a range check stays whatever the two criteria say -- the reference's
+    WSJ denominator, whose initial-context states decay out of the float range in every utterance (marked and cleared by default:
+    redo 0), is then computed by the exact kernels; the results are the float64 oracle's either way.  Per batch, switchable between
+    calls, no environment variable involved."""
     g = wsj_den(wl)
     rng = np.random.default_rng(29)
     B, N = 6, 90
     V = rng.standard_normal((B, N, g.P)).astype(np.float32)
     lens = np.array([90, 90, 71, 90, 84, 90], dtype=np.int32)
-
-    def run():
-        cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
-        bf = mm.batch(*([cf] * B))
-        bf.set_exact_policy("f32_first")
-        gam, ttl = bf.pdfposteriors(V, lens)
-        return gam, ttl, bf.last_redo_count(), bf.last_fallback_count()
-
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(*([cf] * B))
+    bf.set_exact_policy("f32_first")
     g_ref, t_ref = oracle64(oracle, g, V, lens)
-    for env, want in (({}, 0), ({"MM_NEVER_CLEAR": "1"}, B)):
-        gam, ttl, redo, fallback = _with_env(env, run)
-        assert redo == want and fallback == 0
-        check_gamma(gam, g_ref, lens)
-        assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)
+    os.environ["MM_NEVER_CLEAR"] = "1"  # (round 5's switch: no longer read)
+    try:
+        for policy, want in (("decide", 0), ("keep", B), ("decide", 0)):
+            bf.set_mark_policy(policy)
+            gam, ttl = bf.pdfposteriors(V, lens)
+            assert bf.last_redo_count() == want and bf.last_fallback_count() == 0
+            check_gamma(gam, g_ref, lens)
+            assert np.allclose(ttl, t_ref, rtol=1e-5, atol=1e-4)
+    finally:
+        os.environ.pop("MM_NEVER_CLEAR")
+    from importlib import import_module
+
+    _lib = import_module(mm.__name__ + "._lib")
+    assert _lib.lib.mm_batch_set_mark_policy(bf._h, 7) == -1  # MM_ERR_INVALID

@@ -113,7 +113,7 @@ int64_t mm_batch_total_states(mm_batch_t batch);
 /* Names of the kernels a run entry launches for this batch (the engine picks them from the graphs' sizes and
  * shapes): entry 0 = mm_pdfposteriors_f32, 1 = mm_viterbi_f32, 2 = what the last mm_pdfposteriors_ex call on the batch launched
  * (the recursion kernel; for ProbSemiring FSMs in float32 with general state maps, the emission GEMM C_hat * V_hat on the matrix
- * cores before it).  Informational (bench.py quotes it). */
+ * cores before it), 3 = mm_alpharecursion_f32 / mm_betarecursion_f32.  Informational (bench.py quotes it). */
 int mm_batch_kernels(mm_batch_t batch, int entry, char *buf, size_t n);
 /* Allocate the internal workspace for runs of up to N frames now (synchronises if it has to grow). */
 int mm_batch_reserve(mm_batch_t batch, int64_t N);
@@ -147,7 +147,10 @@ int mm_pdfposteriors_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, i
  * called from pdfposteriors (:150-152): out is the reference's state_A, a
  * (sum S1) x (N+1) column-major matrix: element (b, n, s) at
  * out[n*out_stride_n + state_offset_b + s] with state_offset_b the running sum
- * of S1 over the batch.  Values are natural-log (un-normalised). */
+ * of S1 over the batch.  Values are natural-log (un-normalised).
+ * One shared graph in the pair form (the batches of mm_fbp_kernel, up to 250 pdfs) runs phase A of the pair kernels over all
+ * N + 1 frames -- two utterances per workgroup, linear domain -- and one layout pass; utterances whose values leave float32's
+ * range (sharp emissions) and every other batch run the item kernel (log domain, one workgroup per utterance). */
 int mm_alpharecursion_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t v_stride_n,
                           const int32_t *lens, int64_t N, float *out, int64_t out_stride_n, void *stream);
 /* beta-recursion(T_hat, C_hat*V_hat) (src/inference.jl:99-110); same layout (state_B).  Log and Tropical

@@ -130,9 +130,9 @@ struct mm_fsm_s {
     int32_t P1;
     int S1p;
     Csr mat[2];   // 0: T_hat' (forward), 1: T_hat (backward); engine-domain weights
-    Csr qmat[2];  // the same restricted to the useful states (reachable from an initial state AND
-                  // able to reach the final state): the quad kernel computes posteriors, to which
-                  // the other states contribute exactly nothing
+    Csr qmat[2];  // the same restricted to the useful states (able to reach the final state AND reachable from an
+                  // initial state -- or one of a FEW that are not: mm_fsm_create): the kernels compute posteriors,
+                  // to which the other states contribute exactly nothing
     Packed packed[2];      // the item forms: packed when first needed (ensure_packed) -- a numerator graph of the wave kernel never needs them
     std::once_flag packed_once, gen_once;
     // what the generic path's copies are built from when first asked for (gen_build): the matrix as it was handed over
@@ -141,6 +141,7 @@ struct mm_fsm_s {
     std::vector<int32_t> raw_col;
     std::vector<double> raw_val;
     bool fast_ok = false;  // the quad kernel's linear path is valid for this FSM
+    bool export_ok[2] = {false, false};  // the pruned forms (qmat) give the reference's alpha (0) / beta (1) recursion: see mm_fsm_create
     int depth = 0;         // most arcs from an initial state to any (useful) state
     int64_t nquads[2] = {0, 0};
     std::map<int, QuadVariant *> variants;  // by 2 * KQ + direction
@@ -694,14 +695,30 @@ static int fsm_create_impl(int semiring, int64_t S1, int64_t nnz, int layout, in
                     stack.push_back(fwd.col[k]);
                 }
         }
+        // Which states the kernel forms keep.  A state that cannot reach the final state has beta = zero(K), one that cannot be
+        // reached alpha = zero(K): neither contributes to any posterior, and until round 6 both were dropped.  Now a FEW unreachable
+        // states that do reach the final state stay (config 3's generator leaves 4 of 2000 units without a predecessor): their rows
+        // cost nothing to speak of, their alpha is exactly 0 on every path of the kernels, and the backward forms then hold every
+        // state with a non-zero beta -- the beta-recursion export (mm_betarecursion_f32) can run on them.  The alpha-recursion export
+        // needs every reachable state to reach the final state (export_on_pairs).
+        int64_t n_extra = 0;
+        f->export_ok[0] = true;
+        for (int64_t s = 0; s < S1; ++s) {
+            if (reach[s] && !coreach[s]) f->export_ok[0] = false;
+            n_extra += coreach[s] && !reach[s];
+        }
+        const bool keep_extra = n_extra * 64 <= S1;
+        f->export_ok[1] = keep_extra || n_extra == 0;
+        std::vector<char> useful(S1, 0);
+        for (int64_t s = 0; s < S1; ++s) useful[s] = coreach[s] && (reach[s] || keep_extra);
         for (int d = 0; d < 2; ++d) {
             const Csr &m = d == 0 ? fwd : bwd;
             Csr &q = f->qmat[d];
             q.rowptr.assign(S1 + 1, 0);
             for (int64_t r = 0; r < S1; ++r) {
-                if (reach[r] && coreach[r])
+                if (useful[r])
                     for (int64_t k = m.rowptr[r]; k < m.rowptr[r + 1]; ++k)
-                        if (m.val[k] > NINF && reach[m.col[k]] && coreach[m.col[k]]) {
+                        if (m.val[k] > NINF && useful[m.col[k]]) {
                             q.col.push_back(m.col[k]);
                             q.val.push_back(m.val[k]);
                         }
@@ -2302,6 +2319,7 @@ int mm_batch_team_xcd_stats(mm_batch_t h, int out[2]) {
     });
 }
 
+static bool export_on_pairs(mm_batch_t h, int dir);
 int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
     if (!h || !buf || n < 2) return fail(MM_ERR_INVALID, "mm_batch_kernels: bad argument");
     std::string s;
@@ -2355,6 +2373,12 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
     } else if (entry == 1) {  // mm_viterbi_f32
         s = h->vit_ok ? "mm_vit_kernel + mm_vit_backtrace_kernel (mm_tropical_kernel + mm_backtrace_kernel when the int32 back-pointers are asked for)"
                       : "mm_tropical_kernel + mm_backtrace_kernel";
+    } else if (entry == 3) {  // mm_alpharecursion_f32 / mm_betarecursion_f32
+        const bool xa = export_on_pairs(h, 0), xb = export_on_pairs(h, 1);
+        const std::string fast = "mm_fbx_kernel<" + std::to_string(mm_pair_nj(h->max_P1)) + "> (phase A of one direction over all frames, two utterances per workgroup) + "
+                                 "mm_pair_export_kernel, then for marked utterances only the item kernel";
+        s = h->semiring == MM_TROPICAL ? std::string("mm_tropical_kernel / mm_log_kernel<MODE_BETA, TROP>")
+            : "alpha: " + (xa ? fast : std::string("mm_log_kernel<MODE_ALPHA>")) + "; beta: " + (xb ? fast : std::string("mm_log_kernel<MODE_BETA>"));
     } else if (entry == 2) {  // mm_pdfposteriors_ex: what its last call on this batch launched
         s = h->gen.last_kernels.empty() ? std::string("mm_generic_kernel (not called yet)") : h->gen.last_kernels;
     } else {
@@ -2694,6 +2718,25 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
     return launch_log<MODE_FB>(h, p, stream);
 }
 
+// alpha / beta export on the pair kernels (mm_pairs_tu.hip: mm_fbx_kernel + mm_pair_export_kernel): one shared graph in the pair
+// form whose every state takes part (the packer drops states that cannot be reached or cannot reach the final state -- their
+// posteriors are zero, their alpha / beta are not), log semiring, up to 250 pdfs
+static PairLaunch pair_launch_of(mm_batch_t h) {
+    PairLaunch pl;
+    pl.B = h->B;
+    pl.nwc = h->pair_nwc;
+    pl.slotrows = h->pair_slotrows;
+    pl.max_P1 = h->max_P1;
+    pl.pair_ka = h->pair_ka;
+    pl.H = h->pair_H;
+    pl.small = h->pair_H == 1 && h->max_S1p <= 128;
+    return pl;
+}
+static bool export_on_pairs(mm_batch_t h, int dir) {
+    if (h->semiring != MM_LOG || !h->pairs_ok || h->pair_H != 1 || !mm_pair_export_fits(pair_launch_of(h))) return false;
+    return h->fsms[0]->export_ok[dir];
+}
+
 static int run_export(mm_batch_t h, int mode, const float *V, int64_t vsb, int64_t vsn, const int32_t *lens, int64_t N,
                       float *out, int64_t out_stride_n, void *stream) {
     const char *who = mode == MODE_ALPHA ? "mm_alpharecursion_f32" : "mm_betarecursion_f32";
@@ -2711,6 +2754,31 @@ static int run_export(mm_batch_t h, int mode, const float *V, int64_t vsb, int64
     p.B = int(h->B);
     p.out = out;
     p.out_stride_n = out_stride_n;
+    if (export_on_pairs(h, mode == MODE_ALPHA ? 0 : 1)) {
+        // phase A of ONE direction over all N + 1 frames with two utterances per workgroup (linear domain, float32), the layout
+        // pass, then -- for the utterances whose values left float32's range (marked; sharp emissions) -- the item kernel
+        rc = ensure_ws(h, mm_batch_workspace_bytes(h, N), stream);
+        if (rc) return rc;
+        char *const tail0 = static_cast<char *>(h->ws) + ws_alpha_bytes(h, N) + ws_c_bytes(h, N);
+        p.ws_alpha = static_cast<float *>(h->ws);
+        p.ws_c = reinterpret_cast<double *>(static_cast<char *>(h->ws) + ws_alpha_bytes(h, N));
+        p.redo = reinterpret_cast<int *>(tail0 + align_up(size_t(h->B + 1) * 4, 256));
+        p.pair_s1p = h->max_S1p;
+        p.pair_hand = tail0 + 2 * align_up(size_t(h->B + 1) * 4, 256);
+        p.pair_zmin = reinterpret_cast<double *>(static_cast<char *>(p.pair_hand) + align_up(size_t(h->B + 1) * 2 * mm_pair_hand_bytes(), 256));
+        p.split_q10 = 512;
+        p.lt_floor = h->lt_floor;
+        hipLaunchKernelGGL(mm_prologue_kernel, dim3(unsigned((h->B + 1 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           (const int *)nullptr, int(h->B), int(N), (int *)nullptr, p.redo, (int *)nullptr, 0);
+        HIP_TRY(hipGetLastError());
+        rc = mm_launch_pair_export(pair_launch_of(h), p, mode == MODE_ALPHA ? 0 : 1, static_cast<hipStream_t>(stream));
+        if (rc) return rc;
+        h->last_redo = p.redo;  // (mm_batch_last_redo_count: how many utterances the item kernel computed instead)
+        if (h->dbg.no_redo) return MM_OK;
+        p.ws_alpha = nullptr;   // (the item kernel's export modes keep nothing in the workspace)
+        p.ws_c = nullptr;
+        return mode == MODE_ALPHA ? launch_log<MODE_ALPHA>(h, p, stream) : launch_log<MODE_BETA>(h, p, stream);
+    }
     if (h->semiring == MM_TROPICAL) {
         if (mode == MODE_ALPHA) return launch_tropical(h, p, stream);
         const Geometry g = pick_geometry(h);

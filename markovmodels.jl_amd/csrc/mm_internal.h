@@ -87,6 +87,9 @@ struct PairLaunch {
     bool small = false;  // every FSM has at most 127 states: the instance whose service wave copies and scans one row of 64 float4
 };
 int mm_launch_pairs(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
+// alpha / beta export on the pair kernels (phase A of one direction over all frames + a layout pass): dir 0 alpha, 1 beta
+bool mm_pair_export_fits(const PairLaunch &pl);
+int mm_launch_pair_export(const PairLaunch &pl, const RunParams &p, int dir, hipStream_t s0);
 size_t mm_pair_lds_bytes(int phase, int nslotrows, int max_P1);
 size_t mm_pair_hand_bytes();
 // ---- the float64 exact pair kernels (mm_dpair_tu.hip): one utterance per workgroup, for the utterances marked in p.redo

@@ -786,7 +786,12 @@ struct PairHand {  // what an agent hands from phase A to phase B, per utterance
 // and ONE register allocation (the two specialised bodies behind a branch on blockIdx made the register allocator spill 50
 // scalar registers in phase B: the loads of the parameters are hoisted above the branch and stay live through both bodies).
 // What depends on the direction at run time is scalar arithmetic (frame_of, indices) and one select per finished row.
-template <int KA, int RS, int PHASE, int DIRT, int NJ, int H = 1, int RSH = 2 * RS, bool SMALL = false>
+// XPT (phase A only; mm_fbx_kernel): the agent of ONE direction walks ALL N + 1 frames and stores every frame's vector -- the
+// alpha-recursion / beta-recursion export (src/inference.jl:62-74, 99-110): forward p = alpha_n with the frame's emission, as the
+// reference's alpha has it; backward s, the sum BEFORE the frame's emission and normaliser, as the reference's beta has it (:107:
+// B[:, n] = T (B[:, n+1] (*) lhs[:, n+1])), with the offset that goes with it.  mm_pair_export_kernel turns the stored rows into the
+// reference's layout in natural logarithms.
+template <int KA, int RS, int PHASE, int DIRT, int NJ, int H = 1, int RSH = 2 * RS, bool SMALL = false, bool XPT = false>
 __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hset = 0, int rdir = 0) {
 // (teams, tried in round 4 and left OFF: the waves that write a step's vector -- finishes and received rows -- gather its maxima
 // with LDS atomics instead of the service wave scanning the team's whole vector (3300 .. 4200 cycles of its step for teams of
@@ -847,6 +852,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         U[u].offs = p.ws_c + (long long)slot * (p.N + 2);
         NFp = len + 1 > NFp ? len + 1 : NFp;
     }
+    static_assert(!XPT || (PHASE == 0 && H == 1), "the export runs phase A of the one-workgroup instances");
+    if constexpr (XPT) NFp = p.N + 1;  // (every frame of the reference's (sum S1) x (N + 1) matrix, whatever the lengths: expand() pads)
     // state vectors of the pair's frames (alpha~ up to the split, beta~ beyond), the two utterances side by side like
     // in LDS: [N + 2][S1p][2] -- one 8-byte store per finish in phase A, and in phase B ONE ds_read_b64 fetches both
     // partner values of a row (two 4-byte reads at the partner's scattered positions cost the backward agent 9 % of a step)
@@ -866,7 +873,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
     // split: forward steps 1..m are phase A, backward steps 1..NFp-m
     int m = (int)(((long long)NFp * (p.split_q10 > 0 ? p.split_q10 : 512)) >> 10);
     m = m < 1 ? 1 : (m > NFp - 1 && NFp > 1 ? NFp - 1 : m);
-    const int tA = DIR ? NFp - m : m, tEnd = NFp;
+    const int tA = XPT ? NFp : (DIR ? NFp - m : m), tEnd = NFp;
     auto frame_of = [&](int t) { return DIR ? NFp + 1 - t : t; };
     PairHand *hand = reinterpret_cast<PairHand *>(p.pair_hand) + ((long long)pair * 2 + DIR) * 2;
     if (lds_addr_of(lds) != 0u) __builtin_trap();
@@ -1043,7 +1050,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 for (int u = 0; u < 2; ++u) {
                     const double off = LINF ? cum[u] : (DIR ? cum[u] - (double)E[u] : cum[u]);
                     *(__attribute__((address_space(3))) double *)(__UINTPTR_TYPE__)(L::OWN(t & 3) + 8u * u) = LINF ? before[u] : off;
-                    if (PHASE == 0) U[u].offs[frame_of(t)] = off;
+                    // (XPT, backward: the stored vector is s, the sum before this step's normaliser and emission)
+                    if (PHASE == 0) U[u].offs[frame_of(t)] = (XPT && DIR) ? before[u] : off;
                 }
             }
         };
@@ -1470,7 +1478,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 float *xw = H > 1 ? xsend + (long long)(t & 1) * p.x_slot - 2 * xbase : nullptr;
                 const float xsg = (H > 1 && split_tag(t, t0, 1)) ? -1.f : 1.f;
                 if constexpr (PHASE == 1) al = ldsr2((info2 & 0xffffu) + alb);
-                float *rowP = rowsP + (long long)(f <= p.N ? f : 0) * 2 * S1p;
+                float *rowP = rowsP + (long long)(f <= p.N + (XPT ? 1 : 0) ? f : 0) * 2 * S1p;  // (frame N + 1 is stored by the export only)
                 // even / odd arcs (phase B has no registers to spare: one chain there)
                 float worst = 0.f;
                 unsigned smin = 0xffffffffu;
@@ -1499,7 +1507,8 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                             else granule_store(xw, pos8, pv.x * xsg, pv.y * xsg);
                         }
                         if constexpr (PHASE == 0) {
-                            *reinterpret_cast<mm_f32x2 *>(reinterpret_cast<char *>(rowP) + pos8) = pv;
+                            if constexpr (XPT) *reinterpret_cast<mm_f32x2 *>(reinterpret_cast<char *>(rowP) + pos8) = DIR ? sv : pv;
+                            else *reinterpret_cast<mm_f32x2 *>(reinterpret_cast<char *>(rowP) + pos8) = pv;
                         } else {
                             asm("v_pk_mul_f32 %0, %1, %2" : "=v"(qv) : "v"(sv), "v"(al));  // A .* B   (:154)
                             ldsw2((info2 >> 16) + L::Q(WR), qv.x, qv.y);
@@ -1787,6 +1796,54 @@ static __global__ void mm_pair_finish_kernel(RunParams p) {
             f4 *q = reinterpret_cast<f4 *>(p.xps_d + (long long)b * nps);
             for (long long i = threadIdx.x; i < nps / 4; i += blockDim.x) q[i] = f4{0.f, 0.f, 0.f, 0.f};
         }
+    }
+}
+
+// alpha-recursion / beta-recursion export, second half (mm_fbx_kernel first): the rows phase A stored -- [frame][position][2
+// utterances] linear float32 values + a float64 log2 offset per utterance and frame -- into the reference's layout, element (b, n, s)
+// at out[(n - 1) * out_stride_n + state_off_b + s] in natural logarithms (src/inference.jl:62-74, 99-110: state_A / state_B).
+// One workgroup per (pair, chunk of frames): a row of pairs is read as it lies (coalesced), scattered to state order through LDS
+// (position -> state: RowDev::order), and leaves as two contiguous rows.  dir 1: frame N + 1 is B[:, N+1] = one(K) (:103).
+// Utterances the kernel marked (values beyond float32's range) are skipped: the item kernel computes them behind this launch.
+static __global__ void __launch_bounds__(256) mm_pair_export_kernel(RunParams p, int dir, int frames_per_block) {
+    extern __shared__ float xs[];  // [2][S1p]
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int S1p = p.pair_s1p;
+    int b[2], valid[2];
+    for (int u = 0; u < 2; ++u) {
+        const int i = 2 * pair + u;
+        valid[u] = i < p.B;
+        b[u] = valid[u] ? i : p.B - 1;
+        if (valid[u] && p.redo[b[u]] != 0) valid[u] = 0;
+    }
+    const UttDesc &ud = p.utts[b[0]];
+    const RowDev &r = ud.rp[dir];
+    const int S1 = r.rows;
+    const float *rowsP = p.ws_alpha + (long long)pair * (long long)(p.N + 2) * 2 * S1p;
+    const int f0 = 1 + (int)blockIdx.y * frames_per_block, f1 = min(p.N + 1, f0 + frames_per_block - 1);
+    for (int f = f0; f <= f1; ++f) {
+        if (dir == 1 && f == p.N + 1) {  // fill!(B[:, end], one(K))   (src/inference.jl:103: every state, not only the final one)
+            for (int i = tid; i < S1; i += 256) xs[i] = xs[S1p + i] = 0.f;
+        } else {
+            // (the offsets' slots are pair_agent's: the utterance's own, the spare slot B for the copy that fills an odd batch's last pair)
+            const double o0 = p.ws_c[(long long)b[0] * (p.N + 2) + f];
+            const double o1 = p.ws_c[(long long)(2 * pair + 1 < p.B ? b[1] : p.B) * (p.N + 2) + f];
+            const mm_f32x2 *row = reinterpret_cast<const mm_f32x2 *>(rowsP + (long long)f * 2 * S1p);
+            for (int i = tid; i < S1; i += 256) {
+                const mm_f32x2 v = row[i];
+                const int s = r.order[i];
+                // (log2 of a float in double: the offsets reach thousands of log2, whose float ulp is what a posterior is compared at)
+                xs[s] = v.x > 0.f ? (float)(((double)fast_log2(v.x) + o0) * (double)MM_LN2) : MM_NINF;
+                xs[S1p + s] = v.y > 0.f ? (float)(((double)fast_log2(v.y) + o1) * (double)MM_LN2) : MM_NINF;
+            }
+        }
+        __syncthreads();
+        for (int u = 0; u < 2; ++u)
+            if (valid[u]) {
+                float *dst = p.out + (long long)(f - 1) * p.out_stride_n + p.utts[b[u]].state_off;
+                for (int i = tid; i < S1; i += 256) dst[i] = xs[u * S1p + i];
+            }
+        __syncthreads();
     }
 }
 

@@ -1,5 +1,6 @@
 // mm_pairs_tu.hip -- translation unit of the pair kernels (mm_kernel_pairs.hip): their instances and launches.
 #define MM_SECONDARY_TU
+#include <algorithm>
 #include "mm_internal.h"
 #include "mm_kernel_pairs.hip"
 
@@ -45,6 +46,35 @@ int mm_launch_pairs(const PairLaunch &pl, const RunParams &p, hipStream_t s0) {
     if (pl.max_P1 <= 250) return launch_pairs_ka<4, false>(&pl, p, s0);
     if (pl.max_P1 > MM_PAIR_P1MAX) return MM_ERR_UNSUPPORTED;
     return launch_pairs_ka<8, false>(&pl, p, s0);
+}
+// ---- alpha-recursion / beta-recursion export on the pair kernels (src/inference.jl:62-74, 99-110): phase A of ONE direction over all
+// N + 1 frames (pair_agent, XPT), then mm_pair_export_kernel -- instead of the item kernel's one workgroup per utterance with the
+// vectors in the log domain (config 3: 26 ms).  The instances of the linear finishes only (up to 250 pdfs).
+template <int NJ, bool SMALL>
+__global__ void __launch_bounds__(1024) mm_fbx_kernel(RunParams p, int dir) {
+    pair_agent<MM_PAIR_KA, MM_ROW_RS, 0, -1, NJ, 1, 2 * MM_ROW_RS, SMALL, true>(p, (int)blockIdx.x, 0, dir);
+}
+template <int NJ, bool SMALL>
+static int launch_pair_export(const PairLaunch *h, const RunParams &p, int dir, hipStream_t st) {
+    const size_t lds = pair_lds_bytes(MM_ROW_RS, 0, h->slotrows, 0, pair_pc(NJ));
+    if (lds > 160 * 1024) return mm_fail(MM_ERR_UNSUPPORTED, "pair kernel: LDS");
+    auto kernel = mm_fbx_kernel<NJ, SMALL>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    const unsigned npairs = unsigned((h->B + 1) / 2);
+    hipLaunchKernelGGL(kernel, dim3(npairs), dim3(64 * (h->nwc + 1)), lds, st, p, dir);
+    HIP_TRY(hipGetLastError());
+    // the stored rows -> the reference's layout: (pairs, chunks of frames) workgroups, enough of them to keep the memory system busy
+    const int chunks = std::max(1, std::min(p.N + 1, int(4096 / std::max(1u, npairs))));
+    const int fpb = (p.N + 1 + chunks - 1) / chunks;
+    hipLaunchKernelGGL(mm_pair_export_kernel, dim3(npairs, unsigned((p.N + 1 + fpb - 1) / fpb)), dim3(256), size_t(2) * size_t(p.pair_s1p) * 4, st, p, dir, fpb);
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+}
+bool mm_pair_export_fits(const PairLaunch &pl) { return pl.H == 1 && pl.pair_ka <= MM_PAIR_KA && pl.max_P1 <= 250; }
+int mm_launch_pair_export(const PairLaunch &pl, const RunParams &p, int dir, hipStream_t s0) {
+    if (!mm_pair_export_fits(pl)) return MM_ERR_UNSUPPORTED;
+    if (pl.max_P1 <= 128) return pl.small ? launch_pair_export<2, true>(&pl, p, dir, s0) : launch_pair_export<2, false>(&pl, p, dir, s0);
+    return launch_pair_export<4, false>(&pl, p, dir, s0);
 }
 size_t mm_pair_lds_bytes(int phase, int nslotrows, int max_P1) {
     return pair_lds_bytes(MM_ROW_RS, phase, nslotrows, 0, pair_pc(mm_pair_nj(max_P1)));

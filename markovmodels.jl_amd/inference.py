@@ -451,11 +451,12 @@ class BatchedFSM:
         return int(out[0]), int(out[1])
 
     def kernels(self, semiring: str = "log") -> str:
-        """The kernels the engine launches for this batch (informational)."""
+        """The kernels the engine launches for this batch (informational): "log" = pdfposteriors, "tropical" = bestpath, "export" =
+        alpharecursion / betarecursion."""
         import ctypes
 
         buf = ctypes.create_string_buffer(512)
-        check(lib.mm_batch_kernels(self._h, 0 if semiring == "log" else 1, buf, 512))
+        check(lib.mm_batch_kernels(self._h, {"log": 0, "tropical": 1, "export": 3}[semiring], buf, 512))
         return buf.value.decode()
 
     def kernels_generic(self) -> str:

@@ -672,3 +672,50 @@ def test_mark_policy_keep_keeps_every_range_mark(mm, wl, oracle, torch):
 
     _lib = import_module(mm.__name__ + "._lib")
     assert _lib.lib.mm_batch_set_mark_policy(bf._h, 7) == -1  # MM_ERR_INVALID
+
+
+@pytest.mark.parametrize("P", [60, 200])
+def test_alpha_beta_export_on_the_pair_kernels(mm, wl, oracle, torch, P):
+    """alpha-recursion / beta-recursion (src/inference.jl:62-74, 99-110) of a shared graph in the pair form: phase A of the pair kernels
+    over all N + 1 frames (mm_fbx_kernel: two utterances per workgroup, linear domain; the backward agent stores the sums BEFORE the
+    frame's emission, as the reference's beta has them) + the layout pass -- asserted by name -- against the float64 oracle's state_A /
+    state_B: odd batch, lengths 0 .. N (expand()'s padding beyond them: the final state keeps its value, beta of the frames beyond the
+    length is omega).  Sharp emissions leave float32's range: marked, computed by the item kernel, the same results."""
+    o, oc = oracle
+    g = wl.lfmmi_denominator(1200, P, seed=6)
+    of = graphs.to_oracle(o, g)
+    S1 = g.S + 1
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    B, N = 5, 37
+    lens = np.array([37, 20, 0, 1, 36], dtype=np.int32)
+    rng = np.random.default_rng(8)
+    bf = mm.batch(*([cf] * B))
+    assert "mm_fbx_kernel" in bf.kernels("export") and "mm_pair_export_kernel" in bf.kernels("export"), bf.kernels("export")
+    for sharp in (False, True):
+        V = (1.2 * rng.standard_normal((B, N, g.P))).astype(np.float32)
+        if sharp:  # log-softmax of 12 N(0,1)
+            x = 12.0 * rng.standard_normal((B, N, g.P))
+            V = (x - np.log(np.exp(x - x.max(-1, keepdims=True)).sum(-1, keepdims=True)) - x.max(-1, keepdims=True)).astype(np.float32)
+        A = bf.alpharecursion(V, lens)
+        redo_a = bf.last_redo_count()
+        Bm = bf.betarecursion(V, lens)
+        redo_b = bf.last_redo_count()
+        assert A.shape == (B * S1, N + 1) and Bm.shape == (B * S1, N + 1)
+        assert (redo_a, redo_b) == (0, 0) if not sharp else redo_a + redo_b > 0  # (sharp: utterances handed to the item kernel)
+        for b in range(B):
+            _, _, Ar, Br = oc.single(of, g.state2pdf, g.P, o.expand(V[b].T.astype(np.float64), int(lens[b]), o.LOG), want_ab=True)
+            for got, ref, what in ((A[b * S1:(b + 1) * S1], Ar, "alpha"), (Bm[b * S1:(b + 1) * S1], Br, "beta")):
+                assert np.array_equal(np.isneginf(got), np.isneginf(ref)), (what, b, sharp)
+                m = np.isfinite(ref)
+                assert np.allclose(got[m], ref[m], rtol=1e-5, atol=2e-4), (what, b, sharp, np.abs(got[m] - ref[m]).max())
+    # a graph with states that cannot reach the final state: their alpha is not zero(K) -- the item kernel's business
+    g2 = wl.random_fsm(300, 11, 2.0, seed=12)
+    b2 = _with_env({"MM_DEBUG": "1", "MM_KERNEL": "pair"}, lambda: mm.batch(*([mm.compile(wl.to_fsm(mm, g2), mm.statemap(g2.state2pdf, g2.P))] * 2)))
+    info = b2.kernels("export")
+    V2 = rng.standard_normal((2, 9, g2.P)).astype(np.float32)
+    A2 = b2.alpharecursion(V2, None)
+    for b in range(2):
+        _, _, Ar, _ = oc.single(graphs.to_oracle(o, g2), g2.state2pdf, g2.P, o.expand(V2[b].T.astype(np.float64), 9, o.LOG), want_ab=True)
+        got = A2[b * (g2.S + 1):(b + 1) * (g2.S + 1)]
+        assert np.array_equal(np.isneginf(got), np.isneginf(Ar)), info
+        assert np.allclose(got[np.isfinite(Ar)], Ar[np.isfinite(Ar)], rtol=1e-5, atol=2e-4)

@@ -134,7 +134,12 @@ size_t mm_batch_workspace_bytes(mm_batch_t batch, int64_t N);
  *          normaliser (src/inference.jl:159) = log Z_b
  * An utterance with no accepting path (Z = 0) yields gamma = 0, ttl = -inf
  * (the reference yields NaN: src/inference.jl:158; guarded only in the dead
- * code at :198-200). */
+ * code at :198-200).
+ * MM_PROB batches of Float32 FSMs (ProbSemiring{Float32}, non-negative weights): V holds LIKELIHOODS -- the semiring's values, like
+ * the reference's Array{ProbSemiring} --, the library keeps a log-semiring twin of every such FSM (weights = their logarithms),
+ * takes log V in one pass, runs the same fast kernels and returns ttl as the probability Z_b = exp(log Z_b) (0 if no path); gamma is
+ * the same quotient in both semirings (:158-160).  Float64 ProbSemiring FSMs, general state maps, V_hat that expand() did not make:
+ * mm_pdfposteriors_ex. */
 /* Streams: the call is a chain of kernel launches on `stream` and nothing else -- no library-owned streams, no events, no
  * host synchronisation (the forward and the backward agents of an utterance are workgroups of ONE grid per phase); it can be
  * captured in a hipGraph once the workspace is sized (mm_batch_reserve).  Two batches driven from two caller streams do

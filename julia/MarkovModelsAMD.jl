@@ -219,7 +219,8 @@ block's T̂, α̂ and Ĉ): a graph is packed and uploaded the first time it is s
 `compile_many` -- and found again on every later call (the denominator graph; an utterance's numerator across epochs).
 The whole batch is remembered per `(fsm, Ĉs)` object pair as well, so a loop that passes the same objects pays one
 dictionary look-up.  `V̂s` are stacked on the device like `vcat(V̂s...)` (:146).
-With Float32 log-semiring FSMs, one-hot `Ĉs` and `expanded = true` the fast kernels run on V̂[1:P, 1:N, b] IN PLACE (strides).
+With Float32 log-semiring (or, since round 6, ProbSemiring) FSMs, one-hot `Ĉs` and `expanded = true` the fast kernels run on
+V̂[1:P, 1:N, b] IN PLACE (strides).
 The lengths: `seqlengths` (what `expand` was given: a Vector or ROCVector of integers) keeps the call asynchronous; without it
 they are read off the phony row on the host, and the form `expand` gives a matrix (phony row zero(K) up to the length and
 one(K) after, real rows zero(K) beyond it) is CHECKED -- a matrix of another form goes to the generic entry like
@@ -236,7 +237,10 @@ function pdfposteriors(fsm::FSM{K}, V̂s::Vector{<:ROCMatrix{T}}, Ĉs::Vector{<:
     all(size(Ĉ, 2) == P1 for Ĉ in Ĉs) || throw(DimensionMismatch("V̂ has $P1 rows, a Ĉ has another number of pdfs"))
     b, onehot = _cached_batch(fsm, Ĉs)
     V̂ = cat(V̂s...; dims = 3)                                    # (P+1) × (N+1) × B on the device
-    fast = expanded && onehot && K <: LogSemiring && T === Float32
+    # (ProbSemiring{Float32} too: the library keeps a log-semiring twin of such FSMs and runs the fast kernels on log V̂ -- V̂ then
+    # holds likelihoods, ttl comes back as a probability: mm_pdfposteriors_f32 in the header)
+    fast = expanded && onehot && (K <: LogSemiring || K <: ProbSemiring) && T === Float32 && eltype(val(one(K))) === Float32
+    z0, o1 = K <: ProbSemiring ? (0f0, 1f0) : (-Inf32, 0f0)      # val(zero(K)), val(one(K))
     P, N = P1 - 1, N1 - 1
     lens = nothing
     if fast
@@ -246,9 +250,9 @@ function pdfposteriors(fsm::FSM{K}, V̂s::Vector{<:ROCMatrix{T}}, Ĉs::Vector{<:
             # expand (src/inference.jl:54-60): the phony row is zero(K) up to seqlength and one(K) after, the real rows are
             # zero(K) beyond it -- read and verified on the host (one round trip; pass `seqlengths` to avoid it)
             ph = Array(V̂[P1, :, :])                             # (N+1) × B
-            L = vec(sum(ph .== -Inf32, dims = 1))
-            step_ok = all(all(ph[1:L[j], j] .== -Inf32) && all(ph[L[j]+1:end, j] .== 0f0) && L[j] <= N for j in 1:B)
-            tail_ok = step_ok && all(mapreduce(x -> x == -Inf32, &, V̂[1:P, L[j]+1:N1, j]; init = true) for j in 1:B if L[j] < N1)   # (a GPU reduction returns a host scalar)
+            L = vec(sum(ph .== z0, dims = 1))
+            step_ok = all(all(ph[1:L[j], j] .== z0) && all(ph[L[j]+1:end, j] .== o1) && L[j] <= N for j in 1:B)
+            tail_ok = step_ok && all(mapreduce(x -> x == z0, &, V̂[1:P, L[j]+1:N1, j]; init = true) for j in 1:B if L[j] < N1)   # (a GPU reduction returns a host scalar)
             fast = step_ok && tail_ok
             lens = ROCArray(Int32.(L))
         end

@@ -141,6 +141,10 @@ struct mm_fsm_s {
     std::vector<int32_t> raw_col;
     std::vector<double> raw_val;
     bool fast_ok = false;  // the quad kernel's linear path is valid for this FSM
+    // ProbSemiring FSMs in float32 (round 6): the SAME graph in the log semiring -- weights = log of the probabilities -- with all the
+    // kernel forms of a log FSM.  mm_pdfposteriors_f32 on a batch of such FSMs takes the logarithm of the likelihoods in one pass, runs
+    // the fast kernels on the twins and returns ttl as a probability; the generic entry (mm_pdfposteriors_ex) keeps the FSM as given.
+    mm_fsm_s *log_twin = nullptr;
     bool export_ok[2] = {false, false};  // the pruned forms (qmat) give the reference's alpha (0) / beta (1) recursion: see mm_fsm_create
     int depth = 0;         // most arcs from an initial state to any (useful) state
     int64_t nquads[2] = {0, 0};
@@ -295,6 +299,11 @@ struct mm_batch_s {
     int exact_first = -1;               // MM_EXACT_FIRST (under MM_DEBUG): 0 / 1 force the choice, -1: by the statistics
     bool last_exact_first = false;      // what the last call did
     const int *last_redo2 = nullptr;    // marks the float64 kernels left for the log-domain kernels (mm_batch_last_fallback_count)
+    // a batch of ProbSemiring FSMs that all have their log twins: the batch of the twins (what mm_pdfposteriors_f32 runs), and the
+    // logarithms of the call's likelihoods [B][N][P]
+    mm_batch_s *log_twin = nullptr;
+    float *prob_logv = nullptr;
+    size_t prob_logv_bytes = 0;
 };
 
 // Launch geometry of the item kernels: NW waves per workgroup, NI register-resident items per wave
@@ -660,7 +669,30 @@ static int fsm_create_impl(int semiring, int64_t S1, int64_t nnz, int layout, in
         f->gen.init = f->gen_init.data();
         f->gen.s2p = f->s2p.data();
     }
-    if (semiring == MM_PROB) {  // (the generic path only: mm_pdfposteriors_ex)
+    if (semiring == MM_PROB) {
+        // the generic path (mm_pdfposteriors_ex) works on the FSM as given; Float32 FSMs with non-negative weights also get their
+        // log-semiring twin for the fast kernels (mm_pdfposteriors_f32)
+        bool twin = val_bytes == 4;
+        std::vector<float> lv(static_cast<size_t>(nnz)), liv(static_cast<size_t>(n_init));
+        for (int64_t k = 0; k < nnz && twin; ++k) {
+            const float x = static_cast<const float *>(val)[k];
+            twin = x >= 0.f;
+            lv[size_t(k)] = std::log(x);  // (log 0 = -inf = zero(LogSemiring))
+        }
+        for (int64_t k = 0; k < n_init && twin; ++k) {
+            const float x = static_cast<const float *>(init_val)[k];
+            twin = x >= 0.f;
+            liv[size_t(k)] = std::log(x);
+        }
+        if (twin) {
+            mm_fsm_t tw = nullptr;
+            const int rc = fsm_create_impl(MM_LOG, S1, nnz, layout, index_bytes, index_base, 4, ptr, idx, lv.data(), n_init, init_idx, liv.data(), state2pdf, P1, &tw);
+            if (rc) {
+                delete f;
+                return rc;
+            }
+            f->log_twin = tw;
+        }
         *out = f;
         return MM_OK;
     }
@@ -1375,6 +1407,7 @@ static int row_variants(mm_fsm_t f, bool verbose, bool *ok) {
 
 int mm_fsm_destroy(mm_fsm_t f) {
     if (!f) return MM_OK;
+    if (f->log_twin) (void)mm_fsm_destroy(f->log_twin);
     for (void *&d : f->gen.dev)
         if (d) {
             mm_generic_free(d);
@@ -1801,6 +1834,9 @@ int mm_fsm_create_many(int64_t n, int semiring, int layout, int index_bytes, int
     });
 }
 
+// a batch of ProbSemiring FSMs answers for its settings and counters through the batch of its log twins (what runs its fast calls)
+static mm_batch_t twin_of(mm_batch_t h) { return h && h->log_twin ? h->log_twin : h; }
+
 static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     if (!out) return fail(MM_ERR_INVALID, "mm_batch_create: out is NULL");
     *out = nullptr;
@@ -1822,10 +1858,18 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     h->semiring = fsms[0]->semiring;
     h->fsms.assign(fsms, fsms + B);
     if (hipGetDevice(&h->device) != hipSuccess) return fail(MM_ERR_HIP, "mm_batch_create: no device");
-    if (h->semiring == MM_PROB) {  // the generic path only (mm_pdfposteriors_ex): no kernel forms, no descriptors
+    if (h->semiring == MM_PROB) {  // the generic path (mm_pdfposteriors_ex): no kernel forms, no descriptors of its own
+        bool twins = true;
         for (int64_t b = 0; b < B; ++b) {
             h->total_states += fsms[b]->S1;
             h->max_P1 = std::max(h->max_P1, int(fsms[b]->P1));
+            twins = twins && fsms[b]->log_twin != nullptr;
+        }
+        if (twins) {  // ... and the batch of the log twins for the fast entry (a repeated handle repeats its twin: stored once)
+            std::vector<mm_fsm_t> tw(static_cast<size_t>(B));
+            for (int64_t b = 0; b < B; ++b) tw[size_t(b)] = fsms[b]->log_twin;
+            const int rc = batch_create_impl(tw.data(), B, &h->log_twin);
+            if (rc) return rc;
         }
         *out = hold.release();
         return MM_OK;
@@ -2187,6 +2231,8 @@ int mm_debug_read_stamps(unsigned long long *out, int64_t n) {
 
 int mm_batch_destroy(mm_batch_t h) {
     if (!h) return MM_OK;
+    if (h->log_twin) (void)mm_batch_destroy(h->log_twin);
+    if (h->prob_logv) (void)hipFree(h->prob_logv);
     if (h->d_utts) (void)hipFree(h->d_utts);
     if (h->ws_big) (void)hipFree(h->ws_big);
     if (h->ws) (void)hipFree(h->ws);
@@ -2220,6 +2266,7 @@ int mm_batch_gen_view(mm_batch_t h, int64_t *B, const mm_fsm_t **fsms, int *semi
 extern "C" {
 
 int mm_batch_set_posterior_floor(mm_batch_t h, float floor) {
+    h = twin_of(h);
     if (!h) return fail(MM_ERR_INVALID, "mm_batch_set_posterior_floor: NULL batch");
     if (!(floor >= 1e-30f && floor <= 1e-6f)) return fail(MM_ERR_INVALID, "mm_batch_set_posterior_floor: floor outside [1e-30, 1e-6]");
     // a term that dropped out of the linear path would have had a posterior below 2^(-120 - L_n) (mm_pair_finish_kernel):
@@ -2230,6 +2277,7 @@ int mm_batch_set_posterior_floor(mm_batch_t h, float floor) {
 }
 
 int mm_batch_set_exact_policy(mm_batch_t h, int policy) {
+    h = twin_of(h);
     if (!h) return fail(MM_ERR_INVALID, "mm_batch_set_exact_policy: NULL batch");
     if (policy != MM_EXACT_AUTO && policy != MM_EXACT_F32_FIRST && policy != MM_EXACT_F64_FIRST)
         return fail(MM_ERR_INVALID, "mm_batch_set_exact_policy: unknown policy");
@@ -2238,6 +2286,7 @@ int mm_batch_set_exact_policy(mm_batch_t h, int policy) {
 }
 
 int mm_batch_set_gamma_mode(mm_batch_t h, int accumulate, float scale) {
+    h = twin_of(h);
     if (!h) return fail(MM_ERR_INVALID, "mm_batch_set_gamma_mode: NULL batch");
     if (!(scale == scale) || std::isinf(scale)) return fail(MM_ERR_INVALID, "mm_batch_set_gamma_mode: scale is not finite");
     const bool plain = !accumulate && scale == 1.f;
@@ -2252,6 +2301,7 @@ int mm_batch_set_gamma_mode(mm_batch_t h, int accumulate, float scale) {
 }
 
 int mm_batch_set_mark_policy(mm_batch_t h, int policy) {
+    h = twin_of(h);
     if (!h) return fail(MM_ERR_INVALID, "mm_batch_set_mark_policy: NULL batch");
     if (policy != MM_MARKS_DECIDE && policy != MM_MARKS_KEEP) return fail(MM_ERR_INVALID, "mm_batch_set_mark_policy: unknown policy");
     h->keep_marks = policy == MM_MARKS_KEEP;
@@ -2260,12 +2310,14 @@ int mm_batch_set_mark_policy(mm_batch_t h, int policy) {
 }
 
 int mm_batch_set_deterministic(mm_batch_t h, int on) {
+    h = twin_of(h);
     if (!h) return fail(MM_ERR_INVALID, "mm_batch_set_deterministic: NULL batch");
     h->deterministic = on != 0;
     return MM_OK;
 }
 
 int mm_batch_last_redo_count(mm_batch_t h, void *stream, int64_t *n) {
+    h = twin_of(h);
     if (!h || !n) return fail(MM_ERR_INVALID, "mm_batch_last_redo_count: bad argument");
     *n = 0;
     if (!h->last_redo) return MM_OK;
@@ -2294,6 +2346,7 @@ int mm_batch_last_redo_count(mm_batch_t h, void *stream, int64_t *n) {
 }
 
 int mm_batch_last_fallback_count(mm_batch_t h, void *stream, int64_t *n) {
+    h = twin_of(h);
     if (!h || !n) return fail(MM_ERR_INVALID, "mm_batch_last_fallback_count: bad argument");
     *n = 0;
     if (!h->last_redo2) return MM_OK;
@@ -2304,9 +2357,13 @@ int mm_batch_last_fallback_count(mm_batch_t h, void *stream, int64_t *n) {
     return MM_OK;
 }
 
-int mm_batch_last_exact_first(mm_batch_t h) { return h && h->last_exact_first ? 1 : 0; }
+int mm_batch_last_exact_first(mm_batch_t h) {
+    h = twin_of(h);
+    return h && h->last_exact_first ? 1 : 0;
+}
 
 int mm_batch_team_xcd_stats(mm_batch_t h, int out[2]) {
+    h = twin_of(h);
     if (!h || !out) return fail(MM_ERR_INVALID, "mm_batch_team_xcd_stats: bad argument");
     out[0] = out[1] = 0;
     if (!h->stat_dev) return MM_OK;
@@ -2322,6 +2379,9 @@ int mm_batch_team_xcd_stats(mm_batch_t h, int out[2]) {
 static bool export_on_pairs(mm_batch_t h, int dir);
 int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
     if (!h || !buf || n < 2) return fail(MM_ERR_INVALID, "mm_batch_kernels: bad argument");
+    if (entry == 0) h = twin_of(h);  // (ProbSemiring: the fast entry runs the log twins' kernels)
+    if (entry == 0 && h->semiring == MM_PROB)
+        return fail(MM_ERR_UNSUPPORTED, "mm_batch_kernels: this ProbSemiring batch has no log twins (Float64 FSMs, or negative weights): mm_pdfposteriors_ex only");
     std::string s;
     if (entry == 0) {  // mm_pdfposteriors_f32
         const bool quad = quad_kernel_usable(h);
@@ -2428,6 +2488,7 @@ static size_t ws_shift_bytes(mm_batch_t h, int64_t N) {
 }
 size_t mm_batch_workspace_bytes(mm_batch_t h, int64_t N) {
     if (!h || N < 0) return 0;
+    if (h->log_twin) return mm_batch_workspace_bytes(h->log_twin, N) + align_up(size_t(h->B) * size_t(N) * size_t(h->max_P1 - 1) * 4, 256);
     return ws_alpha_bytes(h, N) + ws_c_bytes(h, N) + ws_tail_bytes(h) + ws_shift_bytes(h, N);
 }
 
@@ -2459,8 +2520,29 @@ static int ensure_ws(mm_batch_t h, size_t bytes, void *stream = nullptr) {
     return MM_OK;
 }
 
+// (ProbSemiring batches) room for the logarithms of a call's likelihoods [B][N][P]; grown like the workspace: never during a capture
+static int ensure_prob_logv(mm_batch_t h, int64_t N, void *stream) {
+    const size_t bytes = align_up(size_t(h->B) * size_t(N) * size_t(h->max_P1 - 1) * 4, 256);
+    if (h->prob_logv_bytes >= bytes) return MM_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return fail(MM_ERR_INVALID, "the workspace would have to grow during stream capture: call mm_batch_reserve first");
+    if (h->prob_logv) {
+        HIP_TRY(hipFree(h->prob_logv));
+        h->prob_logv = nullptr;
+        h->prob_logv_bytes = 0;
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->prob_logv), bytes));
+    h->prob_logv_bytes = bytes;
+    return MM_OK;
+}
+
 int mm_batch_reserve(mm_batch_t h, int64_t N) {
     if (!h || N < 1) return fail(MM_ERR_INVALID, "mm_batch_reserve: bad argument");
+    if (h->log_twin) {
+        const int rc = ensure_prob_logv(h, N, nullptr);
+        return rc ? rc : mm_batch_reserve(h->log_twin, N);
+    }
     int dev = -1;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != h->device) return fail(MM_ERR_INVALID, "mm_batch_reserve: batch lives on another device");
@@ -2476,7 +2558,7 @@ static int check_run(mm_batch_t h, const char *who, const float *V, int64_t N, i
     if (want_semiring >= 0 && h->semiring != want_semiring)
         return fail(MM_ERR_INVALID, std::string(who) + ": batch was built for another semiring");
     if (h->semiring == MM_PROB)
-        return fail(MM_ERR_UNSUPPORTED, std::string(who) + ": ProbSemiring batches run through mm_pdfposteriors_ex");
+        return fail(MM_ERR_UNSUPPORTED, std::string(who) + ": ProbSemiring batches run through mm_pdfposteriors_f32 (Float32 FSMs) or mm_pdfposteriors_ex");
     int dev = -1;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != h->device) return fail(MM_ERR_INVALID, std::string(who) + ": batch lives on another device");
@@ -2488,8 +2570,44 @@ static int check_run(mm_batch_t h, const char *who, const float *V, int64_t N, i
     return MM_OK;
 }
 
+// ProbSemiring batches on the fast kernels: V holds LIKELIHOODS (values of the semiring, as the reference's Array{ProbSemiring} does);
+// one pass takes their logarithms, the log twins' kernels do the work, ttl comes back as the probability exp(log Z) -- gamma is a
+// probability in both semirings (src/inference.jl:158-160: the quotient, and exp() of it for the log-like semirings only)
+static __global__ void mm_prob_log_kernel(const float *V, long long vsb, long long vsn, int N, int P, float *out) {
+    const long long row = (long long)blockIdx.x;  // (b, n)
+    const float *src = V + (row / N) * vsb + (row % N) * vsn;
+    float *dst = out + row * P;
+    for (int q = threadIdx.x; q < P; q += blockDim.x) dst[q] = logf(src[q]);  // (log 0 = -inf = zero(LogSemiring))
+}
+static __global__ void mm_prob_exp_kernel(float *ttl, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) ttl[b] = expf(ttl[b]);
+}
+static int prob_pdfposteriors(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const int32_t *lens, int64_t N, float *gamma,
+                              int64_t gsb, int64_t gsn, int64_t gsp, float *ttl, void *stream) {
+    if (!V || !gamma || !ttl) return fail(MM_ERR_INVALID, "mm_pdfposteriors_f32: V / gamma / ttl is NULL");
+    if (N < 1 || N > (int64_t(1) << 30)) return fail(MM_ERR_DIM, "mm_pdfposteriors_f32: need N >= 1");
+    if (!h->log_twin)
+        return fail(MM_ERR_UNSUPPORTED, "mm_pdfposteriors_f32: this ProbSemiring batch has no log twins (Float64 FSMs, or negative weights): mm_pdfposteriors_ex");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != h->device) return fail(MM_ERR_INVALID, "mm_pdfposteriors_f32: batch lives on another device");
+    int rc = ensure_prob_logv(h, N, stream);
+    if (rc) return rc;
+    const int P = h->max_P1 - 1;
+    hipLaunchKernelGGL(mm_prob_log_kernel, dim3(unsigned(h->B * N)), dim3(P <= 64 ? 64 : (P <= 128 ? 128 : 256)), 0, static_cast<hipStream_t>(stream), V,
+                       (long long)vsb, (long long)vsn, int(N), P, h->prob_logv);
+    HIP_TRY(hipGetLastError());
+    rc = mm_pdfposteriors_f32(h->log_twin, h->prob_logv, int64_t(N) * P, P, lens, N, gamma, gsb, gsn, gsp, ttl, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mm_prob_exp_kernel, dim3(unsigned((h->B + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), ttl, int(h->B));
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+}
+
 int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn, const int32_t *lens, int64_t N,
                          float *gamma, int64_t gsb, int64_t gsn, int64_t gsp, float *ttl, void *stream) {
+    if (h && h->semiring == MM_PROB) return prob_pdfposteriors(h, V, vsb, vsn, lens, N, gamma, gsb, gsn, gsp, ttl, stream);
     int rc = check_run(h, "mm_pdfposteriors_f32", V, N, MM_LOG);
     if (rc) return rc;
     if (!gamma || !ttl) return fail(MM_ERR_INVALID, "mm_pdfposteriors_f32: gamma/ttl is NULL");

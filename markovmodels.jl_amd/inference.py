@@ -284,6 +284,19 @@ class BatchedFSM:
             return gamma.cpu().numpy(), ttl.cpu().numpy()
         return gamma, ttl
 
+    def has_fast_entry(self) -> bool:
+        """True if ``pdfposteriors(V, lens)`` -- mm_pdfposteriors_f32, the fast kernels -- serves this batch: Log batches always,
+        ProbSemiring batches of Float32 FSMs (the library keeps their log-semiring twins: ``kernels()`` names the twins' kernels),
+        Tropical batches never (their fast entry is ``viterbi``)."""
+        if self.semiring == "log":
+            return True
+        if self.semiring != "prob" or self.dtype == np.float64:
+            return False
+        try:
+            return bool(self.kernels("log"))
+        except _lib.MarkovModelsAMDError:
+            return False
+
     def reserve_ex(self, dtype, N1: int):
         """Size the generic entry's workspace for V_hat of N1 = N + 1 columns (mm_batch_reserve_ex): before capturing
         ``pdfposteriors_ex`` in a hipGraph."""
@@ -512,29 +525,33 @@ def expand(lhs, seqlength: Optional[int] = None, semiring: str = "log"):
     return out
 
 
-def _unexpand(Vhats: Sequence[np.ndarray]):
+def _unexpand(Vhats: Sequence[np.ndarray], semiring: str = "log"):
     """Recover (V[B, N, P], lens) from matrices made by ``expand`` (what the fast kernels take: they implement expand's
-    semantics themselves); None if a matrix is not of that form -- the caller then takes the generic path."""
+    semantics themselves); None if a matrix is not of that form -- the caller then takes the generic path.  The form
+    (src/inference.jl:54-60): the phony row zero(K) up to the length and one(K) after, the real rows zero(K) beyond it --
+    zero(K) / one(K) = -inf / 0 for the Log and Tropical semirings, 0 / 1 for ProbSemiring."""
     Vh = [np.asarray(v.cpu() if hasattr(v, "cpu") else v) for v in Vhats]
     shp = Vh[0].shape
     if any(v.shape != shp for v in Vh):
         raise _lib.DimensionMismatch(-2, "all V_hat must share one (P+1) x (N+1) shape")
     P1, N1 = shp
+    zero, one = _SEM_ZERO[semiring], _SEM_ONE[semiring]
     lens = []
     for v in Vh:
         ph = v[P1 - 1]
-        L = int(np.argmax(ph == 0)) if (ph == 0).any() else N1
-        ok = np.all(np.isneginf(ph[:L])) and np.all(ph[L:] == 0) and np.all(np.isneginf(v[: P1 - 1, L:])) and L <= N1 - 1
+        L = int(np.argmax(ph == one)) if (ph == one).any() else N1
+        ok = np.all(ph[:L] == zero) and np.all(ph[L:] == one) and np.all(v[: P1 - 1, L:] == zero) and L <= N1 - 1
         if not ok:
             return None
         lens.append(L)
     V = np.stack([v[: P1 - 1, : N1 - 1].T for v in Vh]).astype(np.float32)
-    V[~np.isfinite(V) & (V < 0)] = -np.inf
+    if semiring != "prob":
+        V[~np.isfinite(V) & (V < 0)] = -np.inf
     return np.ascontiguousarray(V), np.asarray(lens, dtype=np.int32)
 
 
-def _need_expanded(Vhats):
-    un = _unexpand(Vhats)
+def _need_expanded(Vhats, semiring: str = "log"):
+    un = _unexpand(Vhats, semiring)
     if un is None:
         raise ValueError("V_hat is not of the form expand(V, seqlength) produces (only pdfposteriors takes arbitrary V_hat)")
     return un
@@ -666,12 +683,13 @@ def _pdfposteriors_device(bf: BatchedFSM, Vd, seqlengths):
     if B != bf.B:
         raise _lib.DimensionMismatch(-2, f"{B} matrices V_hat for a batch of {bf.B} FSMs")
     if seqlengths is None:
+        zero, one = _SEM_ZERO[bf.semiring], _SEM_ONE[bf.semiring]
         ph = Vd[:, P1 - 1, :]
-        lens = torch.isinf(ph).sum(dim=1).to(torch.int32)
+        lens = (ph == zero).sum(dim=1).to(torch.int32)
         step = torch.arange(N1, device=Vd.device)[None, :] < lens[:, None]
-        ok = bool((torch.where(step, torch.isneginf(ph), ph == 0).all() & (lens <= N1 - 1).all()).item())
+        ok = bool((torch.where(step, ph == zero, ph == one).all() & (lens <= N1 - 1).all()).item())
         if ok:  # real pdfs beyond the length are zero(K)
-            ok = bool(torch.isneginf(Vd[:, : P1 - 1, :]).masked_fill(step[:, None, :], True).all().item())
+            ok = bool((Vd[:, : P1 - 1, :] == zero).masked_fill(step[:, None, :], True).all().item())
         if not ok:
             return None
     else:
@@ -694,7 +712,8 @@ def pdfposteriors(fsm, Vhats, Chats=None, seqlengths=None):
         Chats = [(c.one_hot() or c) if isinstance(c, GeneralStateMap) else c for c in Chats]
     bf = _as_batch(fsm, Chats)
     general_c = Chats is not None and any(isinstance(c, GeneralStateMap) for c in Chats)
-    fast = not (general_c or bf.semiring == "prob" or bf.dtype == np.float64)
+    # (ProbSemiring{Float32}: the fast entry too -- the library runs the log twins of the FSMs on log V_hat, mm_pdfposteriors_f32)
+    fast = not (general_c or bf.dtype == np.float64) and (bf.semiring != "prob" or bf.has_fast_entry())
     if Vd is not None and fast:
         out = _pdfposteriors_device(bf, Vd, seqlengths)
         if out is not None:
@@ -702,7 +721,7 @@ def pdfposteriors(fsm, Vhats, Chats=None, seqlengths=None):
     Vh = [np.asarray(v.cpu() if hasattr(v, "cpu") else v) for v in Vhats]
     # the precision follows the FSM's K like the reference (src/inference.jl:147 converts V_hat to K): a Float32 FSM computes
     # in float32 whatever the dtype of V_hat (NumPy's default float64 included), a Float64 FSM in float64
-    un = _unexpand(Vh) if fast else None
+    un = _unexpand(Vh, bf.semiring) if fast else None
     if un is None:
         # a Float64 FSM, ProbSemiring, a general C_hat, or V_hat that expand() did not make: the generic entry
         return bf.pdfposteriors_generic(Vh, Chats if general_c else None)

@@ -59,10 +59,51 @@ def test_three_semirings_two_float_types(mm, wl, oracle, torch, semiring, dtype)
     assert np.allclose(ttl, t_ref, rtol=tol, atol=tol)
     for b, L in enumerate(lens):
         assert (gam[b][:, L:] == 0).all()
-    # ... and through the reference's call shape, which picks the generic entry for float64 / prob by itself
-    if dtype == np.float64 or semiring == "prob":
+    # ... and through the reference's call shape, which picks the generic entry for float64 (and for a ProbSemiring{Float64}) by itself
+    if dtype == np.float64:
         g2, t2 = mm.pdfposteriors(bf, Vh)
         assert np.array_equal(g2, gam) and np.array_equal(t2, ttl)
+        assert not bf.has_fast_entry() or semiring == "log"
+    elif semiring == "prob":
+        # ProbSemiring{Float32} with the FSM's own one-hot map and V_hat of expand()'s form: the FAST kernels (round 6) -- the
+        # library's log twins of the FSMs on log V_hat, ttl back as a probability -- asserted by name, against the float64 oracle
+        assert bf.has_fast_entry() and ("mm_lane_kernel" in bf.kernels() or "mm_wave_kernel" in bf.kernels()), bf.kernels()
+        g2, t2 = mm.pdfposteriors(bf, Vh)
+        assert g2.dtype == np.float32 and np.allclose(g2, g_ref, rtol=1e-4, atol=2e-6) and np.allclose(t2, t_ref, rtol=1e-4)
+        for b, L in enumerate(lens):
+            assert (g2[b][:, L:] == 0).all()
+        # a V_hat that expand() did not make still goes to the generic entry: the same numbers as above
+        Vx = [v.copy() for v in Vh]
+        Vx[0][-1, 0] = 0.25
+        g3, _ = mm.pdfposteriors(bf, Vx)
+        assert np.isfinite(g3).all()
+
+
+def test_prob_semiring_on_the_pair_kernels(mm, wl, oracle, torch):
+    """A ProbSemiring{Float32} denominator-sized graph on the pair kernels (mm_fbp_kernel by name: the log twin's), device-resident
+    likelihoods, against the float64 oracle run in the ProbSemiring itself; zero likelihoods (zero(K)) included; the batch answers
+    for redo counts and settings through its twin."""
+    o, _ = oracle
+    g = wl.lfmmi_denominator(600, 30, seed=4)
+    rng = np.random.default_rng(2)
+    B, N = 4, 25
+    lens = [25, 25, 11, 19]
+    lhs = [np.exp(rng.standard_normal((g.P, N))) for _ in range(B)]
+    lhs[1][3, 5] = 0.0  # a pdf that cannot emit a frame
+    (g_ref, t_ref), K = oracle_run(o, g, "prob", np.float64, lhs, lens, g.state2pdf, g.P)
+    cf = mm.compile(wl.to_fsm(mm, lin(g), "prob", np.float32), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(*([cf] * B))
+    assert bf.semiring == "prob" and "mm_fbp_kernel" in bf.kernels(), bf.kernels()
+    V = torch.from_numpy(np.stack([x.T for x in lhs]).astype(np.float32)).cuda()  # [B, N, P] likelihoods
+    lt = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    bf.reserve(N)
+    gam, ttl = bf.pdfposteriors(V, lt)
+    assert bf.last_redo_count() == 0
+    gam, ttl = gam.cpu().numpy().transpose(0, 2, 1), ttl.cpu().numpy()
+    assert np.allclose(gam, g_ref, rtol=1e-4, atol=2e-6) and np.allclose(ttl, t_ref, rtol=1e-4)
+    bf.set_exact_policy("f64_first")  # (the wide-exponent kernels of the twin)
+    g2, t2 = bf.pdfposteriors(V, lt)
+    assert bf.last_exact_first() and np.allclose(g2.cpu().numpy().transpose(0, 2, 1), g_ref, rtol=1e-4, atol=2e-6) and np.allclose(t2.cpu().numpy(), t_ref, rtol=1e-4)
 
 
 @pytest.mark.parametrize("name", ["l2r3", "rand30", "rand30m"])

@@ -49,6 +49,33 @@ ms = e0.elapsed_time(e1) / K
 flops = 2.0 * N1 * S1 * P1 * B
 res = dict(what=f"ProbSemiring float32, S1 = {S1}, P1 = {P1} (dense C_hat), N1 = {N1}, B = {B}", kernels=bf.kernels_generic(), ms_per_call=ms,
            emission_gemm_flops=flops, finite=bool(torch.isfinite(gam).all().item()))
+# ... and the same ProbSemiring{Float32} FSMs with their OWN one-hot state map and likelihoods of expand()'s form: the fast entry
+# (mm_pdfposteriors_f32 on the library's log twins, round 6) instead of the generic one
+Vf = torch.exp(0.3 * torch.randn(B, N, P, device="cuda"))
+lens = torch.full((B,), N, dtype=torch.int32, device="cuda")
+for _ in range(3):
+    bf.pdfposteriors(Vf, lens)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(K):
+    g2, t2 = bf.pdfposteriors(Vf, lens)
+e1.record()
+torch.cuda.synchronize()
+Vh = torch.zeros(B, N1, P1, device="cuda")
+Vh[:, :N, :P] = Vf
+Vh[:, N, P] = 1.0
+for _ in range(2):
+    g3, t3 = bf.pdfposteriors_ex(Vh, None)
+torch.cuda.synchronize()
+e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e2.record()
+for _ in range(3):
+    g3, t3 = bf.pdfposteriors_ex(Vh, None)
+e3.record()
+torch.cuda.synchronize()
+res["one_hot_map"] = dict(what="the FSMs' own one-hot state map, V_hat of expand()'s form", fast_entry_ms=e0.elapsed_time(e1) / K, fast_entry_kernels=bf.kernels(),
+                          generic_entry_ms=e2.elapsed_time(e3) / 3, max_abs_diff_gamma=float((g2 - g3).abs().max()),
+                          max_rel_diff_ttl=float(((t2 - t3).abs() / t3.abs().clamp_min(1e-30)).max()))
 print(json.dumps(res))
 if len(sys.argv) > 1:
     json.dump(res, open(sys.argv[1], "w"), indent=1)

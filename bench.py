@@ -488,6 +488,8 @@ def main():
         ttl = call()
         return mm.dist.allreduce_logz(ttl) if use_dist else ttl
 
+    if semiring == "log":
+        bf.team_xcd_stats()  # (team kernels: switches their same-XCD counter on; read after the timed steps)
     for _ in range(args.warmup):
         step()
     ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]

@@ -268,7 +268,8 @@ int mm_batch_last_fallback_count(mm_batch_t batch, void *stream, int64_t *n);
 int mm_batch_last_exact_first(mm_batch_t batch);
 /* Team kernels (graphs beyond one compute unit): out[0] = workgroups of the float32 team kernels' phase-A launches, since the last
  * call of this function, that found their whole team on ONE XCD (they exchange rows by plain stores through that XCD's L2; the
- * others by write-through stores), out[1] = all such workgroups.  Synchronises the device; a measurement aid (bench.py). */
+ * others by write-through stores), out[1] = all such workgroups.  The kernels count from the FIRST call of this function on (which
+ * returns zeros): a batch nobody asks carries no measurement atomics.  Synchronises the device; a measurement aid (bench.py). */
 int mm_batch_team_xcd_stats(mm_batch_t batch, int out[2]);
 
 /* Which linear-domain kernels a shared-graph batch starts with (the batches of the pair / split pair kernels; others ignore it).

@@ -294,6 +294,7 @@ struct mm_batch_s {
     bool wpair_ok = false;              // a whole batch on the exact kernels fits the wide pair kernels (mm_kernel_wpair.hip: two utterances per workgroup)
     bool quad_built = false;            // the FSMs' quad forms exist (not built for batches whose exact path is the float64 kernels)
     int *stat_dev = nullptr;            // {count, ticket, team workgroups whose team sits on ONE XCD, team workgroups} (the last two: mm_batch_team_xcd_stats)
+    bool xcd_counting = false;          // ... counted by the team kernels since mm_batch_team_xcd_stats was first called (a measurement aid: off until asked for)
     volatile int *stat_host = nullptr;  // pinned: {count of hard utterances, sequence number of the call that counted}
     int stat_seq = 0;
     int exact_first = -1;               // MM_EXACT_FIRST (under MM_DEBUG): 0 / 1 force the choice, -1: by the statistics
@@ -2367,6 +2368,7 @@ int mm_batch_team_xcd_stats(mm_batch_t h, int out[2]) {
     if (!h || !out) return fail(MM_ERR_INVALID, "mm_batch_team_xcd_stats: bad argument");
     out[0] = out[1] = 0;
     if (!h->stat_dev) return MM_OK;
+    h->xcd_counting = true;  // (the calls from here on count; the first call returns the zeros nothing has been added to)
     return no_throw("mm_batch_team_xcd_stats", [&]() {
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipDeviceSynchronize());
@@ -2671,6 +2673,7 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
             exact_first = h->exact_first >= 0 ? h->exact_first != 0 : (by_rounds && !capturing);
             p.redo2 = reinterpret_cast<int *>(tail0 + ws_tail_bytes(h) - align_up(size_t(h->B + 1) * 4, 256));
             p.stat_dev = h->stat_dev;
+            p.stat_xcd = h->xcd_counting ? 1 : 0;
             p.stat_host = h->stat_host;
             p.stat_seq = ++h->stat_seq;
             p.stat_mode = exact_first ? 1 : 0;

@@ -1269,9 +1269,9 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
                 *redo1 = 2;
             }
             if (lane == 0) ldswu(L::XFLAG, (same && !dead && !(p.x_sleep & 0x800)) ? 1u : 0u);
-            // (how often the hardware's placement puts a whole team on one XCD: counted per workgroup of the phase-A launch,
-            // read and cleared by mm_batch_team_xcd_stats -- bench.py prints it for the team workloads)
-            if (PHASE == 0 && lane == 0 && p.stat_dev) {
+            // (how often the hardware's placement puts a whole team on one XCD: counted per workgroup of the phase-A launch once
+            // mm_batch_team_xcd_stats has been called on the batch, read and cleared by it -- bench.py prints it for the team workloads)
+            if (PHASE == 0 && lane == 0 && p.stat_dev && p.stat_xcd) {
                 atomicAdd(&p.stat_dev[3], 1);
                 if (same && !dead) atomicAdd(&p.stat_dev[2], 1);
             }

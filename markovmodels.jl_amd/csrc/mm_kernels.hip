@@ -145,6 +145,7 @@ struct RunParams {
     int clear_marks;  // mm_pair_finish_kernel: 1 = a range mark is cleared when the two criteria hold; 0 = it stays (see there)
     volatile int *stat_host;
     int stat_seq, stat_mode;
+    int stat_xcd;  // != 0: the team kernels count their same-XCD workgroups in stat_dev[2..3] (on once mm_batch_team_xcd_stats has been called)
     // Pair kernels (mm_kernel_pairs.hip): ws_alpha holds [B + 1][N + 2][pair_s1p] state vectors, ws_c [B + 1][N + 2]
     // cumulative offsets; pair_hand [pairs][2 directions][2 utterances] what phase A hands to phase B; pair_zmin
     // [B][2 directions] the minimum over the frames of the per-frame log2 normaliser.

@@ -29,10 +29,12 @@ struct Lim;
 template <>
 struct Lim<float> {
     static __device__ __forceinline__ float ninf() { return -__builtin_huge_valf(); }
+    static __device__ __forceinline__ float nan() { return __builtin_nanf(""); }
 };
 template <>
 struct Lim<double> {
     static __device__ __forceinline__ double ninf() { return -__builtin_huge_val(); }
+    static __device__ __forceinline__ double nan() { return __builtin_nan(""); }
 };
 
 template <int CTRL>
@@ -76,15 +78,20 @@ struct Acc {
             s = c > Lim<T>::ninf() ? T(1) : T(0);
         }
     }
+    // (a NaN term must reach the result like in the reference's logaddexp / max -- a diverged network's outputs are not to be
+    // hidden: `x > m` is false for a NaN on either side, so NaNs are taken explicitly; once m is a NaN it stays one)
     __device__ __forceinline__ void add(T x) {  // (+)= x
         if constexpr (SR == MM_PROB) s += x;
-        else if constexpr (SR == MM_TROPICAL) m = x > m ? x : m;
+        else if constexpr (SR == MM_TROPICAL) m = (x > m || x != x) ? x : m;
         else {
             if (x > m) {
                 s = s * std::exp(m - x) + T(1);  // (m = -inf: s = 0 * 0 + 1)
                 m = x;
             } else if (x > Lim<T>::ninf()) {
-                s += std::exp(x - m);
+                s += std::exp(x - m);  // (m a NaN: s becomes one, value() returns m)
+            } else if (x != x) {
+                m = x;
+                s = T(1);
             }
         }
     }
@@ -93,10 +100,10 @@ struct Acc {
         if constexpr (SR == MM_PROB) s += partner<LEVEL>(s);
         else if constexpr (SR == MM_TROPICAL) {
             const T o = partner<LEVEL>(m);
-            m = o > m ? o : m;
+            m = (o > m || o != o) ? o : m;
         } else {
             const T om = partner<LEVEL>(m), os = partner<LEVEL>(s);
-            const T M = om > m ? om : m;
+            const T M = (om > m || om != om) ? om : m;  // (a NaN on either side wins)
             const T a = m > Lim<T>::ninf() ? s * std::exp(m - M) : T(0), b = om > Lim<T>::ninf() ? os * std::exp(om - M) : T(0);
             m = M;
             s = a + b;
@@ -105,7 +112,7 @@ struct Acc {
     __device__ __forceinline__ T value() const {
         if constexpr (SR == MM_PROB) return s;
         else if constexpr (SR == MM_TROPICAL) return m;
-        else return m > Lim<T>::ninf() ? m + std::log(s) : m;
+        else return m > Lim<T>::ninf() ? m + std::log(s) : m;  // (m a NaN: returned as it is)
     }
 };
 
@@ -127,7 +134,7 @@ __device__ __forceinline__ T sr_zero() {
 
 // c[r] = (+)_k nzVal[k] (*) b[colVal[k]] over CSR row r (src/linalg.jl:213-233): a group of 1 << LOG2G lanes per row
 template <typename T, int SR, int LOG2G>
-__global__ __launch_bounds__(256) void mm_spmv_kernel(long long rows, const int *__restrict__ rowptr, const int *__restrict__ colval,
+__global__ __launch_bounds__(256) void mm_spmv_kernel(long long rows, long long cols, const int *__restrict__ rowptr, const int *__restrict__ colval,
                                                        int base, const T *__restrict__ nzval, const T *__restrict__ b, T *__restrict__ c) {
     constexpr int G = 1 << LOG2G;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -137,7 +144,11 @@ __global__ __launch_bounds__(256) void mm_spmv_kernel(long long rows, const int 
     const long long beg = live ? (long long)rowptr[r] - base : 0, end = live ? (long long)rowptr[r + 1] - base : 0;
     Acc<T, SR> acc;
     acc.init();
-    for (long long k = beg + sub; k < end; k += G) acc.add(sr_mul<T, SR>(nzval[k], b[(long long)colval[k] - base]));
+    // (a column index outside [0, cols) -- a corrupt matrix -- contributes a NaN instead of a read out of bounds)
+    for (long long k = beg + sub; k < end; k += G) {
+        const long long j = (long long)colval[k] - base;
+        acc.add((unsigned long long)j < (unsigned long long)cols ? sr_mul<T, SR>(nzval[k], b[j]) : Lim<T>::nan());
+    }
     if constexpr (LOG2G >= 1) acc.template merge<0>();
     if constexpr (LOG2G >= 2) acc.template merge<1>();
     if constexpr (LOG2G >= 3) acc.template merge<2>();
@@ -149,7 +160,7 @@ __global__ __launch_bounds__(256) void mm_spmv_kernel(long long rows, const int 
 
 // C[i, j] = (beta (*) C[i, j]) (+) (+)_k nzVal[k] (*) B[colVal[k], j] (src/linalg.jl:240-280), column-major B and C
 template <typename T, int SR, int JT>
-__global__ __launch_bounds__(256) void mm_spmm_kernel(long long rows, long long ncols, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(256) void mm_spmm_kernel(long long rows, long long acols, long long ncols, const int *__restrict__ rowptr,
                                                        const int *__restrict__ colval, int base, const T *__restrict__ nzval,
                                                        const T *__restrict__ B, long long ldb, T *__restrict__ C, long long ldc, int beta_mode,
                                                        T beta) {
@@ -169,10 +180,12 @@ __global__ __launch_bounds__(256) void mm_spmm_kernel(long long rows, long long 
     }
     for (long long k = beg; k < end; ++k) {
         const T w = nzval[k];
-        const T *brow = B + ((long long)colval[k] - base);
+        const long long cj = (long long)colval[k] - base;
+        const bool inside = (unsigned long long)cj < (unsigned long long)acols;  // (outside: a NaN, not a read out of bounds)
+        const T *brow = B + (inside ? cj : 0);
 #pragma unroll
         for (int jj = 0; jj < JT; ++jj)
-            if (j0 + jj < ncols) acc[jj].add(sr_mul<T, SR>(w, brow[(j0 + jj) * ldb]));
+            if (j0 + jj < ncols) acc[jj].add(inside ? sr_mul<T, SR>(w, brow[(j0 + jj) * ldb]) : Lim<T>::nan());
     }
 #pragma unroll
     for (int jj = 0; jj < JT; ++jj)
@@ -186,21 +199,22 @@ __global__ void mm_fill_zero_kernel(long long n, T *dest) {
 }
 // dest[nzInd[i]] = f(nzVal[i], y[nzInd[i]]) (src/linalg.jl:320-328)
 template <typename T, int SR>
-__global__ void mm_svdv_kernel(long long nnz, const int *__restrict__ nzind, int base, const T *__restrict__ nzval, const T *__restrict__ y,
+__global__ void mm_svdv_kernel(long long n, long long nnz, const int *__restrict__ nzind, int base, const T *__restrict__ nzval, const T *__restrict__ y,
                                T *__restrict__ dest, int op) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nnz) return;
     const long long at = (long long)nzind[i] - base;
+    if ((unsigned long long)at >= (unsigned long long)n) return;  // (an index outside the vector: nothing to write to)
     dest[at] = op == 0 ? sr_mul<T, SR>(nzval[i], y[at]) : sr_div<T, SR>(nzval[i], y[at]);
 }
 
 template <typename T, int SR>
-int spmv_launch(int log2g, long long rows, const int *rowptr, const int *colval, int base, const T *nzval, const T *b, T *c, hipStream_t s) {
+int spmv_launch(int log2g, long long rows, long long cols, const int *rowptr, const int *colval, int base, const T *nzval, const T *b, T *c, hipStream_t s) {
     const long long threads = rows << log2g;
     const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
 #define MM_SPMV_CASE(L)                                                                                                  \
     case L:                                                                                                              \
-        hipLaunchKernelGGL((mm_spmv_kernel<T, SR, L>), grid, block, 0, s, rows, rowptr, colval, base, nzval, b, c);       \
+        hipLaunchKernelGGL((mm_spmv_kernel<T, SR, L>), grid, block, 0, s, rows, cols, rowptr, colval, base, nzval, b, c); \
         break;
     switch (log2g) {
         MM_SPMV_CASE(0)
@@ -267,7 +281,7 @@ int mm_spmv(int semiring, int val_bytes, int64_t rows, int64_t cols, int64_t nnz
     const int l2g = pick_log2g(rows, nnz);
     hipStream_t s = static_cast<hipStream_t>(stream);
     MM_DISPATCH(semiring, val_bytes,
-                rc = (spmv_launch<T, SR>(l2g, rows, rowptr, colval, index_base, static_cast<const T *>(nzval), static_cast<const T *>(b), static_cast<T *>(c), s)));
+                rc = (spmv_launch<T, SR>(l2g, rows, cols, rowptr, colval, index_base, static_cast<const T *>(nzval), static_cast<const T *>(b), static_cast<T *>(c), s)));
     return rc;
 }
 
@@ -293,7 +307,7 @@ int mm_spmm(int semiring, int val_bytes, int64_t rows, int64_t cols, int64_t nnz
     const dim3 grid((unsigned)((rows + 255) / 256), (unsigned)((c_cols + JT - 1) / JT)), block(256);
     if (grid.y > 65535u) return mm_fail(MM_ERR_UNSUPPORTED, "mm_spmm: more than 262 140 columns");
     MM_DISPATCH(semiring, val_bytes,
-                hipLaunchKernelGGL((mm_spmm_kernel<T, SR, JT>), grid, block, 0, s, (long long)rows, (long long)c_cols, rowptr, colval, index_base,
+                hipLaunchKernelGGL((mm_spmm_kernel<T, SR, JT>), grid, block, 0, s, (long long)rows, (long long)cols, (long long)c_cols, rowptr, colval, index_base,
                                    static_cast<const T *>(nzval), static_cast<const T *>(B), (long long)ldb, static_cast<T *>(C), (long long)ldc,
                                    beta_mode, T(beta)));
     HIP_TRY(hipGetLastError());
@@ -314,7 +328,7 @@ int mm_svdv(int semiring, int val_bytes, int op, int64_t n, int64_t nnz, const i
     MM_DISPATCH(semiring, val_bytes, {
         hipLaunchKernelGGL((mm_fill_zero_kernel<T, SR>), dim3((unsigned)((n + 255) / 256)), block, 0, s, (long long)n, static_cast<T *>(dest));  // fill!(dest, zero(K)) (:297)
         if (nnz > 0)
-            hipLaunchKernelGGL((mm_svdv_kernel<T, SR>), dim3((unsigned)((nnz + 255) / 256)), block, 0, s, (long long)nnz, nzind, index_base,
+            hipLaunchKernelGGL((mm_svdv_kernel<T, SR>), dim3((unsigned)((nnz + 255) / 256)), block, 0, s, (long long)n, (long long)nnz, nzind, index_base,
                                static_cast<const T *>(nzval), static_cast<const T *>(y), static_cast<T *>(dest), op);
     });
     HIP_TRY(hipGetLastError());

@@ -563,13 +563,21 @@ def _need_expanded(Vhats, semiring: str = "log"):
 # its fields afterwards -- the denominator graph of every call, the numerator graphs of an utterance across epochs.  Misses of
 # one call are compiled together (compile_many: host threads, one allocation, one copy).
 _COMPILED_LRU: "OrderedDict[bytes, CompiledFSM]" = None  # type: ignore[assignment]
-_COMPILED_LRU_MAX = 8192
+_COMPILED_LRU_MAX = 8192            # entries ...
+_COMPILED_LRU_MAX_BYTES = 16 << 30  # ... and an estimate of the device bytes their kernel forms hold (large graphs pin a lot of HBM each)
+_COMPILED_LRU_BYTES = 0
 _CACHE_STATS = {"hits": 0, "misses": 0, "memo_hits": 0}
+
+
+def _device_bytes_estimate(cf: "CompiledFSM") -> int:
+    """What a compiled graph holds on the device, roughly: both directions' arcs in two or three kernel forms (8 to 16 bytes per arc
+    slot and form, padded) and per-state tables."""
+    return int(96 * cf.fsm.nnz + 64 * cf.S1 + 4096)
 
 
 def compiled_cache_stats(reset: bool = False) -> dict:
     """{"hits", "misses", "memo_hits", "entries"} of the compiled-graph cache behind the reference-shaped entries."""
-    out = dict(_CACHE_STATS, entries=0 if _COMPILED_LRU is None else len(_COMPILED_LRU))
+    out = dict(_CACHE_STATS, entries=0 if _COMPILED_LRU is None else len(_COMPILED_LRU), bytes_estimate=_COMPILED_LRU_BYTES)
     if reset:
         for k in _CACHE_STATS:
             _CACHE_STATS[k] = 0
@@ -577,8 +585,9 @@ def compiled_cache_stats(reset: bool = False) -> dict:
 
 
 def compiled_cache_clear():
-    global _COMPILED_LRU
+    global _COMPILED_LRU, _COMPILED_LRU_BYTES
     _COMPILED_LRU = None
+    _COMPILED_LRU_BYTES = 0
 
 
 def _content_key(part: FSM, c: StateMap) -> bytes:
@@ -600,7 +609,7 @@ def _content_key(part: FSM, c: StateMap) -> bytes:
 
 
 def _compiled_for(parts, Cs) -> List[CompiledFSM]:
-    global _COMPILED_LRU
+    global _COMPILED_LRU, _COMPILED_LRU_BYTES
     from collections import OrderedDict
 
     if _COMPILED_LRU is None:
@@ -629,9 +638,12 @@ def _compiled_for(parts, Cs) -> List[CompiledFSM]:
             made = compile_many([g[1] for g in grp], [g[2] for g in grp]) if len(grp) > 1 else [CompiledFSM(grp[0][1], grp[0][2])]
             for (k, _, _), cf in zip(grp, made):
                 lru[k] = cf
-        while len(lru) > _COMPILED_LRU_MAX:
-            lru.popitem(last=False)
-    return [lru[k] for k in keys]
+                _COMPILED_LRU_BYTES += _device_bytes_estimate(cf)
+    out = [lru[k] for k in keys]  # (before anything is evicted: a batch larger than the bounds still gets its graphs)
+    while len(lru) > 1 and (len(lru) > _COMPILED_LRU_MAX or _COMPILED_LRU_BYTES > _COMPILED_LRU_MAX_BYTES):
+        _, old = lru.popitem(last=False)
+        _COMPILED_LRU_BYTES -= _device_bytes_estimate(old)
+    return out
 
 
 def _as_batch(fsm, Chats) -> BatchedFSM:
@@ -641,9 +653,12 @@ def _as_batch(fsm, Chats) -> BatchedFSM:
         return BatchedFSM([fsm])
     if Chats is None:
         raise TypeError("pdfposteriors(fsm::FSM, V_hats, C_hats) needs the state maps")
-    # the same FSM object with the same map objects as last time (a training loop's denominator): the batch as it was
+    # the same FSM object with the same map objects as last time (a training loop's denominator): the batch as it was -- if the
+    # object still holds what it held (a fingerprint of its arrays: their buffers, sizes and a strided sample of their values --
+    # an FSM mutated in place between calls misses here and is found, or compiled, by its content below; the reference re-reads the
+    # FSM on every call)
     memo = fsm.__dict__.get("_mm_batch_memo")
-    if memo is not None and len(memo[0]) == len(Chats) and all(a is b for a, b in zip(memo[0], Chats)):
+    if memo is not None and len(memo[0]) == len(Chats) and all(a is b for a, b in zip(memo[0], Chats)) and memo[2] == _fingerprint(fsm, Chats):
         _CACHE_STATS["memo_hits"] += 1
         return memo[1]
     # (a general sparse C_hat rides along as an argument of the generic entry; its FSM handle gets a placeholder map)
@@ -652,8 +667,26 @@ def _as_batch(fsm, Chats) -> BatchedFSM:
           for c in Chats]
     parts = split_blocks(fsm, [c.shape[0] for c in Cs])
     bf = BatchedFSM(_compiled_for(parts, Cs))
-    fsm.__dict__["_mm_batch_memo"] = (list(Chats), bf)
+    fsm.__dict__["_mm_batch_memo"] = (list(Chats), bf, _fingerprint(fsm, Chats))
     return bf
+
+
+def _fingerprint(fsm: FSM, Chats) -> tuple:
+    """Cheap (O(1) in the size of the graph) and sensitive to what in-place edits do: for every array of the FSM and of the first and
+    last state map its buffer address, size and 64 evenly spaced values."""
+    def one(a):
+        a = np.asarray(a)
+        if a.size == 0:
+            return (0, 0, b"")
+        flat = a.reshape(-1)
+        return (a.__array_interface__["data"][0], a.size, flat[:: max(1, a.size // 64)][:65].tobytes())
+
+    arrs = [fsm.colptr, fsm.rowval, fsm.nzval, fsm.alpha_idx, fsm.alpha_val]
+    for c in (Chats[0], Chats[-1]):
+        s2p = getattr(c, "state2pdf", None)
+        if s2p is not None:
+            arrs.append(s2p)
+    return tuple(one(a) for a in arrs)
 
 
 def _device_vhats(Vhats):
@@ -707,6 +740,8 @@ def pdfposteriors(fsm, Vhats, Chats=None, seqlengths=None):
     that live on the HIP device (a list of (P+1) x (N+1) tensors or one [B, P+1, N+1] tensor), with nothing but the
     compiled-graph cache between the call and the kernels (``seqlengths``: the lengths expand() was given, so that they
     need not be read back from the phony row)."""
+    if not hasattr(Vhats, "dim"):  # (a generator is read once)
+        Vhats = list(Vhats)
     Vd = _device_vhats(Vhats)
     if Chats is not None:  # general sparse maps that are one-hot after all take the fast kernels
         Chats = [(c.one_hot() or c) if isinstance(c, GeneralStateMap) else c for c in Chats]

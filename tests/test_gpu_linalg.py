@@ -177,3 +177,36 @@ def test_spmv_is_the_recursions_product(mm, wl, torch, oracle):
     got = c.cpu().numpy()
     fin = np.isfinite(ref)
     assert (got[~fin] == ref[~fin]).all() and np.allclose(got[fin], ref[fin], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("semiring", ["log", "tropical", "prob"])
+def test_nan_terms_reach_the_result(mm, torch, semiring):
+    """A NaN in b (a diverged network's output) must reach every row of c that reads it -- the reference's logaddexp / max / +
+    propagate it (Semirings.jl) -- and no other row; rows of one entry and rows whose lane groups are merged by the DPP butterflies
+    alike.  A column index outside the matrix gives NaN as well (never a read out of bounds)."""
+    rng = np.random.default_rng(4)
+    rows, cols = 70, 50
+    for mean in (1.5, 12.0, 40.0):  # lane groups of 2, 16 and 64 lanes
+        nnz_r = np.clip(rng.poisson(mean, rows), 1, cols)
+        I = np.repeat(np.arange(rows), nnz_r) + 1
+        J = np.concatenate([rng.choice(cols, n, replace=False) for n in nnz_r]) + 1
+        V = rng.standard_normal(I.size).astype(np.float32)
+        if semiring == "prob":
+            V = np.exp(V)
+        A = mm.SparseCSR.from_coo(I, J, V, (rows, cols), semiring, np.float32)
+        b = rng.standard_normal(cols).astype(np.float32)
+        if semiring == "prob":
+            b = np.exp(b)
+        bad = 7
+        b[bad] = np.nan
+        c = mm.mul_(torch.zeros(rows, device="cuda"), A, torch.from_numpy(b).cuda()).cpu().numpy()
+        reads = np.zeros(rows, bool)
+        reads[I[J == bad + 1] - 1] = True
+        assert np.isnan(c[reads]).all() and np.isfinite(c[~reads]).all(), (semiring, mean)
+        Bm = mm.linalg.colmajor(torch.from_numpy(np.stack([b, np.where(np.isnan(b), 0.5, b)], 1)).cuda())
+        C = mm.mul_(mm.linalg.colmajor(torch.zeros(rows, 2, device="cuda")), A, Bm).cpu().numpy()
+        assert np.isnan(C[reads, 0]).all() and np.isfinite(C[~reads, 0]).all() and np.isfinite(C[:, 1]).all()
+    # an index beyond the columns
+    A2 = mm.SparseCSR(np.array([1, 2, 3], np.int32), np.array([2, 9], np.int32), np.array([0.5, 0.25], np.float32), (2, 3), semiring)
+    c2 = mm.mul_(torch.zeros(2, device="cuda"), A2, torch.ones(3, device="cuda")).cpu().numpy()
+    assert np.isfinite(c2[0]) and np.isnan(c2[1])

@@ -442,6 +442,7 @@ def test_other_kernel_families_are_capturable(mm, wl, torch, kind):
         return bf.pdfposteriors(V, lens, out=gamma)
 
     a0, b0 = (x.clone() for x in call())
+    redo_eager = bf.last_redo_count() if kind != "viterbi" else 0
     assert want in bf.kernels("tropical" if kind == "viterbi" else "log"), bf.kernels()
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
@@ -457,9 +458,10 @@ def test_other_kernel_families_are_capturable(mm, wl, torch, kind):
         torch.cuda.synchronize()
         assert torch.equal(a1, a0) and torch.equal(b1, b0)
     if kind != "viterbi":
-        # (the short utterances may have a frame whose forward and backward mass overlap below 2^-20: the exact kernels, captured
-        # in the same graph, compute those again -- round 5)
-        assert bf.last_redo_count() <= 2
+        # the replay hands exactly the utterances to the exact kernels that the eager call did (the two shortest ones of the split
+        # case have a frame whose forward and backward mass overlap below 2^-20; the wave kernel marks nothing) -- and no team timed
+        # out in the replay (every utterance would be marked: the exchange areas are zeroed by the library's own kernel, round 6)
+        assert bf.last_redo_count() == redo_eager and redo_eager <= (2 if kind == "split" else 0)
 
 
 def test_tropical_beta_and_maxstateposteriors(mm, wl, oracle, torch):

@@ -399,7 +399,27 @@ def test_compiled_graph_cache_is_keyed_by_content(mm, wl):
     st = inf.compiled_cache_stats()
     assert st["misses"] == 2 and c[0] is not a[1] and c[1] is not a[2] and st["entries"] == 6
     assert inf._content_key(fsms[0], maps[0]) == inf._content_key(fsms2[0], maps2[0]) != inf._content_key(fsms[1], maps[1])
+    # the identity memo of `_as_batch` (the same FSM object with the same map objects: no hashing at all) carries a fingerprint of the
+    # object's arrays: an FSM edited IN PLACE between two calls is not served the batch of what it used to hold
+    f4 = wl.to_fsm(mm, gs[3])
+    fp = inf._fingerprint(f4, [maps[3]])
+    assert fp == inf._fingerprint(f4, [maps[3]])
+    f4.nzval[0] += 0.5
+    assert fp != inf._fingerprint(f4, [maps[3]])
+    f4.nzval[0] -= 0.5
+    f4.alpha_val[0] -= 1.0
+    assert fp != inf._fingerprint(f4, [maps[3]])
+    # the table is bounded by entries AND by an estimate of the device bytes its graphs hold
+    assert inf.compiled_cache_stats()["bytes_estimate"] > 0
+    old = inf._COMPILED_LRU_MAX_BYTES
+    inf._COMPILED_LRU_MAX_BYTES = 1
+    try:
+        d = inf._compiled_for(fsms, maps)  # (everything but the newest entry falls out; the call still gets its four graphs)
+        assert len(d) == 4 and inf.compiled_cache_stats()["entries"] == 1
+    finally:
+        inf._COMPILED_LRU_MAX_BYTES = old
     inf.compiled_cache_clear()
+    assert inf.compiled_cache_stats()["bytes_estimate"] == 0
 
 
 @pytest.mark.parametrize("gname", ["rand300", "wide", "den_wsj", "big"])

@@ -17,8 +17,7 @@
 //   * float64 accumulation and the wide format's 1022 log2 of range: no float32 marks; the range marks of the float64 kernels
 //     (decided by the same two criteria, mm_stream_finish_kernel) hand an utterance to the item kernel -- normally none;
 //   * emissions per ROW: a finish reads its pdf's staged emission from LDS (1000 pdfs: 4 KB per frame, staged by the service
-//     wave a step ahead); the state -> pdf sums of the combine are LDS float64 atomics (ds_add_f64) into per-pdf sums the service
-//     wave normalises a step later -- any number of pdfs up to 1024, no per-pdf ranges;
+//     wave a step ahead) -- any number of pdfs up to 1024; the state -> pdf sums are the separate combine kernel's (below);
 //   * BOTH recursions at once: the forward and the backward workgroup of an utterance are workgroups of ONE grid (2 B workgroups:
 //     B = 64 uses 128 compute units; two grids one after the other when 2 B exceeds the chip); each stores its normalised log2
 //     vector of every frame -- alpha~ with, beta~ without the frame's emission -- in a numbering both share (states sorted by

@@ -603,11 +603,15 @@ def test_stream_kernels(mm, wl, oracle, torch, case):
     assert "mm_stream_kernel" in bf.kernels(), bf.kernels()
     gam, ttl = bf.pdfposteriors(V, lens)
     assert bf.last_redo_count() == 0
-    if case == "big":  # (the oracle would take minutes: the item kernel is the independent implementation here)
+    if case == "big":  # (the item kernel is the independent implementation for the whole batch; the float64 oracle for one utterance)
         bi = _with_env({"MM_DEBUG": "1", "MM_KERNEL": "item"}, lambda: mm.batch(*[cfs[id(g)] for g in gs]))
         assert "mm_stream_kernel" not in bi.kernels()
         g_ref, t_ref = bi.pdfposteriors(V, lens)
         g_ref = g_ref.astype(np.float64)
+        o, oc = oracle
+        go, to = oc.batch_shared(graphs.to_oracle(o, gs[1]), gs[1].state2pdf, P, V[1:2], lens[1:2], dtype=np.float64, nthreads=4)
+        check_gamma(gam[1:2], go, lens[1:2])
+        assert np.allclose(ttl[1:2], to, rtol=1e-5, atol=1e-3)
     else:
         o, oc = oracle
         g_ref = np.zeros((B, N, P))
@@ -619,8 +623,8 @@ def test_stream_kernels(mm, wl, oracle, torch, case):
     check_gamma(gam[ok], g_ref[ok], lens[ok])
     assert np.allclose(ttl[ok], t_ref[ok], rtol=1e-5, atol=1e-3)
     assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()
-    g2, t2 = bf.pdfposteriors(V, lens)  # (float64 atomics in the per-pdf sums: the last bits may differ between runs, not more)
-    assert np.allclose(g2, gam, rtol=1e-5, atol=1e-7) and np.allclose(t2[ok], ttl[ok], rtol=1e-6)
+    g2, t2 = bf.pdfposteriors(V, lens)  # (every sum of the combine in a fixed order, float64: the same bits on every run)
+    assert np.array_equal(g2, gam) and np.array_equal(t2, ttl)
 
 
 def test_team_xcd_counter(mm, wl, torch):

@@ -412,6 +412,9 @@ int mm_debug_wave_product(mm_fsm_t fsm, int direction, const float *in, float *o
  * MM_LOG FSMs of up to 16 383 states and 1024 pdfs (MM_ERR_UNSUPPORTED otherwise).  stats (may be NULL) receives {arc slots per
  * lane summed over the 15 waves, segments, real arcs / arc slots, arc slots of the most loaded wave}. */
 int mm_debug_stream_product(mm_fsm_t fsm, int direction, const float *in, float *out, double stats[4]);
+/* ... through the forms of a TEAM of H = 1, 2 or 4 workgroups (round 6: the rows of a direction dealt to H sets, one record stream per
+ * set and wave, the sets' regions of the vector padded to multiples of 4 positions): the same product, set by set. */
+int mm_debug_stream_team_product(mm_fsm_t fsm, int H, int direction, const float *in, float *out, double stats[4]);
 
 /* Test aid (host only, no GPU): the static bound the fast kernels use to recognise dead rows without a walk --
  * the fewest arcs from an initial state to every state (direction 0) or from every state to the phony final

@@ -66,6 +66,7 @@ SYMBOLS = [
     "mm_debug_split_product",
     "mm_debug_wave_product",
     "mm_debug_stream_product",
+    "mm_debug_stream_team_product",
     "mm_debug_reach_distance",
 ]
 
@@ -179,6 +180,8 @@ def _load():
     lib.mm_debug_wave_product.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.mm_debug_stream_product.restype = C.c_int
     lib.mm_debug_stream_product.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.mm_debug_stream_team_product.restype = C.c_int
+    lib.mm_debug_stream_team_product.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     lib.mm_debug_split_product.restype = C.c_int
     lib.mm_debug_split_product.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     lib.mm_debug_row_product_ex.restype = C.c_int

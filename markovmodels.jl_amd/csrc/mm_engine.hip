@@ -162,8 +162,8 @@ struct mm_fsm_s {
     bool wave_tried = false, wave_packed = false;
     void *lane_blob = nullptr;                  // lane form (mm_kernel_lane.hip: up to 64 states): the device image, the LaneDev at its start
     bool lane_tried = false;
-    StreamForm *stream = nullptr;               // stream form (mm_stream.hip: graphs beyond the register-resident forms)
-    bool stream_tried = false;
+    StreamForm *stream_h[3] = {nullptr, nullptr, nullptr};  // stream forms (mm_stream.hip: graphs beyond the register-resident forms) for teams of 1, 2, 4 workgroups
+    bool stream_tried[3] = {false, false, false};
     RowVariant *vrow = nullptr;                 // Viterbi form (mm_kernel_vit.hip)
     bool vit_tried = false;
     int vit_n4 = 0, vit_n2 = 0;                 // its layout: positions of 4 / of 2 arc slots per wave
@@ -199,6 +199,7 @@ struct DebugOpts {
     bool bankopt = false;           // MM_BANKOPT: the pair forms choose the banks of their rows (RowPackOpts::bank_opt; an experiment, off by default)
     bool no_wpair = false;          // MM_NO_WPAIR: a whole batch on the exact kernels runs the one-utterance float64 kernels, not the wide pair kernels
     bool no_fallback = false;       // MM_NO_FALLBACK: the float64 pair kernels run, the log-domain kernels behind them do not
+    int stream_h = 0;               // MM_STREAM_H: workgroups of a team of the stream kernels (0: by the batch size)
     bool no_pdf_halves = false;     // MM_NO_PDF_HALVES: the packer does not deal a segment's rows to its half-waves by the bank pair of their pdf
     int wave_place = -1;            // MM_WAVE_PLACE: placement mode of the wave forms (-1: the packer's default)
     int exact_first = -1;           // MM_EXACT_FIRST=0/1: never / always skip the float32 pair kernels (default: by the last call's marks)
@@ -227,6 +228,7 @@ static DebugOpts read_debug_opts() {
     d.bankopt = getenv("MM_BANKOPT") != nullptr;
     d.no_fallback = getenv("MM_NO_FALLBACK") != nullptr;
     d.no_pdf_halves = getenv("MM_NO_PDF_HALVES") != nullptr;
+    if (const char *e = getenv("MM_STREAM_H")) d.stream_h = atoi(e);
     if (const char *e = getenv("MM_WAVE_PLACE")) d.wave_place = atoi(e);
     if (const char *e = getenv("MM_EXACT_FIRST")) d.exact_first = atoi(e) != 0;
     if (const char *e = getenv("MM_FINISH_COST")) d.finish_cost = atoi(e);
@@ -289,7 +291,7 @@ struct mm_batch_s {
     std::vector<UttDesc> utts_host;     // what d_utts holds
     bool items_resident = true;         // the FSMs' item forms are on the device (a batch of the wave kernel uploads them on first need)
     bool dpair_ok = false;
-    int stream_S1 = 0;
+    int stream_S1 = 0, stream_H = 1;    // ... the most states of one; workgroups of a team (mm_stream_pick_h)
     bool stream_ok = false;             // every FSM has a stream form and nothing faster takes the batch (mm_stream.hip)
     bool wpair_ok = false;              // a whole batch on the exact kernels fits the wide pair kernels (mm_kernel_wpair.hip: two utterances per workgroup)
     bool quad_built = false;            // the FSMs' quad forms exist (not built for batches whose exact path is the float64 kernels)
@@ -1147,20 +1149,22 @@ static int lane_variant(mm_fsm_t f, bool *ok) {
     return MM_OK;
 }
 
-// the stream form of an FSM (mm_stream.hip): built once; *ok = false if the graph does not fit it
-static int stream_variant(mm_fsm_t f, bool *ok) {
-    *ok = f->stream != nullptr;
-    if (f->stream || f->stream_tried) return MM_OK;
-    f->stream_tried = true;
+// the stream form of an FSM for teams of H workgroups (mm_stream.hip): built once per H; *ok = false if the graph does not fit it
+static int stream_hidx(int H) { return H == 4 ? 2 : (H == 2 ? 1 : 0); }
+static int stream_variant(mm_fsm_t f, int H, bool *ok) {
+    const int k = stream_hidx(H);
+    *ok = f->stream_h[k] != nullptr;
+    if (f->stream_h[k] || f->stream_tried[k]) return MM_OK;
+    f->stream_tried[k] = true;
     if (f->semiring != MM_LOG) return MM_OK;
     const int64_t *rp[2] = {f->mat[0].rowptr.data(), f->mat[1].rowptr.data()};
     const int32_t *cl[2] = {f->mat[0].col.data(), f->mat[1].col.data()};
     const float *vl[2] = {f->mat[0].val.data(), f->mat[1].val.data()};
     int dev = -1;
     const bool have_dev = hipGetDevice(&dev) == hipSuccess;
-    int rc = mm_stream_build(f->S1, f->P1, rp, cl, vl, f->init.data(), f->s2p.data(), have_dev, &f->stream);
+    int rc = mm_stream_build(f->S1, f->P1, rp, cl, vl, f->init.data(), f->s2p.data(), have_dev, H, &f->stream_h[k]);
     if (rc) return rc;
-    *ok = f->stream != nullptr;
+    *ok = f->stream_h[k] != nullptr;
     return MM_OK;
 }
 
@@ -1416,7 +1420,7 @@ int mm_fsm_destroy(mm_fsm_t f) {
         }
     if (f->dev_blob) (void)hipFree(f->dev_blob);
     if (f->lane_blob) (void)hipFree(f->lane_blob);
-    mm_stream_free(f->stream);
+    for (StreamForm *sf : f->stream_h) mm_stream_free(sf);
     for (auto &kv : f->variants) {
         if (kv.second->blob) (void)hipFree(kv.second->blob);
         delete kv.second;
@@ -1581,12 +1585,18 @@ int mm_debug_row_product_ex(mm_fsm_t f, int direction, int flags, const float *i
 
 int mm_debug_stream_product(mm_fsm_t f, int direction, const float *in, float *out, double stats[4]) {
     if (!f || !in || !out || (direction != 0 && direction != 1)) return fail(MM_ERR_INVALID, "mm_debug_stream_product: bad argument");
-    return no_throw("mm_debug_stream_product", [&]() {
+    return mm_debug_stream_team_product(f, 1, direction, in, out, stats);
+}
+
+int mm_debug_stream_team_product(mm_fsm_t f, int H, int direction, const float *in, float *out, double stats[4]) {
+    if (!f || !in || !out || (direction != 0 && direction != 1) || (H != 1 && H != 2 && H != 4))
+        return fail(MM_ERR_INVALID, "mm_debug_stream_team_product: bad argument");
+    return no_throw("mm_debug_stream_team_product", [&]() {
         bool ok = false;
-        int rc = stream_variant(f, &ok);
+        int rc = stream_variant(f, H, &ok);
         if (rc) return rc;
-        if (!ok) return fail(MM_ERR_UNSUPPORTED, "mm_debug_stream_product: the FSM does not fit the stream form");
-        mm_stream_eval(f->stream, direction, in, out, stats);
+        if (!ok) return fail(MM_ERR_UNSUPPORTED, "mm_debug_stream_team_product: the FSM does not fit the stream form");
+        mm_stream_eval(f->stream_h[stream_hidx(H)], direction, in, out, stats);
         return int(MM_OK);
     });
 }
@@ -2100,11 +2110,18 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
         if (h->semiring == MM_LOG && !h->lane_ok && !h->wave_ok && !h->pairs_ok && !h->rows_ok &&
             (h->dbg.kernel == DebugOpts::K_STREAM || (h->dbg.kernel == DebugOpts::K_AUTO && beyond))) {
             h->stream_ok = true;
+            // teams of 2 or 4 workgroups per utterance and direction when the batch leaves compute units idle (round 6: a direction's
+            // record stream through ONE compute unit's memory path is what bounds a frame)
+            {
+                int dev = 0, cus = 0;
+                if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->n_cus = cus;
+            }
+            h->stream_H = (h->dbg.stream_h == 1 || h->dbg.stream_h == 2 || h->dbg.stream_h == 4) ? h->dbg.stream_h : mm_stream_pick_h(B, h->n_cus);
             for (int64_t b = 0; b < B && h->stream_ok; ++b) {
                 bool ok = false;
-                int rc = stream_variant(fsms[b], &ok);
+                int rc = stream_variant(fsms[b], h->stream_H, &ok);
                 if (rc) return rc;
-                h->stream_ok = ok && mm_stream_dev(fsms[b]->stream) != nullptr;
+                h->stream_ok = ok && mm_stream_dev(fsms[b]->stream_h[stream_hidx(h->stream_H)]) != nullptr;
             }
             h->stream_S1 = int(s1_max);
         }
@@ -2132,7 +2149,7 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
             u.map_bf = qv[1]->d_map_bf;
         }
         if (h->lane_ok) u.lane = static_cast<const LaneDev *>(f->lane_blob);
-        if (h->stream_ok) u.stream = mm_stream_dev(f->stream);
+        if (h->stream_ok) u.stream = mm_stream_dev(f->stream_h[stream_hidx(h->stream_H)]);
         if (h->vit_ok) u.rv = f->vrow->rdev;
         if (h->wave_ok || h->lane_redo_wave)
             for (int d = 0; d < 2; ++d) u.rw[d] = f->wrows[d]->rdev;
@@ -2397,7 +2414,9 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
             s = "mm_wave_kernel<" + std::to_string(h->wave_nseg <= 2 ? 2 : 4) + "," + std::to_string(h->max_P1 <= 128 ? 2 : 4) +
                 (h->wave_nseg <= 2 && h->B > h->n_cus ? ",two per CU>" : ">");
         } else if (h->stream_ok) {
-            s = "mm_stream_kernel (forward and backward recursions as workgroups of one grid; arcs streamed from L2, the vector in LDS as wide-exponent "
+            s = "mm_stream_kernel (forward and backward recursions as workgroups of one grid" +
+                (h->stream_H > 1 ? ", teams of " + std::to_string(h->stream_H) + " workgroups per utterance and direction" : std::string()) +
+                "; arcs streamed from L2, the vector in LDS as wide-exponent "
                 "32-bit values), mm_stream_combine_kernel, mm_stream_finish_kernel, then for marked utterances only " + exact;
         } else if (h->pairs_ok && h->pair_H > 1) {
             const std::string k = std::to_string(mm_pair_nj(h->max_P1, h->pair_H)), H = std::to_string(h->pair_H);
@@ -2481,9 +2500,9 @@ static size_t ws_tail_bytes(mm_batch_t h) {  // longest-first order, redo marks,
 
 // (quad kernels) the emissions shifted by their per-frame maxima [B][N][P], and the maxima [B][N]
 static size_t ws_shift_bytes(mm_batch_t h, int64_t N) {
-    if (h->stream_ok) {  // (stream kernels: the backward direction's vectors and offsets, the frames' log Z)
-        size_t off[3];
-        return mm_stream_extra_bytes(h->B, h->total_s1p, N, off);
+    if (h->stream_ok) {  // (stream kernels: the backward direction's vectors and offsets, the frames' log Z, the teams' exchange area)
+        size_t off[4];
+        return mm_stream_extra_bytes(h->B, h->total_s1p, N, off, h->stream_H, h->stream_S1);
     }
     if (!h->fast_ok || !h->quad_built) return 0;
     return align_up(size_t(h->B) * size_t(N) * size_t(h->max_P1 - 1) * 4, 256) + align_up(size_t(h->B) * size_t(N) * 4, 256);
@@ -2719,14 +2738,22 @@ int mm_pdfposteriors_f32(mm_batch_t h, const float *V, int64_t vsb, int64_t vsn,
         h->last_redo = p.redo;
         h->last_z = p.pair_zmin;
         {
-            size_t off[3];
-            (void)mm_stream_extra_bytes(h->B, h->total_s1p, N, off);
+            size_t off[4];
+            (void)mm_stream_extra_bytes(h->B, h->total_s1p, N, off, h->stream_H, h->stream_S1);
             char *base = tail0 + ws_tail_bytes(h);
             p.xbuf = reinterpret_cast<float *>(base + off[0]);    // the backward direction's vectors
             p.xbuf_d = reinterpret_cast<float *>(base + off[1]);  // ... and offsets (doubles)
             p.xps = reinterpret_cast<float *>(base + off[2]);     // the frames' {log2 Z, overlap term} (doubles)
+            if (h->stream_H > 1) {  // the teams' exchange area: zeroed before every call (a zero dword = not yet arrived)
+                p.sx = reinterpret_cast<unsigned *>(base + off[3]);
+                p.sx_slot = (long long)mm_stream_slot(h->stream_S1);
+                const size_t zn = mm_stream_exchange_bytes(h->B, h->stream_H, h->stream_S1) / 16;
+                hipLaunchKernelGGL(mm_zero_kernel, dim3(unsigned(std::min<size_t>(2048, (zn + 255) / 256))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                                   reinterpret_cast<char *>(p.sx), (unsigned long long)zn);
+                HIP_TRY(hipGetLastError());
+            }
         }
-        rc = mm_launch_stream(h->B, h->n_cus, h->stream_S1, h->max_P1, p, static_cast<hipStream_t>(stream));
+        rc = mm_launch_stream(h->B, h->n_cus, h->stream_S1, h->max_P1, h->stream_H, p, static_cast<hipStream_t>(stream));
         if (rc || h->dbg.no_redo) return rc;
         return launch(mm_log_kernel<MODE_FB, 0, 0, false, false>, mm_log_kernel<MODE_FB, 0, 0, false, true>, h, p, true, pick_geometry(h).NW, stream);
     }

@@ -122,13 +122,17 @@ int mm_launch_lane(int64_t B, int max_S, const RunParams &p, hipStream_t stream)
 // the vector in LDS as wide-exponent 32-bit values, one utterance per workgroup, forward launch then backward launch
 struct StreamForm;
 size_t mm_stream_lds_bytes(int S1, int P1);
+// (H: workgroups of a team per utterance and direction -- 1, 2 or 4; the rows of a direction dealt to H sets)
 int mm_stream_build(int64_t S1, int32_t P1, const int64_t *const rowptr[2], const int32_t *const col[2], const float *const val[2],
-                    const float *init, const int32_t *s2p, bool upload, StreamForm **out);  // *out NULL: does not fit
+                    const float *init, const int32_t *s2p, bool upload, int H, StreamForm **out);  // *out NULL: does not fit
 void mm_stream_free(StreamForm *f);
 const void *mm_stream_dev(const StreamForm *f);
 void mm_stream_eval(const StreamForm *f, int d, const float *in, float *out, double stats[4]);
-size_t mm_stream_extra_bytes(int64_t B, int64_t total_s1p, int64_t N, size_t off[3]);
-int mm_launch_stream(int64_t B, int n_cus, int max_S1, int max_P1, const RunParams &p, hipStream_t st);
+int mm_stream_pick_h(int64_t B, int n_cus);
+size_t mm_stream_slot(int max_S1);
+size_t mm_stream_extra_bytes(int64_t B, int64_t total_s1p, int64_t N, size_t off[4], int H, int max_S1);
+size_t mm_stream_exchange_bytes(int64_t B, int H, int max_S1);
+int mm_launch_stream(int64_t B, int n_cus, int max_S1, int max_P1, int H, const RunParams &p, hipStream_t st);
 
 // ---- Viterbi on the row-lane form (mm_vit_tu.hip)
 struct VitLaunch {

@@ -181,6 +181,10 @@ struct RunParams {
     // frames beyond len_b are left alone instead of zeroed)
     float g_scale;
     int g_acc;
+    // stream kernels, teams of H workgroups per utterance and direction (mm_stream.hip): what the workgroups of a team send each other --
+    // [utterance][direction][2 slots][sx_slot] wide values (high dwords) by position, the step's tag in their sign bits; zeroed per call
+    unsigned *sx;
+    long long sx_slot;
 };
 
 // one thread per workgroup of a finish kernel: add `hard` to the call's count; the last workgroup publishes it to the host

@@ -43,30 +43,32 @@
 
 namespace mm {
 
-struct StreamDev {  // one direction, device pointers
+constexpr int kStreamHMax = 4;  // workgroups of a team (1: the whole direction in one workgroup)
+struct StreamDev {  // one direction and SET of rows (a team of H workgroups computes a direction: workgroup h finishes the rows of set h)
     const unsigned long long *arcs;  // [slots of all waves][64]: {4 * position of the source, high dword of the weight}
     const unsigned *seg;             // [segments][4]: arc slots, log2 lanes per row (0 or 6), first position, rows
-    const unsigned *rinfo;           // [rows] by position: pdf | position in the pdf-major numbering both directions store in << 12
-    const float *init;               // [rows] by position: alpha_hat, log2 (forward)
+    const unsigned *rinfo;           // [positions] of the WHOLE vector: pdf | position in the pdf-major numbering both directions store in << 12 (padding: ~0)
+    const float *init;               // [positions]: alpha_hat, log2 (forward; padding: -inf)
     int wave_seg0[16], wave_slot0[16];  // per compute wave: first segment / first arc slot (entry 15: the totals)
-    int rows, fpos, vb, pad;         // vb: bytes of one LDS vector
+    int rows, fpos, vb;              // positions of the whole vector (the sets' regions, each padded to a multiple of 4); the final state's; bytes of one LDS vector
+    int base, cnt;                   // this set's region of the vector: first position, rows
     float thr;
-    int pad2;
 };
 struct StreamPairDev {
-    StreamDev d[2];
+    StreamDev d[2][kStreamHMax];
     const int *pdf_ptr;  // [P1 + 1]: the states of pdf q are the pdf-major positions pdf_ptr[q] .. pdf_ptr[q + 1] - 1
-    int P1, pad;
+    int P1, H;
 };
 
 struct StreamForm {
     StreamPairDev host;   // with DEVICE pointers once uploaded
     void *blob = nullptr;
     StreamPairDev *dev = nullptr;  // the descriptor on the device (start of the blob)
-    int S1 = 0, P1 = 0;
+    int S1 = 0, P1 = 0, H = 1;
+    int npos[2] = {0, 0};          // positions of a direction's vector (regions padded to multiples of 4)
     // host copies for mm_stream_eval (test aid)
-    std::vector<unsigned long long> h_arcs[2];
-    std::vector<unsigned> h_seg[2], h_rinfo[2];
+    std::vector<unsigned long long> h_arcs[2][kStreamHMax];
+    std::vector<unsigned> h_seg[2][kStreamHMax], h_rinfo[2];
     std::vector<float> h_init;
     std::vector<int32_t> pos[2], qpos, h_pdf_ptr;
 };
@@ -83,30 +85,35 @@ static unsigned w_hi_of(double v) {  // high dword, 20 mantissa bits rounded to 
 
 static int stream_nj(int P1) { return P1 <= 128 ? 2 : (P1 <= 256 ? 4 : (P1 <= 512 ? 8 : 16)); }  // 64-lane passes over the pdfs
 size_t mm_stream_lds_bytes(int S1, int P1) {
-    const size_t vb = (size_t(4) * (size_t(S1) + 1) + 255) & ~size_t(255);
+    // (+ 12: the regions of up to four sets are padded to multiples of 4 positions)
+    const size_t vb = (size_t(4) * (size_t(S1) + 12 + 1) + 255) & ~size_t(255);
     const size_t pc = size_t(64) * size_t(stream_nj(P1));
     return 2 * vb + 8 * pc /* EM: 2 x 4 bytes per pdf */ + 256;
 }
 
-static bool stream_pack(int d, int64_t S1, const int64_t *rowptr, const int32_t *col, const float *val, std::vector<int32_t> &pos,
-                        std::vector<unsigned> &seg, int (&wave_seg0)[16], int (&wave_slot0)[16], float *wmin_out) {
-    // rows by length, longest first
-    std::vector<int32_t> rows(static_cast<size_t>(S1));
-    std::iota(rows.begin(), rows.end(), 0);
+// the rows `sub` (sorted longest first) of one set: segments of 64 rows (a whole wave for a row of more than kStreamWide arcs), dealt
+// to the waves longest-processing-time first; positions base .. base + |sub| - 1 in finishing order
+// (groups: rows of 65 .. 128 arcs get 4 lanes each, rows of 33 .. 64 two -- no segment is longer than 32 arc slots.  For the teams'
+// forms: a workgroup of a team has 1 / H of the arc slots, and a segment of 64 rows of ~128 arcs -- ONE wave's -- was then the longest
+// thing of every step: 144 of an average 105 slots per wave on a 10 000-state graph of config 3's family with teams of 2)
+static bool stream_pack(const std::vector<int32_t> &sub, int base, const int64_t *rowptr, std::vector<int32_t> &pos, std::vector<unsigned> &seg,
+                        int (&wave_seg0)[16], int (&wave_slot0)[16], bool groups) {
     auto nnz = [&](int32_t r) { return int(rowptr[r + 1] - rowptr[r]); };
-    std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return nnz(a) > nnz(b); });
     struct Seg {
-        int nsl, lg, first, n;  // first: index into `rows`
+        int nsl, lg, first, n;  // first: index into `sub`
     };
     std::vector<Seg> segs;
     size_t i = 0;
-    while (i < rows.size() && nnz(rows[i]) > kStreamWide) {
-        segs.push_back({(nnz(rows[i]) + 63) / 64, 6, int(i), 1});
+    while (i < sub.size() && nnz(sub[i]) > kStreamWide) {
+        segs.push_back({(nnz(sub[i]) + 63) / 64, 6, int(i), 1});
         ++i;
     }
-    for (; i < rows.size(); i += 64) {
-        const int n = int(std::min<size_t>(64, rows.size() - i));
-        segs.push_back({nnz(rows[i]), 0, int(i), n});
+    while (i < sub.size()) {
+        const int len = nnz(sub[i]);
+        const int lg = !groups ? 0 : (len > 64 ? 2 : (len > 32 ? 1 : 0));
+        const int n = int(std::min<size_t>(size_t(64 >> lg), sub.size() - i));
+        segs.push_back({(len + (1 << lg) - 1) >> lg, lg, int(i), n});
+        i += size_t(n);
     }
     // longest-processing-time first over the waves (a finish costs about a dozen arc slots)
     std::vector<int> order(segs.size());
@@ -119,9 +126,8 @@ static bool stream_pack(int d, int64_t S1, const int64_t *rowptr, const int32_t 
         per[w].push_back(s);
         load[w] += segs[s].nsl + 12;
     }
-    pos.assign(static_cast<size_t>(S1), -1);
     seg.clear();
-    int p0 = 0, nseg = 0, nslot = 0;
+    int p0 = base, nseg = 0, nslot = 0;
     for (int w = 0; w < kStreamWaves; ++w) {
         wave_seg0[w] = nseg;
         wave_slot0[w] = nslot;
@@ -132,7 +138,7 @@ static bool stream_pack(int d, int64_t S1, const int64_t *rowptr, const int32_t 
             seg.push_back(unsigned(sg.lg));
             seg.push_back(unsigned(p0));
             seg.push_back(unsigned(sg.n));
-            for (int k = 0; k < sg.n; ++k) pos[size_t(rows[size_t(sg.first + k)])] = p0 + k;
+            for (int k = 0; k < sg.n; ++k) pos[size_t(sub[size_t(sg.first + k)])] = p0 + k;
             p0 += sg.n;
             nslot += kStreamChunk * ((sg.nsl + 1 + kStreamChunk - 1) / kStreamChunk);  // (its arcs + the info record, in whole chunks)
             ++nseg;
@@ -140,32 +146,26 @@ static bool stream_pack(int d, int64_t S1, const int64_t *rowptr, const int32_t 
     }
     wave_seg0[kStreamWaves] = nseg;
     wave_slot0[kStreamWaves] = nslot;
-    float wmin = 0.f;
-    for (int64_t k = 0; k < rowptr[S1]; ++k)
-        if (val[k] > -INFINITY) wmin = std::min(wmin, val[k]);
-    *wmin_out = wmin;
-    (void)d;
-    (void)col;
-    return p0 == S1;
+    return p0 == base + int(sub.size());
 }
 
-static void stream_fill(int64_t S1, const int64_t *rowptr, const int32_t *col, const float *val, const std::vector<int32_t> &pos,
+// the records of one set: `order` = position -> row (-1: padding) of the whole vector, `pos` = row -> position
+static void stream_fill(const int64_t *rowptr, const int32_t *col, const float *val, const std::vector<int32_t> &pos, const std::vector<int32_t> &order,
                         const std::vector<int32_t> &qpos, const int32_t *s2p, const std::vector<unsigned> &seg,
                         const int (&wave_slot0)[16], const int (&wave_seg0)[16], std::vector<unsigned long long> &arcs) {
-    std::vector<int32_t> order(static_cast<size_t>(S1));
-    for (int64_t r = 0; r < S1; ++r) order[size_t(pos[size_t(r)])] = int32_t(r);
     arcs.assign((size_t(wave_slot0[kStreamWaves]) + 32) * 64, 0ull);  // (+ padding: the kernels' ring reads 24 records ahead)
     for (int w = 0; w < kStreamWaves; ++w) {
         size_t slot = size_t(wave_slot0[w]);
         for (int s = wave_seg0[w]; s < wave_seg0[w + 1]; ++s) {
             const unsigned nsl = seg[size_t(4 * s)], lg = seg[size_t(4 * s + 1)], p0 = seg[size_t(4 * s + 2)], n = seg[size_t(4 * s + 3)];
             const unsigned nrec = unsigned(kStreamChunk) * ((nsl + 1 + kStreamChunk - 1) / kStreamChunk);
+            const unsigned G = 1u << lg;  // lanes per row: lane l holds the arcs k * G + l % G of row l / G
             for (unsigned l = 0; l < 64; ++l) {
-                const int32_t r = lg ? order[p0] : (l < n ? order[p0 + l] : -1);
+                const int32_t r = (l >> lg) < n ? order[p0 + (l >> lg)] : -1;
                 if (r < 0) continue;
                 const int64_t b = rowptr[r], e = rowptr[r + 1];
                 for (unsigned k = 0; k < nsl; ++k) {
-                    const int64_t a = lg ? b + int64_t(k) * 64 + l : b + k;
+                    const int64_t a = b + int64_t(k) * G + (l & (G - 1));
                     if (a >= e) break;
                     const double wl = std::exp2(double(val[a]));
                     arcs[(slot + k) * 64 + l] = (static_cast<unsigned long long>(w_hi_of(wl)) << 32) | (4u * unsigned(pos[size_t(col[a])]));
@@ -178,19 +178,45 @@ static void stream_fill(int64_t S1, const int64_t *rowptr, const int32_t *col, c
     }
 }
 
-// host: pack both directions and upload.  rowptr / col / val: [0] T_hat' (forward: row j = the arcs INTO j), [1] T_hat
-// (backward), weights log2; init: dense alpha_hat (log2); s2p: state -> pdf.  *out = NULL (and MM_OK) if the graph does not fit.
+// host: pack both directions for teams of H workgroups (1, 2 or 4) and upload.  rowptr / col / val: [0] T_hat' (forward: row j = the
+// arcs INTO j), [1] T_hat (backward), weights log2; init: dense alpha_hat (log2); s2p: state -> pdf.  *out = NULL (and MM_OK) if the
+// graph does not fit.  The rows of a direction are dealt to the H sets round-robin by decreasing length (every set gets the same mix
+// of long and short rows: the workgroups of a team finish a step together); the sets' regions of the vector follow each other,
+// each padded to a multiple of 4 positions (the 16-byte granules of the exchange).  The two directions partition independently:
+// what they share is the pdf-major numbering they STORE in (the combine kernel's).
 int mm_stream_build(int64_t S1, int32_t P1, const int64_t *const rowptr[2], const int32_t *const col[2], const float *const val[2],
-                    const float *init, const int32_t *s2p, bool upload, StreamForm **out) {
+                    const float *init, const int32_t *s2p, bool upload, int H, StreamForm **out) {
     *out = nullptr;
+    if (H != 1 && H != 2 && H != 4) return MM_OK;
     if (S1 < 2 || S1 > 16383 || P1 > 1024 || mm_stream_lds_bytes(int(S1), P1) > 160 * 1024) return MM_OK;
     auto f = std::make_unique<StreamForm>();
     f->S1 = int(S1);
     f->P1 = P1;
+    f->H = H;
+    memset(&f->host, 0, sizeof(f->host));
     float wmin[2] = {0.f, 0.f};
+    std::vector<int32_t> order[2];  // position -> row (-1: padding)
     for (int d = 0; d < 2; ++d) {
-        if (!stream_pack(d, S1, rowptr[d], col[d], val[d], f->pos[d], f->h_seg[d], f->host.d[d].wave_seg0, f->host.d[d].wave_slot0, &wmin[d]))
-            return MM_OK;
+        std::vector<int32_t> rows(static_cast<size_t>(S1));
+        std::iota(rows.begin(), rows.end(), 0);
+        auto nnz = [&](int32_t r) { return int(rowptr[d][r + 1] - rowptr[d][r]); };
+        std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return nnz(a) > nnz(b); });
+        f->pos[d].assign(static_cast<size_t>(S1), -1);
+        int base = 0;
+        for (int h = 0; h < H; ++h) {
+            std::vector<int32_t> sub;
+            for (size_t i = size_t(h); i < rows.size(); i += size_t(H)) sub.push_back(rows[i]);
+            StreamDev &sd = f->host.d[d][h];
+            if (!stream_pack(sub, base, rowptr[d], f->pos[d], f->h_seg[d][h], sd.wave_seg0, sd.wave_slot0, H > 1)) return MM_OK;
+            sd.base = base;
+            sd.cnt = int(sub.size());
+            base += (int(sub.size()) + 3) & ~3;
+        }
+        f->npos[d] = base;
+        order[d].assign(size_t(base), -1);
+        for (int64_t r = 0; r < S1; ++r) order[d][size_t(f->pos[d][size_t(r)])] = int32_t(r);
+        for (int64_t k = 0; k < rowptr[d][S1]; ++k)
+            if (val[d][k] > -INFINITY) wmin[d] = std::min(wmin[d], val[d][k]);
     }
     // the numbering both directions STORE in: states sorted by pdf (the combine kernel sums a pdf's contiguous range)
     {
@@ -206,33 +232,36 @@ int mm_stream_build(int64_t S1, int32_t P1, const int64_t *const rowptr[2], cons
         }
         for (int q = 0; q < P1; ++q) f->h_pdf_ptr[size_t(q) + 1] += f->h_pdf_ptr[size_t(q)];
     }
-    for (int d = 0; d < 2; ++d)
-        stream_fill(S1, rowptr[d], col[d], val[d], f->pos[d], f->qpos, s2p, f->h_seg[d], f->host.d[d].wave_slot0, f->host.d[d].wave_seg0,
-                    f->h_arcs[d]);
-    f->h_init.assign(size_t(S1), -INFINITY);
     for (int d = 0; d < 2; ++d) {
-        f->h_rinfo[d].assign(size_t(S1), 0u);
+        for (int h = 0; h < H; ++h)
+            stream_fill(rowptr[d], col[d], val[d], f->pos[d], order[d], f->qpos, s2p, f->h_seg[d][h], f->host.d[d][h].wave_slot0, f->host.d[d][h].wave_seg0,
+                        f->h_arcs[d][h]);
+        f->h_rinfo[d].assign(size_t(f->npos[d]), 0xffffffffu);
         for (int64_t r = 0; r < S1; ++r)
             f->h_rinfo[d][size_t(f->pos[d][size_t(r)])] = unsigned(s2p[r]) | (unsigned(f->qpos[size_t(r)]) << 12);
-        StreamDev &sd = f->host.d[d];
-        sd.rows = int(S1);
-        sd.fpos = f->pos[d][size_t(S1 - 1)];
-        sd.vb = int((4 * (S1 + 1) + 255) & ~int64_t(255));
-        sd.thr = 125.f + wmin[d] + 896.f;
-        sd.pad = sd.pad2 = 0;
+        for (int h = 0; h < H; ++h) {
+            StreamDev &sd = f->host.d[d][h];
+            sd.rows = f->npos[d];
+            sd.fpos = f->pos[d][size_t(S1 - 1)];
+            sd.vb = int((4 * (int64_t(f->npos[d]) + 1) + 255) & ~int64_t(255));
+            sd.thr = 125.f + wmin[d] + 896.f;
+        }
     }
+    f->h_init.assign(size_t(f->npos[0]), -INFINITY);
     for (int64_t r = 0; r < S1; ++r) f->h_init[size_t(f->pos[0][size_t(r)])] = init[r];
     if (upload) {
         size_t off = (sizeof(StreamPairDev) + 255) & ~size_t(255);
-        size_t o_arcs[2], o_seg[2], o_rinfo[2], o_init, o_pp;
+        size_t o_arcs[2][kStreamHMax], o_seg[2][kStreamHMax], o_rinfo[2], o_init, o_pp;
         auto place = [&](size_t bytes) {
             const size_t o = off;
             off = (off + bytes + 255) & ~size_t(255);
             return o;
         };
         for (int d = 0; d < 2; ++d) {
-            o_arcs[d] = place(f->h_arcs[d].size() * 8);
-            o_seg[d] = place(f->h_seg[d].size() * 4);
+            for (int h = 0; h < H; ++h) {
+                o_arcs[d][h] = place(f->h_arcs[d][h].size() * 8);
+                o_seg[d][h] = place(f->h_seg[d][h].size() * 4);
+            }
             o_rinfo[d] = place(f->h_rinfo[d].size() * 4);
         }
         o_init = place(f->h_init.size() * 4);
@@ -242,19 +271,21 @@ int mm_stream_build(int64_t S1, int32_t P1, const int64_t *const rowptr[2], cons
         char *base = static_cast<char *>(f->blob);
         StreamPairDev dv = f->host;
         for (int d = 0; d < 2; ++d) {
-            memcpy(img.data() + o_arcs[d], f->h_arcs[d].data(), f->h_arcs[d].size() * 8);
-            memcpy(img.data() + o_seg[d], f->h_seg[d].data(), f->h_seg[d].size() * 4);
             memcpy(img.data() + o_rinfo[d], f->h_rinfo[d].data(), f->h_rinfo[d].size() * 4);
-            dv.d[d].arcs = reinterpret_cast<const unsigned long long *>(base + o_arcs[d]);
-            dv.d[d].seg = reinterpret_cast<const unsigned *>(base + o_seg[d]);
-            dv.d[d].rinfo = reinterpret_cast<const unsigned *>(base + o_rinfo[d]);
-            dv.d[d].init = reinterpret_cast<const float *>(base + o_init);
+            for (int h = 0; h < H; ++h) {
+                memcpy(img.data() + o_arcs[d][h], f->h_arcs[d][h].data(), f->h_arcs[d][h].size() * 8);
+                memcpy(img.data() + o_seg[d][h], f->h_seg[d][h].data(), f->h_seg[d][h].size() * 4);
+                dv.d[d][h].arcs = reinterpret_cast<const unsigned long long *>(base + o_arcs[d][h]);
+                dv.d[d][h].seg = reinterpret_cast<const unsigned *>(base + o_seg[d][h]);
+                dv.d[d][h].rinfo = reinterpret_cast<const unsigned *>(base + o_rinfo[d]);
+                dv.d[d][h].init = reinterpret_cast<const float *>(base + o_init);
+            }
         }
         memcpy(img.data() + o_init, f->h_init.data(), f->h_init.size() * 4);
         memcpy(img.data() + o_pp, f->h_pdf_ptr.data(), f->h_pdf_ptr.size() * 4);
         dv.pdf_ptr = reinterpret_cast<const int *>(base + o_pp);
         dv.P1 = P1;
-        dv.pad = 0;
+        dv.H = H;
         memcpy(img.data(), &dv, sizeof(dv));
         if (hipMemcpy(f->blob, img.data(), off, hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipFree(f->blob);
@@ -271,52 +302,53 @@ void mm_stream_free(StreamForm *f) {
     delete f;
 }
 const void *mm_stream_dev(const StreamForm *f) { return f ? f->dev : nullptr; }
+int mm_stream_positions(const StreamForm *f) { return f ? std::max(f->npos[0], f->npos[1]) : 0; }
 
-// test aid (host): out = M (x) in through the stream form of direction d exactly as a workgroup walks it -- wave by wave, segment by
-// segment, the records' 20-bit weights, float64 accumulation, wave-wide sums for the rows that own a wave; natural log in / out
+// test aid (host): out = M (x) in through the stream form of direction d exactly as the workgroups of a team walk it -- set by set,
+// wave by wave, segment by segment, the records' 20-bit weights, float64 accumulation, wave-wide sums for the rows that own a wave;
+// natural log in / out
 void mm_stream_eval(const StreamForm *f, int d, const float *in, float *out, double stats[4]) {
     const int S1 = f->S1;
-    std::vector<double> lin(static_cast<size_t>(S1) + 1, 0.0);
+    std::vector<double> lin(static_cast<size_t>(f->npos[d]) + 1, 0.0);
     for (int r = 0; r < S1; ++r) lin[size_t(f->pos[d][size_t(r)])] = std::exp(double(in[r]));
-    std::vector<double> res(static_cast<size_t>(S1), 0.0);
-    const StreamDev &sd = f->host.d[d];
-    long long real = 0;
-    for (int w = 0; w < kStreamWaves; ++w) {
-        size_t slot = size_t(sd.wave_slot0[w]);
-        for (int s = sd.wave_seg0[w]; s < sd.wave_seg0[w + 1]; ++s) {
-            const unsigned nsl = f->h_seg[d][size_t(4 * s)], lg = f->h_seg[d][size_t(4 * s + 1)], p0 = f->h_seg[d][size_t(4 * s + 2)],
-                           n = f->h_seg[d][size_t(4 * s + 3)];
-            double acc[64] = {0};
-            for (unsigned k = 0; k < nsl; ++k)
-                for (unsigned l = 0; l < 64; ++l) {
-                    const unsigned long long a = f->h_arcs[d][(slot + k) * 64 + l];
-                    const unsigned long long wb = (a >> 32) << 32;
-                    double wv;
-                    memcpy(&wv, &wb, 8);
-                    real += (a >> 32) != 0;
-                    acc[l] += wv * lin[size_t(unsigned(a) / 4u)];
-                }
-            if (lg) {
-                double t = 0;
-                for (double v : acc) t += v;
-                res[p0] = t;
-            } else {
-                for (unsigned l = 0; l < n; ++l) res[p0 + l] = acc[l];
+    std::vector<double> res(static_cast<size_t>(f->npos[d]), 0.0);
+    long long real = 0, slots = 0, segsum = 0;
+    int mx = 0;
+    for (int h = 0; h < f->H; ++h) {
+        const StreamDev &sd = f->host.d[d][h];
+        for (int w = 0; w < kStreamWaves; ++w) {
+            size_t slot = size_t(sd.wave_slot0[w]);
+            for (int s = sd.wave_seg0[w]; s < sd.wave_seg0[w + 1]; ++s) {
+                const unsigned nsl = f->h_seg[d][h][size_t(4 * s)], lg = f->h_seg[d][h][size_t(4 * s + 1)], p0 = f->h_seg[d][h][size_t(4 * s + 2)],
+                               n = f->h_seg[d][h][size_t(4 * s + 3)];
+                double acc[64] = {0};
+                for (unsigned k = 0; k < nsl; ++k)
+                    for (unsigned l = 0; l < 64; ++l) {
+                        const unsigned long long a = f->h_arcs[d][h][(slot + k) * 64 + l];
+                        const unsigned long long wb = (a >> 32) << 32;
+                        double wv;
+                        memcpy(&wv, &wb, 8);
+                        real += (a >> 32) != 0;
+                        acc[l] += wv * lin[size_t(unsigned(a) / 4u)];
+                    }
+                for (unsigned l = 0; l < 64; ++l)  // (the lanes of a row's group add up)
+                    if ((l >> lg) < n) res[p0 + (l >> lg)] += acc[l];
+                slot += size_t(kStreamChunk) * ((nsl + 1 + kStreamChunk - 1) / kStreamChunk);  // (whole chunks: arcs, padding, the info record)
             }
-            slot += size_t(kStreamChunk) * ((nsl + 1 + kStreamChunk - 1) / kStreamChunk);  // (whole chunks: arcs, padding, the info record)
+            mx = std::max(mx, sd.wave_slot0[w + 1] - sd.wave_slot0[w]);
         }
+        slots += sd.wave_slot0[kStreamWaves];
+        segsum += sd.wave_seg0[kStreamWaves];
     }
     for (int r = 0; r < S1; ++r) {
         const double v = res[size_t(f->pos[d][size_t(r)])];
         out[r] = v > 0 ? float(std::log(v)) : -INFINITY;
     }
     if (stats) {
-        stats[0] = double(sd.wave_slot0[kStreamWaves]);                      // arc slots per lane, all waves
-        stats[1] = double(sd.wave_seg0[kStreamWaves]);                       // segments
-        stats[2] = double(real) / (double(sd.wave_slot0[kStreamWaves]) * 64);  // real arcs / arc slots
-        int mx = 0;
-        for (int w = 0; w < kStreamWaves; ++w) mx = std::max(mx, sd.wave_slot0[w + 1] - sd.wave_slot0[w]);
-        stats[3] = double(mx);                                               // slots of the most loaded wave
+        stats[0] = double(slots);                         // arc slots per lane, all waves of all sets
+        stats[1] = double(segsum);                        // segments
+        stats[2] = double(real) / (double(slots) * 64);   // real arcs / arc slots
+        stats[3] = double(mx);                            // slots of the most loaded wave (of any set)
     }
 }
 
@@ -344,20 +376,33 @@ __device__ __forceinline__ double *stream_offs(const RunParams &p, int dir) { re
 // The record stream of a wave: per segment its arc records, then ONE info record {0, pdf | pdf-major position << 12} of the rows
 // the lanes finish -- everything a finish needs arrives in the ring, nothing is loaded inside it: a load issued in the middle of
 // the stream can only be waited for by draining the ring (the counter is in order), 10 drains per wave and frame.
-template <int NJ>
+// H > 1 (round 6): a direction of an utterance is a TEAM of H workgroups -- when the batch leaves compute units idle (2 B H <= their
+// number).  Workgroup h streams the arcs INTO the rows of set h only (a direction's records are what bounds a frame: 1.3 MB through one
+// compute unit's vector memory path for 10 000 states) and finishes them; every finish also stores its value -- the step's tag in the
+// sign bit: the values are >= 0 -- into the team's exchange slot of the step (write-through), and after its own arcs every compute
+// wave polls its share of the OTHER sets' regions (16-byte sc1 loads: 4 positions) and writes them into the workgroup's LDS vector;
+// the step's barrier then releases everybody with the complete vector.  The protocol is the split pair kernels' (mm_kernel_pairs.hip):
+// two slots by the parity of the step, the tag flips with every reuse, the areas are zeroed before every call, a poll that outlasts
+// RunParams::x_timeout marks the utterance (redo = 2: the item kernel computes it) and waits no more.  Service waves: every workgroup
+// of a team stages the emissions and predicts the normalisers for itself -- from the same complete vector: the same bits.
+template <int NJ, int H>
 __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_base) {
     extern __shared__ float lds[];
     using L = StreamLay<NJ>;
     constexpr int C = kStreamChunk, K = 6;  // records per chunk, chunks in flight per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool service = wave == kStreamWaves;
-    // (one grid holds both directions -- the first B workgroups forward, the second B backward -- or dir_base says which)
-    const int DIR = uni(dir_base >= 0 ? dir_base : ((int)blockIdx.x >= p.B ? 1 : 0));
-    const int ui = (int)blockIdx.x - (dir_base < 0 && DIR ? p.B : 0);
+    // (one grid holds both directions -- the first B teams forward, the second B backward -- or dir_base says which; the H workgroups
+    // of a team are 8 blocks apart: the dispatcher deals consecutive workgroups to the XCDs in turn, so these share one and its L2)
+    const int grp = (int)blockIdx.x / (8 * H), rem = (int)blockIdx.x % (8 * H);
+    const int hset = H > 1 ? uni(rem / 8) : 0, team = H > 1 ? grp * 8 + rem % 8 : (int)blockIdx.x;
+    if (team >= (dir_base >= 0 ? p.B : 2 * p.B)) return;
+    const int DIR = uni(dir_base >= 0 ? dir_base : (team >= p.B ? 1 : 0));
+    const int ui = team - (dir_base < 0 && DIR ? p.B : 0);
     const int b = uni(p.order ? p.order[ui] : ui);
     const UttDesc &ud = p.utts[b];
     const StreamPairDev *spd = uni(reinterpret_cast<const StreamPairDev *>(ud.stream));
-    const StreamDev &sd = spd->d[DIR];
+    const StreamDev &sd = spd->d[DIR][hset];
     const int S1 = uni(sd.rows), P1 = uni(ud.P1), P = P1 - 1, S1p = uni(ud.S1p);
     const unsigned VB = (unsigned)uni(sd.vb), FIX = 2u * VB;
     int len = uni(p.lens ? p.lens[b] : p.N);
@@ -373,6 +418,7 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_ba
     if (len == 0) return;  // no frame: no path of length 0 (the combine / finish kernels write ttl = -inf and the zeros)
     for (unsigned q = tid * 4u; q < FIX + L::TOTAL; q += 4096u) ldsw(q, 0.f);
     __syncthreads();
+    MM_STAMP_DECL;  // (diagnostic build: [0] arcs + finishes / staging, [1] waiting for the team's rows, [2] at the barrier)
 
     if (service) {
         // ================= service wave: emissions, normalisers, offsets =================
@@ -412,19 +458,22 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_ba
             cum += (double)S + (double)E;
             // the offset that turns the step's stored vector into log2 values: forward, p = s * factor, normaliser and emission
             // included; backward, the sum s itself -- beta~ without the frame's emission -- before either
-            if (lane == 0) offs[f] = DIR ? before : cum;
+            if (lane == 0 && hset == 0) offs[f] = DIR ? before : cum;  // (every workgroup of a team has the same numbers: the first stores them)
         };
         if (DIR == 0) stage(1, 0.f, false);  // step 1: alpha_hat (*) lhs[:, 1] needs the emissions of frame 1 (nothing but E is subtracted)
         __syncthreads();  // (1)
         if (2 <= NF) stage(2, 0.f, true);
         __syncthreads();  // (2) the starting vector is in LDS
+        MM_STAMP_RESET;
         for (int t = 2; t <= NF; ++t) {
             // the normaliser of step t + 1 from the maximum of the vector of step t - 1 (complete since the last barrier)
             const unsigned mxa = FIX + L::MX((t - 1) & 1);
             const float mx = w_log2_hi(ldsru(mxa));
             if (lane == 0) ldswu(mxa, 0u);
             if (t + 1 <= NF) stage(t + 1, norm.next(mx), true);
+            MM_STAMP(0);
             __syncthreads();
+            MM_STAMP(2);
         }
     } else {
         // ================= compute waves =================
@@ -436,14 +485,15 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_ba
             const auto rinfo = as_global(uni(sd.rinfo));
             const auto ini = as_global(uni(sd.init));
             const gfptr rows_g = (gfptr)(__UINTPTR_TYPE__)rows;
-            for (int i = tid; i < S1; i += 64 * kStreamWaves) {
+            for (int i = tid; i < S1; i += 64 * kStreamWaves) {  // (every workgroup of a team: the whole vector)
                 const unsigned info = rinfo[i];
+                if (info == 0xffffffffu) continue;  // (padding between the sets' regions: stays 0)
                 const float v0 = ini[i] + ldsr(FIX + L::EM(1) + 4u * (info & 0xfffu));
                 worst = __builtin_fmaxf(worst, __builtin_fmaf(__builtin_fabsf(v0), 0.f, __builtin_fabsf(v0)));
                 const unsigned hi = w_exp2_hi(v0);
                 vmax = vmax > hi ? vmax : hi;
                 ldswu(VB * 1u + 4u * (unsigned)i, hi);
-                rows_g[(long long)0 * S1p + (info >> 12)] = __builtin_bit_cast(float, hi);  // (the stored vectors: wide values)
+                if (hset == 0) rows_g[(long long)0 * S1p + (info >> 12)] = __builtin_bit_cast(float, hi);  // (the stored vectors: wide values)
             }
         } else {  // B[:, N+1] = one at the final state   (src/inference.jl:104)
             if (tid == 0) {
@@ -476,11 +526,17 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_ba
         double eop = 0.0;  // ... and of a finish's emission factor
         asm volatile("" : "+v"(eop));
         unsigned smin = 0xffffffffu;
+        bool cdead = false;  // (teams) a poll of this wave timed out: it waits no more
+        MM_STAMP_RESET;
         for (int t = 2; t <= NF; ++t) {
             const unsigned rd = VB * (unsigned)((t - 1) & 1), wr = VB * (unsigned)(t & 1);
             const int f = frame_of(t);
             const unsigned emb = FIX + L::EM(t & 1);
             const gfptr rowf = (gfptr)(__UINTPTR_TYPE__)(rows + (long long)(f - 1) * S1p);
+            // (teams) the slot of the step in the team's exchange area, and the step's tag as a sign bit
+            typedef __attribute__((address_space(1))) unsigned gu32;
+            gu32 *const xslot = H > 1 ? (gu32 *)(__UINTPTR_TYPE__)(p.sx + ((long long)(2 * b + DIR) * 2 + (t & 1)) * p.sx_slot) : nullptr;
+            const unsigned xtag = (H > 1 && split_tag(t, 1, 1)) ? 0x80000000u : 0u;
             // the segment the wave is in
             int sg = seg0;
             unsigned s_lg = 0, s_p0 = 0, s_n = 0;
@@ -496,9 +552,14 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_ba
             double acc = 0.0;
             auto finish = [&](unsigned info) {
                 double s0 = acc;
-                if (s_lg) s0 = dwave_sum_rl(s0);
-                const bool mine = s_lg ? lane == 0 : (unsigned)lane < s_n;
-                const unsigned posi = s_p0 + (s_lg ? 0u : (unsigned)lane);
+                // (the lanes of a row's group: the whole wave, or -- the teams' forms -- 4 or 2 neighbours; s_lg is a scalar)
+                if (s_lg == 6) s0 = dwave_sum_rl(s0);
+                else if (s_lg) {
+                    s0 = dpp_add_d<MM_DPP_XOR1, 0xF>(s0);
+                    if (s_lg == 2) s0 = dpp_add_d<MM_DPP_XOR2, 0xF>(s0);
+                }
+                const bool mine = (lane & ((1 << s_lg) - 1)) == 0 && ((unsigned)lane >> s_lg) < s_n;
+                const unsigned posi = s_p0 + ((unsigned)lane >> s_lg);
                 // forward: (T' alpha) (*) lhs (src/inference.jl:70-71); backward: T (B (*) lhs) (:106-107), the emission is
                 // multiplied in for the next step's product only
                 mm_u32x2 eo = __builtin_bit_cast(mm_u32x2, eop);
@@ -513,6 +574,7 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_ba
                     const unsigned hi = __builtin_bit_cast(mm_u32x2, p0).y;
                     vmax = vmax > hi ? vmax : hi;
                     ldswu(wr + 4u * posi, hi);
+                    if constexpr (H > 1) __hip_atomic_store(xslot + posi, hi | xtag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the row for the team)
                     rowf[info >> 12] = __builtin_bit_cast(float, DIR ? sh : hi);  // the vector that is combined, in the pdf-major numbering
                 }
                 acc = 0.0;
@@ -572,17 +634,65 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_ba
                     }
                 }
             }
+            MM_STAMP(0);
+            if constexpr (H > 1) {
+                // the rows of the other sets of this step: chunk j (64 granules of 4 positions) of the q-th other set, dealt to the
+                // compute waves in turn -- all chunks are polled at the same time by waves that have nothing else to do until the barrier
+                typedef unsigned mm_u32x4 __attribute__((ext_vector_type(4)));
+                const unsigned tg = xtag >> 31;
+                int item = 0;
+#pragma unroll
+                for (int q = 0; q < H - 1; ++q) {
+                    const int g = q < hset ? q : q + 1;
+                    const int gb = uni(spd->d[DIR][g].base), gn = uni(spd->d[DIR][g].cnt);
+                    for (int j = 0; j * 256 < gn; ++j, ++item) {
+                        if (item % kStreamWaves != wave) continue;
+                        const unsigned at = (unsigned)gb + 256u * (unsigned)j + 4u * (unsigned)lane;
+                        const int left = gn - (256 * j + 4 * lane);  // rows of the set from this granule on (the last granule may hold padding, which nobody stores)
+                        bool pend = left > 0;
+                        if (cdead || __builtin_amdgcn_ballot_w64(pend) == 0ull) continue;
+                        const unsigned off = pend ? 4u * at : 4u * (unsigned)gb;
+                        const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
+                        const gu32 *const xsrc = uni(xslot);
+                        for (;;) {
+                            mm_u32x4 v;
+                            asm volatile("global_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(off), "s"(xsrc) : "memory");
+                            if (pend && (v.x >> 31) == tg && (left < 2 || (v.y >> 31) == tg) && (left < 3 || (v.z >> 31) == tg) && (left < 4 || (v.w >> 31) == tg)) {
+                                mm_u32x4 w = {v.x & 0x7fffffffu, left < 2 ? 0u : v.y & 0x7fffffffu, left < 3 ? 0u : v.z & 0x7fffffffu, left < 4 ? 0u : v.w & 0x7fffffffu};
+                                *(__attribute__((address_space(3))) mm_u32x4 *)(__UINTPTR_TYPE__)(wr + 4u * at) = w;
+                                const unsigned m01 = w.x > w.y ? w.x : w.y, m23 = w.z > w.w ? w.z : w.w;
+                                vmax = vmax > m01 ? vmax : m01;
+                                vmax = vmax > m23 ? vmax : m23;
+                                pend = false;
+                            }
+                            if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
+                            if (__builtin_amdgcn_s_memrealtime() - tstart > p.x_timeout) {
+                                cdead = true;  // the team is not running together: the item kernel computes the utterance
+                                if (lane == 0) p.redo[b] = 2;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                }
+            }
             {
                 const unsigned m = wave_max_u32(vmax);
                 if (lane == 0 && m) lds_atomic_max_u32(FIX + L::MX(t & 1), m);
                 vmax = 0u;
             }
+            MM_STAMP(1);
             __syncthreads();
+            MM_STAMP(2);
         }
         // (sums down to 2^-(thr + MM_WLINF_EMIN), factors down to 2^MM_WLINF_EMIN: every non-zero value of a vector >= 2^-thr)
         const unsigned sthr = ((unsigned)(1023 - (int)(thr + MM_WLINF_EMIN < 1.f ? 1.f : thr + MM_WLINF_EMIN)) << 20) - 1u;
         if (__builtin_amdgcn_ballot_w64(worst > thr || smin < sthr) != 0ull && lane == 0) p.redo[b] = 1;
     }
+#ifdef MM_STAMPS
+    if (p.dbg && lane == 0 && hset == 0)  // [utterance][direction][wave][section]: the first workgroup of every team
+        for (int k = 0; k < 8; ++k) p.dbg[(((long long)b * 2 + DIR) * 16 + wave) * 8 + k] = stamp_acc[k];
+#endif
 }
 
 // C' * (A .* B), the per-frame sums, the division and exp (src/inference.jl:154-160) from the two directions' stored vectors:
@@ -678,18 +788,19 @@ static __global__ void __launch_bounds__(256) mm_stream_finish_kernel(RunParams 
         p.gamma[gbase + (len + q / P) * p.gsn + (q % P) * p.gsp] = 0.f;
 }
 
-// both recursions in ONE grid when the chip holds them (2 B workgroups of one per compute unit), else one grid per direction
-template <int NJ>
+// both recursions in ONE grid when the chip holds them (2 B H workgroups of one per compute unit), else one grid per direction
+template <int NJ, int H>
 static int launch_stream_nj(int64_t B, int n_cus, size_t lds, const RunParams &p, hipStream_t st) {
-    auto k = mm_stream_kernel<NJ>;
+    auto k = mm_stream_kernel<NJ, H>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-    if (2 * B <= int64_t(n_cus)) {
-        hipLaunchKernelGGL(k, dim3(unsigned(2 * B)), dim3(1024), lds, st, p, -1);
+    auto grid = [&](int64_t teams) { return dim3(unsigned(H > 1 ? (teams + 7) / 8 * 8 * H : teams)); };  // (teams: groups of 8, their workgroups 8 apart)
+    if (2 * B * H <= int64_t(n_cus) || H > 1) {  // (a team's workgroups must run together: H > 1 is chosen only when everything fits, mm_stream_pick_h)
+        hipLaunchKernelGGL(k, grid(2 * B), dim3(1024), lds, st, p, -1);
         HIP_TRY(hipGetLastError());
     } else {
-        hipLaunchKernelGGL(k, dim3(unsigned(B)), dim3(1024), lds, st, p, 0);
+        hipLaunchKernelGGL(k, grid(B), dim3(1024), lds, st, p, 0);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k, dim3(unsigned(B)), dim3(1024), lds, st, p, 1);
+        hipLaunchKernelGGL(k, grid(B), dim3(1024), lds, st, p, 1);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(mm_stream_combine_kernel, dim3(unsigned(B), unsigned((p.N + kStreamCombineFrames - 1) / kStreamCombineFrames)), dim3(1024), 0, st, p);
@@ -698,25 +809,40 @@ static int launch_stream_nj(int64_t B, int n_cus, size_t lds, const RunParams &p
     HIP_TRY(hipGetLastError());
     return MM_OK;
 }
+// workgroups per team for a batch of B utterances on n_cus compute units: as many as leave every workgroup of both directions its own
+// compute unit (B = 64 on 256: 2; B <= 32: 4)
+int mm_stream_pick_h(int64_t B, int n_cus) { return 2 * B * 4 <= int64_t(n_cus) ? 4 : (2 * B * 2 <= int64_t(n_cus) ? 2 : 1); }
 // extra workspace of a stream batch behind the common one: the backward direction's vectors [sum S1p][N + 1] floats and offsets
-// [B][N + 2] doubles, the frames' {log2 Z, overlap term} [B][N + 2][2] doubles
-size_t mm_stream_extra_bytes(int64_t B, int64_t total_s1p, int64_t N, size_t off[3]) {
+// [B][N + 2] doubles, the frames' {log2 Z, overlap term} [B][N + 2][2] doubles, (teams) the exchange area [B][2][2 slots][slot] dwords
+size_t mm_stream_extra_bytes(int64_t B, int64_t total_s1p, int64_t N, size_t off[4], int H, int max_S1) {
     auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
     off[0] = 0;
     off[1] = up(size_t(total_s1p) * size_t(N + 1) * 4);
     off[2] = off[1] + up(size_t(B) * size_t(N + 2) * 8);
-    return off[2] + up(size_t(B) * size_t(N + 2) * 16);
+    off[3] = off[2] + up(size_t(B) * size_t(N + 2) * 16);
+    return off[3] + (H > 1 ? up(size_t(B) * 4 * mm_stream_slot(max_S1) * 4) : 0);
 }
-int mm_launch_stream(int64_t B, int n_cus, int max_S1, int max_P1, const RunParams &p, hipStream_t st) {
+size_t mm_stream_slot(int max_S1) { return (size_t(max_S1) + 16 + 63) & ~size_t(63); }  // dwords of one exchange slot (positions incl. padding)
+size_t mm_stream_exchange_bytes(int64_t B, int H, int max_S1) { return H > 1 ? ((size_t(B) * 4 * mm_stream_slot(max_S1) * 4 + 255) & ~size_t(255)) : 0; }
+int mm_launch_stream(int64_t B, int n_cus, int max_S1, int max_P1, int H, const RunParams &p, hipStream_t st) {
     const size_t lds = mm_stream_lds_bytes(max_S1, max_P1);
     if (lds > 160 * 1024 || max_P1 > 1024) return mm_fail(MM_ERR_UNSUPPORTED, "stream kernel: LDS");
     if ((p.N + kStreamCombineFrames - 1) / kStreamCombineFrames > 65535) return mm_fail(MM_ERR_UNSUPPORTED, "stream kernel: more than 524 280 frames");
+#define MM_STREAM_CASE(NJ_)                                                          \
+    case NJ_:                                                                        \
+        if (H == 4) return launch_stream_nj<NJ_, 4>(B, n_cus, lds, p, st);           \
+        if (H == 2) return launch_stream_nj<NJ_, 2>(B, n_cus, lds, p, st);           \
+        return launch_stream_nj<NJ_, 1>(B, n_cus, lds, p, st);
     switch (stream_nj(max_P1)) {
-        case 2: return launch_stream_nj<2>(B, n_cus, lds, p, st);
-        case 4: return launch_stream_nj<4>(B, n_cus, lds, p, st);
-        case 8: return launch_stream_nj<8>(B, n_cus, lds, p, st);
-        default: return launch_stream_nj<16>(B, n_cus, lds, p, st);
+        MM_STREAM_CASE(2)
+        MM_STREAM_CASE(4)
+        MM_STREAM_CASE(8)
+        default:
+            if (H == 4) return launch_stream_nj<16, 4>(B, n_cus, lds, p, st);
+            if (H == 2) return launch_stream_nj<16, 2>(B, n_cus, lds, p, st);
+            return launch_stream_nj<16, 1>(B, n_cus, lds, p, st);
     }
+#undef MM_STREAM_CASE
 }
 
 }  // namespace mm

@@ -108,13 +108,14 @@ class CompiledFSM:
         check(lib.mm_debug_reach_distance(self._h, direction, out.ctypes.data))
         return out
 
-    def stream_product(self, x: np.ndarray, direction: int = 0):
-        """Host evaluation of the product through the stream form of the stream kernels (test aid).  Returns (out, stats = [arc slots
-        per lane over all waves, segments, real arcs / arc slots, slots of the most loaded wave])."""
+    def stream_product(self, x: np.ndarray, direction: int = 0, H: int = 1):
+        """Host evaluation of the product through the stream form of the stream kernels, for teams of H = 1, 2 or 4 workgroups (test
+        aid).  Returns (out, stats = [arc slots per lane over all waves and sets, segments, real arcs / arc slots, slots of the most
+        loaded wave])."""
         x = np.ascontiguousarray(x, dtype=np.float32)
         out = np.empty(self.S1, dtype=np.float32)
         stats = np.zeros(4, dtype=np.float64)
-        check(lib.mm_debug_stream_product(self._h, direction, x.ctypes.data, out.ctypes.data, stats.ctypes.data))
+        check(lib.mm_debug_stream_team_product(self._h, int(H), direction, x.ctypes.data, out.ctypes.data, stats.ctypes.data))
         return out, stats
 
     def quad_product(self, x: np.ndarray, direction: int = 0, KQ: int = 5):

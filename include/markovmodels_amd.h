@@ -409,7 +409,7 @@ int mm_debug_wave_product(mm_fsm_t fsm, int direction, const float *in, float *o
 /* Test aid (host only, no GPU): the product evaluated THROUGH THE STREAM FORM of the stream kernels (mm_stream.hip: rows sorted
  * by length and cut into segments of 64, one lane per row, rows of more than 128 arcs on a whole wave; 8-byte arc records
  * {LDS address of the source, high dword of the weight's double}; float64 accumulation) exactly as a workgroup walks it.
- * MM_LOG FSMs of up to 16 383 states and 1024 pdfs (MM_ERR_UNSUPPORTED otherwise).  stats (may be NULL) receives {arc slots per
+ * MM_LOG FSMs of up to 16 370 states and 1024 pdfs (MM_ERR_UNSUPPORTED otherwise).  stats (may be NULL) receives {arc slots per
  * lane summed over the 15 waves, segments, real arcs / arc slots, arc slots of the most loaded wave}. */
 int mm_debug_stream_product(mm_fsm_t fsm, int direction, const float *in, float *out, double stats[4]);
 /* ... through the forms of a TEAM of H = 1, 2 or 4 workgroups (round 6: the rows of a direction dealt to H sets, one record stream per

@@ -45,7 +45,10 @@ namespace mm {
 
 constexpr int kStreamHMax = 4;  // workgroups of a team (1: the whole direction in one workgroup)
 struct StreamDev {  // one direction and SET of rows (a team of H workgroups computes a direction: workgroup h finishes the rows of set h)
-    const unsigned long long *arcs;  // [slots of all waves][64]: {4 * position of the source, high dword of the weight}
+    // the record stream, 6 bytes per arc slot (round 6; 8 until then: the stream's bytes through ONE compute unit's vector memory path are
+    // what bounds a frame): per chunk of 4 slots [64 lanes][4] high dwords of the weights (16 bytes per lane: one dwordx4 load), then
+    // [64 lanes][4] 16-bit LDS byte offsets of the sources (8 bytes per lane: one dwordx2 load) -- 384 dwords per chunk
+    const unsigned *arcs;
     const unsigned *seg;             // [segments][4]: arc slots, log2 lanes per row (0 or 6), first position, rows
     const unsigned *rinfo;           // [positions] of the WHOLE vector: pdf | position in the pdf-major numbering both directions store in << 12 (padding: ~0)
     const float *init;               // [positions]: alpha_hat, log2 (forward; padding: -inf)
@@ -188,7 +191,8 @@ int mm_stream_build(int64_t S1, int32_t P1, const int64_t *const rowptr[2], cons
                     const float *init, const int32_t *s2p, bool upload, int H, StreamForm **out) {
     *out = nullptr;
     if (H != 1 && H != 2 && H != 4) return MM_OK;
-    if (S1 < 2 || S1 > 16383 || P1 > 1024 || mm_stream_lds_bytes(int(S1), P1) > 160 * 1024) return MM_OK;
+    // (16-bit LDS byte offsets in the records: 4 * position <= 65 532, positions include up to 12 of padding)
+    if (S1 < 2 || S1 > 16370 || P1 > 1024 || mm_stream_lds_bytes(int(S1), P1) > 160 * 1024) return MM_OK;
     auto f = std::make_unique<StreamForm>();
     f->S1 = int(S1);
     f->P1 = P1;
@@ -259,7 +263,7 @@ int mm_stream_build(int64_t S1, int32_t P1, const int64_t *const rowptr[2], cons
         };
         for (int d = 0; d < 2; ++d) {
             for (int h = 0; h < H; ++h) {
-                o_arcs[d][h] = place(f->h_arcs[d][h].size() * 8);
+                o_arcs[d][h] = place(f->h_arcs[d][h].size() / 4 * 24);  // (6 bytes per arc slot and lane)
                 o_seg[d][h] = place(f->h_seg[d][h].size() * 4);
             }
             o_rinfo[d] = place(f->h_rinfo[d].size() * 4);
@@ -273,9 +277,22 @@ int mm_stream_build(int64_t S1, int32_t P1, const int64_t *const rowptr[2], cons
         for (int d = 0; d < 2; ++d) {
             memcpy(img.data() + o_rinfo[d], f->h_rinfo[d].data(), f->h_rinfo[d].size() * 4);
             for (int h = 0; h < H; ++h) {
-                memcpy(img.data() + o_arcs[d][h], f->h_arcs[d][h].data(), f->h_arcs[d][h].size() * 8);
+                {   // the device's 6-byte form of the records: per chunk [64][4] weights' high dwords, [64][4] 16-bit byte offsets
+                    const std::vector<unsigned long long> &a = f->h_arcs[d][h];
+                    unsigned *dst = reinterpret_cast<unsigned *>(img.data() + o_arcs[d][h]);
+                    const size_t nch = a.size() / (size_t(kStreamChunk) * 64);
+                    for (size_t c = 0; c < nch; ++c)
+                        for (unsigned l = 0; l < 64; ++l) {
+                            unsigned short *po = reinterpret_cast<unsigned short *>(dst + c * 384 + 256) + 4 * l;
+                            for (int j = 0; j < kStreamChunk; ++j) {
+                                const unsigned long long r = a[(c * kStreamChunk + size_t(j)) * 64 + l];
+                                dst[c * 384 + 4 * l + unsigned(j)] = unsigned(r >> 32);
+                                po[j] = static_cast<unsigned short>(unsigned(r));  // (4 * position: at most 65 532)
+                            }
+                        }
+                }
                 memcpy(img.data() + o_seg[d][h], f->h_seg[d][h].data(), f->h_seg[d][h].size() * 4);
-                dv.d[d][h].arcs = reinterpret_cast<const unsigned long long *>(base + o_arcs[d][h]);
+                dv.d[d][h].arcs = reinterpret_cast<const unsigned *>(base + o_arcs[d][h]);
                 dv.d[d][h].seg = reinterpret_cast<const unsigned *>(base + o_seg[d][h]);
                 dv.d[d][h].rinfo = reinterpret_cast<const unsigned *>(base + o_rinfo[d]);
                 dv.d[d][h].init = reinterpret_cast<const float *>(base + o_init);
@@ -511,7 +528,10 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_ba
         const int slot0 = uni(sd.wave_slot0[wave]), nslots = uni(sd.wave_slot0[wave + 1]) - slot0;
         // (a scalar base in the GLOBAL address space: global_load, counted by vmcnt alone -- a flat load also counts as an LDS
         // operation, and every wait became a wait for everything)
-        const auto apw = as_global(uni(sd.arcs) + (long long)slot0 * 64);
+        typedef unsigned mm_u32x4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) mm_u32x4 *g_u32x4;
+        typedef const __attribute__((address_space(1))) mm_u32x2 *g_u32x2;
+        const unsigned *const apw = uni(sd.arcs) + (long long)(slot0 / C) * 384;  // (the wave's first chunk)
         // (the segment table through the scalar cache: constant address space, s_load)
         typedef const __attribute__((address_space(4))) unsigned *seg_cptr;
         const seg_cptr segt = (seg_cptr)(__UINTPTR_TYPE__)uni(sd.seg);
@@ -525,6 +545,8 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_ba
         }
         double eop = 0.0;  // ... and of a finish's emission factor
         asm volatile("" : "+v"(eop));
+        double wop[2] = {0.0, 0.0};  // ... and of the 1st and the 3rd weight of a chunk
+        asm volatile("" : "+v"(wop[0]), "+v"(wop[1]));
         unsigned smin = 0xffffffffu;
         bool cdead = false;  // (teams) a poll of this wave timed out: it waits no more
         MM_STAMP_RESET;
@@ -582,54 +604,66 @@ __global__ void __launch_bounds__(1024) mm_stream_kernel(RunParams p, int dir_ba
                 load_seg(sg);
             };
             load_seg(sg);
+            static_assert(C == 4, "a chunk is one dwordx4 of weights and one dwordx2 of offsets");
             // K chunks of C records in flight per wave (the ring's slots are static registers: the chunk loop is unrolled K times;
             // the loads are unconditional -- the array ends in K * C records of padding -- so that their number in flight is a
             // constant of the code).  A segment is a whole number of chunks and its info record the LAST record of its last chunk:
             // ONE scalar test per chunk -- with a test per record (is it in the stream? is it an arc?) the frame was bound by the
             // scalar unit.  Chunks are taken in pairs: the gathers of both leave before the first FMA (half the LDS round trips on
             // a wave's chain).
-            unsigned long long buf[K][C];
+            mm_u32x4 wbuf[K];  // a chunk's 4 weights (high dwords; an info record: {.., .., .., pdf | pdf-major position << 12})
+            mm_u32x2 pbuf[K];  // ... and its 4 LDS byte offsets, 16 bits each
+            auto load_chunk = [&](int slot, long long q) __attribute__((always_inline)) {
+                const unsigned *cb = apw + q * 384;
+                wbuf[slot] = ((g_u32x4)(__UINTPTR_TYPE__)cb)[lane];
+                pbuf[slot] = ((g_u32x2)(__UINTPTR_TYPE__)(cb + 256))[lane];
+            };
 #pragma unroll
-            for (int kk = 0; kk < K; ++kk)
-#pragma unroll
-                for (int j = 0; j < C; ++j) buf[kk][j] = apw[(kk * C + j) * 64 + lane];
+            for (int kk = 0; kk < K; ++kk) load_chunk(kk, kk);
             for (int c = 0; c < nchunks; c += K) {
 #pragma unroll
                 for (int k2 = 0; k2 < K; k2 += 2) {
                     if (c + k2 < nchunks) {
                         const bool two = c + k2 + 1 < nchunks;
 #pragma unroll
-                        for (int h = 0; h < 2; ++h)
+                        for (int h = 0; h < 2; ++h) {
+                            const unsigned off[C] = {pbuf[k2 + h].x & 0xffffu, pbuf[k2 + h].x >> 16, pbuf[k2 + h].y & 0xffffu, pbuf[k2 + h].y >> 16};
 #pragma unroll
                             for (int j = 0; j < C; ++j) {  // (padding and info records gather address 0)
                                 mm_u32x2 o = __builtin_bit_cast(mm_u32x2, xop[h * C + j]);
 #ifdef MM_STREAM_NOGATHER  // (timing experiment: no LDS gathers)
-                                o.y = (unsigned)buf[k2 + h][j] | 0x3ff00000u;
+                                o.y = off[j] | 0x3ff00000u;
 #else
-                                o.y = ldsru(rd + (unsigned)buf[k2 + h][j]);
+                                o.y = ldsru(rd + off[j]);
 #endif
                                 xop[h * C + j] = __builtin_bit_cast(double, o);
                             }
+                        }
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             if (h == 0 || two) {
-#pragma unroll
-                                for (int j = 0; j < C - 1; ++j)
-                                    asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(__builtin_bit_cast(double, buf[k2 + h][j])), "v"(xop[h * C + j]));
+                                // the weights as float64 operands: {low register: whatever lies there, high: the weight's dword} -- the pairs
+                                // (x, y) and (z, w) of the load as they landed give the 2nd and the 4th (their low dwords: another weight's bits,
+                                // a fixed perturbation of the graph below 2^-20 relative), the 1st and the 3rd take a move into a pair of their own
+                                const mm_u32x4 w = wbuf[k2 + h];
+                                mm_u32x2 t0 = __builtin_bit_cast(mm_u32x2, wop[0]), t2 = __builtin_bit_cast(mm_u32x2, wop[1]);
+                                t0.y = w.x;
+                                t2.y = w.z;
+                                wop[0] = __builtin_bit_cast(double, t0);
+                                wop[1] = __builtin_bit_cast(double, t2);
+                                asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(wop[0]), "v"(xop[h * C + 0]));
+                                asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(__builtin_bit_cast(double, mm_u32x2{w.x, w.y})), "v"(xop[h * C + 1]));
+                                asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(wop[1]), "v"(xop[h * C + 2]));
                                 if (--remaining == 0) {
-                                    finish((unsigned)(buf[k2 + h][C - 1] >> 32));
+                                    finish(w.w);
                                 } else {
-                                    asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(__builtin_bit_cast(double, buf[k2 + h][C - 1])), "v"(xop[h * C + C - 1]));
+                                    asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(__builtin_bit_cast(double, mm_u32x2{w.z, w.w})), "v"(xop[h * C + 3]));
                                 }
                             }
                         }
 #ifndef MM_STREAM_NOLOAD  // (timing experiment: the ring is loaded once per frame)
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {  // the slots' next chunks
-                            const auto sp = apw + (long long)(c + k2 + h + K) * (C * 64);
-#pragma unroll
-                            for (int j = 0; j < C; ++j) buf[k2 + h][j] = sp[j * 64 + lane];
-                        }
+                        for (int h = 0; h < 2; ++h) load_chunk(k2 + h, (long long)(c + k2 + h + K));  // the slots' next chunks
 #endif
                     }
                 }

@@ -625,6 +625,17 @@ def test_stream_kernels(mm, wl, oracle, torch, case):
     assert (gam[~ok] == 0).all() and np.isneginf(ttl[~ok]).all()
     g2, t2 = bf.pdfposteriors(V, lens)  # (every sum of the combine in a fixed order, float64: the same bits on every run)
     assert np.array_equal(g2, gam) and np.array_equal(t2, ttl)
+    # teams (round 6): batches this small run as teams of 4 workgroups per utterance and direction; the lone workgroup and the teams of
+    # 2 give the same posteriors (other sums: not the same bits)
+    assert "teams of 4" in bf.kernels(), bf.kernels()
+    if case != "big":
+        for H in (1, 2):
+            bh = _with_env(dict(env, MM_DEBUG="1", MM_STREAM_H=str(H)), lambda: mm.batch(*[cfs[id(g)] for g in gs]))
+            assert ("teams of 2" in bh.kernels()) == (H == 2) and "teams of 4" not in bh.kernels()
+            gh, th = bh.pdfposteriors(V, lens)
+            assert bh.last_redo_count() == 0
+            check_gamma(gh[ok], g_ref[ok], lens[ok])
+            assert np.allclose(th[ok], t_ref[ok], rtol=1e-5, atol=1e-3) and np.allclose(gh, gam, rtol=2e-5, atol=1e-7)
 
 
 def test_team_xcd_counter(mm, wl, torch):

@@ -297,7 +297,8 @@ struct mm_batch_s {
     bool quad_built = false;            // the FSMs' quad forms exist (not built for batches whose exact path is the float64 kernels)
     int *stat_dev = nullptr;            // {count, ticket, team workgroups whose team sits on ONE XCD, team workgroups} (the last two: mm_batch_team_xcd_stats)
     bool xcd_counting = false;          // ... counted by the team kernels since mm_batch_team_xcd_stats was first called (a measurement aid: off until asked for)
-    volatile int *stat_host = nullptr;  // pinned: {count of hard utterances, sequence number of the call that counted}
+    volatile int *stat_host = nullptr;  // pinned: {count of hard utterances, sequence number of the call that counted, marks of the last alpha / beta export}
+    unsigned export_calls[2] = {0, 0};  // alpha / beta exports on this batch (every 32nd tries the linear-domain kernels again)
     int stat_seq = 0;
     int exact_first = -1;               // MM_EXACT_FIRST (under MM_DEBUG): 0 / 1 force the choice, -1: by the statistics
     bool last_exact_first = false;      // what the last call did
@@ -2204,10 +2205,9 @@ static int batch_create_impl(const mm_fsm_t *fsms, int64_t B, mm_batch_t *out) {
     if (want_dpair) {
         void *hp = nullptr;
         if (hipMalloc(&h->stat_dev, 4 * sizeof(int)) == hipSuccess && hipMemset(h->stat_dev, 0, 4 * sizeof(int)) == hipSuccess &&
-            hipHostMalloc(&hp, 2 * sizeof(int), hipHostMallocMapped) == hipSuccess) {
+            hipHostMalloc(&hp, 4 * sizeof(int), hipHostMallocMapped) == hipSuccess) {
             h->stat_host = static_cast<volatile int *>(hp);
-            h->stat_host[0] = 0;
-            h->stat_host[1] = 0;
+            for (int k = 0; k < 4; ++k) h->stat_host[k] = 0;  // ([2], [3]: utterances the last alpha / beta export handed to the item kernel)
             h->dpair_ok = true;
             h->exact_first = h->dbg.exact_first;
             {
@@ -2456,7 +2456,8 @@ int mm_batch_kernels(mm_batch_t h, int entry, char *buf, size_t n) {
                       : "mm_tropical_kernel + mm_backtrace_kernel";
     } else if (entry == 3) {  // mm_alpharecursion_f32 / mm_betarecursion_f32
         const bool xa = export_on_pairs(h, 0), xb = export_on_pairs(h, 1);
-        const std::string fast = "mm_fbx_kernel<" + std::to_string(mm_pair_nj(h->max_P1)) + "> (phase A of one direction over all frames, two utterances per workgroup) + "
+        const std::string fast = (h->pair_H > 1 ? "mm_fbsx_kernel<2," + std::to_string(h->pair_H) + "> (phase A of one direction over all frames, teams of " + std::to_string(h->pair_H) + " workgroups) + "
+                                                : "mm_fbx_kernel<" + std::to_string(mm_pair_nj(h->max_P1)) + "> (phase A of one direction over all frames, two utterances per workgroup) + ") +
                                  "mm_pair_export_kernel, then for marked utterances only the item kernel";
         s = h->semiring == MM_TROPICAL ? std::string("mm_tropical_kernel / mm_log_kernel<MODE_BETA, TROP>")
             : "alpha: " + (xa ? fast : std::string("mm_log_kernel<MODE_ALPHA>")) + "; beta: " + (xb ? fast : std::string("mm_log_kernel<MODE_BETA>"));
@@ -2881,7 +2882,8 @@ static PairLaunch pair_launch_of(mm_batch_t h) {
     return pl;
 }
 static bool export_on_pairs(mm_batch_t h, int dir) {
-    if (h->semiring != MM_LOG || !h->pairs_ok || h->pair_H != 1 || !mm_pair_export_fits(pair_launch_of(h))) return false;
+    if (h->semiring != MM_LOG || !h->pairs_ok) return false;
+    if (!(h->pair_H == 1 ? mm_pair_export_fits(pair_launch_of(h)) : mm_split_export_fits(pair_launch_of(h)))) return false;
     return h->fsms[0]->export_ok[dir];
 }
 
@@ -2902,7 +2904,19 @@ static int run_export(mm_batch_t h, int mode, const float *V, int64_t vsb, int64
     p.B = int(h->B);
     p.out = out;
     p.out_stride_n = out_stride_n;
-    if (export_on_pairs(h, mode == MODE_ALPHA ? 0 : 1)) {
+    // (inputs whose vectors leave float32's range in most utterances -- the reference's WSJ denominator in the forward direction: its
+    // initial-context states decay 2 log2 per frame against the rest, and the reference's alpha holds them as finite logarithms -- go
+    // straight to the item kernel while the last finished export of the direction marked more than half of its utterances (read from
+    // pinned host memory without synchronising, like the exact policy of mm_pdfposteriors_f32); every 32nd call tries again)
+    bool linear_first = export_on_pairs(h, mode == MODE_ALPHA ? 0 : 1);
+    if (linear_first && h->stat_host) {
+        const int dirx = mode == MODE_ALPHA ? 0 : 1;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        const bool probe = (++h->export_calls[dirx] & 31u) == 0u;
+        if (!capturing && !probe && 2 * int64_t(h->stat_host[2 + dirx]) > h->B) linear_first = false;
+    }
+    if (linear_first) {
         // phase A of ONE direction over all N + 1 frames with two utterances per workgroup (linear domain, float32), the layout
         // pass, then -- for the utterances whose values left float32's range (marked; sharp emissions) -- the item kernel
         rc = ensure_ws(h, mm_batch_workspace_bytes(h, N), stream);
@@ -2911,16 +2925,41 @@ static int run_export(mm_batch_t h, int mode, const float *V, int64_t vsb, int64
         p.ws_alpha = static_cast<float *>(h->ws);
         p.ws_c = reinterpret_cast<double *>(static_cast<char *>(h->ws) + ws_alpha_bytes(h, N));
         p.redo = reinterpret_cast<int *>(tail0 + align_up(size_t(h->B + 1) * 4, 256));
-        p.pair_s1p = h->max_S1p;
+        p.pair_s1p = h->pair_H > 1 ? h->split_s1p : h->max_S1p;
         p.pair_hand = tail0 + 2 * align_up(size_t(h->B + 1) * 4, 256);
         p.pair_zmin = reinterpret_cast<double *>(static_cast<char *>(p.pair_hand) + align_up(size_t(h->B + 1) * 2 * mm_pair_hand_bytes(), 256));
         p.split_q10 = 512;
         p.lt_floor = h->lt_floor;
+        p.x_sleep = h->dbg.x_sleep;
+        p.x_timeout = std::min<unsigned long long>(10000000ull, std::max<unsigned long long>(200000ull, 1000ull * (unsigned long long)N));
         hipLaunchKernelGGL(mm_prologue_kernel, dim3(unsigned((h->B + 1 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                            (const int *)nullptr, int(h->B), int(N), (int *)nullptr, p.redo, (int *)nullptr, 0);
         HIP_TRY(hipGetLastError());
-        rc = mm_launch_pair_export(pair_launch_of(h), p, mode == MODE_ALPHA ? 0 : 1, static_cast<hipStream_t>(stream));
+        if (h->pair_H > 1) {  // the teams' exchange areas (the float32 team kernels': phase A's rows), zeroed like before a pdfposteriors call
+            const SplitInfo &si = h->fsms[0]->split;
+            for (int s = 0; s < h->pair_H; ++s) {
+                p.sp_base[s] = si.base[s];
+                p.sp_cnt[s] = si.count[s];
+            }
+            p.xbuf = reinterpret_cast<float *>(reinterpret_cast<char *>(p.pair_zmin) + align_up(size_t(h->B) * 6 * 8, 256));
+            p.xps = reinterpret_cast<float *>(reinterpret_cast<char *>(p.xbuf) + ws_x_rows_bytes(h));
+            p.x_slot = 2ll * h->split_s1p;
+            p.x_psn = mm_pair_xps(h->max_P1, h->pair_H);
+            p.x_phase = (long long)(ws_x_rows_bytes(h) / 8);
+            const size_t zn = ws_x_bytes(h) / 16;
+            hipLaunchKernelGGL(mm_zero_kernel, dim3(unsigned(std::min<size_t>(2048, (zn + 255) / 256))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                               reinterpret_cast<char *>(p.xbuf), (unsigned long long)zn);
+            HIP_TRY(hipGetLastError());
+            rc = mm_launch_split_export(pair_launch_of(h), p, mode == MODE_ALPHA ? 0 : 1, static_cast<hipStream_t>(stream));
+        } else {
+            rc = mm_launch_pair_export(pair_launch_of(h), p, mode == MODE_ALPHA ? 0 : 1, static_cast<hipStream_t>(stream));
+        }
         if (rc) return rc;
+        if (h->stat_host) {  // how many utterances were marked: what the next export of this direction starts with
+            hipLaunchKernelGGL(mm_count_marks_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), p.redo, int(h->B),
+                               const_cast<int *>(h->stat_host) + 2 + (mode == MODE_ALPHA ? 0 : 1));
+            HIP_TRY(hipGetLastError());
+        }
         h->last_redo = p.redo;  // (mm_batch_last_redo_count: how many utterances the item kernel computed instead)
         if (h->dbg.no_redo) return MM_OK;
         p.ws_alpha = nullptr;   // (the item kernel's export modes keep nothing in the workspace)

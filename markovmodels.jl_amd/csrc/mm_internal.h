@@ -100,7 +100,9 @@ bool mm_wpair_fits(const PairLaunch &pl);
 int mm_launch_wpairs(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
 // ---- split pair kernels (mm_split_tu.hip): teams of pl.H workgroups
 int mm_launch_split(const PairLaunch &pl, const RunParams &p, hipStream_t s0);
-size_t mm_split_lds_bytes(int H, int phase, int nslotrows, int max_P1);  // (0: no instance for that many pdfs)
+size_t mm_split_lds_bytes(int H, int phase, int nslotrows, int max_P1);
+bool mm_split_export_fits(const PairLaunch &pl);  // alpha / beta export on the team kernels: teams of 2 and 4, up to 128 pdfs
+int mm_launch_split_export(const PairLaunch &pl, const RunParams &p, int dir, hipStream_t s0);  // (0: no instance for that many pdfs)
 
 
 // ---- wave kernel (mm_wave_tu.hip)

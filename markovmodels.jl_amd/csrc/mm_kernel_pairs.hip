@@ -852,7 +852,7 @@ __device__ __forceinline__ void pair_agent(const RunParams &p, int pair, int hse
         U[u].offs = p.ws_c + (long long)slot * (p.N + 2);
         NFp = len + 1 > NFp ? len + 1 : NFp;
     }
-    static_assert(!XPT || (PHASE == 0 && H == 1), "the export runs phase A of the one-workgroup instances");
+    static_assert(!XPT || PHASE == 0, "the export runs phase A");
     if constexpr (XPT) NFp = p.N + 1;  // (every frame of the reference's (sum S1) x (N + 1) matrix, whatever the lengths: expand() pads)
     // state vectors of the pair's frames (alpha~ up to the split, beta~ beyond), the two utterances side by side like
     // in LDS: [N + 2][S1p][2] -- one 8-byte store per finish in phase A, and in phase B ONE ds_read_b64 fetches both
@@ -1805,10 +1805,12 @@ static __global__ void mm_pair_finish_kernel(RunParams p) {
 // One workgroup per (pair, chunk of frames): a row of pairs is read as it lies (coalesced), scattered to state order through LDS
 // (position -> state: RowDev::order), and leaves as two contiguous rows.  dir 1: frame N + 1 is B[:, N+1] = one(K) (:103).
 // Utterances the kernel marked (values beyond float32's range) are skipped: the item kernel computes them behind this launch.
-static __global__ void __launch_bounds__(256) mm_pair_export_kernel(RunParams p, int dir, int frames_per_block) {
-    extern __shared__ float xs[];  // [2][S1p]
+static __global__ void __launch_bounds__(1024) mm_pair_export_kernel(RunParams p, int dir, int frames_per_block, int H) {
+    extern __shared__ float xs[];  // [2][S1p] values by state, then [S1p] ints: position -> state (-1: padding / a state the forms dropped)
+    constexpr int NT = 1024, NV = 5;  // (a team of 4 has a vector of up to ~4100 positions with the padding between its regions)
     const int pair = blockIdx.x, tid = threadIdx.x;
     const int S1p = p.pair_s1p;
+    int *posmap = reinterpret_cast<int *>(xs + 2 * S1p);
     int b[2], valid[2];
     for (int u = 0; u < 2; ++u) {
         const int i = 2 * pair + u;
@@ -1816,32 +1818,55 @@ static __global__ void __launch_bounds__(256) mm_pair_export_kernel(RunParams p,
         b[u] = valid[u] ? i : p.B - 1;
         if (valid[u] && p.redo[b[u]] != 0) valid[u] = 0;
     }
+    if (!valid[0] && !valid[1]) return;  // (both marked: the item kernel's)
     const UttDesc &ud = p.utts[b[0]];
-    const RowDev &r = ud.rp[dir];
-    const int S1 = r.rows;
+    const int S1 = ud.S1;
     const float *rowsP = p.ws_alpha + (long long)pair * (long long)(p.N + 2) * 2 * S1p;
     const int f0 = 1 + (int)blockIdx.y * frames_per_block, f1 = min(p.N + 1, f0 + frames_per_block - 1);
+    // position -> state over the whole vector: the sets' regions one after the other, each in its own form's finishing order
+    for (int q = tid; q < S1p; q += NT) posmap[q] = -1;
+    __syncthreads();
+    for (int h = 0; h < H; ++h) {
+        const RowDev &r = H > 1 ? ud.rps[dir][h] : ud.rp[dir];
+        const int base = H > 1 ? p.sp_base[h] : 0, cnt = H > 1 ? p.sp_cnt[h] : r.rows;
+        for (int i = tid; i < cnt; i += NT) posmap[base + i] = r.order[i];
+    }
+    __syncthreads();
+    int st[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) st[k] = tid + k * NT < S1p ? posmap[tid + k * NT] : -1;
+    const long long slot1 = 2 * pair + 1 < p.B ? b[1] : p.B;  // (the offsets' slots are pair_agent's: the spare slot B for the copy that fills an odd batch's last pair)
+    auto load_row = [&](int f, mm_f32x2 (&v)[NV]) __attribute__((always_inline)) {
+        const mm_f32x2 *row = reinterpret_cast<const mm_f32x2 *>(rowsP + (long long)f * 2 * S1p);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = st[k] >= 0 ? row[tid + k * NT] : mm_f32x2{0.f, 0.f};
+    };
+    mm_f32x2 nxt[NV];
+    load_row(f0 <= p.N + (dir ? 0 : 1) ? f0 : 1, nxt);
     for (int f = f0; f <= f1; ++f) {
-        if (dir == 1 && f == p.N + 1) {  // fill!(B[:, end], one(K))   (src/inference.jl:103: every state, not only the final one)
-            for (int i = tid; i < S1; i += 256) xs[i] = xs[S1p + i] = 0.f;
-        } else {
-            // (the offsets' slots are pair_agent's: the utterance's own, the spare slot B for the copy that fills an odd batch's last pair)
-            const double o0 = p.ws_c[(long long)b[0] * (p.N + 2) + f];
-            const double o1 = p.ws_c[(long long)(2 * pair + 1 < p.B ? b[1] : p.B) * (p.N + 2) + f];
-            const mm_f32x2 *row = reinterpret_cast<const mm_f32x2 *>(rowsP + (long long)f * 2 * S1p);
-            for (int i = tid; i < S1; i += 256) {
-                const mm_f32x2 v = row[i];
-                const int s = r.order[i];
-                // (log2 of a float in double: the offsets reach thousands of log2, whose float ulp is what a posterior is compared at)
-                xs[s] = v.x > 0.f ? (float)(((double)fast_log2(v.x) + o0) * (double)MM_LN2) : MM_NINF;
-                xs[S1p + s] = v.y > 0.f ? (float)(((double)fast_log2(v.y) + o1) * (double)MM_LN2) : MM_NINF;
-            }
+        mm_f32x2 v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = nxt[k];
+        const bool ones = dir == 1 && f == p.N + 1;  // fill!(B[:, end], one(K))   (src/inference.jl:103: every state, not only the final one)
+        const double o0 = ones ? 0.0 : p.ws_c[(long long)b[0] * (p.N + 2) + f], o1 = ones ? 0.0 : p.ws_c[slot1 * (p.N + 2) + f];
+        if (f + 1 <= f1 && !(dir == 1 && f + 1 == p.N + 1)) load_row(f + 1, nxt);  // (the next frame's row travels while this one is written)
+        if (H > 1 || ones)  // (states without a position: zero(K); the last column of beta: one(K))
+            for (int i = tid; i < S1; i += NT) xs[i] = xs[S1p + i] = ones ? 0.f : MM_NINF;
+        if (H > 1 || ones) __syncthreads();
+        if (!ones) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                if (st[k] >= 0) {
+                    // (log2 of a float in double: the offsets reach thousands of log2, whose float ulp is what a posterior is compared at)
+                    xs[st[k]] = v[k].x > 0.f ? (float)(((double)fast_log2(v[k].x) + o0) * (double)MM_LN2) : MM_NINF;
+                    xs[S1p + st[k]] = v[k].y > 0.f ? (float)(((double)fast_log2(v[k].y) + o1) * (double)MM_LN2) : MM_NINF;
+                }
         }
         __syncthreads();
         for (int u = 0; u < 2; ++u)
             if (valid[u]) {
                 float *dst = p.out + (long long)(f - 1) * p.out_stride_n + p.utts[b[u]].state_off;
-                for (int i = tid; i < S1; i += 256) dst[i] = xs[u * S1p + i];
+                for (int i = tid; i < S1; i += NT) dst[i] = xs[u * S1p + i];
             }
         __syncthreads();
     }

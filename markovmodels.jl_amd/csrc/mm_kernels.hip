@@ -1206,6 +1206,20 @@ __global__ void __launch_bounds__(256) mm_prologue_kernel(const int *lens, int B
     if (i < B) order[rank] = i;
 }
 
+// *out (pinned host memory) = the number of marked utterances
+__global__ void __launch_bounds__(256) mm_count_marks_kernel(const int *redo, int B, int *out) {
+    __shared__ int part[4];
+    int n = 0;
+    for (int b = threadIdx.x; b < B; b += 256) n += redo[b] != 0;
+    for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *out = part[0] + part[1] + part[2] + part[3];
+        __threadfence_system();
+    }
+}
+
 // zero n16 x 16 bytes at dst (16-byte aligned): the team kernels' exchange areas, before every call
 __global__ void __launch_bounds__(256) mm_zero_kernel(char *dst, unsigned long long n16) {
     typedef float f4 __attribute__((ext_vector_type(4)));

@@ -66,7 +66,7 @@ static int launch_pair_export(const PairLaunch *h, const RunParams &p, int dir, 
     // the stored rows -> the reference's layout: (pairs, chunks of frames) workgroups, enough of them to keep the memory system busy
     const int chunks = std::max(1, std::min(p.N + 1, int(4096 / std::max(1u, npairs))));
     const int fpb = (p.N + 1 + chunks - 1) / chunks;
-    hipLaunchKernelGGL(mm_pair_export_kernel, dim3(npairs, unsigned((p.N + 1 + fpb - 1) / fpb)), dim3(256), size_t(2) * size_t(p.pair_s1p) * 4, st, p, dir, fpb);
+    hipLaunchKernelGGL(mm_pair_export_kernel, dim3(npairs, unsigned((p.N + 1 + fpb - 1) / fpb)), dim3(1024), size_t(3) * size_t(p.pair_s1p) * 4, st, p, dir, fpb, 1);
     HIP_TRY(hipGetLastError());
     return MM_OK;
 }

@@ -2,6 +2,7 @@
 // workgroups per utterance pair and direction, for FSMs beyond the registers / LDS of one compute unit (the reference's
 // WSJ denominator graph, misc/benchmark/den_fsm_wsj.txt; the reference itself has no size limit, src/linalg.jl:170-181).
 #define MM_SECONDARY_TU
+#include <algorithm>
 #include "mm_internal.h"
 #include "mm_kernel_pairs.hip"
 
@@ -53,6 +54,37 @@ int mm_launch_split(const PairLaunch &pl, const RunParams &p, hipStream_t s0) {
     if (pl.H == 4) return nj == 2 ? launch_split_nj<2, 4>(&pl, p, s0) : (nj == 4 ? launch_split_nj<4, 4>(&pl, p, s0) : launch_split_nj<8, 4>(&pl, p, s0));
     if (pl.H != 2) return mm_fail(MM_ERR_UNSUPPORTED, "split kernel: teams of 2, 4 or 8");
     return nj == 2 ? launch_split_nj<2, 2>(&pl, p, s0) : (nj == 4 ? launch_split_nj<4, 2>(&pl, p, s0) : launch_split_nj<8, 2>(&pl, p, s0));
+}
+// ---- alpha-recursion / beta-recursion export on the team kernels (mm_pairs_tu.hip, mm_fbx_kernel): phase A of ONE direction over all
+// N + 1 frames by teams of H workgroups, then mm_pair_export_kernel.  Teams of 2 and 4, up to 128 pdfs (the reference's WSJ denominator).
+template <int NJ, int H>
+__global__ void __launch_bounds__(1024) mm_fbsx_kernel(RunParams p, int dir) {
+    const int blk = (int)blockIdx.x;
+    const int pair = (blk / (8 * H)) * 8 + (blk & 7), hset = (blk >> 3) % H;
+    if (pair >= (p.B + 1) / 2) return;
+    pair_agent<SplitGeo<H>::KA, SplitGeo<H>::RS, 0, -1, NJ, H, SplitGeo<H>::RSH, false, true>(p, pair, hset, dir);
+}
+template <int NJ, int H>
+static int launch_split_export(const PairLaunch *h, const RunParams &p, int dir, hipStream_t st) {
+    const size_t lds = pair_lds_bytes(SplitGeo<H>::RS, 0, h->slotrows, SplitGeo<H>::RSH, pair_pc(NJ));
+    if (lds > 160 * 1024) return mm_fail(MM_ERR_UNSUPPORTED, "split kernel: LDS");
+    auto kernel = mm_fbsx_kernel<NJ, H>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    const unsigned npairs = unsigned((h->B + 1) / 2);
+    hipLaunchKernelGGL(kernel, dim3((npairs + 7) / 8 * 8 * H), dim3(64 * (MM_SPLIT_NWC + 2)), lds, st, p, dir);
+    HIP_TRY(hipGetLastError());
+    const int chunks = std::max(1, std::min(p.N + 1, int(4096 / std::max(1u, npairs))));
+    const int fpb = (p.N + 1 + chunks - 1) / chunks;
+    hipLaunchKernelGGL(mm_pair_export_kernel, dim3(npairs, unsigned((p.N + 1 + fpb - 1) / fpb)), dim3(1024), size_t(3) * size_t(p.pair_s1p) * 4, st, p, dir, fpb, H);
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+}
+bool mm_split_export_fits(const PairLaunch &pl) {
+    return (pl.H == 2 || pl.H == 4) && pl.pair_ka <= mm_split_ka(pl.H) && mm_pair_nj(pl.max_P1, pl.H) == 2;
+}
+int mm_launch_split_export(const PairLaunch &pl, const RunParams &p, int dir, hipStream_t s0) {
+    if (!mm_split_export_fits(pl)) return MM_ERR_UNSUPPORTED;
+    return pl.H == 4 ? launch_split_export<2, 4>(&pl, p, dir, s0) : launch_split_export<2, 2>(&pl, p, dir, s0);
 }
 size_t mm_split_lds_bytes(int H, int phase, int nslotrows, int max_P1) {
     const int nj = mm_pair_nj(max_P1, H);

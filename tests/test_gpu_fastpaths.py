@@ -689,6 +689,35 @@ def test_mark_policy_keep_keeps_every_range_mark(mm, wl, oracle, torch):
     assert _lib.lib.mm_batch_set_mark_policy(bf._h, 7) == -1  # MM_ERR_INVALID
 
 
+def test_alpha_beta_export_on_the_team_kernels(mm, wl, oracle, torch):
+    """The same export by TEAMS of workgroups (mm_fbsx_kernel: graphs beyond one compute unit) against the float64 oracle: a 3600-state
+    graph of config 3's family (teams of 4: nothing leaves float32's range, the item kernel computes nothing) and the reference's WSJ
+    denominator (teams of 2), whose initial-context states decay 2 log2 per frame against the rest -- beyond float32 after ~60
+    frames: marked, computed by the item kernel, the reference's finite alpha where the linear domain holds zeros."""
+    o, oc = oracle
+    rng = np.random.default_rng(18)
+    for g, N, want_redo in ((wl.lfmmi_denominator(3600, 84, seed=1), 21, False), (wsj_den(wl), 90, True)):
+        of = graphs.to_oracle(o, g)
+        S1 = g.S + 1
+        B = 3
+        lens = np.array([N, N - 5, 2], dtype=np.int32)
+        cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+        bf = mm.batch(*([cf] * B))
+        assert "mm_fbs_kernel" in bf.kernels() and "mm_fbsx_kernel" in bf.kernels("export"), (bf.kernels(), bf.kernels("export"))
+        V = rng.standard_normal((B, N, g.P)).astype(np.float32)
+        A = bf.alpharecursion(V, lens)
+        redo_a = bf.last_redo_count()
+        Bm = bf.betarecursion(V, lens)
+        redo_b = bf.last_redo_count()
+        assert (redo_a + redo_b > 0) == want_redo, (g.name, redo_a, redo_b)
+        for b in range(B):
+            _, _, Ar, Br = oc.single(of, g.state2pdf, g.P, o.expand(V[b].T.astype(np.float64), int(lens[b]), o.LOG), want_ab=True)
+            for got, ref, what in ((A[b * S1:(b + 1) * S1], Ar, "alpha"), (Bm[b * S1:(b + 1) * S1], Br, "beta")):
+                assert np.array_equal(np.isneginf(got), np.isneginf(ref)), (g.name, what, b)
+                m = np.isfinite(ref)
+                assert np.allclose(got[m], ref[m], rtol=1e-5, atol=3e-4), (g.name, what, b, np.abs(got[m] - ref[m]).max())
+
+
 @pytest.mark.parametrize("P", [60, 200])
 def test_alpha_beta_export_on_the_pair_kernels(mm, wl, oracle, torch, P):
     """alpha-recursion / beta-recursion (src/inference.jl:62-74, 99-110) of a shared graph in the pair form: phase A of the pair kernels

@@ -26,7 +26,8 @@ def timed(fn, K=10, W=3):
 
 
 rows = []
-for name, g, B, N in (("config 3 (lfmmi_den)", wl.lfmmi_denominator(2000, 84, seed=0), 256, 1500), ("WSJ denominator", wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "den_fsm_wsj.npz")), 128, 700)):
+for name, g, B, N in (("config 3 (lfmmi_den)", wl.lfmmi_denominator(2000, 84, seed=0), 256, 1500), ("WSJ denominator", wl.load_npz_graph(os.path.join(ROOT, "tests", "golden", "den_fsm_wsj.npz")), 128, 700),
+                      ("lfmmi_den4000 (teams of 4)", wl.lfmmi_denominator(4000, 84, seed=1), 128, 700)):
     cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
     bf = mm.batch(*([cf] * B))
     V = torch.randn(B, N, g.P, device="cuda")

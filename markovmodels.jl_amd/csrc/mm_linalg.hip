@@ -8,15 +8,18 @@
 // products into their time loops --; this file is the seam for a caller who uses the package's linear algebra directly.
 //
 // SpMV: where the reference gives every row a 32-lane warp whatever its length (17 of 32 lanes busy on an LF-MMI denominator,
-// 2 of 32 on a numerator), a row gets an aligned GROUP of g = 1 ... 64 lanes of a 64-lane wave, g the power of two next to the
-// mean row length: the lanes of a group read consecutive entries of the row (coalesced nzVal / colVal), keep a running
+// 2 of 32 on a numerator), a row gets an aligned GROUP of g = 1 ... 64 lanes of a 64-lane wave, g the largest power of two up to
+// the mean row length: the lanes of a group read consecutive entries of the row (coalesced nzVal / colVal), keep a running
 // (maximum, scaled sum) pair -- one exp per entry, no second pass over the row --, and the group combines with DPP butterflies
 // (quad_perm, row_half_mirror, row_mirror; the LDS crossbar only above 16 lanes).
 // SpMM: a thread per row and JT columns, lanes along the rows (column-major C and B: consecutive lanes write consecutive
 // addresses); the row's indices are read once per JT columns instead of once per column.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <string>
 
 #include "mm_internal.h"
@@ -165,31 +168,35 @@ __global__ __launch_bounds__(256) void mm_spmm_kernel(long long rows, long long 
                                                        const T *__restrict__ B, long long ldb, T *__restrict__ C, long long ldc, int beta_mode,
                                                        T beta) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long j0 = (long long)blockIdx.y * JT;
     if (i >= rows) return;
     const long long beg = (long long)rowptr[i] - base, end = (long long)rowptr[i + 1] - base;
-    Acc<T, SR> acc[JT];
+    // (the column tiles of a row block are a loop of ONE workgroup, not a grid dimension: the row's indices and weights come from HBM
+    // once and from this XCD's L2 for the other tiles -- as grid.y = tiles, every tile's workgroups re-read the CSR arrays and the
+    // rows of B through whichever XCD they landed on: 143 MB fetched for 12 MB of operands, profiles/r06_traffic_linalg.json)
+    for (long long j0 = (long long)blockIdx.y * JT; j0 < ncols; j0 += (long long)gridDim.y * JT) {
+        Acc<T, SR> acc[JT];
 #pragma unroll
-    for (int jj = 0; jj < JT; ++jj) {
-        // beta_mode 0: fill!(C, zero(K)) (:247); 1: C as it is; 2: rmul!(C, beta) first
-        if (beta_mode == 0 || j0 + jj >= ncols) acc[jj].init();
-        else {
-            const T c0 = C[i + (j0 + jj) * ldc];
-            acc[jj].init_from(beta_mode == 1 ? c0 : sr_mul<T, SR>(c0, beta));
+        for (int jj = 0; jj < JT; ++jj) {
+            // beta_mode 0: fill!(C, zero(K)) (:247); 1: C as it is; 2: rmul!(C, beta) first
+            if (beta_mode == 0 || j0 + jj >= ncols) acc[jj].init();
+            else {
+                const T c0 = C[i + (j0 + jj) * ldc];
+                acc[jj].init_from(beta_mode == 1 ? c0 : sr_mul<T, SR>(c0, beta));
+            }
         }
-    }
-    for (long long k = beg; k < end; ++k) {
-        const T w = nzval[k];
-        const long long cj = (long long)colval[k] - base;
-        const bool inside = (unsigned long long)cj < (unsigned long long)acols;  // (outside: a NaN, not a read out of bounds)
-        const T *brow = B + (inside ? cj : 0);
+        for (long long k = beg; k < end; ++k) {
+            const T w = nzval[k];
+            const long long cj = (long long)colval[k] - base;
+            const bool inside = (unsigned long long)cj < (unsigned long long)acols;  // (outside: a NaN, not a read out of bounds)
+            const T *brow = B + (inside ? cj : 0);
+#pragma unroll
+            for (int jj = 0; jj < JT; ++jj)
+                if (j0 + jj < ncols) acc[jj].add(inside ? sr_mul<T, SR>(w, brow[(j0 + jj) * ldb]) : Lim<T>::nan());
+        }
 #pragma unroll
         for (int jj = 0; jj < JT; ++jj)
-            if (j0 + jj < ncols) acc[jj].add(inside ? sr_mul<T, SR>(w, brow[(j0 + jj) * ldb]) : Lim<T>::nan());
+            if (j0 + jj < ncols) C[i + (j0 + jj) * ldc] = acc[jj].value();
     }
-#pragma unroll
-    for (int jj = 0; jj < JT; ++jj)
-        if (j0 + jj < ncols) C[i + (j0 + jj) * ldc] = acc[jj].value();
 }
 
 template <typename T, int SR>
@@ -238,11 +245,22 @@ int check_common(const char *who, int semiring, int val_bytes, int index_base, c
     return MM_OK;
 }
 
-// the group of lanes a row gets: the power of two next above the mean row length, at most a wave
+// the group of lanes a row gets: the largest power of two up to the mean row length, at most a wave -- measured on the reference's WSJ
+// denominator (blockdiag x 128, mean 17.1 entries per row; tools/bench_linalg.py): groups of 4 / 8 / 16 / 32 lanes 0.130 / 0.095 /
+// 0.084 / 0.109 ms: with the power of two ABOVE the mean (round 5) half the lanes of a group had no entry and every row paid a fifth
+// butterfly level.  (MM_SPMV_L2G under MM_DEBUG, read once per process like the engine's other diagnostic switches: a fixed one)
+int debug_log2g() {
+    static const int v = [] {
+        const char *on = getenv("MM_DEBUG"), *e = getenv("MM_SPMV_L2G");
+        return (on && *on && strcmp(on, "0") && e) ? std::max(0, std::min(6, atoi(e))) : -1;
+    }();
+    return v;
+}
 int pick_log2g(long long rows, long long nnz) {
+    if (debug_log2g() >= 0) return debug_log2g();
     const double mean = rows > 0 ? double(nnz) / double(rows) : 0.0;
     int l = 0;
-    while (l < 6 && double(1 << l) < mean) ++l;
+    while (l < 6 && double(2 << l) <= mean) ++l;
     return l;
 }
 
@@ -304,8 +322,9 @@ int mm_spmm(int semiring, int val_bytes, int64_t rows, int64_t cols, int64_t nnz
         if (!rowptr) return mm_fail(MM_ERR_INVALID, "mm_spmm: NULL rowptr");
     }
     constexpr int JT = 4;
-    const dim3 grid((unsigned)((rows + 255) / 256), (unsigned)((c_cols + JT - 1) / JT)), block(256);
-    if (grid.y > 65535u) return mm_fail(MM_ERR_UNSUPPORTED, "mm_spmm: more than 262 140 columns");
+    // (row blocks x as many column-tile lanes as it takes to fill the chip ~16 times over; a workgroup loops over the tiles of its lane)
+    const long long xb = (rows + 255) / 256, tiles = (c_cols + JT - 1) / JT;
+    const dim3 grid((unsigned)xb, (unsigned)std::min<long long>(tiles, std::max<long long>(1, (4096 + xb - 1) / xb))), block(256);
     MM_DISPATCH(semiring, val_bytes,
                 hipLaunchKernelGGL((mm_spmm_kernel<T, SR, JT>), grid, block, 0, s, (long long)rows, (long long)cols, (long long)c_cols, rowptr, colval, index_base,
                                    static_cast<const T *>(nzval), static_cast<const T *>(B), (long long)ldb, static_cast<T *>(C), (long long)ldc,

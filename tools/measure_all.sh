@@ -6,10 +6,11 @@ for w in lfmmi_den wsj_den wsj_num lexicon5000 ergodic64 l2r3 lfmmi_den4000 lfmm
 done
 P=gpurun_out/measure/profiles
 # sharp emissions (a trained acoustic model's outputs): the wide-exponent kernels' regime -- bench line, rocprofv3 kernel statistics, SQ
-# counters and TCC traffic like the randn workloads (round 6); "consistent" = sharp ALONG a path sampled from the graph
-NAME=lfmmi_den_peaky bash tools/measure.sh "$1" lfmmi_den --emissions peaky --no-cpu-baseline > gpurun_out/measure_lfmmi_den_peaky.log 2>&1
-NAME=wsj_den_peaky bash tools/measure.sh "$1" wsj_den --emissions peaky --no-cpu-baseline > gpurun_out/measure_wsj_den_peaky.log 2>&1
-NAME=lfmmi_den_consistent bash tools/measure.sh "$1" lfmmi_den --emissions consistent --no-cpu-baseline > gpurun_out/measure_lfmmi_den_consistent.log 2>&1
+# counters and TCC traffic like the randn workloads (round 6); "consistent" = sharp ALONG a path sampled from the graph.  The counters
+# are read for the THIRD call: the first runs the float32 kernels and the float64 ones behind them, the later ones the wide kernels alone
+PMC_WARMUP=2 LAST_CALL=1 NAME=lfmmi_den_peaky bash tools/measure.sh "$1" lfmmi_den --emissions peaky --no-cpu-baseline > gpurun_out/measure_lfmmi_den_peaky.log 2>&1
+PMC_WARMUP=2 LAST_CALL=1 NAME=wsj_den_peaky bash tools/measure.sh "$1" wsj_den --emissions peaky --no-cpu-baseline > gpurun_out/measure_wsj_den_peaky.log 2>&1
+PMC_WARMUP=2 LAST_CALL=1 NAME=lfmmi_den_consistent bash tools/measure.sh "$1" lfmmi_den --emissions consistent --no-cpu-baseline > gpurun_out/measure_lfmmi_den_consistent.log 2>&1
 timeout 300 python3 bench.py --emissions peaky_offset --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > $P/$1_bench_lfmmi_den_peaky_offset.json
 timeout 300 python3 bench.py --workload lfmmi_den4000 --emissions peaky --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > $P/$1_bench_lfmmi_den4000_peaky.json
 timeout 900 python3 tools/sharpness.py > $P/$1_sharpness.txt 2>/dev/null

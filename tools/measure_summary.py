@@ -25,21 +25,30 @@ sha = source_hash()
 
 
 def short(k):
-    return k.replace("void mm::", "").replace("void ", "").replace("(mm::RunParams)", "")
+    return k.replace("void mm::", "").replace("void ", "").replace("(mm::RunParams)", "").replace("(anonymous namespace)::", "")
 
 
 def ours(k):
     """the engine's kernels (namespace mm, or the global-namespace launch wrappers mm_*)"""
-    return "mm::mm_" in k or k.startswith("void mm_") or k.startswith("mm_")
+    return "mm::mm_" in k or "mm::(anonymous namespace)::mm_" in k or k.startswith("void mm_") or k.startswith("mm_")
 
 
-def counters(sub):
-    """{kernel: {counter: mean per dispatch}} for the engine's kernels"""
+LAST_CALL = os.environ.get("LAST_CALL") == "1"
+
+
+def counters(sub, last_call=False):
+    """{kernel: {counter: mean per dispatch}} for the engine's kernels.  last_call: only the dispatches of the run's LAST engine call
+    (it starts at the last dispatch of the kernel the run's first call started with) -- for inputs whose first call differs from the
+    steady state: on sharp emissions the first call runs the float32 kernels and then the float64 ones for what they marked, every
+    later call the wide kernels alone (PMC_WARMUP=2 LAST_CALL=1 in tools/measure_all.sh)."""
     acc, disp = {}, {}
     for f in glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv")):
-        for r in csv.DictReader(open(f)):
-            if not ours(r["Kernel_Name"]):
-                continue
+        rows = [r for r in csv.DictReader(open(f)) if ours(r["Kernel_Name"])]
+        if last_call and rows:
+            rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+            start = max(int(r["Dispatch_Id"]) for r in rows if r["Kernel_Name"] == rows[0]["Kernel_Name"])
+            rows = [r for r in rows if int(r["Dispatch_Id"]) >= start]
+        for r in rows:
             k = short(r["Kernel_Name"])
             acc.setdefault(k, {}).setdefault(r["Counter_Name"], 0.0)
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -67,8 +76,8 @@ for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
                 w.writerow(r)
                 stats[short(r[0])] = {"calls": int(r[1]), "avg_ns": float(r[3])}
 
-fetch, nf = counters("fetch")
-write, nw = counters("write")
+fetch, nf = counters("fetch", LAST_CALL)
+write, nw = counters("write", LAST_CALL)
 per_kernel = {}
 for k in sorted(set(fetch) | set(write)):
     rd = 2.0 * fetch.get(k, {}).get("FETCH_SIZE", 0.0) * 1024
@@ -84,9 +93,10 @@ traffic = {
     "hbm_bytes_per_launch": sum(v["read_bytes_corrected"] + v["write_bytes"] for v in per_kernel.values()),
     "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"] if bench and "roofline" in bench else None,
     "correction": "gfx950: FETCH_SIZE x2 for wide coalesced reads (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; one "
-                  "pdfposteriors call = one dispatch of each kernel",
+                  "pdfposteriors call = one dispatch of each kernel" + (" (the dispatches of the run's last call only: the steady state)" if LAST_CALL else ""),
 }
-json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic_{workload}.json"), "w"), indent=1)
+if per_kernel:
+    json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic_{workload}.json"), "w"), indent=1)
 
 pa, _ = counters("pmcA")
 pb, _ = counters("pmcB")
@@ -103,7 +113,8 @@ for k in sorted(set(pa) | set(pb)):
     if c.get("SQ_WAVES") and k in stats:
         d["avg_kernel_ns"] = stats[k]["avg_ns"]
     pmc["per_kernel"][k] = {"counters_per_dispatch": c, "derived": d}
-json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_{workload}.json"), "w"), indent=1)
+if pmc["per_kernel"]:
+    json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_{workload}.json"), "w"), indent=1)
 
 print(json.dumps({"source_hash": sha, "kernel_avg_ns": {k: v["avg_ns"] for k, v in stats.items()},
                   "hbm_bytes_per_launch": traffic["hbm_bytes_per_launch"], "bench_ms": bench["ms_per_step"] if bench else None,

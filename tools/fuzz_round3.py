@@ -36,20 +36,20 @@ from fuzz_cases import lens_pattern, split_cases  # noqa: E402  (the team fuzzer
 
 
 def posterior_error(a_g, a_t, ref_g, ref_t):
-    """Largest relative error of log Z, and of the posteriors: relative in the logarithm above 1e-26; between 1e-30 and 1e-26
-    the float32 linear kernels guarantee an ABSOLUTE error only -- a term they drop is below 2^(-120 - L_n) <= 2^-100 (the
-    overlap criterion), a pdf has up to 64 states: 64 x 2^-100 = 5.1e-29 -- scaled here so that 1e-4 is
-    the bar for both."""
+    """Largest relative error of log Z, and of the posteriors, against the contract the header documents for the default mark policy
+    (include/markovmodels_amd.h, mm_batch_set_mark_policy; pinned by tests/test_gpu_exact.py on this fuzzer's findings): relative in
+    the logarithm for posteriors above 1e-24; an ABSOLUTE error of at most 1e-27 below -- a term the float32 linear kernels drop is
+    below 2^(-120 - L_n) (the overlap criterion) and a pdf sums a few dozen of them -- scaled here so that 1e-4 is
+    the bar for both.  (MM_MARKS_KEEP holds the relative bound down to 1e-30: tools/fuzz_find.py.)"""
     same_inf = np.isinf(a_t) & np.isinf(ref_t) & (a_t == ref_t)
     fin = ~same_inf
     et = (np.abs(a_t[fin] - ref_t[fin]) / np.maximum(1.0, np.abs(ref_t[fin]))).max() if fin.any() else 0.0
-    m = ref_g > 1e-26
-    lo = (ref_g > 1e-30) & ~m
-    eg = np.abs(a_g - ref_g).max()
+    m = ref_g >= 1e-24
+    eg = np.abs(a_g - ref_g).max() if a_g.size else 0.0
     if m.any():
         eg = max(eg, (np.abs(np.log(np.maximum(a_g[m], 1e-300)) - np.log(ref_g[m])) / np.maximum(np.abs(np.log(ref_g[m])), 1)).max())
-    if lo.any():
-        eg = max(eg, 1e-4 * (np.abs(a_g[lo] - ref_g[lo]) / (64 * 2.0 ** -100 + 1e-4 * np.abs(np.log(ref_g[lo])) * ref_g[lo])).max())
+    if (~m).any():
+        eg = max(eg, 1e-4 * np.abs(a_g[~m] - ref_g[~m]).max() / 1e-27)
     return et, eg
 
 

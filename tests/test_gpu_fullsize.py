@@ -158,3 +158,70 @@ def test_config2_dense_ergodic(mm, wl, oracle, torch):
     m = g_ref > 1e-30
     assert (np.abs(np.log(gam[m]) - np.log(g_ref[m])) <= 1e-4 * np.maximum(np.abs(np.log(g_ref[m])), 1)).all()
     assert np.allclose(ttl, t_ref, rtol=1e-5)
+
+
+def test_config3_alpha_beta_export_full_size(mm, wl, oracle, torch):
+    """alpha-recursion / beta-recursion (src/inference.jl:62-74, 99-110) at config 3's full size -- S = 2000, T = 1500, B = 256, lengths
+    750 .. 1500: two (512 256 x 1501) matrices of 3.1 GB -- on the pair kernels (by name).  The property that holds for the whole batch
+    whatever its size: (+)_s A[s, n] (*) B[s, n] is the utterance's total for EVERY column n, the frames beyond the length included
+    (expand()'s padding carries the mass on the phony state) -- compared with the ttl of pdfposteriors, an independent set of kernels;
+    the longest and the shortest utterance against the float64 oracle's state_A / state_B."""
+    o, oc = oracle
+    g = wl.lfmmi_denominator(2000, 84, seed=0)
+    B, N = 256, 1500
+    S1 = g.S + 1
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(*([cf] * B))
+    assert "mm_fbx_kernel" in bf.kernels("export") and "mm_pair_export_kernel" in bf.kernels("export"), bf.kernels("export")
+    gen = torch.Generator(device="cuda").manual_seed(13)
+    V = torch.randn(B, N, g.P, device="cuda", generator=gen)
+    lens = torch.randint(N // 2, N + 1, (B,), device="cuda", generator=gen, dtype=torch.int32)
+    lens[0] = N
+    _, ttl = bf.pdfposteriors(V, lens)
+    A = bf.alpharecursion(V, lens)
+    assert bf.last_redo_count() == 0  # (N(0,1) emissions: nothing leaves float32's range, nothing is handed to the item kernel)
+    Bm = bf.betarecursion(V, lens)
+    assert bf.last_redo_count() == 0
+    assert tuple(A.shape) == (B * S1, N + 1) and tuple(Bm.shape) == (B * S1, N + 1)
+    tot = torch.logsumexp((A + Bm).t().reshape(N + 1, B, S1), dim=2)  # [N + 1, B]
+    assert torch.isfinite(tot).all()
+    assert torch.allclose(tot, ttl[None, :].expand_as(tot), rtol=1e-5, atol=5e-3), float((tot - ttl[None, :]).abs().max())
+    del tot
+    L = lens.cpu().numpy()
+    for b in (int(np.argmax(L)), int(np.argmin(L))):
+        Vb = V[b].cpu().numpy().T.astype(np.float64)
+        _, _, Ar, Br = oc.single(graphs.to_oracle(o, g), g.state2pdf, g.P, o.expand(Vb, int(L[b]), o.LOG), want_ab=True)
+        for got, ref, what in ((A[b * S1:(b + 1) * S1].cpu().numpy(), Ar, "alpha"), (Bm[b * S1:(b + 1) * S1].cpu().numpy(), Br, "beta")):
+            assert np.array_equal(np.isneginf(got), np.isneginf(ref)), (what, b)
+            m = np.isfinite(ref)
+            assert np.allclose(got[m], ref[m], rtol=1e-5, atol=5e-3), (what, b, np.abs(got[m] - ref[m]).max())
+
+
+def test_lfmmi_step_full_size_gradient_rows_sum_to_zero(mm, wl, torch):
+    """The caller's step at the size bench.py times it (`--workload lfmmi_step`): the reference's WSJ denominator x 128 and 128
+    different numerator graphs, T = 700, the fused assembly.  gamma_den and gamma_num are both distributions over the pdfs of a
+    frame, so every live row of the gradient sums to zero, the rows beyond the lengths are exactly zero, and the loss is
+    -(sum ttl_num - sum ttl_den) of the two calls made on their own."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    den = wl.load_npz_graph(os.path.join(here, "den_fsm_wsj.npz"))
+    P, N, B = den.P, 700, 128
+    gs = [wl.lexicon_fsm(150 + 3 * b, P, seed=100 + b, hubs=1 + b % 2) for b in range(B)]
+    cden = mm.compile(wl.to_fsm(mm, den), mm.statemap(den.state2pdf, P))
+    bden = mm.batch(*([cden] * B))
+    bnum = mm.batch(*mm.compile_many([wl.to_fsm(mm, g) for g in gs], [mm.statemap(g.state2pdf, P) for g in gs]))
+    assert "mm_fbs_kernel" in bden.kernels() and "mm_wave_kernel" in bnum.kernels()
+    gen = torch.Generator(device="cuda").manual_seed(17)
+    V = torch.randn(B, N, P, device="cuda", generator=gen).requires_grad_(True)
+    lens = torch.randint(N // 2, N + 1, (B,), device="cuda", generator=gen, dtype=torch.int32)
+    loss, tn, td = mm.lfmmi_loss(V, bnum, bden, lens, mode="fused")
+    loss.backward()
+    grad = V.grad
+    assert torch.isfinite(grad).all() and torch.isfinite(tn).all() and torch.isfinite(td).all()
+    valid = torch.arange(N, device="cuda")[None, :] < lens[:, None]
+    assert (grad[~valid] == 0).all()
+    assert float(grad.sum(-1)[valid].abs().max()) <= 3e-5
+    assert float(grad.abs().max()) <= 1.0 + 1e-5
+    _, tn2 = bnum.pdfposteriors(V.detach(), lens)
+    _, td2 = bden.pdfposteriors(V.detach(), lens)
+    assert torch.equal(tn2, tn) and torch.allclose(td2, td, rtol=1e-6)
+    assert np.isclose(float(loss.detach()), -float((tn.double() - td.double()).sum()), rtol=1e-6)

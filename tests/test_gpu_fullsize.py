@@ -225,3 +225,87 @@ def test_lfmmi_step_full_size_gradient_rows_sum_to_zero(mm, wl, torch):
     _, td2 = bden.pdfposteriors(V.detach(), lens)
     assert torch.equal(tn2, tn) and torch.allclose(td2, td, rtol=1e-6)
     assert np.isclose(float(loss.detach()), -float((tn.double() - td.double()).sum()), rtol=1e-6)
+
+
+@pytest.mark.parametrize("emissions", ["randn", "sharp"])
+def test_reference_wsj_denominator_full_size(mm, wl, oracle, torch, emissions):
+    """The reference's own benchmark (README: den_fsm_wsj.txt, batch 128, 700 frames -- SURVEY 8d runs it beside config 3) at full
+    size on the team kernels: N(0,1) log-likelihoods (the float32 teams) and log-softmax(10 N(0,1)) (`sharp`: every utterance leaves
+    float32's range and the exact kernels take the batch -- the second call on the wide teams alone).  Whole batch: per-frame
+    normalisation, exact zeros beyond the lengths, the beta export's column totals against ttl; four utterances against the float64
+    oracle at full length."""
+    o, oc = oracle
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = wl.load_npz_graph(os.path.join(here, "den_fsm_wsj.npz"))
+    B, N, S1 = 128, 700, g.S + 1
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(*([cf] * B))
+    assert "mm_fbs_kernel" in bf.kernels() and "teams of 2" in bf.kernels()
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    V = torch.randn(B, N, g.P, device="cuda", generator=gen)
+    if emissions == "sharp":
+        V = torch.log_softmax(10.0 * V, dim=-1)
+    lens = torch.randint(N // 2, N + 1, (B,), device="cuda", generator=gen, dtype=torch.int32)
+    lens[0] = N
+    gam, ttl = bf.pdfposteriors(V, lens)
+    redo1 = bf.last_redo_count()
+    gam2, ttl2 = bf.pdfposteriors(V, lens)  # (sharp: exact first now -- the wide team kernels alone)
+    if emissions == "sharp":
+        assert redo1 == B and bf.last_exact_first() and bf.last_fallback_count() == 0
+        assert torch.allclose(gam2, gam, atol=2e-5) and torch.allclose(ttl2, ttl, rtol=1e-5)
+    else:
+        assert redo1 == 0 and torch.equal(gam2, gam) and torch.equal(ttl2, ttl)
+    valid = torch.arange(N, device="cuda")[None, :] < lens[:, None]
+    assert torch.isfinite(gam2).all() and torch.isfinite(ttl2).all() and (gam2 >= 0).all()
+    sums = gam2.sum(-1)
+    assert torch.allclose(sums[valid], torch.ones_like(sums[valid]), atol=2e-5)
+    assert (gam2[~valid] == 0).all()
+    if emissions == "randn":  # the beta export on the team kernels: every column's (+)_s alpha_hat-weighted total ... = ttl through column 1
+        assert "mm_fbsx_kernel" in bf.kernels("export")
+        Bm = bf.betarecursion(V, lens)  # [B * S1, N + 1]
+        assert bf.last_redo_count() == 0
+        init = torch.full((S1,), float("-inf"), device="cuda")
+        init[torch.from_numpy(g.init_idx.astype(np.int64)).cuda()] = torch.from_numpy(g.init_w.astype(np.float32)).cuda()
+        pdf = torch.from_numpy(np.concatenate([g.state2pdf, [0]]).astype(np.int64)).cuda()
+        # A[:, 1] = alpha_hat (*) lhs[:, 1] (src/inference.jl:68): total = (+)_s A[s, 1] (*) B[s, 1]
+        e1 = V[:, 0, :][:, pdf]          # [B, S1] emission of every state's pdf at frame 1 (the phony state's entry is masked by init = -inf)
+        tot = torch.logsumexp(init[None, :] + e1 + Bm[:, 0].reshape(B, S1), dim=1)
+        assert torch.allclose(tot, ttl, rtol=1e-5, atol=5e-3), float((tot - ttl).abs().max())
+    sel = pick_utterances(lens.cpu().numpy())
+    Vs, Ls = V[sel].cpu().numpy(), lens[sel].cpu().numpy()
+    g_ref, t_ref = oc.batch_shared(graphs.to_oracle(o, g), g.state2pdf, g.P, Vs, Ls, dtype=np.float64, nthreads=4)
+    check_gamma(gam2[sel].cpu().numpy(), g_ref, Ls)
+    assert np.allclose(ttl2[sel].cpu().numpy(), t_ref, rtol=1e-5, atol=5e-4)
+
+
+def test_stream_kernels_at_the_benchmarked_size(mm, wl, torch):
+    """The stream kernels at the size tools/bench_big.py times them: 10 000 states, 162 k arcs, 1000 pdfs, B = 64, T = 700 -- teams of 2
+    workgroups per utterance and direction.  Whole batch: normalisation, zeros beyond the lengths, a second run the same bits, no
+    utterance handed to the exact kernels; four utterances against the item kernel (the log-domain implementation)."""
+    g = wl.lfmmi_denominator(10000, 1000, seed=0)
+    B, N = 64, 700
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    bf = mm.batch(*([cf] * B))
+    assert "mm_stream_kernel" in bf.kernels() and "teams of 2" in bf.kernels(), bf.kernels()
+    gen = torch.Generator(device="cuda").manual_seed(29)
+    V = torch.randn(B, N, g.P, device="cuda", generator=gen)
+    lens = torch.randint(N // 2, N + 1, (B,), device="cuda", generator=gen, dtype=torch.int32)
+    lens[0] = N
+    gam, ttl = bf.pdfposteriors(V, lens)
+    assert bf.last_redo_count() == 0
+    gam2, ttl2 = bf.pdfposteriors(V, lens)
+    assert torch.equal(gam2, gam) and torch.equal(ttl2, ttl)
+    valid = torch.arange(N, device="cuda")[None, :] < lens[:, None]
+    assert torch.isfinite(gam).all() and torch.isfinite(ttl).all() and (gam >= 0).all()
+    sums = gam.sum(-1)
+    assert torch.allclose(sums[valid], torch.ones_like(sums[valid]), atol=2e-5)
+    assert (gam[~valid] == 0).all()
+    sel = pick_utterances(lens.cpu().numpy())
+    os.environ.update({"MM_DEBUG": "1", "MM_KERNEL": "item"})
+    try:
+        g_item, t_item = mm.batch(*([cf] * len(sel))).pdfposteriors(V[sel].contiguous(), lens[sel].contiguous())
+    finally:
+        os.environ.pop("MM_KERNEL", None)
+        os.environ.pop("MM_DEBUG", None)
+    check_gamma(gam[sel].cpu().numpy(), g_item.cpu().numpy().astype(np.float64), lens[sel].cpu().numpy())
+    assert torch.allclose(t_item, ttl[sel], rtol=1e-5, atol=5e-3)

@@ -87,6 +87,17 @@ def test_gamma_mode_accumulates_into_the_callers_buffer(mm, wl, oracle, torch):
         bd.set_gamma_mode(True, -1.0)
     assert e.value.code == -4
     bd.set_gamma_mode(False, 1.0)  # (the default is always accepted)
+    # a scale that is not a finite number, a NULL batch: MM_ERR_INVALID, the mode left as it was
+    for bad in (float("nan"), float("inf")):
+        with pytest.raises(mm.MarkovModelsAMDError) as e:
+            bf.set_gamma_mode(False, bad)
+        assert e.value.code == -1
+    from importlib import import_module
+
+    lib = import_module(mm.__name__ + "._lib").lib
+    assert lib.mm_batch_set_gamma_mode(None, 0, 1.0) == -1
+    g4, _ = bf.pdfposteriors(Vt, lt)
+    assert torch.equal(g4, g0)
 
 
 @pytest.mark.parametrize("nums", ["lane", "wave"])

@@ -155,7 +155,11 @@ int mm_pdfposteriors_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, i
  * of S1 over the batch.  Values are natural-log (un-normalised).
  * One shared graph in the pair form (the batches of mm_fbp_kernel, up to 250 pdfs) runs phase A of the pair kernels over all
  * N + 1 frames -- two utterances per workgroup, linear domain -- and one layout pass; utterances whose values leave float32's
- * range (sharp emissions) and every other batch run the item kernel (log domain, one workgroup per utterance). */
+ * range (sharp emissions) and every other batch run the item kernel (log domain, one workgroup per utterance).  While the last
+ * finished export of the direction handed more than half of its utterances to the item kernel, the next one starts there
+ * (every 32nd call tries the linear-domain kernels again; the count is read from pinned memory without synchronising; never
+ * during stream capture): the two paths agree within the parity bar, not in the last bits -- mm_batch_set_exact_policy pins the
+ * choice (MM_EXACT_F32_FIRST: the linear-domain kernels first, always; MM_EXACT_F64_FIRST: the item kernel alone). */
 int mm_alpharecursion_f32(mm_batch_t batch, const float *V, int64_t v_stride_b, int64_t v_stride_n,
                           const int32_t *lens, int64_t N, float *out, int64_t out_stride_n, void *stream);
 /* beta-recursion(T_hat, C_hat*V_hat) (src/inference.jl:99-110); same layout (state_B).  Log and Tropical

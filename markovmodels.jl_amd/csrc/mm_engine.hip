@@ -2906,7 +2906,10 @@ static int run_export(mm_batch_t h, int mode, const float *V, int64_t vsb, int64
     // straight to the item kernel while the last finished export of the direction marked more than half of its utterances (read from
     // pinned host memory without synchronising, like the exact policy of mm_pdfposteriors_f32); every 32nd call tries again)
     bool linear_first = export_on_pairs(h, mode == MODE_ALPHA ? 0 : 1);
-    if (linear_first && h->stat_host) {
+    // (mm_batch_set_exact_policy pins this choice too: F32_FIRST = always the linear-domain kernels first, F64_FIRST = always the item
+    // kernel alone -- with a fixed policy the launches of a call, and the last bits of its result, are a function of the call)
+    if (linear_first && h->exact_first == 1) linear_first = false;
+    else if (linear_first && h->stat_host && h->exact_first < 0) {
         const int dirx = mode == MODE_ALPHA ? 0 : 1;
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;

@@ -433,7 +433,8 @@ class BatchedFSM:
         """mm_batch_set_exact_policy: which linear-domain kernels a shared-graph batch starts with -- "auto" (float32 first,
         float64 first while the last finished call left utterances marked: depends on host / device timing for pipelined
         callers), "f32_first" or "f64_first" (both: the launches of a call are a function of the call alone, identical call
-        sequences give identical bits)."""
+        sequences give identical bits).  Pins the path of ``alpharecursion`` / ``betarecursion`` as well ("auto": the item kernel
+        first while the last export handed it more than half of the utterances; "f64_first": the item kernel alone)."""
         pol = {"auto": _lib.MM_EXACT_AUTO, "f32_first": _lib.MM_EXACT_F32_FIRST, "f64_first": _lib.MM_EXACT_F64_FIRST}[policy]
         check(lib.mm_batch_set_exact_policy(self._h, pol))
         return self

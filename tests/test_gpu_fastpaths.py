@@ -689,6 +689,40 @@ def test_mark_policy_keep_keeps_every_range_mark(mm, wl, oracle, torch):
     assert _lib.lib.mm_batch_set_mark_policy(bf._h, 7) == -1  # MM_ERR_INVALID
 
 
+def test_exact_policy_pins_the_export_path(mm, wl, torch):
+    """A graph whose forward vectors leave float32's range in most utterances (here: 3 of 5 marked by the linear-domain export): under the
+    default policy the SECOND alpha export starts on the item kernel -- the same numbers within the bar, other last bits --, under
+    MM_EXACT_F32_FIRST every call launches the same kernels and gives the same bits, under MM_EXACT_F64_FIRST the item kernel alone
+    (bit-identical to a batch forced onto it)."""
+    g = wl.lfmmi_denominator(900, 40, seed=31)
+    cf = mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))
+    B, N = 5, 33
+    lens = torch.tensor([N, N - 4, 9, 1, N], dtype=torch.int32, device="cuda")
+    V = torch.randn(B, N, g.P, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    item = _with_env({"MM_DEBUG": "1", "MM_KERNEL": "item"}, lambda: mm.batch(*([cf] * B))).alpharecursion(V, lens).clone()
+
+    def runs(policy, n=3):
+        bf = mm.batch(*([cf] * B))
+        assert "mm_fbx_kernel" in bf.kernels("export")
+        if policy:
+            bf.set_exact_policy(policy)
+        out = []
+        for _ in range(n):
+            out.append(bf.alpharecursion(V, lens).clone())
+            out.append(bf.last_redo_count())
+        return out
+
+    a0, r0, a1, r1, a2, r2 = runs(None)
+    assert 2 * r0 > B  # (most utterances handed over: the premise of this test)
+    assert torch.equal(a1, item) and torch.equal(a2, item) and not torch.equal(a0, item)  # the second call starts on the item kernel
+    fin = torch.isfinite(item)
+    assert torch.equal(torch.isfinite(a0), fin) and float((a0[fin] - item[fin]).abs().max()) <= 2e-4
+    f0, q0, f1, q1, f2, q2 = runs("f32_first")
+    assert torch.equal(f0, a0) and torch.equal(f1, f0) and torch.equal(f2, f0) and q0 == q1 == q2 == r0
+    d0, _, d1, _, _, _ = runs("f64_first")
+    assert torch.equal(d0, item) and torch.equal(d1, item)
+
+
 def test_alpha_beta_export_on_the_team_kernels(mm, wl, oracle, torch):
     """The same export by TEAMS of workgroups (mm_fbsx_kernel: graphs beyond one compute unit) against the float64 oracle: a 3600-state
     graph of config 3's family (teams of 4: nothing leaves float32's range, the item kernel computes nothing) and the reference's WSJ

@@ -464,6 +464,72 @@ def test_other_kernel_families_are_capturable(mm, wl, torch, kind):
         assert bf.last_redo_count() == redo_eager and redo_eager <= (2 if kind == "split" else 0)
 
 
+@pytest.mark.parametrize("kind", ["export_pairs", "export_teams", "stream_teams", "prob_twin"])
+def test_round6_entries_are_capturable(mm, wl, torch, kind):
+    """What round 6 added, captured in a hipGraph and replayed on new inputs -- the bits of the eager call: the alpha / beta export on
+    the pair kernels and on the team kernels (their exchange areas zeroed by the library's own kernel, the mark count written to pinned
+    memory by a kernel of the graph), the stream kernels as teams (a zeroed exchange area too), a ProbSemiring batch on its log twins
+    (the logarithm pass and the ttl pass are nodes of the graph)."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    N = 33
+    if kind == "export_pairs":
+        g = wl.lfmmi_denominator(900, 40, seed=31)
+        bf = mm.batch(*([mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))] * 5))
+        assert "mm_fbx_kernel" in bf.kernels("export")
+    elif kind == "export_teams":
+        g = wl.load_npz_graph(os.path.join(here, "den_fsm_wsj.npz"))
+        bf = mm.batch(*([mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))] * 5))
+        assert "mm_fbsx_kernel" in bf.kernels("export")
+    elif kind == "stream_teams":
+        g = wl.lfmmi_denominator(2400, 300, seed=32)
+        bf = _with_env({"MM_DEBUG": "1", "MM_KERNEL": "stream", "MM_STREAM_H": "2"},
+                       lambda: mm.batch(*([mm.compile(wl.to_fsm(mm, g), mm.statemap(g.state2pdf, g.P))] * 5)))
+        assert "mm_stream_kernel" in bf.kernels() and "teams of 2" in bf.kernels(), bf.kernels()
+    else:
+        import copy
+
+        g = wl.lfmmi_denominator(700, 30, seed=33)
+        gl = copy.copy(g)
+        gl.w, gl.final_w, gl.init_w = np.exp(g.w), np.exp(g.final_w), np.exp(g.init_w)
+        bf = mm.batch(*([mm.compile(wl.to_fsm(mm, gl, "prob", np.float32), mm.statemap(g.state2pdf, g.P))] * 5))
+        assert bf.has_fast_entry() and "mm_fbp_kernel" in bf.kernels(), bf.kernels()
+    B = 5
+    lens = torch.tensor([N, N - 4, 9, 1, N], dtype=torch.int32, device="cuda")
+    V = torch.randn(B, N, g.P, device="cuda")
+    if kind == "prob_twin":
+        V = torch.exp(0.7 * V)  # likelihoods
+    bf.reserve(N)
+    # (the export hands the utterances whose alpha / beta leave float32's range to the item kernel, and -- under the default policy --
+    # starts there when the export before handed over more than half: a capture never does.  Pinned, the eager call launches what the
+    # captured one did, and the bits agree)
+    bf.set_exact_policy("f32_first")
+
+    def call():
+        if kind.startswith("export"):
+            return bf.alpharecursion(V, lens), bf.betarecursion(V, lens)
+        return bf.pdfposteriors(V, lens)
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        call()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        a1, b1 = call()
+    rng = np.random.default_rng(34)
+    for _ in range(3):  # new inputs in the captured buffer
+        Vn = torch.from_numpy(rng.standard_normal((B, N, g.P)).astype(np.float32)).cuda()
+        V.copy_(torch.exp(0.7 * Vn) if kind == "prob_twin" else Vn)
+        graph.replay()
+        torch.cuda.synchronize()
+        ga, gb = a1.clone(), b1.clone()
+        ea, eb = call()
+        torch.cuda.synchronize()
+        assert torch.equal(ga, ea) and torch.equal(gb, eb), (kind, float((ga - ea).abs().nan_to_num().max()))
+        if not kind.startswith("export"):
+            assert bf.last_redo_count() == 0
+
+
 def test_tropical_beta_and_maxstateposteriors(mm, wl, oracle, torch):
     """beta-recursion with K = TropicalSemiring (src/inference.jl:99-110) and the max-marginals mu = alpha (*) beta
     (/) best (maxstateposteriors, docs/src/inference.md:5): against the NumPy oracle's generic recursions, and

@@ -515,7 +515,8 @@ end
 Which linear-domain kernels a shared-graph batch starts with (mm_batch_set_exact_policy): `:auto` (float32 first; the
 wide-exponent kernels first while the last FINISHED call left utterances marked -- read without synchronising, so a pipelined
 caller's kernel choice depends on host / device timing), `:f32_first`, `:f64_first` (both: the launches of a call are a
-function of the call alone, identical call sequences give identical bits).
+function of the call alone, identical call sequences give identical bits).  Pins the path of `αrecursion` / `βrecursion` too
+(`:auto`: the log-domain kernel first while the last export handed it more than half of the utterances; `:f64_first`: that kernel alone).
 """
 set_exact_policy!(b::ROCBatch, policy::Symbol = :auto) =
     (check(ccall((:mm_batch_set_exact_policy, LIB), Cint, (Ptr{Cvoid}, Cint), b.handle,

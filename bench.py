@@ -544,6 +544,13 @@ def main():
         if Vc is not None and not args.varlen:
             sharp_consistent = sharp_record(torch, bf, g, B, N, gamma, lens, ab, rank, Vs=Vc, workload=wname, suffix="_consistent",
                                             label="log-softmax(10 x (onehot(pdf of a sampled path) + 0.3 N(0,1)))")
+            # ... and what an LF-MMI step pays on those inputs: to a gradient, posteriors below 1e-12 are zero (lfmmi.py:
+            # mm_batch_set_posterior_floor(1e-12)) -- a fresh batch with that floor keeps them on the float32 kernels
+            bfl = mm.batch(*([cf] * B))
+            bfl.set_posterior_floor(1e-12)
+            rec = sharp_record(torch, bfl, g, B, N, gamma, lens, ab, rank, Vs=Vc, label="the same, mm_batch_set_posterior_floor(1e-12)")
+            sharp_consistent["posterior_floor_1e-12"] = {k: rec[k] for k in ("ms_per_step", "kernel_ms", "frac", "redo_utterances", "exact_first")}
+            del bfl
     if rank == 0:
         abytes = algorithmic_bytes(g, B, N, frames_local, semiring)
         achieved = abytes / (kernel_ms * 1e-3) / 1e9

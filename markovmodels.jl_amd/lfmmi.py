@@ -106,7 +106,8 @@ def lfmmi_loss(V, num_batch, den_batch, lens: Optional["torch.Tensor"] = None, m
 
     The gradient is a difference of posteriors: one below 1e-12 changes nothing.  A training loop says so once --
     `den_batch.set_posterior_floor(1e-12)` -- and the denominator stays on the float32 kernels when the model's outputs get
-    sharp (the default floor, 1e-30, sends such utterances to the wide-exponent kernels: ~1.4x the time of a call).
+    sharp (the default floor, 1e-30, sends such utterances to the wide-exponent kernels: ~1.4x the time of a call; with the
+    floor, emissions as sharp as log-softmax(10 x) along a path of the graph mark nothing: profiles/r06_sharpness_floor1e-12.txt).
 
     Host cost: a batch of 128 numerator graphs that are new to the engine takes ~3.8 ms to compile and batch
     (`compile_many`: packed on the host's cores, one allocation, one copy; profiles/r04_host_cost.json), the numerator call

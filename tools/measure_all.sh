@@ -14,6 +14,9 @@ PMC_WARMUP=2 LAST_CALL=1 NAME=lfmmi_den_consistent bash tools/measure.sh "$1" lf
 timeout 300 python3 bench.py --emissions peaky_offset --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > $P/$1_bench_lfmmi_den_peaky_offset.json
 timeout 300 python3 bench.py --workload lfmmi_den4000 --emissions peaky --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > $P/$1_bench_lfmmi_den4000_peaky.json
 timeout 900 python3 tools/sharpness.py > $P/$1_sharpness.txt 2>/dev/null
+# SURVEY 8(d)'s second run of config 3: lengths U[750, 1500] (frames/s counts the frames inside the lengths)
+timeout 300 python3 bench.py --varlen --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > $P/$1_bench_lfmmi_den_varlen.json
+timeout 300 python3 bench.py --workload wsj_den --varlen --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > $P/$1_bench_wsj_den_varlen.json
 # the caller's step (examples/test_cuda.jl:128-152): numerator + denominator + gradient, T = 700 and 150
 timeout 300 python3 bench.py --workload lfmmi_step --frames 700 --steps 20 --warmup 5 2>/dev/null | tail -1 > $P/$1_bench_lfmmi_step.json
 timeout 300 python3 bench.py --workload lfmmi_step --frames 150 --steps 20 --warmup 5 2>/dev/null | tail -1 > $P/$1_bench_lfmmi_step_T150.json

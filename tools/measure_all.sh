@@ -17,6 +17,9 @@ timeout 900 python3 tools/sharpness.py > $P/$1_sharpness.txt 2>/dev/null
 # SURVEY 8(d)'s second run of config 3: lengths U[750, 1500] (frames/s counts the frames inside the lengths)
 timeout 300 python3 bench.py --varlen --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > $P/$1_bench_lfmmi_den_varlen.json
 timeout 300 python3 bench.py --workload wsj_den --varlen --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > $P/$1_bench_wsj_den_varlen.json
+# config 4's global batch (B = 2048) on this one GPU: what eight GPUs would have to beat
+timeout 600 python3 bench.py --batch 2048 --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | tail -1 > $P/$1_bench_lfmmi_den_B2048_one_gpu.json
+timeout 600 python3 bench.py --batch 2048 --varlen --no-cpu-baseline --no-sharp --steps 5 --warmup 2 2>/dev/null | tail -1 > $P/$1_bench_lfmmi_den_B2048_varlen_one_gpu.json
 # the caller's step (examples/test_cuda.jl:128-152): numerator + denominator + gradient, T = 700 and 150
 timeout 300 python3 bench.py --workload lfmmi_step --frames 700 --steps 20 --warmup 5 2>/dev/null | tail -1 > $P/$1_bench_lfmmi_step.json
 timeout 300 python3 bench.py --workload lfmmi_step --frames 150 --steps 20 --warmup 5 2>/dev/null | tail -1 > $P/$1_bench_lfmmi_step_T150.json
